@@ -1,0 +1,629 @@
+// C ABI (include/ralenet.h) + host orchestration of the RA-LENet kernels.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/ralenet.h"
+#include "ral_kernels.hpp"
+#include "ral_unet.hpp"
+
+static thread_local char g_err[512] = "";
+static int fail(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return -1;
+}
+extern "C" const char* ral_last_error(void) { return g_err; }
+
+#define HIP_OK(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) return fail("%s failed: %s", #expr, hipGetErrorString(e_));        \
+  } while (0)
+
+// ---------------------------------------------------------------------------------
+// layout
+// ---------------------------------------------------------------------------------
+static const int CH[5] = {8, 16, 32, 64, 128};
+static const int RWLEN[4] = {32, 16, 8, 4};
+struct StageDef { const char* name; int level; int rw; };
+static const StageDef STAGES[9] = {
+    {"dtransformer1", 0, 1}, {"dtransformer2", 1, 2}, {"dtransformer3", 2, 3}, {"dtransformer34", 3, 4},
+    {"transformer", 4, 0},   {"utransformer4", 4, 0}, {"utranformer3", 3, 4},  {"utransformer2", 2, 3},
+    {"utransformer1", 1, 2}};
+
+struct Entry {
+  std::string name;
+  int kind;
+  int64_t offset;
+  int ndim;
+  int64_t shape[4];
+};
+
+struct BlockOff { int64_t wqkv, bqkv, wp, bp, ln1w, ln1b, ln2w, ln2b, w1, b1, w2, b2, le; };
+struct ResOff { int64_t w, lnw, lnb; int D; };
+
+struct Layout {
+  std::vector<Entry> entries;
+  int64_t nparam = 0, nstate = 0;
+  int64_t conv1_w, conv1_b, bn_w, bn_b, tc_w, tc_b;
+  int64_t rw[4] = {-1, -1, -1, -1};
+  BlockOff blk[18];
+  ResOff res[8];  // pm1..pm4, ps4..ps1
+  bool le = true, rwave = false;
+};
+
+static int64_t alloc_f(int64_t& cur, int64_t n) {
+  const int64_t o = cur;
+  cur += (n + 3) & ~int64_t(3);
+  return o;
+}
+
+static void push(Layout& L, const std::string& name, int kind, int64_t off, std::initializer_list<int64_t> shp) {
+  Entry e;
+  e.name = name; e.kind = kind; e.offset = off; e.ndim = (int)shp.size();
+  int i = 0;
+  for (auto s : shp) e.shape[i++] = s;
+  for (; i < 4; ++i) e.shape[i] = 1;
+  L.entries.push_back(e);
+}
+
+static bool build_layout(const ral_config& c, Layout& L) {
+  if (c.variant < RAL_NRA || c.variant > RAL_MLP) return false;
+  const bool basic = c.variant != RAL_NRA;
+  L.le = c.variant != RAL_MLP;
+  L.rwave = c.variant != RAL_NRA;
+  int64_t cur = 0;
+  const int ld = c.leads;
+  L.conv1_w = alloc_f(cur, 8 * ld * 3); L.conv1_b = alloc_f(cur, 8);
+  L.bn_w = alloc_f(cur, 8); L.bn_b = alloc_f(cur, 8);
+  push(L, "conv1.0.weight", RAL_PARAM, L.conv1_w, {8, ld, 3});
+  push(L, "conv1.0.bias", RAL_PARAM, L.conv1_b, {8});
+  push(L, "conv1.2.weight", RAL_PARAM, L.bn_w, {8});
+  push(L, "conv1.2.bias", RAL_PARAM, L.bn_b, {8});
+  push(L, "conv1.2.running_mean", RAL_STATE_F32, 0, {8});
+  push(L, "conv1.2.running_var", RAL_STATE_F32, 8, {8});
+  push(L, "conv1.2.num_batches_tracked", RAL_COUNTER_I64, 0, {});
+  L.nstate = 16;
+  if (L.rwave) {
+    for (int i = 0; i < 4; ++i) {
+      const int h = CH[i] / 4, n = 2 * RWLEN[i] - 1;
+      L.rw[i] = alloc_f(cur, (int64_t)n * h);
+      const std::string p = "rwattn" + std::to_string(i + 1);
+      push(L, p + ".relative_position_bias_table", RAL_PARAM, L.rw[i], {n, h});
+      push(L, p + ".relative_position_index", RAL_INDEX_I64, 0, {RWLEN[i], RWLEN[i]});
+    }
+  }
+  auto add_block = [&](int bi, const std::string& pre, int C) {
+    BlockOff& b = L.blk[bi];
+    b.wqkv = alloc_f(cur, 3 * C * C); b.bqkv = alloc_f(cur, 3 * C);
+    b.wp = alloc_f(cur, C * C); b.bp = alloc_f(cur, C);
+    b.ln1w = alloc_f(cur, C); b.ln1b = alloc_f(cur, C); b.ln2w = alloc_f(cur, C); b.ln2b = alloc_f(cur, C);
+    b.w1 = alloc_f(cur, 4 * C * C); b.b1 = alloc_f(cur, 4 * C);
+    b.w2 = alloc_f(cur, 4 * C * C); b.b2 = alloc_f(cur, C);
+    b.le = L.le ? alloc_f(cur, 3) : -1;
+    push(L, pre + "attn.qkv_proj.to_q.weight", RAL_PARAM, b.wqkv, {C, C});
+    push(L, pre + "attn.qkv_proj.to_q.bias", RAL_PARAM, b.bqkv, {C});
+    push(L, pre + "attn.qkv_proj.to_kv.weight", RAL_PARAM, b.wqkv + C * C, {2 * C, C});
+    push(L, pre + "attn.qkv_proj.to_kv.bias", RAL_PARAM, b.bqkv + C, {2 * C});
+    push(L, pre + "attn.proj.weight", RAL_PARAM, b.wp, {C, C});
+    push(L, pre + "attn.proj.bias", RAL_PARAM, b.bp, {C});
+    push(L, pre + "norm1.weight", RAL_PARAM, b.ln1w, {C});
+    push(L, pre + "norm1.bias", RAL_PARAM, b.ln1b, {C});
+    push(L, pre + "norm2.weight", RAL_PARAM, b.ln2w, {C});
+    push(L, pre + "norm2.bias", RAL_PARAM, b.ln2b, {C});
+    push(L, pre + "mlp.fc1.weight", RAL_PARAM, b.w1, {4 * C, C});
+    push(L, pre + "mlp.fc1.bias", RAL_PARAM, b.b1, {4 * C});
+    push(L, pre + "mlp.fc2.weight", RAL_PARAM, b.w2, {C, 4 * C});
+    push(L, pre + "mlp.fc2.bias", RAL_PARAM, b.b2, {C});
+    if (L.le) push(L, pre + "mlp.leconv.partial_conv3.weight", RAL_PARAM, b.le, {1, 1, 3});
+  };
+  auto add_stage = [&](int si) {
+    for (int i = 0; i < 2; ++i) {
+      const std::string pre = std::string(STAGES[si].name) + (basic ? ".blocks." : ".") + std::to_string(i) + ".";
+      add_block(si * 2 + i, pre, CH[STAGES[si].level]);
+    }
+  };
+  auto add_res = [&](int ri, const std::string& name, int D) {
+    ResOff& r = L.res[ri];
+    r.D = D;
+    r.w = alloc_f(cur, (int64_t)D * D); r.lnw = alloc_f(cur, D); r.lnb = alloc_f(cur, D);
+    push(L, name + ".reduction.weight", RAL_PARAM, r.w, {D, D});
+    push(L, name + ".norm.weight", RAL_PARAM, r.lnw, {D});
+    push(L, name + ".norm.bias", RAL_PARAM, r.lnb, {D});
+  };
+  add_stage(0); add_res(0, "pm1", 16);
+  add_stage(1); add_res(1, "pm2", 32);
+  add_stage(2); add_res(2, "pm3", 64);
+  add_stage(3); add_res(3, "pm4", 128);
+  add_stage(4);
+  add_stage(5); add_res(4, "ps4", 64);
+  add_stage(6); add_res(5, "ps3", 32);
+  add_stage(7); add_res(6, "ps2", 16);
+  add_stage(8); add_res(7, "ps1", 8);
+  L.tc_w = alloc_f(cur, ld * 8 * 3); L.tc_b = alloc_f(cur, ld);
+  push(L, "transconv.0.weight", RAL_PARAM, L.tc_w, {ld, 8, 3});
+  push(L, "transconv.0.bias", RAL_PARAM, L.tc_b, {ld});
+  L.nparam = cur;
+  return true;
+}
+
+static int check_cfg(const ral_config* c) {
+  if (!c) return fail("null config");
+  if (c->variant == RAL_UNET) return unet_check_cfg(c, g_err, sizeof(g_err));
+  if (c->variant < 0 || c->variant > RAL_UNET) return fail("unknown variant %d", c->variant);
+  if (c->leads != 1 && c->leads != 2) return fail("leads must be 1 or 2 (got %d); use the 12-lead adapter above it", c->leads);
+  if (c->L <= 0 || c->L % 256 != 0 || c->L > 1024) return fail("L must be a multiple of 256 and <= 1024 (got %d)", c->L);
+  if (c->max_batch <= 0) return fail("max_batch must be positive");
+  return 0;
+}
+
+// positional encoding in the reference's op order, fp32 (raletransformer.py:172-181)
+static void fill_pe(float* P, int n, int C) {
+  for (int i = 0; i < C / 2; ++i) {
+    const float den = powf(10000.0f, (float)(2 * i) / (float)C);
+    for (int p = 0; p < n; ++p) {
+      const float X = (float)p / den;
+      P[(size_t)p * C + 2 * i] = sinf(X);
+      P[(size_t)p * C + 2 * i + 1] = cosf(X);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// model
+// ---------------------------------------------------------------------------------
+struct BlockAct { float *in, *qkv, *o, *lse, *x1, *upre, *out; };
+
+struct RalModel {
+  ral_config cfg;
+  Layout lay;
+  int L, E1;  // E1 = 8*L floats per window per stage tensor
+  char* slab = nullptr;
+  size_t slab_bytes = 0;
+  std::map<std::string, std::pair<float*, int64_t>> dbg;
+  // bound buffers
+  float *params = nullptr, *grads = nullptr, *am = nullptr, *av = nullptr, *state = nullptr;
+  double* bn_sums = nullptr;
+  // workspace
+  float* pe[5];
+  float *xin, *a0, *x0, *ss;
+  BlockAct act[18];
+  float* res_out[8];  // p1..p4 (pm), u3,u2,u1,u0 (ps)
+  float* xmid;
+  // backward temporaries
+  float *gA, *gB, *gskip[5], *dx1, *dohm, *dqkv, *dupre, *dz0;
+  const float* last_x = nullptr;
+  int last_B = 0;
+  int nch_f[5], nch_b[5], hg_f[5], hg_b[5];
+};
+
+struct ral_handle {
+  int kind;  // 0 ralenet, 1 unet
+  RalModel* m;
+  UNetModel* u;
+};
+
+static size_t plan_workspace(const ral_config& c, RalModel* m /* may be null: size only */, char* base) {
+  size_t cur = 0;
+  const size_t B = c.max_batch, E = (size_t)8 * c.L * B;
+  auto take = [&](const char* name, size_t nfloat) -> float* {
+    float* p = base ? reinterpret_cast<float*>(base + cur) : nullptr;
+    if (m && base) m->dbg[name] = {p, (int64_t)nfloat};
+    cur += ((nfloat * sizeof(float)) + 255) & ~size_t(255);
+    return p;
+  };
+  RalModel tmp_;
+  RalModel& M = m ? *m : tmp_;
+  for (int l = 0; l < 5; ++l) M.pe[l] = take(("pe" + std::to_string(l)).c_str(), (size_t)(c.L >> l) * CH[l]);
+  M.a0 = take("a0", E); M.x0 = take("x0", E); M.ss = take("bn_ss", 64);
+  const bool tr = c.train != 0;
+  float *sh_qkv = nullptr, *sh_o = nullptr;
+  if (!tr) { sh_qkv = take("qkv", 3 * E); sh_o = take("o", E); }
+  for (int b = 0; b < 18; ++b) {
+    const std::string p = "blk" + std::to_string(b) + ".";
+    BlockAct& a = M.act[b];
+    a.qkv = tr ? take((p + "qkv").c_str(), 3 * E) : sh_qkv;
+    a.o = tr ? take((p + "o").c_str(), E) : sh_o;
+    a.lse = tr ? take((p + "lse").c_str(), E / 4) : nullptr;
+    a.x1 = tr ? take((p + "x1").c_str(), E) : nullptr;
+    a.upre = tr ? take((p + "upre").c_str(), 4 * E) : nullptr;
+    a.out = take((p + "out").c_str(), E);
+  }
+  static const char* RN[8] = {"p1", "p2", "p3", "p4", "u3", "u2", "u1", "u0"};
+  for (int r = 0; r < 8; ++r) M.res_out[r] = take(RN[r], E);
+  M.xmid = take("xmid", E);
+  if (tr) {
+    M.gA = take("gA", E); M.gB = take("gB", E);
+    for (int i = 0; i < 5; ++i) M.gskip[i] = take(("gskip" + std::to_string(i)).c_str(), E);
+    M.dx1 = take("dx1", E); M.dohm = take("do", E); M.dqkv = take("dqkv", 3 * E); M.dupre = take("dupre", 4 * E);
+    M.dz0 = take("dz0", E);
+  }
+  return cur;
+}
+
+static void choose_tiling(RalModel* m) {
+  const size_t budget = 150 * 1024;
+  for (int l = 0; l < 5; ++l) {
+    const int C = CH[l], N = m->L >> l, H = C / 4;
+    int n = 1;
+    while (n < 4 && mlp_fwd_lds(C, N, n) > budget) n *= 2;
+    m->nch_f[l] = n;
+    n = 1;
+    while (n < 4 && mlp_bwd_lds(C, N, n) > budget) n *= 2;
+    m->nch_b[l] = n;
+    const int Len = l < 4 ? RWLEN[l] : 0;
+    int hg = H;
+    while (hg > 1 && attn_fwd_lds(N, hg, Len) > 72 * 1024) hg /= 2;
+    m->hg_f[l] = hg;
+    hg = H;
+    while (hg > 1 && attn_bwd_lds(N, hg, Len) > 78 * 1024) hg /= 2;
+    m->hg_b[l] = hg;
+  }
+}
+
+static BlockP block_ptrs(const BlockOff& o, float* base) {
+  BlockP p;
+  p.wqkv = base + o.wqkv; p.bqkv = base + o.bqkv; p.wp = base + o.wp; p.bp = base + o.bp;
+  p.ln1w = base + o.ln1w; p.ln1b = base + o.ln1b; p.ln2w = base + o.ln2w; p.ln2b = base + o.ln2b;
+  p.w1 = base + o.w1; p.b1 = base + o.b1; p.w2 = base + o.w2; p.b2 = base + o.b2;
+  p.le = o.le >= 0 ? base + o.le : nullptr;
+  return p;
+}
+
+// ---------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------
+static void run_block_fwd(RalModel* m, int bi, const float* in, bool training, int B, hipStream_t s) {
+  const int si = bi / 2, l = STAGES[si].level, C = CH[l], N = m->L >> l, H = C / 4;
+  const BlockP w = block_ptrs(m->lay.blk[bi], m->params);
+  BlockAct& a = m->act[bi];
+  a.in = const_cast<float*>(in);
+  const float* table = nullptr;
+  int Len = 0;
+  if (m->lay.rwave && STAGES[si].rw) {
+    table = m->params + m->lay.rw[STAGES[si].rw - 1];
+    Len = RWLEN[STAGES[si].rw - 1];
+  }
+  launch_qkv_fwd(C, in, m->pe[l], w, a.qkv, N, B, s);
+  launch_attn_fwd(a.qkv, a.o, training ? a.lse : nullptr, table, N, H, m->hg_f[l], Len, B, s);
+  launch_mlp_fwd(C, m->nch_f[l], in, a.o, w, training ? a.x1 : nullptr, training ? a.upre : nullptr, a.out, N, B, s);
+}
+
+static const float* run_stage_fwd(RalModel* m, int si, const float* in, bool training, int B, hipStream_t s) {
+  run_block_fwd(m, si * 2, in, training, B, s);
+  run_block_fwd(m, si * 2 + 1, m->act[si * 2].out, training, B, s);
+  return m->act[si * 2 + 1].out;
+}
+
+static void run_res_fwd(RalModel* m, int ri, const float* in, const float* skip, int B, hipStream_t s) {
+  const ResOff& r = m->lay.res[ri];
+  const int T = m->E1 / r.D;  // output tokens per window
+  launch_resample_fwd(r.D, ri >= 4, in, m->params + r.w, m->params + r.lnw, m->params + r.lnb, skip,
+                      m->res_out[ri], T, B, s);
+}
+
+static int fwd_begin(RalModel* m, const float* x, int B, int training, hipStream_t s) {
+  if (!m->params || !m->state) return fail("ral_bind was not called");
+  if (B <= 0 || B > m->cfg.max_batch) return fail("batch %d outside (0, max_batch=%d]", B, m->cfg.max_batch);
+  if (training && !m->cfg.train) return fail("handle was created with train=0");
+  if (training && !m->bn_sums) return fail("training forward needs bn_sums bound");
+  const Layout& Y = m->lay;
+  m->last_x = x; m->last_B = B;
+  if (training) {
+    HIP_OK(hipMemsetAsync(m->bn_sums, 0, 64 * sizeof(double), s));
+    launch_conv1_fwd(m->cfg.leads, 0, x, m->params + Y.conv1_w, m->params + Y.conv1_b, m->a0, m->bn_sums, nullptr,
+                     nullptr, nullptr, nullptr, m->L, B, s);
+  } else {
+    launch_conv1_fwd(m->cfg.leads, 1, x, m->params + Y.conv1_w, m->params + Y.conv1_b, m->x0, nullptr,
+                     m->params + Y.bn_w, m->params + Y.bn_b, m->state, m->state + 8, m->L, B, s);
+  }
+  return 0;
+}
+
+static int fwd_end(RalModel* m, float* y, int B, int64_t global_windows, int training, hipStream_t s) {
+  const Layout& Y = m->lay;
+  if (training) {
+    launch_bn_finalize(m->bn_sums, (double)global_windows * m->L, m->params + Y.bn_w, m->params + Y.bn_b, m->ss,
+                       m->state, m->state + 8, 8, 1, s);
+    launch_bn_apply8(m->a0, m->ss, m->x0, (size_t)B * m->L, s);
+  }
+  const bool tr = training != 0;
+  const float* cur = m->x0;
+  for (int i = 0; i < 4; ++i) {
+    cur = run_stage_fwd(m, i, cur, tr, B, s);
+    run_res_fwd(m, i, cur, nullptr, B, s);
+    cur = m->res_out[i];
+  }
+  cur = run_stage_fwd(m, 4, cur, tr, B, s);
+  launch_add(cur, m->res_out[3], m->xmid, (size_t)B * m->E1, s);
+  cur = m->xmid;
+  for (int i = 0; i < 4; ++i) {
+    cur = run_stage_fwd(m, 5 + i, cur, tr, B, s);
+    run_res_fwd(m, 4 + i, cur, i < 3 ? m->res_out[2 - i] : nullptr, B, s);
+    cur = m->res_out[4 + i];
+  }
+  launch_final_fwd(m->cfg.leads, cur, m->x0, m->params + Y.tc_w, m->params + Y.tc_b, y, m->L, B, s);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------
+// one block: dy (grad of block output) -> dx (grad of block input) [+ extra]
+static void run_block_bwd(RalModel* m, int bi, const float* dy, const float* extra, float* dx, int B, hipStream_t s) {
+  const int si = bi / 2, l = STAGES[si].level, C = CH[l], N = m->L >> l, H = C / 4;
+  const BlockP w = block_ptrs(m->lay.blk[bi], m->params);
+  const BlockP g = block_ptrs(m->lay.blk[bi], m->grads);
+  BlockAct& a = m->act[bi];
+  const float* table = nullptr;
+  float* gtable = nullptr;
+  int Len = 0;
+  if (m->lay.rwave && STAGES[si].rw) {
+    table = m->params + m->lay.rw[STAGES[si].rw - 1];
+    gtable = m->grads + m->lay.rw[STAGES[si].rw - 1];
+    Len = RWLEN[STAGES[si].rw - 1];
+  }
+  launch_mlp_bwd(C, m->nch_b[l], dy, a.x1, a.upre, w, g, m->dupre, m->dx1, m->dohm, N, B, s);
+  launch_attn_bwd(a.qkv, a.o, m->dohm, a.lse, table, gtable, m->dqkv, N, H, m->hg_b[l], Len, B, s);
+  launch_qkv_bwd(C, m->dqkv, a.in, m->pe[l], m->dx1, extra, w, g, dx, N, B, s);
+  launch_block_dw(C, dy, a.upre, m->dupre, a.x1, m->dx1, a.o, m->dqkv, a.in, m->pe[l], w, g, N, B, 256, s);
+}
+
+// stage: grad of stage output `dy` -> grad of stage input written to `dx` (+extra). Uses `tmp` between blocks.
+static void run_stage_bwd(RalModel* m, int si, const float* dy, const float* extra, float* tmp, float* dx, int B,
+                          hipStream_t s) {
+  run_block_bwd(m, si * 2 + 1, dy, nullptr, tmp, B, s);
+  run_block_bwd(m, si * 2, tmp, extra, dx, B, s);
+}
+
+static void run_res_bwd(RalModel* m, int ri, const float* dy, const float* in, float* dx, int B, hipStream_t s) {
+  const ResOff& r = m->lay.res[ri];
+  const int T = m->E1 / r.D;
+  launch_resample_bwd(r.D, ri >= 4, dy, in, m->params + r.w, m->params + r.lnw, m->grads + r.lnw, m->grads + r.lnb,
+                      dx, T, B, s);
+  launch_resample_dw(r.D, ri >= 4, dy, in, m->params + r.lnw, m->params + r.lnb, m->grads + r.w, T, B, 256, s);
+}
+
+static int bwd_begin(RalModel* m, const float* dy, int B, hipStream_t s) {
+  if (!m->cfg.train) return fail("handle was created with train=0");
+  if (!m->grads || !m->bn_sums) return fail("ral_bind: grads / bn_sums not bound");
+  if (B != m->last_B) return fail("backward batch %d != forward batch %d", B, m->last_B);
+  const Layout& Y = m->lay;
+  HIP_OK(hipMemsetAsync(m->grads, 0, (size_t)Y.nparam * sizeof(float), s));
+  HIP_OK(hipMemsetAsync(m->bn_sums + 32, 0, 32 * sizeof(double), s));
+  float *gA = m->gA, *gB = m->gB;
+  float** sk = m->gskip;  // 0: d u0 (= d x0 skip), 1: g u1, 2: g u2, 3: g u3, 4: g xmid
+  // output conv: dy -> d(u0 + x0)
+  launch_final_bwd(m->cfg.leads, dy, m->res_out[7], m->x0, m->params + Y.tc_w, m->grads + Y.tc_w, m->grads + Y.tc_b,
+                   sk[0], m->L, B, s);
+  // ps1 <- utransformer1 <- (u1 = ps2(.) + p1)
+  run_res_bwd(m, 7, sk[0], m->act[17].out, gA, B, s);
+  run_stage_bwd(m, 8, gA, nullptr, gB, sk[1], B, s);
+  run_res_bwd(m, 6, sk[1], m->act[15].out, gA, B, s);
+  run_stage_bwd(m, 7, gA, nullptr, gB, sk[2], B, s);
+  run_res_bwd(m, 5, sk[2], m->act[13].out, gA, B, s);
+  run_stage_bwd(m, 6, gA, nullptr, gB, sk[3], B, s);
+  run_res_bwd(m, 4, sk[3], m->act[11].out, gA, B, s);
+  run_stage_bwd(m, 5, gA, nullptr, gB, sk[4], B, s);                 // g xmid
+  run_stage_bwd(m, 4, sk[4], sk[4], gB, gA, B, s);                   // g p4 = transformer^T(g xmid) + g xmid
+  run_res_bwd(m, 3, gA, m->act[7].out, gB, B, s);                    // -> g y3
+  run_stage_bwd(m, 3, gB, sk[3], gA, gB, B, s);                      // g p3 (+ g u3)   [tmp=gA, out=gB]
+  run_res_bwd(m, 2, gB, m->act[5].out, gA, B, s);
+  run_stage_bwd(m, 2, gA, sk[2], gB, gA, B, s);                      // g p2 (+ g u2)   [tmp=gB, out=gA]
+  run_res_bwd(m, 1, gA, m->act[3].out, gB, B, s);
+  run_stage_bwd(m, 1, gB, sk[1], gA, gB, B, s);                      // g p1 (+ g u1)
+  run_res_bwd(m, 0, gB, m->act[1].out, gA, B, s);
+  run_stage_bwd(m, 0, gA, sk[0], gB, gA, B, s);                      // g x0 (+ d u0)  -> gA
+  launch_bn8_bwd_stats(gA, m->a0, m->ss, m->bn_sums + 32, (size_t)B * m->L, s);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+static int bwd_end(RalModel* m, float* dx, int B, int64_t global_windows, hipStream_t s) {
+  const Layout& Y = m->lay;
+  launch_conv1_bwd(m->cfg.leads, m->gA, m->a0, m->last_x, m->ss, m->params + Y.bn_w, m->bn_sums + 32,
+                   (double)global_windows * m->L, m->grads + Y.conv1_w, m->grads + Y.conv1_b, dx ? m->dz0 : nullptr,
+                   m->L, B, s);
+  launch_bn_affine_grads(m->bn_sums + 32, m->grads + Y.bn_w, m->grads + Y.bn_b, 8, s);
+  if (dx) launch_conv1_bwd_dx(m->cfg.leads, m->dz0, m->params + Y.conv1_w, dx, m->L, B, s);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------
+extern "C" {
+
+int ral_layout_count(const ral_config* cfg) {
+  if (check_cfg(cfg)) return -1;
+  if (cfg->variant == RAL_UNET) return unet_layout_count(cfg);
+  Layout L;
+  build_layout(*cfg, L);
+  return (int)L.entries.size();
+}
+
+int ral_layout_entry(const ral_config* cfg, int idx, char* name, int name_cap, int32_t* kind, int64_t* offset,
+                     int32_t* ndim, int64_t shape[4]) {
+  if (check_cfg(cfg)) return -1;
+  if (cfg->variant == RAL_UNET) return unet_layout_entry(cfg, idx, name, name_cap, kind, offset, ndim, shape);
+  Layout L;
+  build_layout(*cfg, L);
+  if (idx < 0 || idx >= (int)L.entries.size()) return fail("entry %d out of range", idx);
+  const Entry& e = L.entries[idx];
+  if ((int)e.name.size() + 1 > name_cap) return fail("name buffer too small");
+  strcpy(name, e.name.c_str());
+  *kind = e.kind; *offset = e.offset; *ndim = e.ndim;
+  for (int i = 0; i < 4; ++i) shape[i] = e.shape[i];
+  return 0;
+}
+
+int64_t ral_param_floats(const ral_config* cfg) {
+  if (check_cfg(cfg)) return -1;
+  if (cfg->variant == RAL_UNET) return unet_param_floats(cfg);
+  Layout L;
+  build_layout(*cfg, L);
+  return L.nparam;
+}
+
+int64_t ral_state_floats(const ral_config* cfg) {
+  if (check_cfg(cfg)) return -1;
+  if (cfg->variant == RAL_UNET) return unet_state_floats(cfg);
+  return 16;
+}
+
+int64_t ral_workspace_bytes(const ral_config* cfg) {
+  if (check_cfg(cfg)) return -1;
+  if (cfg->variant == RAL_UNET) return unet_workspace_bytes(cfg);
+  return (int64_t)plan_workspace(*cfg, nullptr, nullptr);
+}
+
+int ral_pe_table(const ral_config* cfg, int level, float* out_host, int64_t cap) {
+  if (check_cfg(cfg)) return -1;
+  if (cfg->variant == RAL_UNET || level < 0 || level > 4) return fail("no PE table for this variant/level");
+  const int n = cfg->L >> level, C = CH[level];
+  if (cap < (int64_t)n * C) return fail("buffer too small");
+  fill_pe(out_host, n, C);
+  return 0;
+}
+
+int ral_create(const ral_config* cfg, ral_handle** out) {
+  if (check_cfg(cfg)) return -1;
+  if (!out) return fail("null out");
+  ral_handle* h = new ral_handle{0, nullptr, nullptr};
+  if (cfg->variant == RAL_UNET) {
+    h->kind = 1;
+    h->u = unet_create(cfg, g_err, sizeof(g_err));
+    if (!h->u) { delete h; return -1; }
+    *out = h;
+    return 0;
+  }
+  RalModel* m = new RalModel();
+  m->cfg = *cfg;
+  m->L = cfg->L;
+  m->E1 = 8 * cfg->L;
+  build_layout(*cfg, m->lay);
+  m->slab_bytes = plan_workspace(*cfg, nullptr, nullptr);
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&m->slab), m->slab_bytes);
+  if (e != hipSuccess) {
+    fail("hipMalloc(%zu bytes) failed: %s", m->slab_bytes, hipGetErrorString(e));
+    delete m; delete h;
+    return -1;
+  }
+  plan_workspace(*cfg, m, m->slab);
+  choose_tiling(m);
+  for (int l = 0; l < 5; ++l) {
+    const int n = cfg->L >> l, C = CH[l];
+    std::vector<float> P((size_t)n * C);
+    fill_pe(P.data(), n, C);
+    e = hipMemcpy(m->pe[l], P.data(), P.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      fail("hipMemcpy(pe) failed: %s", hipGetErrorString(e));
+      (void)hipFree(m->slab); delete m; delete h;
+      return -1;
+    }
+  }
+  h->m = m;
+  *out = h;
+  return 0;
+}
+
+int ral_destroy(ral_handle* h) {
+  if (!h) return 0;
+  if (h->m) { if (h->m->slab) (void)hipFree(h->m->slab); delete h->m; }
+  if (h->u) unet_destroy(h->u);
+  delete h;
+  return 0;
+}
+
+int ral_bind(ral_handle* h, float* params, float* grads, float* adam_m, float* adam_v, float* state, double* bn_sums) {
+  if (!h) return fail("null handle");
+  if (h->kind == 1) return unet_bind(h->u, params, grads, adam_m, adam_v, state, bn_sums);
+  RalModel* m = h->m;
+  m->params = params; m->grads = grads; m->am = adam_m; m->av = adam_v; m->state = state; m->bn_sums = bn_sums;
+  return 0;
+}
+
+int ral_forward_begin(ral_handle* h, const float* x, int B, ral_stream s) {
+  if (!h) return fail("null handle");
+  if (h->kind == 1) return fail("U-Net has one BatchNorm per layer: use ral_forward (per-rank statistics)");
+  return fwd_begin(h->m, x, B, 1, (hipStream_t)s);
+}
+
+int ral_forward_end(ral_handle* h, float* y, int B, int64_t global_windows, ral_stream s) {
+  if (!h) return fail("null handle");
+  if (h->kind == 1) return fail("U-Net has one BatchNorm per layer: use ral_forward (per-rank statistics)");
+  return fwd_end(h->m, y, B, global_windows, 1, (hipStream_t)s);
+}
+
+int ral_forward(ral_handle* h, const float* x, float* y, int B, int training, ral_stream s) {
+  if (!h) return fail("null handle");
+  if (h->kind == 1) return unet_forward(h->u, x, y, B, training, (hipStream_t)s, g_err, sizeof(g_err));
+  if (fwd_begin(h->m, x, B, training, (hipStream_t)s)) return -1;
+  return fwd_end(h->m, y, B, B, training, (hipStream_t)s);
+}
+
+int ral_loss(ral_handle* h, const float* pred, const float* target, int B, int64_t global_windows, float* dy,
+             float* snr, float* rmse, double* loss_sum, ral_stream s) {
+  if (!h) return fail("null handle");
+  const ral_config& c = h->kind == 1 ? unet_public(h->u)->cfg : h->m->cfg;
+  const int n = c.leads * c.L;
+  const float gscale = (float)(2.0 / ((double)global_windows * n));
+  launch_loss(pred, target, dy, snr, rmse, loss_sum, n, B, gscale, (hipStream_t)s);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int ral_backward_begin(ral_handle* h, const float* dy, int B, ral_stream s) {
+  if (!h) return fail("null handle");
+  if (h->kind == 1) return fail("U-Net: use ral_backward");
+  return bwd_begin(h->m, dy, B, (hipStream_t)s);
+}
+
+int ral_backward_end(ral_handle* h, float* dx, int B, int64_t global_windows, ral_stream s) {
+  if (!h) return fail("null handle");
+  if (h->kind == 1) return fail("U-Net: use ral_backward");
+  return bwd_end(h->m, dx, B, global_windows, (hipStream_t)s);
+}
+
+int ral_backward(ral_handle* h, const float* dy, float* dx, int B, ral_stream s) {
+  if (!h) return fail("null handle");
+  if (h->kind == 1) return unet_backward(h->u, dy, dx, B, (hipStream_t)s, g_err, sizeof(g_err));
+  if (bwd_begin(h->m, dy, B, (hipStream_t)s)) return -1;
+  return bwd_end(h->m, dx, B, B, (hipStream_t)s);
+}
+
+int ral_adam_step(ral_handle* h, float lr, float beta1, float beta2, float eps, int step, float grad_scale,
+                  ral_stream s) {
+  if (!h) return fail("null handle");
+  float *p, *g, *am, *av;
+  int64_t n;
+  if (h->kind == 1) { UNetPublic* u = unet_public(h->u); p = u->params; g = u->grads; am = u->am; av = u->av; n = u->nparam; }
+  else { p = h->m->params; g = h->m->grads; am = h->m->am; av = h->m->av; n = h->m->lay.nparam; }
+  if (!p || !g || !am || !av) return fail("ral_bind: params/grads/adam buffers not bound");
+  if (step < 1) return fail("step is 1-based");
+  launch_adam(p, g, am, av, (size_t)n, lr, beta1, beta2, eps, step, grad_scale, (hipStream_t)s);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int ral_debug_tensor(ral_handle* h, const char* name, float** ptr, int64_t* numel) {
+  if (!h || h->kind != 0) return fail("no debug tensors for this handle");
+  auto it = h->m->dbg.find(name);
+  if (it == h->m->dbg.end()) return fail("unknown tensor %s", name);
+  *ptr = it->second.first;
+  *numel = it->second.second;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,803 @@
+// Backward (data-gradient) kernels of the RA-LENet path (gfx950).  Weight gradients
+// of the Linear layers are separate token-contraction GEMMs (ral_dw.hip); the small
+// vector gradients (biases, LayerNorm affines, LE taps, R-wave tables) are reduced
+// here in registers / LDS across the windows a workgroup owns and flushed with one
+// atomic per element per workgroup.
+#include "ral_device.hpp"
+#include "ral_kernels.hpp"
+
+// LDS float4 atomic accumulate of per-channel vectors: red[c..c+3] += v
+RAL_DEV void lds_add4(float* red, int c, float4 v) {
+  atomicAdd(red + c, v.x); atomicAdd(red + c + 1, v.y); atomicAdd(red + c + 2, v.z); atomicAdd(red + c + 3, v.w);
+}
+
+// =================================================================================
+// B3: MLP + attention-projection backward for one block.
+//   in : dx2 (grad of block output), x1, u_pre           out: du_pre, dx1, do (HM)
+//   grads: b2, b1, le taps, ln2 w/b, bp
+// =================================================================================
+template <int C, int NCH>
+__global__ __launch_bounds__(512) void k_mlp_bwd(const float* __restrict__ dx2, const float* __restrict__ x1,
+                                                 const float* __restrict__ upre, BlockP w, BlockP gr,
+                                                 float* __restrict__ dupre, float* __restrict__ dx1,
+                                                 float* __restrict__ do_hm, int N, int B) {
+  extern __shared__ float4 smem4[];
+  constexpr int LD = C + 4, HC = 4 * C / NCH, LDU = HC + 4, LPR = C / 4;
+  float* Ds = reinterpret_cast<float*>(smem4);  // N x LD : dx2 -> dx1
+  float* Gs = Ds + N * LD;                      // N x LD : dg accumulator
+  float* Us = Gs + N * LD;                      // N x LDU: u_pre chunk -> du chunk
+  float* A0 = Us + N * LDU;                     // N + 2  : gelu(u[:,0]), zero halo
+  float* DC0 = A0 + N + 2;                      // N + 2  : d c0, zero halo
+  float* U0 = DC0 + N + 2;                      // N      : u_pre[:,0]
+  float* C0 = U0 + N;                           // N      : conv output c0
+  float* red = C0 + N;                          // 2C + 4 : ln2 grads + le taps (block reduction)
+  const int RPP = blockDim.x / LPR;
+  const int cq = (threadIdx.x % LPR) * 4;
+  const bool le = w.le != nullptr;
+  float lw0 = 0.f, lw1 = 0.f, lw2 = 0.f;
+  if (le) { lw0 = w.le[0]; lw1 = w.le[1]; lw2 = w.le[2]; }
+  const float4 gam2 = *reinterpret_cast<const float4*>(w.ln2w + cq);
+  // per-thread gradient accumulators (live across the window loop)
+  float db1[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) db1[i] = 0.f;
+  float db2 = 0.f, dbp = 0.f, gle0 = 0.f, gle1 = 0.f, gle2 = 0.f;
+  float4 dgam = make_float4(0.f, 0.f, 0.f, 0.f), dbet = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  for (int win = blockIdx.x; win < B; win += gridDim.x) {
+    const size_t wo = (size_t)win * N * C;
+    copy_in(Ds, LD, dx2 + wo, C, N, C);
+#pragma unroll 1
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int j0 = ch * HC;
+      copy_in(Us, LDU, upre + (size_t)win * N * 4 * C + j0, 4 * C, N, HC);
+      __syncthreads();
+      if (le && ch == 0) {
+        for (int i = threadIdx.x; i < N + 2; i += blockDim.x) {
+          const bool halo = (i == 0 || i == N + 1);
+          const float u = halo ? 0.f : Us[(i - 1) * LDU];
+          A0[i] = halo ? 0.f : gelu_f(u);
+          DC0[i] = 0.f;
+          if (!halo) U0[i - 1] = u;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < N; i += blockDim.x) C0[i] = lw0 * A0[i] + lw1 * A0[i + 1] + lw2 * A0[i + 2];
+        __syncthreads();
+      }
+      // d a2 = dx2 W2[:, chunk]  -> du (in place over u_pre)
+      gemm_phase<C, TTBof<C>::v, true, LAY_TOK>(w.w2 + j0, 4 * C, HC, Ds, LD, N >> 4,
+                                                [&](int row0, int tok, f32x4 a) {
+        float4* pu = reinterpret_cast<float4*>(Us + tok * LDU + row0);
+        const float4 u = *pu;
+        float uu[4] = {u.x, u.y, u.z, u.w}, out[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (!le) {
+            out[e] = a[e] * gelu_grad_f(uu[e]);
+          } else if (ch == 0 && row0 + e == 0) {
+            DC0[tok + 1] = a[e] * gelu_grad_f(C0[tok]);
+            out[e] = 0.f;  // filled by the channel-0 pass below
+          } else {
+            out[e] = a[e] * gelu_grad_f(gelu_f(uu[e])) * gelu_grad_f(uu[e]);
+          }
+        }
+        *pu = make_float4(out[0], out[1], out[2], out[3]);
+      });
+      __syncthreads();
+      if (le && ch == 0) {
+        for (int n = threadIdx.x; n < N; n += blockDim.x) {
+          const float da1 = lw0 * DC0[n + 2] + lw1 * DC0[n + 1] + lw2 * DC0[n];
+          Us[n * LDU] = da1 * gelu_grad_f(U0[n]);
+          const float dc = DC0[n + 1];
+          gle0 += dc * A0[n]; gle1 += dc * A0[n + 1]; gle2 += dc * A0[n + 2];
+        }
+        __syncthreads();
+      }
+      copy_out(dupre + (size_t)win * N * 4 * C + j0, 4 * C, Us, LDU, N, HC);
+      if ((int)threadIdx.x < HC) {
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s += Us[n * LDU + threadIdx.x];
+        db1[ch] += s;
+      }
+      // dg (+)= du W1[chunk, :]
+      gemm_phase<HC, TTBof<C>::v, true, LAY_TOK>(w.w1 + (size_t)j0 * C, C, C, Us, LDU, N >> 4,
+                                                 [&](int row0, int tok, f32x4 a) {
+        float4* pg = reinterpret_cast<float4*>(Gs + tok * LD + row0);
+        *pg = (ch == 0) ? tofloat4(a) : f4add(*pg, tofloat4(a));
+      });
+      __syncthreads();
+    }
+    if ((int)threadIdx.x < C) {
+      float s = 0.f;
+      for (int n = 0; n < N; ++n) s += Ds[n * LD + threadIdx.x];
+      db2 += s;
+    }
+    __syncthreads();
+    // LN2 backward, dx1 = dx2 + dLN
+    for (int row = threadIdx.x / LPR; row < N; row += RPP) {
+      const float4 v = *reinterpret_cast<const float4*>(x1 + wo + (size_t)row * C + cq);
+      float4 d; float rstd;
+      ln_stats<LPR>(v, d, rstd);
+      const float4 xh = f4scale(d, rstd);
+      const float4 dg = *reinterpret_cast<const float4*>(Gs + row * LD + cq);
+      const float4 dyh = f4mul(dg, gam2);
+      constexpr float invC = 1.0f / C;
+      const float m1 = group_sum<LPR>(f4hsum(dyh)) * invC;
+      const float m2 = group_sum<LPR>(f4dot(dyh, xh)) * invC;
+      float4* pd = reinterpret_cast<float4*>(Ds + row * LD + cq);
+      const float4 dx = make_float4(rstd * (dyh.x - m1 - xh.x * m2), rstd * (dyh.y - m1 - xh.y * m2),
+                                    rstd * (dyh.z - m1 - xh.z * m2), rstd * (dyh.w - m1 - xh.w * m2));
+      *pd = f4add(*pd, dx);
+      dgam = f4add(dgam, f4mul(dg, xh));
+      dbet = f4add(dbet, dg);
+    }
+    __syncthreads();
+    copy_out(dx1 + wo, C, Ds, LD, N, C);
+    if ((int)threadIdx.x < C) {
+      float s = 0.f;
+      for (int n = 0; n < N; ++n) s += Ds[n * LD + threadIdx.x];
+      dbp += s;
+    }
+    // do = dx1 Wp  (head-major)
+    float* dow = do_hm + wo;
+    gemm_phase<C, TTBof<C>::v, true, LAY_TOK>(w.wp, C, C, Ds, LD, N >> 4, [&](int row0, int tok, f32x4 a) {
+      *reinterpret_cast<float4*>(dow + ((size_t)(row0 >> 2) * N + tok) * 4) = tofloat4(a);
+    });
+    __syncthreads();
+  }
+  // ---- flush the small gradients ----
+  for (int i = threadIdx.x; i < 2 * C + 4; i += blockDim.x) red[i] = 0.f;
+  __syncthreads();
+  lds_add4(red, cq, dgam);
+  lds_add4(red, C + cq, dbet);
+  if (le) {
+    const float s0 = group_sum<64>(gle0), s1 = group_sum<64>(gle1), s2 = group_sum<64>(gle2);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(red + 2 * C, s0); atomicAdd(red + 2 * C + 1, s1); atomicAdd(red + 2 * C + 2, s2); }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < C) {
+    atomicAdd(gr.ln2w + threadIdx.x, red[threadIdx.x]);
+    atomicAdd(gr.ln2b + threadIdx.x, red[C + threadIdx.x]);
+    atomicAdd(gr.b2 + threadIdx.x, db2);
+    atomicAdd(gr.bp + threadIdx.x, dbp);
+  }
+  if (le && threadIdx.x < 3) atomicAdd(gr.le + threadIdx.x, red[2 * C + threadIdx.x]);
+  if ((int)threadIdx.x < HC) {
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) atomicAdd(gr.b1 + ch * HC + threadIdx.x, db1[ch]);
+  }
+}
+
+// =================================================================================
+// B2: attention backward per (window, head group).  P is recomputed from q, k and the
+// saved log-sum-exp.  Sweep A keeps a query block on the lanes (dQ accumulates lane-
+// privately over keys), sweep B keeps a key block on the lanes (dK, dV accumulate over
+// queries): no cross-workgroup sums, no atomics except the tiny R-wave table gradient.
+// Output dqkv has the qkv layout; dq already carries the 0.5 of q = 0.5 (h Wq^T + b).
+// =================================================================================
+template <int QT>
+__global__ __launch_bounds__(512) void k_attn_bwd(const float* __restrict__ qkv, const float* __restrict__ o_hm,
+                                                  const float* __restrict__ do_hm, const float* __restrict__ lse,
+                                                  const float* __restrict__ table, float* __restrict__ gtable,
+                                                  float* __restrict__ dqkv, int N, int H, int HG, int Len, int B) {
+  extern __shared__ float4 smem4[];
+  float* Qs = reinterpret_cast<float*>(smem4);
+  float* Ks = Qs + HG * N * 4;
+  float* Vs = Ks + HG * N * 4;
+  float* dOs = Vs + HG * N * 4;
+  float* Ls = dOs + HG * N * 4;  // lse * log2e
+  float* Dl = Ls + HG * N;       // delta = rowsum(dO * O)
+  const int ntab = table ? (2 * Len - 1) * HG : 0;
+  float* tab = Dl + HG * N;
+  float* dtab = tab + ntab;
+  const int ngrp = H / HG;
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int off = (N - Len) >> 1;
+  const float LOG2E = 1.4426950408889634f;
+  for (int i = threadIdx.x; i < ntab; i += blockDim.x) dtab[i] = 0.f;
+  for (int item = blockIdx.x; item < B * ngrp; item += gridDim.x) {
+    const int win = item / ngrp, h0 = (item - win * ngrp) * HG;
+    const float* base = qkv + (size_t)win * 3 * H * N * 4;
+    float* dbase = dqkv + (size_t)win * 3 * H * N * 4;
+    copy_flat(Qs, base + (size_t)h0 * N * 4, HG * N);
+    copy_flat(Ks, base + (size_t)(H + h0) * N * 4, HG * N);
+    copy_flat(Vs, base + (size_t)(2 * H + h0) * N * 4, HG * N);
+    const size_t hq0 = ((size_t)win * H + h0) * N;
+    for (int i = threadIdx.x; i < HG * N; i += blockDim.x) {
+      const float4 d4 = reinterpret_cast<const float4*>(do_hm)[hq0 + i];
+      const float4 o4 = reinterpret_cast<const float4*>(o_hm)[hq0 + i];
+      reinterpret_cast<float4*>(dOs)[i] = d4;
+      Dl[i] = f4dot(d4, o4);
+      Ls[i] = lse[hq0 + i] * LOG2E;
+    }
+    for (int i = threadIdx.x; i < ntab; i += blockDim.x) tab[i] = table[(i / HG) * H + h0 + (i % HG)];
+    __syncthreads();
+    const int nblk = N / (16 * QT);
+    // ---------------- sweep A: dQ ----------------
+    for (int task = wave; task < HG * nblk; task += nw) {
+      const int hl = task / nblk, q0 = (task - hl * nblk) * 16 * QT;
+      const float* Qh = Qs + hl * N * 4; const float* Kh = Ks + hl * N * 4;
+      const float* Vh = Vs + hl * N * 4; const float* Dh = dOs + hl * N * 4;
+      float qf[QT], df[QT], lq[QT], dl[QT];
+      float4 dq[QT];
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        const int q = q0 + 16 * qt + r;
+        qf[qt] = Qh[q * 4 + g]; df[qt] = Dh[q * 4 + g];
+        lq[qt] = Ls[hl * N + q]; dl[qt] = Dl[hl * N + q];
+        dq[qt] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      const bool qbias = table && (q0 < off + Len) && (q0 + 16 * QT > off);
+      for (int kt = 0; kt < N; kt += 16) {
+        const float kf = Kh[(kt + r) * 4 + g], vf = Vh[(kt + r) * 4 + g];
+        float4 k4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) k4[j] = *reinterpret_cast<const float4*>(Kh + (kt + 4 * g + j) * 4);
+        const bool tb = qbias && (kt < off + Len) && (kt + 16 > off);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+          f32x4 s = mfma4(kf, qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});
+          const f32x4 dp = mfma4(vf, df[qt], f32x4{0.f, 0.f, 0.f, 0.f});
+          const int qi = q0 + 16 * qt + r - off;
+          if (tb) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int ki = kt + 4 * g + j - off;
+              if (qi >= 0 && qi < Len && ki >= 0 && ki < Len) s[j] += tab[(qi - ki + Len - 1) * HG + hl];
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float p = __builtin_amdgcn_exp2f(fmaf(s[j], LOG2E, -lq[qt]));
+            const float ds = p * (dp[j] - dl[qt]);
+            dq[qt].x = fmaf(ds, k4[j].x, dq[qt].x);
+            dq[qt].y = fmaf(ds, k4[j].y, dq[qt].y);
+            dq[qt].z = fmaf(ds, k4[j].z, dq[qt].z);
+            dq[qt].w = fmaf(ds, k4[j].w, dq[qt].w);
+            if (tb) {
+              const int ki = kt + 4 * g + j - off;
+              if (qi >= 0 && qi < Len && ki >= 0 && ki < Len) atomicAdd(dtab + (qi - ki + Len - 1) * HG + hl, ds);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+#pragma unroll
+        for (int sh = 16; sh <= 32; sh <<= 1) {
+          dq[qt].x += __shfl_xor(dq[qt].x, sh); dq[qt].y += __shfl_xor(dq[qt].y, sh);
+          dq[qt].z += __shfl_xor(dq[qt].z, sh); dq[qt].w += __shfl_xor(dq[qt].w, sh);
+        }
+        if (g == 0)
+          *reinterpret_cast<float4*>(dbase + ((size_t)(h0 + hl) * N + q0 + 16 * qt + r) * 4) = f4scale(dq[qt], 0.5f);
+      }
+    }
+    // ---------------- sweep B: dK, dV ----------------
+    for (int task = wave; task < HG * nblk; task += nw) {
+      const int hl = task / nblk, k0 = (task - hl * nblk) * 16 * QT;
+      const float* Qh = Qs + hl * N * 4; const float* Kh = Ks + hl * N * 4;
+      const float* Vh = Vs + hl * N * 4; const float* Dh = dOs + hl * N * 4;
+      float kf[QT], vf[QT];
+      float4 dk[QT], dv[QT];
+#pragma unroll
+      for (int t = 0; t < QT; ++t) {
+        const int k = k0 + 16 * t + r;
+        kf[t] = Kh[k * 4 + g]; vf[t] = Vh[k * 4 + g];
+        dk[t] = make_float4(0.f, 0.f, 0.f, 0.f); dv[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      const bool kbias = table && (k0 < off + Len) && (k0 + 16 * QT > off);
+      for (int qt = 0; qt < N; qt += 16) {
+        const float qa = Qh[(qt + r) * 4 + g], da = Dh[(qt + r) * 4 + g];
+        const float4 l4 = *reinterpret_cast<const float4*>(Ls + hl * N + qt + 4 * g);
+        const float4 d4 = *reinterpret_cast<const float4*>(Dl + hl * N + qt + 4 * g);
+        const float lj[4] = {l4.x, l4.y, l4.z, l4.w}, dj[4] = {d4.x, d4.y, d4.z, d4.w};
+        float4 q4[4], o4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          q4[j] = *reinterpret_cast<const float4*>(Qh + (qt + 4 * g + j) * 4);
+          o4[j] = *reinterpret_cast<const float4*>(Dh + (qt + 4 * g + j) * 4);
+        }
+        const bool tb = kbias && (qt < off + Len) && (qt + 16 > off);
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+          f32x4 s = mfma4(qa, kf[t], f32x4{0.f, 0.f, 0.f, 0.f});        // S[query 4g+j][key r]
+          const f32x4 dp = mfma4(da, vf[t], f32x4{0.f, 0.f, 0.f, 0.f});  // dP[query][key]
+          if (tb) {
+            const int ki = k0 + 16 * t + r - off;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int qi = qt + 4 * g + j - off;
+              if (qi >= 0 && qi < Len && ki >= 0 && ki < Len) s[j] += tab[(qi - ki + Len - 1) * HG + hl];
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float p = __builtin_amdgcn_exp2f(fmaf(s[j], LOG2E, -lj[j]));
+            const float ds = p * (dp[j] - dj[j]);
+            dv[t].x = fmaf(p, o4[j].x, dv[t].x); dv[t].y = fmaf(p, o4[j].y, dv[t].y);
+            dv[t].z = fmaf(p, o4[j].z, dv[t].z); dv[t].w = fmaf(p, o4[j].w, dv[t].w);
+            dk[t].x = fmaf(ds, q4[j].x, dk[t].x); dk[t].y = fmaf(ds, q4[j].y, dk[t].y);
+            dk[t].z = fmaf(ds, q4[j].z, dk[t].z); dk[t].w = fmaf(ds, q4[j].w, dk[t].w);
+          }
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < QT; ++t) {
+#pragma unroll
+        for (int sh = 16; sh <= 32; sh <<= 1) {
+          dk[t].x += __shfl_xor(dk[t].x, sh); dk[t].y += __shfl_xor(dk[t].y, sh);
+          dk[t].z += __shfl_xor(dk[t].z, sh); dk[t].w += __shfl_xor(dk[t].w, sh);
+          dv[t].x += __shfl_xor(dv[t].x, sh); dv[t].y += __shfl_xor(dv[t].y, sh);
+          dv[t].z += __shfl_xor(dv[t].z, sh); dv[t].w += __shfl_xor(dv[t].w, sh);
+        }
+        if (g == 0) {
+          const size_t kk = (size_t)(h0 + hl) * N + k0 + 16 * t + r;
+          *reinterpret_cast<float4*>(dbase + ((size_t)H * N + kk) * 4) = dk[t];
+          *reinterpret_cast<float4*>(dbase + ((size_t)2 * H * N + kk) * 4) = dv[t];
+        }
+      }
+    }
+    __syncthreads();
+    if (ntab) {  // flush this item's table gradient (heads differ between items)
+      for (int i = threadIdx.x; i < ntab; i += blockDim.x) {
+        const float v = dtab[i];
+        if (v != 0.f) atomicAdd(gtable + (i / HG) * H + h0 + (i % HG), v);
+        dtab[i] = 0.f;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// =================================================================================
+// B1: QKV projection + LN1 backward:  dh = dqkv Wqkv;  dx = dx1 + sqrt(C) * LN1bwd(dh)
+//   grads: bqkv, ln1 w/b.   `extra` (optional) is added to dx (skip-connection gradient).
+// =================================================================================
+template <int C>
+__global__ __launch_bounds__(512) void k_qkv_bwd(const float* __restrict__ dqkv, const float* __restrict__ x,
+                                                 const float* __restrict__ pe, const float* __restrict__ dx1,
+                                                 const float* __restrict__ extra, BlockP w, BlockP gr,
+                                                 float* __restrict__ dx, int N, int B) {
+  extern __shared__ float4 smem4[];
+  constexpr int LD = C + 4, LPR = C / 4, TTB = TTBof<C>::v;
+  float* DQ = reinterpret_cast<float*>(smem4);  // HM, N x 3C
+  float* Dh = DQ + N * 3 * C;                   // N x LD
+  float* red = Dh + N * LD;                     // 2C
+  const int RPP = blockDim.x / LPR;
+  const int cq = (threadIdx.x % LPR) * 4;
+  const float sqrtC = sqrtf((float)C);
+  const float4 gam1 = *reinterpret_cast<const float4*>(w.ln1w + cq);
+  float dbq = 0.f;  // thread c < 3C (C=128: 384 <= 512 threads)
+  float4 dgam = make_float4(0.f, 0.f, 0.f, 0.f), dbet = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  for (int win = blockIdx.x; win < B; win += gridDim.x) {
+    const size_t wo = (size_t)win * N * C;
+    copy_flat(DQ, dqkv + 3 * wo, N * 3 * C / 4);
+    __syncthreads();
+    // dh[t][c] = sum_m dqkv[t][m] Wqkv[m][c]   (K = 3C split as C (q rows) + 2C (kv rows))
+    {
+      constexpr int mt = (C + 15) >> 4;
+      const int tg = (N >> 4) / TTB;
+      for (int u = wave; u < mt * tg; u += nw) {
+        const int m = u % mt, tgi = u / mt;
+        f32x4 acc[TTB];
+#pragma unroll
+        for (int tt = 0; tt < TTB; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        gemm_wx<C, TTB, true, LAY_HM>(w.wqkv, C, m * 16, C, DQ, N, tgi * TTB * 16, acc);
+        gemm_wx<2 * C, TTB, true, LAY_HM>(w.wqkv + C * C, C, m * 16, C, DQ + (C / 4) * N * 4, N, tgi * TTB * 16, acc);
+        const int row0 = m * 16 + 4 * g;
+        if (row0 < C) {
+#pragma unroll
+          for (int tt = 0; tt < TTB; ++tt)
+            *reinterpret_cast<float4*>(Dh + ((tgi * TTB + tt) * 16 + r) * LD + row0) = tofloat4(acc[tt]);
+        }
+      }
+    }
+    if ((int)threadIdx.x < 3 * C) {
+      const int c = threadIdx.x;
+      const float* col = DQ + (c >> 2) * N * 4 + (c & 3);
+      float s = 0.f;
+      for (int n = 0; n < N; ++n) s += col[n * 4];
+      dbq += s;
+    }
+    __syncthreads();
+    for (int row = threadIdx.x / LPR; row < N; row += RPP) {
+      float4 v = *reinterpret_cast<const float4*>(x + wo + (size_t)row * C + cq);
+      const float4 p = *reinterpret_cast<const float4*>(pe + row * C + cq);
+      v = f4add(f4scale(v, sqrtC), p);
+      float4 d; float rstd;
+      ln_stats<LPR>(v, d, rstd);
+      const float4 xh = f4scale(d, rstd);
+      const float4 dh = *reinterpret_cast<const float4*>(Dh + row * LD + cq);
+      const float4 dyh = f4mul(dh, gam1);
+      constexpr float invC = 1.0f / C;
+      const float m1 = group_sum<LPR>(f4hsum(dyh)) * invC;
+      const float m2 = group_sum<LPR>(f4dot(dyh, xh)) * invC;
+      const float k = rstd * sqrtC;
+      float4 out = make_float4(k * (dyh.x - m1 - xh.x * m2), k * (dyh.y - m1 - xh.y * m2),
+                               k * (dyh.z - m1 - xh.z * m2), k * (dyh.w - m1 - xh.w * m2));
+      out = f4add(out, *reinterpret_cast<const float4*>(dx1 + wo + (size_t)row * C + cq));
+      if (extra) out = f4add(out, *reinterpret_cast<const float4*>(extra + wo + (size_t)row * C + cq));
+      *reinterpret_cast<float4*>(dx + wo + (size_t)row * C + cq) = out;
+      dgam = f4add(dgam, f4mul(dh, xh));
+      dbet = f4add(dbet, dh);
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) red[i] = 0.f;
+  __syncthreads();
+  lds_add4(red, cq, dgam);
+  lds_add4(red, C + cq, dbet);
+  __syncthreads();
+  if ((int)threadIdx.x < C) {
+    atomicAdd(gr.ln1w + threadIdx.x, red[threadIdx.x]);
+    atomicAdd(gr.ln1b + threadIdx.x, red[C + threadIdx.x]);
+  }
+  if ((int)threadIdx.x < 3 * C) atomicAdd(gr.bqkv + threadIdx.x, dbq);
+}
+
+// =================================================================================
+// PatchMerging / PatchSeparate backward: dh = dy W;  dx = LNbwd(dh) scattered back to
+// the input layout;  grads: LN w/b.  (dW of the reduction is a ral_dw.hip product.)
+// =================================================================================
+template <int D, bool SEP>
+__global__ __launch_bounds__(256) void k_resample_bwd(const float* __restrict__ dy, const float* __restrict__ x,
+                                                      const float* __restrict__ wred, const float* __restrict__ lnw,
+                                                      float* __restrict__ g_lnw, float* __restrict__ g_lnb,
+                                                      float* __restrict__ dx, int T, int B) {
+  extern __shared__ float4 smem4[];
+  constexpr int LD = D + 4, LPR = D / 4, RPP = 256 / LPR;
+  float* Ys = reinterpret_cast<float*>(smem4);  // T x LD
+  float* Dh = Ys + T * LD;                      // T x LD
+  float* red = Dh + T * LD;                     // 2D
+  const int cq = (threadIdx.x % LPR) * 4;
+  const float4 gam = *reinterpret_cast<const float4*>(lnw + cq);
+  float4 dgam = make_float4(0.f, 0.f, 0.f, 0.f), dbet = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int win = blockIdx.x; win < B; win += gridDim.x) {
+    const size_t wo = (size_t)win * T * D;
+    copy_in(Ys, LD, dy + wo, D, T, D);
+    __syncthreads();
+    gemm_phase<D, TTBof<D>::v, true, LAY_TOK>(wred, D, D, Ys, LD, T >> 4, [&](int row0, int tok, f32x4 a) {
+      *reinterpret_cast<float4*>(Dh + tok * LD + row0) = tofloat4(a);
+    });
+    __syncthreads();
+    for (int row = threadIdx.x / LPR; row < T; row += RPP) {
+      const size_t src = SEP ? wo + (size_t)(row % (T / 2)) * 2 * D + (row / (T / 2)) * D : wo + (size_t)row * D;
+      const float4 v = *reinterpret_cast<const float4*>(x + src + cq);
+      float4 d; float rstd;
+      ln_stats<LPR>(v, d, rstd);
+      const float4 xh = f4scale(d, rstd);
+      const float4 dh = *reinterpret_cast<const float4*>(Dh + row * LD + cq);
+      const float4 dyh = f4mul(dh, gam);
+      constexpr float invD = 1.0f / D;
+      const float m1 = group_sum<LPR>(f4hsum(dyh)) * invD;
+      const float m2 = group_sum<LPR>(f4dot(dyh, xh)) * invD;
+      *reinterpret_cast<float4*>(dx + src + cq) =
+          make_float4(rstd * (dyh.x - m1 - xh.x * m2), rstd * (dyh.y - m1 - xh.y * m2),
+                      rstd * (dyh.z - m1 - xh.z * m2), rstd * (dyh.w - m1 - xh.w * m2));
+      dgam = f4add(dgam, f4mul(dh, xh));
+      dbet = f4add(dbet, dh);
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < 2 * D; i += blockDim.x) red[i] = 0.f;
+  __syncthreads();
+  lds_add4(red, cq, dgam);
+  lds_add4(red, D + cq, dbet);
+  __syncthreads();
+  if ((int)threadIdx.x < D) {
+    atomicAdd(g_lnw + threadIdx.x, red[threadIdx.x]);
+    atomicAdd(g_lnb + threadIdx.x, red[D + threadIdx.x]);
+  }
+}
+
+// =================================================================================
+// output conv backward: dz[b][l][c] = sum_o sum_k w[o][c][k] dy[b][o][l-k+1]  (token-major, 8 ch)
+//   grads: transconv w (leads x 8 x 3), b (leads);  z = u0 + x0 is re-formed on the fly
+// =================================================================================
+template <int LEADS>
+__global__ __launch_bounds__(256) void k_final_bwd(const float* __restrict__ dy, const float* __restrict__ u0,
+                                                   const float* __restrict__ x0, const float* __restrict__ w,
+                                                   float* __restrict__ gw, float* __restrict__ gb,
+                                                   float* __restrict__ dz, int L, int B) {
+  constexpr int NG = LEADS * 24 + LEADS;
+  __shared__ float red[4][NG];
+  float wr[LEADS][8][3];
+#pragma unroll
+  for (int o = 0; o < LEADS; ++o)
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) wr[o][c][k] = w[(o * 8 + c) * 3 + k];
+  float acc[NG];
+#pragma unroll
+  for (int i = 0; i < NG; ++i) acc[i] = 0.f;
+  const size_t total = (size_t)B * L;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / L), l = (int)(i - (size_t)b * L);
+    float dyv[LEADS][3];  // dy[o][l-1], dy[o][l], dy[o][l+1]
+#pragma unroll
+    for (int o = 0; o < LEADS; ++o) {
+      const float* dr = dy + ((size_t)b * LEADS + o) * L;
+      dyv[o][0] = l > 0 ? dr[l - 1] : 0.f;
+      dyv[o][1] = dr[l];
+      dyv[o][2] = l < L - 1 ? dr[l + 1] : 0.f;
+    }
+    // dz[l][c] = sum_o ( w[o][c][0] dy[o][l+1] + w[o][c][1] dy[o][l] + w[o][c][2] dy[o][l-1] )
+    float z8[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float a = 0.f;
+#pragma unroll
+      for (int o = 0; o < LEADS; ++o)
+        a += wr[o][c][0] * dyv[o][2] + wr[o][c][1] * dyv[o][1] + wr[o][c][2] * dyv[o][0];
+      z8[c] = a;
+    }
+    float4* pz = reinterpret_cast<float4*>(dz + i * 8);
+    pz[0] = make_float4(z8[0], z8[1], z8[2], z8[3]);
+    pz[1] = make_float4(z8[4], z8[5], z8[6], z8[7]);
+    // weight grads: gw[o][c][k] += dy[o][l'] z[l'+k-1][c]  summed over l'  ==  z[l][c] * dy[o][l-k+1]
+    const float4 a0 = reinterpret_cast<const float4*>(u0)[i * 2], a1 = reinterpret_cast<const float4*>(u0)[i * 2 + 1];
+    const float4 b0 = reinterpret_cast<const float4*>(x0)[i * 2], b1 = reinterpret_cast<const float4*>(x0)[i * 2 + 1];
+    const float z[8] = {a0.x + b0.x, a0.y + b0.y, a0.z + b0.z, a0.w + b0.w,
+                        a1.x + b1.x, a1.y + b1.y, a1.z + b1.z, a1.w + b1.w};
+#pragma unroll
+    for (int o = 0; o < LEADS; ++o) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc[(o * 8 + c) * 3 + k] += z[c] * dyv[o][2 - k];
+      acc[LEADS * 24 + o] += dyv[o][1];
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NG; ++i) {
+    const float s = group_sum<64>(acc[i]);
+    if (lane == 0) red[wave][i] = s;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < NG) {
+    const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if ((int)threadIdx.x < LEADS * 24) atomicAdd(gw + threadIdx.x, s);
+    else atomicAdd(gb + threadIdx.x - LEADS * 24, s);
+  }
+}
+
+// =================================================================================
+// conv stem backward.  Pass 1: per-channel sums of dy and dy*xhat (BatchNorm backward).
+// Pass 2: d a0 = gamma rstd (dy - mean(dy) - xhat mean(dy xhat)); LeakyReLU'; conv w/b grads.
+// ss = [scale(8), shift(8), mean(8), rstd(8)] from k_bn_finalize.
+// =================================================================================
+__global__ __launch_bounds__(256) void k_bn8_bwd_stats(const float* __restrict__ dy, const float* __restrict__ a0,
+                                                       const float* __restrict__ ss, double* __restrict__ out,
+                                                       size_t ntok) {
+  __shared__ double red[16 * 4];
+  float acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < ntok; t += (size_t)gridDim.x * blockDim.x) {
+    const float4 d0 = reinterpret_cast<const float4*>(dy)[t * 2], d1 = reinterpret_cast<const float4*>(dy)[t * 2 + 1];
+    const float4 v0 = reinterpret_cast<const float4*>(a0)[t * 2], v1 = reinterpret_cast<const float4*>(a0)[t * 2 + 1];
+    const float d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float xh = (v[c] - ss[16 + c]) * ss[24 + c];
+      acc[c] += d[c];
+      acc[8 + c] += d[c] * xh;
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const float s = group_sum<64>(acc[i]);
+    if (lane == 0) red[wave * 16 + i] = (double)s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    double t = 0.0;
+    for (int w = 0; w < nw; ++w) t += red[w * 16 + threadIdx.x];
+    atomicAdd(out + threadIdx.x, t);
+  }
+}
+
+template <int LEADS>
+__global__ __launch_bounds__(256) void k_conv1_bwd(const float* __restrict__ dy, const float* __restrict__ a0,
+                                                   const float* __restrict__ x, const float* __restrict__ ss,
+                                                   const float* __restrict__ bnw, const double* __restrict__ bst,
+                                                   double count, float* __restrict__ gw, float* __restrict__ gb,
+                                                   float* __restrict__ dzout, int L, int B) {
+  constexpr int NG = 8 * LEADS * 3 + 8;
+  __shared__ float red[4][NG];
+  float k1[8], m1[8], m2[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    k1[c] = bnw[c] * ss[24 + c];
+    m1[c] = (float)(bst[c] / count);
+    m2[c] = (float)(bst[8 + c] / count);
+  }
+  float acc[NG];
+#pragma unroll
+  for (int i = 0; i < NG; ++i) acc[i] = 0.f;
+  const size_t total = (size_t)B * L;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / L), l = (int)(i - (size_t)b * L);
+    const float4 d0 = reinterpret_cast<const float4*>(dy)[i * 2], d1 = reinterpret_cast<const float4*>(dy)[i * 2 + 1];
+    const float4 v0 = reinterpret_cast<const float4*>(a0)[i * 2], v1 = reinterpret_cast<const float4*>(a0)[i * 2 + 1];
+    const float d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    float xv[LEADS][3];
+#pragma unroll
+    for (int c = 0; c < LEADS; ++c) {
+      const float* xr = x + ((size_t)b * LEADS + c) * L;
+      xv[c][0] = l > 0 ? xr[l - 1] : 0.f;
+      xv[c][1] = xr[l];
+      xv[c][2] = l < L - 1 ? xr[l + 1] : 0.f;
+    }
+    float dz[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+      const float xh = (v[o] - ss[16 + o]) * ss[24 + o];
+      float da = k1[o] * (d[o] - m1[o] - xh * m2[o]);
+      da = v[o] > 0.f ? da : 0.2f * da;
+      dz[o] = da;
+#pragma unroll
+      for (int c = 0; c < LEADS; ++c)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc[(o * LEADS + c) * 3 + k] += da * xv[c][k];
+      acc[8 * LEADS * 3 + o] += da;
+    }
+    if (dzout) {
+      float4* pz = reinterpret_cast<float4*>(dzout + i * 8);
+      pz[0] = make_float4(dz[0], dz[1], dz[2], dz[3]);
+      pz[1] = make_float4(dz[4], dz[5], dz[6], dz[7]);
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NG; ++i) {
+    const float s = group_sum<64>(acc[i]);
+    if (lane == 0) red[wave][i] = s;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < NG) {
+    const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if ((int)threadIdx.x < 8 * LEADS * 3) atomicAdd(gw + threadIdx.x, s);
+    else atomicAdd(gb + threadIdx.x - 8 * LEADS * 3, s);
+  }
+}
+
+// BatchNorm affine grads from the (all-reduced) backward sums: g_w += sum dy*xhat, g_b += sum dy
+__global__ void k_bn_affine_grads(const double* __restrict__ bst, float* __restrict__ gw, float* __restrict__ gb, int nch) {
+  const int c = threadIdx.x;
+  if (c < nch) { gb[c] += (float)bst[c]; gw[c] += (float)bst[nch + c]; }
+}
+
+// dx[b][c][l] = sum_o sum_k w[o][c][k] dz[b][l-k+1][o]   (input gradient of the stem, 12-lead adapter only)
+template <int LEADS>
+__global__ void k_conv1_bwd_dx(const float* __restrict__ dz, const float* __restrict__ w, float* __restrict__ dx,
+                               int L, int B) {
+  const size_t total = (size_t)B * L;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / L), l = (int)(i - (size_t)b * L);
+    float acc[LEADS];
+#pragma unroll
+    for (int c = 0; c < LEADS; ++c) acc[c] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int ll = l - k + 1;
+      if (ll < 0 || ll >= L) continue;
+      const float* dr = dz + ((size_t)b * L + ll) * 8;
+#pragma unroll
+      for (int o = 0; o < 8; ++o)
+#pragma unroll
+        for (int c = 0; c < LEADS; ++c) acc[c] += w[(o * LEADS + c) * 3 + k] * dr[o];
+    }
+#pragma unroll
+    for (int c = 0; c < LEADS; ++c) dx[((size_t)b * LEADS + c) * L + l] = acc[c];
+  }
+}
+
+// =================================================================================
+// host launchers
+// =================================================================================
+static inline int grid_bwd(int items) { return items < 1024 ? items : 1024; }
+static inline int ew_grid(size_t n, int per = 256) {
+  size_t g = (n + per - 1) / per;
+  return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+size_t mlp_bwd_lds(int C, int N, int nch) {
+  return ((size_t)2 * N * (C + 4) + (size_t)N * (4 * C / nch + 4) + 2 * (N + 2) + 2 * N + 2 * C + 8) * sizeof(float);
+}
+
+template <int C>
+static void launch_mlp_bwd_c(int nch, const float* dx2, const float* x1, const float* upre, const BlockP& w,
+                             const BlockP& gr, float* dupre, float* dx1, float* do_hm, int N, int B, hipStream_t s) {
+  const size_t lds = mlp_bwd_lds(C, N, nch);
+  const int grid = grid_bwd(B);
+  if (nch == 1) { RAL_SET_LDS((k_mlp_bwd<C, 1>), lds); k_mlp_bwd<C, 1><<<grid, 512, lds, s>>>(dx2, x1, upre, w, gr, dupre, dx1, do_hm, N, B); }
+  else if (nch == 2) { RAL_SET_LDS((k_mlp_bwd<C, 2>), lds); k_mlp_bwd<C, 2><<<grid, 512, lds, s>>>(dx2, x1, upre, w, gr, dupre, dx1, do_hm, N, B); }
+  else { RAL_SET_LDS((k_mlp_bwd<C, 4>), lds); k_mlp_bwd<C, 4><<<grid, 512, lds, s>>>(dx2, x1, upre, w, gr, dupre, dx1, do_hm, N, B); }
+}
+
+void launch_mlp_bwd(int C, int nch, const float* dx2, const float* x1, const float* upre, const BlockP& w,
+                    const BlockP& gr, float* dupre, float* dx1, float* do_hm, int N, int B, hipStream_t s) {
+  switch (C) {
+#define CASE(c) case c: launch_mlp_bwd_c<c>(nch, dx2, x1, upre, w, gr, dupre, dx1, do_hm, N, B, s); break;
+    CASE(8) CASE(16) CASE(32) CASE(64) CASE(128)
+#undef CASE
+  }
+}
+
+size_t attn_bwd_lds(int N, int HG, int Len) {
+  return ((size_t)4 * HG * N * 4 + (size_t)2 * HG * N + (Len > 0 ? (size_t)2 * (2 * Len - 1) * HG : 0) + 4) * sizeof(float);
+}
+
+void launch_attn_bwd(const float* qkv, const float* o_hm, const float* do_hm, const float* lse, const float* table,
+                     float* gtable, float* dqkv, int N, int H, int HG, int Len, int B, hipStream_t s) {
+  const size_t lds = attn_bwd_lds(N, HG, Len);
+  const int items = B * (H / HG);
+  const int grid = items < 4096 ? items : 4096;
+  if (N % 32 == 0) {
+    RAL_SET_LDS((k_attn_bwd<2>), lds);
+    k_attn_bwd<2><<<grid, 512, lds, s>>>(qkv, o_hm, do_hm, lse, table, gtable, dqkv, N, H, HG, Len, B);
+  } else {
+    RAL_SET_LDS((k_attn_bwd<1>), lds);
+    k_attn_bwd<1><<<grid, 512, lds, s>>>(qkv, o_hm, do_hm, lse, table, gtable, dqkv, N, H, HG, Len, B);
+  }
+}
+
+size_t qkv_bwd_lds(int C, int N) { return ((size_t)N * 3 * C + (size_t)N * (C + 4) + 2 * C + 4) * sizeof(float); }
+
+void launch_qkv_bwd(int C, const float* dqkv, const float* x, const float* pe, const float* dx1, const float* extra,
+                    const BlockP& w, const BlockP& gr, float* dx, int N, int B, hipStream_t s) {
+  const size_t lds = qkv_bwd_lds(C, N);
+  const int grid = grid_bwd(B);
+  switch (C) {
+#define CASE(c) case c: RAL_SET_LDS((k_qkv_bwd<c>), lds); \
+    k_qkv_bwd<c><<<grid, 512, lds, s>>>(dqkv, x, pe, dx1, extra, w, gr, dx, N, B); break;
+    CASE(8) CASE(16) CASE(32) CASE(64) CASE(128)
+#undef CASE
+  }
+}
+
+void launch_resample_bwd(int D, bool sep, const float* dy, const float* x, const float* wred, const float* lnw,
+                         float* g_lnw, float* g_lnb, float* dx, int T, int B, hipStream_t s) {
+  const size_t lds = ((size_t)2 * T * (D + 4) + 2 * D + 4) * sizeof(float);
+  const int grid = grid_bwd(B);
+#define CASE(d) case d: if (sep) { RAL_SET_LDS((k_resample_bwd<d, true>), lds); k_resample_bwd<d, true><<<grid, 256, lds, s>>>(dy, x, wred, lnw, g_lnw, g_lnb, dx, T, B); } \
+                        else { RAL_SET_LDS((k_resample_bwd<d, false>), lds); k_resample_bwd<d, false><<<grid, 256, lds, s>>>(dy, x, wred, lnw, g_lnw, g_lnb, dx, T, B); } break;
+  switch (D) { CASE(8) CASE(16) CASE(32) CASE(64) CASE(128) }
+#undef CASE
+}
+
+void launch_final_bwd(int leads, const float* dy, const float* u0, const float* x0, const float* w, float* gw,
+                      float* gb, float* dz, int L, int B, hipStream_t s) {
+  const int grid = ew_grid((size_t)B * L, 1024);
+  if (leads == 1) k_final_bwd<1><<<grid, 256, 0, s>>>(dy, u0, x0, w, gw, gb, dz, L, B);
+  else k_final_bwd<2><<<grid, 256, 0, s>>>(dy, u0, x0, w, gw, gb, dz, L, B);
+}
+
+void launch_bn8_bwd_stats(const float* dy, const float* a0, const float* ss, double* out, size_t ntok, hipStream_t s) {
+  k_bn8_bwd_stats<<<ew_grid(ntok, 1024), 256, 0, s>>>(dy, a0, ss, out, ntok);
+}
+
+void launch_conv1_bwd(int leads, const float* dy, const float* a0, const float* x, const float* ss, const float* bnw,
+                      const double* bst, double count, float* gw, float* gb, float* dz, int L, int B, hipStream_t s) {
+  const int grid = ew_grid((size_t)B * L, 1024);
+  if (leads == 1) k_conv1_bwd<1><<<grid, 256, 0, s>>>(dy, a0, x, ss, bnw, bst, count, gw, gb, dz, L, B);
+  else k_conv1_bwd<2><<<grid, 256, 0, s>>>(dy, a0, x, ss, bnw, bst, count, gw, gb, dz, L, B);
+}
+
+void launch_bn_affine_grads(const double* bst, float* gw, float* gb, int nch, hipStream_t s) {
+  k_bn_affine_grads<<<1, 64, 0, s>>>(bst, gw, gb, nch);
+}
+
+void launch_conv1_bwd_dx(int leads, const float* dz, const float* w, float* dx, int L, int B, hipStream_t s) {
+  const int grid = ew_grid((size_t)B * L);
+  if (leads == 1) k_conv1_bwd_dx<1><<<grid, 256, 0, s>>>(dz, w, dx, L, B);
+  else k_conv1_bwd_dx<2><<<grid, 256, 0, s>>>(dz, w, dx, L, B);
+}

@@ -1,0 +1,208 @@
+// Device-side building blocks for the RA-LENet kernels (gfx950 / CDNA4 only).
+//
+// Every contraction on the path goes through v_mfma_f32_16x16x4_f32 (exact fp32, the
+// f32 matrix rate of gfx950 = 157 TFLOP/s).  Operand conventions used everywhere:
+//
+//   D[i][j] = sum_k A[i][k] * B[k][j]      i, j in [0,16), k in [0,4)
+//   lane l: r = l & 15, g = l >> 4
+//   A operand: lane holds A[i = r][k = g]          B operand: lane holds B[k = g][j = r]
+//   C/D:       lane holds D[row = 4g + q][col = r], q = 0..3  (one f32x4)
+//
+// "weights x activations" products put the OUTPUT CHANNEL on the MFMA row and the
+// TOKEN on the MFMA column, so a lane ends up with 4 consecutive channels of one
+// token: exactly one float4 of a token-major row, or one head's 4-vector.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define RAL_DEV __device__ __forceinline__
+
+RAL_DEV f32x4 mfma4(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// Activation tile layouts (global memory and LDS use the same two forms):
+//   LAY_TOK: token-major rows,   elem(t, c) at  t*ld + c
+//   LAY_HM : head-major quads,   elem(t, c) at ((c>>2)*ntok + t)*4 + (c&3)   ("ld" = ntok)
+enum { LAY_TOK = 0, LAY_HM = 1 };
+
+template <int LAY>
+RAL_DEV int xoff(int ld, int t, int c) {
+  if (LAY == LAY_TOK) return t * ld + c;
+  return (((c >> 2) * ld + t) << 2) + (c & 3);
+}
+
+// ---------------------------------------------------------------------------------
+// acc[tt] (+)= W[m0.., :K] x X[t0 + 16 tt .., :K]^T
+//   WT == false: W is (M, K) row-major in global memory, A[i][k] = W[(m0+i)*ldw + k]
+//   WT == true : W is (K, M) row-major,                  A[i][k] = W[k*ldw + m0 + i]
+//   X is an LDS tile in layout LAY.  K is a multiple of 16, or exactly 8.
+// The k index handled by (lane group g, step s) is k0 + 4g + s (K%16==0) so that one
+// 16-byte read feeds four MFMAs; both operands use the same permutation.
+template <int K, int TT, bool WT, int LAY>
+RAL_DEV void gemm_wx(const float* __restrict__ W, int ldw, int m0, int M, const float* Xs, int ldx,
+                     int t0, f32x4 (&acc)[TT]) {
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  int mrow = m0 + r;
+  if (mrow >= M) mrow = M - 1;  // clamp: rows >= M are computed on garbage and discarded
+  if constexpr (K % 16 == 0) {
+#pragma unroll 2
+    for (int k0 = 0; k0 < K; k0 += 16) {
+      float wv[4];
+      if constexpr (!WT) {
+        const float4 w4 = *reinterpret_cast<const float4*>(W + (size_t)mrow * ldw + k0 + 4 * g);
+        wv[0] = w4.x; wv[1] = w4.y; wv[2] = w4.z; wv[3] = w4.w;
+      } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) wv[s] = W[(size_t)(k0 + 4 * g + s) * ldw + mrow];
+      }
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) {
+        const float4 x4 = *reinterpret_cast<const float4*>(Xs + xoff<LAY>(ldx, t0 + 16 * tt + r, k0 + 4 * g));
+        acc[tt] = mfma4(wv[0], x4.x, acc[tt]);
+        acc[tt] = mfma4(wv[1], x4.y, acc[tt]);
+        acc[tt] = mfma4(wv[2], x4.z, acc[tt]);
+        acc[tt] = mfma4(wv[3], x4.w, acc[tt]);
+      }
+    }
+  } else {
+    static_assert(K == 8, "K must be a multiple of 16 or exactly 8");
+    float wv[2];
+    if constexpr (!WT) {
+      const float2 w2 = *reinterpret_cast<const float2*>(W + (size_t)mrow * ldw + 2 * g);
+      wv[0] = w2.x; wv[1] = w2.y;
+    } else {
+      wv[0] = W[(size_t)(2 * g) * ldw + mrow];
+      wv[1] = W[(size_t)(2 * g + 1) * ldw + mrow];
+    }
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+      const float2 x2 = *reinterpret_cast<const float2*>(Xs + xoff<LAY>(ldx, t0 + 16 * tt + r, 2 * g));
+      acc[tt] = mfma4(wv[0], x2.x, acc[tt]);
+      acc[tt] = mfma4(wv[1], x2.y, acc[tt]);
+    }
+  }
+}
+
+// One GEMM phase of a workgroup: out(M rows x ntiles*16 tokens) = W x X^T, work units
+// (16-row m tile, TTB token tiles) dealt round-robin to the waves.  epi(row0, tok, v)
+// receives rows row0..row0+3 (row0 % 4 == 0, row0 < M) of token `tok`.
+template <int K, int TTB, bool WT, int LAY, class Epi>
+RAL_DEV void gemm_phase(const float* __restrict__ W, int ldw, int M, const float* Xs, int ldx,
+                        int ntiles, Epi epi) {
+  const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int mt = (M + 15) >> 4, tg = ntiles / TTB;
+  for (int u = wave; u < mt * tg; u += nw) {
+    const int m = u % mt, tgi = u / mt;
+    f32x4 acc[TTB];
+#pragma unroll
+    for (int tt = 0; tt < TTB; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gemm_wx<K, TTB, WT, LAY>(W, ldw, m * 16, M, Xs, ldx, tgi * TTB * 16, acc);
+    const int row0 = m * 16 + 4 * g;
+    if (row0 < M) {
+#pragma unroll
+      for (int tt = 0; tt < TTB; ++tt) epi(row0, (tgi * TTB + tt) * 16 + r, acc[tt]);
+    }
+  }
+}
+
+// token tiles processed per weight-fragment load, by channel width (keeps ntiles % TTB == 0
+// for every window length that is a multiple of 256)
+template <int C> struct TTBof { static constexpr int v = (C <= 32) ? 4 : (C == 64 ? 2 : 1); };
+
+// ---------------------------------------------------------------------------------
+// acc[mi][ni] += sum_t Y[t][m0 + 16 mi + i] * X[t][n0 + 16 ni + j],  t in [0, T), T % 16 == 0
+// (weight-gradient products: both operands are LDS tiles, the contraction runs over tokens)
+template <int MI, int NI, int LAYY, int LAYX>
+RAL_DEV void gemm_yx(const float* Ys, int ldy, int m0, const float* Xs, int ldx, int n0, int T,
+                     f32x4 (&acc)[MI][NI]) {
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  for (int t0 = 0; t0 < T; t0 += 16) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int t = t0 + 4 * g + s;
+      float a[MI], b[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) a[mi] = Ys[xoff<LAYY>(ldy, t, m0 + 16 * mi + r)];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) b[ni] = Xs[xoff<LAYX>(ldx, t, n0 + 16 * ni + r)];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = mfma4(a[mi], b[ni], acc[mi][ni]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// small math
+RAL_DEV float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+RAL_DEV float gelu_grad_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+template <int W>
+RAL_DEV float group_sum(float v) {  // sum over W consecutive lanes (W power of two <= 64)
+#pragma unroll
+  for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+RAL_DEV float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+RAL_DEV float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+RAL_DEV float4 f4mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+RAL_DEV float4 f4scale(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+RAL_DEV float f4hsum(float4 a) { return (a.x + a.y) + (a.z + a.w); }
+RAL_DEV float f4dot(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+RAL_DEV float4 tofloat4(f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); }
+
+// LayerNorm statistics of one row held as float4 per lane across LPR lanes (C = 4*LPR).
+// Returns centred values in d, and rstd (biased variance, eps 1e-5 as nn.LayerNorm).
+template <int LPR>
+RAL_DEV void ln_stats(float4 v, float4& d, float& rstd) {
+  constexpr float invC = 1.0f / (4 * LPR);
+  const float mean = group_sum<LPR>(f4hsum(v)) * invC;
+  d = make_float4(v.x - mean, v.y - mean, v.z - mean, v.w - mean);
+  const float var = group_sum<LPR>(f4dot(d, d)) * invC;
+  rstd = 1.0f / sqrtf(var + 1e-5f);
+}
+
+// coalesced copy of an LDS tile (rows x width, row stride ld) to global rows of `gld` floats
+RAL_DEV void copy_out(float* __restrict__ dst, int gld, const float* src, int ld, int rows, int width) {
+  const int q = width >> 2;
+  for (int i = threadIdx.x; i < rows * q; i += blockDim.x) {
+    const int row = i / q, c = (i - row * q) << 2;
+    *reinterpret_cast<float4*>(dst + (size_t)row * gld + c) = *reinterpret_cast<const float4*>(src + row * ld + c);
+  }
+}
+RAL_DEV void copy_in(float* dst, int ld, const float* __restrict__ src, int gld, int rows, int width) {
+  const int q = width >> 2;
+  for (int i = threadIdx.x; i < rows * q; i += blockDim.x) {
+    const int row = i / q, c = (i - row * q) << 2;
+    *reinterpret_cast<float4*>(dst + row * ld + c) = *reinterpret_cast<const float4*>(src + (size_t)row * gld + c);
+  }
+}
+// flat float4 copy (n4 float4s)
+RAL_DEV void copy_flat(float* dst, const float* __restrict__ src, int n4) {
+  for (int i = threadIdx.x; i < n4; i += blockDim.x)
+    reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+}
+
+// Parameters of one TransformerBlock inside the flat parameter (or gradient) buffer.
+struct BlockP {
+  float* wqkv;  // (3C, C): to_q.weight then to_kv.weight
+  float* bqkv;  // (3C)
+  float* wp;    // (C, C)   attn.proj
+  float* bp;    // (C)
+  float* ln1w; float* ln1b; float* ln2w; float* ln2b;
+  float* w1;    // (4C, C)  mlp.fc1
+  float* b1;    // (4C)
+  float* w2;    // (C, 4C)  mlp.fc2
+  float* b2;    // (C)
+  float* le;    // (3) leconv.partial_conv3.weight or nullptr
+};

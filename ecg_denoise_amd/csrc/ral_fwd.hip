@@ -1,0 +1,357 @@
+// Forward kernels of the RA-LENet path (gfx950).  One workgroup = one ECG window
+// (or one window x head group for attention); every inter-kernel tensor of a window
+// is 8*L floats, so a whole stage tile lives in LDS.
+//
+// Reference behaviour restated (see oracle/ralenet_oracle.py for the line map):
+//   TransformerBlock  model/raletransformer.py:383-410, model/transformer.py:289-323
+//   PatchMerging / PatchSeparate  model/raletransformer.py:411-459
+#include "ral_device.hpp"
+#include "ral_kernels.hpp"
+
+// =================================================================================
+// K1: h = LN1(x*sqrt(C) + PE);  [q|k|v] = h Wqkv^T + b;  q *= 0.5  ->  qkv (HM layout)
+// =================================================================================
+template <int C>
+__global__ __launch_bounds__(256) void k_qkv_fwd(const float* __restrict__ x, const float* __restrict__ pe,
+                                                 BlockP w, float* __restrict__ qkv, int N, int B) {
+  extern __shared__ float4 smem4[];
+  float* Hs = reinterpret_cast<float*>(smem4);
+  constexpr int LD = C + 4, LPR = C / 4, RPP = 256 / LPR;
+  const float sqrtC = sqrtf((float)C);
+  const int cq = (threadIdx.x % LPR) * 4;
+  const float4 gam = *reinterpret_cast<const float4*>(w.ln1w + cq);
+  const float4 bet = *reinterpret_cast<const float4*>(w.ln1b + cq);
+  for (int win = blockIdx.x; win < B; win += gridDim.x) {
+    const float* xw = x + (size_t)win * N * C;
+    for (int row = threadIdx.x / LPR; row < N; row += RPP) {
+      float4 v = *reinterpret_cast<const float4*>(xw + row * C + cq);
+      const float4 p = *reinterpret_cast<const float4*>(pe + row * C + cq);
+      v = f4add(f4scale(v, sqrtC), p);
+      float4 d; float rstd;
+      ln_stats<LPR>(v, d, rstd);
+      *reinterpret_cast<float4*>(Hs + row * LD + cq) = f4add(f4mul(f4scale(d, rstd), gam), bet);
+    }
+    __syncthreads();
+    float* qw = qkv + (size_t)win * 3 * N * C;
+    gemm_phase<C, TTBof<C>::v, false, LAY_TOK>(w.wqkv, C, 3 * C, Hs, LD, N >> 4, [&](int row0, int tok, f32x4 a) {
+      float4 v = f4add(tofloat4(a), *reinterpret_cast<const float4*>(w.bqkv + row0));
+      if (row0 < C) v = f4scale(v, 0.5f);  // q * head_dim^-0.5, head_dim = 4
+      *reinterpret_cast<float4*>(qw + ((size_t)(row0 >> 2) * N + tok) * 4) = v;
+    });
+    __syncthreads();
+  }
+}
+
+// =================================================================================
+// K2: softmax(q k^T + bias) v per (window, head); full N x N, head_dim 4, two sweeps
+// (row max, then exp / sum / P.V) so nothing N x N is ever stored.  S^T tiles come from
+// the fp32 MFMA with the KEY on the row and the QUERY on the lane column: a lane owns
+// one query and four keys per tile, so P.V and the row sums accumulate lane-privately
+// on the VALU and are folded across the four lane groups once per query block.
+// =================================================================================
+template <int QT>
+__global__ __launch_bounds__(512) void k_attn_fwd(const float* __restrict__ qkv, float* __restrict__ o_hm,
+                                                  float* __restrict__ lse, const float* __restrict__ table,
+                                                  int N, int H, int HG, int Len, int B) {
+  extern __shared__ float4 smem4[];
+  float* Qs = reinterpret_cast<float*>(smem4);
+  float* Ks = Qs + HG * N * 4;
+  float* Vs = Ks + HG * N * 4;
+  float* tab = Vs + HG * N * 4;  // (2Len-1) x HG
+  const int ngrp = H / HG;
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int off = (N - Len) >> 1;
+  const float LOG2E = 1.4426950408889634f;
+  for (int item = blockIdx.x; item < B * ngrp; item += gridDim.x) {
+    const int win = item / ngrp, h0 = (item - win * ngrp) * HG;
+    const float* base = qkv + (size_t)win * 3 * H * N * 4;
+    copy_flat(Qs, base + (size_t)h0 * N * 4, HG * N);
+    copy_flat(Ks, base + (size_t)(H + h0) * N * 4, HG * N);
+    copy_flat(Vs, base + (size_t)(2 * H + h0) * N * 4, HG * N);
+    if (table)
+      for (int i = threadIdx.x; i < (2 * Len - 1) * HG; i += blockDim.x)
+        tab[i] = table[(i / HG) * H + h0 + (i % HG)];
+    __syncthreads();
+    const int qblocks = N / (16 * QT);
+    for (int task = wave; task < HG * qblocks; task += nw) {
+      const int hl = task / qblocks, q0 = (task - hl * qblocks) * 16 * QT;
+      const float* Qh = Qs + hl * N * 4;
+      const float* Kh = Ks + hl * N * 4;
+      const float* Vh = Vs + hl * N * 4;
+      float qf[QT], mx[QT], l[QT];
+      float4 o[QT];
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        qf[qt] = Qh[(q0 + 16 * qt + r) * 4 + g];
+        mx[qt] = -3.0e38f; l[qt] = 0.f; o[qt] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      // does any query of this task fall inside the centred R-wave window?
+      const bool qbias = table && (q0 < off + Len) && (q0 + 16 * QT > off);
+      // ---- sweep 1: row maxima ----
+      for (int kt = 0; kt < N; kt += 16) {
+        const float kf = Kh[(kt + r) * 4 + g];
+        const bool tb = qbias && (kt < off + Len) && (kt + 16 > off);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+          f32x4 s = mfma4(kf, qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});
+          if (tb) {
+            const int qi = q0 + 16 * qt + r - off;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int ki = kt + 4 * g + j - off;
+              if (qi >= 0 && qi < Len && ki >= 0 && ki < Len) s[j] += tab[(qi - ki + Len - 1) * HG + hl];
+            }
+          }
+          mx[qt] = fmaxf(mx[qt], fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])));
+        }
+      }
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        mx[qt] = fmaxf(mx[qt], __shfl_xor(mx[qt], 16));
+        mx[qt] = fmaxf(mx[qt], __shfl_xor(mx[qt], 32));
+      }
+      // ---- sweep 2: p = exp(s - max), l = sum p, o = sum p v ----
+      for (int kt = 0; kt < N; kt += 16) {
+        const float kf = Kh[(kt + r) * 4 + g];
+        float4 v4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v4[j] = *reinterpret_cast<const float4*>(Vh + (kt + 4 * g + j) * 4);
+        const bool tb = qbias && (kt < off + Len) && (kt + 16 > off);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+          f32x4 s = mfma4(kf, qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});
+          if (tb) {
+            const int qi = q0 + 16 * qt + r - off;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int ki = kt + 4 * g + j - off;
+              if (qi >= 0 && qi < Len && ki >= 0 && ki < Len) s[j] += tab[(qi - ki + Len - 1) * HG + hl];
+            }
+          }
+          const float nm = -mx[qt] * LOG2E;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float p = __builtin_amdgcn_exp2f(fmaf(s[j], LOG2E, nm));
+            l[qt] += p;
+            o[qt].x = fmaf(p, v4[j].x, o[qt].x);
+            o[qt].y = fmaf(p, v4[j].y, o[qt].y);
+            o[qt].z = fmaf(p, v4[j].z, o[qt].z);
+            o[qt].w = fmaf(p, v4[j].w, o[qt].w);
+          }
+        }
+      }
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+#pragma unroll
+        for (int sh = 16; sh <= 32; sh <<= 1) {
+          l[qt] += __shfl_xor(l[qt], sh);
+          o[qt].x += __shfl_xor(o[qt].x, sh);
+          o[qt].y += __shfl_xor(o[qt].y, sh);
+          o[qt].z += __shfl_xor(o[qt].z, sh);
+          o[qt].w += __shfl_xor(o[qt].w, sh);
+        }
+        if (g == 0) {
+          const float inv = 1.0f / l[qt];
+          const int q = q0 + 16 * qt + r;
+          const size_t hq = ((size_t)win * H + h0 + hl) * N + q;
+          *reinterpret_cast<float4*>(o_hm + hq * 4) = f4scale(o[qt], inv);
+          if (lse) lse[hq] = mx[qt] + logf(l[qt]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// =================================================================================
+// K3: x1 = x + o Wp^T + bp;  g = LN2(x1);  u = g W1^T + b1;  a = GELU(u)
+//     [LE: a[:,0] = conv3(a[:,0]) over tokens; a = GELU(a)];  x2 = x1 + a W2^T + b2
+// The hidden (N x 4C) tile is processed in NCH column chunks so that long windows fit.
+// =================================================================================
+template <int C, int NCH>
+__global__ __launch_bounds__(512) void k_mlp_fwd(const float* __restrict__ x, const float* __restrict__ o_hm,
+                                                 BlockP w, float* __restrict__ x1_out,
+                                                 float* __restrict__ upre_out, float* __restrict__ x2_out,
+                                                 int N, int B) {
+  extern __shared__ float4 smem4[];
+  constexpr int LD = C + 4, HC = 4 * C / NCH, LDU = HC + 4, LPR = C / 4;
+  float* Xs = reinterpret_cast<float*>(smem4);  // N x LD   : x -> x1 -> x2
+  float* Gs = Xs + N * LD;                      // N x LD   : o (HM, N*C) then LN2(x1)
+  float* Us = Gs + N * LD;                      // N x LDU  : hidden chunk
+  float* A0 = Us + N * LDU;                     // N + 2    : GELU(u[:,0]) with zero halo
+  const int RPP = blockDim.x / LPR;
+  const int cq = (threadIdx.x % LPR) * 4;
+  const bool le = w.le != nullptr;
+  float lw0 = 0.f, lw1 = 0.f, lw2 = 0.f;
+  if (le) { lw0 = w.le[0]; lw1 = w.le[1]; lw2 = w.le[2]; }
+  for (int win = blockIdx.x; win < B; win += gridDim.x) {
+    const size_t wo = (size_t)win * N * C;
+    copy_in(Xs, LD, x + wo, C, N, C);
+    copy_flat(Gs, o_hm + wo, N * C / 4);
+    __syncthreads();
+    // ---- attention output projection + residual ----
+    gemm_phase<C, TTBof<C>::v, false, LAY_HM>(w.wp, C, C, Gs, N, N >> 4, [&](int row0, int tok, f32x4 a) {
+      float4* px = reinterpret_cast<float4*>(Xs + tok * LD + row0);
+      *px = f4add(*px, f4add(tofloat4(a), *reinterpret_cast<const float4*>(w.bp + row0)));
+    });
+    __syncthreads();
+    if (x1_out) copy_out(x1_out + wo, C, Xs, LD, N, C);
+    // ---- LN2 ----
+    {
+      const float4 gam = *reinterpret_cast<const float4*>(w.ln2w + cq);
+      const float4 bet = *reinterpret_cast<const float4*>(w.ln2b + cq);
+      for (int row = threadIdx.x / LPR; row < N; row += RPP) {
+        const float4 v = *reinterpret_cast<const float4*>(Xs + row * LD + cq);
+        float4 d; float rstd;
+        ln_stats<LPR>(v, d, rstd);
+        *reinterpret_cast<float4*>(Gs + row * LD + cq) = f4add(f4mul(f4scale(d, rstd), gam), bet);
+      }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int j0 = ch * HC;
+      gemm_phase<C, TTBof<C>::v, false, LAY_TOK>(w.w1 + (size_t)j0 * C, C, HC, Gs, LD, N >> 4,
+                                                 [&](int row0, int tok, f32x4 a) {
+        *reinterpret_cast<float4*>(Us + tok * LDU + row0) =
+            f4add(tofloat4(a), *reinterpret_cast<const float4*>(w.b1 + j0 + row0));
+      });
+      __syncthreads();
+      if (upre_out) copy_out(upre_out + (size_t)win * N * 4 * C + j0, 4 * C, Us, LDU, N, HC);
+      if (le && ch == 0) {
+        for (int i = threadIdx.x; i < N + 2; i += blockDim.x)
+          A0[i] = (i == 0 || i == N + 1) ? 0.f : gelu_f(Us[(i - 1) * LDU]);
+        __syncthreads();
+      }
+      for (int i = threadIdx.x; i < N * (HC / 4); i += blockDim.x) {
+        const int row = i / (HC / 4), q = i - row * (HC / 4);
+        float4* pu = reinterpret_cast<float4*>(Us + row * LDU + 4 * q);
+        float4 a = *pu;
+        a.x = gelu_f(a.x); a.y = gelu_f(a.y); a.z = gelu_f(a.z); a.w = gelu_f(a.w);
+        if (le) {
+          if (ch == 0 && q == 0) a.x = lw0 * A0[row] + lw1 * A0[row + 1] + lw2 * A0[row + 2];
+          a.x = gelu_f(a.x); a.y = gelu_f(a.y); a.z = gelu_f(a.z); a.w = gelu_f(a.w);
+        }
+        *pu = a;
+      }
+      __syncthreads();
+      gemm_phase<HC, TTBof<C>::v, false, LAY_TOK>(w.w2 + j0, 4 * C, C, Us, LDU, N >> 4,
+                                                  [&](int row0, int tok, f32x4 a) {
+        float4* px = reinterpret_cast<float4*>(Xs + tok * LD + row0);
+        float4 v = f4add(*px, tofloat4(a));
+        if (ch == 0) v = f4add(v, *reinterpret_cast<const float4*>(w.b2 + row0));
+        *px = v;
+      });
+      __syncthreads();
+    }
+    copy_out(x2_out + wo, C, Xs, LD, N, C);
+    __syncthreads();
+  }
+}
+
+// =================================================================================
+// PatchMerging  : (N, C) viewed as (N/2, 2C) -> LN(2C) -> Linear(2C, 2C, no bias)
+// PatchSeparate : rows [x[:, :C/2] ; x[:, C/2:]] (2N, C/2) -> LN -> Linear (+ skip)
+// D = feature width of the LayerNorm / Linear; T = output tokens per window.
+// =================================================================================
+template <int D, bool SEP>
+__global__ __launch_bounds__(256) void k_resample_fwd(const float* __restrict__ x, const float* __restrict__ wred,
+                                                      const float* __restrict__ lnw, const float* __restrict__ lnb,
+                                                      const float* __restrict__ skip, float* __restrict__ y,
+                                                      int T, int B) {
+  extern __shared__ float4 smem4[];
+  float* Hs = reinterpret_cast<float*>(smem4);
+  constexpr int LD = D + 4, LPR = D / 4, RPP = 256 / LPR;
+  const int cq = (threadIdx.x % LPR) * 4;
+  const float4 gam = *reinterpret_cast<const float4*>(lnw + cq);
+  const float4 bet = *reinterpret_cast<const float4*>(lnb + cq);
+  for (int win = blockIdx.x; win < B; win += gridDim.x) {
+    const float* xw = x + (size_t)win * T * D;
+    for (int row = threadIdx.x / LPR; row < T; row += RPP) {
+      // SEP: out token t = c1*(T/2) + l  reads  x[l][c1*D + :D] of the (T/2, 2D) input
+      const float* src = SEP ? xw + (size_t)(row % (T / 2)) * 2 * D + (row / (T / 2)) * D : xw + (size_t)row * D;
+      const float4 v = *reinterpret_cast<const float4*>(src + cq);
+      float4 d; float rstd;
+      ln_stats<LPR>(v, d, rstd);
+      *reinterpret_cast<float4*>(Hs + row * LD + cq) = f4add(f4mul(f4scale(d, rstd), gam), bet);
+    }
+    __syncthreads();
+    float* yw = y + (size_t)win * T * D;
+    const float* sw = skip ? skip + (size_t)win * T * D : nullptr;
+    gemm_phase<D, TTBof<D>::v, false, LAY_TOK>(wred, D, D, Hs, LD, T >> 4, [&](int row0, int tok, f32x4 a) {
+      float4 v = tofloat4(a);
+      if (sw) v = f4add(v, *reinterpret_cast<const float4*>(sw + (size_t)tok * D + row0));
+      *reinterpret_cast<float4*>(yw + (size_t)tok * D + row0) = v;
+    });
+    __syncthreads();
+  }
+}
+
+// y = a + b (flat), used for x_mid = transformer(x4) + x4
+__global__ void k_add(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+    reinterpret_cast<float4*>(y)[i] = f4add(reinterpret_cast<const float4*>(a)[i], reinterpret_cast<const float4*>(b)[i]);
+}
+
+// =================================================================================
+// host launchers
+// =================================================================================
+static inline int grid_for(int items) { return items < 4096 ? items : 4096; }
+
+void launch_qkv_fwd(int C, const float* x, const float* pe, const BlockP& w, float* qkv, int N, int B, hipStream_t s) {
+  const size_t lds = (size_t)N * (C + 4) * sizeof(float);
+  switch (C) {
+#define CASE(c) case c: k_qkv_fwd<c><<<grid_for(B), 256, lds, s>>>(x, pe, w, qkv, N, B); break;
+    CASE(8) CASE(16) CASE(32) CASE(64) CASE(128)
+#undef CASE
+  }
+}
+
+size_t attn_fwd_lds(int N, int HG, int Len) { return ((size_t)3 * HG * N * 4 + (size_t)(2 * Len - 1) * HG + 4) * sizeof(float); }
+
+void launch_attn_fwd(const float* qkv, float* o_hm, float* lse, const float* table, int N, int H, int HG, int Len,
+                     int B, hipStream_t s) {
+  const size_t lds = attn_fwd_lds(N, HG, Len);
+  const int items = B * (H / HG);
+  if (N % 32 == 0)
+    k_attn_fwd<2><<<grid_for(items), 512, lds, s>>>(qkv, o_hm, lse, table, N, H, HG, Len, B);
+  else
+    k_attn_fwd<1><<<grid_for(items), 512, lds, s>>>(qkv, o_hm, lse, table, N, H, HG, Len, B);
+}
+
+size_t mlp_fwd_lds(int C, int N, int nch) {
+  return ((size_t)2 * N * (C + 4) + (size_t)N * (4 * C / nch + 4) + N + 2 + 2) * sizeof(float);
+}
+
+template <int C>
+static void launch_mlp_fwd_c(int nch, const float* x, const float* o, const BlockP& w, float* x1, float* upre,
+                             float* x2, int N, int B, hipStream_t s) {
+  const size_t lds = mlp_fwd_lds(C, N, nch);
+  if (nch == 1) k_mlp_fwd<C, 1><<<grid_for(B), 512, lds, s>>>(x, o, w, x1, upre, x2, N, B);
+  else if (nch == 2) k_mlp_fwd<C, 2><<<grid_for(B), 512, lds, s>>>(x, o, w, x1, upre, x2, N, B);
+  else k_mlp_fwd<C, 4><<<grid_for(B), 512, lds, s>>>(x, o, w, x1, upre, x2, N, B);
+}
+
+void launch_mlp_fwd(int C, int nch, const float* x, const float* o, const BlockP& w, float* x1, float* upre,
+                    float* x2, int N, int B, hipStream_t s) {
+  switch (C) {
+#define CASE(c) case c: launch_mlp_fwd_c<c>(nch, x, o, w, x1, upre, x2, N, B, s); break;
+    CASE(8) CASE(16) CASE(32) CASE(64) CASE(128)
+#undef CASE
+  }
+}
+
+void launch_resample_fwd(int D, bool sep, const float* x, const float* wred, const float* lnw, const float* lnb,
+                         const float* skip, float* y, int T, int B, hipStream_t s) {
+  const size_t lds = (size_t)T * (D + 4) * sizeof(float);
+#define CASE(d) case d: if (sep) k_resample_fwd<d, true><<<grid_for(B), 256, lds, s>>>(x, wred, lnw, lnb, skip, y, T, B); \
+                        else k_resample_fwd<d, false><<<grid_for(B), 256, lds, s>>>(x, wred, lnw, lnb, skip, y, T, B); break;
+  switch (D) { CASE(8) CASE(16) CASE(32) CASE(64) CASE(128) CASE(256) }
+#undef CASE
+}
+
+void launch_add(const float* a, const float* b, float* y, size_t n, hipStream_t s) {
+  const size_t n4 = n / 4;
+  k_add<<<(int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192), 256, 0, s>>>(a, b, y, n4);
+}

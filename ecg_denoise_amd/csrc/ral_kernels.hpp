@@ -1,0 +1,69 @@
+// Host-side launch interface of the RA-LENet / U-Net kernels (internal to libralenet).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include "ral_device.hpp"
+
+// gfx950 has 160 KB of LDS per CU; dynamic LDS above 64 KB must be opted into per kernel.
+#define RAL_SET_LDS(kernel, bytes)                                                                     \
+  do {                                                                                                 \
+    static size_t ral_cur_ = 0;                                                                        \
+    if ((size_t)(bytes) > ral_cur_) {                                                                  \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),                                 \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes));             \
+      ral_cur_ = (size_t)(bytes);                                                                      \
+    }                                                                                                  \
+  } while (0)
+
+// ---- forward (ral_fwd.hip)
+void launch_qkv_fwd(int C, const float* x, const float* pe, const BlockP& w, float* qkv, int N, int B, hipStream_t s);
+size_t attn_fwd_lds(int N, int HG, int Len);
+void launch_attn_fwd(const float* qkv, float* o_hm, float* lse, const float* table, int N, int H, int HG, int Len,
+                     int B, hipStream_t s);
+size_t mlp_fwd_lds(int C, int N, int nch);
+void launch_mlp_fwd(int C, int nch, const float* x, const float* o, const BlockP& w, float* x1, float* upre,
+                    float* x2, int N, int B, hipStream_t s);
+void launch_resample_fwd(int D, bool sep, const float* x, const float* wred, const float* lnw, const float* lnb,
+                         const float* skip, float* y, int T, int B, hipStream_t s);
+void launch_add(const float* a, const float* b, float* y, size_t n, hipStream_t s);
+
+// ---- stem / head / loss / optimiser (ral_misc.hip)
+void launch_conv1_fwd(int leads, int mode, const float* x, const float* w, const float* b, float* out, double* stats,
+                      const float* bnw, const float* bnb, const float* rmean, const float* rvar, int L, int B,
+                      hipStream_t s);
+void launch_bn_finalize(const double* stats, double count, const float* bnw, const float* bnb, float* ss,
+                        float* rmean, float* rvar, int nch, int update_running, hipStream_t s);
+void launch_bn_apply8(const float* a0, const float* ss, float* x0, size_t ntok, hipStream_t s);
+void launch_final_fwd(int leads, const float* u0, const float* x0, const float* w, const float* b, float* y, int L,
+                      int B, hipStream_t s);
+void launch_loss(const float* pred, const float* target, float* dy, float* snr, float* rmse, double* loss_sum,
+                 int n, int B, float gscale, hipStream_t s);
+void launch_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
+                 int step, float gscale, hipStream_t s);
+
+// ---- backward (ral_bwd.hip)
+size_t mlp_bwd_lds(int C, int N, int nch);
+void launch_mlp_bwd(int C, int nch, const float* dx2, const float* x1, const float* upre, const BlockP& w,
+                    const BlockP& gr, float* dupre, float* dx1, float* do_hm, int N, int B, hipStream_t s);
+size_t attn_bwd_lds(int N, int HG, int Len);
+void launch_attn_bwd(const float* qkv, const float* o_hm, const float* do_hm, const float* lse, const float* table,
+                     float* gtable, float* dqkv, int N, int H, int HG, int Len, int B, hipStream_t s);
+size_t qkv_bwd_lds(int C, int N);
+void launch_qkv_bwd(int C, const float* dqkv, const float* x, const float* pe, const float* dx1, const float* extra,
+                    const BlockP& w, const BlockP& gr, float* dx, int N, int B, hipStream_t s);
+void launch_resample_bwd(int D, bool sep, const float* dy, const float* x, const float* wred, const float* lnw,
+                         float* g_lnw, float* g_lnb, float* dx, int T, int B, hipStream_t s);
+void launch_final_bwd(int leads, const float* dy, const float* u0, const float* x0, const float* w, float* gw,
+                      float* gb, float* dz, int L, int B, hipStream_t s);
+void launch_bn8_bwd_stats(const float* dy, const float* a0, const float* ss, double* out, size_t ntok, hipStream_t s);
+void launch_conv1_bwd(int leads, const float* dy, const float* a0, const float* x, const float* ss, const float* bnw,
+                      const double* bst, double count, float* gw, float* gb, float* dz, int L, int B, hipStream_t s);
+void launch_bn_affine_grads(const double* bst, float* gw, float* gb, int nch, hipStream_t s);
+void launch_conv1_bwd_dx(int leads, const float* dz, const float* w, float* dx, int L, int B, hipStream_t s);
+
+// ---- weight gradients (ral_dw.hip)
+void launch_block_dw(int C, const float* dx2, const float* upre, const float* dupre, const float* x1,
+                     const float* dx1, const float* o_hm, const float* dqkv, const float* x, const float* pe,
+                     const BlockP& w, const BlockP& gr, int N, int B, int ksplit, hipStream_t s);
+void launch_resample_dw(int D, bool sep, const float* dy, const float* x, const float* lnw, const float* lnb,
+                        float* dW, int T, int B, int ksplit, hipStream_t s);

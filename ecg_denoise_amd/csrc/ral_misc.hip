@@ -1,0 +1,264 @@
+// HBM-bound kernels around the transformer stack: conv stem (+LeakyReLU +BatchNorm),
+// output conv, loss/SNR/RMSE reduction, fused flat Adam.  (gfx950)
+//
+// Reference behaviour: model/raletransformer.py:568-572, 636, 676-678;
+// local_utils/evaluate.py:10-51; denoise_train.py:24,53 (Adam lr 1e-3, mse mean).
+#include "ral_device.hpp"
+#include "ral_kernels.hpp"
+
+// block-wide sum of NV per-thread values -> double atomics into out[0..NV)
+template <int NV>
+RAL_DEV void block_atomic_sums(const float (&v)[NV], double* __restrict__ out, double* red /* LDS NV*nwaves */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float s = group_sum<64>(v[i]);
+    if (lane == 0) red[wave * NV + i] = (double)s;
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    double t = 0.0;
+    for (int w = 0; w < nw; ++w) t += red[w * NV + threadIdx.x];
+    atomicAdd(out + threadIdx.x, t);
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------
+// conv1: Conv1d(leads, 8, k3, p1) + LeakyReLU(0.2) -> a0 (B, L, 8) token-major.
+// MODE 0: training, also accumulates per-channel sum / sum of squares (double).
+// MODE 1: eval, applies BatchNorm with the running statistics and writes x0 directly.
+// ---------------------------------------------------------------------------------
+template <int LEADS, int MODE>
+__global__ __launch_bounds__(256) void k_conv1_fwd(const float* __restrict__ x, const float* __restrict__ w,
+                                                   const float* __restrict__ bias, float* __restrict__ out,
+                                                   double* __restrict__ stats, const float* __restrict__ bnw,
+                                                   const float* __restrict__ bnb, const float* __restrict__ rmean,
+                                                   const float* __restrict__ rvar, int L, int B) {
+  __shared__ double red[16 * 4];
+  float wr[8][LEADS][3], br[8];
+#pragma unroll
+  for (int o = 0; o < 8; ++o) {
+    br[o] = bias[o];
+#pragma unroll
+    for (int c = 0; c < LEADS; ++c)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) wr[o][c][k] = w[(o * LEADS + c) * 3 + k];
+  }
+  float sc[8], sh[8];
+  if (MODE == 1) {
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+      sc[o] = bnw[o] / sqrtf(rvar[o] + 1e-5f);
+      sh[o] = bnb[o] - rmean[o] * sc[o];
+    }
+  }
+  float acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  const size_t total = (size_t)B * L;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / L), l = (int)(i - (size_t)b * L);
+    float xv[LEADS][3];
+#pragma unroll
+    for (int c = 0; c < LEADS; ++c) {
+      const float* xr = x + ((size_t)b * LEADS + c) * L;
+      xv[c][0] = l > 0 ? xr[l - 1] : 0.f;
+      xv[c][1] = xr[l];
+      xv[c][2] = l < L - 1 ? xr[l + 1] : 0.f;
+    }
+    float y[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+      float a = br[o];
+#pragma unroll
+      for (int c = 0; c < LEADS; ++c)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) a = fmaf(wr[o][c][k], xv[c][k], a);
+      a = a > 0.f ? a : 0.2f * a;
+      if (MODE == 0) { acc[o] += a; acc[8 + o] += a * a; }
+      else a = a * sc[o] + sh[o];
+      y[o] = a;
+    }
+    float4* po = reinterpret_cast<float4*>(out + i * 8);
+    po[0] = make_float4(y[0], y[1], y[2], y[3]);
+    po[1] = make_float4(y[4], y[5], y[6], y[7]);
+  }
+  if (MODE == 0) block_atomic_sums<16>(acc, stats, red);
+}
+
+// BatchNorm (training) finalize: scale/shift from the (all-reduced) sums, running-stat update.
+// stats: [sum(8), sumsq(8)] double; ss: [scale(8), shift(8), mean(8), rstd(8)] float
+__global__ void k_bn_finalize(const double* __restrict__ stats, double count, const float* __restrict__ bnw,
+                              const float* __restrict__ bnb, float* __restrict__ ss, float* __restrict__ rmean,
+                              float* __restrict__ rvar, int nch, int update_running) {
+  const int c = threadIdx.x;
+  if (c >= nch) return;
+  const double mean = stats[c] / count;
+  double var = stats[nch + c] / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + 1e-5));
+  const float sc = bnw[c] * rstd;
+  ss[c] = sc;
+  ss[nch + c] = bnb[c] - (float)mean * sc;
+  ss[2 * nch + c] = (float)mean;
+  ss[3 * nch + c] = rstd;
+  if (update_running) {
+    rmean[c] = 0.9f * rmean[c] + 0.1f * (float)mean;
+    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    rvar[c] = 0.9f * rvar[c] + 0.1f * (float)unb;
+  }
+}
+
+// x0 = a0 * scale[c] + shift[c]   (token-major, 8 channels)
+__global__ void k_bn_apply8(const float* __restrict__ a0, const float* __restrict__ ss, float* __restrict__ x0,
+                            size_t ntok) {
+  const float4 s0 = *reinterpret_cast<const float4*>(ss), s1 = *reinterpret_cast<const float4*>(ss + 4);
+  const float4 h0 = *reinterpret_cast<const float4*>(ss + 8), h1 = *reinterpret_cast<const float4*>(ss + 12);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ntok * 2; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(a0)[i];
+    const bool hi = i & 1;
+    reinterpret_cast<float4*>(x0)[i] = f4add(f4mul(v, hi ? s1 : s0), hi ? h1 : h0);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// output stage: z = u0 + x0 (token-major, 8 ch); y = Conv1d(8, leads, k3, p1)(z^T)
+// ---------------------------------------------------------------------------------
+template <int LEADS>
+__global__ __launch_bounds__(256) void k_final_fwd(const float* __restrict__ u0, const float* __restrict__ x0,
+                                                   const float* __restrict__ w, const float* __restrict__ bias,
+                                                   float* __restrict__ y, int L, int B) {
+  float wr[LEADS][8][3];
+#pragma unroll
+  for (int o = 0; o < LEADS; ++o)
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) wr[o][c][k] = w[(o * 8 + c) * 3 + k];
+  const size_t total = (size_t)B * L;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / L), l = (int)(i - (size_t)b * L);
+    float acc[LEADS];
+#pragma unroll
+    for (int o = 0; o < LEADS; ++o) acc[o] = bias[o];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int ll = l + k - 1;
+      if (ll < 0 || ll >= L) continue;
+      const size_t t = (size_t)b * L + ll;
+      const float4 a0 = reinterpret_cast<const float4*>(u0)[t * 2], a1 = reinterpret_cast<const float4*>(u0)[t * 2 + 1];
+      const float4 b0 = reinterpret_cast<const float4*>(x0)[t * 2], b1 = reinterpret_cast<const float4*>(x0)[t * 2 + 1];
+      const float z[8] = {a0.x + b0.x, a0.y + b0.y, a0.z + b0.z, a0.w + b0.w,
+                          a1.x + b1.x, a1.y + b1.y, a1.z + b1.z, a1.w + b1.w};
+#pragma unroll
+      for (int o = 0; o < LEADS; ++o)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[o] = fmaf(wr[o][c][k], z[c], acc[o]);
+    }
+#pragma unroll
+    for (int o = 0; o < LEADS; ++o) y[((size_t)b * LEADS + o) * L + l] = acc[o];
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// loss + metrics: per window sse = sum (p-t)^2, sy2 = sum t^2 over leads*L
+//   snr = 10 log10(sy2/sse), rmse = sqrt(sse/n), dy = 2 (p-t) / (global_B * n)
+//   loss_sum += sse / n   (caller divides by the global batch)
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_loss(const float* __restrict__ pred, const float* __restrict__ target,
+                                              float* __restrict__ dy, float* __restrict__ snr,
+                                              float* __restrict__ rmse, double* __restrict__ loss_sum, int n,
+                                              float gscale) {
+  __shared__ double red[2 * 4];
+  const size_t base = (size_t)blockIdx.x * n;
+  float v[2] = {0.f, 0.f};
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float p = pred[base + i], t = target[base + i], d = p - t;
+    v[0] += d * d;
+    v[1] += t * t;
+    if (dy) dy[base + i] = d * gscale;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float s0 = group_sum<64>(v[0]), s1 = group_sum<64>(v[1]);
+  if (lane == 0) { red[wave * 2] = s0; red[wave * 2 + 1] = s1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double sse = 0, sy2 = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { sse += red[w * 2]; sy2 += red[w * 2 + 1]; }
+    const float mse = (float)(sse / n), my2 = (float)(sy2 / n);
+    if (snr) snr[blockIdx.x] = 10.0f * log10f(my2 / mse);
+    if (rmse) rmse[blockIdx.x] = sqrtf(mse);
+    if (loss_sum) atomicAdd(loss_sum, sse / n);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// fused flat Adam (torch.optim.Adam defaults, no weight decay / amsgrad)
+// ---------------------------------------------------------------------------------
+__global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                       float* __restrict__ v, size_t n4, float lr, float b1, float b2, float eps, float bc1,
+                       float sqrt_bc2, float gscale) {
+  const float step = lr / bc1;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 pp = reinterpret_cast<float4*>(p)[i];
+    const float4 gg = f4scale(reinterpret_cast<const float4*>(g)[i], gscale);
+    float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+#define UPD(f)                                              \
+    mm.f = b1 * mm.f + (1.f - b1) * gg.f;                   \
+    vv.f = b2 * vv.f + (1.f - b2) * gg.f * gg.f;            \
+    pp.f -= step * mm.f / (sqrtf(vv.f) / sqrt_bc2 + eps);
+    UPD(x) UPD(y) UPD(z) UPD(w)
+#undef UPD
+    reinterpret_cast<float4*>(p)[i] = pp;
+    reinterpret_cast<float4*>(m)[i] = mm;
+    reinterpret_cast<float4*>(v)[i] = vv;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+static inline int ew_grid(size_t n, int per = 256) {
+  size_t g = (n + per - 1) / per;
+  return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+void launch_conv1_fwd(int leads, int mode, const float* x, const float* w, const float* b, float* out, double* stats,
+                      const float* bnw, const float* bnb, const float* rmean, const float* rvar, int L, int B,
+                      hipStream_t s) {
+  const int grid = ew_grid((size_t)B * L);
+#define CASE(ld)                                                                                             \
+  case ld:                                                                                                   \
+    if (mode == 0) k_conv1_fwd<ld, 0><<<grid, 256, 0, s>>>(x, w, b, out, stats, bnw, bnb, rmean, rvar, L, B); \
+    else k_conv1_fwd<ld, 1><<<grid, 256, 0, s>>>(x, w, b, out, stats, bnw, bnb, rmean, rvar, L, B);           \
+    break;
+  switch (leads) { CASE(1) CASE(2) }
+#undef CASE
+}
+
+void launch_bn_finalize(const double* stats, double count, const float* bnw, const float* bnb, float* ss,
+                        float* rmean, float* rvar, int nch, int update_running, hipStream_t s) {
+  k_bn_finalize<<<1, 64, 0, s>>>(stats, count, bnw, bnb, ss, rmean, rvar, nch, update_running);
+}
+
+void launch_bn_apply8(const float* a0, const float* ss, float* x0, size_t ntok, hipStream_t s) {
+  k_bn_apply8<<<ew_grid(ntok * 2), 256, 0, s>>>(a0, ss, x0, ntok);
+}
+
+void launch_final_fwd(int leads, const float* u0, const float* x0, const float* w, const float* b, float* y, int L,
+                      int B, hipStream_t s) {
+  const int grid = ew_grid((size_t)B * L);
+  if (leads == 1) k_final_fwd<1><<<grid, 256, 0, s>>>(u0, x0, w, b, y, L, B);
+  else k_final_fwd<2><<<grid, 256, 0, s>>>(u0, x0, w, b, y, L, B);
+}
+
+void launch_loss(const float* pred, const float* target, float* dy, float* snr, float* rmse, double* loss_sum,
+                 int n, int B, float gscale, hipStream_t s) {
+  k_loss<<<B, 256, 0, s>>>(pred, target, dy, snr, rmse, loss_sum, n, gscale);
+}
+
+void launch_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
+                 int step, float gscale, hipStream_t s) {
+  const float bc1 = 1.0f - powf(b1, (float)step);
+  const float bc2 = 1.0f - powf(b2, (float)step);
+  k_adam<<<ew_grid(n / 4), 256, 0, s>>>(p, g, m, v, n / 4, lr, b1, b2, eps, bc1, sqrtf(bc2), gscale);
+}

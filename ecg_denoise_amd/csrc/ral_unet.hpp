@@ -1,0 +1,27 @@
+// U-Net baseline (model/UNet.py) — internal interface used by ral_api.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/ralenet.h"
+
+struct UNetModel;
+struct UNetPublic {  // leading members of UNetModel that ral_api.hip reads
+  ral_config cfg;
+  float *params, *grads, *am, *av, *state;
+  double* bn_sums;
+  int64_t nparam;
+};
+
+int unet_check_cfg(const ral_config* c, char* err, size_t cap);
+int unet_layout_count(const ral_config* c);
+int unet_layout_entry(const ral_config* c, int idx, char* name, int name_cap, int32_t* kind, int64_t* offset,
+                      int32_t* ndim, int64_t shape[4]);
+int64_t unet_param_floats(const ral_config* c);
+int64_t unet_state_floats(const ral_config* c);
+int64_t unet_workspace_bytes(const ral_config* c);
+UNetModel* unet_create(const ral_config* c, char* err, size_t cap);
+void unet_destroy(UNetModel* u);
+int unet_bind(UNetModel* u, float* params, float* grads, float* am, float* av, float* state, double* bn_sums);
+int unet_forward(UNetModel* u, const float* x, float* y, int B, int training, hipStream_t s, char* err, size_t cap);
+int unet_backward(UNetModel* u, const float* dy, float* dx, int B, hipStream_t s, char* err, size_t cap);
+UNetPublic* unet_public(UNetModel* u);

@@ -1,0 +1,282 @@
+"""Host-side mirror of the reference's model boundary.
+
+`RALENet` / `UNet` duck-type the nn.Module surface that `denoise_train.train` uses
+(`model(x)`, `.parameters()`, `.train()/.eval()`, `.state_dict()/.load_state_dict()`,
+reference: denoise_train.py:20-24,44,52,66,72,93; main.py:63-77) on top of
+libralenet.so.  PyTorch is used only as the owner of device memory and streams: every
+tensor handed to the library is a raw device pointer, all arithmetic is HIP.
+"""
+import ctypes as C
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib
+
+RW_LEN = (32, 16, 8, 4)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _Engine:
+    """One libralenet handle + the caller-owned flat buffers."""
+
+    def __init__(self, variant, leads, L, max_batch, train, device):
+        self.variant, self.leads, self.L = variant, int(leads), int(L)
+        self.max_batch, self.trainable = int(max_batch), bool(train)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.RalError("the RA-LENet path runs on a HIP device only (no CPU fallback)")
+        self.cfg = _lib.make_config(variant, leads, L, max_batch, train)
+        self.entries = _lib.layout(self.cfg)
+        L_ = _lib.lib()
+        self.nparam = L_.ral_param_floats(C.byref(self.cfg))
+        self.nstate = L_.ral_state_floats(C.byref(self.cfg))
+        with torch.cuda.device(self.device):
+            z = lambda n, dt=torch.float32: torch.zeros(n, dtype=dt, device=self.device)
+            self.params = z(self.nparam)
+            self.state = z(self.nstate)
+            self.grads = z(self.nparam) if train else None
+            self.adam_m = z(self.nparam) if train else None
+            self.adam_v = z(self.nparam) if train else None
+            self.bn_sums = z(64 * max(1, self.nstate // 16), torch.float64) if train else None
+            h = C.c_void_p()
+            _lib.check(L_.ral_create(C.byref(self.cfg), C.byref(h)))
+            self.h = h
+            _lib.check(L_.ral_bind(h, _ptr(self.params), _ptr(self.grads), _ptr(self.adam_m), _ptr(self.adam_v),
+                                   _ptr(self.state), _ptr(self.bn_sums)))
+        self.counters = {e["name"]: 0 for e in self.entries if e["kind"] == _lib.KIND_COUNTER}
+
+    def __del__(self):
+        h = getattr(self, "h", None)
+        if h and _lib is not None and getattr(_lib, "_lib", None) is not None:
+            try:
+                _lib._lib.ral_destroy(h)
+            except Exception:
+                pass
+            self.h = None
+
+    def view(self, buf, e):
+        n = int(np.prod(e["shape"])) if e["shape"] else 1
+        return buf[e["offset"]:e["offset"] + n].view(e["shape"])
+
+
+class _ModuleBase:
+    VARIANT = None
+
+    def __init__(self, variant, leads=2, L=512, max_batch=32, train=True, device="cuda:0", seed=None):
+        self.eng = _Engine(variant, leads, L, max_batch, train, device)
+        self.training = bool(train)
+        self.step_count = 0
+        self._dy = None
+        self._loss_sum = None
+        self.reset_parameters(seed)
+
+    # ---- nn.Module surface ------------------------------------------------------
+    def train(self, mode=True):
+        if mode and not self.eng.trainable:
+            raise _lib.RalError("model was created with train=False")
+        self.training = bool(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def cuda(self, device=None):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def named_parameters(self):
+        for e in self.eng.entries:
+            if e["kind"] == _lib.KIND_PARAM:
+                yield e["name"], self.eng.view(self.eng.params, e)
+
+    def parameters(self):
+        return [p for _, p in self.named_parameters()]
+
+    def named_grads(self):
+        return OrderedDict((e["name"], self.eng.view(self.eng.grads, e)) for e in self.eng.entries
+                           if e["kind"] == _lib.KIND_PARAM)
+
+    def num_parameters(self):
+        return sum(int(np.prod(e["shape"])) for e in self.eng.entries if e["kind"] == _lib.KIND_PARAM)
+
+    def state_dict(self):
+        """Reference checkpoint contract: same keys, shapes and dtypes, same order."""
+        sd = OrderedDict()
+        for e in self.eng.entries:
+            k = e["kind"]
+            if k == _lib.KIND_PARAM:
+                sd[e["name"]] = self.eng.view(self.eng.params, e).detach().clone()
+            elif k == _lib.KIND_STATE:
+                sd[e["name"]] = self.eng.view(self.eng.state, e).detach().clone()
+            elif k == _lib.KIND_COUNTER:
+                sd[e["name"]] = torch.tensor(self.eng.counters[e["name"]], dtype=torch.int64)
+            else:  # relative_position_index (transformer.py:517-529): i - j + Len - 1
+                n = e["shape"][0]
+                i = torch.arange(n)
+                sd[e["name"]] = (i[:, None] - i[None, :] + n - 1).to(torch.int64)
+        return sd
+
+    def load_state_dict(self, sd, strict=True):
+        missing, unexpected = [], [k for k in sd if k not in {e["name"] for e in self.eng.entries}]
+        for e in self.eng.entries:
+            if e["name"] not in sd:
+                if e["kind"] in (_lib.KIND_PARAM, _lib.KIND_STATE):
+                    missing.append(e["name"])
+                continue
+            v = sd[e["name"]]
+            if e["kind"] == _lib.KIND_PARAM or e["kind"] == _lib.KIND_STATE:
+                buf = self.eng.params if e["kind"] == _lib.KIND_PARAM else self.eng.state
+                dst = self.eng.view(buf, e)
+                v = torch.as_tensor(v)
+                if tuple(v.shape) != tuple(dst.shape):
+                    raise _lib.RalError(f"size mismatch for {e['name']}: {tuple(v.shape)} vs {tuple(dst.shape)}")
+                dst.copy_(v.to(dtype=torch.float32, device=dst.device))
+            elif e["kind"] == _lib.KIND_COUNTER:
+                self.eng.counters[e["name"]] = int(v)
+        if strict and (missing or unexpected):
+            raise _lib.RalError(f"load_state_dict: missing {missing}, unexpected {unexpected}")
+        return missing, unexpected
+
+    def reset_parameters(self, seed=None):
+        """PyTorch default initialisation (nothing is re-initialised by the reference):
+        Linear/Conv weight and bias ~ U(+-1/sqrt(fan_in)); norm weight 1, bias 0; running stats 0/1;
+        R-wave tables 0."""
+        rng = np.random.default_rng(seed)
+        host = np.zeros(self.eng.nparam, dtype=np.float32)
+        fan = None
+        for e in self.eng.entries:
+            if e["kind"] != _lib.KIND_PARAM:
+                continue
+            shp, name = e["shape"], e["name"]
+            n = int(np.prod(shp))
+            if "relative_position_bias_table" in name:
+                a = np.zeros(n)
+            elif len(shp) == 1 and (".norm" in name or ".bn." in name or name.startswith("conv1.2.")
+                                    or name.startswith("bottleneck.2.") or name.startswith("bottleneck.5.")):
+                a = np.ones(n) if name.endswith("weight") else np.zeros(n)
+            elif len(shp) >= 2:
+                fan = int(np.prod(shp[1:]))
+                a = rng.uniform(-1 / math.sqrt(fan), 1 / math.sqrt(fan), n)
+            else:
+                b = 1 / math.sqrt(fan) if fan else 0.1
+                a = rng.uniform(-b, b, n)
+            host[e["offset"]:e["offset"] + n] = a
+        self.eng.params.copy_(torch.from_numpy(host))
+        st = np.zeros(self.eng.nstate, dtype=np.float32)
+        for e in self.eng.entries:
+            if e["kind"] == _lib.KIND_STATE and e["name"].endswith("running_var"):
+                st[e["offset"]:e["offset"] + int(np.prod(e["shape"]))] = 1.0
+        self.eng.state.copy_(torch.from_numpy(st))
+        for k in self.eng.counters:
+            self.eng.counters[k] = 0
+
+    # ---- hot path -----------------------------------------------------------------
+    def _check_x(self, x):
+        e = self.eng
+        if x.dim() != 3 or x.shape[1] != e.leads or x.shape[2] != e.L:
+            raise _lib.RalError(f"expected input (B, {e.leads}, {e.L}), got {tuple(x.shape)}")
+        if x.shape[0] > e.max_batch:
+            raise _lib.RalError(f"batch {x.shape[0]} > max_batch {e.max_batch}")
+        if x.dtype != torch.float32 or not x.is_cuda:
+            raise _lib.RalError("input must be a float32 HIP tensor")
+        return x.contiguous()
+
+    def forward(self, x):
+        x = self._check_x(x)
+        y = torch.empty_like(x)
+        self._x = x  # keep alive for backward (the stem gradient re-reads it)
+        _lib.check(_lib.lib().ral_forward(self.eng.h, _ptr(x), _ptr(y), x.shape[0], int(self.training), _stream()))
+        if self.training:
+            for k in self.eng.counters:
+                self.eng.counters[k] += 1
+        return y
+
+    __call__ = forward
+
+    def loss_and_metrics(self, pred, target, want_grad=True, global_windows=None):
+        """F.mse_loss(pred, target), SNR(target, pred), RMSE(target, pred) of denoise_train.py:53,58-59
+        in one pass; keeps d loss / d pred for `backward()`."""
+        B = pred.shape[0]
+        gw = int(global_windows or B)
+        target = target.contiguous()
+        snr = torch.empty(B, dtype=torch.float32, device=pred.device)
+        rmse = torch.empty_like(snr)
+        loss_sum = torch.zeros(1, dtype=torch.float64, device=pred.device)
+        dy = torch.empty_like(pred) if want_grad else None
+        _lib.check(_lib.lib().ral_loss(self.eng.h, _ptr(pred), _ptr(target), B, gw, _ptr(dy), _ptr(snr), _ptr(rmse),
+                                       _ptr(loss_sum), _stream()))
+        self._dy = dy
+        return loss_sum / gw, snr, rmse
+
+    def backward(self, dy=None, want_dx=False):
+        dy = self._dy if dy is None else dy.contiguous()
+        dx = torch.empty_like(dy) if want_dx else None
+        _lib.check(_lib.lib().ral_backward(self.eng.h, _ptr(dy), _ptr(dx), dy.shape[0], _stream()))
+        return dx
+
+    def zero_grad(self):
+        pass  # ral_backward zeroes the flat gradient buffer itself
+
+    def step(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
+        """torch.optim.Adam(lr=1e-3) of denoise_train.py:24 as one fused flat kernel."""
+        self.step_count += 1
+        _lib.check(_lib.lib().ral_adam_step(self.eng.h, lr, betas[0], betas[1], eps, self.step_count, grad_scale,
+                                            _stream()))
+
+    def train_step(self, x, target, lr=1e-3):
+        """zero_grad -> forward -> mse -> backward -> Adam (denoise_train.py:51-57)."""
+        pred = self.forward(x)
+        loss, snr, rmse = self.loss_and_metrics(pred, target)
+        self.backward()
+        self.step(lr)
+        return {"loss": loss, "pred": pred, "snr": snr, "rmse": rmse}
+
+    def debug_tensor(self, name):
+        p, n = C.c_void_p(), C.c_int64()
+        _lib.check(_lib.lib().ral_debug_tensor(self.eng.h, name.encode(), C.byref(p), C.byref(n)))
+        out = torch.empty(n.value, dtype=torch.float32, device=self.eng.device)
+        torch.cuda.synchronize()
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        rc = hip.hipMemcpy(C.c_void_p(out.data_ptr()), p, n.value * 4, 3)  # hipMemcpyDeviceToDevice
+        if rc != 0:
+            raise _lib.RalError(f"hipMemcpy failed ({rc})")
+        return out
+
+
+class RALENet(_ModuleBase):
+    """variant: "nra" = model/raletransformer.py::ralenet(), "full" =
+    model/transformer.py::ralenet(high_level_enhence=True), "mlp" = ...(low_level_enhence=False)
+    (main.py:69-77), generalised to `leads` in {1,2} and `L` in {256,512,768,1024} the way
+    SURVEY §8c states (R-wave window stays centred, Len constants unchanged)."""
+
+    def __init__(self, variant="full", leads=2, L=512, max_batch=32, train=True, device="cuda:0", seed=None):
+        if variant not in ("nra", "full", "mlp"):
+            raise _lib.RalError(f"unknown RA-LENet variant {variant!r}")
+        super().__init__(variant, leads, L, max_batch, train, device, seed)
+
+
+def ralenet(high_level_enhence=False, low_level_enhence=True, **kw):
+    """Constructor spelled like model/transformer.py::ralenet (main.py:71-77)."""
+    return RALENet("full" if high_level_enhence else "mlp", **kw)
+
+
+def pe_table_host(L, level, leads=2, variant="full"):
+    cfg = _lib.make_config(variant, leads, L, 1, 0)
+    C_ = 8 << level
+    n = L >> level
+    out = np.empty((n, C_), dtype=np.float32)
+    _lib.check(_lib.lib().ral_pe_table(C.byref(cfg), level, out.ctypes.data_as(C.c_void_p), out.size))
+    return out
