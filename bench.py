@@ -1,0 +1,182 @@
+"""Headline benchmark: RA-LENet training-step throughput (ECG windows/s) on MI355X.
+
+    python bench.py [--gpus N --steps K --warmup W]            (N>1: launched by torch.distributed.run)
+
+One "step" = zero_grad -> forward -> mse/SNR/RMSE -> backward -> (all-reduce) -> Adam on one batch of
+synthetic 512-sample windows already resident in HBM.  Prints ONE JSON line (rank 0).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CH = [8, 16, 32, 64, 128]
+BLOCKS_PER_LEVEL = [2, 4, 4, 4, 4]
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TF = 157.3     # fp32-input MFMA peak (the dtype every contraction here runs in)
+VALU_F32_PEAK_TF = 157.3
+
+
+def kind_work(kind, L, B):
+    """Algorithmic FLOPs of all launches of one kernel kind in a train step."""
+    fl = 0.0
+    for lvl, nb in enumerate(BLOCKS_PER_LEVEL):
+        N, Cc = L >> lvl, CH[lvl]
+        if kind == "attn_fwd":
+            fl += nb * 4.0 * N * N * Cc * B                 # QK^T + PV, mul+add
+        elif kind == "attn_bwd":
+            fl += nb * 2.5 * 4.0 * N * N * Cc * B           # S, dP, dV, dK, dQ: 5 products (S, dP counted once)
+        elif kind == "mlp_fwd":
+            fl += nb * 2.0 * N * Cc * Cc * 9 * B            # proj C*C + fc1 4C*C + fc2 4C*C
+        elif kind == "mlp_bwd":
+            fl += nb * 2.0 * N * Cc * Cc * 9 * B
+        elif kind == "qkv_fwd" or kind == "qkv_bwd":
+            fl += nb * 2.0 * N * Cc * Cc * 3 * B
+        elif kind == "dw":
+            fl += nb * 2.0 * N * Cc * Cc * 12 * B
+    return fl
+
+
+def cpu_baseline(leads, L, variant):
+    """The oracle (CPU restatement of the reference op graph, parity-pinned by tests/golden) timed on the
+    host cores of this box on a bounded sample: batch 32 (the reference's own batch, BASELINE config 0)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from collections import OrderedDict
+    import torch
+    import ralenet_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    B = 32
+    p = O.init_params(O.ralenet_param_shapes(variant, leads), 1)
+    g = torch.Generator().manual_seed(2023)
+    x = torch.randn(B, leads, L, generator=g); tgt = torch.randn(B, leads, L, generator=g)
+    m = OrderedDict((k, torch.zeros_like(v)) for k, v in p.items())
+    v = OrderedDict((k, torch.zeros_like(t)) for k, t in p.items())
+    bn = O.new_bn_state()
+    fwd = lambda pp, xx: O.ralenet_forward(pp, xx, variant, True, bn)
+    O.train_step(p, x, tgt, fwd, m, v, 1)
+    n, t0 = 0, time.time()
+    while n < 5 or time.time() - t0 < 8.0:
+        O.train_step(p, x, tgt, fwd, m, v, n + 2)
+        n += 1
+        if time.time() - t0 > 25.0:
+            break
+    dt = time.time() - t0
+    return {"value": round(B * n / dt, 2), "unit": "windows/s", "cores": cores, "kind": "port",
+            "sample": f"{n} train steps of the CPU oracle at batch {B} x {leads} x {L} fp32 "
+                      f"(torch-CPU op graph of the reference, {cores} threads)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=2048, help="windows per GPU")
+    ap.add_argument("--leads", type=int, default=1)
+    ap.add_argument("--L", type=int, default=512)
+    ap.add_argument("--variant", default="full")
+    ap.add_argument("--kind", default="attn_bwd", help="kernel kind timed for the roofline object")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--infer", action="store_true", help="also time the inference forward")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from ecg_denoise_amd import RALENet, _lib
+    from ecg_denoise_amd.dp import DataParallelTrainer, HipEngineAdapter
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} needs WORLD_SIZE={a.gpus} (launch with torch.distributed.run)")
+    torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    B = a.batch
+    model = RALENet(a.variant, leads=a.leads, L=a.L, max_batch=B, train=True, device=dev, seed=2023)
+    g = torch.Generator().manual_seed(2023 + rank)
+    x = torch.randn(B, a.leads, a.L, generator=g).to(dev)
+    tgt = torch.randn(B, a.leads, a.L, generator=g).to(dev)
+    trainer = DataParallelTrainer(HipEngineAdapter(model))
+    model.train()
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        trainer.train_step(x, tgt)
+    sync()
+    lib = _lib.lib()
+    _lib.check(lib.ral_profile_select(model.eng.h, a.kind.encode()))
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = trainer.train_step(x, tgt)
+    sync()
+    dt = time.perf_counter() - t0
+    ms, cnt = C.c_double(), C.c_int64()
+    _lib.check(lib.ral_profile_read(model.eng.h, C.byref(ms), C.byref(cnt)))
+    _lib.check(lib.ral_profile_select(model.eng.h, b""))
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = tmax.item()
+    loss = out["loss"].item()
+
+    infer = None
+    if a.infer:
+        model.eval()
+        with torch.no_grad():
+            for _ in range(2):
+                model(x)
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                model(x)
+            sync()
+            infer = B * world * a.steps / (time.perf_counter() - t1)
+
+    if rank == 0:
+        ksec = ms.value * 1e-3
+        flops = kind_work(a.kind, a.L, B) * a.steps
+        ach = flops / ksec / 1e12 if ksec > 0 else 0.0
+        peak = VALU_F32_PEAK_TF if a.kind.startswith("attn") else MFMA_F32_PEAK_TF
+        res = {
+            "metric": "ECG windows/sec (512-sample, bs2048) train",
+            "value": round(B * world * a.steps / dt, 1), "unit": "windows/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"RA-LENet '{a.variant}' train step (fwd+mse/SNR/RMSE+bwd+Adam), "
+                                   f"{a.leads}-lead {a.L}-sample windows, batch {B}/GPU, "
+                                   f"N(0,1) inputs seed 2023, random-init weights",
+                       "global_batch": B * world, "parallelism": f"dp{world}", "sync_bn": True},
+            "final_loss": round(loss, 6),
+            "roofline": {"bound": "mfma", "kernel": a.kind, "achieved": round(ach, 3), "peak": peak,
+                         "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                         "launches": int(cnt.value), "avg_launch_ms": round(ms.value / max(cnt.value, 1), 4),
+                         "share_of_step": round(ksec / dt, 4)},
+        }
+        if infer is not None:
+            res["infer_windows_per_s"] = round(infer, 1)
+        if world == 1 and not a.no_cpu:
+            res["cpu_baseline"] = cpu_baseline(a.leads, a.L, a.variant)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

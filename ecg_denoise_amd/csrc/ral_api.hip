@@ -204,6 +204,33 @@ struct RalModel {
   const float* last_x = nullptr;
   int last_B = 0;
   int nch_f[5], nch_b[5], hg_f[5], hg_b[5];
+  // optional in-library kernel timing (bench.py roofline leg): hipEvent pairs around the
+  // launches of ONE selected kernel kind, on the stream the kernels run on
+  int prof_kind = -1;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
+  size_t prof_used = 0;
+};
+
+enum { K_QKV_FWD = 0, K_ATTN_FWD, K_MLP_FWD, K_MLP_BWD, K_ATTN_BWD, K_QKV_BWD, K_DW, K_RES_FWD, K_RES_BWD, K_STEM, K_NKINDS };
+static const char* KIND_NAMES[K_NKINDS] = {"qkv_fwd", "attn_fwd", "mlp_fwd", "mlp_bwd", "attn_bwd", "qkv_bwd",
+                                           "dw", "resample_fwd", "resample_bwd", "stem"};
+
+struct ProfScope {
+  RalModel* m; hipStream_t s; bool on;
+  ProfScope(RalModel* m_, int kind, hipStream_t s_) : m(m_), s(s_), on(m_->prof_kind == kind) {
+    if (!on) return;
+    if (m->prof_used == m->prof_ev.size()) {
+      hipEvent_t a, b;
+      (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+      m->prof_ev.push_back({a, b});
+    }
+    (void)hipEventRecord(m->prof_ev[m->prof_used].first, s);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(m->prof_ev[m->prof_used].second, s);
+    m->prof_used++;
+  }
 };
 
 struct ral_handle {
@@ -293,9 +320,10 @@ static void run_block_fwd(RalModel* m, int bi, const float* in, bool training, i
     table = m->params + m->lay.rw[STAGES[si].rw - 1];
     Len = RWLEN[STAGES[si].rw - 1];
   }
-  launch_qkv_fwd(C, in, m->pe[l], w, a.qkv, N, B, s);
-  launch_attn_fwd(a.qkv, a.o, training ? a.lse : nullptr, table, N, H, m->hg_f[l], Len, B, s);
-  launch_mlp_fwd(C, m->nch_f[l], in, a.o, w, training ? a.x1 : nullptr, training ? a.upre : nullptr, a.out, N, B, s);
+  { ProfScope p(m, K_QKV_FWD, s); launch_qkv_fwd(C, in, m->pe[l], w, a.qkv, N, B, s); }
+  { ProfScope p(m, K_ATTN_FWD, s); launch_attn_fwd(a.qkv, a.o, training ? a.lse : nullptr, table, N, H, m->hg_f[l], Len, B, s); }
+  { ProfScope p(m, K_MLP_FWD, s);
+    launch_mlp_fwd(C, m->nch_f[l], in, a.o, w, training ? a.x1 : nullptr, training ? a.upre : nullptr, a.out, N, B, s); }
 }
 
 static const float* run_stage_fwd(RalModel* m, int si, const float* in, bool training, int B, hipStream_t s) {
@@ -307,6 +335,7 @@ static const float* run_stage_fwd(RalModel* m, int si, const float* in, bool tra
 static void run_res_fwd(RalModel* m, int ri, const float* in, const float* skip, int B, hipStream_t s) {
   const ResOff& r = m->lay.res[ri];
   const int T = m->E1 / r.D;  // output tokens per window
+  ProfScope p(m, K_RES_FWD, s);
   launch_resample_fwd(r.D, ri >= 4, in, m->params + r.w, m->params + r.lnw, m->params + r.lnb, skip,
                       m->res_out[ri], T, B, s);
 }
@@ -373,10 +402,12 @@ static void run_block_bwd(RalModel* m, int bi, const float* dy, const float* ext
     gtable = m->grads + m->lay.rw[STAGES[si].rw - 1];
     Len = RWLEN[STAGES[si].rw - 1];
   }
-  launch_mlp_bwd(C, m->nch_b[l], dy, a.x1, a.upre, w, g, m->dupre, m->dx1, m->dohm, N, B, s);
-  launch_attn_bwd(a.qkv, a.o, m->dohm, a.lse, table, gtable, m->dqkv, N, H, m->hg_b[l], Len, B, s);
-  launch_qkv_bwd(C, m->dqkv, a.in, m->pe[l], m->dx1, extra, w, g, dx, N, B, s);
-  launch_block_dw(C, dy, a.upre, m->dupre, a.x1, m->dx1, a.o, m->dqkv, a.in, m->pe[l], w, g, N, B, 256, s);
+  { ProfScope p(m, K_MLP_BWD, s); launch_mlp_bwd(C, m->nch_b[l], dy, a.x1, a.upre, w, g, m->dupre, m->dx1, m->dohm, N, B, s); }
+  { ProfScope p(m, K_ATTN_BWD, s);
+    launch_attn_bwd(a.qkv, a.o, m->dohm, a.lse, table, gtable, m->dqkv, N, H, m->hg_b[l], Len, B, s); }
+  { ProfScope p(m, K_QKV_BWD, s); launch_qkv_bwd(C, m->dqkv, a.in, m->pe[l], m->dx1, extra, w, g, dx, N, B, s); }
+  { ProfScope p(m, K_DW, s);
+    launch_block_dw(C, dy, a.upre, m->dupre, a.x1, m->dx1, a.o, m->dqkv, a.in, m->pe[l], w, g, N, B, 256, s); }
 }
 
 // stage: grad of stage output `dy` -> grad of stage input written to `dx` (+extra). Uses `tmp` between blocks.
@@ -389,6 +420,7 @@ static void run_stage_bwd(RalModel* m, int si, const float* dy, const float* ext
 static void run_res_bwd(RalModel* m, int ri, const float* dy, const float* in, float* dx, int B, hipStream_t s) {
   const ResOff& r = m->lay.res[ri];
   const int T = m->E1 / r.D;
+  ProfScope p(m, K_RES_BWD, s);
   launch_resample_bwd(r.D, ri >= 4, dy, in, m->params + r.w, m->params + r.lnw, m->grads + r.lnw, m->grads + r.lnb,
                       dx, T, B, s);
   launch_resample_dw(r.D, ri >= 4, dy, in, m->params + r.lnw, m->params + r.lnb, m->grads + r.w, T, B, 256, s);
@@ -614,6 +646,33 @@ int ral_adam_step(ral_handle* h, float lr, float beta1, float beta2, float eps, 
   if (step < 1) return fail("step is 1-based");
   launch_adam(p, g, am, av, (size_t)n, lr, beta1, beta2, eps, step, grad_scale, (hipStream_t)s);
   HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int ral_profile_select(ral_handle* h, const char* kind) {
+  if (!h || h->kind != 0) return fail("profiling is available for RA-LENet handles only");
+  RalModel* m = h->m;
+  m->prof_used = 0;
+  m->prof_kind = -1;
+  if (!kind || !*kind) return 0;
+  for (int k = 0; k < K_NKINDS; ++k)
+    if (!strcmp(kind, KIND_NAMES[k])) { m->prof_kind = k; return 0; }
+  return fail("unknown kernel kind %s", kind);
+}
+
+int ral_profile_read(ral_handle* h, double* total_ms, int64_t* launches) {
+  if (!h || h->kind != 0) return fail("profiling is available for RA-LENet handles only");
+  RalModel* m = h->m;
+  double tot = 0.0;
+  for (size_t i = 0; i < m->prof_used; ++i) {
+    float ms = 0.f;
+    HIP_OK(hipEventSynchronize(m->prof_ev[i].second));
+    HIP_OK(hipEventElapsedTime(&ms, m->prof_ev[i].first, m->prof_ev[i].second));
+    tot += ms;
+  }
+  *total_ms = tot;
+  *launches = (int64_t)m->prof_used;
+  m->prof_used = 0;
   return 0;
 }
 

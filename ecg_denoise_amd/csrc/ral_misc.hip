@@ -258,7 +258,8 @@ void launch_loss(const float* pred, const float* target, float* dy, float* snr, 
 
 void launch_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
                  int step, float gscale, hipStream_t s) {
-  const float bc1 = 1.0f - powf(b1, (float)step);
-  const float bc2 = 1.0f - powf(b2, (float)step);
-  k_adam<<<ew_grid(n / 4), 256, 0, s>>>(p, g, m, v, n / 4, lr, b1, b2, eps, bc1, sqrtf(bc2), gscale);
+  // bias corrections in double, as torch.optim.Adam computes them on the host
+  const double bc1 = 1.0 - pow((double)b1, (double)step);
+  const double bc2 = 1.0 - pow((double)b2, (double)step);
+  k_adam<<<ew_grid(n / 4), 256, 0, s>>>(p, g, m, v, n / 4, lr, b1, b2, eps, (float)bc1, (float)sqrt(bc2), gscale);
 }

@@ -1,0 +1,82 @@
+"""Data-parallel training over the GPUs of one node: one process per GPU, windows of the
+global batch sharded evenly, parameters / Adam state replicated.
+
+Collectives per step (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm):
+  1. BatchNorm forward sums   (16 doubles)   -> exact global-batch statistics (sync-BN)
+  2. BatchNorm backward sums  (16 doubles)
+  3. flat gradient buffer     (4.35 MB fp32, one bucket: latency- not bandwidth-bound)
+No collective touches activations; inference needs none (replicas).
+
+The trainer only sequences engine calls and collectives, so it is testable on CPU with
+`gloo` and any engine exposing the same methods (tests/test_dp_gloo.py).
+"""
+import torch
+import torch.distributed as dist
+
+
+class HipEngineAdapter:
+    """Splits RALENet's train step at the two BatchNorm reduction points."""
+
+    def __init__(self, model):
+        import ctypes as C
+        from . import _lib
+        from .model import _ptr, _stream
+        self.m, self._lib, self._ptr, self._stream, self._C = model, _lib, _ptr, _stream, C
+        self.bn_sums = model.eng.bn_sums
+        self.grads = model.eng.grads
+
+    def forward_begin(self, x):
+        self.x = x.contiguous()
+        self._lib.check(self._lib.lib().ral_forward_begin(self.m.eng.h, self._ptr(self.x), x.shape[0], self._stream()))
+
+    def forward_end(self, global_windows):
+        self.y = torch.empty_like(self.x)
+        self._lib.check(self._lib.lib().ral_forward_end(self.m.eng.h, self._ptr(self.y), self.x.shape[0],
+                                                        global_windows, self._stream()))
+        for k in self.m.eng.counters:
+            self.m.eng.counters[k] += 1
+        return self.y
+
+    def loss(self, pred, target, global_windows):
+        return self.m.loss_and_metrics(pred, target, True, global_windows)   # loss already / global_windows
+
+    def backward_begin(self):
+        dy = self.m._dy
+        self._lib.check(self._lib.lib().ral_backward_begin(self.m.eng.h, self._ptr(dy), dy.shape[0], self._stream()))
+
+    def backward_end(self, global_windows):
+        self._lib.check(self._lib.lib().ral_backward_end(self.m.eng.h, self._C.c_void_p(0), self.x.shape[0],
+                                                         global_windows, self._stream()))
+
+    def adam(self, lr):
+        self.m.step(lr)
+
+
+class DataParallelTrainer:
+    def __init__(self, engine, group=None, sync_bn=True):
+        self.e, self.group, self.sync_bn = engine, group, sync_bn
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def _allreduce(self, t):
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    def train_step(self, x_local, target_local, lr=1e-3):
+        """x_local: this rank's shard (equal shard sizes).  Returns loss (global mean), snr, rmse (local)."""
+        B = x_local.shape[0]
+        G = B * self.world
+        e = self.e
+        e.forward_begin(x_local)
+        if self.sync_bn:
+            self._allreduce(e.bn_sums[:32])
+        pred = e.forward_end(G if self.sync_bn else B)
+        loss, snr, rmse = e.loss(pred, target_local, G)
+        e.backward_begin()
+        if self.sync_bn:
+            self._allreduce(e.bn_sums[32:64])
+        e.backward_end(G if self.sync_bn else B)
+        self._allreduce(e.grads)          # dy already carries 1/G: the sum IS the global-mean gradient
+        e.adam(lr)
+        loss = loss.clone()
+        self._allreduce(loss)             # sum of local (sse/n)/G -> global mean
+        return {"loss": loss, "snr": snr, "rmse": rmse, "pred": pred}

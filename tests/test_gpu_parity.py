@@ -1,0 +1,167 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and with the golden
+vectors generated from the reference.  Needs an MI355X: `pytest -m gpu`.
+
+Tolerances (fp32 kernels vs the oracle evaluated in fp64): forward 1e-5 relative L2
+(north-star bar: 1e-3), gradients 1e-4, both far above the observed 2e-7 / 2e-6."""
+import os
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+import ralenet_oracle as O
+from parity_util import rel, run_parity
+
+pytestmark = pytest.mark.gpu
+FWD_TOL, GRAD_TOL = 1e-5, 1e-4
+DEV = "cuda:0"
+
+
+def _check(res):
+    bad = {}
+    for k, v in res.items():
+        if k.startswith("gradabs:"):
+            if v > 1e-5:
+                bad[k] = v
+        elif k.startswith("grad:"):
+            if v > GRAD_TOL:
+                bad[k] = v
+        elif v > FWD_TOL:
+            bad[k] = v
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("variant,leads,L,B", [
+    ("full", 2, 512, 4), ("nra", 2, 512, 3), ("mlp", 2, 256, 4), ("full", 2, 256, 5),
+    ("full", 1, 512, 2), ("full", 2, 1024, 2), ("nra", 1, 256, 1),
+])
+def test_train_step_matches_oracle(variant, leads, L, B):
+    res, _, _ = run_parity(variant, leads, L, B, DEV)
+    _check(res)
+
+
+@pytest.mark.parametrize("variant,leads,L", [("nra", 2, 512), ("full", 2, 256), ("mlp", 2, 256), ("full", 2, 512),
+                                             ("full", 1, 512), ("full", 2, 1024)])
+def test_against_reference_golden(variant, leads, L, golden_dir):
+    """Same weights/inputs as oracle/gen_golden.py fed to the reference itself."""
+    from ecg_denoise_amd import RALENet
+    g = np.load(os.path.join(golden_dir, f"g3_{variant}_l{leads}_L{L}.npz"))
+    p = O.init_params(O.ralenet_param_shapes(variant, leads), 1234)
+    x = torch.tensor(g["x"]).to(DEV); tgt = torch.tensor(g["target"]).to(DEV)
+    m = RALENet(variant, leads=leads, L=L, max_batch=x.shape[0], device=DEV)
+    m.load_state_dict(p, strict=False)
+    m.train()
+    y = m(x)
+    loss, snr, rmse = m.loss_and_metrics(y, tgt)
+    m.backward()
+    assert rel(y.cpu().numpy(), g["y_train"]) < 1e-5
+    assert abs(loss.item() - g["loss"]) < 1e-5 * abs(g["loss"])
+    ng = m.named_grads()
+    keys = [str(k) for k in g["keys"]]
+    gn = np.array([ng[k].double().norm().item() for k in keys])
+    skip = np.array([k.endswith("to_kv.bias") for k in keys])  # key-bias half is rounding noise
+    np.testing.assert_allclose(gn[~skip], g["grad_norm"][~skip], rtol=2e-4, atol=1e-8)
+    for k in ("conv1.0.weight", "conv1.2.weight", "conv1.2.bias", "transconv.0.weight",
+              "rwattn1.relative_position_bias_table", "rwattn4.relative_position_bias_table"):
+        if "gradfull_" + k in g.files:
+            assert rel(ng[k].cpu().numpy(), g["gradfull_" + k]) < 2e-4, k
+    sd = m.state_dict()
+    np.testing.assert_allclose(sd["conv1.2.running_mean"].cpu().numpy(), g["bn_mean_conv1.2"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(sd["conv1.2.running_var"].cpu().numpy(), g["bn_var_conv1.2"], rtol=1e-5, atol=1e-7)
+    assert int(sd["conv1.2.num_batches_tracked"]) == 1
+    m.eval()
+    ye = m(x)
+    assert rel(ye.cpu().numpy(), g["y_eval"]) < 1e-5
+    # three Adam steps from the initial state reproduce the reference loss trajectory
+    m2 = RALENet(variant, leads=leads, L=L, max_batch=x.shape[0], device=DEV)
+    m2.load_state_dict(p, strict=False)
+    m2.train()
+    losses = [m2.train_step(x, tgt)["loss"].item() for _ in range(3)]
+    np.testing.assert_allclose(losses, g["adam_losses"], rtol=5e-4)
+
+
+def test_adam_kernel_matches_torch_semantics():
+    from ecg_denoise_amd import RALENet
+    m = RALENet("nra", leads=2, L=256, max_batch=2, device=DEV, seed=3)
+    n = m.eng.nparam
+    gen = torch.Generator().manual_seed(0)
+    p0 = torch.randn(n, generator=gen); 
+    ref_p = {"w": p0.clone().double()}
+    ref_m = {"w": torch.zeros(n, dtype=torch.float64)}; ref_v = {"w": torch.zeros(n, dtype=torch.float64)}
+    m.eng.params.copy_(p0)
+    for step in range(1, 6):
+        gr = torch.randn(n, generator=gen) * (10.0 ** torch.randint(-6, 2, (n,), generator=gen).float())
+        m.eng.grads.copy_(gr)
+        m.step(1e-3)
+        O.adam_step(ref_p, {"w": gr.double()}, ref_m, ref_v, step)
+    torch.cuda.synchronize()
+    assert rel(m.eng.params.cpu().numpy(), ref_p["w"].numpy()) < 1e-6
+    assert rel(m.eng.adam_v.cpu().numpy(), ref_v["w"].numpy()) < 1e-6
+
+
+def test_metrics_known_answers(golden_dir):
+    from ecg_denoise_amd import RALENet
+    g = np.load(os.path.join(golden_dir, "g4_metrics.npz"))
+    y = torch.tensor(g["y"]); pred = torch.tensor(g["pred"])
+    pad = lambda t: torch.nn.functional.pad(t, (0, 128)).to(DEV)   # L=256 model: zero tail leaves the sums unchanged
+    m = RALENet("nra", leads=2, L=256, max_batch=8, device=DEV, seed=0)
+    loss, snr, rmse = m.loss_and_metrics(pad(pred), pad(y), want_grad=False)
+    np.testing.assert_allclose(snr.cpu().numpy(), g["snr"], rtol=1e-5)
+    np.testing.assert_allclose(rmse.cpu().numpy() * np.sqrt(2.0), g["rmse"], rtol=1e-5)
+    _, snr9, _ = m.loss_and_metrics(pad(0.9 * y), pad(y), want_grad=False)
+    np.testing.assert_allclose(snr9.cpu().numpy(), 20.0, atol=1e-3)
+
+
+def test_variants_agree_at_zero_tables():
+    """Reference quirk A7: with zero R-wave tables the full model equals the LE-only model."""
+    from ecg_denoise_amd import RALENet
+    a = RALENet("nra", leads=2, L=256, max_batch=2, device=DEV, seed=5)
+    b = RALENet("full", leads=2, L=256, max_batch=2, device=DEV, seed=6)
+    sd = a.state_dict()
+    renamed = OrderedDict()
+    for k, v in sd.items():
+        parts = k.split(".")
+        if parts[0] in [s for s, _, _ in O.BLOCK_STAGES]:
+            k = ".".join([parts[0], "blocks"] + parts[1:])
+        renamed[k] = v
+    b.load_state_dict(renamed, strict=False)
+    x = torch.randn(2, 2, 256, device=DEV)
+    a.eval(); b.eval()
+    assert rel(a(x).cpu().numpy(), b(x).cpu().numpy()) < 1e-6
+
+
+def test_linearity_of_backward_in_dy_full_size():
+    """Size-independent property at the BASELINE batch: gradients are linear in dy."""
+    from ecg_denoise_amd import RALENet
+    B = 256
+    m = RALENet("full", leads=1, L=512, max_batch=B, device=DEV, seed=1)
+    x = torch.randn(B, 1, 512, device=DEV)
+    m.train()
+    y = m(x)
+    dy = torch.randn_like(y) / y.numel()
+    m.backward(dy)
+    g1 = m.eng.grads.clone()
+    m.backward(2.0 * dy)
+    g2 = m.eng.grads.clone()
+    assert rel(g2.cpu().numpy(), 2.0 * g1.cpu().numpy()) < 1e-5
+
+
+def test_state_dict_round_trip_and_errors():
+    from ecg_denoise_amd import RALENet, RalError
+    m = RALENet("full", leads=2, L=256, max_batch=2, device=DEV, seed=9)
+    sd = m.state_dict()
+    assert sd["rwattn1.relative_position_index"].shape == (32, 32)
+    assert sd["rwattn1.relative_position_index"][0, 31] == 0 and sd["rwattn1.relative_position_index"][31, 0] == 62
+    m2 = RALENet("full", leads=2, L=256, max_batch=2, device=DEV, seed=10)
+    m2.load_state_dict(sd)
+    x = torch.randn(2, 2, 256, device=DEV)
+    m.eval(); m2.eval()
+    assert torch.equal(m(x), m2(x))
+    with pytest.raises(RalError):
+        m(torch.randn(3, 2, 256, device=DEV))      # > max_batch
+    with pytest.raises(RalError):
+        m(torch.randn(2, 2, 512, device=DEV))      # wrong L
+    bad = dict(sd); bad["conv1.0.weight"] = torch.zeros(8, 3, 3)
+    with pytest.raises(RalError):
+        m.load_state_dict(bad)
