@@ -635,7 +635,7 @@ int ral_backward(ral_handle* h, const float* dy, float* dx, int B, ral_stream s)
   return bwd_end(h->m, dx, B, B, (hipStream_t)s);
 }
 
-int ral_adam_step(ral_handle* h, float lr, float beta1, float beta2, float eps, int step, float grad_scale,
+int ral_adam_step(ral_handle* h, double lr, double beta1, double beta2, double eps, int step, float grad_scale,
                   ral_stream s) {
   if (!h) return fail("null handle");
   float *p, *g, *am, *av;

@@ -22,7 +22,7 @@ __global__ __launch_bounds__(512) void k_mlp_bwd(const float* __restrict__ dx2, 
                                                  float* __restrict__ dupre, float* __restrict__ dx1,
                                                  float* __restrict__ do_hm, int N, int B) {
   extern __shared__ float4 smem4[];
-  constexpr int LD = C + 4, HC = 4 * C / NCH, LDU = HC + 4, LPR = C / 4;
+  constexpr int LD = LDof<C>::v, HC = 4 * C / NCH, LDU = LDof<HC>::v, LPR = C / 4;
   float* Ds = reinterpret_cast<float*>(smem4);  // N x LD : dx2 -> dx1
   float* Gs = Ds + N * LD;                      // N x LD : dg accumulator
   float* Us = Gs + N * LD;                      // N x LDU: u_pre chunk -> du chunk
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(512) void k_qkv_bwd(const float* __restrict__ dqkv,
                                                  const float* __restrict__ extra, BlockP w, BlockP gr,
                                                  float* __restrict__ dx, int N, int B) {
   extern __shared__ float4 smem4[];
-  constexpr int LD = C + 4, LPR = C / 4, TTB = TTBof<C>::v;
+  constexpr int LD = LDof<C>::v, LPR = C / 4, TTB = TTBof<C>::v;
   float* DQ = reinterpret_cast<float*>(smem4);  // HM, N x 3C
   float* Dh = DQ + N * 3 * C;                   // N x LD
   float* red = Dh + N * LD;                     // 2C
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256) void k_resample_bwd(const float* __restrict__ 
                                                       float* __restrict__ g_lnw, float* __restrict__ g_lnb,
                                                       float* __restrict__ dx, int T, int B) {
   extern __shared__ float4 smem4[];
-  constexpr int LD = D + 4, LPR = D / 4, RPP = 256 / LPR;
+  constexpr int LD = LDof<D>::v, LPR = D / 4, RPP = 256 / LPR;
   float* Ys = reinterpret_cast<float*>(smem4);  // T x LD
   float* Dh = Ys + T * LD;                      // T x LD
   float* red = Dh + T * LD;                     // 2D
@@ -710,7 +710,7 @@ static inline int ew_grid(size_t n, int per = 256) {
 }
 
 size_t mlp_bwd_lds(int C, int N, int nch) {
-  return ((size_t)2 * N * (C + 4) + (size_t)N * (4 * C / nch + 4) + 2 * (N + 2) + 2 * N + 2 * C + 8) * sizeof(float);
+  return ((size_t)2 * N * ld_of(C) + (size_t)N * ld_of(4 * C / nch) + 2 * (N + 2) + 2 * N + 2 * C + 8) * sizeof(float);
 }
 
 template <int C>
@@ -750,7 +750,7 @@ void launch_attn_bwd(const float* qkv, const float* o_hm, const float* do_hm, co
   }
 }
 
-size_t qkv_bwd_lds(int C, int N) { return ((size_t)N * 3 * C + (size_t)N * (C + 4) + 2 * C + 4) * sizeof(float); }
+size_t qkv_bwd_lds(int C, int N) { return ((size_t)N * 3 * C + (size_t)N * ld_of(C) + 2 * C + 4) * sizeof(float); }
 
 void launch_qkv_bwd(int C, const float* dqkv, const float* x, const float* pe, const float* dx1, const float* extra,
                     const BlockP& w, const BlockP& gr, float* dx, int N, int B, hipStream_t s) {
@@ -766,7 +766,7 @@ void launch_qkv_bwd(int C, const float* dqkv, const float* x, const float* pe, c
 
 void launch_resample_bwd(int D, bool sep, const float* dy, const float* x, const float* wred, const float* lnw,
                          float* g_lnw, float* g_lnb, float* dx, int T, int B, hipStream_t s) {
-  const size_t lds = ((size_t)2 * T * (D + 4) + 2 * D + 4) * sizeof(float);
+  const size_t lds = ((size_t)2 * T * ld_of(D) + 2 * D + 4) * sizeof(float);
   const int grid = grid_bwd(B);
 #define CASE(d) case d: if (sep) { RAL_SET_LDS((k_resample_bwd<d, true>), lds); k_resample_bwd<d, true><<<grid, 256, lds, s>>>(dy, x, wred, lnw, g_lnw, g_lnb, dx, T, B); } \
                         else { RAL_SET_LDS((k_resample_bwd<d, false>), lds); k_resample_bwd<d, false><<<grid, 256, lds, s>>>(dy, x, wred, lnw, g_lnw, g_lnb, dx, T, B); } break;

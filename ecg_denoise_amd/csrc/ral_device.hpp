@@ -109,6 +109,11 @@ RAL_DEV void gemm_phase(const float* __restrict__ W, int ldw, int M, const float
   }
 }
 
+// row stride (floats) of a token-major LDS tile of width C: +4 breaks the power-of-two stride for the
+// b128 fragment reads; the 8-wide level keeps its rows dense so that 1024-sample windows still fit
+template <int C> struct LDof { static constexpr int v = (C == 8) ? 8 : C + 4; };
+static inline int ld_of(int C) { return C == 8 ? 8 : C + 4; }
+
 // token tiles processed per weight-fragment load, by channel width (keeps ntiles % TTB == 0
 // for every window length that is a multiple of 256)
 template <int C> struct TTBof { static constexpr int v = (C <= 32) ? 4 : (C == 64 ? 2 : 1); };

@@ -17,7 +17,7 @@ __global__ __launch_bounds__(512) void k_dw(const float* __restrict__ Y, const f
   extern __shared__ float4 smem4[];
   constexpr int MT = (M + 15) / 16, NT = (NC + 15) / 16, NWV = 8, TPW = (MT * NT + NWV - 1) / NWV;
   constexpr int LAYX = (XF == XF_HM) ? LAY_HM : LAY_TOK;
-  constexpr int LDY = M + 4, LDX = NC + 4;
+  constexpr int LDY = LDof<M>::v, LDX = LDof<NC>::v;
   float* Ys = reinterpret_cast<float*>(smem4);
   float* Xs = Ys + (LAYY == LAY_HM ? TC * M : TC * LDY);
   float* A0 = Xs + (LAYX == LAY_HM ? TC * NC : TC * LDX);  // N + 2 (XF_A2 with LE only)
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(512) void k_dw(const float* __restrict__ Y, const f
 
 // ---------------------------------------------------------------------------------
 size_t dw_lds(int M, int NC, bool yhm, bool xhm, int TC, int N) {
-  return ((size_t)TC * (yhm ? M : M + 4) + (size_t)TC * (xhm ? NC : NC + 4) + N + 2 + 4) * sizeof(float);
+  return ((size_t)TC * (yhm ? M : ld_of(M)) + (size_t)TC * (xhm ? NC : ld_of(NC)) + N + 2 + 4) * sizeof(float);
 }
 
 // largest token chunk (multiple of 16 dividing N) whose staging fits the LDS budget

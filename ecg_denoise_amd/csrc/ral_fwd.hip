@@ -16,7 +16,7 @@ __global__ __launch_bounds__(256) void k_qkv_fwd(const float* __restrict__ x, co
                                                  BlockP w, float* __restrict__ qkv, int N, int B) {
   extern __shared__ float4 smem4[];
   float* Hs = reinterpret_cast<float*>(smem4);
-  constexpr int LD = C + 4, LPR = C / 4, RPP = 256 / LPR;
+  constexpr int LD = LDof<C>::v, LPR = C / 4, RPP = 256 / LPR;
   const float sqrtC = sqrtf((float)C);
   const int cq = (threadIdx.x % LPR) * 4;
   const float4 gam = *reinterpret_cast<const float4*>(w.ln1w + cq);
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(512) void k_mlp_fwd(const float* __restrict__ x, co
                                                  float* __restrict__ upre_out, float* __restrict__ x2_out,
                                                  int N, int B) {
   extern __shared__ float4 smem4[];
-  constexpr int LD = C + 4, HC = 4 * C / NCH, LDU = HC + 4, LPR = C / 4;
+  constexpr int LD = LDof<C>::v, HC = 4 * C / NCH, LDU = LDof<HC>::v, LPR = C / 4;
   float* Xs = reinterpret_cast<float*>(smem4);  // N x LD   : x -> x1 -> x2
   float* Gs = Xs + N * LD;                      // N x LD   : o (HM, N*C) then LN2(x1)
   float* Us = Gs + N * LD;                      // N x LDU  : hidden chunk
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void k_resample_fwd(const float* __restrict__ 
                                                       int T, int B) {
   extern __shared__ float4 smem4[];
   float* Hs = reinterpret_cast<float*>(smem4);
-  constexpr int LD = D + 4, LPR = D / 4, RPP = 256 / LPR;
+  constexpr int LD = LDof<D>::v, LPR = D / 4, RPP = 256 / LPR;
   const int cq = (threadIdx.x % LPR) * 4;
   const float4 gam = *reinterpret_cast<const float4*>(lnw + cq);
   const float4 bet = *reinterpret_cast<const float4*>(lnb + cq);
@@ -300,7 +300,7 @@ __global__ void k_add(const float* __restrict__ a, const float* __restrict__ b, 
 static inline int grid_for(int items) { return items < 4096 ? items : 4096; }
 
 void launch_qkv_fwd(int C, const float* x, const float* pe, const BlockP& w, float* qkv, int N, int B, hipStream_t s) {
-  const size_t lds = (size_t)N * (C + 4) * sizeof(float);
+  const size_t lds = (size_t)N * ld_of(C) * sizeof(float);
   switch (C) {
 #define CASE(c) case c: k_qkv_fwd<c><<<grid_for(B), 256, lds, s>>>(x, pe, w, qkv, N, B); break;
     CASE(8) CASE(16) CASE(32) CASE(64) CASE(128)
@@ -321,7 +321,7 @@ void launch_attn_fwd(const float* qkv, float* o_hm, float* lse, const float* tab
 }
 
 size_t mlp_fwd_lds(int C, int N, int nch) {
-  return ((size_t)2 * N * (C + 4) + (size_t)N * (4 * C / nch + 4) + N + 2 + 2) * sizeof(float);
+  return ((size_t)2 * N * ld_of(C) + (size_t)N * ld_of(4 * C / nch) + N + 2 + 2) * sizeof(float);
 }
 
 template <int C>
@@ -344,7 +344,7 @@ void launch_mlp_fwd(int C, int nch, const float* x, const float* o, const BlockP
 
 void launch_resample_fwd(int D, bool sep, const float* x, const float* wred, const float* lnw, const float* lnb,
                          const float* skip, float* y, int T, int B, hipStream_t s) {
-  const size_t lds = (size_t)T * (D + 4) * sizeof(float);
+  const size_t lds = (size_t)T * ld_of(D) * sizeof(float);
 #define CASE(d) case d: if (sep) k_resample_fwd<d, true><<<grid_for(B), 256, lds, s>>>(x, wred, lnw, lnb, skip, y, T, B); \
                         else k_resample_fwd<d, false><<<grid_for(B), 256, lds, s>>>(x, wred, lnw, lnb, skip, y, T, B); break;
   switch (D) { CASE(8) CASE(16) CASE(32) CASE(64) CASE(128) CASE(256) }

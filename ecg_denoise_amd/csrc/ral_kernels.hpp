@@ -38,7 +38,7 @@ void launch_final_fwd(int leads, const float* u0, const float* x0, const float* 
                       int B, hipStream_t s);
 void launch_loss(const float* pred, const float* target, float* dy, float* snr, float* rmse, double* loss_sum,
                  int n, int B, float gscale, hipStream_t s);
-void launch_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
+void launch_adam(float* p, const float* g, float* m, float* v, size_t n, double lr, double b1, double b2, double eps,
                  int step, float gscale, hipStream_t s);
 
 // ---- backward (ral_bwd.hip)

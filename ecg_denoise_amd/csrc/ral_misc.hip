@@ -197,16 +197,15 @@ __global__ __launch_bounds__(256) void k_loss(const float* __restrict__ pred, co
 // fused flat Adam (torch.optim.Adam defaults, no weight decay / amsgrad)
 // ---------------------------------------------------------------------------------
 __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                       float* __restrict__ v, size_t n4, float lr, float b1, float b2, float eps, float bc1,
-                       float sqrt_bc2, float gscale) {
-  const float step = lr / bc1;
+                       float* __restrict__ v, size_t n4, float step, float b1, float b2, float omb1, float omb2,
+                       float eps, float sqrt_bc2, float gscale) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     float4 pp = reinterpret_cast<float4*>(p)[i];
     const float4 gg = f4scale(reinterpret_cast<const float4*>(g)[i], gscale);
     float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
 #define UPD(f)                                              \
-    mm.f = b1 * mm.f + (1.f - b1) * gg.f;                   \
-    vv.f = b2 * vv.f + (1.f - b2) * gg.f * gg.f;            \
+    mm.f = b1 * mm.f + omb1 * gg.f;                         \
+    vv.f = b2 * vv.f + omb2 * gg.f * gg.f;                  \
     pp.f -= step * mm.f / (sqrtf(vv.f) / sqrt_bc2 + eps);
     UPD(x) UPD(y) UPD(z) UPD(w)
 #undef UPD
@@ -256,10 +255,11 @@ void launch_loss(const float* pred, const float* target, float* dy, float* snr, 
   k_loss<<<B, 256, 0, s>>>(pred, target, dy, snr, rmse, loss_sum, n, gscale);
 }
 
-void launch_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
+void launch_adam(float* p, const float* g, float* m, float* v, size_t n, double lr, double b1, double b2, double eps,
                  int step, float gscale, hipStream_t s) {
-  // bias corrections in double, as torch.optim.Adam computes them on the host
-  const double bc1 = 1.0 - pow((double)b1, (double)step);
-  const double bc2 = 1.0 - pow((double)b2, (double)step);
-  k_adam<<<ew_grid(n / 4), 256, 0, s>>>(p, g, m, v, n / 4, lr, b1, b2, eps, (float)bc1, (float)sqrt(bc2), gscale);
+  // scalars are formed in double on the host and rounded once, as torch.optim.Adam does
+  const double bc1 = 1.0 - pow(b1, (double)step);
+  const double bc2 = 1.0 - pow(b2, (double)step);
+  k_adam<<<ew_grid(n / 4), 256, 0, s>>>(p, g, m, v, n / 4, (float)(lr / bc1), (float)b1, (float)b2, (float)(1.0 - b1),
+                                        (float)(1.0 - b2), (float)eps, (float)sqrt(bc2), gscale);
 }
