@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--kind", default="attn_bwd", help="kernel kind timed for the roofline object")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--infer", action="store_true", help="also time the inference forward")
+    ap.add_argument("--kinds", action="store_true", help="print a per-kernel-kind time table to stderr (3 steps each)")
     a = ap.parse_args()
 
     import torch
@@ -134,6 +135,21 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = tmax.item()
     loss = out["loss"].item()
+
+    if a.kinds and rank == 0:
+        tot = 0.0
+        for kind in ("qkv_fwd", "attn_fwd", "mlp_fwd", "resample_fwd", "mlp_bwd", "attn_bwd", "qkv_bwd", "dw", "resample_bwd"):
+            _lib.check(lib.ral_profile_select(model.eng.h, kind.encode()))
+            for _ in range(3):
+                trainer.train_step(x, tgt)
+            sync()
+            _lib.check(lib.ral_profile_read(model.eng.h, C.byref(ms), C.byref(cnt)))
+            w = kind_work(kind, a.L, B)
+            tot += ms.value / 3
+            print(f"  {kind:14s} {ms.value/3:8.3f} ms/step  {cnt.value//3:4d} launches  "
+                  f"{(w / (ms.value / 3 * 1e-3) / 1e12) if w else 0:7.2f} TF/s", file=sys.stderr)
+        print(f"  sum of kinds   {tot:8.3f} ms/step", file=sys.stderr)
+        _lib.check(lib.ral_profile_select(model.eng.h, b""))
 
     infer = None
     if a.infer:

@@ -3,6 +3,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -204,6 +205,7 @@ struct RalModel {
   const float* last_x = nullptr;
   int last_B = 0;
   int nch_f[5], nch_b[5], hg_f[5], hg_b[5];
+  int dw_ksplit = 256;
   // optional in-library kernel timing (bench.py roofline leg): hipEvent pairs around the
   // launches of ONE selected kernel kind, on the stream the kernels run on
   int prof_kind = -1;
@@ -277,8 +279,17 @@ static size_t plan_workspace(const ral_config& c, RalModel* m /* may be null: si
   return cur;
 }
 
+static size_t env_size(const char* name, size_t dflt) {
+  const char* v = getenv(name);
+  return v && *v ? (size_t)atoll(v) : dflt;
+}
+
 static void choose_tiling(RalModel* m) {
-  const size_t budget = 150 * 1024;
+  // tuning knobs (bytes of LDS a workgroup may take; fewer bytes = more hidden chunks / smaller head
+  // groups but more co-resident workgroups per CU).  Environment overrides are for experiments only.
+  const size_t budget = env_size("RAL_MLP_LDS", 78000);
+  const size_t budget_af = env_size("RAL_ATTN_FWD_LDS", 72 * 1024), budget_ab = env_size("RAL_ATTN_BWD_LDS", 78 * 1024);
+  m->dw_ksplit = (int)env_size("RAL_DW_KSPLIT", 256);
   for (int l = 0; l < 5; ++l) {
     const int C = CH[l], N = m->L >> l, H = C / 4;
     int n = 1;
@@ -289,10 +300,10 @@ static void choose_tiling(RalModel* m) {
     m->nch_b[l] = n;
     const int Len = l < 4 ? RWLEN[l] : 0;
     int hg = H;
-    while (hg > 1 && attn_fwd_lds(N, hg, Len) > 72 * 1024) hg /= 2;
+    while (hg > 1 && attn_fwd_lds(N, hg, Len) > budget_af) hg /= 2;
     m->hg_f[l] = hg;
     hg = H;
-    while (hg > 1 && attn_bwd_lds(N, hg, Len) > 78 * 1024) hg /= 2;
+    while (hg > 1 && attn_bwd_lds(N, hg, Len) > budget_ab) hg /= 2;
     m->hg_b[l] = hg;
   }
 }
@@ -407,7 +418,7 @@ static void run_block_bwd(RalModel* m, int bi, const float* dy, const float* ext
     launch_attn_bwd(a.qkv, a.o, m->dohm, a.lse, table, gtable, m->dqkv, N, H, m->hg_b[l], Len, B, s); }
   { ProfScope p(m, K_QKV_BWD, s); launch_qkv_bwd(C, m->dqkv, a.in, m->pe[l], m->dx1, extra, w, g, dx, N, B, s); }
   { ProfScope p(m, K_DW, s);
-    launch_block_dw(C, dy, a.upre, m->dupre, a.x1, m->dx1, a.o, m->dqkv, a.in, m->pe[l], w, g, N, B, 256, s); }
+    launch_block_dw(C, dy, a.upre, m->dupre, a.x1, m->dx1, a.o, m->dqkv, a.in, m->pe[l], w, g, N, B, m->dw_ksplit, s); }
 }
 
 // stage: grad of stage output `dy` -> grad of stage input written to `dx` (+extra). Uses `tmp` between blocks.
@@ -423,7 +434,7 @@ static void run_res_bwd(RalModel* m, int ri, const float* dy, const float* in, f
   ProfScope p(m, K_RES_BWD, s);
   launch_resample_bwd(r.D, ri >= 4, dy, in, m->params + r.w, m->params + r.lnw, m->grads + r.lnw, m->grads + r.lnb,
                       dx, T, B, s);
-  launch_resample_dw(r.D, ri >= 4, dy, in, m->params + r.lnw, m->params + r.lnb, m->grads + r.w, T, B, 256, s);
+  launch_resample_dw(r.D, ri >= 4, dy, in, m->params + r.lnw, m->params + r.lnb, m->grads + r.w, T, B, m->dw_ksplit, s);
 }
 
 static int bwd_begin(RalModel* m, const float* dy, int B, hipStream_t s) {

@@ -5,6 +5,7 @@
 // atomic per element per workgroup.
 #include "ral_device.hpp"
 #include "ral_kernels.hpp"
+#include <type_traits>
 
 // LDS float4 atomic accumulate of per-channel vectors: red[c..c+3] += v
 RAL_DEV void lds_add4(float* red, int c, float4 v) {
@@ -78,7 +79,9 @@ __global__ __launch_bounds__(512) void k_mlp_bwd(const float* __restrict__ dx2, 
             DC0[tok + 1] = a[e] * gelu_grad_f(C0[tok]);
             out[e] = 0.f;  // filled by the channel-0 pass below
           } else {
-            out[e] = a[e] * gelu_grad_f(gelu_f(uu[e])) * gelu_grad_f(uu[e]);
+            float a1, d1;
+            gelu_pair(uu[e], a1, d1);
+            out[e] = a[e] * gelu_grad_f(a1) * d1;
           }
         }
         *pu = make_float4(out[0], out[1], out[2], out[3]);
@@ -175,135 +178,144 @@ __global__ __launch_bounds__(512) void k_mlp_bwd(const float* __restrict__ dx2, 
 // queries): no cross-workgroup sums, no atomics except the tiny R-wave table gradient.
 // Output dqkv has the qkv layout; dq already carries the 0.5 of q = 0.5 (h Wq^T + b).
 // =================================================================================
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+RAL_DEV f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+RAL_DEV f32x2 splat2(float v) { return f32x2{v, v}; }
+#define RAL_LOG2E 1.4426950408889634f
+#define RAL_LN2 0.6931471805599453f
+
 template <int QT>
 __global__ __launch_bounds__(512) void k_attn_bwd(const float* __restrict__ qkv, const float* __restrict__ o_hm,
                                                   const float* __restrict__ do_hm, const float* __restrict__ lse,
                                                   const float* __restrict__ table, float* __restrict__ gtable,
                                                   float* __restrict__ dqkv, int N, int H, int HG, int Len, int B) {
   extern __shared__ float4 smem4[];
-  float* Qs = reinterpret_cast<float*>(smem4);
+  float* Qs = reinterpret_cast<float*>(smem4);  // q * log2(e)
   float* Ks = Qs + HG * N * 4;
   float* Vs = Ks + HG * N * 4;
   float* dOs = Vs + HG * N * 4;
-  float* Ls = dOs + HG * N * 4;  // lse * log2e
-  float* Dl = Ls + HG * N;       // delta = rowsum(dO * O)
+  float* Ls = dOs + HG * N * 4;  // -lse * log2e      (negated: they enter the MFMAs as C operands,
+  float* Dl = Ls + HG * N;       // -rowsum(dO * O)    so tiles come out as s - lse and dP - delta)
   const int ntab = table ? (2 * Len - 1) * HG : 0;
-  float* tab = Dl + HG * N;
+  float* tab = Dl + HG * N;      // bias * log2e
   float* dtab = tab + ntab;
   const int ngrp = H / HG;
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
   const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int off = (N - Len) >> 1;
-  const float LOG2E = 1.4426950408889634f;
+  const int kb0 = table ? (off & ~15) : N, kb1 = table ? ((off + Len + 15) & ~15) : N;
   for (int i = threadIdx.x; i < ntab; i += blockDim.x) dtab[i] = 0.f;
   for (int item = blockIdx.x; item < B * ngrp; item += gridDim.x) {
     const int win = item / ngrp, h0 = (item - win * ngrp) * HG;
     const float* base = qkv + (size_t)win * 3 * H * N * 4;
     float* dbase = dqkv + (size_t)win * 3 * H * N * 4;
-    copy_flat(Qs, base + (size_t)h0 * N * 4, HG * N);
-    copy_flat(Ks, base + (size_t)(H + h0) * N * 4, HG * N);
-    copy_flat(Vs, base + (size_t)(2 * H + h0) * N * 4, HG * N);
     const size_t hq0 = ((size_t)win * H + h0) * N;
     for (int i = threadIdx.x; i < HG * N; i += blockDim.x) {
+      reinterpret_cast<float4*>(Qs)[i] = f4scale(reinterpret_cast<const float4*>(base + (size_t)h0 * N * 4)[i], RAL_LOG2E);
       const float4 d4 = reinterpret_cast<const float4*>(do_hm)[hq0 + i];
       const float4 o4 = reinterpret_cast<const float4*>(o_hm)[hq0 + i];
       reinterpret_cast<float4*>(dOs)[i] = d4;
-      Dl[i] = f4dot(d4, o4);
-      Ls[i] = lse[hq0 + i] * LOG2E;
+      Dl[i] = -f4dot(d4, o4);
+      Ls[i] = -lse[hq0 + i] * RAL_LOG2E;
     }
-    for (int i = threadIdx.x; i < ntab; i += blockDim.x) tab[i] = table[(i / HG) * H + h0 + (i % HG)];
+    copy_flat(Ks, base + (size_t)(H + h0) * N * 4, HG * N);
+    copy_flat(Vs, base + (size_t)(2 * H + h0) * N * 4, HG * N);
+    for (int i = threadIdx.x; i < ntab; i += blockDim.x) tab[i] = table[(i / HG) * H + h0 + (i % HG)] * RAL_LOG2E;
     __syncthreads();
     const int nblk = N / (16 * QT);
-    // ---------------- sweep A: dQ ----------------
+    // ---------------- sweep A: dQ (query block on the lanes, loop over key tiles) ----------------
     for (int task = wave; task < HG * nblk; task += nw) {
       const int hl = task / nblk, q0 = (task - hl * nblk) * 16 * QT;
       const float* Qh = Qs + hl * N * 4; const float* Kh = Ks + hl * N * 4;
       const float* Vh = Vs + hl * N * 4; const float* Dh = dOs + hl * N * 4;
+      const float4* K4 = reinterpret_cast<const float4*>(Kh);
       float qf[QT], df[QT], lq[QT], dl[QT];
-      float4 dq[QT];
+      f32x2 dq01[QT], dq23[QT];
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {
         const int q = q0 + 16 * qt + r;
         qf[qt] = Qh[q * 4 + g]; df[qt] = Dh[q * 4 + g];
         lq[qt] = Ls[hl * N + q]; dl[qt] = Dl[hl * N + q];
-        dq[qt] = make_float4(0.f, 0.f, 0.f, 0.f);
+        dq01[qt] = f32x2{0.f, 0.f}; dq23[qt] = f32x2{0.f, 0.f};
       }
-      const bool qbias = table && (q0 < off + Len) && (q0 + 16 * QT > off);
-      for (int kt = 0; kt < N; kt += 16) {
+      auto tileA = [&](int kt, auto biased) {
         const float kf = Kh[(kt + r) * 4 + g], vf = Vh[(kt + r) * 4 + g];
         float4 k4[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) k4[j] = *reinterpret_cast<const float4*>(Kh + (kt + 4 * g + j) * 4);
-        const bool tb = qbias && (kt < off + Len) && (kt + 16 > off);
+        for (int j = 0; j < 4; ++j) k4[j] = K4[kt + 4 * g + j];
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
-          f32x4 s = mfma4(kf, qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});
-          const f32x4 dp = mfma4(vf, df[qt], f32x4{0.f, 0.f, 0.f, 0.f});
+          f32x4 s = mfma4(kf, qf[qt], f32x4{lq[qt], lq[qt], lq[qt], lq[qt]});          // s - lse
+          const f32x4 dp = mfma4(vf, df[qt], f32x4{dl[qt], dl[qt], dl[qt], dl[qt]});   // dP - delta
           const int qi = q0 + 16 * qt + r - off;
-          if (tb) {
+          if constexpr (decltype(biased)::value) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const int ki = kt + 4 * g + j - off;
               if (qi >= 0 && qi < Len && ki >= 0 && ki < Len) s[j] += tab[(qi - ki + Len - 1) * HG + hl];
             }
           }
+          float ds[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ds[j] = __builtin_amdgcn_exp2f(s[j]) * dp[j];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const float p = __builtin_amdgcn_exp2f(fmaf(s[j], LOG2E, -lq[qt]));
-            const float ds = p * (dp[j] - dl[qt]);
-            dq[qt].x = fmaf(ds, k4[j].x, dq[qt].x);
-            dq[qt].y = fmaf(ds, k4[j].y, dq[qt].y);
-            dq[qt].z = fmaf(ds, k4[j].z, dq[qt].z);
-            dq[qt].w = fmaf(ds, k4[j].w, dq[qt].w);
-            if (tb) {
+            dq01[qt] = pk_fma(splat2(ds[j]), f32x2{k4[j].x, k4[j].y}, dq01[qt]);
+            dq23[qt] = pk_fma(splat2(ds[j]), f32x2{k4[j].z, k4[j].w}, dq23[qt]);
+          }
+          if constexpr (decltype(biased)::value) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
               const int ki = kt + 4 * g + j - off;
-              if (qi >= 0 && qi < Len && ki >= 0 && ki < Len) atomicAdd(dtab + (qi - ki + Len - 1) * HG + hl, ds);
+              if (qi >= 0 && qi < Len && ki >= 0 && ki < Len) atomicAdd(dtab + (qi - ki + Len - 1) * HG + hl, ds[j]);
             }
           }
         }
-      }
+      };
+      const bool qbias = table && (q0 < off + Len) && (q0 + 16 * QT > off);
+      const int e0 = qbias ? kb0 : N, e1 = qbias ? kb1 : N;
+      for (int kt = 0; kt < e0; kt += 16) tileA(kt, std::false_type{});
+      for (int kt = e0; kt < e1; kt += 16) tileA(kt, std::true_type{});
+      for (int kt = e1; kt < N; kt += 16) tileA(kt, std::false_type{});
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {
+        float4 v = make_float4(dq01[qt][0], dq01[qt][1], dq23[qt][0], dq23[qt][1]);
 #pragma unroll
         for (int sh = 16; sh <= 32; sh <<= 1) {
-          dq[qt].x += __shfl_xor(dq[qt].x, sh); dq[qt].y += __shfl_xor(dq[qt].y, sh);
-          dq[qt].z += __shfl_xor(dq[qt].z, sh); dq[qt].w += __shfl_xor(dq[qt].w, sh);
+          v.x += __shfl_xor(v.x, sh); v.y += __shfl_xor(v.y, sh);
+          v.z += __shfl_xor(v.z, sh); v.w += __shfl_xor(v.w, sh);
         }
         if (g == 0)
-          *reinterpret_cast<float4*>(dbase + ((size_t)(h0 + hl) * N + q0 + 16 * qt + r) * 4) = f4scale(dq[qt], 0.5f);
+          *reinterpret_cast<float4*>(dbase + ((size_t)(h0 + hl) * N + q0 + 16 * qt + r) * 4) = f4scale(v, 0.5f);
       }
     }
-    // ---------------- sweep B: dK, dV ----------------
+    // ---------------- sweep B: dK, dV (key block on the lanes, loop over query tiles) ----------------
     for (int task = wave; task < HG * nblk; task += nw) {
       const int hl = task / nblk, k0 = (task - hl * nblk) * 16 * QT;
       const float* Qh = Qs + hl * N * 4; const float* Kh = Ks + hl * N * 4;
       const float* Vh = Vs + hl * N * 4; const float* Dh = dOs + hl * N * 4;
+      const float4* Q4 = reinterpret_cast<const float4*>(Qh);
+      const float4* D4 = reinterpret_cast<const float4*>(Dh);
       float kf[QT], vf[QT];
-      float4 dk[QT], dv[QT];
+      f32x2 dk01[QT], dk23[QT], dv01[QT], dv23[QT];
 #pragma unroll
       for (int t = 0; t < QT; ++t) {
         const int k = k0 + 16 * t + r;
         kf[t] = Kh[k * 4 + g]; vf[t] = Vh[k * 4 + g];
-        dk[t] = make_float4(0.f, 0.f, 0.f, 0.f); dv[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        dk01[t] = f32x2{0.f, 0.f}; dk23[t] = f32x2{0.f, 0.f}; dv01[t] = f32x2{0.f, 0.f}; dv23[t] = f32x2{0.f, 0.f};
       }
-      const bool kbias = table && (k0 < off + Len) && (k0 + 16 * QT > off);
-      for (int qt = 0; qt < N; qt += 16) {
+      auto tileB = [&](int qt, auto biased) {
         const float qa = Qh[(qt + r) * 4 + g], da = Dh[(qt + r) * 4 + g];
         const float4 l4 = *reinterpret_cast<const float4*>(Ls + hl * N + qt + 4 * g);
         const float4 d4 = *reinterpret_cast<const float4*>(Dl + hl * N + qt + 4 * g);
-        const float lj[4] = {l4.x, l4.y, l4.z, l4.w}, dj[4] = {d4.x, d4.y, d4.z, d4.w};
         float4 q4[4], o4[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          q4[j] = *reinterpret_cast<const float4*>(Qh + (qt + 4 * g + j) * 4);
-          o4[j] = *reinterpret_cast<const float4*>(Dh + (qt + 4 * g + j) * 4);
-        }
-        const bool tb = kbias && (qt < off + Len) && (qt + 16 > off);
+        for (int j = 0; j < 4; ++j) { q4[j] = Q4[qt + 4 * g + j]; o4[j] = D4[qt + 4 * g + j]; }
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
-          f32x4 s = mfma4(qa, kf[t], f32x4{0.f, 0.f, 0.f, 0.f});        // S[query 4g+j][key r]
-          const f32x4 dp = mfma4(da, vf[t], f32x4{0.f, 0.f, 0.f, 0.f});  // dP[query][key]
-          if (tb) {
+          f32x4 s = mfma4(qa, kf[t], f32x4{l4.x, l4.y, l4.z, l4.w});        // S[query 4g+j][key r] - lse
+          const f32x4 dp = mfma4(da, vf[t], f32x4{d4.x, d4.y, d4.z, d4.w});  // dP[query][key] - delta
+          if constexpr (decltype(biased)::value) {
             const int ki = k0 + 16 * t + r - off;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -313,28 +325,35 @@ __global__ __launch_bounds__(512) void k_attn_bwd(const float* __restrict__ qkv,
           }
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const float p = __builtin_amdgcn_exp2f(fmaf(s[j], LOG2E, -lj[j]));
-            const float ds = p * (dp[j] - dj[j]);
-            dv[t].x = fmaf(p, o4[j].x, dv[t].x); dv[t].y = fmaf(p, o4[j].y, dv[t].y);
-            dv[t].z = fmaf(p, o4[j].z, dv[t].z); dv[t].w = fmaf(p, o4[j].w, dv[t].w);
-            dk[t].x = fmaf(ds, q4[j].x, dk[t].x); dk[t].y = fmaf(ds, q4[j].y, dk[t].y);
-            dk[t].z = fmaf(ds, q4[j].z, dk[t].z); dk[t].w = fmaf(ds, q4[j].w, dk[t].w);
+            const float p = __builtin_amdgcn_exp2f(s[j]);
+            const float ds = p * dp[j];
+            dv01[t] = pk_fma(splat2(p), f32x2{o4[j].x, o4[j].y}, dv01[t]);
+            dv23[t] = pk_fma(splat2(p), f32x2{o4[j].z, o4[j].w}, dv23[t]);
+            dk01[t] = pk_fma(splat2(ds), f32x2{q4[j].x, q4[j].y}, dk01[t]);
+            dk23[t] = pk_fma(splat2(ds), f32x2{q4[j].z, q4[j].w}, dk23[t]);
           }
         }
-      }
+      };
+      const bool kbias = table && (k0 < off + Len) && (k0 + 16 * QT > off);
+      const int e0 = kbias ? kb0 : N, e1 = kbias ? kb1 : N;
+      for (int qt = 0; qt < e0; qt += 16) tileB(qt, std::false_type{});
+      for (int qt = e0; qt < e1; qt += 16) tileB(qt, std::true_type{});
+      for (int qt = e1; qt < N; qt += 16) tileB(qt, std::false_type{});
 #pragma unroll
       for (int t = 0; t < QT; ++t) {
+        float4 vk = make_float4(dk01[t][0], dk01[t][1], dk23[t][0], dk23[t][1]);
+        float4 vv = make_float4(dv01[t][0], dv01[t][1], dv23[t][0], dv23[t][1]);
 #pragma unroll
         for (int sh = 16; sh <= 32; sh <<= 1) {
-          dk[t].x += __shfl_xor(dk[t].x, sh); dk[t].y += __shfl_xor(dk[t].y, sh);
-          dk[t].z += __shfl_xor(dk[t].z, sh); dk[t].w += __shfl_xor(dk[t].w, sh);
-          dv[t].x += __shfl_xor(dv[t].x, sh); dv[t].y += __shfl_xor(dv[t].y, sh);
-          dv[t].z += __shfl_xor(dv[t].z, sh); dv[t].w += __shfl_xor(dv[t].w, sh);
+          vk.x += __shfl_xor(vk.x, sh); vk.y += __shfl_xor(vk.y, sh);
+          vk.z += __shfl_xor(vk.z, sh); vk.w += __shfl_xor(vk.w, sh);
+          vv.x += __shfl_xor(vv.x, sh); vv.y += __shfl_xor(vv.y, sh);
+          vv.z += __shfl_xor(vv.z, sh); vv.w += __shfl_xor(vv.w, sh);
         }
         if (g == 0) {
           const size_t kk = (size_t)(h0 + hl) * N + k0 + 16 * t + r;
-          *reinterpret_cast<float4*>(dbase + ((size_t)H * N + kk) * 4) = dk[t];
-          *reinterpret_cast<float4*>(dbase + ((size_t)2 * H * N + kk) * 4) = dv[t];
+          *reinterpret_cast<float4*>(dbase + ((size_t)H * N + kk) * 4) = f4scale(vk, RAL_LN2);  // Qs carried log2(e)
+          *reinterpret_cast<float4*>(dbase + ((size_t)2 * H * N + kk) * 4) = vv;
         }
       }
     }

@@ -7,6 +7,7 @@
 //   PatchMerging / PatchSeparate  model/raletransformer.py:411-459
 #include "ral_device.hpp"
 #include "ral_kernels.hpp"
+#include <type_traits>
 
 // =================================================================================
 // K1: h = LN1(x*sqrt(C) + PE);  [q|k|v] = h Wqkv^T + b;  q *= 0.5  ->  qkv (HM layout)
@@ -43,12 +44,25 @@ __global__ __launch_bounds__(256) void k_qkv_fwd(const float* __restrict__ x, co
 }
 
 // =================================================================================
-// K2: softmax(q k^T + bias) v per (window, head); full N x N, head_dim 4, two sweeps
-// (row max, then exp / sum / P.V) so nothing N x N is ever stored.  S^T tiles come from
-// the fp32 MFMA with the KEY on the row and the QUERY on the lane column: a lane owns
-// one query and four keys per tile, so P.V and the row sums accumulate lane-privately
-// on the VALU and are folded across the four lane groups once per query block.
+// K2: softmax(q k^T + bias) v per (window, head); full N x N, head_dim 4.  Nothing
+// N x N is ever stored.  S^T tiles come from the fp32 MFMA with the KEY on the row and
+// the QUERY on the lane column: a lane owns one query and four keys per tile, so the
+// whole online-softmax state (running max, row sum, P.V) is LANE-PRIVATE on the VALU
+// (packed fp32 math) and the four lane groups of a query are merged once per block.
+// q is pre-multiplied by log2(e) when staged, so p = exp2(s - m) needs no scaling.
 // =================================================================================
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+RAL_DEV f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+RAL_DEV f32x2 splat2(float v) { return f32x2{v, v}; }
+#define RAL_LOG2E 1.4426950408889634f
+#define RAL_LN2 0.6931471805599453f
+
+// Softmax shift without a running maximum: softmax is invariant to any per-row shift, and
+//   s[q][k] = q.k + bias <= |q| max_k |k| + max(bias, 0) =: m[q]   (Cauchy-Schwarz)
+// is known before the sweep.  -m[q] is fed to the MFMA as its C operand, so the tile comes out
+// as s - m <= 0 ready for exp2 with no VALU subtract, no max and no rescale.  If a row's bound is
+// so loose that every term underflows (row sum < 1e-30) the task is redone with the exact
+// running-max recurrence (never seen on real data; exercised by tests/test_gpu_parity.py).
 template <int QT>
 __global__ __launch_bounds__(512) void k_attn_fwd(const float* __restrict__ qkv, float* __restrict__ o_hm,
                                                   float* __restrict__ lse, const float* __restrict__ table,
@@ -57,71 +71,62 @@ __global__ __launch_bounds__(512) void k_attn_fwd(const float* __restrict__ qkv,
   float* Qs = reinterpret_cast<float*>(smem4);
   float* Ks = Qs + HG * N * 4;
   float* Vs = Ks + HG * N * 4;
-  float* tab = Vs + HG * N * 4;  // (2Len-1) x HG
+  float* Mq = Vs + HG * N * 4;                  // HG*N : |q| (log2 units)
+  int* Kmax = reinterpret_cast<int*>(Mq + HG * N);  // HG : max |k|^2 as float bits
+  float* tab = reinterpret_cast<float*>(Kmax + HG + 4);  // (2Len-1) x HG, times log2(e)
+  float* Bmax = tab + (table ? (2 * Len - 1) * HG : 0);   // HG : max(bias, 0)
   const int ngrp = H / HG;
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
   const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int off = (N - Len) >> 1;
-  const float LOG2E = 1.4426950408889634f;
+  const int kb0 = table ? (off & ~15) : N, kb1 = table ? ((off + Len + 15) & ~15) : N;  // biased key tiles
   for (int item = blockIdx.x; item < B * ngrp; item += gridDim.x) {
     const int win = item / ngrp, h0 = (item - win * ngrp) * HG;
     const float* base = qkv + (size_t)win * 3 * H * N * 4;
-    copy_flat(Qs, base + (size_t)h0 * N * 4, HG * N);
-    copy_flat(Ks, base + (size_t)(H + h0) * N * 4, HG * N);
-    copy_flat(Vs, base + (size_t)(2 * H + h0) * N * 4, HG * N);
+    if ((int)threadIdx.x < HG) { Kmax[threadIdx.x] = 0; if (table) Bmax[threadIdx.x] = 0.f; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < HG * N; i += blockDim.x) {
+      const float4 q = f4scale(reinterpret_cast<const float4*>(base + (size_t)h0 * N * 4)[i], RAL_LOG2E);
+      const float4 k = reinterpret_cast<const float4*>(base + (size_t)(H + h0) * N * 4)[i];
+      reinterpret_cast<float4*>(Qs)[i] = q;
+      reinterpret_cast<float4*>(Ks)[i] = k;
+      reinterpret_cast<float4*>(Vs)[i] = reinterpret_cast<const float4*>(base + (size_t)(2 * H + h0) * N * 4)[i];
+      Mq[i] = sqrtf(f4dot(q, q));
+      atomicMax(Kmax + i / N, __float_as_int(f4dot(k, k)));   // non-negative floats order like ints
+    }
     if (table)
-      for (int i = threadIdx.x; i < (2 * Len - 1) * HG; i += blockDim.x)
-        tab[i] = table[(i / HG) * H + h0 + (i % HG)];
+      for (int i = threadIdx.x; i < (2 * Len - 1) * HG; i += blockDim.x) {
+        const float t = table[(i / HG) * H + h0 + (i % HG)] * RAL_LOG2E;
+        tab[i] = t;
+        if (t > 0.f) atomicMax(reinterpret_cast<int*>(Bmax) + i % HG, __float_as_int(t));
+      }
     __syncthreads();
     const int qblocks = N / (16 * QT);
     for (int task = wave; task < HG * qblocks; task += nw) {
       const int hl = task / qblocks, q0 = (task - hl * qblocks) * 16 * QT;
       const float* Qh = Qs + hl * N * 4;
       const float* Kh = Ks + hl * N * 4;
-      const float* Vh = Vs + hl * N * 4;
-      float qf[QT], mx[QT], l[QT];
-      float4 o[QT];
+      const float4* Vh = reinterpret_cast<const float4*>(Vs + hl * N * 4);
+      const float kmx = sqrtf(__int_as_float(Kmax[hl])) * 1.0000002f;
+      float qf[QT], mq[QT];
+      f32x2 l2[QT], o01[QT], o23[QT];
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {
-        qf[qt] = Qh[(q0 + 16 * qt + r) * 4 + g];
-        mx[qt] = -3.0e38f; l[qt] = 0.f; o[qt] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int q = q0 + 16 * qt + r;
+        qf[qt] = Qh[q * 4 + g];
+        mq[qt] = Mq[hl * N + q] * kmx + (table ? Bmax[hl] : 0.f);
+        l2[qt] = f32x2{0.f, 0.f}; o01[qt] = f32x2{0.f, 0.f}; o23[qt] = f32x2{0.f, 0.f};
       }
-      // does any query of this task fall inside the centred R-wave window?
-      const bool qbias = table && (q0 < off + Len) && (q0 + 16 * QT > off);
-      // ---- sweep 1: row maxima ----
-      for (int kt = 0; kt < N; kt += 16) {
-        const float kf = Kh[(kt + r) * 4 + g];
-        const bool tb = qbias && (kt < off + Len) && (kt + 16 > off);
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-          f32x4 s = mfma4(kf, qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});
-          if (tb) {
-            const int qi = q0 + 16 * qt + r - off;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int ki = kt + 4 * g + j - off;
-              if (qi >= 0 && qi < Len && ki >= 0 && ki < Len) s[j] += tab[(qi - ki + Len - 1) * HG + hl];
-            }
-          }
-          mx[qt] = fmaxf(mx[qt], fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])));
-        }
-      }
-#pragma unroll
-      for (int qt = 0; qt < QT; ++qt) {
-        mx[qt] = fmaxf(mx[qt], __shfl_xor(mx[qt], 16));
-        mx[qt] = fmaxf(mx[qt], __shfl_xor(mx[qt], 32));
-      }
-      // ---- sweep 2: p = exp(s - max), l = sum p, o = sum p v ----
-      for (int kt = 0; kt < N; kt += 16) {
+      auto tile = [&](int kt, auto biased) {
         const float kf = Kh[(kt + r) * 4 + g];
         float4 v4[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v4[j] = *reinterpret_cast<const float4*>(Vh + (kt + 4 * g + j) * 4);
-        const bool tb = qbias && (kt < off + Len) && (kt + 16 > off);
+        for (int j = 0; j < 4; ++j) v4[j] = Vh[kt + 4 * g + j];
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
-          f32x4 s = mfma4(kf, qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});
-          if (tb) {
+          const float nm = -mq[qt];
+          f32x4 s = mfma4(kf, qf[qt], f32x4{nm, nm, nm, nm});   // s - m, log2 units
+          if constexpr (decltype(biased)::value) {
             const int qi = q0 + 16 * qt + r - off;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -129,34 +134,89 @@ __global__ __launch_bounds__(512) void k_attn_fwd(const float* __restrict__ qkv,
               if (qi >= 0 && qi < Len && ki >= 0 && ki < Len) s[j] += tab[(qi - ki + Len - 1) * HG + hl];
             }
           }
-          const float nm = -mx[qt] * LOG2E;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float p = __builtin_amdgcn_exp2f(fmaf(s[j], LOG2E, nm));
-            l[qt] += p;
-            o[qt].x = fmaf(p, v4[j].x, o[qt].x);
-            o[qt].y = fmaf(p, v4[j].y, o[qt].y);
-            o[qt].z = fmaf(p, v4[j].z, o[qt].z);
-            o[qt].w = fmaf(p, v4[j].w, o[qt].w);
-          }
+          const f32x2 p01 = f32x2{__builtin_amdgcn_exp2f(s[0]), __builtin_amdgcn_exp2f(s[1])};
+          const f32x2 p23 = f32x2{__builtin_amdgcn_exp2f(s[2]), __builtin_amdgcn_exp2f(s[3])};
+          l2[qt] += p01;
+          l2[qt] += p23;
+          o01[qt] = pk_fma(splat2(p01[0]), f32x2{v4[0].x, v4[0].y}, o01[qt]);
+          o23[qt] = pk_fma(splat2(p01[0]), f32x2{v4[0].z, v4[0].w}, o23[qt]);
+          o01[qt] = pk_fma(splat2(p01[1]), f32x2{v4[1].x, v4[1].y}, o01[qt]);
+          o23[qt] = pk_fma(splat2(p01[1]), f32x2{v4[1].z, v4[1].w}, o23[qt]);
+          o01[qt] = pk_fma(splat2(p23[0]), f32x2{v4[2].x, v4[2].y}, o01[qt]);
+          o23[qt] = pk_fma(splat2(p23[0]), f32x2{v4[2].z, v4[2].w}, o23[qt]);
+          o01[qt] = pk_fma(splat2(p23[1]), f32x2{v4[3].x, v4[3].y}, o01[qt]);
+          o23[qt] = pk_fma(splat2(p23[1]), f32x2{v4[3].z, v4[3].w}, o23[qt]);
         }
-      }
+      };
+      // only query blocks that touch the centred R-wave window take the biased key tiles
+      const bool qbias = table && (q0 < off + Len) && (q0 + 16 * QT > off);
+      const int e0 = qbias ? kb0 : N, e1 = qbias ? kb1 : N;
+      for (int kt = 0; kt < e0; kt += 16) tile(kt, std::false_type{});
+      for (int kt = e0; kt < e1; kt += 16) tile(kt, std::true_type{});
+      for (int kt = e1; kt < N; kt += 16) tile(kt, std::false_type{});
+      bool redo = false;
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {
+        float lv = l2[qt][0] + l2[qt][1];
+        float4 ov = make_float4(o01[qt][0], o01[qt][1], o23[qt][0], o23[qt][1]);
 #pragma unroll
         for (int sh = 16; sh <= 32; sh <<= 1) {
-          l[qt] += __shfl_xor(l[qt], sh);
-          o[qt].x += __shfl_xor(o[qt].x, sh);
-          o[qt].y += __shfl_xor(o[qt].y, sh);
-          o[qt].z += __shfl_xor(o[qt].z, sh);
-          o[qt].w += __shfl_xor(o[qt].w, sh);
+          lv += __shfl_xor(lv, sh);
+          ov.x += __shfl_xor(ov.x, sh); ov.y += __shfl_xor(ov.y, sh);
+          ov.z += __shfl_xor(ov.z, sh); ov.w += __shfl_xor(ov.w, sh);
         }
+        redo = redo || !(lv > 1e-30f);
         if (g == 0) {
-          const float inv = 1.0f / l[qt];
+          const float inv = 1.0f / lv;
           const int q = q0 + 16 * qt + r;
           const size_t hq = ((size_t)win * H + h0 + hl) * N + q;
-          *reinterpret_cast<float4*>(o_hm + hq * 4) = f4scale(o[qt], inv);
-          if (lse) lse[hq] = mx[qt] + logf(l[qt]);
+          *reinterpret_cast<float4*>(o_hm + hq * 4) = f4scale(ov, inv);
+          if (lse) lse[hq] = (mq[qt] + __builtin_amdgcn_logf(lv)) * RAL_LN2;   // natural-log units
+        }
+      }
+      if (__any(redo)) {   // exact running-max recurrence (lane-private state, merged at the end)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+          float mx = -INFINITY, l = 0.f;
+          float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+          const int qi = q0 + 16 * qt + r - off;
+          for (int kt = 0; kt < N; kt += 16) {
+            f32x4 s = mfma4(Kh[(kt + r) * 4 + g], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});
+            if (table) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const int ki = kt + 4 * g + j - off;
+                if (qi >= 0 && qi < Len && ki >= 0 && ki < Len) s[j] += tab[(qi - ki + Len - 1) * HG + hl];
+              }
+            }
+            const float mn = fmaxf(fmaxf(mx, fmaxf(s[0], s[1])), fmaxf(s[2], s[3]));
+            const float corr = __builtin_amdgcn_exp2f(mx - mn);
+            mx = mn;
+            l *= corr; o = f4scale(o, corr);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float p = __builtin_amdgcn_exp2f(s[j] - mn);
+              const float4 v = Vh[kt + 4 * g + j];
+              l += p;
+              o.x = fmaf(p, v.x, o.x); o.y = fmaf(p, v.y, o.y); o.z = fmaf(p, v.z, o.z); o.w = fmaf(p, v.w, o.w);
+            }
+          }
+          float mg = fmaxf(mx, __shfl_xor(mx, 16));
+          mg = fmaxf(mg, __shfl_xor(mg, 32));
+          const float sc = __builtin_amdgcn_exp2f(mx - mg);
+          l *= sc; o = f4scale(o, sc);
+#pragma unroll
+          for (int sh = 16; sh <= 32; sh <<= 1) {
+            l += __shfl_xor(l, sh);
+            o.x += __shfl_xor(o.x, sh); o.y += __shfl_xor(o.y, sh);
+            o.z += __shfl_xor(o.z, sh); o.w += __shfl_xor(o.w, sh);
+          }
+          if (g == 0) {
+            const int q = q0 + 16 * qt + r;
+            const size_t hq = ((size_t)win * H + h0 + hl) * N + q;
+            *reinterpret_cast<float4*>(o_hm + hq * 4) = f4scale(o, 1.0f / l);
+            if (lse) lse[hq] = (mg + __builtin_amdgcn_logf(l)) * RAL_LN2;
+          }
         }
       }
     }
@@ -308,16 +368,21 @@ void launch_qkv_fwd(int C, const float* x, const float* pe, const BlockP& w, flo
   }
 }
 
-size_t attn_fwd_lds(int N, int HG, int Len) { return ((size_t)3 * HG * N * 4 + (size_t)(2 * Len - 1) * HG + 4) * sizeof(float); }
+size_t attn_fwd_lds(int N, int HG, int Len) {
+  return ((size_t)3 * HG * N * 4 + (size_t)HG * N + 2 * HG + 8 + (Len > 0 ? (size_t)(2 * Len - 1) * HG : 0)) * sizeof(float);
+}
 
 void launch_attn_fwd(const float* qkv, float* o_hm, float* lse, const float* table, int N, int H, int HG, int Len,
                      int B, hipStream_t s) {
   const size_t lds = attn_fwd_lds(N, HG, Len);
   const int items = B * (H / HG);
-  if (N % 32 == 0)
+  if (N % 32 == 0) {
+    RAL_SET_LDS((k_attn_fwd<2>), lds);
     k_attn_fwd<2><<<grid_for(items), 512, lds, s>>>(qkv, o_hm, lse, table, N, H, HG, Len, B);
-  else
+  } else {
+    RAL_SET_LDS((k_attn_fwd<1>), lds);
     k_attn_fwd<1><<<grid_for(items), 512, lds, s>>>(qkv, o_hm, lse, table, N, H, HG, Len, B);
+  }
 }
 
 size_t mlp_fwd_lds(int C, int N, int nch) {
@@ -328,9 +393,9 @@ template <int C>
 static void launch_mlp_fwd_c(int nch, const float* x, const float* o, const BlockP& w, float* x1, float* upre,
                              float* x2, int N, int B, hipStream_t s) {
   const size_t lds = mlp_fwd_lds(C, N, nch);
-  if (nch == 1) k_mlp_fwd<C, 1><<<grid_for(B), 512, lds, s>>>(x, o, w, x1, upre, x2, N, B);
-  else if (nch == 2) k_mlp_fwd<C, 2><<<grid_for(B), 512, lds, s>>>(x, o, w, x1, upre, x2, N, B);
-  else k_mlp_fwd<C, 4><<<grid_for(B), 512, lds, s>>>(x, o, w, x1, upre, x2, N, B);
+  if (nch == 1) { RAL_SET_LDS((k_mlp_fwd<C, 1>), lds); k_mlp_fwd<C, 1><<<grid_for(B), 512, lds, s>>>(x, o, w, x1, upre, x2, N, B); }
+  else if (nch == 2) { RAL_SET_LDS((k_mlp_fwd<C, 2>), lds); k_mlp_fwd<C, 2><<<grid_for(B), 512, lds, s>>>(x, o, w, x1, upre, x2, N, B); }
+  else { RAL_SET_LDS((k_mlp_fwd<C, 4>), lds); k_mlp_fwd<C, 4><<<grid_for(B), 512, lds, s>>>(x, o, w, x1, upre, x2, N, B); }
 }
 
 void launch_mlp_fwd(int C, int nch, const float* x, const float* o, const BlockP& w, float* x1, float* upre,
