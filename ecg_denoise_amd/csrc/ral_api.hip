@@ -477,7 +477,7 @@ static int bwd_end(RalModel* m, float* dx, int B, int64_t global_windows, hipStr
   launch_conv1_bwd(m->cfg.leads, m->gA, m->a0, m->last_x, m->ss, m->params + Y.bn_w, m->bn_sums + 32,
                    (double)global_windows * m->L, m->grads + Y.conv1_w, m->grads + Y.conv1_b, dx ? m->dz0 : nullptr,
                    m->L, B, s);
-  launch_bn_affine_grads(m->bn_sums + 32, m->grads + Y.bn_w, m->grads + Y.bn_b, 8, s);
+  launch_bn_affine_grads(m->bn_sums + 32, m->grads + Y.bn_w, m->grads + Y.bn_b, 8, (double)B / (double)global_windows, s);
   if (dx) launch_conv1_bwd_dx(m->cfg.leads, m->dz0, m->params + Y.conv1_w, dx, m->L, B, s);
   HIP_OK(hipGetLastError());
   return 0;

@@ -689,9 +689,12 @@ __global__ __launch_bounds__(256) void k_conv1_bwd(const float* __restrict__ dy,
 }
 
 // BatchNorm affine grads from the (all-reduced) backward sums: g_w += sum dy*xhat, g_b += sum dy
-__global__ void k_bn_affine_grads(const double* __restrict__ bst, float* __restrict__ gw, float* __restrict__ gb, int nch) {
+// `share` = this rank's fraction of the global batch: the sums are already all-reduced, and the gradient
+// all-reduce (sum over ranks) that follows must reproduce them exactly once.
+__global__ void k_bn_affine_grads(const double* __restrict__ bst, float* __restrict__ gw, float* __restrict__ gb, int nch,
+                                  double share) {
   const int c = threadIdx.x;
-  if (c < nch) { gb[c] += (float)bst[c]; gw[c] += (float)bst[nch + c]; }
+  if (c < nch) { gb[c] += (float)(bst[c] * share); gw[c] += (float)(bst[nch + c] * share); }
 }
 
 // dx[b][c][l] = sum_o sum_k w[o][c][k] dz[b][l-k+1][o]   (input gradient of the stem, 12-lead adapter only)
@@ -811,8 +814,8 @@ void launch_conv1_bwd(int leads, const float* dy, const float* a0, const float* 
   else k_conv1_bwd<2><<<grid, 256, 0, s>>>(dy, a0, x, ss, bnw, bst, count, gw, gb, dz, L, B);
 }
 
-void launch_bn_affine_grads(const double* bst, float* gw, float* gb, int nch, hipStream_t s) {
-  k_bn_affine_grads<<<1, 64, 0, s>>>(bst, gw, gb, nch);
+void launch_bn_affine_grads(const double* bst, float* gw, float* gb, int nch, double share, hipStream_t s) {
+  k_bn_affine_grads<<<1, 64, 0, s>>>(bst, gw, gb, nch, share);
 }
 
 void launch_conv1_bwd_dx(int leads, const float* dz, const float* w, float* dx, int L, int B, hipStream_t s) {

@@ -58,7 +58,7 @@ void launch_final_bwd(int leads, const float* dy, const float* u0, const float* 
 void launch_bn8_bwd_stats(const float* dy, const float* a0, const float* ss, double* out, size_t ntok, hipStream_t s);
 void launch_conv1_bwd(int leads, const float* dy, const float* a0, const float* x, const float* ss, const float* bnw,
                       const double* bst, double count, float* gw, float* gb, float* dz, int L, int B, hipStream_t s);
-void launch_bn_affine_grads(const double* bst, float* gw, float* gb, int nch, hipStream_t s);
+void launch_bn_affine_grads(const double* bst, float* gw, float* gb, int nch, double share, hipStream_t s);
 void launch_conv1_bwd_dx(int leads, const float* dz, const float* w, float* dx, int L, int B, hipStream_t s);
 
 // ---- weight gradients (ral_dw.hip)

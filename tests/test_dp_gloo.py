@@ -1,0 +1,155 @@
+"""Data-parallel host logic on CPU: world_size-2 `gloo` processes driving the trainer of
+ecg_denoise_amd/dp.py with a CPU stand-in engine (built from the oracle, split at the two
+BatchNorm reduction points exactly like the C ABI) must reproduce the single-process step
+on the concatenated batch: same loss, same gradients, same parameters after Adam."""
+import os
+import sys
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn.functional as F
+
+import ralenet_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleEngine:
+    """Same call surface as dp.HipEngineAdapter; fp64 torch-CPU arithmetic."""
+
+    def __init__(self, variant, leads, seed):
+        self.variant = variant
+        self.p = OrderedDict((k, v.double()) for k, v in O.init_params(O.ralenet_param_shapes(variant, leads), seed).items())
+        self.m = OrderedDict((k, torch.zeros_like(v)) for k, v in self.p.items())
+        self.v = OrderedDict((k, torch.zeros_like(v)) for k, v in self.p.items())
+        self.bn_sums = torch.zeros(64, dtype=torch.float64)
+        n = sum(v.numel() for v in self.p.values())
+        self.grads = torch.zeros(n, dtype=torch.float64)
+        self.step = 0
+        self.running = O.new_bn_state(8, torch.float64)
+
+    def forward_begin(self, x):
+        self.x = x.double()
+        self.leaf = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in self.p.items())
+        a = F.leaky_relu(F.conv1d(self.x, self.leaf["conv1.0.weight"], self.leaf["conv1.0.bias"], padding=1), 0.2)
+        self.a0 = a
+        self.bn_sums[:8] = a.detach().sum((0, 2)); self.bn_sums[8:16] = (a.detach() ** 2).sum((0, 2))
+
+    def forward_end(self, G):
+        cnt = G * self.x.shape[2]
+        mean = self.bn_sums[:8] / cnt
+        var = self.bn_sums[8:16] / cnt - mean ** 2
+        self.mean, self.rstd, self.cnt = mean, 1.0 / torch.sqrt(var + 1e-5), cnt
+        # x0 as a LEAF: the global-statistics BatchNorm backward is applied by hand in backward_end
+        xhat = (self.a0.detach() - mean[None, :, None]) * self.rstd[None, :, None]
+        self.xhat = xhat
+        self.x0 = (xhat * self.p["conv1.2.weight"][None, :, None] + self.p["conv1.2.bias"][None, :, None]).requires_grad_(True)
+        p = dict(self.leaf)
+        self.pred = _rest_of_network(p, self.x0, self.variant)
+        return self.pred.detach()
+
+    def loss(self, pred, target, G):
+        n = target[0].numel()
+        self.l = ((self.pred - target.double()) ** 2).sum() / (G * n)
+        return self.l.detach().reshape(1), O.snr(target.double(), pred), O.rmse(target.double(), pred)
+
+    def backward_begin(self):
+        names = [k for k in self.leaf if not k.startswith("conv1.")]
+        gs = torch.autograd.grad(self.l, [self.x0] + [self.leaf[k] for k in names], allow_unused=True)
+        self.gx0 = gs[0]
+        self.gdict = {k: (g if g is not None else torch.zeros_like(self.leaf[k])) for k, g in zip(names, gs[1:])}
+        self.bn_sums[32:40] = self.gx0.sum((0, 2)); self.bn_sums[40:48] = (self.gx0 * self.xhat).sum((0, 2))
+
+    def backward_end(self, G):
+        gam = self.p["conv1.2.weight"]
+        s1, s2 = self.bn_sums[32:40] / self.cnt, self.bn_sums[40:48] / self.cnt
+        da = gam[None, :, None] * self.rstd[None, :, None] * (self.gx0 - s1[None, :, None] - self.xhat * s2[None, :, None])
+        gw, gb = torch.autograd.grad(self.a0, [self.leaf["conv1.0.weight"], self.leaf["conv1.0.bias"]], da)
+        self.gdict["conv1.0.weight"], self.gdict["conv1.0.bias"] = gw, gb
+        # affine grads use the ALL-REDUCED sums on every rank; the later gradient all-reduce (sum) would
+        # count them world_size times, so each rank contributes its 1/world share
+        w = dist.get_world_size() if dist.is_initialized() else 1
+        self.gdict["conv1.2.weight"] = self.bn_sums[40:48].clone() / w
+        self.gdict["conv1.2.bias"] = self.bn_sums[32:40].clone() / w
+        self.grads.copy_(torch.cat([self.gdict[k].reshape(-1) for k in self.p]))
+
+    def adam(self, lr):
+        self.step += 1
+        off = 0
+        g = OrderedDict()
+        for k, v in self.p.items():
+            g[k] = self.grads[off:off + v.numel()].view_as(v); off += v.numel()
+        O.adam_step(self.p, g, self.m, self.v, self.step, lr)
+
+
+def _rest_of_network(p, x0, variant):
+    """ralenet_forward from the BatchNorm output on (same code path as the oracle)."""
+    le, rw, _ = O.variant_flags(variant)
+    L = x0.shape[2]
+    biases = [None] * 5
+    if rw:
+        for i, ln in enumerate(O.RW_LEN):
+            biases[i + 1] = O.rwave_bias(p[f"rwattn{i+1}.relative_position_bias_table"], ln, L >> i)
+
+    def stage(t, name, rwi):
+        for i in range(2):
+            t = O.transformer_block(t, p, O.block_prefix(variant, name, i), le, biases[rwi] if rwi else None)
+        return t
+    t = x0.permute(0, 2, 1)
+    x1 = O.patch_merge(stage(t, "dtransformer1", 1), p, "pm1")
+    x2 = O.patch_merge(stage(x1, "dtransformer2", 2), p, "pm2")
+    x3 = O.patch_merge(stage(x2, "dtransformer3", 3), p, "pm3")
+    x4 = O.patch_merge(stage(x3, "dtransformer34", 4), p, "pm4")
+    xm = stage(x4, "transformer", 0) + x4
+    d = O.patch_separate(stage(xm, "utransformer4", 0), p, "ps4") + x3
+    d = O.patch_separate(stage(d, "utranformer3", 4), p, "ps3") + x2
+    d = O.patch_separate(stage(d, "utransformer2", 3), p, "ps2") + x1
+    d = O.patch_separate(stage(d, "utransformer1", 2), p, "ps1")
+    d = d.permute(0, 2, 1) + x0
+    return F.conv1d(d, p["transconv.0.weight"], p["transconv.0.bias"], padding=1)
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from ecg_denoise_amd.dp import DataParallelTrainer
+    torch.set_num_threads(2)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(4, 2, 256, generator=g); y = torch.randn(4, 2, 256, generator=g)
+    eng = OracleEngine("full", 2, 1234)
+    tr = DataParallelTrainer(eng)
+    sh = slice(rank * 2, rank * 2 + 2)
+    losses = [tr.train_step(x[sh], y[sh])["loss"].item() for _ in range(2)]
+    if rank == 0:
+        q.put((losses, {k: v.numpy() for k, v in eng.p.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one_process_on_the_concatenated_batch():
+    torch.set_num_threads(4)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(4, 2, 256, generator=g); y = torch.randn(4, 2, 256, generator=g)
+    # single process reference: plain oracle train steps (fp64)
+    p = OrderedDict((k, v.double()) for k, v in O.init_params(O.ralenet_param_shapes("full", 2), 1234).items())
+    m = OrderedDict((k, torch.zeros_like(v)) for k, v in p.items()); v = OrderedDict((k, torch.zeros_like(t)) for k, t in p.items())
+    bn = O.new_bn_state(8, torch.float64)
+    fwd = lambda pp, xx: O.ralenet_forward(pp, xx, "full", True, bn)
+    ref_losses = [O.train_step(p, x.double(), y.double(), fwd, m, v, s)["loss"].item() for s in (1, 2)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    [pr.start() for pr in procs]
+    losses, params = q.get(timeout=600)
+    [pr.join(60) for pr in procs]
+    np.testing.assert_allclose(losses, ref_losses, rtol=1e-9)
+    for k in p:
+        if k.endswith("to_kv.bias"):
+            continue   # key-bias gradient is pure rounding noise (softmax shift invariance)
+        np.testing.assert_allclose(params[k], p[k].numpy(), rtol=1e-6, atol=1e-9, err_msg=k)
