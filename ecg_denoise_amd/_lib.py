@@ -46,6 +46,7 @@ _SIGS = {
     "ral_param_floats": (C.c_int64, [C.POINTER(RalConfig)]),
     "ral_state_floats": (C.c_int64, [C.POINTER(RalConfig)]),
     "ral_workspace_bytes": (C.c_int64, [C.POINTER(RalConfig)]),
+    "ral_bn_sums_doubles": (C.c_int64, [C.POINTER(RalConfig)]),
     "ral_create": (C.c_int, [C.POINTER(RalConfig), C.POINTER(_VP)]),
     "ral_destroy": (C.c_int, [_VP]),
     "ral_bind": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP]),

@@ -525,6 +525,11 @@ int64_t ral_state_floats(const ral_config* cfg) {
   return 16;
 }
 
+int64_t ral_bn_sums_doubles(const ral_config* cfg) {
+  if (check_cfg(cfg)) return -1;
+  return cfg->variant == RAL_UNET ? 1280 : 64;
+}
+
 int64_t ral_workspace_bytes(const ral_config* cfg) {
   if (check_cfg(cfg)) return -1;
   if (cfg->variant == RAL_UNET) return unet_workspace_bytes(cfg);

@@ -47,7 +47,7 @@ class _Engine:
             self.grads = z(self.nparam) if train else None
             self.adam_m = z(self.nparam) if train else None
             self.adam_v = z(self.nparam) if train else None
-            self.bn_sums = z(64 * max(1, self.nstate // 16), torch.float64) if train else None
+            self.bn_sums = z(L_.ral_bn_sums_doubles(C.byref(self.cfg)), torch.float64) if train else None
             h = C.c_void_p()
             _lib.check(L_.ral_create(C.byref(self.cfg), C.byref(h)))
             self.h = h
@@ -266,6 +266,14 @@ class RALENet(_ModuleBase):
         if variant not in ("nra", "full", "mlp"):
             raise _lib.RalError(f"unknown RA-LENet variant {variant!r}")
         super().__init__(variant, leads, L, max_batch, train, device, seed)
+
+
+class UNet(_ModuleBase):
+    """model/UNet.py::UNet (main.py:63-65): conv U-Net baseline, BatchNorm after every conv
+    (the reference's LazyBatchNorm1d materialised eagerly, quirk A15)."""
+
+    def __init__(self, leads=2, L=512, max_batch=32, train=True, device="cuda:0", seed=None):
+        super().__init__("unet", leads, L, max_batch, train, device, seed)
 
 
 def ralenet(high_level_enhence=False, low_level_enhence=True, **kw):

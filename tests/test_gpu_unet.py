@@ -1,0 +1,87 @@
+"""U-Net baseline (reference model/UNet.py) on the HIP path vs the oracle and the golden vectors."""
+import os
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+import ralenet_oracle as O
+from parity_util import rel
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _run(leads, L, B, seed=1234):
+    from ecg_denoise_amd import UNet
+    p32 = O.init_params(O.unet_param_shapes(leads), seed)
+    g = torch.Generator().manual_seed(2023)
+    x = torch.randn(B, leads, L, generator=g); tgt = torch.randn(B, leads, L, generator=g)
+    m = UNet(leads=leads, L=L, max_batch=B, device=DEV)
+    m.load_state_dict(p32, strict=False)
+    m.train()
+    y = m(x.to(DEV))
+    loss, snr, rmse = m.loss_and_metrics(y, tgt.to(DEV))
+    m.backward()
+    torch.cuda.synchronize()
+    p = OrderedDict((k, v.double().requires_grad_(True)) for k, v in p32.items())
+    bn = O.unet_bn_state(p, torch.float64)
+    yo = O.unet_forward(p, x.double(), True, bn)
+    lo = O.mse(yo, tgt.double())
+    grads = torch.autograd.grad(lo, list(p.values()))
+    return m, y, loss, p, bn, yo, lo, grads, x, tgt
+
+
+@pytest.mark.parametrize("leads,L,B", [(2, 512, 4), (1, 256, 3), (2, 1024, 2)])
+def test_unet_train_step_matches_oracle(leads, L, B):
+    m, y, loss, p, bn, yo, lo, grads, x, tgt = _run(leads, L, B)
+    assert rel(y.cpu().numpy(), yo.detach().numpy()) < 1e-5
+    assert abs(loss.item() - lo.item()) < 1e-5 * abs(lo.item())
+    ng = m.named_grads()
+    bad = {}
+    for (k, _), g in zip(p.items(), grads):
+        e = rel(ng[k].cpu().numpy(), g.numpy())
+        # conv biases feeding a BatchNorm have an exactly-zero gradient: bounded by rounding noise
+        if g.norm().item() < 1e-9:
+            e = float(np.abs(ng[k].cpu().numpy()).max())
+            if e > 2e-5:
+                bad[k] = e
+        elif e > 1e-4:
+            bad[k] = e
+    assert not bad, bad
+    sd = m.state_dict()
+    for k in O.UNET_BN:
+        np.testing.assert_allclose(sd[k + ".running_mean"].cpu().numpy(), bn[k]["running_mean"].numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(sd[k + ".running_var"].cpu().numpy(), bn[k]["running_var"].numpy(), rtol=1e-5, atol=1e-6)
+    m.eval()
+    with torch.no_grad():
+        ye = O.unet_forward(OrderedDict((k, v.detach()) for k, v in p.items()), x.double(), False, bn)
+    assert rel(m(x.to(DEV)).cpu().numpy(), ye.numpy()) < 1e-5
+
+
+def test_unet_against_reference_golden(golden_dir):
+    from ecg_denoise_amd import UNet
+    g = np.load(os.path.join(golden_dir, "g3_unet_l2_L512.npz"))
+    p = O.init_params(O.unet_param_shapes(2), 1234)
+    x = torch.tensor(g["x"]).to(DEV); tgt = torch.tensor(g["target"]).to(DEV)
+    m = UNet(leads=2, L=512, max_batch=4, device=DEV)
+    m.load_state_dict(p, strict=False)
+    assert [k for k, _ in m.named_parameters()] == [str(k) for k in g["keys"]]
+    m.train()
+    y = m(x)
+    assert rel(y.cpu().numpy(), g["y_train"]) < 1e-5
+    loss, _, _ = m.loss_and_metrics(y, tgt)
+    m.backward()
+    ng = m.named_grads()
+    keys = [str(k) for k in g["keys"]]
+    gn = np.array([ng[k].double().norm().item() for k in keys])
+    ok = g["grad_norm"] > 1e-5   # conv biases in front of a BatchNorm: exactly-zero gradient, rounding noise
+    np.testing.assert_allclose(gn[ok], g["grad_norm"][ok], rtol=2e-4)
+    m.eval()
+    assert rel(m(x).cpu().numpy(), g["y_eval"]) < 1e-5
+    m2 = UNet(leads=2, L=512, max_batch=4, device=DEV)
+    m2.load_state_dict(p, strict=False)
+    m2.train()
+    losses = [m2.train_step(x, tgt)["loss"].item() for _ in range(3)]
+    np.testing.assert_allclose(losses, g["adam_losses"], rtol=5e-4)
