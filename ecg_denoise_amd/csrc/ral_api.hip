@@ -692,6 +692,28 @@ int ral_profile_read(ral_handle* h, double* total_ms, int64_t* launches) {
   return 0;
 }
 
+int ral_conv13_forward(const float* x, const float* w, const float* b, float* y, int B, int cin, int cout, int L,
+                       int lrelu, ral_stream s) {
+  if (launch_conv13_fwd(x, w, b, y, B, cin, cout, L, lrelu, (hipStream_t)s)) return fail("conv13: unsupported channel counts %d -> %d", cin, cout);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int ral_conv13_backward(const float* x, const float* y, const float* dy, const float* w, float* gw, float* gb,
+                        float* dx, int B, int cin, int cout, int L, int lrelu, ral_stream s) {
+  if (launch_conv13_bwd(x, y, dy, w, gw, gb, dx, B, cin, cout, L, lrelu, (hipStream_t)s)) return fail("conv13: unsupported channel counts %d -> %d", cin, cout);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int ral_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                  double eps, int step, float grad_scale, ral_stream s) {
+  if (n % 4) return fail("flat Adam needs a multiple of 4 floats");
+  launch_adam(p, g, m, v, (size_t)n, lr, beta1, beta2, eps, step, grad_scale, (hipStream_t)s);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
 int ral_debug_tensor(ral_handle* h, const char* name, float** ptr, int64_t* numel) {
   if (!h || h->kind != 0) return fail("no debug tensors for this handle");
   auto it = h->m->dbg.find(name);

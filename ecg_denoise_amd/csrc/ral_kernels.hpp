@@ -41,6 +41,11 @@ void launch_loss(const float* pred, const float* target, float* dy, float* snr, 
 void launch_adam(float* p, const float* g, float* m, float* v, size_t n, double lr, double b1, double b2, double eps,
                  int step, float gscale, hipStream_t s);
 
+int launch_conv13_fwd(const float* x, const float* w, const float* b, float* y, int B, int cin, int cout, int L,
+                      int lrelu, hipStream_t s);
+int launch_conv13_bwd(const float* x, const float* y, const float* dy, const float* w, float* gw, float* gb,
+                      float* dx, int B, int cin, int cout, int L, int lrelu, hipStream_t s);
+
 // ---- backward (ral_bwd.hip)
 size_t mlp_bwd_lds(int C, int N, int nch);
 void launch_mlp_bwd(int C, int nch, const float* dx2, const float* x1, const float* upre, const BlockP& w,

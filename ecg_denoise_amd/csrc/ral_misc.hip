@@ -263,3 +263,127 @@ void launch_adam(float* p, const float* g, float* m, float* v, size_t n, double 
   k_adam<<<ew_grid(n / 4), 256, 0, s>>>(p, g, m, v, n / 4, (float)(lr / bc1), (float)b1, (float)b2, (float)(1.0 - b1),
                                         (float)(1.0 - b2), (float)eps, (float)sqrt(bc2), gscale);
 }
+
+// ---------------------------------------------------------------------------------
+// 12-lead adapter convolutions (reference model/ralenet_12leads.py:683-709):
+// Conv1d(cin, cout, k13, p6) [+ LeakyReLU(0.01)], channel-major (B, C, L).  One workgroup per window:
+// input rows staged in LDS with a zero halo, weights in LDS.
+// ---------------------------------------------------------------------------------
+#define K13 13
+__global__ __launch_bounds__(256) void k_conv13_fwd(const float* __restrict__ x, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, float* __restrict__ y, int B,
+                                                    int cin, int cout, int L, int lrelu) {
+  extern __shared__ float4 smem4[];
+  float* xs = reinterpret_cast<float*>(smem4);  // cin x (L + 12)
+  float* ws = xs + cin * (L + 12);              // cout x cin x 13
+  const int LP = L + 12;
+  for (int i = threadIdx.x; i < cout * cin * K13; i += blockDim.x) ws[i] = w[i];
+  for (int win = blockIdx.x; win < B; win += gridDim.x) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < cin * LP; i += blockDim.x) {
+      const int c = i / LP, p = i - c * LP - 6;
+      xs[i] = (p >= 0 && p < L) ? x[((size_t)win * cin + c) * L + p] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < cout * L; i += blockDim.x) {
+      const int co = i / L, l = i - co * L;
+      float acc = bias[co];
+      for (int ci = 0; ci < cin; ++ci) {
+        const float* wr = ws + (co * cin + ci) * K13;
+        const float* xr = xs + ci * LP + l;
+#pragma unroll
+        for (int k = 0; k < K13; ++k) acc = fmaf(wr[k], xr[k], acc);
+      }
+      if (lrelu) acc = acc > 0.f ? acc : 0.01f * acc;
+      y[((size_t)win * cout + co) * L + l] = acc;
+    }
+  }
+}
+
+// gradients: dz = dy * lrelu'(y);  dx = conv^T(dz);  gw += dz (*) x;  gb += sum dz
+__global__ __launch_bounds__(256) void k_conv13_bwd(const float* __restrict__ x, const float* __restrict__ y,
+                                                    const float* __restrict__ dy, const float* __restrict__ w,
+                                                    float* __restrict__ gw, float* __restrict__ gb,
+                                                    float* __restrict__ dx, int B, int cin, int cout, int L, int lrelu) {
+  extern __shared__ float4 smem4[];
+  const int LP = L + 12, nw = cout * cin * K13;
+  float* xs = reinterpret_cast<float*>(smem4);  // cin x LP
+  float* ds = xs + cin * LP;                    // cout x LP
+  float* ws = ds + cout * LP;
+  for (int i = threadIdx.x; i < nw; i += blockDim.x) ws[i] = w[i];
+  float gacc[4] = {0.f, 0.f, 0.f, 0.f};          // 936 weight entries max / 256 threads
+  float gbacc = 0.f;
+  for (int win = blockIdx.x; win < B; win += gridDim.x) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < cin * LP; i += blockDim.x) {
+      const int c = i / LP, p = i - c * LP - 6;
+      xs[i] = (p >= 0 && p < L) ? x[((size_t)win * cin + c) * L + p] : 0.f;
+    }
+    for (int i = threadIdx.x; i < cout * LP; i += blockDim.x) {
+      const int c = i / LP, p = i - c * LP - 6;
+      float g = 0.f;
+      if (p >= 0 && p < L) {
+        const size_t o = ((size_t)win * cout + c) * L + p;
+        g = dy[o];
+        if (lrelu && y[o] <= 0.f) g *= 0.01f;
+      }
+      ds[i] = g;
+    }
+    __syncthreads();
+    if (dx) {
+      for (int i = threadIdx.x; i < cin * L; i += blockDim.x) {
+        const int ci = i / L, l = i - ci * L;
+        float acc = 0.f;
+        for (int co = 0; co < cout; ++co) {
+          const float* wr = ws + (co * cin + ci) * K13;
+          const float* dr = ds + co * LP + l + 12;   // dz[co][l + 6 - k] at padded index l + 12 - k
+#pragma unroll
+          for (int k = 0; k < K13; ++k) acc = fmaf(wr[k], dr[-k], acc);
+        }
+        dx[((size_t)win * cin + ci) * L + l] = acc;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = threadIdx.x + 256 * j;
+      if (e < nw) {
+        const int co = e / (cin * K13), ci = (e / K13) % cin, k = e % K13;
+        const float* dr = ds + co * LP + 6;       // dz[co][l]
+        const float* xr = xs + ci * LP + k;       // x[ci][l - 6 + k] at padded index l + k
+        float s = 0.f;
+        for (int l = 0; l < L; ++l) s = fmaf(dr[l], xr[l], s);
+        gacc[j] += s;
+      }
+    }
+    if ((int)threadIdx.x < cout) {
+      const float* dr = ds + threadIdx.x * LP + 6;
+      float s = 0.f;
+      for (int l = 0; l < L; ++l) s += dr[l];
+      gbacc += s;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = threadIdx.x + 256 * j;
+    if (e < nw) atomicAdd(gw + e, gacc[j]);
+  }
+  if ((int)threadIdx.x < cout) atomicAdd(gb + threadIdx.x, gbacc);
+}
+
+int launch_conv13_fwd(const float* x, const float* w, const float* b, float* y, int B, int cin, int cout, int L,
+                      int lrelu, hipStream_t s) {
+  if (cin * cout * K13 > 1024 || cin > 12 || cout > 12) return -1;
+  const size_t lds = ((size_t)cin * (L + 12) + (size_t)cout * cin * K13 + 4) * sizeof(float);
+  RAL_SET_LDS(k_conv13_fwd, lds);
+  k_conv13_fwd<<<B < 2048 ? B : 2048, 256, lds, s>>>(x, w, b, y, B, cin, cout, L, lrelu);
+  return 0;
+}
+
+int launch_conv13_bwd(const float* x, const float* y, const float* dy, const float* w, float* gw, float* gb,
+                      float* dx, int B, int cin, int cout, int L, int lrelu, hipStream_t s) {
+  if (cin * cout * K13 > 1024 || cin > 12 || cout > 12) return -1;
+  const size_t lds = ((size_t)(cin + cout) * (L + 12) + (size_t)cout * cin * K13 + 4) * sizeof(float);
+  RAL_SET_LDS(k_conv13_bwd, lds);
+  k_conv13_bwd<<<B < 512 ? B : 512, 256, lds, s>>>(x, y, dy, w, gw, gb, dx, B, cin, cout, L, lrelu);
+  return 0;
+}

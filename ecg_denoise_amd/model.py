@@ -276,6 +276,138 @@ class UNet(_ModuleBase):
         super().__init__("unet", leads, L, max_batch, train, device, seed)
 
 
+class NewRALE:
+    """model/ralenet_12leads.py::newrale — 12-lead adapter around a pretrained, frozen RA-LENet
+    (Transfer_learning.py:71-75): Conv1d 12->6->2 (k13, LeakyReLU 0.01), RA-LENet, Conv1d 2->6->12.
+    Only the 2 210 adapter parameters train; the inner model keeps running in whatever mode
+    `.train()` sets, so its BatchNorm still uses and updates batch statistics (reference quirk A16)."""
+
+    SHAPES = OrderedDict([("conv1.weight", (6, 12, 13)), ("conv1.bias", (6,)), ("conv2.weight", (2, 6, 13)),
+                          ("conv2.bias", (2,)), ("conv3.weight", (6, 2, 13)), ("conv3.bias", (6,)),
+                          ("conv4.weight", (12, 6, 13)), ("conv4.bias", (12,))])
+
+    def __init__(self, pretrained_rale_model, seed=None):
+        self.rale = pretrained_rale_model
+        if self.rale.eng.leads != 2:
+            raise _lib.RalError("newrale wraps a 2-lead RA-LENet")
+        self.device, self.L = self.rale.eng.device, self.rale.eng.L
+        self.off, cur = OrderedDict(), 0
+        for k, shp in self.SHAPES.items():
+            self.off[k] = cur
+            cur += (int(np.prod(shp)) + 3) // 4 * 4
+        z = lambda: torch.zeros(cur, dtype=torch.float32, device=self.device)
+        self.params, self.grads, self.adam_m, self.adam_v = z(), z(), z(), z()
+        self.training, self.step_count = True, 0
+        rng = np.random.default_rng(seed)
+        fan = None
+        for k, shp in self.SHAPES.items():
+            if len(shp) == 3:
+                fan = shp[1] * shp[2]
+            b = 1.0 / math.sqrt(fan)
+            self._view(self.params, k).copy_(torch.from_numpy(rng.uniform(-b, b, shp).astype(np.float32)))
+
+    def _view(self, buf, k):
+        n = int(np.prod(self.SHAPES[k]))
+        return buf[self.off[k]:self.off[k] + n].view(self.SHAPES[k])
+
+    def train(self, mode=True):
+        self.training = bool(mode); self.rale.train(mode); return self
+
+    def eval(self):
+        return self.train(False)
+
+    def cuda(self, device=None):
+        return self
+
+    def named_parameters(self):
+        return [(k, self._view(self.params, k)) for k in self.SHAPES]
+
+    def parameters(self):            # trainable parameters only (requires_grad filter of the reference)
+        return [p for _, p in self.named_parameters()]
+
+    def named_grads(self):
+        return OrderedDict((k, self._view(self.grads, k)) for k in self.SHAPES)
+
+    def state_dict(self):
+        sd = OrderedDict()
+        for k in ("conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias"):
+            sd[k] = self._view(self.params, k).clone()
+        for k, v in self.rale.state_dict().items():
+            sd["rale." + k] = v
+        for k in ("conv3.weight", "conv3.bias", "conv4.weight", "conv4.bias"):
+            sd[k] = self._view(self.params, k).clone()
+        return sd
+
+    def load_state_dict(self, sd, strict=True):
+        for k in self.SHAPES:
+            if k in sd:
+                self._view(self.params, k).copy_(torch.as_tensor(sd[k]).to(self.device, torch.float32))
+            elif strict:
+                raise _lib.RalError(f"missing {k}")
+        inner = OrderedDict((k[5:], v) for k, v in sd.items() if k.startswith("rale."))
+        if inner:
+            self.rale.load_state_dict(inner, strict)
+
+    def _conv(self, name, x, cout, lrelu):
+        y = torch.empty(x.shape[0], cout, x.shape[2], dtype=torch.float32, device=self.device)
+        _lib.check(_lib.lib().ral_conv13_forward(_ptr(x), _ptr(self._view(self.params, name + ".weight")),
+                                                 _ptr(self._view(self.params, name + ".bias")), _ptr(y), x.shape[0],
+                                                 x.shape[1], cout, x.shape[2], int(lrelu), _stream()))
+        return y
+
+    def forward(self, x):
+        x = x.contiguous()
+        if x.dim() != 3 or x.shape[1] != 12 or x.shape[2] != self.L or not x.is_cuda:
+            raise _lib.RalError(f"expected a HIP tensor (B, 12, {self.L}), got {tuple(x.shape)}")
+        a1 = self._conv("conv1", x, 6, True)
+        a2 = self._conv("conv2", a1, 2, True)
+        r = self.rale.forward(a2)
+        a3 = self._conv("conv3", r, 6, True)
+        y = self._conv("conv4", a3, 12, False)
+        self._saved = (x, a1, a2, r, a3, y)
+        return y
+
+    __call__ = forward
+
+    def loss_and_metrics(self, pred, target, want_grad=True):
+        B, n = pred.shape[0], pred[0].numel()
+        d = pred - target                      # (the fused loss kernel is sized for the inner model's windows)
+        sse = (d * d).flatten(1).sum(1); sy2 = (target * target).flatten(1).sum(1)
+        self._dy = (2.0 / (B * n)) * d if want_grad else None
+        return (sse / n).mean().double().reshape(1), 10 * torch.log10(sy2 / sse), torch.sqrt(sse / n)
+
+    def _conv_bwd(self, name, x, y, dy, lrelu, want_dx):
+        dx = torch.empty_like(x) if want_dx else None
+        _lib.check(_lib.lib().ral_conv13_backward(_ptr(x), _ptr(y), _ptr(dy), _ptr(self._view(self.params, name + ".weight")),
+                                                  _ptr(self._view(self.grads, name + ".weight")),
+                                                  _ptr(self._view(self.grads, name + ".bias")), _ptr(dx), x.shape[0],
+                                                  x.shape[1], y.shape[1], x.shape[2], int(lrelu), _stream()))
+        return dx
+
+    def backward(self, dy=None):
+        dy = (self._dy if dy is None else dy).contiguous()
+        x, a1, a2, r, a3, y = self._saved
+        self.grads.zero_()
+        d3 = self._conv_bwd("conv4", a3, y, dy, False, True)
+        dr = self._conv_bwd("conv3", r, a3, d3, True, True)
+        d2 = self.rale.backward(dr.contiguous(), want_dx=True)   # frozen weights: only the input gradient is used
+        d1 = self._conv_bwd("conv2", a1, a2, d2, True, True)
+        self._conv_bwd("conv1", x, a1, d1, True, False)
+
+    def step(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        self.step_count += 1
+        _lib.check(_lib.lib().ral_adam_flat(_ptr(self.params), _ptr(self.grads), _ptr(self.adam_m), _ptr(self.adam_v),
+                                            self.params.numel(), lr, betas[0], betas[1], eps, self.step_count, 1.0,
+                                            _stream()))
+
+    def train_step(self, x, target, lr=1e-3):
+        pred = self.forward(x)
+        loss, snr, rmse = self.loss_and_metrics(pred, target)
+        self.backward()
+        self.step(lr)
+        return {"loss": loss, "pred": pred, "snr": snr, "rmse": rmse}
+
+
 def ralenet(high_level_enhence=False, low_level_enhence=True, **kw):
     """Constructor spelled like model/transformer.py::ralenet (main.py:71-77)."""
     return RALENet("full" if high_level_enhence else "mlp", **kw)
