@@ -142,7 +142,9 @@ def test_unet_whole_model(golden_dir):
     r = O.train_step(p, x, tgt, fwd, m, v, 1)
     assert rel(r["pred"].numpy(), g["y_train"]) < 5e-6
     gn, gs = summarize(r["grads"])
-    np.testing.assert_allclose(gn, g["grad_norm"], rtol=2e-4, atol=1e-9)
+    # conv biases in front of a BatchNorm have an exactly-zero true gradient: their computed value is
+    # rounding noise (~1e-8) that depends on the thread count, hence the absolute floor
+    np.testing.assert_allclose(gn, g["grad_norm"], rtol=2e-4, atol=1e-6)
     for k in O.UNET_BN:
         np.testing.assert_allclose(bn[k]["running_var"].numpy(), g["bn_var_" + k], rtol=1e-5, atol=1e-7)
     with torch.no_grad():
