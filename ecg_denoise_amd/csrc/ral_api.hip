@@ -205,7 +205,7 @@ struct RalModel {
   const float* last_x = nullptr;
   int last_B = 0;
   int nch_f[5], nch_b[5], hg_f[5], hg_b[5];
-  int dw_ksplit = 256;
+  int dw_ksplit[5] = {256, 256, 256, 256, 256};
   // optional in-library kernel timing (bench.py roofline leg): hipEvent pairs around the
   // launches of ONE selected kernel kind, on the stream the kernels run on
   int prof_kind = -1;
@@ -289,7 +289,12 @@ static void choose_tiling(RalModel* m) {
   // groups but more co-resident workgroups per CU).  Environment overrides are for experiments only.
   const size_t budget = env_size("RAL_MLP_LDS", 78000);
   const size_t budget_af = env_size("RAL_ATTN_FWD_LDS", 72 * 1024), budget_ab = env_size("RAL_ATTN_BWD_LDS", 78 * 1024);
-  m->dw_ksplit = (int)env_size("RAL_DW_KSPLIT", 256);
+  // split-K workgroups of the weight-gradient kernels per channel width {8,16,32,64,128}: many for the
+  // narrow levels (staging latency-bound, tiny dW), few for the wide ones (the final atomics scale with it)
+  static const int KS_DEFAULT[5] = {1024, 1024, 512, 256, 128};
+  for (int l = 0; l < 5; ++l) m->dw_ksplit[l] = KS_DEFAULT[l];
+  if (const char* v = getenv("RAL_DW_KSPLIT")) sscanf(v, "%d,%d,%d,%d,%d", &m->dw_ksplit[0], &m->dw_ksplit[1], &m->dw_ksplit[2], &m->dw_ksplit[3], &m->dw_ksplit[4]);
+  set_dw_lds_budget(env_size("RAL_DW_LDS", 50 * 1024));
   for (int l = 0; l < 5; ++l) {
     const int C = CH[l], N = m->L >> l, H = C / 4;
     int n = 1;
@@ -418,7 +423,7 @@ static void run_block_bwd(RalModel* m, int bi, const float* dy, const float* ext
     launch_attn_bwd(a.qkv, a.o, m->dohm, a.lse, table, gtable, m->dqkv, N, H, m->hg_b[l], Len, B, s); }
   { ProfScope p(m, K_QKV_BWD, s); launch_qkv_bwd(C, m->dqkv, a.in, m->pe[l], m->dx1, extra, w, g, dx, N, B, s); }
   { ProfScope p(m, K_DW, s);
-    launch_block_dw(C, dy, a.upre, m->dupre, a.x1, m->dx1, a.o, m->dqkv, a.in, m->pe[l], w, g, N, B, m->dw_ksplit, s); }
+    launch_block_dw(C, dy, a.upre, m->dupre, a.x1, m->dx1, a.o, m->dqkv, a.in, m->pe[l], w, g, N, B, m->dw_ksplit[l], s); }
 }
 
 // stage: grad of stage output `dy` -> grad of stage input written to `dx` (+extra). Uses `tmp` between blocks.
@@ -434,7 +439,9 @@ static void run_res_bwd(RalModel* m, int ri, const float* dy, const float* in, f
   ProfScope p(m, K_RES_BWD, s);
   launch_resample_bwd(r.D, ri >= 4, dy, in, m->params + r.w, m->params + r.lnw, m->grads + r.lnw, m->grads + r.lnb,
                       dx, T, B, s);
-  launch_resample_dw(r.D, ri >= 4, dy, in, m->params + r.lnw, m->params + r.lnb, m->grads + r.w, T, B, m->dw_ksplit, s);
+  int lvl = 0;
+  while ((8 << lvl) < r.D) ++lvl;
+  launch_resample_dw(r.D, ri >= 4, dy, in, m->params + r.lnw, m->params + r.lnb, m->grads + r.w, T, B, m->dw_ksplit[lvl], s);
 }
 
 static int bwd_begin(RalModel* m, const float* dy, int B, hipStream_t s) {

@@ -185,7 +185,7 @@ RAL_DEV f32x2 splat2(float v) { return f32x2{v, v}; }
 #define RAL_LN2 0.6931471805599453f
 
 template <int QT>
-__global__ __launch_bounds__(512) void k_attn_bwd(const float* __restrict__ qkv, const float* __restrict__ o_hm,
+__global__ __launch_bounds__(512, 4) void k_attn_bwd(const float* __restrict__ qkv, const float* __restrict__ o_hm,
                                                   const float* __restrict__ do_hm, const float* __restrict__ lse,
                                                   const float* __restrict__ table, float* __restrict__ gtable,
                                                   float* __restrict__ dqkv, int N, int H, int HG, int Len, int B) {
@@ -210,16 +210,15 @@ __global__ __launch_bounds__(512) void k_attn_bwd(const float* __restrict__ qkv,
     const float* base = qkv + (size_t)win * 3 * H * N * 4;
     float* dbase = dqkv + (size_t)win * 3 * H * N * 4;
     const size_t hq0 = ((size_t)win * H + h0) * N;
-    for (int i = threadIdx.x; i < HG * N; i += blockDim.x) {
-      reinterpret_cast<float4*>(Qs)[i] = f4scale(reinterpret_cast<const float4*>(base + (size_t)h0 * N * 4)[i], RAL_LOG2E);
-      const float4 d4 = reinterpret_cast<const float4*>(do_hm)[hq0 + i];
-      const float4 o4 = reinterpret_cast<const float4*>(o_hm)[hq0 + i];
-      reinterpret_cast<float4*>(dOs)[i] = d4;
-      Dl[i] = -f4dot(d4, o4);
-      Ls[i] = -lse[hq0 + i] * RAL_LOG2E;
-    }
+    for_each_f4<4>(base + (size_t)h0 * N * 4, HG * N, [&](int i, float4 q) {
+      reinterpret_cast<float4*>(Qs)[i] = f4scale(q, RAL_LOG2E);
+    });
+    for_each_f4<4>(do_hm + hq0 * 4, HG * N, [&](int i, float4 d4) { reinterpret_cast<float4*>(dOs)[i] = d4; });
+    for (int i = threadIdx.x; i < HG * N; i += blockDim.x) Ls[i] = -lse[hq0 + i] * RAL_LOG2E;
     copy_flat(Ks, base + (size_t)(H + h0) * N * 4, HG * N);
     copy_flat(Vs, base + (size_t)(2 * H + h0) * N * 4, HG * N);
+    // delta = rowsum(dO * O): each thread re-reads the dO rows it staged itself (same index mapping)
+    for_each_f4<4>(o_hm + hq0 * 4, HG * N, [&](int i, float4 o4) { Dl[i] = -f4dot(reinterpret_cast<const float4*>(dOs)[i], o4); });
     for (int i = threadIdx.x; i < ntab; i += blockDim.x) tab[i] = table[(i / HG) * H + h0 + (i % HG)] * RAL_LOG2E;
     __syncthreads();
     const int nblk = N / (16 * QT);

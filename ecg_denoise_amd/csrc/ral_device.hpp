@@ -190,6 +190,48 @@ RAL_DEV void ln_stats(float4 v, float4& d, float& rstd) {
   rstd = 1.0f / sqrtf(var + 1e-5f);
 }
 
+// ---------------------------------------------------------------------------------
+// Staging loops.  hipcc waits for each global load right before its use, so a plain
+// `for (i = tid; i < n; i += blockDim) dst[i] = src[i]` costs one full HBM latency PER ITERATION.
+// These helpers issue U independent 16-byte loads first and consume them afterwards.
+template <int U, class F>
+RAL_DEV void for_each_f4(const float* __restrict__ src, int n4, F f) {   // f(index, value) over a flat float4 array
+  const float4* s = reinterpret_cast<const float4*>(src);
+  const int bd = blockDim.x;
+  int i = threadIdx.x;
+  for (; i + (U - 1) * bd < n4; i += U * bd) {
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = s[i + u * bd];
+#pragma unroll
+    for (int u = 0; u < U; ++u) f(i + u * bd, v[u]);
+  }
+  for (; i < n4; i += bd) f(i, s[i]);
+}
+
+// rows x width (floats, width % 4 == 0) block of a row-major global array with row stride gld: f(row, col, value)
+template <int U, class F>
+RAL_DEV void for_each_row_f4(const float* __restrict__ src, int gld, int rows, int width, F f) {
+  const int q = width >> 2, n4 = rows * q, bd = blockDim.x;
+  int i = threadIdx.x;
+  for (; i + (U - 1) * bd < n4; i += U * bd) {
+    float4 v[U];
+    int rr[U], cc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = i + u * bd;
+      rr[u] = j / q; cc[u] = (j - rr[u] * q) << 2;
+      v[u] = *reinterpret_cast<const float4*>(src + (size_t)rr[u] * gld + cc[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) f(rr[u], cc[u], v[u]);
+  }
+  for (; i < n4; i += bd) {
+    const int row = i / q, c = (i - row * q) << 2;
+    f(row, c, *reinterpret_cast<const float4*>(src + (size_t)row * gld + c));
+  }
+}
+
 // coalesced copy of an LDS tile (rows x width, row stride ld) to global rows of `gld` floats
 RAL_DEV void copy_out(float* __restrict__ dst, int gld, const float* src, int ld, int rows, int width) {
   const int q = width >> 2;
@@ -199,16 +241,13 @@ RAL_DEV void copy_out(float* __restrict__ dst, int gld, const float* src, int ld
   }
 }
 RAL_DEV void copy_in(float* dst, int ld, const float* __restrict__ src, int gld, int rows, int width) {
-  const int q = width >> 2;
-  for (int i = threadIdx.x; i < rows * q; i += blockDim.x) {
-    const int row = i / q, c = (i - row * q) << 2;
-    *reinterpret_cast<float4*>(dst + row * ld + c) = *reinterpret_cast<const float4*>(src + (size_t)row * gld + c);
-  }
+  for_each_row_f4<4>(src, gld, rows, width, [&](int row, int c, float4 v) {
+    *reinterpret_cast<float4*>(dst + row * ld + c) = v;
+  });
 }
 // flat float4 copy (n4 float4s)
 RAL_DEV void copy_flat(float* dst, const float* __restrict__ src, int n4) {
-  for (int i = threadIdx.x; i < n4; i += blockDim.x)
-    reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+  for_each_f4<4>(src, n4, [&](int i, float4 v) { reinterpret_cast<float4*>(dst)[i] = v; });
 }
 
 // Parameters of one TransformerBlock inside the flat parameter (or gradient) buffer.

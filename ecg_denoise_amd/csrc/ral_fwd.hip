@@ -64,7 +64,7 @@ RAL_DEV f32x2 splat2(float v) { return f32x2{v, v}; }
 // so loose that every term underflows (row sum < 1e-30) the task is redone with the exact
 // running-max recurrence (never seen on real data; exercised by tests/test_gpu_parity.py).
 template <int QT>
-__global__ __launch_bounds__(512) void k_attn_fwd(const float* __restrict__ qkv, float* __restrict__ o_hm,
+__global__ __launch_bounds__(512, 4) void k_attn_fwd(const float* __restrict__ qkv, float* __restrict__ o_hm,
                                                   float* __restrict__ lse, const float* __restrict__ table,
                                                   int N, int H, int HG, int Len, int B) {
   extern __shared__ float4 smem4[];
@@ -85,15 +85,16 @@ __global__ __launch_bounds__(512) void k_attn_fwd(const float* __restrict__ qkv,
     const float* base = qkv + (size_t)win * 3 * H * N * 4;
     if ((int)threadIdx.x < HG) { Kmax[threadIdx.x] = 0; if (table) Bmax[threadIdx.x] = 0.f; }
     __syncthreads();
-    for (int i = threadIdx.x; i < HG * N; i += blockDim.x) {
-      const float4 q = f4scale(reinterpret_cast<const float4*>(base + (size_t)h0 * N * 4)[i], RAL_LOG2E);
-      const float4 k = reinterpret_cast<const float4*>(base + (size_t)(H + h0) * N * 4)[i];
+    for_each_f4<4>(base + (size_t)h0 * N * 4, HG * N, [&](int i, float4 q) {
+      q = f4scale(q, RAL_LOG2E);
       reinterpret_cast<float4*>(Qs)[i] = q;
-      reinterpret_cast<float4*>(Ks)[i] = k;
-      reinterpret_cast<float4*>(Vs)[i] = reinterpret_cast<const float4*>(base + (size_t)(2 * H + h0) * N * 4)[i];
       Mq[i] = sqrtf(f4dot(q, q));
+    });
+    for_each_f4<4>(base + (size_t)(H + h0) * N * 4, HG * N, [&](int i, float4 k) {
+      reinterpret_cast<float4*>(Ks)[i] = k;
       atomicMax(Kmax + i / N, __float_as_int(f4dot(k, k)));   // non-negative floats order like ints
-    }
+    });
+    copy_flat(Vs, base + (size_t)(2 * H + h0) * N * 4, HG * N);
     if (table)
       for (int i = threadIdx.x; i < (2 * Len - 1) * HG; i += blockDim.x) {
         const float t = table[(i / HG) * H + h0 + (i % HG)] * RAL_LOG2E;

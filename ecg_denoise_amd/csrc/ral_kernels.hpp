@@ -70,5 +70,6 @@ void launch_conv1_bwd_dx(int leads, const float* dz, const float* w, float* dx, 
 void launch_block_dw(int C, const float* dx2, const float* upre, const float* dupre, const float* x1,
                      const float* dx1, const float* o_hm, const float* dqkv, const float* x, const float* pe,
                      const BlockP& w, const BlockP& gr, int N, int B, int ksplit, hipStream_t s);
+void set_dw_lds_budget(size_t bytes);
 void launch_resample_dw(int D, bool sep, const float* dy, const float* x, const float* lnw, const float* lnb,
                         float* dW, int T, int B, int ksplit, hipStream_t s);
