@@ -5,6 +5,7 @@
 // atomic per element per workgroup.
 #include "ral_device.hpp"
 #include "ral_kernels.hpp"
+#include <stdlib.h>
 #include <type_traits>
 
 // LDS float4 atomic accumulate of per-channel vectors: red[c..c+3] += v
@@ -762,7 +763,8 @@ void launch_attn_bwd(const float* qkv, const float* o_hm, const float* do_hm, co
   const size_t lds = attn_bwd_lds(N, HG, Len);
   const int items = B * (H / HG);
   const int grid = items < 4096 ? items : 4096;
-  if (N % 32 == 0) {
+  static const bool force1 = getenv("RAL_ATTN_QT1") != nullptr;   // experiment knob
+  if (N % 32 == 0 && !force1) {
     RAL_SET_LDS((k_attn_bwd<2>), lds);
     k_attn_bwd<2><<<grid, 512, lds, s>>>(qkv, o_hm, do_hm, lse, table, gtable, dqkv, N, H, HG, Len, B);
   } else {

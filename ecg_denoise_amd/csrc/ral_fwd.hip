@@ -7,6 +7,7 @@
 //   PatchMerging / PatchSeparate  model/raletransformer.py:411-459
 #include "ral_device.hpp"
 #include "ral_kernels.hpp"
+#include <stdlib.h>
 #include <type_traits>
 
 // =================================================================================
@@ -377,7 +378,8 @@ void launch_attn_fwd(const float* qkv, float* o_hm, float* lse, const float* tab
                      int B, hipStream_t s) {
   const size_t lds = attn_fwd_lds(N, HG, Len);
   const int items = B * (H / HG);
-  if (N % 32 == 0) {
+  static const bool force1 = getenv("RAL_ATTN_QT1") != nullptr;   // experiment knob
+  if (N % 32 == 0 && !force1) {
     RAL_SET_LDS((k_attn_fwd<2>), lds);
     k_attn_fwd<2><<<grid_for(items), 512, lds, s>>>(qkv, o_hm, lse, table, N, H, HG, Len, B);
   } else {
