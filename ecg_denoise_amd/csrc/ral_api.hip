@@ -201,7 +201,17 @@ struct RalModel {
   float* res_out[8];  // p1..p4 (pm), u3,u2,u1,u0 (ps)
   float* xmid;
   // backward temporaries
-  float *gA, *gB, *gskip[5], *dx1, *dohm, *dqkv, *dupre, *dz0;
+  // every gradient tensor has its own buffer (no ping-pong): the weight-gradient kernels run on a side
+  // stream and read them long after the data-gradient chain has moved on
+  float *gy[18], *gin[9], *du0, *dz0;
+  float *dx1[2], *dohm[2], *dqkv[2], *dupre[2];     // per-block temporaries, two sets (side-stream overlap)
+  hipStream_t s2 = nullptr;
+  hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}, ev_join = nullptr;
+  bool dw_pending[2] = {false, false};
+  int bwd_count = 0;
+  bool side_stream = true;
+  float* paramsT = nullptr;   // transposed copies of the weight matrices (same offsets), refreshed per backward
+  void* tdesc = nullptr; int tn = 0, ttotal = 0;
   const float* last_x = nullptr;
   int last_B = 0;
   int nch_f[5], nch_b[5], hg_f[5], hg_b[5];
@@ -271,10 +281,18 @@ static size_t plan_workspace(const ral_config& c, RalModel* m /* may be null: si
   for (int r = 0; r < 8; ++r) M.res_out[r] = take(RN[r], E);
   M.xmid = take("xmid", E);
   if (tr) {
-    M.gA = take("gA", E); M.gB = take("gB", E);
-    for (int i = 0; i < 5; ++i) M.gskip[i] = take(("gskip" + std::to_string(i)).c_str(), E);
-    M.dx1 = take("dx1", E); M.dohm = take("do", E); M.dqkv = take("dqkv", 3 * E); M.dupre = take("dupre", 4 * E);
+    for (int i = 0; i < 18; ++i) M.gy[i] = (i == 9) ? nullptr : take(("gy" + std::to_string(i)).c_str(), E);
+    for (int i = 0; i < 9; ++i) M.gin[i] = take(("gin" + std::to_string(i)).c_str(), E);
+    M.gy[9] = M.gin[5];   // x_mid = transformer(x4) + x4: the stage-4 output gradient IS g x_mid
+    M.du0 = take("du0", E);
+    for (int k = 0; k < 2; ++k) {
+      M.dx1[k] = take(("dx1_" + std::to_string(k)).c_str(), E); M.dohm[k] = take(("do_" + std::to_string(k)).c_str(), E);
+      M.dqkv[k] = take(("dqkv_" + std::to_string(k)).c_str(), 3 * E); M.dupre[k] = take(("dupre_" + std::to_string(k)).c_str(), 4 * E);
+    }
     M.dz0 = take("dz0", E);
+    Layout L_; build_layout(c, L_);
+    M.paramsT = take("paramsT", (size_t)L_.nparam);
+    M.tdesc = take("tdesc", 4 * 128);
   }
   return cur;
 }
@@ -418,12 +436,21 @@ static void run_block_bwd(RalModel* m, int bi, const float* dy, const float* ext
     gtable = m->grads + m->lay.rw[STAGES[si].rw - 1];
     Len = RWLEN[STAGES[si].rw - 1];
   }
-  { ProfScope p(m, K_MLP_BWD, s); launch_mlp_bwd(C, m->nch_b[l], dy, a.x1, a.upre, w, g, m->dupre, m->dx1, m->dohm, N, B, s); }
+  const BlockP wt = block_ptrs(m->lay.blk[bi], m->paramsT);
+  const int k = m->bwd_count++ & 1;                    // temporary set of this block
+  hipStream_t sd = m->side_stream ? m->s2 : s;         // stream of the weight-gradient kernels
+  if (m->side_stream && m->dw_pending[k]) (void)hipStreamWaitEvent(s, m->ev_done[k], 0);   // set k free again?
+  { ProfScope p(m, K_MLP_BWD, s); launch_mlp_bwd(C, m->nch_b[l], dy, a.x1, a.upre, w, wt, g, m->dupre[k], m->dx1[k], m->dohm[k], N, B, s); }
   { ProfScope p(m, K_ATTN_BWD, s);
-    launch_attn_bwd(a.qkv, a.o, m->dohm, a.lse, table, gtable, m->dqkv, N, H, m->hg_b[l], Len, B, s); }
-  { ProfScope p(m, K_QKV_BWD, s); launch_qkv_bwd(C, m->dqkv, a.in, m->pe[l], m->dx1, extra, w, g, dx, N, B, s); }
-  { ProfScope p(m, K_DW, s);
-    launch_block_dw(C, dy, a.upre, m->dupre, a.x1, m->dx1, a.o, m->dqkv, a.in, m->pe[l], w, g, N, B, m->dw_ksplit[l], s); }
+    launch_attn_bwd(a.qkv, a.o, m->dohm[k], a.lse, table, gtable, m->dqkv[k], N, H, m->hg_b[l], Len, B, s); }
+  { ProfScope p(m, K_QKV_BWD, s); launch_qkv_bwd(C, m->dqkv[k], a.in, m->pe[l], m->dx1[k], extra, w, wt, g, dx, N, B, s); }
+  if (m->side_stream) {
+    (void)hipEventRecord(m->ev_ready[k], s);
+    (void)hipStreamWaitEvent(sd, m->ev_ready[k], 0);
+  }
+  { ProfScope p(m, K_DW, sd);
+    launch_block_dw(C, dy, a.upre, m->dupre[k], a.x1, m->dx1[k], a.o, m->dqkv[k], a.in, m->pe[l], w, g, N, B, m->dw_ksplit[l], sd); }
+  if (m->side_stream) { (void)hipEventRecord(m->ev_done[k], sd); m->dw_pending[k] = true; }
 }
 
 // stage: grad of stage output `dy` -> grad of stage input written to `dx` (+extra). Uses `tmp` between blocks.
@@ -437,11 +464,19 @@ static void run_res_bwd(RalModel* m, int ri, const float* dy, const float* in, f
   const ResOff& r = m->lay.res[ri];
   const int T = m->E1 / r.D;
   ProfScope p(m, K_RES_BWD, s);
-  launch_resample_bwd(r.D, ri >= 4, dy, in, m->params + r.w, m->params + r.lnw, m->grads + r.lnw, m->grads + r.lnb,
+  launch_resample_bwd(r.D, ri >= 4, dy, in, m->paramsT + r.w, m->params + r.lnw, m->grads + r.lnw, m->grads + r.lnb,
                       dx, T, B, s);
   int lvl = 0;
   while ((8 << lvl) < r.D) ++lvl;
-  launch_resample_dw(r.D, ri >= 4, dy, in, m->params + r.lnw, m->params + r.lnb, m->grads + r.w, T, B, m->dw_ksplit[lvl], s);
+  hipStream_t sd = s;
+  if (m->side_stream) {   // dy was produced on s: fork
+    const int k = m->bwd_count & 1;
+    (void)hipEventRecord(m->ev_join, s);
+    (void)hipStreamWaitEvent(m->s2, m->ev_join, 0);
+    sd = m->s2;
+    (void)k;
+  }
+  launch_resample_dw(r.D, ri >= 4, dy, in, m->params + r.lnw, m->params + r.lnb, m->grads + r.w, T, B, m->dw_ksplit[lvl], sd);
 }
 
 static int bwd_begin(RalModel* m, const float* dy, int B, hipStream_t s) {
@@ -451,37 +486,47 @@ static int bwd_begin(RalModel* m, const float* dy, int B, hipStream_t s) {
   const Layout& Y = m->lay;
   HIP_OK(hipMemsetAsync(m->grads, 0, (size_t)Y.nparam * sizeof(float), s));
   HIP_OK(hipMemsetAsync(m->bn_sums + 32, 0, 32 * sizeof(double), s));
-  float *gA = m->gA, *gB = m->gB;
-  float** sk = m->gskip;  // 0: d u0 (= d x0 skip), 1: g u1, 2: g u2, 3: g u3, 4: g xmid
+  launch_transpose_mats(m->params, m->paramsT, m->tdesc, m->tn, m->ttotal, s);
+  float** gy = m->gy; float** gin = m->gin;
+  m->bwd_count = 0; m->dw_pending[0] = m->dw_pending[1] = false;
+  if (m->side_stream) {   // the side stream starts after the gradient buffer has been zeroed
+    (void)hipEventRecord(m->ev_join, s);
+    (void)hipStreamWaitEvent(m->s2, m->ev_join, 0);
+  }
   // output conv: dy -> d(u0 + x0)
   launch_final_bwd(m->cfg.leads, dy, m->res_out[7], m->x0, m->params + Y.tc_w, m->grads + Y.tc_w, m->grads + Y.tc_b,
-                   sk[0], m->L, B, s);
-  // ps1 <- utransformer1 <- (u1 = ps2(.) + p1)
-  run_res_bwd(m, 7, sk[0], m->act[17].out, gA, B, s);
-  run_stage_bwd(m, 8, gA, nullptr, gB, sk[1], B, s);
-  run_res_bwd(m, 6, sk[1], m->act[15].out, gA, B, s);
-  run_stage_bwd(m, 7, gA, nullptr, gB, sk[2], B, s);
-  run_res_bwd(m, 5, sk[2], m->act[13].out, gA, B, s);
-  run_stage_bwd(m, 6, gA, nullptr, gB, sk[3], B, s);
-  run_res_bwd(m, 4, sk[3], m->act[11].out, gA, B, s);
-  run_stage_bwd(m, 5, gA, nullptr, gB, sk[4], B, s);                 // g xmid
-  run_stage_bwd(m, 4, sk[4], sk[4], gB, gA, B, s);                   // g p4 = transformer^T(g xmid) + g xmid
-  run_res_bwd(m, 3, gA, m->act[7].out, gB, B, s);                    // -> g y3
-  run_stage_bwd(m, 3, gB, sk[3], gA, gB, B, s);                      // g p3 (+ g u3)   [tmp=gA, out=gB]
-  run_res_bwd(m, 2, gB, m->act[5].out, gA, B, s);
-  run_stage_bwd(m, 2, gA, sk[2], gB, gA, B, s);                      // g p2 (+ g u2)   [tmp=gB, out=gA]
-  run_res_bwd(m, 1, gA, m->act[3].out, gB, B, s);
-  run_stage_bwd(m, 1, gB, sk[1], gA, gB, B, s);                      // g p1 (+ g u1)
-  run_res_bwd(m, 0, gB, m->act[1].out, gA, B, s);
-  run_stage_bwd(m, 0, gA, sk[0], gB, gA, B, s);                      // g x0 (+ d u0)  -> gA
-  launch_bn8_bwd_stats(gA, m->a0, m->ss, m->bn_sums + 32, (size_t)B * m->L, s);
+                   m->du0, m->L, B, s);
+  // decoder: ps_k <- stage <- (u = ps(.) + p)
+  run_res_bwd(m, 7, m->du0, m->act[17].out, gy[17], B, s);
+  run_stage_bwd(m, 8, gy[17], nullptr, gy[16], gin[8], B, s);          // g u1
+  run_res_bwd(m, 6, gin[8], m->act[15].out, gy[15], B, s);
+  run_stage_bwd(m, 7, gy[15], nullptr, gy[14], gin[7], B, s);          // g u2
+  run_res_bwd(m, 5, gin[7], m->act[13].out, gy[13], B, s);
+  run_stage_bwd(m, 6, gy[13], nullptr, gy[12], gin[6], B, s);          // g u3
+  run_res_bwd(m, 4, gin[6], m->act[11].out, gy[11], B, s);
+  run_stage_bwd(m, 5, gy[11], nullptr, gy[10], gin[5], B, s);          // g x_mid
+  run_stage_bwd(m, 4, gin[5], gin[5], gy[8], gin[4], B, s);            // g p4 = transformer^T(g x_mid) + g x_mid
+  // encoder: pm_k <- stage, skip gradients added by the first block of each stage
+  run_res_bwd(m, 3, gin[4], m->act[7].out, gy[7], B, s);
+  run_stage_bwd(m, 3, gy[7], gin[6], gy[6], gin[3], B, s);             // g p3 (+ g u3)
+  run_res_bwd(m, 2, gin[3], m->act[5].out, gy[5], B, s);
+  run_stage_bwd(m, 2, gy[5], gin[7], gy[4], gin[2], B, s);             // g p2 (+ g u2)
+  run_res_bwd(m, 1, gin[2], m->act[3].out, gy[3], B, s);
+  run_stage_bwd(m, 1, gy[3], gin[8], gy[2], gin[1], B, s);             // g p1 (+ g u1)
+  run_res_bwd(m, 0, gin[1], m->act[1].out, gy[1], B, s);
+  run_stage_bwd(m, 0, gy[1], m->du0, gy[0], gin[0], B, s);             // g x0 (+ d u0)
+  if (m->side_stream) {   // join: everything after this point (optimizer) sees the complete gradients
+    (void)hipEventRecord(m->ev_join, m->s2);
+    (void)hipStreamWaitEvent(s, m->ev_join, 0);
+  }
+  launch_bn8_bwd_stats(gin[0], m->a0, m->ss, m->bn_sums + 32, (size_t)B * m->L, s);
   HIP_OK(hipGetLastError());
   return 0;
 }
 
 static int bwd_end(RalModel* m, float* dx, int B, int64_t global_windows, hipStream_t s) {
   const Layout& Y = m->lay;
-  launch_conv1_bwd(m->cfg.leads, m->gA, m->a0, m->last_x, m->ss, m->params + Y.bn_w, m->bn_sums + 32,
+  launch_conv1_bwd(m->cfg.leads, m->gin[0], m->a0, m->last_x, m->ss, m->params + Y.bn_w, m->bn_sums + 32,
                    (double)global_windows * m->L, m->grads + Y.conv1_w, m->grads + Y.conv1_b, dx ? m->dz0 : nullptr,
                    m->L, B, s);
   launch_bn_affine_grads(m->bn_sums + 32, m->grads + Y.bn_w, m->grads + Y.bn_b, 8, (double)B / (double)global_windows, s);
@@ -588,6 +633,27 @@ int ral_create(const ral_config* cfg, ral_handle** out) {
       return -1;
     }
   }
+  if (cfg->train) {
+    m->side_stream = getenv("RAL_NO_SIDE_STREAM") == nullptr;
+    (void)hipStreamCreateWithFlags(&m->s2, hipStreamNonBlocking);
+    for (int k = 0; k < 2; ++k) {
+      (void)hipEventCreateWithFlags(&m->ev_ready[k], hipEventDisableTiming);
+      (void)hipEventCreateWithFlags(&m->ev_done[k], hipEventDisableTiming);
+    }
+    (void)hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming);
+    std::vector<int> d;
+    int run = 0;
+    auto add = [&](int64_t off, int rows, int cols) { d.push_back((int)off); d.push_back(rows); d.push_back(cols); d.push_back(run); run += rows * cols; };
+    for (int b = 0; b < 18; ++b) {
+      const int C = CH[STAGES[b / 2].level];
+      const BlockOff& o = m->lay.blk[b];
+      add(o.wqkv, 3 * C, C); add(o.wp, C, C); add(o.w1, 4 * C, C); add(o.w2, C, 4 * C);
+    }
+    for (int r = 0; r < 8; ++r) add(m->lay.res[r].w, m->lay.res[r].D, m->lay.res[r].D);
+    m->tn = (int)d.size() / 4; m->ttotal = run;
+    e = hipMemcpy(m->tdesc, d.data(), d.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { fail("hipMemcpy(tdesc) failed"); (void)hipFree(m->slab); delete m; delete h; return -1; }
+  }
   h->m = m;
   *out = h;
   return 0;
@@ -595,7 +661,13 @@ int ral_create(const ral_config* cfg, ral_handle** out) {
 
 int ral_destroy(ral_handle* h) {
   if (!h) return 0;
-  if (h->m) { if (h->m->slab) (void)hipFree(h->m->slab); delete h->m; }
+  if (h->m) {
+    if (h->m->s2) (void)hipStreamDestroy(h->m->s2);
+    for (int k = 0; k < 2; ++k) { if (h->m->ev_ready[k]) (void)hipEventDestroy(h->m->ev_ready[k]); if (h->m->ev_done[k]) (void)hipEventDestroy(h->m->ev_done[k]); }
+    if (h->m->ev_join) (void)hipEventDestroy(h->m->ev_join);
+    if (h->m->slab) (void)hipFree(h->m->slab);
+    delete h->m;
+  }
   if (h->u) unet_destroy(h->u);
   delete h;
   return 0;

@@ -20,7 +20,7 @@ RAL_DEV void lds_add4(float* red, int c, float4 v) {
 // =================================================================================
 template <int C, int NCH>
 __global__ __launch_bounds__(512) void k_mlp_bwd(const float* __restrict__ dx2, const float* __restrict__ x1,
-                                                 const float* __restrict__ upre, BlockP w, BlockP gr,
+                                                 const float* __restrict__ upre, BlockP w, BlockP wt, BlockP gr,
                                                  float* __restrict__ dupre, float* __restrict__ dx1,
                                                  float* __restrict__ do_hm, int N, int B) {
   extern __shared__ float4 smem4[];
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(512) void k_mlp_bwd(const float* __restrict__ dx2, 
         __syncthreads();
       }
       // d a2 = dx2 W2[:, chunk]  -> du (in place over u_pre)
-      gemm_phase<C, TTBof<C>::v, true, LAY_TOK>(w.w2 + j0, 4 * C, HC, Ds, LD, N >> 4,
+      gemm_phase<C, TTBof<C>::v, false, LAY_TOK>(wt.w2 + (size_t)j0 * C, C, HC, Ds, LD, N >> 4,
                                                 [&](int row0, int tok, f32x4 a) {
         float4* pu = reinterpret_cast<float4*>(Us + tok * LDU + row0);
         const float4 u = *pu;
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(512) void k_mlp_bwd(const float* __restrict__ dx2, 
         db1[ch] += s;
       }
       // dg (+)= du W1[chunk, :]
-      gemm_phase<HC, TTBof<C>::v, true, LAY_TOK>(w.w1 + (size_t)j0 * C, C, C, Us, LDU, N >> 4,
+      gemm_phase<HC, TTBof<C>::v, false, LAY_TOK>(wt.w1 + j0, 4 * C, C, Us, LDU, N >> 4,
                                                  [&](int row0, int tok, f32x4 a) {
         float4* pg = reinterpret_cast<float4*>(Gs + tok * LD + row0);
         *pg = (ch == 0) ? tofloat4(a) : f4add(*pg, tofloat4(a));
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(512) void k_mlp_bwd(const float* __restrict__ dx2, 
     }
     // do = dx1 Wp  (head-major)
     float* dow = do_hm + wo;
-    gemm_phase<C, TTBof<C>::v, true, LAY_TOK>(w.wp, C, C, Ds, LD, N >> 4, [&](int row0, int tok, f32x4 a) {
+    gemm_phase<C, TTBof<C>::v, false, LAY_TOK>(wt.wp, C, C, Ds, LD, N >> 4, [&](int row0, int tok, f32x4 a) {
       *reinterpret_cast<float4*>(dow + ((size_t)(row0 >> 2) * N + tok) * 4) = tofloat4(a);
     });
     __syncthreads();
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd(const float* __restrict__ q
 template <int C>
 __global__ __launch_bounds__(512) void k_qkv_bwd(const float* __restrict__ dqkv, const float* __restrict__ x,
                                                  const float* __restrict__ pe, const float* __restrict__ dx1,
-                                                 const float* __restrict__ extra, BlockP w, BlockP gr,
+                                                 const float* __restrict__ extra, BlockP w, BlockP wt, BlockP gr,
                                                  float* __restrict__ dx, int N, int B) {
   extern __shared__ float4 smem4[];
   constexpr int LD = LDof<C>::v, LPR = C / 4, TTB = TTBof<C>::v;
@@ -403,8 +403,8 @@ __global__ __launch_bounds__(512) void k_qkv_bwd(const float* __restrict__ dqkv,
         f32x4 acc[TTB];
 #pragma unroll
         for (int tt = 0; tt < TTB; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        gemm_wx<C, TTB, true, LAY_HM>(w.wqkv, C, m * 16, C, DQ, N, tgi * TTB * 16, acc);
-        gemm_wx<2 * C, TTB, true, LAY_HM>(w.wqkv + C * C, C, m * 16, C, DQ + (C / 4) * N * 4, N, tgi * TTB * 16, acc);
+        gemm_wx<C, TTB, false, LAY_HM>(wt.wqkv, 3 * C, m * 16, C, DQ, N, tgi * TTB * 16, acc);
+        gemm_wx<2 * C, TTB, false, LAY_HM>(wt.wqkv + C, 3 * C, m * 16, C, DQ + (C / 4) * N * 4, N, tgi * TTB * 16, acc);
         const int row0 = m * 16 + 4 * g;
         if (row0 < C) {
 #pragma unroll
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256) void k_resample_bwd(const float* __restrict__ 
     const size_t wo = (size_t)win * T * D;
     copy_in(Ys, LD, dy + wo, D, T, D);
     __syncthreads();
-    gemm_phase<D, TTBof<D>::v, true, LAY_TOK>(wred, D, D, Ys, LD, T >> 4, [&](int row0, int tok, f32x4 a) {
+    gemm_phase<D, TTBof<D>::v, false, LAY_TOK>(wred /* W^T */, D, D, Ys, LD, T >> 4, [&](int row0, int tok, f32x4 a) {
       *reinterpret_cast<float4*>(Dh + tok * LD + row0) = tofloat4(a);
     });
     __syncthreads();
@@ -737,18 +737,18 @@ size_t mlp_bwd_lds(int C, int N, int nch) {
 
 template <int C>
 static void launch_mlp_bwd_c(int nch, const float* dx2, const float* x1, const float* upre, const BlockP& w,
-                             const BlockP& gr, float* dupre, float* dx1, float* do_hm, int N, int B, hipStream_t s) {
+                             const BlockP& wt, const BlockP& gr, float* dupre, float* dx1, float* do_hm, int N, int B, hipStream_t s) {
   const size_t lds = mlp_bwd_lds(C, N, nch);
   const int grid = grid_bwd(B);
-  if (nch == 1) { RAL_SET_LDS((k_mlp_bwd<C, 1>), lds); k_mlp_bwd<C, 1><<<grid, 512, lds, s>>>(dx2, x1, upre, w, gr, dupre, dx1, do_hm, N, B); }
-  else if (nch == 2) { RAL_SET_LDS((k_mlp_bwd<C, 2>), lds); k_mlp_bwd<C, 2><<<grid, 512, lds, s>>>(dx2, x1, upre, w, gr, dupre, dx1, do_hm, N, B); }
-  else { RAL_SET_LDS((k_mlp_bwd<C, 4>), lds); k_mlp_bwd<C, 4><<<grid, 512, lds, s>>>(dx2, x1, upre, w, gr, dupre, dx1, do_hm, N, B); }
+  if (nch == 1) { RAL_SET_LDS((k_mlp_bwd<C, 1>), lds); k_mlp_bwd<C, 1><<<grid, 512, lds, s>>>(dx2, x1, upre, w, wt, gr, dupre, dx1, do_hm, N, B); }
+  else if (nch == 2) { RAL_SET_LDS((k_mlp_bwd<C, 2>), lds); k_mlp_bwd<C, 2><<<grid, 512, lds, s>>>(dx2, x1, upre, w, wt, gr, dupre, dx1, do_hm, N, B); }
+  else { RAL_SET_LDS((k_mlp_bwd<C, 4>), lds); k_mlp_bwd<C, 4><<<grid, 512, lds, s>>>(dx2, x1, upre, w, wt, gr, dupre, dx1, do_hm, N, B); }
 }
 
 void launch_mlp_bwd(int C, int nch, const float* dx2, const float* x1, const float* upre, const BlockP& w,
-                    const BlockP& gr, float* dupre, float* dx1, float* do_hm, int N, int B, hipStream_t s) {
+                    const BlockP& wt, const BlockP& gr, float* dupre, float* dx1, float* do_hm, int N, int B, hipStream_t s) {
   switch (C) {
-#define CASE(c) case c: launch_mlp_bwd_c<c>(nch, dx2, x1, upre, w, gr, dupre, dx1, do_hm, N, B, s); break;
+#define CASE(c) case c: launch_mlp_bwd_c<c>(nch, dx2, x1, upre, w, wt, gr, dupre, dx1, do_hm, N, B, s); break;
     CASE(8) CASE(16) CASE(32) CASE(64) CASE(128)
 #undef CASE
   }
@@ -776,12 +776,12 @@ void launch_attn_bwd(const float* qkv, const float* o_hm, const float* do_hm, co
 size_t qkv_bwd_lds(int C, int N) { return ((size_t)N * 3 * C + (size_t)N * ld_of(C) + 2 * C + 4) * sizeof(float); }
 
 void launch_qkv_bwd(int C, const float* dqkv, const float* x, const float* pe, const float* dx1, const float* extra,
-                    const BlockP& w, const BlockP& gr, float* dx, int N, int B, hipStream_t s) {
+                    const BlockP& w, const BlockP& wt, const BlockP& gr, float* dx, int N, int B, hipStream_t s) {
   const size_t lds = qkv_bwd_lds(C, N);
   const int grid = grid_bwd(B);
   switch (C) {
 #define CASE(c) case c: RAL_SET_LDS((k_qkv_bwd<c>), lds); \
-    k_qkv_bwd<c><<<grid, 512, lds, s>>>(dqkv, x, pe, dx1, extra, w, gr, dx, N, B); break;
+    k_qkv_bwd<c><<<grid, 512, lds, s>>>(dqkv, x, pe, dx1, extra, w, wt, gr, dx, N, B); break;
     CASE(8) CASE(16) CASE(32) CASE(64) CASE(128)
 #undef CASE
   }

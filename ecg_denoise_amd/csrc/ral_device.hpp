@@ -48,23 +48,34 @@ RAL_DEV void gemm_wx(const float* __restrict__ W, int ldw, int m0, int M, const 
   int mrow = m0 + r;
   if (mrow >= M) mrow = M - 1;  // clamp: rows >= M are computed on garbage and discarded
   if constexpr (K % 16 == 0) {
-#pragma unroll 2
-    for (int k0 = 0; k0 < K; k0 += 16) {
-      float wv[4];
-      if constexpr (!WT) {
-        const float4 w4 = *reinterpret_cast<const float4*>(W + (size_t)mrow * ldw + k0 + 4 * g);
-        wv[0] = w4.x; wv[1] = w4.y; wv[2] = w4.z; wv[3] = w4.w;
-      } else {
+    // weight fragments of up to KB k-chunks are requested together (one L2 round trip for all of them)
+    constexpr int NK = K / 16, KBMAX = WT ? 2 : 8, KB = NK < KBMAX ? NK : KBMAX;
+#pragma unroll 1
+    for (int kb = 0; kb < NK; kb += KB) {
+      float4 wv[KB];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) wv[s] = W[(size_t)(k0 + 4 * g + s) * ldw + mrow];
+      for (int c = 0; c < KB; ++c) {
+        const int k0 = (kb + c) * 16;
+        if constexpr (!WT) {
+          wv[c] = *reinterpret_cast<const float4*>(W + (size_t)mrow * ldw + k0 + 4 * g);
+        } else {
+          wv[c].x = W[(size_t)(k0 + 4 * g + 0) * ldw + mrow];
+          wv[c].y = W[(size_t)(k0 + 4 * g + 1) * ldw + mrow];
+          wv[c].z = W[(size_t)(k0 + 4 * g + 2) * ldw + mrow];
+          wv[c].w = W[(size_t)(k0 + 4 * g + 3) * ldw + mrow];
+        }
       }
 #pragma unroll
-      for (int tt = 0; tt < TT; ++tt) {
-        const float4 x4 = *reinterpret_cast<const float4*>(Xs + xoff<LAY>(ldx, t0 + 16 * tt + r, k0 + 4 * g));
-        acc[tt] = mfma4(wv[0], x4.x, acc[tt]);
-        acc[tt] = mfma4(wv[1], x4.y, acc[tt]);
-        acc[tt] = mfma4(wv[2], x4.z, acc[tt]);
-        acc[tt] = mfma4(wv[3], x4.w, acc[tt]);
+      for (int c = 0; c < KB; ++c) {
+        const int k0 = (kb + c) * 16;
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+          const float4 x4 = *reinterpret_cast<const float4*>(Xs + xoff<LAY>(ldx, t0 + 16 * tt + r, k0 + 4 * g));
+          acc[tt] = mfma4(wv[c].x, x4.x, acc[tt]);
+          acc[tt] = mfma4(wv[c].y, x4.y, acc[tt]);
+          acc[tt] = mfma4(wv[c].z, x4.z, acc[tt]);
+          acc[tt] = mfma4(wv[c].w, x4.w, acc[tt]);
+        }
       }
     }
   } else {

@@ -46,16 +46,18 @@ int launch_conv13_fwd(const float* x, const float* w, const float* b, float* y, 
 int launch_conv13_bwd(const float* x, const float* y, const float* dy, const float* w, float* gw, float* gb,
                       float* dx, int B, int cin, int cout, int L, int lrelu, hipStream_t s);
 
+void launch_transpose_mats(const float* src, float* dst, const void* desc, int nmat, int total, hipStream_t s);
+
 // ---- backward (ral_bwd.hip)
 size_t mlp_bwd_lds(int C, int N, int nch);
 void launch_mlp_bwd(int C, int nch, const float* dx2, const float* x1, const float* upre, const BlockP& w,
-                    const BlockP& gr, float* dupre, float* dx1, float* do_hm, int N, int B, hipStream_t s);
+                    const BlockP& wt, const BlockP& gr, float* dupre, float* dx1, float* do_hm, int N, int B, hipStream_t s);
 size_t attn_bwd_lds(int N, int HG, int Len);
 void launch_attn_bwd(const float* qkv, const float* o_hm, const float* do_hm, const float* lse, const float* table,
                      float* gtable, float* dqkv, int N, int H, int HG, int Len, int B, hipStream_t s);
 size_t qkv_bwd_lds(int C, int N);
 void launch_qkv_bwd(int C, const float* dqkv, const float* x, const float* pe, const float* dx1, const float* extra,
-                    const BlockP& w, const BlockP& gr, float* dx, int N, int B, hipStream_t s);
+                    const BlockP& w, const BlockP& wt, const BlockP& gr, float* dx, int N, int B, hipStream_t s);
 void launch_resample_bwd(int D, bool sep, const float* dy, const float* x, const float* wred, const float* lnw,
                          float* g_lnw, float* g_lnb, float* dx, int T, int B, hipStream_t s);
 void launch_final_bwd(int leads, const float* dy, const float* u0, const float* x0, const float* w, float* gw,

@@ -387,3 +387,26 @@ int launch_conv13_bwd(const float* x, const float* y, const float* dy, const flo
   k_conv13_bwd<<<B < 512 ? B : 512, 256, lds, s>>>(x, y, dy, w, gw, gb, dx, B, cin, cout, L, lrelu);
   return 0;
 }
+
+// ---------------------------------------------------------------------------------
+// transposed copies of the weight matrices for the backward GEMMs (dX = dY W): with W^T row-major the
+// A-operand fragment of those products is one 16-byte load, like in the forward pass
+// ---------------------------------------------------------------------------------
+__global__ void k_transpose_mats(const float* __restrict__ src, float* __restrict__ dst, const int4* __restrict__ desc,
+                                 int nmat) {
+  // desc[i] = (offset, rows, cols, first flat element index of this matrix in the launch)
+  const int total = desc[nmat - 1].w + desc[nmat - 1].y * desc[nmat - 1].z;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    int lo = 0, hi = nmat - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (desc[mid].w <= e) lo = mid; else hi = mid - 1; }
+    const int4 d = desc[lo];
+    const int i = e - d.w, r = i / d.z, c = i - r * d.z;
+    dst[d.x + c * d.y + r] = src[d.x + i];
+  }
+}
+
+void launch_transpose_mats(const float* src, float* dst, const void* desc, int nmat, int total, hipStream_t s) {
+  int grid = (total + 255) / 256;
+  if (grid > 2048) grid = 2048;
+  k_transpose_mats<<<grid, 256, 0, s>>>(src, dst, reinterpret_cast<const int4*>(desc), nmat);
+}
