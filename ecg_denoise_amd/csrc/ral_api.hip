@@ -205,10 +205,8 @@ struct RalModel {
   // stream and read them long after the data-gradient chain has moved on
   float *gy[18], *gin[9], *du0, *dz0;
   float *dx1[2], *dohm[2], *dqkv[2], *dupre[2];     // per-block temporaries, two sets (side-stream overlap)
-  hipStream_t s2 = nullptr;
-  hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}, ev_join = nullptr;
-  bool dw_pending[2] = {false, false};
-  int bwd_count = 0;
+  void* lanes = nullptr;   // LaneSet
+  int n_lanes = 2;
   bool side_stream = true;
   float* paramsT = nullptr;   // transposed copies of the weight matrices (same offsets), refreshed per backward
   void* tdesc = nullptr; int tn = 0, ttotal = 0;
@@ -341,37 +339,93 @@ static BlockP block_ptrs(const BlockOff& o, float* base) {
 }
 
 // ---------------------------------------------------------------------------------
+// lanes: the windows of a batch are independent through the whole transformer stack, so a batch is cut
+// into NL contiguous micro-batches ("lanes") that run the same kernel chain on separate HIP streams.
+// Kernels of different kinds (VALU-bound attention, MFMA/latency-bound projections) then share the CUs.
+// Every tensor is batch-major, so a lane is just a pointer offset of w0 windows.
+// ---------------------------------------------------------------------------------
+struct Lane {
+  int w0 = 0, B = 0;
+  hipStream_t s = nullptr, s2 = nullptr;     // chain stream, weight-gradient side stream
+  hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}, ev_fork = nullptr, ev_join = nullptr;
+  bool dw_pending[2] = {false, false};
+  int bwd_count = 0;
+};
+#define MAX_LANES 4
+struct LaneSet { Lane l[MAX_LANES]; int n = 1; hipStream_t own[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr}; };
+static LaneSet* lanes_of(RalModel* m);
+
+template <class T> static inline T* woff(T* p, int w0, size_t per_window) { return p ? p + (size_t)w0 * per_window : p; }
+
+// ---------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------
-static void run_block_fwd(RalModel* m, int bi, const float* in, bool training, int B, hipStream_t s) {
+static void run_block_fwd(RalModel* m, int bi, const float* in, bool training, const Lane& ln) {
   const int si = bi / 2, l = STAGES[si].level, C = CH[l], N = m->L >> l, H = C / 4;
+  const size_t E1 = m->E1;
   const BlockP w = block_ptrs(m->lay.blk[bi], m->params);
   BlockAct& a = m->act[bi];
-  a.in = const_cast<float*>(in);
+  a.in = const_cast<float*>(in);   // base pointer (window 0); lanes offset it
   const float* table = nullptr;
   int Len = 0;
   if (m->lay.rwave && STAGES[si].rw) {
     table = m->params + m->lay.rw[STAGES[si].rw - 1];
     Len = RWLEN[STAGES[si].rw - 1];
   }
-  { ProfScope p(m, K_QKV_FWD, s); launch_qkv_fwd(C, in, m->pe[l], w, a.qkv, N, B, s); }
-  { ProfScope p(m, K_ATTN_FWD, s); launch_attn_fwd(a.qkv, a.o, training ? a.lse : nullptr, table, N, H, m->hg_f[l], Len, B, s); }
+  const int w0 = ln.w0, B = ln.B;
+  hipStream_t s = ln.s;
+  const float* x = woff(in, w0, E1);
+  float* qkv = woff(a.qkv, w0, 3 * E1);
+  float* o = woff(a.o, w0, E1);
+  { ProfScope p(m, K_QKV_FWD, s); launch_qkv_fwd(C, x, m->pe[l], w, qkv, N, B, s); }
+  { ProfScope p(m, K_ATTN_FWD, s);
+    launch_attn_fwd(qkv, o, training ? woff(a.lse, w0, E1 / 4) : nullptr, table, N, H, m->hg_f[l], Len, B, s); }
   { ProfScope p(m, K_MLP_FWD, s);
-    launch_mlp_fwd(C, m->nch_f[l], in, a.o, w, training ? a.x1 : nullptr, training ? a.upre : nullptr, a.out, N, B, s); }
+    launch_mlp_fwd(C, m->nch_f[l], x, o, w, training ? woff(a.x1, w0, E1) : nullptr, training ? woff(a.upre, w0, 4 * E1) : nullptr,
+                   woff(a.out, w0, E1), N, B, s); }
 }
 
-static const float* run_stage_fwd(RalModel* m, int si, const float* in, bool training, int B, hipStream_t s) {
-  run_block_fwd(m, si * 2, in, training, B, s);
-  run_block_fwd(m, si * 2 + 1, m->act[si * 2].out, training, B, s);
+static const float* run_stage_fwd(RalModel* m, int si, const float* in, bool training, const Lane& ln) {
+  run_block_fwd(m, si * 2, in, training, ln);
+  run_block_fwd(m, si * 2 + 1, m->act[si * 2].out, training, ln);
   return m->act[si * 2 + 1].out;
 }
 
-static void run_res_fwd(RalModel* m, int ri, const float* in, const float* skip, int B, hipStream_t s) {
+static void run_res_fwd(RalModel* m, int ri, const float* in, const float* skip, const Lane& ln) {
   const ResOff& r = m->lay.res[ri];
   const int T = m->E1 / r.D;  // output tokens per window
-  ProfScope p(m, K_RES_FWD, s);
-  launch_resample_fwd(r.D, ri >= 4, in, m->params + r.w, m->params + r.lnw, m->params + r.lnb, skip,
-                      m->res_out[ri], T, B, s);
+  ProfScope p(m, K_RES_FWD, ln.s);
+  launch_resample_fwd(r.D, ri >= 4, woff(in, ln.w0, m->E1), m->params + r.w, m->params + r.lnw, m->params + r.lnb,
+                      woff(skip, ln.w0, m->E1), woff(m->res_out[ri], ln.w0, m->E1), T, ln.B, ln.s);
+}
+
+// split [0, B) over the lanes; lane 0 runs on the caller's stream
+static int plan_lanes(RalModel* m, int B, hipStream_t s) {
+  LaneSet* L = lanes_of(m);
+  int n = m->n_lanes;
+  if (B < 64 * n || B % n != 0) n = 1;
+  for (int i = 0; i < n; ++i) {
+    Lane& ln = L->l[i];
+    ln.w0 = i * (B / n); ln.B = B / n;
+    ln.s = i == 0 ? s : L->own[i];
+    ln.bwd_count = 0; ln.dw_pending[0] = ln.dw_pending[1] = false;
+  }
+  L->n = n;
+  return n;
+}
+
+static void fork_lanes(RalModel* m, hipStream_t s) {     // lanes 1.. start after everything queued on s so far
+  LaneSet* L = lanes_of(m);
+  if (L->n < 2) return;
+  (void)hipEventRecord(L->l[0].ev_fork, s);
+  for (int i = 1; i < L->n; ++i) (void)hipStreamWaitEvent(L->l[i].s, L->l[0].ev_fork, 0);
+}
+static void join_lanes(RalModel* m, hipStream_t s) {     // s continues after every lane has finished
+  LaneSet* L = lanes_of(m);
+  for (int i = 1; i < L->n; ++i) {
+    (void)hipEventRecord(L->l[i].ev_join, L->l[i].s);
+    (void)hipStreamWaitEvent(s, L->l[i].ev_join, 0);
+  }
 }
 
 static int fwd_begin(RalModel* m, const float* x, int B, int training, hipStream_t s) {
@@ -400,21 +454,34 @@ static int fwd_end(RalModel* m, float* y, int B, int64_t global_windows, int tra
     launch_bn_apply8(m->a0, m->ss, m->x0, (size_t)B * m->L, s);
   }
   const bool tr = training != 0;
+  const int nl = plan_lanes(m, B, s);
+  fork_lanes(m, s);
+  LaneSet* LS = lanes_of(m);
+  // issue stage by stage, alternating lanes, so that the lanes progress together
   const float* cur = m->x0;
   for (int i = 0; i < 4; ++i) {
-    cur = run_stage_fwd(m, i, cur, tr, B, s);
-    run_res_fwd(m, i, cur, nullptr, B, s);
+    for (int k = 0; k < nl; ++k) run_stage_fwd(m, i, cur, tr, LS->l[k]);
+    for (int k = 0; k < nl; ++k) run_res_fwd(m, i, m->act[2 * i + 1].out, nullptr, LS->l[k]);
     cur = m->res_out[i];
   }
-  cur = run_stage_fwd(m, 4, cur, tr, B, s);
-  launch_add(cur, m->res_out[3], m->xmid, (size_t)B * m->E1, s);
+  for (int k = 0; k < nl; ++k) {
+    const Lane& ln = LS->l[k];
+    run_stage_fwd(m, 4, cur, tr, ln);
+    launch_add(woff(m->act[9].out, ln.w0, m->E1), woff(m->res_out[3], ln.w0, m->E1), woff(m->xmid, ln.w0, m->E1),
+               (size_t)ln.B * m->E1, ln.s);
+  }
   cur = m->xmid;
   for (int i = 0; i < 4; ++i) {
-    cur = run_stage_fwd(m, 5 + i, cur, tr, B, s);
-    run_res_fwd(m, 4 + i, cur, i < 3 ? m->res_out[2 - i] : nullptr, B, s);
+    for (int k = 0; k < nl; ++k) run_stage_fwd(m, 5 + i, cur, tr, LS->l[k]);
+    for (int k = 0; k < nl; ++k) run_res_fwd(m, 4 + i, m->act[2 * (5 + i) + 1].out, i < 3 ? m->res_out[2 - i] : nullptr, LS->l[k]);
     cur = m->res_out[4 + i];
   }
-  launch_final_fwd(m->cfg.leads, cur, m->x0, m->params + Y.tc_w, m->params + Y.tc_b, y, m->L, B, s);
+  for (int k = 0; k < nl; ++k) {
+    const Lane& ln = LS->l[k];
+    launch_final_fwd(m->cfg.leads, woff(cur, ln.w0, m->E1), woff(m->x0, ln.w0, m->E1), m->params + Y.tc_w, m->params + Y.tc_b,
+                     woff(y, ln.w0, (size_t)m->cfg.leads * m->L), m->L, ln.B, ln.s);
+  }
+  join_lanes(m, s);
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -422,11 +489,13 @@ static int fwd_end(RalModel* m, float* y, int B, int64_t global_windows, int tra
 // ---------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------
-// one block: dy (grad of block output) -> dx (grad of block input) [+ extra]
-static void run_block_bwd(RalModel* m, int bi, const float* dy, const float* extra, float* dx, int B, hipStream_t s) {
+// one block: dy (grad of block output) -> dx (grad of block input) [+ extra]; all pointers are window-0 bases
+static void run_block_bwd(RalModel* m, int bi, const float* dy, const float* extra, float* dx, Lane& ln) {
   const int si = bi / 2, l = STAGES[si].level, C = CH[l], N = m->L >> l, H = C / 4;
+  const size_t E1 = m->E1;
   const BlockP w = block_ptrs(m->lay.blk[bi], m->params);
   const BlockP g = block_ptrs(m->lay.blk[bi], m->grads);
+  const BlockP wt = block_ptrs(m->lay.blk[bi], m->paramsT);
   BlockAct& a = m->act[bi];
   const float* table = nullptr;
   float* gtable = nullptr;
@@ -436,47 +505,53 @@ static void run_block_bwd(RalModel* m, int bi, const float* dy, const float* ext
     gtable = m->grads + m->lay.rw[STAGES[si].rw - 1];
     Len = RWLEN[STAGES[si].rw - 1];
   }
-  const BlockP wt = block_ptrs(m->lay.blk[bi], m->paramsT);
-  const int k = m->bwd_count++ & 1;                    // temporary set of this block
-  hipStream_t sd = m->side_stream ? m->s2 : s;         // stream of the weight-gradient kernels
-  if (m->side_stream && m->dw_pending[k]) (void)hipStreamWaitEvent(s, m->ev_done[k], 0);   // set k free again?
-  { ProfScope p(m, K_MLP_BWD, s); launch_mlp_bwd(C, m->nch_b[l], dy, a.x1, a.upre, w, wt, g, m->dupre[k], m->dx1[k], m->dohm[k], N, B, s); }
-  { ProfScope p(m, K_ATTN_BWD, s);
-    launch_attn_bwd(a.qkv, a.o, m->dohm[k], a.lse, table, gtable, m->dqkv[k], N, H, m->hg_b[l], Len, B, s); }
-  { ProfScope p(m, K_QKV_BWD, s); launch_qkv_bwd(C, m->dqkv[k], a.in, m->pe[l], m->dx1[k], extra, w, wt, g, dx, N, B, s); }
+  const int w0 = ln.w0, B = ln.B;
+  hipStream_t s = ln.s;
+  const int k = ln.bwd_count++ & 1;                    // temporary set of this block
+  hipStream_t sd = m->side_stream ? ln.s2 : s;         // stream of the weight-gradient kernels
+  if (m->side_stream && ln.dw_pending[k]) (void)hipStreamWaitEvent(s, ln.ev_done[k], 0);   // set k free again?
+  const float* dyw = woff(dy, w0, E1);
+  float *dupre = woff(m->dupre[k], w0, 4 * E1), *dx1 = woff(m->dx1[k], w0, E1), *dohm = woff(m->dohm[k], w0, E1),
+        *dqkv = woff(m->dqkv[k], w0, 3 * E1);
+  const float *x1 = woff(a.x1, w0, E1), *upre = woff(a.upre, w0, 4 * E1), *qkv = woff(a.qkv, w0, 3 * E1),
+              *o = woff(a.o, w0, E1), *lse = woff(a.lse, w0, E1 / 4), *xin = woff(a.in, w0, E1);
+  { ProfScope p(m, K_MLP_BWD, s); launch_mlp_bwd(C, m->nch_b[l], dyw, x1, upre, w, wt, g, dupre, dx1, dohm, N, B, s); }
+  { ProfScope p(m, K_ATTN_BWD, s); launch_attn_bwd(qkv, o, dohm, lse, table, gtable, dqkv, N, H, m->hg_b[l], Len, B, s); }
+  { ProfScope p(m, K_QKV_BWD, s);
+    launch_qkv_bwd(C, dqkv, xin, m->pe[l], dx1, woff(extra, w0, E1), w, wt, g, woff(dx, w0, E1), N, B, s); }
   if (m->side_stream) {
-    (void)hipEventRecord(m->ev_ready[k], s);
-    (void)hipStreamWaitEvent(sd, m->ev_ready[k], 0);
+    (void)hipEventRecord(ln.ev_ready[k], s);
+    (void)hipStreamWaitEvent(sd, ln.ev_ready[k], 0);
   }
   { ProfScope p(m, K_DW, sd);
-    launch_block_dw(C, dy, a.upre, m->dupre[k], a.x1, m->dx1[k], a.o, m->dqkv[k], a.in, m->pe[l], w, g, N, B, m->dw_ksplit[l], sd); }
-  if (m->side_stream) { (void)hipEventRecord(m->ev_done[k], sd); m->dw_pending[k] = true; }
+    launch_block_dw(C, dyw, upre, dupre, x1, dx1, o, dqkv, xin, m->pe[l], w, g, N, B, m->dw_ksplit[l], sd); }
+  if (m->side_stream) { (void)hipEventRecord(ln.ev_done[k], sd); ln.dw_pending[k] = true; }
 }
 
 // stage: grad of stage output `dy` -> grad of stage input written to `dx` (+extra). Uses `tmp` between blocks.
-static void run_stage_bwd(RalModel* m, int si, const float* dy, const float* extra, float* tmp, float* dx, int B,
-                          hipStream_t s) {
-  run_block_bwd(m, si * 2 + 1, dy, nullptr, tmp, B, s);
-  run_block_bwd(m, si * 2, tmp, extra, dx, B, s);
+static void run_stage_bwd(RalModel* m, int si, const float* dy, const float* extra, float* tmp, float* dx, Lane& ln) {
+  run_block_bwd(m, si * 2 + 1, dy, nullptr, tmp, ln);
+  run_block_bwd(m, si * 2, tmp, extra, dx, ln);
 }
 
-static void run_res_bwd(RalModel* m, int ri, const float* dy, const float* in, float* dx, int B, hipStream_t s) {
+static void run_res_bwd(RalModel* m, int ri, const float* dy, const float* in, float* dx, Lane& ln) {
   const ResOff& r = m->lay.res[ri];
   const int T = m->E1 / r.D;
-  ProfScope p(m, K_RES_BWD, s);
-  launch_resample_bwd(r.D, ri >= 4, dy, in, m->paramsT + r.w, m->params + r.lnw, m->grads + r.lnw, m->grads + r.lnb,
-                      dx, T, B, s);
+  const size_t E1 = m->E1;
+  hipStream_t s = ln.s;
+  { ProfScope p(m, K_RES_BWD, s);
+    launch_resample_bwd(r.D, ri >= 4, woff(dy, ln.w0, E1), woff(in, ln.w0, E1), m->paramsT + r.w, m->params + r.lnw,
+                        m->grads + r.lnw, m->grads + r.lnb, woff(dx, ln.w0, E1), T, ln.B, s); }
   int lvl = 0;
   while ((8 << lvl) < r.D) ++lvl;
   hipStream_t sd = s;
-  if (m->side_stream) {   // dy was produced on s: fork
-    const int k = m->bwd_count & 1;
-    (void)hipEventRecord(m->ev_join, s);
-    (void)hipStreamWaitEvent(m->s2, m->ev_join, 0);
-    sd = m->s2;
-    (void)k;
+  if (m->side_stream) {   // dy was produced on s: fork the weight-gradient product to the side stream
+    (void)hipEventRecord(ln.ev_fork, s);
+    (void)hipStreamWaitEvent(ln.s2, ln.ev_fork, 0);
+    sd = ln.s2;
   }
-  launch_resample_dw(r.D, ri >= 4, dy, in, m->params + r.lnw, m->params + r.lnb, m->grads + r.w, T, B, m->dw_ksplit[lvl], sd);
+  launch_resample_dw(r.D, ri >= 4, woff(dy, ln.w0, E1), woff(in, ln.w0, E1), m->params + r.lnw, m->params + r.lnb,
+                     m->grads + r.w, T, ln.B, m->dw_ksplit[lvl], sd);
 }
 
 static int bwd_begin(RalModel* m, const float* dy, int B, hipStream_t s) {
@@ -488,37 +563,44 @@ static int bwd_begin(RalModel* m, const float* dy, int B, hipStream_t s) {
   HIP_OK(hipMemsetAsync(m->bn_sums + 32, 0, 32 * sizeof(double), s));
   launch_transpose_mats(m->params, m->paramsT, m->tdesc, m->tn, m->ttotal, s);
   float** gy = m->gy; float** gin = m->gin;
-  m->bwd_count = 0; m->dw_pending[0] = m->dw_pending[1] = false;
-  if (m->side_stream) {   // the side stream starts after the gradient buffer has been zeroed
-    (void)hipEventRecord(m->ev_join, s);
-    (void)hipStreamWaitEvent(m->s2, m->ev_join, 0);
-  }
-  // output conv: dy -> d(u0 + x0)
+  const int nl = plan_lanes(m, B, s);
+  LaneSet* LS = lanes_of(m);
+  // output conv: dy -> d(u0 + x0)   (whole batch, then the lanes fork)
   launch_final_bwd(m->cfg.leads, dy, m->res_out[7], m->x0, m->params + Y.tc_w, m->grads + Y.tc_w, m->grads + Y.tc_b,
                    m->du0, m->L, B, s);
+  fork_lanes(m, s);
+  if (m->side_stream)   // side streams start after the gradient buffer has been zeroed
+    for (int k = 0; k < nl; ++k) {
+      (void)hipEventRecord(LS->l[k].ev_fork, LS->l[k].s);
+      (void)hipStreamWaitEvent(LS->l[k].s2, LS->l[k].ev_fork, 0);
+    }
+#define EACH_LANE(stmt) for (int k_ = 0; k_ < nl; ++k_) { Lane& ln = LS->l[k_]; stmt; }
   // decoder: ps_k <- stage <- (u = ps(.) + p)
-  run_res_bwd(m, 7, m->du0, m->act[17].out, gy[17], B, s);
-  run_stage_bwd(m, 8, gy[17], nullptr, gy[16], gin[8], B, s);          // g u1
-  run_res_bwd(m, 6, gin[8], m->act[15].out, gy[15], B, s);
-  run_stage_bwd(m, 7, gy[15], nullptr, gy[14], gin[7], B, s);          // g u2
-  run_res_bwd(m, 5, gin[7], m->act[13].out, gy[13], B, s);
-  run_stage_bwd(m, 6, gy[13], nullptr, gy[12], gin[6], B, s);          // g u3
-  run_res_bwd(m, 4, gin[6], m->act[11].out, gy[11], B, s);
-  run_stage_bwd(m, 5, gy[11], nullptr, gy[10], gin[5], B, s);          // g x_mid
-  run_stage_bwd(m, 4, gin[5], gin[5], gy[8], gin[4], B, s);            // g p4 = transformer^T(g x_mid) + g x_mid
+  EACH_LANE(run_res_bwd(m, 7, m->du0, m->act[17].out, gy[17], ln))
+  EACH_LANE(run_stage_bwd(m, 8, gy[17], nullptr, gy[16], gin[8], ln))          // g u1
+  EACH_LANE(run_res_bwd(m, 6, gin[8], m->act[15].out, gy[15], ln))
+  EACH_LANE(run_stage_bwd(m, 7, gy[15], nullptr, gy[14], gin[7], ln))          // g u2
+  EACH_LANE(run_res_bwd(m, 5, gin[7], m->act[13].out, gy[13], ln))
+  EACH_LANE(run_stage_bwd(m, 6, gy[13], nullptr, gy[12], gin[6], ln))          // g u3
+  EACH_LANE(run_res_bwd(m, 4, gin[6], m->act[11].out, gy[11], ln))
+  EACH_LANE(run_stage_bwd(m, 5, gy[11], nullptr, gy[10], gin[5], ln))          // g x_mid
+  EACH_LANE(run_stage_bwd(m, 4, gin[5], gin[5], gy[8], gin[4], ln))            // g p4 = transformer^T(g x_mid) + g x_mid
   // encoder: pm_k <- stage, skip gradients added by the first block of each stage
-  run_res_bwd(m, 3, gin[4], m->act[7].out, gy[7], B, s);
-  run_stage_bwd(m, 3, gy[7], gin[6], gy[6], gin[3], B, s);             // g p3 (+ g u3)
-  run_res_bwd(m, 2, gin[3], m->act[5].out, gy[5], B, s);
-  run_stage_bwd(m, 2, gy[5], gin[7], gy[4], gin[2], B, s);             // g p2 (+ g u2)
-  run_res_bwd(m, 1, gin[2], m->act[3].out, gy[3], B, s);
-  run_stage_bwd(m, 1, gy[3], gin[8], gy[2], gin[1], B, s);             // g p1 (+ g u1)
-  run_res_bwd(m, 0, gin[1], m->act[1].out, gy[1], B, s);
-  run_stage_bwd(m, 0, gy[1], m->du0, gy[0], gin[0], B, s);             // g x0 (+ d u0)
-  if (m->side_stream) {   // join: everything after this point (optimizer) sees the complete gradients
-    (void)hipEventRecord(m->ev_join, m->s2);
-    (void)hipStreamWaitEvent(s, m->ev_join, 0);
-  }
+  EACH_LANE(run_res_bwd(m, 3, gin[4], m->act[7].out, gy[7], ln))
+  EACH_LANE(run_stage_bwd(m, 3, gy[7], gin[6], gy[6], gin[3], ln))             // g p3 (+ g u3)
+  EACH_LANE(run_res_bwd(m, 2, gin[3], m->act[5].out, gy[5], ln))
+  EACH_LANE(run_stage_bwd(m, 2, gy[5], gin[7], gy[4], gin[2], ln))             // g p2 (+ g u2)
+  EACH_LANE(run_res_bwd(m, 1, gin[2], m->act[3].out, gy[3], ln))
+  EACH_LANE(run_stage_bwd(m, 1, gy[3], gin[8], gy[2], gin[1], ln))             // g p1 (+ g u1)
+  EACH_LANE(run_res_bwd(m, 0, gin[1], m->act[1].out, gy[1], ln))
+  EACH_LANE(run_stage_bwd(m, 0, gy[1], m->du0, gy[0], gin[0], ln))             // g x0 (+ d u0)
+#undef EACH_LANE
+  if (m->side_stream)   // join the side streams into their lanes, then the lanes into s
+    for (int k = 0; k < nl; ++k) {
+      (void)hipEventRecord(LS->l[k].ev_join, LS->l[k].s2);
+      (void)hipStreamWaitEvent(LS->l[k].s, LS->l[k].ev_join, 0);
+    }
+  join_lanes(m, s);
   launch_bn8_bwd_stats(gin[0], m->a0, m->ss, m->bn_sums + 32, (size_t)B * m->L, s);
   HIP_OK(hipGetLastError());
   return 0;
@@ -538,6 +620,8 @@ static int bwd_end(RalModel* m, float* dx, int B, int64_t global_windows, hipStr
 // ---------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------
+static LaneSet* lanes_of(RalModel* m) { return reinterpret_cast<LaneSet*>(m->lanes); }
+
 extern "C" {
 
 int ral_layout_count(const ral_config* cfg) {
@@ -622,6 +706,24 @@ int ral_create(const ral_config* cfg, ral_handle** out) {
   }
   plan_workspace(*cfg, m, m->slab);
   choose_tiling(m);
+  {
+    LaneSet* LS = new LaneSet();
+    m->lanes = LS;
+    m->n_lanes = (int)env_size("RAL_LANES", 2);
+    if (m->n_lanes < 1) m->n_lanes = 1;
+    if (m->n_lanes > MAX_LANES) m->n_lanes = MAX_LANES;
+    for (int i = 0; i < MAX_LANES; ++i) {
+      Lane& ln = LS->l[i];
+      if (i > 0) { (void)hipStreamCreateWithFlags(&LS->own[i], hipStreamNonBlocking); }
+      (void)hipStreamCreateWithFlags(&ln.s2, hipStreamNonBlocking);
+      for (int k = 0; k < 2; ++k) {
+        (void)hipEventCreateWithFlags(&ln.ev_ready[k], hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&ln.ev_done[k], hipEventDisableTiming);
+      }
+      (void)hipEventCreateWithFlags(&ln.ev_fork, hipEventDisableTiming);
+      (void)hipEventCreateWithFlags(&ln.ev_join, hipEventDisableTiming);
+    }
+  }
   for (int l = 0; l < 5; ++l) {
     const int n = cfg->L >> l, C = CH[l];
     std::vector<float> P((size_t)n * C);
@@ -635,12 +737,6 @@ int ral_create(const ral_config* cfg, ral_handle** out) {
   }
   if (cfg->train) {
     m->side_stream = getenv("RAL_NO_SIDE_STREAM") == nullptr;
-    (void)hipStreamCreateWithFlags(&m->s2, hipStreamNonBlocking);
-    for (int k = 0; k < 2; ++k) {
-      (void)hipEventCreateWithFlags(&m->ev_ready[k], hipEventDisableTiming);
-      (void)hipEventCreateWithFlags(&m->ev_done[k], hipEventDisableTiming);
-    }
-    (void)hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming);
     std::vector<int> d;
     int run = 0;
     auto add = [&](int64_t off, int rows, int cols) { d.push_back((int)off); d.push_back(rows); d.push_back(cols); d.push_back(run); run += rows * cols; };
@@ -662,9 +758,18 @@ int ral_create(const ral_config* cfg, ral_handle** out) {
 int ral_destroy(ral_handle* h) {
   if (!h) return 0;
   if (h->m) {
-    if (h->m->s2) (void)hipStreamDestroy(h->m->s2);
-    for (int k = 0; k < 2; ++k) { if (h->m->ev_ready[k]) (void)hipEventDestroy(h->m->ev_ready[k]); if (h->m->ev_done[k]) (void)hipEventDestroy(h->m->ev_done[k]); }
-    if (h->m->ev_join) (void)hipEventDestroy(h->m->ev_join);
+    if (h->m->lanes) {
+      LaneSet* LS = reinterpret_cast<LaneSet*>(h->m->lanes);
+      for (int i = 0; i < MAX_LANES; ++i) {
+        Lane& ln = LS->l[i];
+        if (LS->own[i]) (void)hipStreamDestroy(LS->own[i]);
+        if (ln.s2) (void)hipStreamDestroy(ln.s2);
+        for (int k = 0; k < 2; ++k) { if (ln.ev_ready[k]) (void)hipEventDestroy(ln.ev_ready[k]); if (ln.ev_done[k]) (void)hipEventDestroy(ln.ev_done[k]); }
+        if (ln.ev_fork) (void)hipEventDestroy(ln.ev_fork);
+        if (ln.ev_join) (void)hipEventDestroy(ln.ev_join);
+      }
+      delete LS;
+    }
     if (h->m->slab) (void)hipFree(h->m->slab);
     delete h->m;
   }

@@ -1,4 +1,6 @@
 #!/bin/bash
-run() { echo "=== $*"; env "$@" python bench.py --steps 3 --warmup 1 --no-cpu --kinds 2>&1 | grep -E "attn|value" | cut -c1-120; }
-run RAL_ATTN_QT1=1
-run RAL_X=1
+run() { echo "=== $*"; env "$@" python bench.py --steps 10 --warmup 2 --no-cpu --infer 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d.get('infer_windows_per_s'))"; }
+run RAL_LANES=1
+run RAL_LANES=2
+run RAL_LANES=4
+run RAL_LANES=2 RAL_NO_SIDE_STREAM=1
