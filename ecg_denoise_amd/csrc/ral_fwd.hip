@@ -65,7 +65,7 @@ RAL_DEV f32x2 splat2(float v) { return f32x2{v, v}; }
 // so loose that every term underflows (row sum < 1e-30) the task is redone with the exact
 // running-max recurrence (never seen on real data; exercised by tests/test_gpu_parity.py).
 template <int QT>
-__global__ __launch_bounds__(512, 4) void k_attn_fwd(const float* __restrict__ qkv, float* __restrict__ o_hm,
+__global__ __launch_bounds__(512, (QT >= 4 ? 3 : 4)) void k_attn_fwd(const float* __restrict__ qkv, float* __restrict__ o_hm,
                                                   float* __restrict__ lse, const float* __restrict__ table,
                                                   int N, int H, int HG, int Len, int B) {
   extern __shared__ float4 smem4[];
@@ -378,8 +378,12 @@ void launch_attn_fwd(const float* qkv, float* o_hm, float* lse, const float* tab
                      int B, hipStream_t s) {
   const size_t lds = attn_fwd_lds(N, HG, Len);
   const int items = B * (H / HG);
-  static const bool force1 = getenv("RAL_ATTN_QT1") != nullptr;   // experiment knob
-  if (N % 32 == 0 && !force1) {
+  static const bool force1 = getenv("RAL_ATTN_QT1") != nullptr;   // experiment knobs
+  static const bool force4 = getenv("RAL_ATTN_QT4") != nullptr;
+  if (N % 64 == 0 && force4) {
+    RAL_SET_LDS((k_attn_fwd<4>), lds);
+    k_attn_fwd<4><<<grid_for(items), 512, lds, s>>>(qkv, o_hm, lse, table, N, H, HG, Len, B);
+  } else if (N % 32 == 0 && !force1) {
     RAL_SET_LDS((k_attn_fwd<2>), lds);
     k_attn_fwd<2><<<grid_for(items), 512, lds, s>>>(qkv, o_hm, lse, table, N, H, HG, Len, B);
   } else {
