@@ -42,6 +42,15 @@ def kind_work(kind, L, B):
     return fl
 
 
+def measured_traffic(kind):
+    """HBM bytes per launch of this kernel kind from the committed PMC run (profiles/r01_hbm_traffic.json)."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
+        return d["per_launch_bytes"][kind]["total"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(leads, L, variant):
     """The oracle (CPU restatement of the reference op graph, parity-pinned by tests/golden) timed on the
     host cores of this box on a bounded sample: batch 32 (the reference's own batch, BASELINE config 0)."""
@@ -181,7 +190,7 @@ def main():
                        "global_batch": B * world, "parallelism": f"dp{world}", "sync_bn": True},
             "final_loss": round(loss, 6),
             "roofline": {"bound": "mfma", "kernel": a.kind, "achieved": round(ach, 3), "peak": peak,
-                         "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": measured_traffic(a.kind),
                          "launches": int(cnt.value), "avg_launch_ms": round(ms.value / max(cnt.value, 1), 4),
                          "share_of_step": round(ksec / dt, 4)},
         }
