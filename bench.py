@@ -160,18 +160,26 @@ def main():
         print(f"  sum of kinds   {tot:8.3f} ms/step", file=sys.stderr)
         _lib.check(lib.ral_profile_select(model.eng.h, b""))
 
-    infer = None
+    infer = infer_graph = None
     if a.infer:
+        # BASELINE config 4: eval-mode forward (BatchNorm running statistics), eager and hipGraph-captured
+        from ecg_denoise_amd.infer import GraphedForward
         model.eval()
-        with torch.no_grad():
-            for _ in range(2):
-                model(x)
-            sync()
-            t1 = time.perf_counter()
-            for _ in range(a.steps):
-                model(x)
-            sync()
-            infer = B * world * a.steps / (time.perf_counter() - t1)
+        for _ in range(2):
+            model(x)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            model(x)
+        sync()
+        infer = B * world * a.steps / (time.perf_counter() - t1)
+        gf = GraphedForward(model, B)
+        gf(x); sync()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            gf.graph.replay()
+        sync()
+        infer_graph = B * world * a.steps / (time.perf_counter() - t1)
 
     if rank == 0:
         ksec = ms.value * 1e-3
@@ -196,6 +204,7 @@ def main():
         }
         if infer is not None:
             res["infer_windows_per_s"] = round(infer, 1)
+            res["infer_hipgraph_windows_per_s"] = round(infer_graph, 1)
         if world == 1 and not a.no_cpu:
             res["cpu_baseline"] = cpu_baseline(a.leads, a.L, a.variant)
         print(json.dumps(res))
