@@ -849,6 +849,14 @@ int ral_adam_step(ral_handle* h, double lr, double beta1, double beta2, double e
   return 0;
 }
 
+int ral_set_option(ral_handle* h, const char* key, int value) {
+  if (!h || h->kind != 0) return fail("options exist for RA-LENet handles only");
+  RalModel* m = h->m;
+  if (!strcmp(key, "lanes")) { m->n_lanes = value < 1 ? 1 : (value > MAX_LANES ? MAX_LANES : value); return 0; }
+  if (!strcmp(key, "side_stream")) { m->side_stream = value != 0; return 0; }
+  return fail("unknown option %s", key);
+}
+
 int ral_profile_select(ral_handle* h, const char* kind) {
   if (!h || h->kind != 0) return fail("profiling is available for RA-LENet handles only");
   RalModel* m = h->m;
