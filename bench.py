@@ -150,28 +150,28 @@ def main():
         sync()
         _lib.check(lib.ral_profile_read(model.eng.h, C.byref(ms), C.byref(cnt)))
         _lib.check(lib.ral_profile_select(model.eng.h, b""))
-        _lib.check(lib.ral_set_option(model.eng.h, b"lanes", 2))
-        _lib.check(lib.ral_set_option(model.eng.h, b"side_stream", 1))
+        if a.kinds and rank == 0:
+            tot = 0.0
+            for kind in ("qkv_fwd", "attn_fwd", "mlp_fwd", "resample_fwd", "mlp_bwd", "attn_bwd", "qkv_bwd", "dw", "resample_bwd"):
+                _lib.check(lib.ral_profile_select(model.eng.h, kind.encode()))
+                for _ in range(3):
+                    trainer.train_step(x, tgt)
+                sync()
+                ms2, cnt2 = C.c_double(), C.c_int64()
+                _lib.check(lib.ral_profile_read(model.eng.h, C.byref(ms2), C.byref(cnt2)))
+                w = kind_work(kind, a.L, B)
+                tot += ms2.value / 3
+                print(f"  {kind:14s} {ms2.value/3:8.3f} ms/step  {cnt2.value//3:4d} launches  "
+                      f"{(w / (ms2.value / 3 * 1e-3) / 1e12) if w else 0:7.2f} TF/s", file=sys.stderr)
+            print(f"  sum of kinds   {tot:8.3f} ms/step (serialised)", file=sys.stderr)
+            _lib.check(lib.ral_profile_select(model.eng.h, b""))
+        _lib.check(lib.ral_set_option(model.eng.h, b"lanes", int(os.environ.get("RAL_LANES", "2"))))
+        _lib.check(lib.ral_set_option(model.eng.h, b"side_stream", 0 if os.environ.get("RAL_NO_SIDE_STREAM") else 1))
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = tmax.item()
     loss = out["loss"].item()
-
-    if a.kinds and rank == 0:
-        tot = 0.0
-        for kind in ("qkv_fwd", "attn_fwd", "mlp_fwd", "resample_fwd", "mlp_bwd", "attn_bwd", "qkv_bwd", "dw", "resample_bwd"):
-            _lib.check(lib.ral_profile_select(model.eng.h, kind.encode()))
-            for _ in range(3):
-                trainer.train_step(x, tgt)
-            sync()
-            _lib.check(lib.ral_profile_read(model.eng.h, C.byref(ms), C.byref(cnt)))
-            w = kind_work(kind, a.L, B)
-            tot += ms.value / 3
-            print(f"  {kind:14s} {ms.value/3:8.3f} ms/step  {cnt.value//3:4d} launches  "
-                  f"{(w / (ms.value / 3 * 1e-3) / 1e12) if w else 0:7.2f} TF/s", file=sys.stderr)
-        print(f"  sum of kinds   {tot:8.3f} ms/step", file=sys.stderr)
-        _lib.check(lib.ral_profile_select(model.eng.h, b""))
 
     infer = infer_graph = None
     if a.infer:

@@ -379,7 +379,7 @@ __global__ __launch_bounds__(512) void k_qkv_bwd(const float* __restrict__ dqkv,
                                                  const float* __restrict__ extra, BlockP w, BlockP wt, BlockP gr,
                                                  float* __restrict__ dx, int N, int B) {
   extern __shared__ float4 smem4[];
-  constexpr int LD = LDof<C>::v, LPR = C / 4, TTB = TTBof<C>::v;
+  constexpr int LD = LDof<C>::v, LPR = C / 4;
   float* DQ = reinterpret_cast<float*>(smem4);  // HM, N x 3C
   float* Dh = DQ + N * 3 * C;                   // N x LD
   float* red = Dh + N * LD;                     // 2C
@@ -396,22 +396,29 @@ __global__ __launch_bounds__(512) void k_qkv_bwd(const float* __restrict__ dqkv,
     __syncthreads();
     // dh[t][c] = sum_m dqkv[t][m] Wqkv[m][c]   (K = 3C split as C (q rows) + 2C (kv rows))
     {
-      constexpr int mt = (C + 15) >> 4;
-      const int tg = (N >> 4) / TTB;
-      for (int u = wave; u < mt * tg; u += nw) {
-        const int m = u % mt, tgi = u / mt;
-        f32x4 acc[TTB];
+      auto run = [&](auto ttb_tag) {
+        constexpr int TT = decltype(ttb_tag)::value;
+        constexpr int mt = (C + 15) >> 4;
+        const int tg = (N >> 4) / TT;
+        for (int u = wave; u < mt * tg; u += nw) {
+          const int m = u % mt, tgi = u / mt;
+          f32x4 acc[TT];
 #pragma unroll
-        for (int tt = 0; tt < TTB; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        gemm_wx<C, TTB, false, LAY_HM>(wt.wqkv, 3 * C, m * 16, C, DQ, N, tgi * TTB * 16, acc);
-        gemm_wx<2 * C, TTB, false, LAY_HM>(wt.wqkv + C, 3 * C, m * 16, C, DQ + (C / 4) * N * 4, N, tgi * TTB * 16, acc);
-        const int row0 = m * 16 + 4 * g;
-        if (row0 < C) {
+          for (int tt = 0; tt < TT; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+          gemm_wx<C, TT, false, LAY_HM>(wt.wqkv, 3 * C, m * 16, C, DQ, N, tgi * TT * 16, acc);
+          gemm_wx<2 * C, TT, false, LAY_HM>(wt.wqkv + C, 3 * C, m * 16, C, DQ + (C / 4) * N * 4, N, tgi * TT * 16, acc);
+          const int row0 = m * 16 + 4 * g;
+          if (row0 < C) {
 #pragma unroll
-          for (int tt = 0; tt < TTB; ++tt)
-            *reinterpret_cast<float4*>(Dh + ((tgi * TTB + tt) * 16 + r) * LD + row0) = tofloat4(acc[tt]);
+            for (int tt = 0; tt < TT; ++tt)
+              *reinterpret_cast<float4*>(Dh + ((tgi * TT + tt) * 16 + r) * LD + row0) = tofloat4(acc[tt]);
+          }
         }
-      }
+      };
+      const int nt = N >> 4;
+      if ((nt & 3) == 0) run(std::integral_constant<int, 4>{});
+      else if ((nt & 1) == 0) run(std::integral_constant<int, 2>{});
+      else run(std::integral_constant<int, 1>{});
     }
     if ((int)threadIdx.x < 3 * C) {
       const int c = threadIdx.x;

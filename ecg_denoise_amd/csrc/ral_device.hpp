@@ -101,8 +101,8 @@ RAL_DEV void gemm_wx(const float* __restrict__ W, int ldw, int m0, int M, const 
 // (16-row m tile, TTB token tiles) dealt round-robin to the waves.  epi(row0, tok, v)
 // receives rows row0..row0+3 (row0 % 4 == 0, row0 < M) of token `tok`.
 template <int K, int TTB, bool WT, int LAY, class Epi>
-RAL_DEV void gemm_phase(const float* __restrict__ W, int ldw, int M, const float* Xs, int ldx,
-                        int ntiles, Epi epi) {
+RAL_DEV void gemm_phase_t(const float* __restrict__ W, int ldw, int M, const float* Xs, int ldx,
+                          int ntiles, Epi& epi) {
   const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
   const int mt = (M + 15) >> 4, tg = ntiles / TTB;
@@ -118,6 +118,17 @@ RAL_DEV void gemm_phase(const float* __restrict__ W, int ldw, int M, const float
       for (int tt = 0; tt < TTB; ++tt) epi(row0, (tgi * TTB + tt) * 16 + r, acc[tt]);
     }
   }
+}
+
+// The number of token tiles that share one weight-fragment load is the largest of {4, 2, 1} dividing the
+// tile count (a wide level with few tokens would otherwise re-read every weight once per 16 tokens).
+// TTBHINT is kept for call-site documentation only.
+template <int K, int TTBHINT, bool WT, int LAY, class Epi>
+RAL_DEV void gemm_phase(const float* __restrict__ W, int ldw, int M, const float* Xs, int ldx,
+                        int ntiles, Epi epi) {
+  if ((ntiles & 3) == 0) gemm_phase_t<K, 4, WT, LAY>(W, ldw, M, Xs, ldx, ntiles, epi);
+  else if ((ntiles & 1) == 0) gemm_phase_t<K, 2, WT, LAY>(W, ldw, M, Xs, ldx, ntiles, epi);
+  else gemm_phase_t<K, 1, WT, LAY>(W, ldw, M, Xs, ldx, ntiles, epi);
 }
 
 // row stride (floats) of a token-major LDS tile of width C: +4 breaks the power-of-two stride for the
