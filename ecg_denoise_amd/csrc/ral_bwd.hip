@@ -33,6 +33,7 @@ __global__ __launch_bounds__(512) void k_mlp_bwd(const float* __restrict__ dx2, 
   float* U0 = DC0 + N + 2;                      // N      : u_pre[:,0]
   float* C0 = U0 + N;                           // N      : conv output c0
   float* red = C0 + N;                          // 2C + 4 : ln2 grads + le taps (block reduction)
+  float* cs = red + 2 * C + 4;                  // 4C + 2C : column sums db1 | db2 | dbp, accumulated over the windows
   const int RPP = blockDim.x / LPR;
   const int cq = (threadIdx.x % LPR) * 4;
   const bool le = w.le != nullptr;
@@ -40,10 +41,8 @@ __global__ __launch_bounds__(512) void k_mlp_bwd(const float* __restrict__ dx2, 
   if (le) { lw0 = w.le[0]; lw1 = w.le[1]; lw2 = w.le[2]; }
   const float4 gam2 = *reinterpret_cast<const float4*>(w.ln2w + cq);
   // per-thread gradient accumulators (live across the window loop)
-  float db1[NCH];
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) db1[i] = 0.f;
-  float db2 = 0.f, dbp = 0.f, gle0 = 0.f, gle1 = 0.f, gle2 = 0.f;
+  float gle0 = 0.f, gle1 = 0.f, gle2 = 0.f;
+  for (int i = threadIdx.x; i < 6 * C; i += blockDim.x) cs[i] = 0.f;   // visible after the first barrier below
   float4 dgam = make_float4(0.f, 0.f, 0.f, 0.f), dbet = make_float4(0.f, 0.f, 0.f, 0.f);
 
   for (int win = blockIdx.x; win < B; win += gridDim.x) {
@@ -98,11 +97,7 @@ __global__ __launch_bounds__(512) void k_mlp_bwd(const float* __restrict__ dx2, 
         __syncthreads();
       }
       copy_out(dupre + (size_t)win * N * 4 * C + j0, 4 * C, Us, LDU, N, HC);
-      if ((int)threadIdx.x < HC) {
-        float s = 0.f;
-        for (int n = 0; n < N; ++n) s += Us[n * LDU + threadIdx.x];
-        db1[ch] += s;
-      }
+      lds_colsum_add<LAY_TOK>(cs + j0, Us, LDU, N, HC);   // db1
       // dg (+)= du W1[chunk, :]
       gemm_phase<HC, TTBof<C>::v, false, LAY_TOK>(wt.w1 + j0, 4 * C, C, Us, LDU, N >> 4,
                                                  [&](int row0, int tok, f32x4 a) {
@@ -111,11 +106,7 @@ __global__ __launch_bounds__(512) void k_mlp_bwd(const float* __restrict__ dx2, 
       });
       __syncthreads();
     }
-    if ((int)threadIdx.x < C) {
-      float s = 0.f;
-      for (int n = 0; n < N; ++n) s += Ds[n * LD + threadIdx.x];
-      db2 += s;
-    }
+    lds_colsum_add<LAY_TOK>(cs + 4 * C, Ds, LD, N, C);    // db2
     __syncthreads();
     // LN2 backward, dx1 = dx2 + dLN
     for (int row = threadIdx.x / LPR; row < N; row += RPP) {
@@ -137,11 +128,7 @@ __global__ __launch_bounds__(512) void k_mlp_bwd(const float* __restrict__ dx2, 
     }
     __syncthreads();
     copy_out(dx1 + wo, C, Ds, LD, N, C);
-    if ((int)threadIdx.x < C) {
-      float s = 0.f;
-      for (int n = 0; n < N; ++n) s += Ds[n * LD + threadIdx.x];
-      dbp += s;
-    }
+    lds_colsum_add<LAY_TOK>(cs + 5 * C, Ds, LD, N, C);    // dbp
     // do = dx1 Wp  (head-major)
     float* dow = do_hm + wo;
     gemm_phase<C, TTBof<C>::v, false, LAY_TOK>(wt.wp, C, C, Ds, LD, N >> 4, [&](int row0, int tok, f32x4 a) {
@@ -162,14 +149,11 @@ __global__ __launch_bounds__(512) void k_mlp_bwd(const float* __restrict__ dx2, 
   if ((int)threadIdx.x < C) {
     atomicAdd(gr.ln2w + threadIdx.x, red[threadIdx.x]);
     atomicAdd(gr.ln2b + threadIdx.x, red[C + threadIdx.x]);
-    atomicAdd(gr.b2 + threadIdx.x, db2);
-    atomicAdd(gr.bp + threadIdx.x, dbp);
+    atomicAdd(gr.b2 + threadIdx.x, cs[4 * C + threadIdx.x]);
+    atomicAdd(gr.bp + threadIdx.x, cs[5 * C + threadIdx.x]);
   }
   if (le && threadIdx.x < 3) atomicAdd(gr.le + threadIdx.x, red[2 * C + threadIdx.x]);
-  if ((int)threadIdx.x < HC) {
-#pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) atomicAdd(gr.b1 + ch * HC + threadIdx.x, db1[ch]);
-  }
+  for (int i = threadIdx.x; i < 4 * C; i += blockDim.x) atomicAdd(gr.b1 + i, cs[i]);
 }
 
 // =================================================================================
@@ -383,11 +367,12 @@ __global__ __launch_bounds__(512) void k_qkv_bwd(const float* __restrict__ dqkv,
   float* DQ = reinterpret_cast<float*>(smem4);  // HM, N x 3C
   float* Dh = DQ + N * 3 * C;                   // N x LD
   float* red = Dh + N * LD;                     // 2C
+  float* cs = red + 2 * C;                      // 3C : column sums of dqkv (bias gradient), accumulated over the windows
   const int RPP = blockDim.x / LPR;
   const int cq = (threadIdx.x % LPR) * 4;
   const float sqrtC = sqrtf((float)C);
   const float4 gam1 = *reinterpret_cast<const float4*>(w.ln1w + cq);
-  float dbq = 0.f;  // thread c < 3C (C=128: 384 <= 512 threads)
+  for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) cs[i] = 0.f;
   float4 dgam = make_float4(0.f, 0.f, 0.f, 0.f), dbet = make_float4(0.f, 0.f, 0.f, 0.f);
   const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
   for (int win = blockIdx.x; win < B; win += gridDim.x) {
@@ -420,13 +405,7 @@ __global__ __launch_bounds__(512) void k_qkv_bwd(const float* __restrict__ dqkv,
       else if ((nt & 1) == 0) run(std::integral_constant<int, 2>{});
       else run(std::integral_constant<int, 1>{});
     }
-    if ((int)threadIdx.x < 3 * C) {
-      const int c = threadIdx.x;
-      const float* col = DQ + (c >> 2) * N * 4 + (c & 3);
-      float s = 0.f;
-      for (int n = 0; n < N; ++n) s += col[n * 4];
-      dbq += s;
-    }
+    lds_colsum_add<LAY_HM>(cs, DQ, N, N, 3 * C);
     __syncthreads();
     for (int row = threadIdx.x / LPR; row < N; row += RPP) {
       float4 v = *reinterpret_cast<const float4*>(x + wo + (size_t)row * C + cq);
@@ -460,7 +439,7 @@ __global__ __launch_bounds__(512) void k_qkv_bwd(const float* __restrict__ dqkv,
     atomicAdd(gr.ln1w + threadIdx.x, red[threadIdx.x]);
     atomicAdd(gr.ln1b + threadIdx.x, red[C + threadIdx.x]);
   }
-  if ((int)threadIdx.x < 3 * C) atomicAdd(gr.bqkv + threadIdx.x, dbq);
+  if ((int)threadIdx.x < 3 * C) atomicAdd(gr.bqkv + threadIdx.x, cs[threadIdx.x]);
 }
 
 // =================================================================================
@@ -739,7 +718,7 @@ static inline int ew_grid(size_t n, int per = 256) {
 }
 
 size_t mlp_bwd_lds(int C, int N, int nch) {
-  return ((size_t)2 * N * ld_of(C) + (size_t)N * ld_of(4 * C / nch) + 2 * (N + 2) + 2 * N + 2 * C + 8) * sizeof(float);
+  return ((size_t)2 * N * ld_of(C) + (size_t)N * ld_of(4 * C / nch) + 2 * (N + 2) + 2 * N + 8 * C + 16) * sizeof(float);
 }
 
 template <int C>
@@ -780,7 +759,7 @@ void launch_attn_bwd(const float* qkv, const float* o_hm, const float* do_hm, co
   }
 }
 
-size_t qkv_bwd_lds(int C, int N) { return ((size_t)N * 3 * C + (size_t)N * ld_of(C) + 2 * C + 4) * sizeof(float); }
+size_t qkv_bwd_lds(int C, int N) { return ((size_t)N * 3 * C + (size_t)N * ld_of(C) + 5 * C + 8) * sizeof(float); }
 
 void launch_qkv_bwd(int C, const float* dqkv, const float* x, const float* pe, const float* dx1, const float* extra,
                     const BlockP& w, const BlockP& wt, const BlockP& gr, float* dx, int N, int B, hipStream_t s) {

@@ -272,6 +272,19 @@ RAL_DEV void copy_flat(float* dst, const float* __restrict__ src, int n4) {
   for_each_f4<4>(src, n4, [&](int i, float4 v) { reinterpret_cast<float4*>(dst)[i] = v; });
 }
 
+// column sums of an LDS tile (rows x width) added into an LDS vector cs[width] by ALL threads of the block
+// (thread = (row group, column); one LDS atomic per thread).  The bias gradients are such sums over tokens.
+template <int LAY>
+RAL_DEV void lds_colsum_add(float* cs, const float* tile, int ld, int rows, int width) {
+  const int groups = blockDim.x / width;
+  const int col = threadIdx.x % width, grp = threadIdx.x / width;
+  if (grp < groups) {
+    float s = 0.f;
+    for (int n = grp; n < rows; n += groups) s += tile[xoff<LAY>(ld, n, col)];
+    atomicAdd(cs + col, s);
+  }
+}
+
 // Parameters of one TransformerBlock inside the flat parameter (or gradient) buffer.
 struct BlockP {
   float* wqkv;  // (3C, C): to_q.weight then to_kv.weight
