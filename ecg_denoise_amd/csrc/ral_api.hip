@@ -307,7 +307,7 @@ static void choose_tiling(RalModel* m) {
   const size_t budget_af = env_size("RAL_ATTN_FWD_LDS", 72 * 1024), budget_ab = env_size("RAL_ATTN_BWD_LDS", 78 * 1024);
   // split-K workgroups of the weight-gradient kernels per channel width {8,16,32,64,128}: many for the
   // narrow levels (staging latency-bound, tiny dW), few for the wide ones (the final atomics scale with it)
-  static const int KS_DEFAULT[5] = {1024, 1024, 512, 256, 128};
+  static const int KS_DEFAULT[5] = {256, 256, 256, 128, 64};
   for (int l = 0; l < 5; ++l) m->dw_ksplit[l] = KS_DEFAULT[l];
   if (const char* v = getenv("RAL_DW_KSPLIT")) sscanf(v, "%d,%d,%d,%d,%d", &m->dw_ksplit[0], &m->dw_ksplit[1], &m->dw_ksplit[2], &m->dw_ksplit[3], &m->dw_ksplit[4]);
   set_dw_lds_budget(env_size("RAL_DW_LDS", 50 * 1024));

@@ -177,7 +177,7 @@ static void launch_dw_t(const float* Y, const float* X, const float* pe, const f
 }
 
 // slice widths: at most 256 rows/columns of the wide operand per workgroup
-template <int W> struct SliceOf { static constexpr int v = W > 256 ? ((W % 256 == 0) ? 256 : W / 2) : W; };
+template <int W> struct SliceOf { static constexpr int v = W > 128 ? ((W % 128 == 0) ? 128 : W / 2) : W; };
 
 template <int C>
 static void launch_block_dw_c(const float* dx2, const float* upre, const float* dupre, const float* x1,

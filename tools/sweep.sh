@@ -1,6 +1,7 @@
 #!/bin/bash
-run() { echo "=== $*"; env "$@" python bench.py --steps 10 --warmup 2 --no-cpu --infer 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d.get('infer_windows_per_s'))"; }
-run RAL_LANES=1
-run RAL_LANES=2
-run RAL_LANES=4
-run RAL_LANES=2 RAL_NO_SIDE_STREAM=1
+run() { echo "=== $*"; env "$@" python bench.py --steps 8 --warmup 2 --no-cpu 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"; }
+run RAL_DW_KSPLIT=512,512,256,128,64
+run RAL_DW_KSPLIT=256,256,128,64,32
+run RAL_DW_KSPLIT=256,256,256,128,64
+run RAL_DW_KSPLIT=512,512,256,64,32
+run RAL_DW_KSPLIT=128,128,128,64,32
