@@ -170,9 +170,14 @@ static void launch_dw_t(const float* Y, const float* X, const float* pe, const f
   const int TC = dw_chunk(MS, NS, yhm, xhm, N, g_dw_budget);
   const size_t lds = dw_lds(MS, NS, yhm, xhm, TC, N);
   RAL_SET_LDS((k_dw<M, NC, MS, NS, LAYY, XF>), lds);
-  dim3 grid(B < ksplit ? B : ksplit, (M / MS) * (NC / NS));
-  // the staging loops are blockDim-generic; keep at least two waves so staging has some parallelism
-  constexpr int threads = (WM * WN * 64 < 128) ? 128 : WM * WN * 64;
+  // ksplit is the split-K count of a fully sliced product; products with fewer slices get proportionally more
+  // split-K workgroups so that every launch still fills the chip (at least ~256 workgroups)
+  constexpr int nsl = (M / MS) * (NC / NS);
+  int ks = ksplit;
+  if (ks * nsl < 256) ks = (256 + nsl - 1) / nsl;
+  dim3 grid(B < ks ? B : ks, nsl);
+  // staging (LayerNorm / GELU re-computation) uses all 8 waves even when only WM*WN of them own MFMA tiles
+  constexpr int threads = 512;
   k_dw<M, NC, MS, NS, LAYY, XF><<<grid, threads, lds, s>>>(Y, X, pe, lnw, lnb, le, dW, N, TC, B);
 }
 
