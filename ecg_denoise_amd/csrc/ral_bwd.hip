@@ -195,15 +195,35 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd(const float* __restrict__ q
     const float* base = qkv + (size_t)win * 3 * H * N * 4;
     float* dbase = dqkv + (size_t)win * 3 * H * N * 4;
     const size_t hq0 = ((size_t)win * H + h0) * N;
-    for_each_f4<4>(base + (size_t)h0 * N * 4, HG * N, [&](int i, float4 q) {
-      reinterpret_cast<float4*>(Qs)[i] = f4scale(q, RAL_LOG2E);
-    });
-    for_each_f4<4>(do_hm + hq0 * 4, HG * N, [&](int i, float4 d4) { reinterpret_cast<float4*>(dOs)[i] = d4; });
-    for (int i = threadIdx.x; i < HG * N; i += blockDim.x) Ls[i] = -lse[hq0 + i] * RAL_LOG2E;
-    copy_flat(Ks, base + (size_t)(H + h0) * N * 4, HG * N);
-    copy_flat(Vs, base + (size_t)(2 * H + h0) * N * 4, HG * N);
-    // delta = rowsum(dO * O): each thread re-reads the dO rows it staged itself (same index mapping)
-    for_each_f4<4>(o_hm + hq0 * 4, HG * N, [&](int i, float4 o4) { Dl[i] = -f4dot(reinterpret_cast<const float4*>(dOs)[i], o4); });
+    // one staging pass: the six loads of an index are issued together (a separate loop per tensor would pay
+    // one HBM round trip each)
+    {
+      const float4* gq = reinterpret_cast<const float4*>(base + (size_t)h0 * N * 4);
+      const float4* gk = reinterpret_cast<const float4*>(base + (size_t)(H + h0) * N * 4);
+      const float4* gv = reinterpret_cast<const float4*>(base + (size_t)(2 * H + h0) * N * 4);
+      const float4* gd = reinterpret_cast<const float4*>(do_hm) + hq0;
+      const float4* go = reinterpret_cast<const float4*>(o_hm) + hq0;
+      const int n4 = HG * N, bd = blockDim.x;
+      int i = threadIdx.x;
+      for (; i + bd < n4; i += 2 * bd) {
+        const float4 q0 = gq[i], q1 = gq[i + bd], k0 = gk[i], k1 = gk[i + bd], v0 = gv[i], v1 = gv[i + bd];
+        const float4 d0 = gd[i], d1 = gd[i + bd], o0 = go[i], o1 = go[i + bd];
+        const float l0 = lse[hq0 + i], l1 = lse[hq0 + i + bd];
+        reinterpret_cast<float4*>(Qs)[i] = f4scale(q0, RAL_LOG2E); reinterpret_cast<float4*>(Qs)[i + bd] = f4scale(q1, RAL_LOG2E);
+        reinterpret_cast<float4*>(Ks)[i] = k0; reinterpret_cast<float4*>(Ks)[i + bd] = k1;
+        reinterpret_cast<float4*>(Vs)[i] = v0; reinterpret_cast<float4*>(Vs)[i + bd] = v1;
+        reinterpret_cast<float4*>(dOs)[i] = d0; reinterpret_cast<float4*>(dOs)[i + bd] = d1;
+        Dl[i] = -f4dot(d0, o0); Dl[i + bd] = -f4dot(d1, o1);
+        Ls[i] = -l0 * RAL_LOG2E; Ls[i + bd] = -l1 * RAL_LOG2E;
+      }
+      for (; i < n4; i += bd) {
+        const float4 q0 = gq[i], k0 = gk[i], v0 = gv[i], d0 = gd[i], o0 = go[i];
+        const float l0 = lse[hq0 + i];
+        reinterpret_cast<float4*>(Qs)[i] = f4scale(q0, RAL_LOG2E);
+        reinterpret_cast<float4*>(Ks)[i] = k0; reinterpret_cast<float4*>(Vs)[i] = v0; reinterpret_cast<float4*>(dOs)[i] = d0;
+        Dl[i] = -f4dot(d0, o0); Ls[i] = -l0 * RAL_LOG2E;
+      }
+    }
     for (int i = threadIdx.x; i < ntab; i += blockDim.x) tab[i] = table[(i / HG) * H + h0 + (i % HG)] * RAL_LOG2E;
     __syncthreads();
     const int nblk = N / (16 * QT);

@@ -86,16 +86,30 @@ __global__ __launch_bounds__(512, (QT >= 4 ? 3 : 4)) void k_attn_fwd(const float
     const float* base = qkv + (size_t)win * 3 * H * N * 4;
     if ((int)threadIdx.x < HG) { Kmax[threadIdx.x] = 0; if (table) Bmax[threadIdx.x] = 0.f; }
     __syncthreads();
-    for_each_f4<4>(base + (size_t)h0 * N * 4, HG * N, [&](int i, float4 q) {
-      q = f4scale(q, RAL_LOG2E);
-      reinterpret_cast<float4*>(Qs)[i] = q;
-      Mq[i] = sqrtf(f4dot(q, q));
-    });
-    for_each_f4<4>(base + (size_t)(H + h0) * N * 4, HG * N, [&](int i, float4 k) {
-      reinterpret_cast<float4*>(Ks)[i] = k;
-      atomicMax(Kmax + i / N, __float_as_int(f4dot(k, k)));   // non-negative floats order like ints
-    });
-    copy_flat(Vs, base + (size_t)(2 * H + h0) * N * 4, HG * N);
+    {   // one staging pass with the q, k and v loads of two indices in flight together
+      const float4* gq = reinterpret_cast<const float4*>(base + (size_t)h0 * N * 4);
+      const float4* gk = reinterpret_cast<const float4*>(base + (size_t)(H + h0) * N * 4);
+      const float4* gv = reinterpret_cast<const float4*>(base + (size_t)(2 * H + h0) * N * 4);
+      const int n4 = HG * N, bd = blockDim.x;
+      int i = threadIdx.x;
+      for (; i + bd < n4; i += 2 * bd) {
+        float4 q0 = gq[i], q1 = gq[i + bd];
+        const float4 k0 = gk[i], k1 = gk[i + bd], v0 = gv[i], v1 = gv[i + bd];
+        q0 = f4scale(q0, RAL_LOG2E); q1 = f4scale(q1, RAL_LOG2E);
+        reinterpret_cast<float4*>(Qs)[i] = q0; reinterpret_cast<float4*>(Qs)[i + bd] = q1;
+        reinterpret_cast<float4*>(Ks)[i] = k0; reinterpret_cast<float4*>(Ks)[i + bd] = k1;
+        reinterpret_cast<float4*>(Vs)[i] = v0; reinterpret_cast<float4*>(Vs)[i + bd] = v1;
+        Mq[i] = sqrtf(f4dot(q0, q0)); Mq[i + bd] = sqrtf(f4dot(q1, q1));
+        atomicMax(Kmax + i / N, __float_as_int(f4dot(k0, k0)));   // non-negative floats order like ints
+        atomicMax(Kmax + (i + bd) / N, __float_as_int(f4dot(k1, k1)));
+      }
+      for (; i < n4; i += bd) {
+        const float4 q0 = f4scale(gq[i], RAL_LOG2E), k0 = gk[i], v0 = gv[i];
+        reinterpret_cast<float4*>(Qs)[i] = q0; reinterpret_cast<float4*>(Ks)[i] = k0; reinterpret_cast<float4*>(Vs)[i] = v0;
+        Mq[i] = sqrtf(f4dot(q0, q0));
+        atomicMax(Kmax + i / N, __float_as_int(f4dot(k0, k0)));
+      }
+    }
     if (table)
       for (int i = threadIdx.x; i < (2 * Len - 1) * HG; i += blockDim.x) {
         const float t = table[(i / HG) * H + h0 + (i % HG)] * RAL_LOG2E;
