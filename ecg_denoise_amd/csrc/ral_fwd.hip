@@ -263,8 +263,24 @@ __global__ __launch_bounds__(512) void k_mlp_fwd(const float* __restrict__ x, co
   if (le) { lw0 = w.le[0]; lw1 = w.le[1]; lw2 = w.le[2]; }
   for (int win = blockIdx.x; win < B; win += gridDim.x) {
     const size_t wo = (size_t)win * N * C;
-    copy_in(Xs, LD, x + wo, C, N, C);
-    copy_flat(Gs, o_hm + wo, N * C / 4);
+    {   // x (token-major -> padded rows) and o (head-major, flat) staged in one pass: 4 loads in flight per thread
+      const float4* gx = reinterpret_cast<const float4*>(x + wo);
+      const float4* go = reinterpret_cast<const float4*>(o_hm + wo);
+      constexpr int q = C / 4;
+      const int n4 = N * q, bd = blockDim.x;
+      int i = threadIdx.x;
+      for (; i + bd < n4; i += 2 * bd) {
+        const float4 x0 = gx[i], x1 = gx[i + bd], o0 = go[i], o1 = go[i + bd];
+        *reinterpret_cast<float4*>(Xs + (i / q) * LD + (i % q) * 4) = x0;
+        *reinterpret_cast<float4*>(Xs + ((i + bd) / q) * LD + ((i + bd) % q) * 4) = x1;
+        reinterpret_cast<float4*>(Gs)[i] = o0; reinterpret_cast<float4*>(Gs)[i + bd] = o1;
+      }
+      for (; i < n4; i += bd) {
+        const float4 x0 = gx[i], o0 = go[i];
+        *reinterpret_cast<float4*>(Xs + (i / q) * LD + (i % q) * 4) = x0;
+        reinterpret_cast<float4*>(Gs)[i] = o0;
+      }
+    }
     __syncthreads();
     // ---- attention output projection + residual ----
     gemm_phase<C, TTBof<C>::v, false, LAY_HM>(w.wp, C, C, Gs, N, N >> 4, [&](int row0, int tok, f32x4 a) {
