@@ -136,6 +136,114 @@ __global__ __launch_bounds__(256) void k_unet_fwd(Stage st, int B) {
   }
 }
 
+// ---------------------------------------------------------------------------------
+// forward stage, specialised: channel counts, kernel size and conv type are template parameters, every
+// thread produces 4 consecutive positions of one output channel from registers (inputs of a channel are
+// read once from the zero-haloed LDS row and reused by the 4 outputs), per-channel statistics go to LDS
+// with two atomics per thread.  MODE 0: Conv1d(k3, s2, p1); 1: Conv1d(k1 | k3, s1, same); 2: ConvTranspose1d(k4, s2, p1)
+// ---------------------------------------------------------------------------------
+template <int CIN, int COUT, int KS, int MODE>
+__global__ __launch_bounds__(256) void k_unet_fwd_t(Stage st, int B) {
+  extern __shared__ float4 smem4[];
+  constexpr int HALO = 4;                       // 16-byte aligned zero halo on both sides of every input row
+  const int lin = st.lin, lout = st.lout, LP = lin + 2 * HALO;
+  float* in = reinterpret_cast<float*>(smem4);  // CIN x LP
+  float* ws = in + CIN * LP;
+  constexpr int nw = CIN * COUT * KS;
+  float* bs = ws + nw;
+  float* ca = bs + MAXC; float* cb = ca + 4 * MAXC; float* cr = cb + 4 * MAXC;
+  float* red = cr + 4 * MAXC;
+  for (int i = threadIdx.x; i < nw; i += blockDim.x) ws[i] = st.w[i];
+  for (int i = threadIdx.x; i < COUT; i += blockDim.x) bs[i] = st.bias[i];
+  for (int i = threadIdx.x; i < 2 * MAXC; i += blockDim.x) red[i] = 0.f;
+  for (int i = threadIdx.x; i < CIN * 2 * HALO; i += blockDim.x) {   // halos stay zero for every window
+    const int c = i / (2 * HALO), h = i % (2 * HALO);
+    in[c * LP + (h < HALO ? h : lin + h)] = 0.f;
+  }
+  src_coeffs(st.a, CIN, st.count_a, ca);
+  if (st.b.z) src_coeffs(st.b, CIN, st.count_b, cb);
+  if (st.r.z) src_coeffs(st.r, COUT, st.count_r, cr);
+  __syncthreads();
+  const int nin = CIN * lin, nout = COUT * lout, q = lout >> 2, nslots = COUT * q;
+  for (int win = blockIdx.x; win < B; win += gridDim.x) {
+    const float* za = st.a.z + (size_t)win * nin;
+    const float* zb = st.b.z ? st.b.z + (size_t)win * nin : nullptr;
+    for (int i = threadIdx.x; i < (nin >> 2); i += blockDim.x) {
+      const int e = i << 2, c = e / lin, p = e - c * lin;
+      float4 v = *reinterpret_cast<const float4*>(za + e);
+      const float sa = ca[c], ha = ca[CIN + c];
+      v = make_float4(v.x * sa + ha, v.y * sa + ha, v.z * sa + ha, v.w * sa + ha);
+      if (st.a.act == ACT_LRELU) v = make_float4(lrelu01(v.x), lrelu01(v.y), lrelu01(v.z), lrelu01(v.w));
+      if (zb) {
+        const float4 u = *reinterpret_cast<const float4*>(zb + e);
+        const float sb = cb[c], hb = cb[CIN + c];
+        v.x += lrelu01(u.x * sb + hb); v.y += lrelu01(u.y * sb + hb); v.z += lrelu01(u.z * sb + hb); v.w += lrelu01(u.w * sb + hb);
+      }
+      *reinterpret_cast<float4*>(in + c * LP + HALO + p) = v;
+    }
+    __syncthreads();
+    for (int slot = threadIdx.x; slot < nslots; slot += blockDim.x) {
+      const int co = slot / q, l0 = (slot - co * q) << 2;
+      float acc[4] = {bs[co], bs[co], bs[co], bs[co]};
+#pragma unroll 4
+      for (int ci = 0; ci < CIN; ++ci) {
+        const float* row = in + ci * LP + HALO;
+        if constexpr (MODE == 0) {                      // out[l] = sum_k w[k] in[2l - 1 + k]
+          const float* wr = ws + (co * CIN + ci) * 3;
+          const float w0 = wr[0], w1 = wr[1], w2 = wr[2];
+          float x[9];
+#pragma unroll
+          for (int t = 0; t < 9; ++t) x[t] = row[2 * l0 - 1 + t];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] = fmaf(w0, x[2 * j], fmaf(w1, x[2 * j + 1], fmaf(w2, x[2 * j + 2], acc[j])));
+        } else if constexpr (MODE == 1 && KS == 3) {    // out[l] = sum_k w[k] in[l - 1 + k]
+          const float* wr = ws + (co * CIN + ci) * 3;
+          const float w0 = wr[0], w1 = wr[1], w2 = wr[2];
+          float x[6];
+#pragma unroll
+          for (int t = 0; t < 6; ++t) x[t] = row[l0 - 1 + t];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] = fmaf(w0, x[j], fmaf(w1, x[j + 1], fmaf(w2, x[j + 2], acc[j])));
+        } else if constexpr (MODE == 1) {               // 1x1
+          const float w0 = ws[co * CIN + ci];
+          const float4 x = *reinterpret_cast<const float4*>(row + l0);
+          acc[0] = fmaf(w0, x.x, acc[0]); acc[1] = fmaf(w0, x.y, acc[1]); acc[2] = fmaf(w0, x.z, acc[2]); acc[3] = fmaf(w0, x.w, acc[3]);
+        } else {                                        // ConvTranspose1d: out[j] += w[ci][co][k] in[i], j = 2i - 1 + k
+          const float* wr = ws + (ci * COUT + co) * 4;
+          const float w0 = wr[0], w1 = wr[1], w2 = wr[2], w3 = wr[3];
+          const int h = l0 >> 1;
+          const float x0 = row[h - 1], x1 = row[h], x2 = row[h + 1], x3 = row[h + 2];
+          acc[0] = fmaf(w1, x1, fmaf(w3, x0, acc[0]));
+          acc[1] = fmaf(w0, x2, fmaf(w2, x1, acc[1]));
+          acc[2] = fmaf(w1, x2, fmaf(w3, x1, acc[2]));
+          acc[3] = fmaf(w0, x3, fmaf(w2, x2, acc[3]));
+        }
+      }
+      if (st.post_lrelu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = lrelu01(acc[j]);
+      }
+      const size_t o = (size_t)win * nout + (size_t)co * lout + l0;
+      if (st.r.z) {
+        const float4 zr = *reinterpret_cast<const float4*>(st.r.z + o);
+        const float sr = cr[co], hr = cr[COUT + co];
+        acc[0] += lrelu01(zr.x * sr + hr); acc[1] += lrelu01(zr.y * sr + hr);
+        acc[2] += lrelu01(zr.z * sr + hr); acc[3] += lrelu01(zr.w * sr + hr);
+      }
+      *reinterpret_cast<float4*>(st.out + o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      if (st.sums_out) {
+        atomicAdd(red + co, (acc[0] + acc[1]) + (acc[2] + acc[3]));
+        atomicAdd(red + MAXC + co, (acc[0] * acc[0] + acc[1] * acc[1]) + (acc[2] * acc[2] + acc[3] * acc[3]));
+      }
+    }
+    __syncthreads();
+  }
+  if (st.sums_out && (int)threadIdx.x < COUT) {
+    atomicAdd(st.sums_out + threadIdx.x, (double)red[threadIdx.x]);
+    atomicAdd(st.sums_out + MAXC + threadIdx.x, (double)red[MAXC + threadIdx.x]);
+  }
+}
+
 // final: y = BN9(z9) elementwise;  also running-stat updates of all layers
 __global__ void k_unet_out(Src s, float* __restrict__ y, int C, int L, double count, size_t total) {
   __shared__ float ss[4 * MAXC];
@@ -343,6 +451,237 @@ __global__ __launch_bounds__(256) void k_unet_bwd(Stage st, int B) {
     }
   }
   if (st.r.z && st.r.G && (int)threadIdx.x < st.cout) {
+    atomicAdd(st.r.bsums + threadIdx.x, (double)sr[threadIdx.x]);
+    atomicAdd(st.r.bsums + MAXC + threadIdx.x, (double)sr[MAXC + threadIdx.x]);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// backward stage, specialised (same template parameters as k_unet_fwd_t).  Per window:
+//   1. input tile (BatchNorm + LeakyReLU + skip applied on load) and the gradient tile at the conv output
+//      (BatchNorm-backward correction applied on load) go to zero-haloed LDS rows;
+//   2. input gradient: a thread produces 4 consecutive positions of one input channel and emits the gradients at
+//      the producers' BatchNorm outputs (+ their per-channel sums);
+//   3. weight gradient: a thread owns one (co, ci) pair and a 32-position chunk, all KS taps in registers;
+//      partial sums are accumulated in an LDS copy of the weight tensor and flushed once per workgroup.
+// ---------------------------------------------------------------------------------
+template <int CIN, int COUT, int KS, int MODE>
+__global__ __launch_bounds__(256) void k_unet_bwd_t(Stage st, int B) {
+  extern __shared__ float4 smem4[];
+  constexpr int HALO = 4, nw = CIN * COUT * KS;
+  const int lin = st.lin, lout = st.lout, LP = lin + 2 * HALO, LPO = lout + 2 * HALO;
+  float* in = reinterpret_cast<float*>(smem4);   // CIN x LP
+  float* dc = in + CIN * LP;                     // COUT x LPO
+  float* ws = dc + COUT * LPO;                   // weights
+  float* gws = ws + nw;                          // weight-gradient accumulators
+  float* ca = gws + nw; float* cb = ca + 4 * MAXC; float* cr = cb + 4 * MAXC; float* co_ = cr + 4 * MAXC;
+  float* sa = co_ + 5 * MAXC; float* sb = sa + 2 * MAXC; float* sr = sb + 2 * MAXC;
+  float* gbs = sr + 2 * MAXC;                    // MAXC bias grads + 4*MAXC scratch
+  for (int i = threadIdx.x; i < nw; i += blockDim.x) { ws[i] = st.w[i]; gws[i] = 0.f; }
+  for (int i = threadIdx.x; i < 7 * MAXC; i += blockDim.x) sa[i] = 0.f;   // sa, sb, sr, gbs[0:MAXC]
+  for (int i = threadIdx.x; i < CIN * 2 * HALO; i += blockDim.x) {
+    const int c = i / (2 * HALO), h = i % (2 * HALO);
+    in[c * LP + (h < HALO ? h : lin + h)] = 0.f;
+  }
+  for (int i = threadIdx.x; i < COUT * 2 * HALO; i += blockDim.x) {
+    const int c = i / (2 * HALO), h = i % (2 * HALO);
+    dc[c * LPO + (h < HALO ? h : lout + h)] = 0.f;
+  }
+  src_coeffs(st.a, CIN, st.count_a, ca);
+  if (st.b.z) src_coeffs(st.b, CIN, st.count_b, cb);
+  if (st.r.z) src_coeffs(st.r, COUT, st.count_r, cr);
+  if (st.type != TY_PLAIN) {   // BN-backward coefficients of this stage's output
+    Src o; o.norm = NORM_BATCH; o.sums = st.sums_out; o.gamma = st.gamma_out; o.beta = st.gamma_out; o.act = ACT_NONE;
+    float* tmp = gbs + MAXC;
+    src_coeffs(o, COUT, st.count, tmp);
+    __syncthreads();
+    for (int c = threadIdx.x; c < COUT; c += blockDim.x) {
+      co_[c] = st.gamma_out[c] * tmp[3 * COUT + c];                      // gamma * rstd
+      co_[MAXC + c] = (float)(st.bsums_out[c] / st.count);               // mean(G)
+      co_[2 * MAXC + c] = (float)(st.bsums_out[MAXC + c] / st.count);    // mean(G * zhat)
+      co_[3 * MAXC + c] = tmp[2 * COUT + c];                             // mean
+      co_[4 * MAXC + c] = tmp[3 * COUT + c];                             // rstd
+    }
+  }
+  __syncthreads();
+  const int nin = CIN * lin, nout = COUT * lout;
+  for (int win = blockIdx.x; win < B; win += gridDim.x) {
+    const float* za = st.a.z + (size_t)win * nin;
+    const float* zb = st.b.z ? st.b.z + (size_t)win * nin : nullptr;
+    for (int i = threadIdx.x; i < (nin >> 2); i += blockDim.x) {
+      const int e = i << 2, c = e / lin, p = e - c * lin;
+      float4 v = *reinterpret_cast<const float4*>(za + e);
+      const float s = ca[c], h = ca[CIN + c];
+      v = make_float4(v.x * s + h, v.y * s + h, v.z * s + h, v.w * s + h);
+      if (st.a.act == ACT_LRELU) v = make_float4(lrelu01(v.x), lrelu01(v.y), lrelu01(v.z), lrelu01(v.w));
+      if (zb) {
+        const float4 u = *reinterpret_cast<const float4*>(zb + e);
+        const float s2 = cb[c], h2 = cb[CIN + c];
+        v.x += lrelu01(u.x * s2 + h2); v.y += lrelu01(u.y * s2 + h2); v.z += lrelu01(u.z * s2 + h2); v.w += lrelu01(u.w * s2 + h2);
+      }
+      *reinterpret_cast<float4*>(in + c * LP + HALO + p) = v;
+    }
+    // gradient at the conv output (+ bias gradient, + gradient of the residual operand)
+    for (int i = threadIdx.x; i < (nout >> 2); i += blockDim.x) {
+      const int e = i << 2, c = e / lout, p = e - c * lout;
+      const size_t o = (size_t)win * nout + e;
+      const float4 g4 = *reinterpret_cast<const float4*>(st.Gout + o);
+      float g[4] = {g4.x, g4.y, g4.z, g4.w};
+      if (st.type != TY_PLAIN) {
+        const float4 z4 = *reinterpret_cast<const float4*>(st.out + o);
+        const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
+        const float k = co_[c], m1 = co_[MAXC + c], m2 = co_[2 * MAXC + c], mu = co_[3 * MAXC + c], rs = co_[4 * MAXC + c];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float zh = (zz[j] - mu) * rs;
+          float v = k * (g[j] - m1 - zh * m2);
+          if (st.type == TY_ABN && zz[j] <= 0.f) v *= 0.01f;   // stored tensor is lrelu(conv)
+          g[j] = v;
+        }
+      }
+      *reinterpret_cast<float4*>(dc + c * LPO + HALO + p) = make_float4(g[0], g[1], g[2], g[3]);
+      atomicAdd(gbs + c, (g[0] + g[1]) + (g[2] + g[3]));
+      if (st.r.z && st.r.G) {   // residual operand lrelu(BN(z_r)) was added to the output: its gradient is Gout * lrelu'
+        const float4 zr = *reinterpret_cast<const float4*>(st.r.z + o);
+        const float zrr[4] = {zr.x, zr.y, zr.z, zr.w}, gg[4] = {g4.x, g4.y, g4.z, g4.w};
+        const float s = cr[c], h = cr[COUT + c], mu = cr[2 * COUT + c], rs = cr[3 * COUT + c];
+        float gr[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          gr[j] = (zrr[j] * s + h <= 0.f) ? 0.01f * gg[j] : gg[j];
+          s1 += gr[j]; s2 += gr[j] * (zrr[j] - mu) * rs;
+        }
+        float4* dst = reinterpret_cast<float4*>(st.r.G + o);
+        float4 outv = make_float4(gr[0], gr[1], gr[2], gr[3]);
+        if (st.r.accumulate) outv = f4add(outv, *dst);
+        *dst = outv;
+        atomicAdd(sr + c, s1); atomicAdd(sr + MAXC + c, s2);
+      }
+    }
+    __syncthreads();
+    // ---- input gradient ----
+    if (st.a.G) {
+      const int q = lin >> 2;
+      for (int slot = threadIdx.x; slot < CIN * q; slot += blockDim.x) {
+        const int ci = slot / q, p0 = (slot - ci * q) << 2;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int co = 0; co < COUT; ++co) {
+          const float* row = dc + co * LPO + HALO;
+          if constexpr (MODE == 0) {         // out[l] = sum_k w[k] in[2l-1+k]
+            const float* wr = ws + (co * CIN + ci) * 3;
+            const float w0 = wr[0], w1 = wr[1], w2 = wr[2];
+            const int h = p0 >> 1;
+            const float d0 = row[h], d1 = row[h + 1], d2 = row[h + 2];
+            acc[0] = fmaf(w1, d0, acc[0]);
+            acc[1] = fmaf(w0, d1, fmaf(w2, d0, acc[1]));
+            acc[2] = fmaf(w1, d1, acc[2]);
+            acc[3] = fmaf(w0, d2, fmaf(w2, d1, acc[3]));
+          } else if constexpr (MODE == 1 && KS == 3) {   // out[l] = sum_k w[k] in[l-1+k]  =>  d_in[p] = sum_k w[k] dc[p+1-k]
+            const float* wr = ws + (co * CIN + ci) * 3;
+            const float w0 = wr[0], w1 = wr[1], w2 = wr[2];
+            float d[6];
+#pragma unroll
+            for (int t = 0; t < 6; ++t) d[t] = row[p0 - 1 + t];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = fmaf(w0, d[j + 2], fmaf(w1, d[j + 1], fmaf(w2, d[j], acc[j])));
+          } else if constexpr (MODE == 1) {
+            const float w0 = ws[co * CIN + ci];
+            const float4 d = *reinterpret_cast<const float4*>(row + p0);
+            acc[0] = fmaf(w0, d.x, acc[0]); acc[1] = fmaf(w0, d.y, acc[1]); acc[2] = fmaf(w0, d.z, acc[2]); acc[3] = fmaf(w0, d.w, acc[3]);
+          } else {                           // d_in[i] = sum_k w[ci][co][k] dc[2i-1+k]
+            const float* wr = ws + (ci * COUT + co) * 4;
+            const float w0 = wr[0], w1 = wr[1], w2 = wr[2], w3 = wr[3];
+            float d[10];
+#pragma unroll
+            for (int t = 0; t < 10; ++t) d[t] = row[2 * p0 - 1 + t];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              acc[j] = fmaf(w0, d[2 * j], fmaf(w1, d[2 * j + 1], fmaf(w2, d[2 * j + 2], fmaf(w3, d[2 * j + 3], acc[j]))));
+          }
+        }
+        const size_t o = (size_t)win * nin + (size_t)ci * lin + p0;
+        {
+          const float4 z4 = *reinterpret_cast<const float4*>(za + (size_t)ci * lin + p0);
+          const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
+          const float s = ca[ci], h = ca[CIN + ci], mu = ca[2 * CIN + ci], rs = ca[3 * CIN + ci];
+          float ga[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            ga[j] = (st.a.act == ACT_LRELU && zz[j] * s + h <= 0.f) ? 0.01f * acc[j] : acc[j];
+            s1 += ga[j]; s2 += ga[j] * (zz[j] - mu) * rs;
+          }
+          float4* dst = reinterpret_cast<float4*>(st.a.G + o);
+          float4 outv = make_float4(ga[0], ga[1], ga[2], ga[3]);
+          if (st.a.accumulate) outv = f4add(outv, *dst);
+          *dst = outv;
+          if (st.a.bsums) { atomicAdd(sa + ci, s1); atomicAdd(sa + MAXC + ci, s2); }
+        }
+        if (zb && st.b.G) {
+          const float4 z4 = *reinterpret_cast<const float4*>(zb + (size_t)ci * lin + p0);
+          const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
+          const float s = cb[ci], h = cb[CIN + ci], mu = cb[2 * CIN + ci], rs = cb[3 * CIN + ci];
+          float gb4[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            gb4[j] = (zz[j] * s + h <= 0.f) ? 0.01f * acc[j] : acc[j];
+            s1 += gb4[j]; s2 += gb4[j] * (zz[j] - mu) * rs;
+          }
+          float4* dst = reinterpret_cast<float4*>(st.b.G + o);
+          float4 outv = make_float4(gb4[0], gb4[1], gb4[2], gb4[3]);
+          if (st.b.accumulate) outv = f4add(outv, *dst);
+          *dst = outv;
+          atomicAdd(sb + ci, s1); atomicAdd(sb + MAXC + ci, s2);
+        }
+      }
+    }
+    // ---- weight gradient: unit = (co, ci, chunk of output positions) ----
+    {
+      constexpr int CH = 32;
+      const int nchunk = (lout + CH - 1) / CH;
+      for (int u = threadIdx.x; u < COUT * CIN * nchunk; u += blockDim.x) {
+        const int pair = u / nchunk, chn = u - pair * nchunk;
+        const int co = pair / CIN, ci = pair - co * CIN;
+        const int l0 = chn * CH, l1 = (l0 + CH < lout) ? l0 + CH : lout;
+        const float* dr = dc + co * LPO + HALO;
+        const float* ir = in + ci * LP + HALO;
+        float g[KS];
+#pragma unroll
+        for (int k = 0; k < KS; ++k) g[k] = 0.f;
+        for (int l = l0; l < l1; ++l) {
+          const float d = dr[l];
+          if constexpr (MODE == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) g[k] = fmaf(d, ir[2 * l - 1 + k], g[k]);
+          } else if constexpr (MODE == 1) {
+#pragma unroll
+            for (int k = 0; k < KS; ++k) g[k] = fmaf(d, ir[l - (KS - 1) / 2 + k], g[k]);
+          } else {   // out[j] += w[k] in[i], j = 2i-1+k  =>  gw[k] += dc[j] in[(j+1-k)/2] for matching parity
+            const int k0 = (l + 1) & 1, i0 = (l + 1 - k0) >> 1;
+            g[k0] = fmaf(d, ir[i0], g[k0]);         // inactive taps of this parity keep their value
+            g[k0 + 2] = fmaf(d, ir[i0 - 1], g[k0 + 2]);
+          }
+        }
+        float* gd = (MODE == 2) ? gws + (ci * COUT + co) * KS : gws + (co * CIN + ci) * KS;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) atomicAdd(gd + k, g[k]);
+      }
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < nw; i += blockDim.x) atomicAdd(st.gw + i, gws[i]);
+  if ((int)threadIdx.x < COUT) atomicAdd(st.gb + threadIdx.x, gbs[threadIdx.x]);
+  if ((int)threadIdx.x < CIN) {
+    if (st.a.G && st.a.bsums) {
+      atomicAdd(st.a.bsums + threadIdx.x, (double)sa[threadIdx.x]);
+      atomicAdd(st.a.bsums + MAXC + threadIdx.x, (double)sa[MAXC + threadIdx.x]);
+    }
+    if (st.b.z && st.b.G) {
+      atomicAdd(st.b.bsums + threadIdx.x, (double)sb[threadIdx.x]);
+      atomicAdd(st.b.bsums + MAXC + threadIdx.x, (double)sb[MAXC + threadIdx.x]);
+    }
+  }
+  if (st.r.z && st.r.G && (int)threadIdx.x < COUT) {
     atomicAdd(st.r.bsums + threadIdx.x, (double)sr[threadIdx.x]);
     atomicAdd(st.r.bsums + MAXC + threadIdx.x, (double)sr[MAXC + threadIdx.x]);
   }
@@ -564,6 +903,32 @@ static Stage make_stage(UNetModel* m, int si, const float* x, bool training, boo
   return s;
 }
 
+
+// residual operand r of the specialised kernel is always lrelu(BN(z)) (bottleneck.6 + x); main operand act is a runtime flag
+template <int CIN, int COUT, int KS, int MODE>
+static void launch_fwd_t(const Stage& st, int B, int grid, hipStream_t s) {
+  const size_t lds = ((size_t)CIN * (st.lin + 8) + (size_t)CIN * COUT * KS + MAXC + 12 * MAXC + 2 * MAXC + 8) * sizeof(float);
+  k_unet_fwd_t<CIN, COUT, KS, MODE><<<grid, 256, lds, s>>>(st, B);
+}
+
+static bool launch_unet_fwd_fast(const Stage& st, int si, int leads, int B, int grid, hipStream_t s) {
+  if (st.lout % 4 || st.lin % 4) return false;
+  switch (si) {
+    case 0: if (leads == 1) launch_fwd_t<1, 4, 3, 0>(st, B, grid, s); else launch_fwd_t<2, 4, 3, 0>(st, B, grid, s); return true;
+    case 1: launch_fwd_t<4, 8, 3, 0>(st, B, grid, s); return true;
+    case 2: launch_fwd_t<8, 16, 3, 0>(st, B, grid, s); return true;
+    case 3: launch_fwd_t<16, 32, 3, 0>(st, B, grid, s); return true;
+    case 4: launch_fwd_t<32, 32, 1, 1>(st, B, grid, s); return true;
+    case 5: launch_fwd_t<32, 32, 3, 1>(st, B, grid, s); return true;
+    case 6: launch_fwd_t<32, 32, 1, 1>(st, B, grid, s); return true;
+    case 7: launch_fwd_t<32, 16, 4, 2>(st, B, grid, s); return true;
+    case 8: launch_fwd_t<16, 8, 4, 2>(st, B, grid, s); return true;
+    case 9: launch_fwd_t<8, 4, 4, 2>(st, B, grid, s); return true;
+    case 10: if (leads == 1) launch_fwd_t<4, 1, 4, 2>(st, B, grid, s); else launch_fwd_t<4, 2, 4, 2>(st, B, grid, s); return true;
+  }
+  return false;
+}
+
 int unet_forward(UNetModel* m, const float* x, float* y, int B, int training, hipStream_t s, char* err, size_t cap) {
   UNetPublic& P = m->pub;
   if (!P.params || !P.state) { snprintf(err, cap, "ral_bind was not called"); return -1; }
@@ -575,7 +940,7 @@ int unet_forward(UNetModel* m, const float* x, float* y, int B, int training, hi
   for (int si = 0; si < 11; ++si) {
     Stage st = make_stage(m, si, x, training != 0, false, B);
     if (!training) st.sums_out = nullptr;
-    k_unet_fwd<<<grid, 256, fwd_lds(st), s>>>(st, B);
+    if (!launch_unet_fwd_fast(st, si, P.cfg.leads, B, grid, s)) k_unet_fwd<<<grid, 256, fwd_lds(st), s>>>(st, B);
   }
   Src o = make_src(m, 10, ACT_NONE, training != 0, false, 0);
   const size_t total = (size_t)B * m->C[10] * m->Ln[10];
@@ -592,6 +957,32 @@ int unet_forward(UNetModel* m, const float* x, float* y, int B, int training, hi
   }
   if (hipGetLastError() != hipSuccess) { snprintf(err, cap, "U-Net forward launch failed"); return -1; }
   return 0;
+}
+
+
+template <int CIN, int COUT, int KS, int MODE>
+static void launch_bwd_t(const Stage& st, int B, int grid, hipStream_t s) {
+  const size_t lds = ((size_t)CIN * (st.lin + 8) + (size_t)COUT * (st.lout + 8) + (size_t)2 * CIN * COUT * KS + 17 * MAXC + 6 * MAXC +
+                      5 * MAXC + 8) * sizeof(float);
+  k_unet_bwd_t<CIN, COUT, KS, MODE><<<grid, 256, lds, s>>>(st, B);
+}
+
+static bool launch_unet_bwd_fast(const Stage& st, int si, int leads, int B, int grid, hipStream_t s) {
+  if (st.lout % 4 || st.lin % 4) return false;
+  switch (si) {
+    case 0: if (leads == 1) launch_bwd_t<1, 4, 3, 0>(st, B, grid, s); else launch_bwd_t<2, 4, 3, 0>(st, B, grid, s); return true;
+    case 1: launch_bwd_t<4, 8, 3, 0>(st, B, grid, s); return true;
+    case 2: launch_bwd_t<8, 16, 3, 0>(st, B, grid, s); return true;
+    case 3: launch_bwd_t<16, 32, 3, 0>(st, B, grid, s); return true;
+    case 4: launch_bwd_t<32, 32, 1, 1>(st, B, grid, s); return true;
+    case 5: launch_bwd_t<32, 32, 3, 1>(st, B, grid, s); return true;
+    case 6: launch_bwd_t<32, 32, 1, 1>(st, B, grid, s); return true;
+    case 7: launch_bwd_t<32, 16, 4, 2>(st, B, grid, s); return true;
+    case 8: launch_bwd_t<16, 8, 4, 2>(st, B, grid, s); return true;
+    case 9: launch_bwd_t<8, 4, 4, 2>(st, B, grid, s); return true;
+    case 10: if (leads == 1) launch_bwd_t<4, 1, 4, 2>(st, B, grid, s); else launch_bwd_t<4, 2, 4, 2>(st, B, grid, s); return true;
+  }
+  return false;
 }
 
 int unet_backward(UNetModel* m, const float* dy, float* dx, int B, hipStream_t s, char* err, size_t cap) {
@@ -616,7 +1007,7 @@ int unet_backward(UNetModel* m, const float* dy, float* dx, int B, hipStream_t s
     const size_t lds = bwd_lds(st);
     static size_t cur = 0;
     if (lds > cur) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_unet_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); cur = lds; }
-    k_unet_bwd<<<grid, 256, lds, s>>>(st, B);
+    if (!launch_unet_bwd_fast(st, si, P.cfg.leads, B, grid, s)) k_unet_bwd<<<grid, 256, lds, s>>>(st, B);
   }
   BnGradAll u;
   for (int bi = 0; bi < 10; ++bi)
