@@ -1,0 +1,37 @@
+"""SNR-improvement experiment on the synthetic ECG set: the main.py protocol — 10 000 windows,
+8000/2000 split, batch 32, Adam 1e-3, 100 epochs, emb noise at 0 dB — run through ecg_denoise_amd.train.train on
+one MI355X, compared with the per-epoch curve the REFERENCE produced on the same arrays
+(tests/golden/g6_ref_train_curve_full.npz, made by tools/ref_train_curve.py in the build container)."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from ecg_denoise_amd import RALENet, synth
+from ecg_denoise_amd.train import train
+
+epochs = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+variant = sys.argv[2] if len(sys.argv) > 2 else "full"
+noisy, clean = synth.make_dataset(10000, 2, 256, "emb", 0.0, seed=2023)
+(trn, trc), (ten, tec) = synth.split_8000_2000(noisy, clean)
+batches = lambda a, b: [(a[i:i + 32], b[i:i + 32]) for i in range(0, len(a), 32)]
+m = RALENet(variant, leads=2, L=256, max_batch=32, device="cuda:0", seed=777)
+in_snr = float(np.mean(10 * np.log10((tec ** 2).mean((1, 2)) / ((ten - tec) ** 2).mean((1, 2)))))
+t0 = time.time()
+res = train(epochs=epochs, model=m, batch_size=32, train_loader=batches(trn, trc), test_loader=batches(ten, tec), use_gpu=True,
+            model_name="ralenet", noise_name="emb", noise_intensity=0, out_dir=os.path.join(ROOT, "gpurun_out", "snr_run"),
+            log=lambda *_: None)
+dt = time.time() - t0
+out = {"variant": variant, "epochs": epochs, "seconds": round(dt, 1), "input_snr_test_db": round(in_snr, 4),
+       "final_test_snr_db": res[1][-1], "snr_improvement_db": res[1][-1] - in_snr, "test_snr_curve": res[1], "train_snr_curve": res[0]}
+ref_path = os.path.join(ROOT, "tests", "golden", f"g6_ref_train_curve_{variant}.npz")
+if os.path.exists(ref_path):
+    g = np.load(ref_path)
+    n = min(len(g["test_snr"]), epochs)
+    out["reference_final_test_snr_db"] = float(g["test_snr"][n - 1])
+    out["reference_snr_improvement_db"] = float(g["test_snr"][n - 1] - g["input_snr_test"])
+    out["delta_vs_reference_db"] = res[1][n - 1] - float(g["test_snr"][n - 1])
+    out["reference_epochs"] = int(g["epochs"])
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"snr_experiment_{variant}.json"), "w"), indent=1)
+print(json.dumps({k: v for k, v in out.items() if "curve" not in k}))
+print("test SNR by epoch (every 10th):", [round(v, 3) for v in res[1][9::10]])
