@@ -8,7 +8,7 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libralenet.so")
+LIB_PATH = os.environ.get("RAL_LIB_PATH") or os.path.join(HERE, "libralenet.so")   # override: diagnostic builds only
 CSRC = os.path.join(HERE, "csrc")
 
 VARIANTS = {"nra": 0, "full": 1, "mlp": 2, "unet": 3}

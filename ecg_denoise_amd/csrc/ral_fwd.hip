@@ -261,6 +261,7 @@ __global__ __launch_bounds__(512) void k_mlp_fwd(const float* __restrict__ x, co
   const bool le = w.le != nullptr;
   float lw0 = 0.f, lw1 = 0.f, lw2 = 0.f;
   if (le) { lw0 = w.le[0]; lw1 = w.le[1]; lw2 = w.le[2]; }
+  if (threadIdx.x == 0) { A0[0] = 0.f; A0[N + 1] = 0.f; }   // zero halo of the LE conv (never overwritten)
   for (int win = blockIdx.x; win < B; win += gridDim.x) {
     const size_t wo = (size_t)win * N * C;
     {   // x (token-major -> padded rows) and o (head-major, flat) staged in one pass: 4 loads in flight per thread
@@ -282,13 +283,15 @@ __global__ __launch_bounds__(512) void k_mlp_fwd(const float* __restrict__ x, co
       }
     }
     __syncthreads();
-    // ---- attention output projection + residual ----
+    // ---- attention output projection + residual (x1 goes to HBM straight from the epilogue registers) ----
+    float* x1w = x1_out ? x1_out + wo : nullptr;
     gemm_phase<C, TTBof<C>::v, false, LAY_HM>(w.wp, C, C, Gs, N, N >> 4, [&](int row0, int tok, f32x4 a) {
       float4* px = reinterpret_cast<float4*>(Xs + tok * LD + row0);
-      *px = f4add(*px, f4add(tofloat4(a), *reinterpret_cast<const float4*>(w.bp + row0)));
+      const float4 v = f4add(*px, f4add(tofloat4(a), *reinterpret_cast<const float4*>(w.bp + row0)));
+      *px = v;
+      if (x1w) *reinterpret_cast<float4*>(x1w + (size_t)tok * C + row0) = v;
     });
     __syncthreads();
-    if (x1_out) copy_out(x1_out + wo, C, Xs, LD, N, C);
     // ---- LN2 ----
     {
       const float4 gam = *reinterpret_cast<const float4*>(w.ln2w + cq);
@@ -301,44 +304,40 @@ __global__ __launch_bounds__(512) void k_mlp_fwd(const float* __restrict__ x, co
       }
     }
     __syncthreads();
+    float* upw = upre_out ? upre_out + (size_t)win * N * 4 * C : nullptr;
+    float* x2w = x2_out + wo;
 #pragma unroll 1
     for (int ch = 0; ch < NCH; ++ch) {
       const int j0 = ch * HC;
+      // fc1 + both GELUs in the epilogue (the VALU work of one wave overlaps the MFMAs of the others); only hidden
+      // channel 0 of the LE variant waits for its 3-tap conv over tokens
       gemm_phase<C, TTBof<C>::v, false, LAY_TOK>(w.w1 + (size_t)j0 * C, C, HC, Gs, LD, N >> 4,
                                                  [&](int row0, int tok, f32x4 a) {
-        *reinterpret_cast<float4*>(Us + tok * LDU + row0) =
-            f4add(tofloat4(a), *reinterpret_cast<const float4*>(w.b1 + j0 + row0));
+        const float4 u = f4add(tofloat4(a), *reinterpret_cast<const float4*>(w.b1 + j0 + row0));
+        if (upw) *reinterpret_cast<float4*>(upw + (size_t)tok * 4 * C + j0 + row0) = u;
+        float4 h = make_float4(gelu_f(u.x), gelu_f(u.y), gelu_f(u.z), gelu_f(u.w));
+        if (le) {
+          if (ch == 0 && row0 == 0) A0[tok + 1] = h.x;          // conv input; Us[tok][0] is filled below
+          h = make_float4(gelu_f(h.x), gelu_f(h.y), gelu_f(h.z), gelu_f(h.w));
+        }
+        *reinterpret_cast<float4*>(Us + tok * LDU + row0) = h;
       });
       __syncthreads();
-      if (upre_out) copy_out(upre_out + (size_t)win * N * 4 * C + j0, 4 * C, Us, LDU, N, HC);
       if (le && ch == 0) {
-        for (int i = threadIdx.x; i < N + 2; i += blockDim.x)
-          A0[i] = (i == 0 || i == N + 1) ? 0.f : gelu_f(Us[(i - 1) * LDU]);
+        for (int n = threadIdx.x; n < N; n += blockDim.x)
+          Us[n * LDU] = gelu_f(lw0 * A0[n] + lw1 * A0[n + 1] + lw2 * A0[n + 2]);
         __syncthreads();
       }
-      for (int i = threadIdx.x; i < N * (HC / 4); i += blockDim.x) {
-        const int row = i / (HC / 4), q = i - row * (HC / 4);
-        float4* pu = reinterpret_cast<float4*>(Us + row * LDU + 4 * q);
-        float4 a = *pu;
-        a.x = gelu_f(a.x); a.y = gelu_f(a.y); a.z = gelu_f(a.z); a.w = gelu_f(a.w);
-        if (le) {
-          if (ch == 0 && q == 0) a.x = lw0 * A0[row] + lw1 * A0[row + 1] + lw2 * A0[row + 2];
-          a.x = gelu_f(a.x); a.y = gelu_f(a.y); a.z = gelu_f(a.z); a.w = gelu_f(a.w);
-        }
-        *pu = a;
-      }
-      __syncthreads();
       gemm_phase<HC, TTBof<C>::v, false, LAY_TOK>(w.w2 + j0, 4 * C, C, Us, LDU, N >> 4,
                                                   [&](int row0, int tok, f32x4 a) {
         float4* px = reinterpret_cast<float4*>(Xs + tok * LD + row0);
         float4 v = f4add(*px, tofloat4(a));
         if (ch == 0) v = f4add(v, *reinterpret_cast<const float4*>(w.b2 + row0));
-        *px = v;
+        if (ch == NCH - 1) *reinterpret_cast<float4*>(x2w + (size_t)tok * C + row0) = v;   // block output
+        else *px = v;
       });
       __syncthreads();
     }
-    copy_out(x2_out + wo, C, Xs, LD, N, C);
-    __syncthreads();
   }
 }
 
