@@ -38,7 +38,11 @@ __global__ __launch_bounds__(512) void k_dw(const float* __restrict__ Y, const f
   const int ldy = (LAYY == LAY_HM) ? TC : LDY, ldx = (LAYX == LAY_HM) ? TC : LDX;
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
   const int mb = (blockIdx.y / NSL_N) * MS, nb = (blockIdx.y % NSL_N) * NS;   // this workgroup's slice of dW
-  const int m0 = (wave / WN) * MI * 16, n0 = (wave % WN) * NI * 16;           // this wave's block inside the slice
+  // narrow slices own fewer than 8 wave blocks: the spare waves take every KW-th 16-token step of the chunk and
+  // their partial sums are folded through LDS at the end (the global atomics stay one per element per workgroup)
+  constexpr int NWB = WM * WN, KW = 8 / NWB;
+  const int wb = wave % NWB, kw = wave / NWB;
+  const int m0 = (wb / WN) * MI * 16, n0 = (wb % WN) * NI * 16;               // this wave's block inside the slice
   f32x4 acc[MI][NI];
 #pragma unroll
   for (int i = 0; i < MI; ++i)
@@ -101,8 +105,8 @@ __global__ __launch_bounds__(512) void k_dw(const float* __restrict__ Y, const f
       }
       __syncthreads();
       // ---- accumulate over the chunk's tokens ----
-      if (wave < WM * WN) {
-        for (int tb = 0; tb < TC; tb += 16) {
+      if (kw < KW) {
+        for (int tb = kw * 16; tb < TC; tb += 16 * KW) {
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             const int t = tb + 4 * g + s;
@@ -129,7 +133,28 @@ __global__ __launch_bounds__(512) void k_dw(const float* __restrict__ Y, const f
       __syncthreads();
     }
   }
-  if (wave < WM * WN) {
+  if constexpr (KW > 1) {   // fold the K-split partials: wave (wb, kw > 0) -> LDS -> wave (wb, 0)
+    float* red = reinterpret_cast<float*>(smem4);   // staging buffers are free now (last barrier of the loop)
+    if (kw > 0 && kw < KW) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          *reinterpret_cast<f32x4*>(red + ((((kw - 1) * NWB + wb) * MI + i) * NI + j) * 256 + lane * 4) = acc[i][j];
+    }
+    __syncthreads();
+    if (kw == 0) {
+      for (int k = 1; k < KW; ++k)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(red + ((((k - 1) * NWB + wb) * MI + i) * NI + j) * 256 + lane * 4);
+            acc[i][j] += v;
+          }
+    }
+  }
+  if (kw == 0) {
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -168,7 +193,10 @@ static void launch_dw_t(const float* Y, const float* X, const float* pe, const f
   static_assert(M % MS == 0 && NC % NS == 0, "slices must tile dW");
   const bool yhm = LAYY == LAY_HM, xhm = XF == XF_HM;
   const int TC = dw_chunk(MS, NS, yhm, xhm, N, g_dw_budget);
-  const size_t lds = dw_lds(MS, NS, yhm, xhm, TC, N);
+  constexpr int KW = 8 / (WM * WN);
+  const size_t fold = (size_t)(KW - 1) * TM * TN * 256 * sizeof(float);   // K-split partials of the spare waves
+  const size_t stage = dw_lds(MS, NS, yhm, xhm, TC, N);
+  const size_t lds = stage > fold ? stage : fold;
   RAL_SET_LDS((k_dw<M, NC, MS, NS, LAYY, XF>), lds);
   // ksplit is the split-K count of a fully sliced product; products with fewer slices get proportionally more
   // split-K workgroups so that every launch still fills the chip (at least ~256 workgroups)

@@ -1,7 +1,6 @@
-#!/bin/bash
-run() { echo "=== $*"; env "$@" python bench.py --steps 8 --warmup 2 --no-cpu 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"; }
-run RAL_DW_KSPLIT=512,512,256,128,64
-run RAL_DW_KSPLIT=256,256,128,64,32
+run() { echo "=== $*"; env "$@" python bench.py --steps 4 --warmup 2 --no-cpu --kinds 2>&1 | grep -E "^  dw|value" | cut -c1-120; }
 run RAL_DW_KSPLIT=256,256,256,128,64
-run RAL_DW_KSPLIT=512,512,256,64,32
-run RAL_DW_KSPLIT=128,128,128,64,32
+run RAL_DW_KSPLIT=1024,1024,1024,128,64
+run RAL_DW_KSPLIT=1024,1024,1024,128,64 RAL_DW_LDS=24000
+run RAL_DW_KSPLIT=2048,2048,1024,256,128 RAL_DW_LDS=24000
+run RAL_DW_KSPLIT=512,512,512,256,128 RAL_DW_LDS=32000
