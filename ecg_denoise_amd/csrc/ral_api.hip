@@ -204,7 +204,7 @@ struct RalModel {
   // every gradient tensor has its own buffer (no ping-pong): the weight-gradient kernels run on a side
   // stream and read them long after the data-gradient chain has moved on
   float *gy[18], *gin[9], *du0, *dz0;
-  float *dx1[2], *dohm[2], *dqkv[2], *dupre[2];     // per-block temporaries, two sets (side-stream overlap)
+  float *dx1[2], *dohm[2], *dqkv[2], *dupre[2], *a2c0[2];     // per-block temporaries, two sets (side-stream overlap)
   void* lanes = nullptr;   // LaneSet
   int n_lanes = 2;
   bool side_stream = true;
@@ -286,6 +286,7 @@ static size_t plan_workspace(const ral_config& c, RalModel* m /* may be null: si
     for (int k = 0; k < 2; ++k) {
       M.dx1[k] = take(("dx1_" + std::to_string(k)).c_str(), E); M.dohm[k] = take(("do_" + std::to_string(k)).c_str(), E);
       M.dqkv[k] = take(("dqkv_" + std::to_string(k)).c_str(), 3 * E); M.dupre[k] = take(("dupre_" + std::to_string(k)).c_str(), 4 * E);
+      M.a2c0[k] = take(("a2c0_" + std::to_string(k)).c_str(), E / 8);
     }
     M.dz0 = take("dz0", E);
     Layout L_; build_layout(c, L_);
@@ -310,7 +311,7 @@ static void choose_tiling(RalModel* m) {
   static const int KS_DEFAULT[5] = {256, 256, 256, 128, 64};
   for (int l = 0; l < 5; ++l) m->dw_ksplit[l] = KS_DEFAULT[l];
   if (const char* v = getenv("RAL_DW_KSPLIT")) sscanf(v, "%d,%d,%d,%d,%d", &m->dw_ksplit[0], &m->dw_ksplit[1], &m->dw_ksplit[2], &m->dw_ksplit[3], &m->dw_ksplit[4]);
-  set_dw_lds_budget(env_size("RAL_DW_LDS", 50 * 1024));
+  set_dw_lds_budget(env_size("RAL_DW_LDS", 76 * 1024));
   for (int l = 0; l < 5; ++l) {
     const int C = CH[l], N = m->L >> l, H = C / 4;
     int n = 1;
@@ -512,10 +513,10 @@ static void run_block_bwd(RalModel* m, int bi, const float* dy, const float* ext
   if (m->side_stream && ln.dw_pending[k]) (void)hipStreamWaitEvent(s, ln.ev_done[k], 0);   // set k free again?
   const float* dyw = woff(dy, w0, E1);
   float *dupre = woff(m->dupre[k], w0, 4 * E1), *dx1 = woff(m->dx1[k], w0, E1), *dohm = woff(m->dohm[k], w0, E1),
-        *dqkv = woff(m->dqkv[k], w0, 3 * E1);
+        *dqkv = woff(m->dqkv[k], w0, 3 * E1), *a2c0 = woff(m->a2c0[k], w0, m->L);   // (per-window stride L at every level: the lanes run different levels concurrently)
   const float *x1 = woff(a.x1, w0, E1), *upre = woff(a.upre, w0, 4 * E1), *qkv = woff(a.qkv, w0, 3 * E1),
               *o = woff(a.o, w0, E1), *lse = woff(a.lse, w0, E1 / 4), *xin = woff(a.in, w0, E1);
-  { ProfScope p(m, K_MLP_BWD, s); launch_mlp_bwd(C, m->nch_b[l], dyw, x1, upre, w, wt, g, dupre, dx1, dohm, N, B, s); }
+  { ProfScope p(m, K_MLP_BWD, s); launch_mlp_bwd(C, m->nch_b[l], dyw, x1, upre, w, wt, g, dupre, dx1, dohm, a2c0, N, B, s); }
   { ProfScope p(m, K_ATTN_BWD, s); launch_attn_bwd(qkv, o, dohm, lse, table, gtable, dqkv, N, H, m->hg_b[l], Len, B, s); }
   { ProfScope p(m, K_QKV_BWD, s);
     launch_qkv_bwd(C, dqkv, xin, m->pe[l], dx1, woff(extra, w0, E1), w, wt, g, woff(dx, w0, E1), N, B, s); }
@@ -524,7 +525,7 @@ static void run_block_bwd(RalModel* m, int bi, const float* dy, const float* ext
     (void)hipStreamWaitEvent(sd, ln.ev_ready[k], 0);
   }
   { ProfScope p(m, K_DW, sd);
-    launch_block_dw(C, dyw, upre, dupre, x1, dx1, o, dqkv, xin, m->pe[l], w, g, N, B, m->dw_ksplit[l], sd); }
+    launch_block_dw(C, dyw, upre, w.le ? a2c0 : nullptr, dupre, x1, dx1, o, dqkv, xin, m->pe[l], w, g, N, B, m->dw_ksplit[l], sd); }
   if (m->side_stream) { (void)hipEventRecord(ln.ev_done[k], sd); ln.dw_pending[k] = true; }
 }
 

@@ -22,7 +22,7 @@ template <int C, int NCH>
 __global__ __launch_bounds__(512) void k_mlp_bwd(const float* __restrict__ dx2, const float* __restrict__ x1,
                                                  const float* __restrict__ upre, BlockP w, BlockP wt, BlockP gr,
                                                  float* __restrict__ dupre, float* __restrict__ dx1,
-                                                 float* __restrict__ do_hm, int N, int B) {
+                                                 float* __restrict__ do_hm, float* __restrict__ a2c0, int N, int B) {
   extern __shared__ float4 smem4[];
   constexpr int LD = LDof<C>::v, HC = 4 * C / NCH, LDU = LDof<HC>::v, LPR = C / 4;
   float* Ds = reinterpret_cast<float*>(smem4);  // N x LD : dx2 -> dx1
@@ -62,7 +62,11 @@ __global__ __launch_bounds__(512) void k_mlp_bwd(const float* __restrict__ dx2, 
           if (!halo) U0[i - 1] = u;
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < N; i += blockDim.x) C0[i] = lw0 * A0[i] + lw1 * A0[i + 1] + lw2 * A0[i + 2];
+        for (int i = threadIdx.x; i < N; i += blockDim.x) {
+          const float c0 = lw0 * A0[i] + lw1 * A0[i + 1] + lw2 * A0[i + 2];
+          C0[i] = c0;
+          a2c0[(size_t)win * N + i] = gelu_f(c0);   // fc2 input of the LE channel, for the fc2 weight-gradient kernel
+        }
         __syncthreads();
       }
       // d a2 = dx2 W2[:, chunk]  -> du (in place over u_pre)
@@ -284,11 +288,7 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd(const float* __restrict__ q
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {
         float4 v = make_float4(dq01[qt][0], dq01[qt][1], dq23[qt][0], dq23[qt][1]);
-#pragma unroll
-        for (int sh = 16; sh <= 32; sh <<= 1) {
-          v.x += __shfl_xor(v.x, sh); v.y += __shfl_xor(v.y, sh);
-          v.z += __shfl_xor(v.z, sh); v.w += __shfl_xor(v.w, sh);
-        }
+        v = make_float4(rows_sum(v.x), rows_sum(v.y), rows_sum(v.z), rows_sum(v.w));
         if (g == 0)
           *reinterpret_cast<float4*>(dbase + ((size_t)(h0 + hl) * N + q0 + 16 * qt + r) * 4) = f4scale(v, 0.5f);
       }
@@ -347,13 +347,8 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd(const float* __restrict__ q
       for (int t = 0; t < QT; ++t) {
         float4 vk = make_float4(dk01[t][0], dk01[t][1], dk23[t][0], dk23[t][1]);
         float4 vv = make_float4(dv01[t][0], dv01[t][1], dv23[t][0], dv23[t][1]);
-#pragma unroll
-        for (int sh = 16; sh <= 32; sh <<= 1) {
-          vk.x += __shfl_xor(vk.x, sh); vk.y += __shfl_xor(vk.y, sh);
-          vk.z += __shfl_xor(vk.z, sh); vk.w += __shfl_xor(vk.w, sh);
-          vv.x += __shfl_xor(vv.x, sh); vv.y += __shfl_xor(vv.y, sh);
-          vv.z += __shfl_xor(vv.z, sh); vv.w += __shfl_xor(vv.w, sh);
-        }
+        vk = make_float4(rows_sum(vk.x), rows_sum(vk.y), rows_sum(vk.z), rows_sum(vk.w));
+        vv = make_float4(rows_sum(vv.x), rows_sum(vv.y), rows_sum(vv.z), rows_sum(vv.w));
         if (g == 0) {
           const size_t kk = (size_t)(h0 + hl) * N + k0 + 16 * t + r;
           *reinterpret_cast<float4*>(dbase + ((size_t)H * N + kk) * 4) = f4scale(vk, RAL_LN2);  // Qs carried log2(e)
@@ -743,18 +738,18 @@ size_t mlp_bwd_lds(int C, int N, int nch) {
 
 template <int C>
 static void launch_mlp_bwd_c(int nch, const float* dx2, const float* x1, const float* upre, const BlockP& w,
-                             const BlockP& wt, const BlockP& gr, float* dupre, float* dx1, float* do_hm, int N, int B, hipStream_t s) {
+                             const BlockP& wt, const BlockP& gr, float* dupre, float* dx1, float* do_hm, float* a2c0, int N, int B, hipStream_t s) {
   const size_t lds = mlp_bwd_lds(C, N, nch);
   const int grid = grid_bwd(B);
-  if (nch == 1) { RAL_SET_LDS((k_mlp_bwd<C, 1>), lds); k_mlp_bwd<C, 1><<<grid, 512, lds, s>>>(dx2, x1, upre, w, wt, gr, dupre, dx1, do_hm, N, B); }
-  else if (nch == 2) { RAL_SET_LDS((k_mlp_bwd<C, 2>), lds); k_mlp_bwd<C, 2><<<grid, 512, lds, s>>>(dx2, x1, upre, w, wt, gr, dupre, dx1, do_hm, N, B); }
-  else { RAL_SET_LDS((k_mlp_bwd<C, 4>), lds); k_mlp_bwd<C, 4><<<grid, 512, lds, s>>>(dx2, x1, upre, w, wt, gr, dupre, dx1, do_hm, N, B); }
+  if (nch == 1) { RAL_SET_LDS((k_mlp_bwd<C, 1>), lds); k_mlp_bwd<C, 1><<<grid, 512, lds, s>>>(dx2, x1, upre, w, wt, gr, dupre, dx1, do_hm, a2c0, N, B); }
+  else if (nch == 2) { RAL_SET_LDS((k_mlp_bwd<C, 2>), lds); k_mlp_bwd<C, 2><<<grid, 512, lds, s>>>(dx2, x1, upre, w, wt, gr, dupre, dx1, do_hm, a2c0, N, B); }
+  else { RAL_SET_LDS((k_mlp_bwd<C, 4>), lds); k_mlp_bwd<C, 4><<<grid, 512, lds, s>>>(dx2, x1, upre, w, wt, gr, dupre, dx1, do_hm, a2c0, N, B); }
 }
 
 void launch_mlp_bwd(int C, int nch, const float* dx2, const float* x1, const float* upre, const BlockP& w,
-                    const BlockP& wt, const BlockP& gr, float* dupre, float* dx1, float* do_hm, int N, int B, hipStream_t s) {
+                    const BlockP& wt, const BlockP& gr, float* dupre, float* dx1, float* do_hm, float* a2c0, int N, int B, hipStream_t s) {
   switch (C) {
-#define CASE(c) case c: launch_mlp_bwd_c<c>(nch, dx2, x1, upre, w, wt, gr, dupre, dx1, do_hm, N, B, s); break;
+#define CASE(c) case c: launch_mlp_bwd_c<c>(nch, dx2, x1, upre, w, wt, gr, dupre, dx1, do_hm, a2c0, N, B, s); break;
     CASE(8) CASE(16) CASE(32) CASE(64) CASE(128)
 #undef CASE
   }

@@ -186,10 +186,29 @@ RAL_DEV void gelu_pair(float x, float& g, float& dg) {
 RAL_DEV float gelu_f(float x) { float g, d; gelu_pair(x, g, d); return g; }
 RAL_DEV float gelu_grad_f(float x) { float g, d; gelu_pair(x, g, d); return d; }
 
+// Cross-lane sums without the LDS crossbar (__shfl_xor compiles to ds_bpermute_b32, ~100 cycles of latency per
+// step): DPP quad permutes / row mirrors inside a row of 16 lanes, and the gfx950 row-swap instructions across
+// rows.  After each step every lane of the group holds the same partial sum, so mirrors can replace xors.
+template <int CTRL> RAL_DEV float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+RAL_DEV float swap16_add(float v) {   // v[lane] + v[lane ^ 16]
+  const auto p = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(p[0]) + __uint_as_float(p[1]);
+}
+RAL_DEV float swap32_add(float v) {   // v[lane] + v[lane ^ 32]
+  const auto p = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(p[0]) + __uint_as_float(p[1]);
+}
+RAL_DEV float rows_sum(float v) { return swap32_add(swap16_add(v)); }   // over the 4 rows of 16 lanes (same column)
 template <int W>
-RAL_DEV float group_sum(float v) {  // sum over W consecutive lanes (W power of two <= 64)
-#pragma unroll
-  for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+RAL_DEV float group_sum(float v) {  // sum over W consecutive lanes (W power of two <= 64), result in every lane
+  if constexpr (W >= 2) v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+  if constexpr (W >= 4) v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+  if constexpr (W >= 8) v = dpp_add<0x141>(v);   // row_half_mirror
+  if constexpr (W >= 16) v = dpp_add<0x140>(v);  // row_mirror
+  if constexpr (W >= 32) v = swap16_add(v);
+  if constexpr (W >= 64) v = swap32_add(v);
   return v;
 }
 

@@ -175,12 +175,8 @@ __global__ __launch_bounds__(512, (QT >= 4 ? 3 : 4)) void k_attn_fwd(const float
       for (int qt = 0; qt < QT; ++qt) {
         float lv = l2[qt][0] + l2[qt][1];
         float4 ov = make_float4(o01[qt][0], o01[qt][1], o23[qt][0], o23[qt][1]);
-#pragma unroll
-        for (int sh = 16; sh <= 32; sh <<= 1) {
-          lv += __shfl_xor(lv, sh);
-          ov.x += __shfl_xor(ov.x, sh); ov.y += __shfl_xor(ov.y, sh);
-          ov.z += __shfl_xor(ov.z, sh); ov.w += __shfl_xor(ov.w, sh);
-        }
+        lv = rows_sum(lv);
+        ov = make_float4(rows_sum(ov.x), rows_sum(ov.y), rows_sum(ov.z), rows_sum(ov.w));
         redo = redo || !(lv > 1e-30f);
         if (g == 0) {
           const float inv = 1.0f / lv;

@@ -51,7 +51,8 @@ void launch_transpose_mats(const float* src, float* dst, const void* desc, int n
 // ---- backward (ral_bwd.hip)
 size_t mlp_bwd_lds(int C, int N, int nch);
 void launch_mlp_bwd(int C, int nch, const float* dx2, const float* x1, const float* upre, const BlockP& w,
-                    const BlockP& wt, const BlockP& gr, float* dupre, float* dx1, float* do_hm, int N, int B, hipStream_t s);
+                    const BlockP& wt, const BlockP& gr, float* dupre, float* dx1, float* do_hm, float* a2c0, int N, int B,
+                    hipStream_t s);
 size_t attn_bwd_lds(int N, int HG, int Len);
 void launch_attn_bwd(const float* qkv, const float* o_hm, const float* do_hm, const float* lse, const float* table,
                      float* gtable, float* dqkv, int N, int H, int HG, int Len, int B, hipStream_t s);
@@ -69,7 +70,7 @@ void launch_bn_affine_grads(const double* bst, float* gw, float* gb, int nch, do
 void launch_conv1_bwd_dx(int leads, const float* dz, const float* w, float* dx, int L, int B, hipStream_t s);
 
 // ---- weight gradients (ral_dw.hip)
-void launch_block_dw(int C, const float* dx2, const float* upre, const float* dupre, const float* x1,
+void launch_block_dw(int C, const float* dx2, const float* upre, const float* a2c0, const float* dupre, const float* x1,
                      const float* dx1, const float* o_hm, const float* dqkv, const float* x, const float* pe,
                      const BlockP& w, const BlockP& gr, int N, int B, int ksplit, hipStream_t s);
 void set_dw_lds_budget(size_t bytes);
