@@ -55,10 +55,11 @@ RAL_DEV void issue_then_store(LD ld, ST st, IN inner) {
 }
 
 template <int M, int NC, int MS, int NS, int LAYY, int XF>
-__global__ __launch_bounds__(512, 4) void k_dw(const float* __restrict__ Y, const float* __restrict__ X,
-                                               const float* __restrict__ pe, const float* __restrict__ lnw,
-                                               const float* __restrict__ lnb, const float* __restrict__ a2c0,
-                                               float* __restrict__ dW, int N, int TC, int B) {
+// (Y, X, pe and a2c0 are deliberately NOT __restrict__: loads the compiler can prove invariant are sunk across the
+// compiler barrier of the staging code, next to their stores, which costs one HBM round trip per load)
+__global__ __launch_bounds__(512, 4) void k_dw(const float* Y, const float* X, const float* pe,
+                                               const float* __restrict__ lnw, const float* __restrict__ lnb,
+                                               const float* a2c0, float* dW, int N, int TC, int B) {
   extern __shared__ float4 smem4[];
   constexpr bool YHM = LAYY == LAY_HM, XHM = XF == XF_HM;
   constexpr int TM = (MS + 15) / 16, TN = (NS + 15) / 16;
@@ -83,12 +84,12 @@ __global__ __launch_bounds__(512, 4) void k_dw(const float* __restrict__ Y, cons
   const int nwin = ((int)blockIdx.x < B) ? (B - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
   const int nci = nwin * cpw;
 
-  f32x4 acc[MI][NI];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
+  float4 gam = make_float4(0.f, 0.f, 0.f, 0.f), bet = gam;   // LayerNorm affine of this thread's column group
+  if constexpr (XF == XF_LN || XF == XF_LNPE || XF == XF_LN_SEP) {
+    const int c = (threadIdx.x % (NS / 4)) * 4;
+    gam = *reinterpret_cast<const float4*>(lnw + c);
+    bet = *reinterpret_cast<const float4*>(lnb + c);
+  }
   // ---- producer: stage chunk ci into buf (256 threads, no barriers inside).  Straight-line code: indices past
   // the chunk are clamped rather than branched around (the duplicates rewrite identical values), because hipcc
   // waits for a conditional load on the spot and the whole point is to have every load of the chunk in flight.
@@ -159,57 +160,75 @@ __global__ __launch_bounds__(512, 4) void k_dw(const float* __restrict__ Y, cons
           if constexpr (XF == XF_LNPE) a = f4add(f4scale(a, sqrtf((float)NC)), o.p);
           float4 d; float rstd;
           ln_stats<LPR>(a, d, rstd);
-          a = f4add(f4mul(f4scale(d, rstd), *reinterpret_cast<const float4*>(lnw + c)),
-                    *reinterpret_cast<const float4*>(lnb + c));
+          a = f4add(f4mul(f4scale(d, rstd), gam), bet);   // (column c is the same for every u: 256 % (NS/4) == 0)
         }
         *reinterpret_cast<float4*>(Xs + row * LDX + c) = a;
       }
     };
-    issue_then_store<0, UY>(load_y, store_y, [&] { issue_then_store<0, UX>(load_x, store_x, [] {}); });
+    // (the compiler barrier pins the loads above it -- otherwise they are sunk next to their stores, one HBM
+    // round trip each -- and the scheduling barrier keeps the machine scheduler from undoing that)
+    issue_then_store<0, UY>(load_y, store_y, [&] {
+      issue_then_store<0, UX>(load_x, store_x, [] {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    });
   };
 
-  // ---- consumer: MFMAs over one staged chunk ----
-  auto consume = [&](const float* buf) {
-    const float* Ys = buf;
-    const float* Xs = buf + ysz;
-    for (int tb = kw * 16; tb < TC; tb += 16 * KW) {
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int t = tb + 4 * g + s;
-        float a[MI], b[NI];
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-          int cm = m0 + 16 * i + r;
-          if constexpr (MS % 16 != 0) cm = cm < MS ? cm : MS - 1;   // half tiles (C = 8): stay inside the tile
-          a[i] = YHM ? Ys[((cm >> 2) * (TC + 1) + t) * 4 + (cm & 3)] : Ys[t * LDY + cm];
-        }
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-          int cn = n0 + 16 * j + r;
-          if constexpr (NS % 16 != 0) cn = cn < NS ? cn : NS - 1;
-          b[j] = XHM ? Xs[((cn >> 2) * (TC + 1) + t) * 4 + (cn & 3)] : Xs[t * LDX + cn];
-        }
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < NI; ++j) acc[i][j] = mfma4(a[i], b[j], acc[i][j]);
-      }
+  // The two roles run separate loops with matching barrier counts (the role is wave-uniform), so that the
+  // accumulators are not live in the producer path and its loads are not squeezed by register pressure.
+  if (producer) {
+    if (nci > 0) stage(0, buf0);
+    __syncthreads();
+    for (int ci = 0; ci < nci; ++ci) {
+      if (ci + 1 < nci) stage(ci + 1, (ci & 1) ? buf0 : buf1);
+      __syncthreads();
     }
-  };
+    if constexpr (KW > 1) __syncthreads();
+    return;
+  }
 
-  if (producer && nci > 0) stage(0, buf0);
+  // ---- consumer: MFMAs over the staged chunks ----
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
   for (int ci = 0; ci < nci; ++ci) {
-    float* cur = (ci & 1) ? buf1 : buf0;
-    float* nxt = (ci & 1) ? buf0 : buf1;
-    if (producer) { if (ci + 1 < nci) stage(ci + 1, nxt); }
-    else if (kw < KW) consume(cur);
+    const float* Ys = (ci & 1) ? buf1 : buf0;
+    const float* Xs = Ys + ysz;
+    if (kw < KW) {
+      for (int tb = kw * 16; tb < TC; tb += 16 * KW) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int t = tb + 4 * g + s;
+          float a[MI], b[NI];
+#pragma unroll
+          for (int i = 0; i < MI; ++i) {
+            int cm = m0 + 16 * i + r;
+            if constexpr (MS % 16 != 0) cm = cm < MS ? cm : MS - 1;   // half tiles (C = 8): stay inside the tile
+            a[i] = YHM ? Ys[((cm >> 2) * (TC + 1) + t) * 4 + (cm & 3)] : Ys[t * LDY + cm];
+          }
+#pragma unroll
+          for (int j = 0; j < NI; ++j) {
+            int cn = n0 + 16 * j + r;
+            if constexpr (NS % 16 != 0) cn = cn < NS ? cn : NS - 1;
+            b[j] = XHM ? Xs[((cn >> 2) * (TC + 1) + t) * 4 + (cn & 3)] : Xs[t * LDX + cn];
+          }
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = mfma4(a[i], b[j], acc[i][j]);
+        }
+      }
+    }
     __syncthreads();
   }
 
   if constexpr (KW > 1) {   // fold the K-split partials: wave (wb, kw > 0) -> LDS -> wave (wb, 0)
     float* red = buf0;      // staging buffers are free now (last barrier of the loop)
-    if (!producer && kw > 0 && kw < KW) {
+    if (kw > 0 && kw < KW) {
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -217,7 +236,7 @@ __global__ __launch_bounds__(512, 4) void k_dw(const float* __restrict__ Y, cons
           *reinterpret_cast<f32x4*>(red + ((((kw - 1) * NWB + wb) * MI + i) * NI + j) * 256 + lane * 4) = acc[i][j];
     }
     __syncthreads();
-    if (!producer && kw == 0) {
+    if (kw == 0) {
       for (int k = 1; k < KW; ++k)
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -226,7 +245,7 @@ __global__ __launch_bounds__(512, 4) void k_dw(const float* __restrict__ Y, cons
             acc[i][j] += *reinterpret_cast<const f32x4*>(red + ((((k - 1) * NWB + wb) * MI + i) * NI + j) * 256 + lane * 4);
     }
   }
-  if (!producer && kw == 0) {
+  if (kw == 0) {
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
