@@ -8,6 +8,8 @@
 #include <stdlib.h>
 #include <type_traits>
 
+RAL_STAMPS_DEFINE
+
 // LDS float4 atomic accumulate of per-channel vectors: red[c..c+3] += v
 RAL_DEV void lds_add4(float* red, int c, float4 v) {
   atomicAdd(red + c, v.x); atomicAdd(red + c + 1, v.y); atomicAdd(red + c + 2, v.z); atomicAdd(red + c + 3, v.w);
@@ -33,7 +35,6 @@ __global__ __launch_bounds__(512) void k_mlp_bwd(const float* __restrict__ dx2, 
   float* U0 = DC0 + N + 2;                      // N      : u_pre[:,0]
   float* C0 = U0 + N;                           // N      : conv output c0
   float* red = C0 + N;                          // 2C + 4 : ln2 grads + le taps (block reduction)
-  float* cs = red + 2 * C + 4;                  // 4C + 2C : column sums db1 | db2 | dbp, accumulated over the windows
   const int RPP = blockDim.x / LPR;
   const int cq = (threadIdx.x % LPR) * 4;
   const bool le = w.le != nullptr;
@@ -42,17 +43,19 @@ __global__ __launch_bounds__(512) void k_mlp_bwd(const float* __restrict__ dx2, 
   const float4 gam2 = *reinterpret_cast<const float4*>(w.ln2w + cq);
   // per-thread gradient accumulators (live across the window loop)
   float gle0 = 0.f, gle1 = 0.f, gle2 = 0.f;
-  for (int i = threadIdx.x; i < 6 * C; i += blockDim.x) cs[i] = 0.f;   // visible after the first barrier below
   float4 dgam = make_float4(0.f, 0.f, 0.f, 0.f), dbet = make_float4(0.f, 0.f, 0.f, 0.f);
 
+  RAL_STAMP_INIT();
   for (int win = blockIdx.x; win < B; win += gridDim.x) {
     const size_t wo = (size_t)win * N * C;
+    RAL_STAMP_AT(15);
     copy_in(Ds, LD, dx2 + wo, C, N, C);
 #pragma unroll 1
     for (int ch = 0; ch < NCH; ++ch) {
       const int j0 = ch * HC;
       copy_in(Us, LDU, upre + (size_t)win * N * 4 * C + j0, 4 * C, N, HC);
       __syncthreads();
+      RAL_STAMP_AT(0);
       if (le && ch == 0) {
         for (int i = threadIdx.x; i < N + 2; i += blockDim.x) {
           const bool halo = (i == 0 || i == N + 1);
@@ -69,6 +72,7 @@ __global__ __launch_bounds__(512) void k_mlp_bwd(const float* __restrict__ dx2, 
         }
         __syncthreads();
       }
+      RAL_STAMP_AT(1);
       // d a2 = dx2 W2[:, chunk]  -> du (in place over u_pre)
       gemm_phase<C, TTBof<C>::v, false, LAY_TOK>(wt.w2 + (size_t)j0 * C, C, HC, Ds, LD, N >> 4,
                                                 [&](int row0, int tok, f32x4 a) {
@@ -91,6 +95,7 @@ __global__ __launch_bounds__(512) void k_mlp_bwd(const float* __restrict__ dx2, 
         *pu = make_float4(out[0], out[1], out[2], out[3]);
       });
       __syncthreads();
+      RAL_STAMP_AT(2);
       if (le && ch == 0) {
         for (int n = threadIdx.x; n < N; n += blockDim.x) {
           const float da1 = lw0 * DC0[n + 2] + lw1 * DC0[n + 1] + lw2 * DC0[n];
@@ -100,8 +105,10 @@ __global__ __launch_bounds__(512) void k_mlp_bwd(const float* __restrict__ dx2, 
         }
         __syncthreads();
       }
+      RAL_STAMP_AT(3);
       copy_out(dupre + (size_t)win * N * 4 * C + j0, 4 * C, Us, LDU, N, HC);
-      lds_colsum_add<LAY_TOK>(cs + j0, Us, LDU, N, HC);   // db1
+      RAL_STAMP_AT(4);
+      RAL_STAMP_AT(5);
       // dg (+)= du W1[chunk, :]
       gemm_phase<HC, TTBof<C>::v, false, LAY_TOK>(wt.w1 + j0, 4 * C, C, Us, LDU, N >> 4,
                                                  [&](int row0, int tok, f32x4 a) {
@@ -109,9 +116,9 @@ __global__ __launch_bounds__(512) void k_mlp_bwd(const float* __restrict__ dx2, 
         *pg = (ch == 0) ? tofloat4(a) : f4add(*pg, tofloat4(a));
       });
       __syncthreads();
+      RAL_STAMP_AT(6);
     }
-    lds_colsum_add<LAY_TOK>(cs + 4 * C, Ds, LD, N, C);    // db2
-    __syncthreads();
+    RAL_STAMP_AT(7);
     // LN2 backward, dx1 = dx2 + dLN
     for (int row = threadIdx.x / LPR; row < N; row += RPP) {
       const float4 v = *reinterpret_cast<const float4*>(x1 + wo + (size_t)row * C + cq);
@@ -131,14 +138,17 @@ __global__ __launch_bounds__(512) void k_mlp_bwd(const float* __restrict__ dx2, 
       dbet = f4add(dbet, dg);
     }
     __syncthreads();
+    RAL_STAMP_AT(8);
     copy_out(dx1 + wo, C, Ds, LD, N, C);
-    lds_colsum_add<LAY_TOK>(cs + 5 * C, Ds, LD, N, C);    // dbp
+    RAL_STAMP_AT(9);
+    RAL_STAMP_AT(10);
     // do = dx1 Wp  (head-major)
     float* dow = do_hm + wo;
     gemm_phase<C, TTBof<C>::v, false, LAY_TOK>(wt.wp, C, C, Ds, LD, N >> 4, [&](int row0, int tok, f32x4 a) {
       *reinterpret_cast<float4*>(dow + ((size_t)(row0 >> 2) * N + tok) * 4) = tofloat4(a);
     });
     __syncthreads();
+    RAL_STAMP_AT(11);
   }
   // ---- flush the small gradients ----
   for (int i = threadIdx.x; i < 2 * C + 4; i += blockDim.x) red[i] = 0.f;
@@ -153,11 +163,8 @@ __global__ __launch_bounds__(512) void k_mlp_bwd(const float* __restrict__ dx2, 
   if ((int)threadIdx.x < C) {
     atomicAdd(gr.ln2w + threadIdx.x, red[threadIdx.x]);
     atomicAdd(gr.ln2b + threadIdx.x, red[C + threadIdx.x]);
-    atomicAdd(gr.b2 + threadIdx.x, cs[4 * C + threadIdx.x]);
-    atomicAdd(gr.bp + threadIdx.x, cs[5 * C + threadIdx.x]);
   }
   if (le && threadIdx.x < 3) atomicAdd(gr.le + threadIdx.x, red[2 * C + threadIdx.x]);
-  for (int i = threadIdx.x; i < 4 * C; i += blockDim.x) atomicAdd(gr.b1 + i, cs[i]);
 }
 
 // =================================================================================
@@ -382,12 +389,10 @@ __global__ __launch_bounds__(512) void k_qkv_bwd(const float* __restrict__ dqkv,
   float* DQ = reinterpret_cast<float*>(smem4);  // HM, N x 3C
   float* Dh = DQ + N * 3 * C;                   // N x LD
   float* red = Dh + N * LD;                     // 2C
-  float* cs = red + 2 * C;                      // 3C : column sums of dqkv (bias gradient), accumulated over the windows
   const int RPP = blockDim.x / LPR;
   const int cq = (threadIdx.x % LPR) * 4;
   const float sqrtC = sqrtf((float)C);
   const float4 gam1 = *reinterpret_cast<const float4*>(w.ln1w + cq);
-  for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) cs[i] = 0.f;
   float4 dgam = make_float4(0.f, 0.f, 0.f, 0.f), dbet = make_float4(0.f, 0.f, 0.f, 0.f);
   const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
   for (int win = blockIdx.x; win < B; win += gridDim.x) {
@@ -420,7 +425,6 @@ __global__ __launch_bounds__(512) void k_qkv_bwd(const float* __restrict__ dqkv,
       else if ((nt & 1) == 0) run(std::integral_constant<int, 2>{});
       else run(std::integral_constant<int, 1>{});
     }
-    lds_colsum_add<LAY_HM>(cs, DQ, N, N, 3 * C);
     __syncthreads();
     for (int row = threadIdx.x / LPR; row < N; row += RPP) {
       float4 v = *reinterpret_cast<const float4*>(x + wo + (size_t)row * C + cq);
@@ -454,7 +458,6 @@ __global__ __launch_bounds__(512) void k_qkv_bwd(const float* __restrict__ dqkv,
     atomicAdd(gr.ln1w + threadIdx.x, red[threadIdx.x]);
     atomicAdd(gr.ln1b + threadIdx.x, red[C + threadIdx.x]);
   }
-  if ((int)threadIdx.x < 3 * C) atomicAdd(gr.bqkv + threadIdx.x, cs[threadIdx.x]);
 }
 
 // =================================================================================

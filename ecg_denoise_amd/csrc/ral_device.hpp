@@ -232,6 +232,35 @@ RAL_DEV void ln_stats(float4 v, float4& d, float& rstd) {
 }
 
 // ---------------------------------------------------------------------------------
+// Phase stamps (diagnostic builds only: `make STAMP=1`, tools/diag/stamp_kernel.py).  Thread 0 of workgroup 0 adds
+// the cycles since the previous stamp to slot i; the product library compiles these macros to nothing.
+#ifdef RAL_STAMP
+#define RAL_STAMPS_DEFINE                                                                              \
+  __device__ unsigned long long g_ral_stamps[32];                                                      \
+  extern "C" int ral_debug_stamps(unsigned long long* out, int reset) {                                \
+    unsigned long long z[32] = {0};                                                                    \
+    if (reset) return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ral_stamps), z, sizeof(z));                  \
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ral_stamps), sizeof(z));                         \
+  }
+#ifndef RAL_STAMP_COND
+#define RAL_STAMP_COND true   /* e.g. -DRAL_STAMP_COND='(C==128)' to stamp one channel width only */
+#endif
+#define RAL_STAMP_INIT() long long ral_st_prev_ = clock64()
+#define RAL_STAMP_AT(i)                                                                                \
+  do {                                                                                                 \
+    if (RAL_STAMP_COND && blockIdx.x == 0 && threadIdx.x == 0) {                                       \
+      const long long t_ = clock64();                                                                  \
+      atomicAdd(&g_ral_stamps[i], (unsigned long long)(t_ - ral_st_prev_));                            \
+      ral_st_prev_ = t_;                                                                               \
+    }                                                                                                  \
+  } while (0)
+#else
+#define RAL_STAMPS_DEFINE
+#define RAL_STAMP_INIT() do {} while (0)
+#define RAL_STAMP_AT(i) do {} while (0)
+#endif
+
+// ---------------------------------------------------------------------------------
 // Staging loops.  hipcc waits for each global load right before its use, so a plain
 // `for (i = tid; i < n; i += blockDim) dst[i] = src[i]` costs one full HBM latency PER ITERATION.
 // These helpers issue U independent 16-byte loads first and consume them afterwards.

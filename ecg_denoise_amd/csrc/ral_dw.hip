@@ -59,7 +59,7 @@ template <int M, int NC, int MS, int NS, int LAYY, int XF>
 // compiler barrier of the staging code, next to their stores, which costs one HBM round trip per load)
 __global__ __launch_bounds__(512, 4) void k_dw(const float* Y, const float* X, const float* pe,
                                                const float* __restrict__ lnw, const float* __restrict__ lnb,
-                                               const float* a2c0, float* dW, int N, int TC, int B) {
+                                               const float* a2c0, float* dW, float* dB, int N, int TC, int B) {
   extern __shared__ float4 smem4[];
   constexpr bool YHM = LAYY == LAY_HM, XHM = XF == XF_HM;
   constexpr int TM = (MS + 15) / 16, TN = (NS + 15) / 16;
@@ -194,6 +194,12 @@ __global__ __launch_bounds__(512, 4) void k_dw(const float* Y, const float* X, c
   for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // Bias gradient of the layer = column sums of Y over the tokens: the A fragments pass through registers anyway,
+  // so the waves of the first column block (of the first N-slice) add them up on the side.
+  const bool bias = dB != nullptr && nb == 0 && n0 == 0;
+  float bsum[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) bsum[i] = 0.f;
   __syncthreads();
   for (int ci = 0; ci < nci; ++ci) {
     const float* Ys = (ci & 1) ? buf1 : buf0;
@@ -209,6 +215,7 @@ __global__ __launch_bounds__(512, 4) void k_dw(const float* Y, const float* X, c
             int cm = m0 + 16 * i + r;
             if constexpr (MS % 16 != 0) cm = cm < MS ? cm : MS - 1;   // half tiles (C = 8): stay inside the tile
             a[i] = YHM ? Ys[((cm >> 2) * (TC + 1) + t) * 4 + (cm & 3)] : Ys[t * LDY + cm];
+            bsum[i] += a[i];
           }
 #pragma unroll
           for (int j = 0; j < NI; ++j) {
@@ -226,9 +233,15 @@ __global__ __launch_bounds__(512, 4) void k_dw(const float* Y, const float* X, c
     __syncthreads();
   }
 
+#pragma unroll
+  for (int i = 0; i < MI; ++i) bsum[i] = rows_sum(bsum[i]);   // over the 4 k-groups: every lane (r, *) holds column r
   if constexpr (KW > 1) {   // fold the K-split partials: wave (wb, kw > 0) -> LDS -> wave (wb, 0)
     float* red = buf0;      // staging buffers are free now (last barrier of the loop)
+    float* redb = red + (KW - 1) * NWB * MI * NI * 256;
     if (kw > 0 && kw < KW) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+        if (g == 0) redb[(((kw - 1) * NWB + wb) * MI + i) * 16 + r] = bsum[i];
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -243,6 +256,16 @@ __global__ __launch_bounds__(512, 4) void k_dw(const float* Y, const float* X, c
 #pragma unroll
           for (int j = 0; j < NI; ++j)
             acc[i][j] += *reinterpret_cast<const f32x4*>(red + ((((k - 1) * NWB + wb) * MI + i) * NI + j) * 256 + lane * 4);
+      for (int k = 1; k < KW; ++k)
+#pragma unroll
+        for (int i = 0; i < MI; ++i) bsum[i] += redb[(((k - 1) * NWB + wb) * MI + i) * 16 + r];
+    }
+  }
+  if (kw == 0 && bias && g == 0) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = m0 + 16 * i + r;
+      if (m < MS) atomicAdd(dB + mb + m, bsum[i]);
     }
   }
   if (kw == 0) {
@@ -266,7 +289,7 @@ void set_dw_lds_budget(size_t bytes) { g_dw_budget = bytes < (size_t)RAL_DW_LDS_
 
 template <int M, int NC, int MS, int NS, int LAYY, int XF>
 static void launch_dw_t(const float* Y, const float* X, const float* pe, const float* lnw, const float* lnb,
-                        const float* a2c0, float* dW, int N, int B, int ksplit, hipStream_t s) {
+                        const float* a2c0, float* dW, float* dB, int N, int B, int ksplit, hipStream_t s) {
   static_assert(M % MS == 0 && NC % NS == 0, "slices must tile dW");
   constexpr bool yhm = LAYY == LAY_HM, xhm = XF == XF_HM;
   constexpr int TM = (MS + 15) / 16, TN = (NS + 15) / 16;
@@ -275,7 +298,7 @@ static void launch_dw_t(const float* Y, const float* X, const float* pe, const f
   int TC = dw_tcmax(MS, NS, yhm, xhm, XF == XF_LNPE);
   auto bytes = [&](int tc) { return (size_t)2 * (dw_tile_floats(MS, yhm, tc) + dw_tile_floats(NS, xhm, tc)) * sizeof(float); };
   while (TC > 16 && (N % TC != 0 || bytes(TC) > g_dw_budget)) TC /= 2;
-  const size_t fold = (size_t)(KW - 1) * TM * TN * 256 * sizeof(float);   // K-split partials of the spare waves
+  const size_t fold = (size_t)(KW - 1) * (TM * TN * 256 + TM * 16) * sizeof(float);   // K-split partials of the spare waves
   const size_t lds = bytes(TC) > fold ? bytes(TC) : fold;
   RAL_SET_LDS((k_dw<M, NC, MS, NS, LAYY, XF>), lds);
   // ksplit is the split-K count of a fully sliced product; products with fewer slices get proportionally more
@@ -284,7 +307,7 @@ static void launch_dw_t(const float* Y, const float* X, const float* pe, const f
   int ks = ksplit;
   if (ks * nsl < 256) ks = (256 + nsl - 1) / nsl;
   dim3 grid(B < ks ? B : ks, nsl);
-  k_dw<M, NC, MS, NS, LAYY, XF><<<grid, 512, lds, s>>>(Y, X, pe, lnw, lnb, a2c0, dW, N, TC, B);
+  k_dw<M, NC, MS, NS, LAYY, XF><<<grid, 512, lds, s>>>(Y, X, pe, lnw, lnb, a2c0, dW, dB, N, TC, B);
 }
 
 // slice widths: at most 128 rows/columns of the wide operand per workgroup
@@ -294,10 +317,10 @@ template <int C>
 static void launch_block_dw_c(const float* dx2, const float* upre, const float* a2c0, const float* dupre, const float* x1,
                               const float* dx1, const float* o_hm, const float* dqkv, const float* x, const float* pe,
                               const BlockP& w, const BlockP& gr, int N, int B, int ks, hipStream_t s) {
-  launch_dw_t<C, 4 * C, C, SliceOf<4 * C>::v, LAY_TOK, XF_A2>(dx2, upre, nullptr, nullptr, nullptr, a2c0, gr.w2, N, B, ks, s);
-  launch_dw_t<4 * C, C, SliceOf<4 * C>::v, C, LAY_TOK, XF_LN>(dupre, x1, nullptr, w.ln2w, w.ln2b, nullptr, gr.w1, N, B, ks, s);
-  launch_dw_t<C, C, C, C, LAY_TOK, XF_HM>(dx1, o_hm, nullptr, nullptr, nullptr, nullptr, gr.wp, N, B, ks, s);
-  launch_dw_t<3 * C, C, SliceOf<3 * C>::v, C, LAY_HM, XF_LNPE>(dqkv, x, pe, w.ln1w, w.ln1b, nullptr, gr.wqkv, N, B, ks, s);
+  launch_dw_t<C, 4 * C, C, SliceOf<4 * C>::v, LAY_TOK, XF_A2>(dx2, upre, nullptr, nullptr, nullptr, a2c0, gr.w2, gr.b2, N, B, ks, s);
+  launch_dw_t<4 * C, C, SliceOf<4 * C>::v, C, LAY_TOK, XF_LN>(dupre, x1, nullptr, w.ln2w, w.ln2b, nullptr, gr.w1, gr.b1, N, B, ks, s);
+  launch_dw_t<C, C, C, C, LAY_TOK, XF_HM>(dx1, o_hm, nullptr, nullptr, nullptr, nullptr, gr.wp, gr.bp, N, B, ks, s);
+  launch_dw_t<3 * C, C, SliceOf<3 * C>::v, C, LAY_HM, XF_LNPE>(dqkv, x, pe, w.ln1w, w.ln1b, nullptr, gr.wqkv, gr.bqkv, N, B, ks, s);
 }
 
 void launch_block_dw(int C, const float* dx2, const float* upre, const float* a2c0, const float* dupre, const float* x1,
@@ -312,8 +335,8 @@ void launch_block_dw(int C, const float* dx2, const float* upre, const float* a2
 
 void launch_resample_dw(int D, bool sep, const float* dy, const float* x, const float* lnw, const float* lnb,
                         float* dW, int T, int B, int ksplit, hipStream_t s) {
-#define CASE(d) case d: if (sep) launch_dw_t<d, d, d, d, LAY_TOK, XF_LN_SEP>(dy, x, nullptr, lnw, lnb, nullptr, dW, T, B, ksplit, s); \
-                        else launch_dw_t<d, d, d, d, LAY_TOK, XF_LN>(dy, x, nullptr, lnw, lnb, nullptr, dW, T, B, ksplit, s); break;
+#define CASE(d) case d: if (sep) launch_dw_t<d, d, d, d, LAY_TOK, XF_LN_SEP>(dy, x, nullptr, lnw, lnb, nullptr, dW, nullptr, T, B, ksplit, s); \
+                        else launch_dw_t<d, d, d, d, LAY_TOK, XF_LN>(dy, x, nullptr, lnw, lnb, nullptr, dW, nullptr, T, B, ksplit, s); break;
   switch (D) { CASE(8) CASE(16) CASE(32) CASE(64) CASE(128) }
 #undef CASE
 }

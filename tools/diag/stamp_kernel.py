@@ -1,0 +1,27 @@
+"""Per-phase cycle shares of a stamped kernel (diagnostic).  Build: make -C ecg_denoise_amd/csrc STAMP=<C>;
+run on the GPU box: STAMP_C=<C> python tools/diag/stamp_kernel.py [fwd|bwd].  Slots are whatever RAL_STAMP_AT(i)
+calls the kernels of ral_bwd.hip currently carry (workgroup 0 of every launch of one training step)."""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["RAL_LIB_PATH"] = os.path.join(ROOT, "tools", "diag", "libralenet_stamp%s.so" % os.environ.get("STAMP_C", "1"))
+os.environ["RAL_LANES"] = "1"; os.environ["RAL_NO_SIDE_STREAM"] = "1"
+sys.path.insert(0, ROOT)
+import torch
+from ecg_denoise_amd import RALENet, _lib
+B = 2048
+m = RALENet("full", leads=1, L=512, max_batch=B, device="cuda:0", seed=1)
+x = torch.randn(B, 1, 512, device="cuda:0")
+lib = _lib.lib()
+lib.ral_debug_stamps.argtypes = [C.c_void_p, C.c_int]
+m.train()
+def step():
+    y = m(x); m.backward(torch.randn_like(y) / y.numel())
+for _ in range(2): step()
+torch.cuda.synchronize()
+buf = (C.c_ulonglong * 32)()
+lib.ral_debug_stamps(buf, 1)
+step(); torch.cuda.synchronize()
+lib.ral_debug_stamps(buf, 0)
+tot = sum(buf[i] for i in range(32))
+for i in range(32):
+    if buf[i]: print(f"  slot {i:2d} {buf[i]:12d}  {100.0*buf[i]/tot:5.1f}%")
