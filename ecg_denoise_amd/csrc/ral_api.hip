@@ -713,10 +713,17 @@ int ral_create(const ral_config* cfg, ral_handle** out) {
     m->n_lanes = (int)env_size("RAL_LANES", 2);
     if (m->n_lanes < 1) m->n_lanes = 1;
     if (m->n_lanes > MAX_LANES) m->n_lanes = MAX_LANES;
+    // the weight-gradient streams are off the critical path: lowest priority, so that their workgroups fill the
+    // gaps the main chain leaves instead of competing with it (RAL_DW_PRIO=0 keeps the default priority)
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    const int pmode = (int)env_size("RAL_DW_PRIO", 0);   // 0 default, 1 lowest, 2 highest
+    const bool low = pmode != 0;
     for (int i = 0; i < MAX_LANES; ++i) {
       Lane& ln = LS->l[i];
       if (i > 0) { (void)hipStreamCreateWithFlags(&LS->own[i], hipStreamNonBlocking); }
-      (void)hipStreamCreateWithFlags(&ln.s2, hipStreamNonBlocking);
+      if (low) (void)hipStreamCreateWithPriority(&ln.s2, hipStreamNonBlocking, pmode == 2 ? prio_greatest : prio_least);
+      else (void)hipStreamCreateWithFlags(&ln.s2, hipStreamNonBlocking);
       for (int k = 0; k < 2; ++k) {
         (void)hipEventCreateWithFlags(&ln.ev_ready[k], hipEventDisableTiming);
         (void)hipEventCreateWithFlags(&ln.ev_done[k], hipEventDisableTiming);

@@ -27,6 +27,13 @@ template <int TM, int TN> struct WaveGrid4 {
 // read (row t0 + g, column c0 + r) hit disjoint banks
 constexpr int dw_ld(int w) { int l = 16; while (l < w) l += 32; return l; }
 constexpr int dw_tile_floats(int w, bool hm, int tc) { return hm ? (w / 4) * (tc + 1) * 4 : tc * dw_ld(w); }
+// widest slice of the sliced operand, and the workgroup count below which a launch gets more split-K workgroups
+#ifndef RAL_DW_SLICE
+#define RAL_DW_SLICE 128
+#endif
+#ifndef RAL_DW_MINWG
+#define RAL_DW_MINWG 256
+#endif
 #ifndef RAL_DW_LDS_BYTES
 #define RAL_DW_LDS_BYTES (76 * 1024)
 #endif
@@ -35,7 +42,7 @@ constexpr int dw_tile_floats(int w, bool hm, int tc) { return hm ? (w / 4) * (tc
 constexpr int dw_tcmax(int MS, int NS, bool yhm, bool xhm, bool lnpe) {
   const int TM = (MS + 15) / 16, TN = (NS + 15) / 16;
   const int tiles = TM * TN >= 4 ? TM * TN / 4 : 1;
-  const int cap = tiles >= 16 ? 6 : 12;
+  const int cap = 12;   // (the accumulators are not live in the producer path)
   int tc = 128;
   while (tc > 16 && (2 * (dw_tile_floats(MS, yhm, tc) + dw_tile_floats(NS, xhm, tc)) * 4 > RAL_DW_LDS_BYTES ||
                      tc * (MS + NS * (lnpe ? 2 : 1)) / 4 > cap * 256)) tc /= 2;
@@ -305,13 +312,13 @@ static void launch_dw_t(const float* Y, const float* X, const float* pe, const f
   // split-K workgroups so that every launch still fills the chip (at least ~256 workgroups)
   constexpr int nsl = (M / MS) * (NC / NS);
   int ks = ksplit;
-  if (ks * nsl < 256) ks = (256 + nsl - 1) / nsl;
+  if (ks * nsl < RAL_DW_MINWG) ks = (RAL_DW_MINWG + nsl - 1) / nsl;
   dim3 grid(B < ks ? B : ks, nsl);
   k_dw<M, NC, MS, NS, LAYY, XF><<<grid, 512, lds, s>>>(Y, X, pe, lnw, lnb, a2c0, dW, dB, N, TC, B);
 }
 
-// slice widths: at most 128 rows/columns of the wide operand per workgroup
-template <int W> struct SliceOf { static constexpr int v = W > 128 ? ((W % 128 == 0) ? 128 : W / 2) : W; };
+// slice widths: at most RAL_DW_SLICE rows/columns of the wide operand per workgroup
+template <int W> struct SliceOf { static constexpr int v = W > RAL_DW_SLICE ? ((W % RAL_DW_SLICE == 0) ? RAL_DW_SLICE : W / 2) : W; };
 
 template <int C>
 static void launch_block_dw_c(const float* dx2, const float* upre, const float* a2c0, const float* dupre, const float* x1,
@@ -319,7 +326,7 @@ static void launch_block_dw_c(const float* dx2, const float* upre, const float* 
                               const BlockP& w, const BlockP& gr, int N, int B, int ks, hipStream_t s) {
   launch_dw_t<C, 4 * C, C, SliceOf<4 * C>::v, LAY_TOK, XF_A2>(dx2, upre, nullptr, nullptr, nullptr, a2c0, gr.w2, gr.b2, N, B, ks, s);
   launch_dw_t<4 * C, C, SliceOf<4 * C>::v, C, LAY_TOK, XF_LN>(dupre, x1, nullptr, w.ln2w, w.ln2b, nullptr, gr.w1, gr.b1, N, B, ks, s);
-  launch_dw_t<C, C, C, C, LAY_TOK, XF_HM>(dx1, o_hm, nullptr, nullptr, nullptr, nullptr, gr.wp, gr.bp, N, B, ks, s);
+  launch_dw_t<C, C, SliceOf<C>::v, C, LAY_TOK, XF_HM>(dx1, o_hm, nullptr, nullptr, nullptr, nullptr, gr.wp, gr.bp, N, B, ks, s);
   launch_dw_t<3 * C, C, SliceOf<3 * C>::v, C, LAY_HM, XF_LNPE>(dqkv, x, pe, w.ln1w, w.ln1b, nullptr, gr.wqkv, gr.bqkv, N, B, ks, s);
 }
 

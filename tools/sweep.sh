@@ -1,6 +1,4 @@
-run() { echo "=== $*"; env "$@" python bench.py --steps 4 --warmup 2 --no-cpu --kinds 2>&1 | grep -E "^  dw|value" | cut -c1-120; }
-run RAL_DW_KSPLIT=256,256,256,128,64
-run RAL_DW_KSPLIT=1024,1024,1024,128,64
-run RAL_DW_KSPLIT=1024,1024,1024,128,64 RAL_DW_LDS=24000
-run RAL_DW_KSPLIT=2048,2048,1024,256,128 RAL_DW_LDS=24000
-run RAL_DW_KSPLIT=512,512,512,256,128 RAL_DW_LDS=32000
+run() { echo "=== $*"; for i in 1 2; do env "$@" python bench.py --steps 20 --warmup 3 --no-cpu 2>&1 | grep -E "value" | cut -c1-110; done; }
+run RAL_DW_PRIO=2
+run RAL_DW_PRIO=2 RAL_LIB_PATH=tools/diag/libralenet_s64w256.so
+run RAL_DW_PRIO=0
