@@ -516,7 +516,8 @@ static void run_block_bwd(RalModel* m, int bi, const float* dy, const float* ext
         *dqkv = woff(m->dqkv[k], w0, 3 * E1), *a2c0 = woff(m->a2c0[k], w0, m->L);   // (per-window stride L at every level: the lanes run different levels concurrently)
   const float *x1 = woff(a.x1, w0, E1), *upre = woff(a.upre, w0, 4 * E1), *qkv = woff(a.qkv, w0, 3 * E1),
               *o = woff(a.o, w0, E1), *lse = woff(a.lse, w0, E1 / 4), *xin = woff(a.in, w0, E1);
-  { ProfScope p(m, K_MLP_BWD, s); launch_mlp_bwd(C, m->nch_b[l], dyw, x1, upre, w, wt, g, dupre, dx1, dohm, a2c0, N, B, s); }
+  bool fused_mlp_dw;
+  { ProfScope p(m, K_MLP_BWD, s); fused_mlp_dw = launch_mlp_bwd(C, m->nch_b[l], dyw, x1, upre, w, wt, g, dupre, dx1, dohm, a2c0, N, B, s); }
   { ProfScope p(m, K_ATTN_BWD, s); launch_attn_bwd(qkv, o, dohm, lse, table, gtable, dqkv, N, H, m->hg_b[l], Len, B, s); }
   { ProfScope p(m, K_QKV_BWD, s);
     launch_qkv_bwd(C, dqkv, xin, m->pe[l], dx1, woff(extra, w0, E1), w, wt, g, woff(dx, w0, E1), N, B, s); }
@@ -525,7 +526,7 @@ static void run_block_bwd(RalModel* m, int bi, const float* dy, const float* ext
     (void)hipStreamWaitEvent(sd, ln.ev_ready[k], 0);
   }
   { ProfScope p(m, K_DW, sd);
-    launch_block_dw(C, dyw, upre, w.le ? a2c0 : nullptr, dupre, x1, dx1, o, dqkv, xin, m->pe[l], w, g, N, B, m->dw_ksplit[l], sd); }
+    launch_block_dw(C, dyw, upre, w.le ? a2c0 : nullptr, dupre, x1, dx1, o, dqkv, xin, m->pe[l], w, g, N, B, m->dw_ksplit[l], fused_mlp_dw, sd); }
   if (m->side_stream) { (void)hipEventRecord(ln.ev_done[k], sd); ln.dw_pending[k] = true; }
 }
 

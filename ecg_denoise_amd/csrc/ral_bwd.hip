@@ -8,7 +8,7 @@
 #include <stdlib.h>
 #include <type_traits>
 
-RAL_STAMPS_DEFINE
+RAL_STAMPS_DEFINE(ral_debug_stamps)
 
 // LDS float4 atomic accumulate of per-channel vectors: red[c..c+3] += v
 RAL_DEV void lds_add4(float* red, int c, float4 v) {
@@ -165,6 +165,242 @@ __global__ __launch_bounds__(512) void k_mlp_bwd(const float* __restrict__ dx2, 
     atomicAdd(gr.ln2b + threadIdx.x, red[C + threadIdx.x]);
   }
   if (le && threadIdx.x < 3) atomicAdd(gr.le + threadIdx.x, red[2 * C + threadIdx.x]);
+}
+
+// =================================================================================
+// B3s: the same backward for the narrow levels (C <= 32) with the fc1 / fc2 WEIGHT gradients fused in.
+// At these widths dW1 (4C x C) and dW2 (C x 4C) fit in a few accumulator registers per wave, and both of
+// their operands (du | LN2(x1) and dx2 | a2) are already in LDS here, so the two token-contraction kernels
+// of ral_dw.hip -- which re-read u_pre and du_pre from HBM and re-compute the GELU chain and the LayerNorm --
+// disappear, and du_pre is never written.  Workgroups are persistent (a few windows each) so that the
+// accumulators are flushed with one atomic per element per workgroup.
+//   hidden chunks of HC = C channels (4 chunks); LDS: dx2->dx1 | LN2(x1) | u_pre->du (->dg) | a2, each N x LD
+//   per chunk: da2 GEMM (epilogue: du, a2) -> barrier -> [dg tiles in registers, dW tile jobs] -> barrier
+//   TW = token tiles of dg per wave (N * max(C,16) / 2048)
+// =================================================================================
+template <int C, int TW>
+__global__ __launch_bounds__(512, 4) void k_mlp_bwd_s(const float* __restrict__ dx2, const float* __restrict__ x1,
+                                                      const float* __restrict__ upre, BlockP w, BlockP wt, BlockP gr,
+                                                      float* __restrict__ dx1, float* __restrict__ do_hm, int N, int B) {
+  extern __shared__ float4 smem4[];
+  constexpr int LD = LDof<C>::v, HC = C, NCH = 4, LPR = C / 4;
+  constexpr int MT = C >= 16 ? C / 16 : 1;          // 16-row tiles along C (half a tile at C = 8)
+  constexpr int T = MT * MT, JOBS = 2 * T;          // dW tiles per product and chunk; jobs = both products
+  constexpr int KS = JOBS >= 8 ? 1 : 8 / JOBS;      // spare waves split the tokens of a job
+  static_assert(JOBS <= 8 && 8 % JOBS == 0, "one dW job per wave");
+  float* Ds = reinterpret_cast<float*>(smem4);  // N x LD : dx2 -> dx1
+  float* Xl = Ds + N * LD;                      // N x LD : LN2(x1)  (fc1 input)
+  float* Us = Xl + N * LD;                      // N x LD : u_pre chunk -> du chunk; dg after the chunks
+  float* As = Us + N * LD;                      // N x LD : a2 chunk (fc2 input)
+  float* A0 = As + N * LD;                      // N + 2  : gelu(u[:,0]), zero halo
+  float* DC0 = A0 + N + 2;                      // N + 2  : d c0, zero halo
+  float* U0 = DC0 + N + 2;                      // N      : u_pre[:,0]
+  float* C0 = U0 + N;                           // N      : conv output c0
+  float* red = C0 + N;                          // 2C + 4 : ln2 grads + le taps (block reduction)
+  const int RPP = blockDim.x / LPR;
+  const int cq = (threadIdx.x % LPR) * 4;
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
+  const bool le = w.le != nullptr;
+  float lw0 = 0.f, lw1 = 0.f, lw2 = 0.f;
+  if (le) { lw0 = w.le[0]; lw1 = w.le[1]; lw2 = w.le[2]; }
+  const float4 gam2 = *reinterpret_cast<const float4*>(w.ln2w + cq);
+  const float4 bet2 = *reinterpret_cast<const float4*>(w.ln2b + cq);
+  float gle0 = 0.f, gle1 = 0.f, gle2 = 0.f;
+  float4 dgam = make_float4(0.f, 0.f, 0.f, 0.f), dbet = make_float4(0.f, 0.f, 0.f, 0.f);
+  // this wave's dW job: product 0 = dW2 (rows c, columns hidden j), product 1 = dW1 (rows hidden j, columns c)
+  const int job = wave % JOBS, kpart = wave / JOBS;
+  const int prod = job / T, mi = (job % T) / MT, nj = (job % T) % MT;
+  int arow = mi * 16 + r, bcol = nj * 16 + r;       // operand columns of this lane, clamped into the half tile
+  if (arow >= C) arow = C - 1;
+  if (bcol >= C) bcol = C - 1;
+  f32x4 accw[NCH];
+  float bs1[NCH], bs2 = 0.f;                         // column sums of du (db1) and of dx2 (db2)
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) { accw[ch] = f32x4{0.f, 0.f, 0.f, 0.f}; bs1[ch] = 0.f; }
+  // this wave's dg tiles: channel tile gm, token tiles [gt0, gt0 + TW)
+  const int gm = wave % MT, gt0 = (wave / MT) * TW;
+
+  for (int win = blockIdx.x; win < B; win += gridDim.x) {
+    const size_t wo = (size_t)win * N * C;
+    copy_in(Ds, LD, dx2 + wo, C, N, C);
+    for_each_row_f4<4>(x1 + wo, C, N, C, [&](int row, int c, float4 v) {   // (row = LPR consecutive lanes)
+      float4 d; float rstd;
+      ln_stats<LPR>(v, d, rstd);
+      *reinterpret_cast<float4*>(Xl + row * LD + c) = f4add(f4mul(f4scale(d, rstd), gam2), bet2);
+    });
+    f32x4 accg[TW];
+#pragma unroll
+    for (int i = 0; i < TW; ++i) accg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int j0 = ch * HC;
+      copy_in(Us, LD, upre + (size_t)win * N * 4 * C + j0, 4 * C, N, HC);
+      __syncthreads();
+      if (le && ch == 0) {
+        for (int i = threadIdx.x; i < N + 2; i += blockDim.x) {
+          const bool halo = (i == 0 || i == N + 1);
+          const float u = halo ? 0.f : Us[(i - 1) * LD];
+          A0[i] = halo ? 0.f : gelu_f(u);
+          DC0[i] = 0.f;
+          if (!halo) U0[i - 1] = u;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < N; i += blockDim.x) C0[i] = lw0 * A0[i] + lw1 * A0[i + 1] + lw2 * A0[i + 2];
+        __syncthreads();
+      }
+      // d a2 = dx2 W2[:, chunk]  -> du (in place over u_pre), a2 -> As
+      gemm_phase<C, TTBof<C>::v, false, LAY_TOK>(wt.w2 + (size_t)j0 * C, C, HC, Ds, LD, N >> 4,
+                                                [&](int row0, int tok, f32x4 a) {
+        float4* pu = reinterpret_cast<float4*>(Us + tok * LD + row0);
+        const float4 u = *pu;
+        float uu[4] = {u.x, u.y, u.z, u.w}, out[4], a2[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float a1, d1;
+          gelu_pair(uu[e], a1, d1);
+          if (!le) {
+            out[e] = a[e] * d1; a2[e] = a1;
+          } else if (ch == 0 && row0 + e == 0) {
+            DC0[tok + 1] = a[e] * gelu_grad_f(C0[tok]);
+            out[e] = 0.f; a2[e] = 0.f;  // both filled by the channel-0 pass below
+          } else {
+            float g2, d2;
+            gelu_pair(a1, g2, d2);
+            out[e] = a[e] * d2 * d1; a2[e] = g2;
+          }
+        }
+        *pu = make_float4(out[0], out[1], out[2], out[3]);
+        *reinterpret_cast<float4*>(As + tok * LD + row0) = make_float4(a2[0], a2[1], a2[2], a2[3]);
+      });
+      __syncthreads();
+      if (le && ch == 0) {
+        for (int n = threadIdx.x; n < N; n += blockDim.x) {
+          const float da1 = lw0 * DC0[n + 2] + lw1 * DC0[n + 1] + lw2 * DC0[n];
+          Us[n * LD] = da1 * gelu_grad_f(U0[n]);
+          As[n * LD] = gelu_f(C0[n]);
+          const float dc = DC0[n + 1];
+          gle0 += dc * A0[n]; gle1 += dc * A0[n + 1]; gle2 += dc * A0[n + 2];
+        }
+        __syncthreads();
+      }
+      // dg += du W1[chunk, :]   (this wave's tiles, accumulated in registers over the chunks)
+      gemm_wx<HC, TW, false, LAY_TOK>(wt.w1 + j0, 4 * C, gm * 16, C, Us, LD, gt0 * 16, accg);
+      // dW job of this wave: contraction over its share of the window's tokens, both operands in LDS
+      {
+        const float* Ap = prod ? Us : Ds;
+        const float* Bp = prod ? Xl : As;
+        const int tlen = N / KS;
+        for (int t0 = kpart * tlen; t0 < (kpart + 1) * tlen; t0 += 16) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const int t = t0 + 4 * g + s;
+            const float av = Ap[t * LD + arow], bv = Bp[t * LD + bcol];
+            accw[ch] = mfma4(av, bv, accw[ch]);
+            bs1[ch] += av;
+            if (ch == 0) bs2 += av;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    // dg -> LDS (over the du buffer) for the row-wise LayerNorm backward
+    {
+      const int row0 = gm * 16 + 4 * g;
+      if (row0 < C) {
+#pragma unroll
+        for (int i = 0; i < TW; ++i)
+          *reinterpret_cast<float4*>(Us + ((gt0 + i) * 16 + r) * LD + row0) = tofloat4(accg[i]);
+      }
+    }
+    __syncthreads();
+    // LN2 backward, dx1 = dx2 + dLN
+    for (int row = threadIdx.x / LPR; row < N; row += RPP) {
+      const float4 v = *reinterpret_cast<const float4*>(x1 + wo + (size_t)row * C + cq);
+      float4 d; float rstd;
+      ln_stats<LPR>(v, d, rstd);
+      const float4 xh = f4scale(d, rstd);
+      const float4 dg = *reinterpret_cast<const float4*>(Us + row * LD + cq);
+      const float4 dyh = f4mul(dg, gam2);
+      constexpr float invC = 1.0f / C;
+      const float m1 = group_sum<LPR>(f4hsum(dyh)) * invC;
+      const float m2 = group_sum<LPR>(f4dot(dyh, xh)) * invC;
+      float4* pd = reinterpret_cast<float4*>(Ds + row * LD + cq);
+      const float4 dx = make_float4(rstd * (dyh.x - m1 - xh.x * m2), rstd * (dyh.y - m1 - xh.y * m2),
+                                    rstd * (dyh.z - m1 - xh.z * m2), rstd * (dyh.w - m1 - xh.w * m2));
+      *pd = f4add(*pd, dx);
+      dgam = f4add(dgam, f4mul(dg, xh));
+      dbet = f4add(dbet, dg);
+    }
+    __syncthreads();
+    copy_out(dx1 + wo, C, Ds, LD, N, C);
+    // do = dx1 Wp  (head-major)
+    float* dow = do_hm + wo;
+    gemm_phase<C, TTBof<C>::v, false, LAY_TOK>(wt.wp, C, C, Ds, LD, N >> 4, [&](int row0, int tok, f32x4 a) {
+      *reinterpret_cast<float4*>(dow + ((size_t)(row0 >> 2) * N + tok) * 4) = tofloat4(a);
+    });
+    __syncthreads();
+  }
+  // ---- flush the small gradients ----
+  for (int i = threadIdx.x; i < 2 * C + 4; i += blockDim.x) red[i] = 0.f;
+  __syncthreads();
+  lds_add4(red, cq, dgam);
+  lds_add4(red, C + cq, dbet);
+  if (le) {
+    const float s0 = group_sum<64>(gle0), s1 = group_sum<64>(gle1), s2 = group_sum<64>(gle2);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(red + 2 * C, s0); atomicAdd(red + 2 * C + 1, s1); atomicAdd(red + 2 * C + 2, s2); }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < C) {
+    atomicAdd(gr.ln2w + threadIdx.x, red[threadIdx.x]);
+    atomicAdd(gr.ln2b + threadIdx.x, red[C + threadIdx.x]);
+  }
+  if (le && threadIdx.x < 3) atomicAdd(gr.le + threadIdx.x, red[2 * C + threadIdx.x]);
+  // ---- flush the weight gradients: fold the token-split partials through LDS, then one atomic per element ----
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) bs1[ch] = rows_sum(bs1[ch]);
+  bs2 = rows_sum(bs2);
+  if constexpr (KS > 1) {
+    float* fold = Ds;   // (KS - 1) x JOBS x (NCH x 256 + NCH x 16 + 16) floats <= 3 x 2 x 1104: inside the 4 N x LD tiles
+    constexpr int PER = NCH * 256 + NCH * 16 + 16;
+    float* mine = fold + ((kpart - 1) * JOBS + job) * PER;
+    if (kpart > 0) {
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) {
+        *reinterpret_cast<f32x4*>(mine + ch * 256 + lane * 4) = accw[ch];
+        if (g == 0) mine[NCH * 256 + ch * 16 + r] = bs1[ch];
+      }
+      if (g == 0) mine[NCH * 256 + NCH * 16 + r] = bs2;
+    }
+    __syncthreads();
+    if (kpart == 0) {
+      for (int k = 1; k < KS; ++k) {
+        const float* o = fold + ((k - 1) * JOBS + job) * PER;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+          accw[ch] += *reinterpret_cast<const f32x4*>(o + ch * 256 + lane * 4);
+          bs1[ch] += o[NCH * 256 + ch * 16 + r];
+        }
+        bs2 += o[NCH * 256 + NCH * 16 + r];
+      }
+    }
+  }
+  if (kpart == 0) {
+    const int col = nj * 16 + r;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int j0 = ch * HC;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = mi * 16 + 4 * g + q;
+        if (row < C && col < C) {
+          if (prod) atomicAdd(gr.w1 + (size_t)(j0 + row) * C + col, accw[ch][q]);       // dW1[hidden][c]
+          else atomicAdd(gr.w2 + (size_t)row * 4 * C + j0 + col, accw[ch][q]);          // dW2[c][hidden]
+        }
+      }
+      if (prod && nj == 0 && g == 0 && mi * 16 + r < C) atomicAdd(gr.b1 + j0 + mi * 16 + r, bs1[ch]);
+    }
+    if (!prod && nj == 0 && g == 0 && mi * 16 + r < C) atomicAdd(gr.b2 + mi * 16 + r, bs2);
+  }
 }
 
 // =================================================================================
@@ -739,23 +975,47 @@ size_t mlp_bwd_lds(int C, int N, int nch) {
   return ((size_t)2 * N * ld_of(C) + (size_t)N * ld_of(4 * C / nch) + 2 * (N + 2) + 2 * N + 8 * C + 16) * sizeof(float);
 }
 
+// narrow levels: fused weight-gradient variant (k_mlp_bwd_s) when the window length gives each wave a whole
+// number (1, 2, 4 or 8) of dg token tiles; RAL_FUSE_DW=0 keeps the separate dW kernels
 template <int C>
-static void launch_mlp_bwd_c(int nch, const float* dx2, const float* x1, const float* upre, const BlockP& w,
+static bool launch_mlp_bwd_s(const float* dx2, const float* x1, const float* upre, const BlockP& w, const BlockP& wt,
+                             const BlockP& gr, float* dx1, float* do_hm, int N, int B, hipStream_t s) {
+  static const bool off = getenv("RAL_FUSE_DW") && atoi(getenv("RAL_FUSE_DW")) == 0;
+  constexpr int MT = C >= 16 ? C / 16 : 1;
+  if (off || (N * MT) % 128 != 0) return false;
+  const int tw = N * MT / 128;
+  const size_t lds = ((size_t)4 * N * ld_of(C) + 2 * (N + 2) + 2 * N + 2 * C + 8) * sizeof(float);
+  if (lds > 80 * 1024) return false;
+  const int grid = B < 512 ? B : 512;
+#define GO(t) { RAL_SET_LDS((k_mlp_bwd_s<C, t>), lds); k_mlp_bwd_s<C, t><<<grid, 512, lds, s>>>(dx2, x1, upre, w, wt, gr, dx1, do_hm, N, B); return true; }
+  switch (tw) { case 1: GO(1) case 2: GO(2) case 4: GO(4) case 8: GO(8) default: return false; }
+#undef GO
+}
+
+template <int C>
+static bool launch_mlp_bwd_c(int nch, const float* dx2, const float* x1, const float* upre, const BlockP& w,
                              const BlockP& wt, const BlockP& gr, float* dupre, float* dx1, float* do_hm, float* a2c0, int N, int B, hipStream_t s) {
+  if constexpr (C <= 32) {
+    if (launch_mlp_bwd_s<C>(dx2, x1, upre, w, wt, gr, dx1, do_hm, N, B, s)) return true;
+  }
   const size_t lds = mlp_bwd_lds(C, N, nch);
   const int grid = grid_bwd(B);
   if (nch == 1) { RAL_SET_LDS((k_mlp_bwd<C, 1>), lds); k_mlp_bwd<C, 1><<<grid, 512, lds, s>>>(dx2, x1, upre, w, wt, gr, dupre, dx1, do_hm, a2c0, N, B); }
   else if (nch == 2) { RAL_SET_LDS((k_mlp_bwd<C, 2>), lds); k_mlp_bwd<C, 2><<<grid, 512, lds, s>>>(dx2, x1, upre, w, wt, gr, dupre, dx1, do_hm, a2c0, N, B); }
   else { RAL_SET_LDS((k_mlp_bwd<C, 4>), lds); k_mlp_bwd<C, 4><<<grid, 512, lds, s>>>(dx2, x1, upre, w, wt, gr, dupre, dx1, do_hm, a2c0, N, B); }
+  return false;
 }
 
-void launch_mlp_bwd(int C, int nch, const float* dx2, const float* x1, const float* upre, const BlockP& w,
+// returns true when the fc1 / fc2 weight (and bias) gradients were produced here (narrow levels): the caller then
+// skips those two products in launch_block_dw
+bool launch_mlp_bwd(int C, int nch, const float* dx2, const float* x1, const float* upre, const BlockP& w,
                     const BlockP& wt, const BlockP& gr, float* dupre, float* dx1, float* do_hm, float* a2c0, int N, int B, hipStream_t s) {
   switch (C) {
-#define CASE(c) case c: launch_mlp_bwd_c<c>(nch, dx2, x1, upre, w, wt, gr, dupre, dx1, do_hm, a2c0, N, B, s); break;
+#define CASE(c) case c: return launch_mlp_bwd_c<c>(nch, dx2, x1, upre, w, wt, gr, dupre, dx1, do_hm, a2c0, N, B, s);
     CASE(8) CASE(16) CASE(32) CASE(64) CASE(128)
 #undef CASE
   }
+  return false;
 }
 
 size_t attn_bwd_lds(int N, int HG, int Len) {

@@ -235,9 +235,10 @@ RAL_DEV void ln_stats(float4 v, float4& d, float& rstd) {
 // Phase stamps (diagnostic builds only: `make STAMP=1`, tools/diag/stamp_kernel.py).  Thread 0 of workgroup 0 adds
 // the cycles since the previous stamp to slot i; the product library compiles these macros to nothing.
 #ifdef RAL_STAMP
-#define RAL_STAMPS_DEFINE                                                                              \
-  __device__ unsigned long long g_ral_stamps[32];                                                      \
-  extern "C" int ral_debug_stamps(unsigned long long* out, int reset) {                                \
+// every translation unit has its own slot array; RAL_STAMPS_DEFINE(name) exports its accessor
+static __device__ unsigned long long g_ral_stamps[32];
+#define RAL_STAMPS_DEFINE(name)                                                                        \
+  extern "C" int name(unsigned long long* out, int reset) {                                            \
     unsigned long long z[32] = {0};                                                                    \
     if (reset) return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ral_stamps), z, sizeof(z));                  \
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ral_stamps), sizeof(z));                         \
@@ -255,7 +256,7 @@ RAL_DEV void ln_stats(float4 v, float4& d, float& rstd) {
     }                                                                                                  \
   } while (0)
 #else
-#define RAL_STAMPS_DEFINE
+#define RAL_STAMPS_DEFINE(name)
 #define RAL_STAMP_INIT() do {} while (0)
 #define RAL_STAMP_AT(i) do {} while (0)
 #endif

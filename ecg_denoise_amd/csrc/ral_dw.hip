@@ -323,18 +323,20 @@ template <int W> struct SliceOf { static constexpr int v = W > RAL_DW_SLICE ? ((
 template <int C>
 static void launch_block_dw_c(const float* dx2, const float* upre, const float* a2c0, const float* dupre, const float* x1,
                               const float* dx1, const float* o_hm, const float* dqkv, const float* x, const float* pe,
-                              const BlockP& w, const BlockP& gr, int N, int B, int ks, hipStream_t s) {
+                              const BlockP& w, const BlockP& gr, int N, int B, int ks, bool skip_mlp, hipStream_t s) {
+  if (!skip_mlp) {
   launch_dw_t<C, 4 * C, C, SliceOf<4 * C>::v, LAY_TOK, XF_A2>(dx2, upre, nullptr, nullptr, nullptr, a2c0, gr.w2, gr.b2, N, B, ks, s);
   launch_dw_t<4 * C, C, SliceOf<4 * C>::v, C, LAY_TOK, XF_LN>(dupre, x1, nullptr, w.ln2w, w.ln2b, nullptr, gr.w1, gr.b1, N, B, ks, s);
+  }
   launch_dw_t<C, C, SliceOf<C>::v, C, LAY_TOK, XF_HM>(dx1, o_hm, nullptr, nullptr, nullptr, nullptr, gr.wp, gr.bp, N, B, ks, s);
   launch_dw_t<3 * C, C, SliceOf<3 * C>::v, C, LAY_HM, XF_LNPE>(dqkv, x, pe, w.ln1w, w.ln1b, nullptr, gr.wqkv, gr.bqkv, N, B, ks, s);
 }
 
 void launch_block_dw(int C, const float* dx2, const float* upre, const float* a2c0, const float* dupre, const float* x1,
                      const float* dx1, const float* o_hm, const float* dqkv, const float* x, const float* pe,
-                     const BlockP& w, const BlockP& gr, int N, int B, int ksplit, hipStream_t s) {
+                     const BlockP& w, const BlockP& gr, int N, int B, int ksplit, bool skip_mlp, hipStream_t s) {
   switch (C) {
-#define CASE(c) case c: launch_block_dw_c<c>(dx2, upre, a2c0, dupre, x1, dx1, o_hm, dqkv, x, pe, w, gr, N, B, ksplit, s); break;
+#define CASE(c) case c: launch_block_dw_c<c>(dx2, upre, a2c0, dupre, x1, dx1, o_hm, dqkv, x, pe, w, gr, N, B, ksplit, skip_mlp, s); break;
     CASE(8) CASE(16) CASE(32) CASE(64) CASE(128)
 #undef CASE
   }

@@ -58,6 +58,8 @@ RAL_DEV f32x2 splat2(float v) { return f32x2{v, v}; }
 #define RAL_LOG2E 1.4426950408889634f
 #define RAL_LN2 0.6931471805599453f
 
+RAL_STAMPS_DEFINE(ral_debug_stamps_fwd)
+
 // Softmax shift without a running maximum: softmax is invariant to any per-row shift, and
 //   s[q][k] = q.k + bias <= |q| max_k |k| + max(bias, 0) =: m[q]   (Cauchy-Schwarz)
 // is known before the sweep.  -m[q] is fed to the MFMA as its C operand, so the tile comes out
@@ -81,8 +83,10 @@ __global__ __launch_bounds__(512, (QT >= 4 ? 3 : 4)) void k_attn_fwd(const float
   const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int off = (N - Len) >> 1;
   const int kb0 = table ? (off & ~15) : N, kb1 = table ? ((off + Len + 15) & ~15) : N;  // biased key tiles
+  RAL_STAMP_INIT();
   for (int item = blockIdx.x; item < B * ngrp; item += gridDim.x) {
     const int win = item / ngrp, h0 = (item - win * ngrp) * HG;
+    RAL_STAMP_AT(19);
     const float* base = qkv + (size_t)win * 3 * H * N * 4;
     if ((int)threadIdx.x < HG) { Kmax[threadIdx.x] = 0; if (table) Bmax[threadIdx.x] = 0.f; }
     __syncthreads();
@@ -117,6 +121,7 @@ __global__ __launch_bounds__(512, (QT >= 4 ? 3 : 4)) void k_attn_fwd(const float
         if (t > 0.f) atomicMax(reinterpret_cast<int*>(Bmax) + i % HG, __float_as_int(t));
       }
     __syncthreads();
+    RAL_STAMP_AT(20);
     const int qblocks = N / (16 * QT);
     for (int task = wave; task < HG * qblocks; task += nw) {
       const int hl = task / qblocks, q0 = (task - hl * qblocks) * 16 * QT;
@@ -133,6 +138,7 @@ __global__ __launch_bounds__(512, (QT >= 4 ? 3 : 4)) void k_attn_fwd(const float
         mq[qt] = Mq[hl * N + q] * kmx + (table ? Bmax[hl] : 0.f);
         l2[qt] = f32x2{0.f, 0.f}; o01[qt] = f32x2{0.f, 0.f}; o23[qt] = f32x2{0.f, 0.f};
       }
+      RAL_STAMP_AT(21);
       auto tile = [&](int kt, auto biased) {
         const float kf = Kh[(kt + r) * 4 + g];
         float4 v4[4];
@@ -170,6 +176,7 @@ __global__ __launch_bounds__(512, (QT >= 4 ? 3 : 4)) void k_attn_fwd(const float
       for (int kt = 0; kt < e0; kt += 16) tile(kt, std::false_type{});
       for (int kt = e0; kt < e1; kt += 16) tile(kt, std::true_type{});
       for (int kt = e1; kt < N; kt += 16) tile(kt, std::false_type{});
+      RAL_STAMP_AT(22);
       bool redo = false;
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {
@@ -186,6 +193,7 @@ __global__ __launch_bounds__(512, (QT >= 4 ? 3 : 4)) void k_attn_fwd(const float
           if (lse) lse[hq] = (mq[qt] + __builtin_amdgcn_logf(lv)) * RAL_LN2;   // natural-log units
         }
       }
+      RAL_STAMP_AT(23);
       if (__any(redo)) {   // exact running-max recurrence (lane-private state, merged at the end)
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
@@ -232,7 +240,9 @@ __global__ __launch_bounds__(512, (QT >= 4 ? 3 : 4)) void k_attn_fwd(const float
         }
       }
     }
+    RAL_STAMP_AT(24);
     __syncthreads();
+    RAL_STAMP_AT(25);
   }
 }
 

@@ -50,7 +50,7 @@ void launch_transpose_mats(const float* src, float* dst, const void* desc, int n
 
 // ---- backward (ral_bwd.hip)
 size_t mlp_bwd_lds(int C, int N, int nch);
-void launch_mlp_bwd(int C, int nch, const float* dx2, const float* x1, const float* upre, const BlockP& w,
+bool launch_mlp_bwd(int C, int nch, const float* dx2, const float* x1, const float* upre, const BlockP& w,
                     const BlockP& wt, const BlockP& gr, float* dupre, float* dx1, float* do_hm, float* a2c0, int N, int B,
                     hipStream_t s);
 size_t attn_bwd_lds(int N, int HG, int Len);
@@ -72,7 +72,7 @@ void launch_conv1_bwd_dx(int leads, const float* dz, const float* w, float* dx, 
 // ---- weight gradients (ral_dw.hip)
 void launch_block_dw(int C, const float* dx2, const float* upre, const float* a2c0, const float* dupre, const float* x1,
                      const float* dx1, const float* o_hm, const float* dqkv, const float* x, const float* pe,
-                     const BlockP& w, const BlockP& gr, int N, int B, int ksplit, hipStream_t s);
+                     const BlockP& w, const BlockP& gr, int N, int B, int ksplit, bool skip_mlp, hipStream_t s);
 void set_dw_lds_budget(size_t bytes);
 void launch_resample_dw(int D, bool sep, const float* dy, const float* x, const float* lnw, const float* lnb,
                         float* dW, int T, int B, int ksplit, hipStream_t s);

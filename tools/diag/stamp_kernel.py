@@ -12,16 +12,17 @@ B = 2048
 m = RALENet("full", leads=1, L=512, max_batch=B, device="cuda:0", seed=1)
 x = torch.randn(B, 1, 512, device="cuda:0")
 lib = _lib.lib()
-lib.ral_debug_stamps.argtypes = [C.c_void_p, C.c_int]
+fn = getattr(lib, "ral_debug_stamps_fwd" if (len(sys.argv) > 1 and sys.argv[1] == "fwd") else "ral_debug_stamps")
+fn.argtypes = [C.c_void_p, C.c_int]
 m.train()
 def step():
     y = m(x); m.backward(torch.randn_like(y) / y.numel())
 for _ in range(2): step()
 torch.cuda.synchronize()
 buf = (C.c_ulonglong * 32)()
-lib.ral_debug_stamps(buf, 1)
+fn(buf, 1)
 step(); torch.cuda.synchronize()
-lib.ral_debug_stamps(buf, 0)
+fn(buf, 0)
 tot = sum(buf[i] for i in range(32))
 for i in range(32):
     if buf[i]: print(f"  slot {i:2d} {buf[i]:12d}  {100.0*buf[i]/tot:5.1f}%")
