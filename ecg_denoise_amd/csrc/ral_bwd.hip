@@ -184,15 +184,18 @@ __global__ __launch_bounds__(512, 4) void k_mlp_bwd_s(const float* __restrict__ 
                                                       float* __restrict__ dx1, float* __restrict__ do_hm, int N, int B) {
   extern __shared__ float4 smem4[];
   constexpr int LD = LDof<C>::v, HC = C, NCH = 4, LPR = C / 4;
+  // Xl and As are only read as B operands of the dW jobs (4-byte reads): at C = 16 they go unpadded so that two
+  // workgroups still fit a CU (the 4-way bank conflict of those few reads costs less than the occupancy)
+  constexpr int LDB = (C == 16) ? C : LD;
   constexpr int MT = C >= 16 ? C / 16 : 1;          // 16-row tiles along C (half a tile at C = 8)
   constexpr int T = MT * MT, JOBS = 2 * T;          // dW tiles per product and chunk; jobs = both products
   constexpr int KS = JOBS >= 8 ? 1 : 8 / JOBS;      // spare waves split the tokens of a job
   static_assert(JOBS <= 8 && 8 % JOBS == 0, "one dW job per wave");
   float* Ds = reinterpret_cast<float*>(smem4);  // N x LD : dx2 -> dx1
   float* Xl = Ds + N * LD;                      // N x LD : LN2(x1)  (fc1 input)
-  float* Us = Xl + N * LD;                      // N x LD : u_pre chunk -> du chunk; dg after the chunks
+  float* Us = Xl + N * LDB;                      // N x LD : u_pre chunk -> du chunk; dg after the chunks
   float* As = Us + N * LD;                      // N x LD : a2 chunk (fc2 input)
-  float* A0 = As + N * LD;                      // N + 2  : gelu(u[:,0]), zero halo
+  float* A0 = As + N * LDB;                      // N + 2  : gelu(u[:,0]), zero halo
   float* DC0 = A0 + N + 2;                      // N + 2  : d c0, zero halo
   float* U0 = DC0 + N + 2;                      // N      : u_pre[:,0]
   float* C0 = U0 + N;                           // N      : conv output c0
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(512, 4) void k_mlp_bwd_s(const float* __restrict__ 
     for_each_row_f4<4>(x1 + wo, C, N, C, [&](int row, int c, float4 v) {   // (row = LPR consecutive lanes)
       float4 d; float rstd;
       ln_stats<LPR>(v, d, rstd);
-      *reinterpret_cast<float4*>(Xl + row * LD + c) = f4add(f4mul(f4scale(d, rstd), gam2), bet2);
+      *reinterpret_cast<float4*>(Xl + row * LDB + c) = f4add(f4mul(f4scale(d, rstd), gam2), bet2);
     });
     f32x4 accg[TW];
 #pragma unroll
@@ -270,14 +273,14 @@ __global__ __launch_bounds__(512, 4) void k_mlp_bwd_s(const float* __restrict__ 
           }
         }
         *pu = make_float4(out[0], out[1], out[2], out[3]);
-        *reinterpret_cast<float4*>(As + tok * LD + row0) = make_float4(a2[0], a2[1], a2[2], a2[3]);
+        *reinterpret_cast<float4*>(As + tok * LDB + row0) = make_float4(a2[0], a2[1], a2[2], a2[3]);
       });
       __syncthreads();
       if (le && ch == 0) {
         for (int n = threadIdx.x; n < N; n += blockDim.x) {
           const float da1 = lw0 * DC0[n + 2] + lw1 * DC0[n + 1] + lw2 * DC0[n];
           Us[n * LD] = da1 * gelu_grad_f(U0[n]);
-          As[n * LD] = gelu_f(C0[n]);
+          As[n * LDB] = gelu_f(C0[n]);
           const float dc = DC0[n + 1];
           gle0 += dc * A0[n]; gle1 += dc * A0[n + 1]; gle2 += dc * A0[n + 2];
         }
@@ -286,6 +289,7 @@ __global__ __launch_bounds__(512, 4) void k_mlp_bwd_s(const float* __restrict__ 
       // dg += du W1[chunk, :]   (this wave's tiles, accumulated in registers over the chunks)
       gemm_wx<HC, TW, false, LAY_TOK>(wt.w1 + j0, 4 * C, gm * 16, C, Us, LD, gt0 * 16, accg);
       // dW job of this wave: contraction over its share of the window's tokens, both operands in LDS
+#ifndef RAL_EXP_NOJOBS
       {
         const float* Ap = prod ? Us : Ds;
         const float* Bp = prod ? Xl : As;
@@ -294,13 +298,14 @@ __global__ __launch_bounds__(512, 4) void k_mlp_bwd_s(const float* __restrict__ 
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             const int t = t0 + 4 * g + s;
-            const float av = Ap[t * LD + arow], bv = Bp[t * LD + bcol];
+            const float av = Ap[t * LD + arow], bv = Bp[t * LDB + bcol];
             accw[ch] = mfma4(av, bv, accw[ch]);
             bs1[ch] += av;
             if (ch == 0) bs2 += av;
           }
         }
       }
+#endif
       __syncthreads();
     }
     // dg -> LDS (over the du buffer) for the row-wise LayerNorm backward
@@ -980,11 +985,15 @@ size_t mlp_bwd_lds(int C, int N, int nch) {
 template <int C>
 static bool launch_mlp_bwd_s(const float* dx2, const float* x1, const float* upre, const BlockP& w, const BlockP& wt,
                              const BlockP& gr, float* dx1, float* do_hm, int N, int B, hipStream_t s) {
-  static const bool off = getenv("RAL_FUSE_DW") && atoi(getenv("RAL_FUSE_DW")) == 0;
+  // widest level that takes the fused kernel (RAL_FUSE_DW=0 disables it, 8 / 16 narrow it).  Measured at batch 2048:
+  // none 102.8k, C <= 8 103.8k, C <= 16 105.5k, C <= 32 105.8k windows/s (at C = 32 the weight-gradient MFMAs are
+  // no longer negligible on the critical stream, so the gain flattens)
+  static const int maxc = getenv("RAL_FUSE_DW") ? atoi(getenv("RAL_FUSE_DW")) : 32;
   constexpr int MT = C >= 16 ? C / 16 : 1;
-  if (off || (N * MT) % 128 != 0) return false;
+  if (C > maxc || (N * MT) % 128 != 0) return false;
   const int tw = N * MT / 128;
-  const size_t lds = ((size_t)4 * N * ld_of(C) + 2 * (N + 2) + 2 * N + 2 * C + 8) * sizeof(float);
+  const int ldb = C == 16 ? C : ld_of(C);
+  const size_t lds = ((size_t)2 * N * ld_of(C) + (size_t)2 * N * ldb + 2 * (N + 2) + 2 * N + 2 * C + 8) * sizeof(float);
   if (lds > 80 * 1024) return false;
   const int grid = B < 512 ? B : 512;
 #define GO(t) { RAL_SET_LDS((k_mlp_bwd_s<C, t>), lds); k_mlp_bwd_s<C, t><<<grid, 512, lds, s>>>(dx2, x1, upre, w, wt, gr, dx1, do_hm, N, B); return true; }
