@@ -3,6 +3,9 @@
 // vector gradients (biases, LayerNorm affines, LE taps, R-wave tables) are reduced
 // here in registers / LDS across the windows a workgroup owns and flushed with one
 // atomic per element per workgroup.
+#ifdef RAL_STAMP_TU_BWD
+#define RAL_STAMP_HERE
+#endif
 #include "ral_device.hpp"
 #include "ral_kernels.hpp"
 #include <stdlib.h>

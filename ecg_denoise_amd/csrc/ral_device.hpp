@@ -232,9 +232,10 @@ RAL_DEV void ln_stats(float4 v, float4& d, float& rstd) {
 }
 
 // ---------------------------------------------------------------------------------
-// Phase stamps (diagnostic builds only: `make STAMP=1`, tools/diag/stamp_kernel.py).  Thread 0 of workgroup 0 adds
+// Phase stamps (diagnostic builds only: `make STAMP=<name> STAMPTU=FWD|BWD|DW STAMPCOND='<expr>'`,
+// tools/diag/stamp_kernel.py; a translation unit opts in by defining RAL_STAMP_HERE before this header).  Thread 0 of workgroup 0 adds
 // the cycles since the previous stamp to slot i; the product library compiles these macros to nothing.
-#ifdef RAL_STAMP
+#if defined(RAL_STAMP) && defined(RAL_STAMP_HERE)
 // every translation unit has its own slot array; RAL_STAMPS_DEFINE(name) exports its accessor
 static __device__ unsigned long long g_ral_stamps[32];
 #define RAL_STAMPS_DEFINE(name)                                                                        \

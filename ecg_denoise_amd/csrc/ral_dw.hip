@@ -12,6 +12,9 @@
 // workgroup; two to three workgroups fit a CU.  The accumulators are added to the gradient buffer once at the
 // end (fp32 global atomics; a same-address atomic chain costs ~30 ns per link on MI355X, which is what bounds
 // the split-K count of the narrow levels).
+#ifdef RAL_STAMP_TU_DW
+#define RAL_STAMP_HERE
+#endif
 #include "ral_device.hpp"
 #include "ral_kernels.hpp"
 
@@ -100,9 +103,8 @@ __global__ __launch_bounds__(512, 4) void k_dw(const float* Y, const float* X, c
   // ---- producer: stage chunk ci into buf (256 threads, no barriers inside).  Straight-line code: indices past
   // the chunk are clamped rather than branched around (the duplicates rewrite identical values), because hipcc
   // waits for a conditional load on the spot and the whole point is to have every load of the chunk in flight.
-  // issue_then_store<> nests load(0) .. load(U-1), store(U-1) .. store(0) with every value an SSA local (register
-  // arrays indexed in unrolled loops end up in scratch here).
-  auto stage = [&](int ci, float* buf) {
+  struct Pack { float4 y[UY]; XLoad x[UX]; };   // the in-flight loads of one chunk (static indices only)
+  auto with_chunk = [&](int ci, float* buf, auto&& fn) {
     const int tid = threadIdx.x - 256;
     const int win = blockIdx.x + (ci / cpw) * gridDim.x, t0 = (ci % cpw) * TC;
     const float* Yw = Y + (size_t)win * N * M;
@@ -172,23 +174,49 @@ __global__ __launch_bounds__(512, 4) void k_dw(const float* Y, const float* X, c
         *reinterpret_cast<float4*>(Xs + row * LDX + c) = a;
       }
     };
-    // (the compiler barrier pins the loads above it -- otherwise they are sunk next to their stores, one HBM
-    // round trip each -- and the scheduling barrier keeps the machine scheduler from undoing that)
-    issue_then_store<0, UY>(load_y, store_y, [&] {
-      issue_then_store<0, UX>(load_x, store_x, [] {
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-      });
+    fn(load_y, store_y, load_x, store_x);
+  };
+  // issue(): request every load of chunk ci (nothing waits on them here).  The compiler barrier pins the loads
+  // above it -- otherwise they are sunk next to their stores, one HBM round trip each -- and the scheduling barrier
+  // keeps the machine scheduler from undoing that.
+  auto issue = [&](int ci, Pack& p) {
+    with_chunk(ci, buf0, [&](auto& load_y, auto&, auto& load_x, auto&) {
+#pragma unroll
+      for (int u = 0; u < UY; ++u) p.y[u] = load_y(u);
+#pragma unroll
+      for (int u = 0; u < UX; ++u) p.x[u] = load_x(u);
+    });
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // commit(): wait for the chunk's loads, transform, store into the LDS buffer
+  auto commit = [&](int ci, float* buf, const Pack& p) {
+    with_chunk(ci, buf, [&](auto&, auto& store_y, auto&, auto& store_x) {
+#pragma unroll
+      for (int u = 0; u < UX; ++u) store_x(u, p.x[u]);
+#pragma unroll
+      for (int u = 0; u < UY; ++u) store_y(u, p.y[u]);
     });
   };
 
   // The two roles run separate loops with matching barrier counts (the role is wave-uniform), so that the
   // accumulators are not live in the producer path and its loads are not squeezed by register pressure.
+  // The producer keeps the loads of the chunk after next in flight across the barrier: while the consumers work on
+  // chunk ci it commits chunk ci+1 (requested one iteration ago, normally already there) and requests chunk ci+2,
+  // so a chunk's HBM round trip overlaps a whole consumer phase instead of sitting in front of every barrier.
   if (producer) {
-    if (nci > 0) stage(0, buf0);
-    __syncthreads();
-    for (int ci = 0; ci < nci; ++ci) {
-      if (ci + 1 < nci) stage(ci + 1, (ci & 1) ? buf0 : buf1);
+    if (nci > 0) {
+      Pack p;
+      issue(0, p);
+      commit(0, buf0, p);
+      issue(nci > 1 ? 1 : 0, p);
+      __syncthreads();
+      for (int ci = 0; ci < nci; ++ci) {
+        if (ci + 1 < nci) commit(ci + 1, (ci & 1) ? buf0 : buf1, p);
+        issue(ci + 2 < nci ? ci + 2 : nci - 1, p);   // (past the end: a harmless re-read, no branch around the loads)
+        __syncthreads();
+      }
+    } else {
       __syncthreads();
     }
     if constexpr (KW > 1) __syncthreads();

@@ -5,6 +5,9 @@
 // Reference behaviour restated (see oracle/ralenet_oracle.py for the line map):
 //   TransformerBlock  model/raletransformer.py:383-410, model/transformer.py:289-323
 //   PatchMerging / PatchSeparate  model/raletransformer.py:411-459
+#ifdef RAL_STAMP_TU_FWD
+#define RAL_STAMP_HERE
+#endif
 #include "ral_device.hpp"
 #include "ral_kernels.hpp"
 #include <stdlib.h>

@@ -1,6 +1,7 @@
-"""Per-phase cycle shares of a stamped kernel (diagnostic).  Build: make -C ecg_denoise_amd/csrc STAMP=<C>;
-run on the GPU box: STAMP_C=<C> python tools/diag/stamp_kernel.py [fwd|bwd].  Slots are whatever RAL_STAMP_AT(i)
-calls the kernels of ral_bwd.hip currently carry (workgroup 0 of every launch of one training step)."""
+"""Per-phase cycle shares of a stamped kernel (diagnostic).  Build: make -C ecg_denoise_amd/csrc STAMP=<name>
+STAMPTU=FWD|BWD|DW [STAMPCOND='<expr>']; run on the GPU box: STAMP_C=<name> python tools/diag/stamp_kernel.py
+[fwd|bwd|dw].  Slots are whatever RAL_STAMP_AT(i) calls the stamped translation unit currently carries (thread 0 of
+workgroup 0 of every launch of one training step)."""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["RAL_LIB_PATH"] = os.path.join(ROOT, "tools", "diag", "libralenet_stamp%s.so" % os.environ.get("STAMP_C", "1"))
@@ -12,7 +13,8 @@ B = 2048
 m = RALENet("full", leads=1, L=512, max_batch=B, device="cuda:0", seed=1)
 x = torch.randn(B, 1, 512, device="cuda:0")
 lib = _lib.lib()
-fn = getattr(lib, "ral_debug_stamps_fwd" if (len(sys.argv) > 1 and sys.argv[1] == "fwd") else "ral_debug_stamps")
+tu = sys.argv[1] if len(sys.argv) > 1 else "bwd"
+fn = getattr(lib, {"fwd": "ral_debug_stamps_fwd", "bwd": "ral_debug_stamps", "dw": "ral_debug_stamps_dw"}[tu])
 fn.argtypes = [C.c_void_p, C.c_int]
 m.train()
 def step():
