@@ -63,6 +63,7 @@ _SIGS = {
     "ral_conv13_backward": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _VP]),
     "ral_adam_flat": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
                                 C.c_float, _VP]),
+    "ral_prep_windows": (C.c_int, [_VP, _VP, C.c_int64, C.c_int, C.c_int, C.c_double, _VP, _VP, _VP, _VP]),
     "ral_set_option": (C.c_int, [_VP, C.c_char_p, C.c_int]),
     "ral_profile_select": (C.c_int, [_VP, C.c_char_p]),
     "ral_profile_read": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -915,6 +915,15 @@ int ral_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, doubl
   return 0;
 }
 
+int ral_prep_windows(const float* sig, const float* noise, int64_t T, int leads, int L, double snr_db, double* sums,
+                     float* noisy, float* clean, ral_stream s) {
+  if (!sig || !noise || !sums || !noisy || !clean) return fail("prep_windows: null pointer");
+  if (launch_prep_windows(sig, noise, (long long)T, leads, L, snr_db, sums, noisy, clean, (hipStream_t)s))
+    return fail("prep_windows: need 1 <= leads <= 16 and T a positive multiple of L (T=%lld leads=%d L=%d)", (long long)T, leads, L);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
 int ral_debug_tensor(ral_handle* h, const char* name, float** ptr, int64_t* numel) {
   if (!h || h->kind != 0) return fail("no debug tensors for this handle");
   auto it = h->m->dbg.find(name);

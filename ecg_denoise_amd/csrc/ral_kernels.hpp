@@ -41,6 +41,8 @@ void launch_loss(const float* pred, const float* target, float* dy, float* snr, 
 void launch_adam(float* p, const float* g, float* m, float* v, size_t n, double lr, double b1, double b2, double eps,
                  int step, float gscale, hipStream_t s);
 
+int launch_prep_windows(const float* sig, const float* noise, long long T, int leads, int L, double snr_db, double* sums,
+                        float* noisy, float* clean, hipStream_t s);
 int launch_conv13_fwd(const float* x, const float* w, const float* b, float* y, int B, int cin, int cout, int L,
                       int lrelu, hipStream_t s);
 int launch_conv13_bwd(const float* x, const float* y, const float* dy, const float* w, float* gw, float* gb,

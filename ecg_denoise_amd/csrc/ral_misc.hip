@@ -410,3 +410,69 @@ void launch_transpose_mats(const float* src, float* dst, const void* desc, int n
   if (grid > 2048) grid = 2048;
   k_transpose_mats<<<grid, 256, 0, s>>>(src, dst, reinterpret_cast<const int4*>(desc), nmat);
 }
+
+// =================================================================================
+// Record windowing + noise mixing in front of the model: one iteration of the reference's
+// `batch_norm_snr_iter` (local_utils/local_utils.py:116-130) on the GPU --
+//   clean = np_norm(segment, dim=0)                (per-lead z-score over the whole segment, population std, :261-266)
+//   noisy = clean + sqrt(P_clean / 10^(snr/10) / P_noise) * noise      (`Gnoisegen`, :86-114)
+//   '(b l) c -> b c l' windows of L samples, fp32
+// Statistics are double sums (like the reference's float64 numpy arithmetic); the element-wise pass works in double and
+// rounds once, so outputs equal the reference's `torch.FloatTensor(...)` casts up to the summation order of the sums.
+// Both kernels are one HBM pass: (T, leads) row-major in, channel-major windows out.
+// =================================================================================
+#define RAL_PREP_MAXL 16
+__global__ __launch_bounds__(256) void k_prep_stats(const float* __restrict__ sig, const float* __restrict__ noise,
+                                                    long long T, int leads, double* __restrict__ sums) {
+  __shared__ double red[2 * RAL_PREP_MAXL + 1];
+  for (int i = threadIdx.x; i < 2 * leads + 1; i += blockDim.x) red[i] = 0.0;
+  __syncthreads();
+  double sx[RAL_PREP_MAXL], sxx[RAL_PREP_MAXL], snn = 0.0;
+#pragma unroll
+  for (int c = 0; c < RAL_PREP_MAXL; ++c) { sx[c] = 0.0; sxx[c] = 0.0; }
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < T; t += (long long)gridDim.x * blockDim.x) {
+#pragma unroll
+    for (int c = 0; c < RAL_PREP_MAXL; ++c) {
+      if (c < leads) {
+        const double x = sig[t * leads + c], n = noise[t * leads + c];
+        sx[c] += x; sxx[c] += x * x; snn += n * n;
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < RAL_PREP_MAXL; ++c) {
+    if (c < leads) { atomicAdd(&red[c], sx[c]); atomicAdd(&red[leads + c], sxx[c]); }
+  }
+  atomicAdd(&red[2 * leads], snn);
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * leads + 1; i += blockDim.x) atomicAdd(sums + i, red[i]);
+}
+
+__global__ __launch_bounds__(256) void k_prep_mix(const float* __restrict__ sig, const float* __restrict__ noise,
+                                                  const double* __restrict__ sums, long long T, int leads, int L,
+                                                  double snr_db, float* __restrict__ noisy, float* __restrict__ clean) {
+  // P_clean = sum(clean^2) / T = leads (every lead has unit population variance); P_noise = sum(noise^2) / T
+  const double scale = sqrt((double)leads / pow(10.0, snr_db / 10.0) / (sums[2 * leads] / (double)T));
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < T; t += (long long)gridDim.x * blockDim.x) {
+    const long long b = t / L;
+    const int l = (int)(t - b * L);
+    for (int c = 0; c < leads; ++c) {
+      const double mean = sums[c] / (double)T;
+      const double var = sums[leads + c] / (double)T - mean * mean;
+      const double xn = ((double)sig[t * leads + c] - mean) / sqrt(var);
+      const size_t o = ((size_t)b * leads + c) * L + l;
+      clean[o] = (float)xn;
+      noisy[o] = (float)(xn + scale * (double)noise[t * leads + c]);
+    }
+  }
+}
+
+int launch_prep_windows(const float* sig, const float* noise, long long T, int leads, int L, double snr_db, double* sums,
+                        float* noisy, float* clean, hipStream_t s) {
+  if (leads < 1 || leads > RAL_PREP_MAXL || L < 1 || T < L || T % L != 0) return -1;
+  (void)hipMemsetAsync(sums, 0, (2 * leads + 1) * sizeof(double), s);
+  const int grid = (int)((T + 255) / 256 < 2048 ? (T + 255) / 256 : 2048);
+  k_prep_stats<<<grid, 256, 0, s>>>(sig, noise, T, leads, sums);
+  k_prep_mix<<<grid, 256, 0, s>>>(sig, noise, sums, T, leads, L, snr_db, noisy, clean);
+  return 0;
+}

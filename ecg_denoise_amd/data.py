@@ -80,3 +80,53 @@ def write_synthetic_dataset(path, n=10000, leads=2, L=256, seed=2023, noise_type
             np.save(os.path.join(sub, nt + '.npy'), noisy)
     np.save(os.path.join(path, 'ecg.npy'), clean)
     return path
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Record iterators: the step in front of the model (reference local_utils/local_utils.py:116-130,
+# `batch_norm_snr_iter`), with the z-score, the SNR-scaled noise add and the windowing done on the GPU
+# (`ral_prep_windows`) instead of numpy + torch.FloatTensor + einops on the host.
+# ---------------------------------------------------------------------------------------------------------------
+def prep_windows(signal, noise, snr, L=256, stream=None):
+    """One `batch_norm_snr_iter` iteration after the file reads: `signal` and `noise` are (T, leads) device tensors
+    (ADC units; any float/int dtype), T a multiple of L.  Returns fp32 device tensors (noisy, clean), each
+    (T // L, leads, L): `clean` is the per-lead z-score of the segment (`np_norm(..., dim=0)`), `noisy` adds the noise
+    scaled to `snr` dB (`Gnoisegen`)."""
+    import torch
+    from . import _lib
+    if not signal.is_cuda or not noise.is_cuda:
+        raise _lib.RalError("prep_windows runs on the GPU: pass device tensors (there is no CPU fallback)")
+    sig = signal.to(torch.float32).contiguous()
+    noi = noise.to(torch.float32).contiguous()
+    if sig.dim() != 2 or sig.shape != noi.shape:
+        raise _lib.RalError(f"signal and noise must both be (T, leads); got {tuple(sig.shape)} and {tuple(noi.shape)}")
+    T, leads = sig.shape
+    if T % L:
+        raise _lib.RalError(f"segment length {T} is not a multiple of the window length {L}")
+    noisy = torch.empty(T // L, leads, L, dtype=torch.float32, device=sig.device)
+    clean = torch.empty_like(noisy)
+    sums = torch.empty(2 * leads + 1, dtype=torch.float64, device=sig.device)
+    s = stream if stream is not None else torch.cuda.current_stream(sig.device)
+    _lib.check(_lib.lib().ral_prep_windows(sig.data_ptr(), noi.data_ptr(), T, leads, L, float(snr), sums.data_ptr(),
+                                           noisy.data_ptr(), clean.data_ptr(), s.cuda_stream))
+    return noisy, clean
+
+
+def batch_norm_snr_iter(records, noise_record, batch_size, snr, L=256, rng=None, device="cuda:0"):
+    """Mirror of the reference generator of the same name (local_utils.py:116-130) over in-memory records: `records`
+    is an iterable of (650000, leads) arrays, `noise_record` one (>= 650000, leads) array; every full segment of
+    `L * batch_size` samples yields (noisy, clean) device tensors of shape (batch_size, leads, L).  The noise offset is
+    drawn like the reference's `random.randint(0, 650000 - len - 1)` from `rng` (a `random.Random`)."""
+    import random
+    import torch
+    rng = rng or random.Random()
+    noise_dev = torch.as_tensor(noise_record).to(device)
+    seg = L * batch_size
+    for rec in records:
+        rec_dev = torch.as_tensor(rec).to(device)
+        n = rec_dev.shape[0]
+        for i in range(0, n, seg):
+            if i + seg > n:
+                break
+            j = rng.randint(0, noise_dev.shape[0] - seg - 1)
+            yield prep_windows(rec_dev[i:i + seg], noise_dev[j:j + seg], snr, L)
