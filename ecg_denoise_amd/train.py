@@ -30,7 +30,7 @@ def train(epochs, model, batch_size, train_loader, test_loader, use_gpu=True, mo
     lr = kwargs.get("lr", 1e-3)
     if not use_gpu:
         raise RuntimeError("the RA-LENet path runs on a HIP device only (no CPU fallback)")
-    device = model.eng.device
+    device = model.eng.device if hasattr(model, "eng") else model.device      # NewRALE wraps an engine-backed model
     if model_path:
         model.load_state_dict(torch.load(model_path, map_location="cpu"))
     train_snr_list, test_snr_list, train_rmse_list, test_rmse_list = [], [], [], []

@@ -37,3 +37,34 @@ def test_newrale_matches_reference_golden(golden_dir):
     m.step()
     assert torch.equal(before, inner.eng.params)                             # frozen inner weights
     assert not torch.equal(m.params, torch.zeros_like(m.params))
+
+
+def test_transfer_learning_flow_end_to_end(tmp_path):
+    """Transfer_learning.py:71-80 with this package: pretrain the 2-lead RA-LENet with train() (checkpoint written in
+    the reference's file-name pattern), load that .pth into a fresh model, wrap it in newrale and train the 12-lead
+    adapter with the same train() harness: inner weights stay frozen, adapter weights move, the loss goes down."""
+    from ecg_denoise_amd import NewRALE, RALENet, synth
+    from ecg_denoise_amd.train import train
+    noisy, clean = synth.make_dataset(96, 2, 256, "emb", 0.0, seed=5)
+    bat = lambda a, b, bs: [(a[i:i + bs], b[i:i + bs]) for i in range(0, len(a), bs)]
+    pre = RALENet("full", leads=2, L=256, max_batch=32, device=DEV, seed=11)
+    train(epochs=10, model=pre, batch_size=32, train_loader=bat(noisy[:64], clean[:64], 32), test_loader=bat(noisy[64:], clean[64:], 32),
+          use_gpu=True, model_name="ralenet", noise_name="emb", noise_intensity=0, out_dir=str(tmp_path), log=lambda *_: None)
+    ckpt = tmp_path / "model_save" / "ralenet" / "ralenet_9_emb_intensity0.pth"
+    assert ckpt.exists()
+    pretrained = RALENet("full", leads=2, L=256, max_batch=8, device=DEV)
+    pretrained.load_state_dict(torch.load(ckpt))
+    model = NewRALE(pretrained, seed=3)
+    rng = np.random.default_rng(0)
+    c12 = np.stack([clean[i % 96, i % 2] for i in range(16 * 12)]).reshape(16, 12, 256).astype(np.float32)
+    n12 = (c12 + 0.3 * rng.standard_normal(c12.shape)).astype(np.float32)
+    inner_before = pretrained.eng.params.clone(); adapter_before = model.params.clone()
+    res = train(epochs=10, model=model, batch_size=8, train_loader=bat(n12[:8], c12[:8], 8), test_loader=bat(n12[8:], c12[8:], 8),
+                use_gpu=True, model_name="newrale", noise_name="emb", noise_intensity=0, out_dir=str(tmp_path), log=lambda *_: None)
+    assert torch.equal(inner_before, pretrained.eng.params)
+    assert not torch.equal(adapter_before, model.params)
+    tl, _ = train.last_losses
+    assert tl[-1] < tl[0]
+    assert len(res[1]) == 10 and all(np.isfinite(res[1]))
+    sd = torch.load(tmp_path / "model_save" / "newrale" / "newrale_9_emb_intensity0.pth")
+    assert "conv4.weight" in sd and "rale.dtransformer1.blocks.0.attn.qkv_proj.to_q.weight" in sd
