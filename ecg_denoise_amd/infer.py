@@ -80,13 +80,22 @@ class StreamingDenoiser:
             else:
                 out[i:i + chunk.shape[0]] = self.model(chunk.contiguous())
         out = out * sd + mu
+        # keep the centre of every window; the edges of the record keep the full window.  The sample -> (window,
+        # offset) map depends only on the record length: built once on the host, applied as one device gather
         T = rec.shape[-1]
-        y = torch.empty_like(rec)
-        h = self.overlap // 2
-        for k, s in enumerate(starts):     # keep the centre of every window; edges of the record keep the full window
-            a = 0 if k == 0 else h
-            b = self.L if k == len(starts) - 1 else self.L - h
-            if k == len(starts) - 1 and k > 0:
-                a = max(h, starts[k - 1] + self.L - h - s)
-            y[:, s + a:s + b] = out[k][:, a:b]
-        return y
+        src = self._stitch_map(T, starts, dev)
+        return out.permute(1, 0, 2).reshape(self.leads, -1)[:, src]
+
+    def _stitch_map(self, T, starts, dev):
+        cache = self.__dict__.setdefault("_maps", {})
+        if T not in cache:
+            idx = np.empty(T, dtype=np.int64)
+            h = self.overlap // 2
+            for k, s in enumerate(starts):
+                a = 0 if k == 0 else h
+                b = self.L if k == len(starts) - 1 else self.L - h
+                if k == len(starts) - 1 and k > 0:
+                    a = max(h, starts[k - 1] + self.L - h - s)
+                idx[s + a:s + b] = k * self.L + np.arange(a, b)
+            cache[T] = torch.as_tensor(idx, device=dev)
+        return cache[T]
