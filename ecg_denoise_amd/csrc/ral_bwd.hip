@@ -729,22 +729,34 @@ __global__ __launch_bounds__(256) void k_resample_bwd(const float* __restrict__ 
       *reinterpret_cast<float4*>(Dh + tok * LD + row0) = tofloat4(a);
     });
     __syncthreads();
-    for (int row = threadIdx.x / LPR; row < T; row += RPP) {
-      const size_t src = SEP ? wo + (size_t)(row % (T / 2)) * 2 * D + (row / (T / 2)) * D : wo + (size_t)row * D;
-      const float4 v = *reinterpret_cast<const float4*>(x + src + cq);
-      float4 d; float rstd;
-      ln_stats<LPR>(v, d, rstd);
-      const float4 xh = f4scale(d, rstd);
-      const float4 dh = *reinterpret_cast<const float4*>(Dh + row * LD + cq);
-      const float4 dyh = f4mul(dh, gam);
-      constexpr float invD = 1.0f / D;
-      const float m1 = group_sum<LPR>(f4hsum(dyh)) * invD;
-      const float m2 = group_sum<LPR>(f4dot(dyh, xh)) * invD;
-      *reinterpret_cast<float4*>(dx + src + cq) =
-          make_float4(rstd * (dyh.x - m1 - xh.x * m2), rstd * (dyh.y - m1 - xh.y * m2),
-                      rstd * (dyh.z - m1 - xh.z * m2), rstd * (dyh.w - m1 - xh.w * m2));
-      dgam = f4add(dgam, f4mul(dh, xh));
-      dbet = f4add(dbet, dh);
+    // LayerNorm backward, four rows per thread with their x loads in flight together (one HBM round trip, not four)
+    for (int row0 = threadIdx.x / LPR; row0 < T; row0 += 4 * RPP) {
+      float4 v4[4]; size_t src4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int row = min(row0 + u * RPP, T - 1);
+        src4[u] = SEP ? wo + (size_t)(row % (T / 2)) * 2 * D + (row / (T / 2)) * D : wo + (size_t)row * D;
+        v4[u] = *reinterpret_cast<const float4*>(x + src4[u] + cq);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int row = row0 + u * RPP;
+        float4 d; float rstd;
+        ln_stats<LPR>(v4[u], d, rstd);
+        if (row < T) {
+          const float4 xh = f4scale(d, rstd);
+          const float4 dh = *reinterpret_cast<const float4*>(Dh + row * LD + cq);
+          const float4 dyh = f4mul(dh, gam);
+          constexpr float invD = 1.0f / D;
+          const float m1 = group_sum<LPR>(f4hsum(dyh)) * invD;
+          const float m2 = group_sum<LPR>(f4dot(dyh, xh)) * invD;
+          *reinterpret_cast<float4*>(dx + src4[u] + cq) =
+              make_float4(rstd * (dyh.x - m1 - xh.x * m2), rstd * (dyh.y - m1 - xh.y * m2),
+                          rstd * (dyh.z - m1 - xh.z * m2), rstd * (dyh.w - m1 - xh.w * m2));
+          dgam = f4add(dgam, f4mul(dh, xh));
+          dbet = f4add(dbet, dh);
+        }
+      }
     }
     __syncthreads();
   }
