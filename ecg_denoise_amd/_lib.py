@@ -57,6 +57,8 @@ _SIGS = {
     "ral_backward": (C.c_int, [_VP, _VP, _VP, C.c_int, _VP]),
     "ral_backward_begin": (C.c_int, [_VP, _VP, C.c_int, _VP]),
     "ral_backward_end": (C.c_int, [_VP, _VP, C.c_int, C.c_int64, _VP]),
+    "ral_grad_bucket": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "ral_grad_bucket_wait": (C.c_int, [_VP, C.c_int, _VP]),
     "ral_adam_step": (C.c_int, [_VP, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_float, _VP]),
     "ral_debug_tensor": (C.c_int, [_VP, C.c_char_p, C.POINTER(_VP), C.POINTER(C.c_int64)]),
     "ral_conv13_forward": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _VP]),

@@ -55,6 +55,7 @@ struct ResOff { int64_t w, lnw, lnb; int D; };
 struct Layout {
   std::vector<Entry> entries;
   int64_t nparam = 0, nstate = 0;
+  int64_t dec_off = 0;   // first float of the decoder's parameters (utransformer4 .. transconv are contiguous up to nparam)
   int64_t conv1_w, conv1_b, bn_w, bn_b, tc_w, tc_b;
   int64_t rw[4] = {-1, -1, -1, -1};
   BlockOff blk[18];
@@ -154,6 +155,9 @@ static bool build_layout(const ral_config& c, Layout& L) {
   push(L, "transconv.0.weight", RAL_PARAM, L.tc_w, {ld, 8, 3});
   push(L, "transconv.0.bias", RAL_PARAM, L.tc_b, {ld});
   L.nparam = cur;
+  L.dec_off = cur;
+  for (const Entry& e : L.entries)
+    if (e.kind == RAL_PARAM && e.name.rfind("utransformer4.", 0) == 0 && e.offset < L.dec_off) L.dec_off = e.offset;
   return true;
 }
 
@@ -208,6 +212,8 @@ struct RalModel {
   void* lanes = nullptr;   // LaneSet
   int n_lanes = 2;
   bool side_stream = true;
+  int dec_lanes = 0; bool dec_side = false;   // lanes / side streams that carried the last backward (bucket events)
+  hipEvent_t ev_bwd_done = nullptr;          // recorded at the end of ral_backward_end
   float* paramsT = nullptr;   // transposed copies of the weight matrices (same offsets), refreshed per backward
   void* tdesc = nullptr; int tn = 0, ttotal = 0;
   const float* last_x = nullptr;
@@ -349,6 +355,7 @@ struct Lane {
   int w0 = 0, B = 0;
   hipStream_t s = nullptr, s2 = nullptr;     // chain stream, weight-gradient side stream
   hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}, ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_dec_main = nullptr, ev_dec_side = nullptr;   // decoder half of the gradients complete (this lane)
   bool dw_pending[2] = {false, false};
   int bwd_count = 0;
 };
@@ -586,6 +593,10 @@ static int bwd_begin(RalModel* m, const float* dy, int B, hipStream_t s) {
   EACH_LANE(run_stage_bwd(m, 6, gy[13], nullptr, gy[12], gin[6], ln))          // g u3
   EACH_LANE(run_res_bwd(m, 4, gin[6], m->act[11].out, gy[11], ln))
   EACH_LANE(run_stage_bwd(m, 5, gy[11], nullptr, gy[10], gin[5], ln))          // g x_mid
+  // the decoder's parameters (utransformer4 .. transconv: the upper half of the flat gradient buffer) have their
+  // final gradients once every lane's chain and weight-gradient stream pass this point: gradient bucket 1
+  EACH_LANE((void)hipEventRecord(ln.ev_dec_main, ln.s); if (m->side_stream) (void)hipEventRecord(ln.ev_dec_side, ln.s2);)
+  m->dec_lanes = nl; m->dec_side = m->side_stream;
   EACH_LANE(run_stage_bwd(m, 4, gin[5], gin[5], gy[8], gin[4], ln))            // g p4 = transformer^T(g x_mid) + g x_mid
   // encoder: pm_k <- stage, skip gradients added by the first block of each stage
   EACH_LANE(run_res_bwd(m, 3, gin[4], m->act[7].out, gy[7], ln))
@@ -615,6 +626,8 @@ static int bwd_end(RalModel* m, float* dx, int B, int64_t global_windows, hipStr
                    m->L, B, s);
   launch_bn_affine_grads(m->bn_sums + 32, m->grads + Y.bn_w, m->grads + Y.bn_b, 8, (double)B / (double)global_windows, s);
   if (dx) launch_conv1_bwd_dx(m->cfg.leads, m->dz0, m->params + Y.conv1_w, dx, m->L, B, s);
+  if (!m->ev_bwd_done) (void)hipEventCreateWithFlags(&m->ev_bwd_done, hipEventDisableTiming);
+  (void)hipEventRecord(m->ev_bwd_done, s);
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -731,6 +744,8 @@ int ral_create(const ral_config* cfg, ral_handle** out) {
       }
       (void)hipEventCreateWithFlags(&ln.ev_fork, hipEventDisableTiming);
       (void)hipEventCreateWithFlags(&ln.ev_join, hipEventDisableTiming);
+      (void)hipEventCreateWithFlags(&ln.ev_dec_main, hipEventDisableTiming);
+      (void)hipEventCreateWithFlags(&ln.ev_dec_side, hipEventDisableTiming);
     }
   }
   for (int l = 0; l < 5; ++l) {
@@ -835,6 +850,35 @@ int ral_backward_end(ral_handle* h, float* dx, int B, int64_t global_windows, ra
   if (!h) return fail("null handle");
   if (h->kind == 1) return fail("U-Net: use ral_backward");
   return bwd_end(h->m, dx, B, global_windows, (hipStream_t)s);
+}
+
+int ral_grad_bucket(ral_handle* h, int k, int64_t* offset, int64_t* count) {
+  if (!h || h->kind == 1) return fail("gradient buckets: RA-LENet handles only");
+  if (k < 0 || k > 1 || !offset || !count) return fail("gradient bucket index must be 0 or 1");
+  const Layout& Y = h->m->lay;
+  *offset = k == 0 ? 0 : Y.dec_off;
+  *count = k == 0 ? Y.dec_off : Y.nparam - Y.dec_off;
+  return 0;
+}
+
+int ral_grad_bucket_wait(ral_handle* h, int k, ral_stream s) {
+  if (!h || h->kind == 1) return fail("gradient buckets: RA-LENet handles only");
+  RalModel* m = h->m;
+  if (k == 1) {
+    if (m->dec_lanes <= 0) return fail("bucket 1 is available after ral_backward_begin");
+    LaneSet* LS = lanes_of(m);
+    for (int i = 0; i < m->dec_lanes; ++i) {
+      HIP_OK(hipStreamWaitEvent((hipStream_t)s, LS->l[i].ev_dec_main, 0));
+      if (m->dec_side) HIP_OK(hipStreamWaitEvent((hipStream_t)s, LS->l[i].ev_dec_side, 0));
+    }
+    return 0;
+  }
+  if (k == 0) {
+    if (!m->ev_bwd_done) return fail("bucket 0 is available after ral_backward_end");
+    HIP_OK(hipStreamWaitEvent((hipStream_t)s, m->ev_bwd_done, 0));
+    return 0;
+  }
+  return fail("gradient bucket index must be 0 or 1");
 }
 
 int ral_backward(ral_handle* h, const float* dy, float* dx, int B, ral_stream s) {

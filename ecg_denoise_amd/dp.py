@@ -4,7 +4,10 @@ global batch sharded evenly, parameters / Adam state replicated.
 Collectives per step (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm):
   1. BatchNorm forward sums   (16 doubles)   -> exact global-batch statistics (sync-BN)
   2. BatchNorm backward sums  (16 doubles)
-  3. flat gradient buffer     (4.35 MB fp32, one bucket: latency- not bandwidth-bound)
+  3. flat gradient buffer     (4.35 MB fp32) in two buckets: the decoder half (utransformer4 .. transconv) is
+     final about half-way through the backward pass and is all-reduced on a side stream WHILE the bottleneck and
+     encoder backward kernels run (`ral_grad_bucket` / `ral_grad_bucket_wait`); the other half follows the stem
+  4. the scalar loss (reporting only)
 No collective touches activations; inference needs none (replicas).
 
 The trainer only sequences engine calls and collectives, so it is testable on CPU with
@@ -51,6 +54,26 @@ class HipEngineAdapter:
     def adam(self, lr):
         self.m.step(lr)
 
+    # ---- gradient buckets (overlap of the all-reduce with the backward pass) ----
+    def grad_buckets(self):
+        """[(offset, count)] of bucket 0 (final after backward_end) and bucket 1 (final inside backward_begin)"""
+        C = self._C
+        out = []
+        for k in (0, 1):
+            off, cnt = C.c_int64(), C.c_int64()
+            self._lib.check(self._lib.lib().ral_grad_bucket(self.m.eng.h, k, C.byref(off), C.byref(cnt)))
+            out.append((off.value, cnt.value))
+        return out
+
+    def bucket_stream(self):
+        if getattr(self, "_comm", None) is None:
+            self._comm = torch.cuda.Stream(device=self.m.eng.device)
+        return self._comm
+
+    def bucket_wait(self, k, stream):
+        """make `stream` wait until bucket k holds its final gradients (call after the engine call producing it)"""
+        self._lib.check(self._lib.lib().ral_grad_bucket_wait(self.m.eng.h, k, stream.cuda_stream))
+
 
 class DataParallelTrainer:
     def __init__(self, engine, group=None, sync_bn=True):
@@ -72,10 +95,26 @@ class DataParallelTrainer:
         pred = e.forward_end(G if self.sync_bn else B)
         loss, snr, rmse = e.loss(pred, target_local, G)
         e.backward_begin()
+        early = None
+        if self.world > 1 and hasattr(e, "grad_buckets"):
+            # decoder half of the gradients: all-reduced on the engine's communication stream, which only waits
+            # for the kernels that write it, so the collective runs under the rest of the backward pass
+            (o0, n0), (o1, n1) = e.grad_buckets()
+            comm = e.bucket_stream()
+            e.bucket_wait(1, comm)
+            if comm is not None:
+                with torch.cuda.stream(comm):
+                    early = dist.all_reduce(e.grads[o1:o1 + n1], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            else:
+                early = dist.all_reduce(e.grads[o1:o1 + n1], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         if self.sync_bn:
             self._allreduce(e.bn_sums[32:64])
         e.backward_end(G if self.sync_bn else B)
-        self._allreduce(e.grads)          # dy already carries 1/G: the sum IS the global-mean gradient
+        if early is not None:
+            self._allreduce(e.grads[o0:o0 + n0])
+            early.wait()                  # the current stream waits for the early bucket
+        else:
+            self._allreduce(e.grads)      # dy already carries 1/G: the sum IS the global-mean gradient
         e.adam(lr)
         loss = loss.clone()
         self._allreduce(loss)             # sum of local (sse/n)/G -> global mean

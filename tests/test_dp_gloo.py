@@ -63,6 +63,23 @@ class OracleEngine:
         self.gx0 = gs[0]
         self.gdict = {k: (g if g is not None else torch.zeros_like(self.leaf[k])) for k, g in zip(names, gs[1:])}
         self.bn_sums[32:40] = self.gx0.sum((0, 2)); self.bn_sums[40:48] = (self.gx0 * self.xhat).sum((0, 2))
+        # like the C ABI: the decoder half of the flat gradient buffer is final here (gradient bucket 1)
+        o1 = self.grad_buckets()[1][0]
+        self.grads[o1:] = torch.cat([self.gdict[k].reshape(-1) for k in self._decoder_keys()])
+
+    def _decoder_keys(self):
+        ks = list(self.p)
+        return ks[next(i for i, k in enumerate(ks) if k.startswith("utransformer4.")):]
+
+    def grad_buckets(self):
+        o1 = sum(v.numel() for k, v in self.p.items() if k not in set(self._decoder_keys()))
+        return [(0, o1), (o1, self.grads.numel() - o1)]
+
+    def bucket_stream(self):
+        return None          # CPU: no streams; the early all-reduce is still issued asynchronously
+
+    def bucket_wait(self, k, stream):
+        pass
 
     def backward_end(self, G):
         gam = self.p["conv1.2.weight"]
@@ -75,7 +92,9 @@ class OracleEngine:
         w = dist.get_world_size() if dist.is_initialized() else 1
         self.gdict["conv1.2.weight"] = self.bn_sums[40:48].clone() / w
         self.gdict["conv1.2.bias"] = self.bn_sums[32:40].clone() / w
-        self.grads.copy_(torch.cat([self.gdict[k].reshape(-1) for k in self.p]))
+        dec = set(self._decoder_keys())     # bucket 0 only: bucket 1 may already have been all-reduced
+        o1 = self.grad_buckets()[1][0]
+        self.grads[:o1] = torch.cat([self.gdict[k].reshape(-1) for k in self.p if k not in dec])
 
     def adam(self, lr):
         self.step += 1
