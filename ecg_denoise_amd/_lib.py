@@ -57,6 +57,12 @@ _SIGS = {
     "ral_backward": (C.c_int, [_VP, _VP, _VP, C.c_int, _VP]),
     "ral_backward_begin": (C.c_int, [_VP, _VP, C.c_int, _VP]),
     "ral_backward_end": (C.c_int, [_VP, _VP, C.c_int, C.c_int64, _VP]),
+    "ral_unet_stage_bn": (C.c_int, [C.c_int]),
+    "ral_unet_forward_stage": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int64, _VP]),
+    "ral_unet_forward_finish": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int64, _VP]),
+    "ral_unet_backward_start": (C.c_int, [_VP, _VP, C.c_int, C.c_int64, _VP]),
+    "ral_unet_backward_stage": (C.c_int, [_VP, C.c_int, C.c_int, C.c_int64, _VP]),
+    "ral_unet_backward_finish": (C.c_int, [_VP, C.c_int, C.c_int64, _VP]),
     "ral_grad_bucket": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "ral_grad_bucket_wait": (C.c_int, [_VP, C.c_int, _VP]),
     "ral_adam_step": (C.c_int, [_VP, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_float, _VP]),

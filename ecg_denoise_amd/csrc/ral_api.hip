@@ -852,6 +852,31 @@ int ral_backward_end(ral_handle* h, float* dx, int B, int64_t global_windows, ra
   return bwd_end(h->m, dx, B, global_windows, (hipStream_t)s);
 }
 
+// ---- U-Net, one stage at a time (sync-BatchNorm under data parallelism) ----
+int ral_unet_stage_bn(int si) { return unet_stage_bn(si); }
+#define UNET_ONLY if (!h) return fail("null handle"); if (h->kind != 1) return fail("U-Net handles only")
+int ral_unet_forward_stage(ral_handle* h, const float* x, int B, int training, int si, int64_t global_windows, ral_stream s) {
+  UNET_ONLY;
+  return unet_forward_stage(h->u, x, B, training, si, global_windows, (hipStream_t)s, g_err, sizeof(g_err));
+}
+int ral_unet_forward_finish(ral_handle* h, float* y, int B, int training, int64_t global_windows, ral_stream s) {
+  UNET_ONLY;
+  return unet_forward_finish(h->u, y, B, training, global_windows, (hipStream_t)s, g_err, sizeof(g_err));
+}
+int ral_unet_backward_start(ral_handle* h, const float* dy, int B, int64_t global_windows, ral_stream s) {
+  UNET_ONLY;
+  return unet_backward_start(h->u, dy, B, global_windows, (hipStream_t)s, g_err, sizeof(g_err));
+}
+int ral_unet_backward_stage(ral_handle* h, int B, int si, int64_t global_windows, ral_stream s) {
+  UNET_ONLY;
+  return unet_backward_stage(h->u, B, si, global_windows, (hipStream_t)s, g_err, sizeof(g_err));
+}
+int ral_unet_backward_finish(ral_handle* h, int B, int64_t global_windows, ral_stream s) {
+  UNET_ONLY;
+  return unet_backward_finish(h->u, B, global_windows, (hipStream_t)s, g_err, sizeof(g_err));
+}
+#undef UNET_ONLY
+
 int ral_grad_bucket(ral_handle* h, int k, int64_t* offset, int64_t* count) {
   if (!h || h->kind == 1) return fail("gradient buckets: RA-LENet handles only");
   if (k < 0 || k > 1 || !offset || !count) return fail("gradient bucket index must be 0 or 1");

@@ -690,10 +690,12 @@ __global__ __launch_bounds__(256) void k_unet_bwd_t(Stage st, int B) {
 // BatchNorm affine gradients of all layers from the backward sums: g_gamma = S2, g_beta = S1
 struct BnGrad { const double* bsums; float* gw; float* gb; int C; };
 struct BnGradAll { BnGrad l[10]; };
-__global__ void k_unet_bn_grads(BnGradAll u) {
+// `share` = local / global windows: under data parallelism the sums are global and the later gradient all-reduce adds
+// the ranks' copies, so each rank contributes its share
+__global__ void k_unet_bn_grads(BnGradAll u, double share) {
   const BnGrad& b = u.l[blockIdx.x];
   const int c = threadIdx.x;
-  if (c < b.C) { b.gb[c] = (float)b.bsums[c]; b.gw[c] = (float)b.bsums[MAXC + c]; }
+  if (c < b.C) { b.gb[c] = (float)(b.bsums[c] * share); b.gw[c] = (float)(b.bsums[MAXC + c] * share); }
 }
 
 // =================================================================================
@@ -856,12 +858,12 @@ static size_t bwd_lds(const Stage& s) {
 }
 
 // stage table: index 0-3 enc, 4-6 bottleneck, 7-10 dec
-static Stage make_stage(UNetModel* m, int si, const float* x, bool training, bool bwd, int B) {
+static Stage make_stage(UNetModel* m, int si, const float* x, bool training, bool bwd, int B, double gwin) {
   const ral_config& c = m->pub.cfg;
   const UNetPublic& P = m->pub;
   const ULayout& Y = m->lay;
   Stage s; memset(&s, 0, sizeof(s));
-  const double cnt = (double)B;
+  const double cnt = gwin;   // windows behind every BatchNorm statistic: B, or the global batch under data parallelism
   auto cnt_of = [&](int zi) { return cnt * m->Ln[zi]; };
   s.w = P.params + Y.w[si]; s.bias = P.params + Y.b[si];
   s.out = m->z[si]; s.cout = m->C[si]; s.lout = m->Ln[si];
@@ -929,35 +931,52 @@ static bool launch_unet_fwd_fast(const Stage& st, int si, int leads, int B, int 
   return false;
 }
 
-int unet_forward(UNetModel* m, const float* x, float* y, int B, int training, hipStream_t s, char* err, size_t cap) {
+// ---- forward, one stage at a time (a data-parallel caller all-reduces the stage's BatchNorm sums in between) ----
+int unet_forward_stage(UNetModel* m, const float* x, int B, int training, int si, int64_t gwin, hipStream_t s, char* err, size_t cap) {
   UNetPublic& P = m->pub;
   if (!P.params || !P.state) { snprintf(err, cap, "ral_bind was not called"); return -1; }
   if (B <= 0 || B > P.cfg.max_batch) { snprintf(err, cap, "batch %d outside (0, %d]", B, P.cfg.max_batch); return -1; }
+  if (si < 0 || si > 10) { snprintf(err, cap, "U-Net stage %d outside [0, 10]", si); return -1; }
   if (training && (!P.cfg.train || !P.bn_sums)) { snprintf(err, cap, "training forward needs train=1 and bn_sums"); return -1; }
-  m->last_x = x; m->last_B = B;
-  if (training) (void)hipMemsetAsync(P.bn_sums, 0, 1280 * sizeof(double), s);
+  if (si == 0) {
+    m->last_x = x; m->last_B = B;
+    if (training) (void)hipMemsetAsync(P.bn_sums, 0, 1280 * sizeof(double), s);
+  } else if (x != m->last_x || B != m->last_B) { snprintf(err, cap, "U-Net stages must follow stage 0 of the same batch"); return -1; }
   const int grid = B < 1024 ? B : 1024;
-  for (int si = 0; si < 11; ++si) {
-    Stage st = make_stage(m, si, x, training != 0, false, B);
-    if (!training) st.sums_out = nullptr;
-    if (!launch_unet_fwd_fast(st, si, P.cfg.leads, B, grid, s)) k_unet_fwd<<<grid, 256, fwd_lds(st), s>>>(st, B);
-  }
+  Stage st = make_stage(m, si, x, training != 0, false, B, (double)gwin);
+  if (!training) st.sums_out = nullptr;
+  if (!launch_unet_fwd_fast(st, si, P.cfg.leads, B, grid, s)) k_unet_fwd<<<grid, 256, fwd_lds(st), s>>>(st, B);
+  if (hipGetLastError() != hipSuccess) { snprintf(err, cap, "U-Net forward launch failed"); return -1; }
+  return 0;
+}
+
+int unet_forward_finish(UNetModel* m, float* y, int B, int training, int64_t gwin, hipStream_t s, char* err, size_t cap) {
+  UNetPublic& P = m->pub;
+  if (B != m->last_B) { snprintf(err, cap, "finish batch %d != stage batch %d", B, m->last_B); return -1; }
   Src o = make_src(m, 10, ACT_NONE, training != 0, false, 0);
   const size_t total = (size_t)B * m->C[10] * m->Ln[10];
   k_unet_out<<<(int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048), 256, 0, s>>>(o, y, m->C[10], m->Ln[10],
-                                                                                          (double)B * m->Ln[10], total);
+                                                                                          (double)gwin * m->Ln[10], total);
   if (training) {
     BnUpdAll u;
     for (int zi = 0, k = 0; zi < 11; ++zi) {
       const int bi = BN_OF_Z[zi];
       if (bi < 0) continue;
-      u.l[k++] = BnUpd{P.bn_sums + 128 * bi, P.state + m->lay.run[bi], m->C[zi], (double)B * m->Ln[zi]};
+      u.l[k++] = BnUpd{P.bn_sums + 128 * bi, P.state + m->lay.run[bi], m->C[zi], (double)gwin * m->Ln[zi]};
     }
     k_unet_running<<<10, MAXC, 0, s>>>(u);
   }
   if (hipGetLastError() != hipSuccess) { snprintf(err, cap, "U-Net forward launch failed"); return -1; }
   return 0;
 }
+
+int unet_forward(UNetModel* m, const float* x, float* y, int B, int training, hipStream_t s, char* err, size_t cap) {
+  for (int si = 0; si < 11; ++si)
+    if (unet_forward_stage(m, x, B, training, si, B, s, err, cap)) return -1;
+  return unet_forward_finish(m, y, B, training, B, s, err, cap);
+}
+
+int unet_stage_bn(int si) { return (si >= 0 && si <= 10) ? BN_OF_Z[si] : -1; }
 
 
 template <int CIN, int COUT, int KS, int MODE>
@@ -985,11 +1004,12 @@ static bool launch_unet_bwd_fast(const Stage& st, int si, int leads, int B, int 
   return false;
 }
 
-int unet_backward(UNetModel* m, const float* dy, float* dx, int B, hipStream_t s, char* err, size_t cap) {
+// ---- backward, one stage at a time: stage si needs the BatchNorm-backward sums of ITS OUTPUT's BatchNorm, which
+// the backward of its consumers (stages > si, and unet_backward_start for the last layer) has accumulated ----
+int unet_backward_start(UNetModel* m, const float* dy, int B, int64_t gwin, hipStream_t s, char* err, size_t cap) {
   UNetPublic& P = m->pub;
   if (!P.cfg.train || !P.grads || !P.bn_sums) { snprintf(err, cap, "backward needs train=1, grads and bn_sums bound"); return -1; }
   if (B != m->last_B) { snprintf(err, cap, "backward batch %d != forward batch %d", B, m->last_B); return -1; }
-  if (dx) { snprintf(err, cap, "U-Net input gradient is not provided"); return -1; }
   (void)hipMemsetAsync(P.grads, 0, (size_t)m->lay.nparam * sizeof(float), s);
   for (int bi = 0; bi < 10; ++bi) (void)hipMemsetAsync(P.bn_sums + 128 * bi + 64, 0, 64 * sizeof(double), s);
   // last layer: gradient at BN9's output is dy itself
@@ -997,22 +1017,42 @@ int unet_backward(UNetModel* m, const float* dy, float* dx, int B, hipStream_t s
   (void)hipMemcpyAsync(m->G[10], dy, total * sizeof(float), hipMemcpyDeviceToDevice, s);
   Src o = make_src(m, 10, ACT_NONE, true, false, 0);
   k_unet_gsums<<<(int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024), 256, 0, s>>>(
-      dy, o, m->C[10], m->Ln[10], (double)B * m->Ln[10], P.bn_sums + 128 * 9 + 64, total);
+      dy, o, m->C[10], m->Ln[10], (double)gwin * m->Ln[10], P.bn_sums + 128 * 9 + 64, total);
+  if (hipGetLastError() != hipSuccess) { snprintf(err, cap, "U-Net backward launch failed"); return -1; }
+  return 0;
+}
+
+int unet_backward_stage(UNetModel* m, int B, int si, int64_t gwin, hipStream_t s, char* err, size_t cap) {
+  UNetPublic& P = m->pub;
+  if (B != m->last_B) { snprintf(err, cap, "backward batch %d != forward batch %d", B, m->last_B); return -1; }
+  if (si < 0 || si > 10) { snprintf(err, cap, "U-Net stage %d outside [0, 10]", si); return -1; }
   const int grid = B < 1024 ? B : 1024;
   // consumers run in reverse order; an encoder tensor's gradient is first WRITTEN by its decoder-side consumer
   // (skip / residual, accumulate = 0) and later ACCUMULATED by the next encoder / bottleneck stage (accumulate = 1)
-  for (int si = 10; si >= 0; --si) {
-    Stage st = make_stage(m, si, m->last_x, true, true, B);
-    if (si == 0) { st.a.G = nullptr; }
-    const size_t lds = bwd_lds(st);
-    static size_t cur = 0;
-    if (lds > cur) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_unet_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); cur = lds; }
-    if (!launch_unet_bwd_fast(st, si, P.cfg.leads, B, grid, s)) k_unet_bwd<<<grid, 256, lds, s>>>(st, B);
-  }
+  Stage st = make_stage(m, si, m->last_x, true, true, B, (double)gwin);
+  if (si == 0) { st.a.G = nullptr; }
+  const size_t lds = bwd_lds(st);
+  static size_t cur = 0;
+  if (lds > cur) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_unet_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); cur = lds; }
+  if (!launch_unet_bwd_fast(st, si, P.cfg.leads, B, grid, s)) k_unet_bwd<<<grid, 256, lds, s>>>(st, B);
+  if (hipGetLastError() != hipSuccess) { snprintf(err, cap, "U-Net backward launch failed"); return -1; }
+  return 0;
+}
+
+int unet_backward_finish(UNetModel* m, int B, int64_t gwin, hipStream_t s, char* err, size_t cap) {
+  UNetPublic& P = m->pub;
   BnGradAll u;
   for (int bi = 0; bi < 10; ++bi)
     u.l[bi] = BnGrad{P.bn_sums + 128 * bi + 64, P.grads + m->lay.bnw[bi], P.grads + m->lay.bnb[bi], m->lay.bnC[bi]};
-  k_unet_bn_grads<<<10, MAXC, 0, s>>>(u);
+  k_unet_bn_grads<<<10, MAXC, 0, s>>>(u, (double)B / (double)gwin);
   if (hipGetLastError() != hipSuccess) { snprintf(err, cap, "U-Net backward launch failed"); return -1; }
   return 0;
+}
+
+int unet_backward(UNetModel* m, const float* dy, float* dx, int B, hipStream_t s, char* err, size_t cap) {
+  if (dx) { snprintf(err, cap, "U-Net input gradient is not provided"); return -1; }
+  if (unet_backward_start(m, dy, B, B, s, err, cap)) return -1;
+  for (int si = 10; si >= 0; --si)
+    if (unet_backward_stage(m, B, si, B, s, err, cap)) return -1;
+  return unet_backward_finish(m, B, B, s, err, cap);
 }

@@ -24,4 +24,11 @@ void unet_destroy(UNetModel* u);
 int unet_bind(UNetModel* u, float* params, float* grads, float* am, float* av, float* state, double* bn_sums);
 int unet_forward(UNetModel* u, const float* x, float* y, int B, int training, hipStream_t s, char* err, size_t cap);
 int unet_backward(UNetModel* u, const float* dy, float* dx, int B, hipStream_t s, char* err, size_t cap);
+// staged execution (data-parallel sync-BatchNorm): gwin = windows of the global batch
+int unet_forward_stage(UNetModel* u, const float* x, int B, int training, int si, int64_t gwin, hipStream_t s, char* err, size_t cap);
+int unet_forward_finish(UNetModel* u, float* y, int B, int training, int64_t gwin, hipStream_t s, char* err, size_t cap);
+int unet_backward_start(UNetModel* u, const float* dy, int B, int64_t gwin, hipStream_t s, char* err, size_t cap);
+int unet_backward_stage(UNetModel* u, int B, int si, int64_t gwin, hipStream_t s, char* err, size_t cap);
+int unet_backward_finish(UNetModel* u, int B, int64_t gwin, hipStream_t s, char* err, size_t cap);
+int unet_stage_bn(int si);
 UNetPublic* unet_public(UNetModel* u);

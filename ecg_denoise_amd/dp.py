@@ -9,6 +9,8 @@ Collectives per step (torch.distributed; backend "nccl" is RCCL over xGMI on ROC
      encoder backward kernels run (`ral_grad_bucket` / `ral_grad_bucket_wait`); the other half follows the stem
   4. the scalar loss (reporting only)
 No collective touches activations; inference needs none (replicas).
+U-Net (a BatchNorm after every conv): `UNetEngineAdapter` cuts the step at every layer, 10 + 10 reductions of 64
+doubles per step, for exact global-batch statistics.
 
 The trainer only sequences engine calls and collectives, so it is testable on CPU with
 `gloo` and any engine exposing the same methods (tests/test_dp_gloo.py).
@@ -75,6 +77,54 @@ class HipEngineAdapter:
         self._lib.check(self._lib.lib().ral_grad_bucket_wait(self.m.eng.h, k, stream.cuda_stream))
 
 
+class UNetEngineAdapter:
+    """U-Net under data parallelism with exact global-batch BatchNorm: the model has a BatchNorm after every conv
+    (UNet.py:46-141), so the step is cut at every layer.  `forward_iter` / `backward_iter` run one stage per
+    iteration and yield the slice of `bn_sums` (64 doubles) that must be summed over the ranks before the next
+    stage may run; the trainer all-reduces whatever is yielded."""
+
+    def __init__(self, model):
+        import ctypes as C
+        from . import _lib
+        from .model import _ptr, _stream
+        self.m, self._lib, self._ptr, self._stream, self._C = model, _lib, _ptr, _stream, C
+        self.bn_sums = model.eng.bn_sums
+        self.grads = model.eng.grads
+        self.pred = None
+
+    def forward_iter(self, x, global_windows):
+        L, h = self._lib.lib(), self.m.eng.h
+        self.x = x.contiguous()
+        B = x.shape[0]
+        for si in range(11):
+            self._lib.check(L.ral_unet_forward_stage(h, self._ptr(self.x), B, 1, si, global_windows, self._stream()))
+            bn = L.ral_unet_stage_bn(si)
+            if bn >= 0:
+                yield self.bn_sums[128 * bn:128 * bn + 64]
+        self.pred = torch.empty_like(self.x)
+        self._lib.check(L.ral_unet_forward_finish(h, self._ptr(self.pred), B, 1, global_windows, self._stream()))
+        for k in self.m.eng.counters:
+            self.m.eng.counters[k] += 1
+
+    def loss(self, pred, target, global_windows):
+        return self.m.loss_and_metrics(pred, target, True, global_windows)
+
+    def backward_iter(self, global_windows):
+        L, h = self._lib.lib(), self.m.eng.h
+        dy = self.m._dy
+        B = dy.shape[0]
+        self._lib.check(L.ral_unet_backward_start(h, self._ptr(dy), B, global_windows, self._stream()))
+        for si in range(10, -1, -1):
+            bn = L.ral_unet_stage_bn(si)
+            if bn >= 0:       # the BatchNorm-backward sums of this stage's output, accumulated by its consumers
+                yield self.bn_sums[128 * bn + 64:128 * bn + 128]
+            self._lib.check(L.ral_unet_backward_stage(h, B, si, global_windows, self._stream()))
+        self._lib.check(L.ral_unet_backward_finish(h, B, global_windows, self._stream()))
+
+    def adam(self, lr):
+        self.m.step(lr)
+
+
 class DataParallelTrainer:
     def __init__(self, engine, group=None, sync_bn=True):
         self.e, self.group, self.sync_bn = engine, group, sync_bn
@@ -89,6 +139,18 @@ class DataParallelTrainer:
         B = x_local.shape[0]
         G = B * self.world
         e = self.e
+        if hasattr(e, "forward_iter"):     # an engine with one reduction point per layer (U-Net sync-BatchNorm)
+            for t in e.forward_iter(x_local, G):
+                self._allreduce(t)
+            pred = e.pred
+            loss, snr, rmse = e.loss(pred, target_local, G)
+            for t in e.backward_iter(G):
+                self._allreduce(t)
+            self._allreduce(e.grads)
+            e.adam(lr)
+            loss = loss.clone()
+            self._allreduce(loss)
+            return {"loss": loss, "snr": snr, "rmse": rmse, "pred": pred}
         e.forward_begin(x_local)
         if self.sync_bn:
             self._allreduce(e.bn_sums[:32])

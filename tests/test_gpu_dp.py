@@ -40,3 +40,94 @@ def test_early_gradient_bucket_is_final_when_its_event_fires():
     g_split = m.eng.grads.clone()
     y = m(x); m.loss_and_metrics(y, t); m.backward()
     torch.testing.assert_close(g_split, m.eng.grads, rtol=1e-4, atol=1e-7)
+
+
+def _lockstep(adapters, xs, ts, G):
+    """drive several engines like ranks of one job: whatever they yield is summed across them (the all-reduce)"""
+    def reduce(gens):
+        while True:
+            parts = [next(g, None) for g in gens]     # every engine advances, also into its tail after the last yield
+            if all(p is None for p in parts):
+                return
+            assert all(p is not None for p in parts), "ranks must reach the same reduction points"
+            tot = sum(p.clone() for p in parts)
+            for p in parts:
+                p.copy_(tot)
+    reduce([a.forward_iter(x, G) for a, x in zip(adapters, xs)])
+    for a, t in zip(adapters, ts):
+        a.loss(a.pred, t, G)
+    reduce([a.backward_iter(G) for a in adapters])
+
+
+def test_unet_sync_batchnorm_two_ranks_equal_one_process():
+    """Two U-Net engines with half the batch each, run stage by stage with their BatchNorm sums added after every
+    layer (what the data-parallel trainer's all-reduces do), reproduce one engine on the whole batch: outputs,
+    running statistics, and gradients (sum of the two) -- i.e. exact global-batch BatchNorm."""
+    from ecg_denoise_amd import UNet
+    from ecg_denoise_amd.dp import UNetEngineAdapter
+    B, L = 16, 512
+    torch.manual_seed(0)
+    x = torch.randn(B, 2, L, device=DEV); t = torch.randn(B, 2, L, device=DEV)
+    ref = UNet(leads=2, L=L, max_batch=B, device=DEV, seed=21); ref.train()
+    y = ref(x); ref.loss_and_metrics(y, t); ref.backward()
+    halves = [UNet(leads=2, L=L, max_batch=B // 2, device=DEV, seed=21) for _ in range(2)]
+    for h in halves:
+        h.train()
+    # ref's state_dict already holds the post-forward running statistics: reset the halves to a fresh model's
+    fresh = UNet(leads=2, L=L, max_batch=1, device=DEV, seed=21)
+    for h in halves:
+        h.load_state_dict(fresh.state_dict())
+    ads = [UNetEngineAdapter(h) for h in halves]
+    _lockstep(ads, [x[:B // 2], x[B // 2:]], [t[:B // 2], t[B // 2:]], B)
+    torch.cuda.synchronize()
+    pred = torch.cat([a.pred for a in ads])
+    torch.testing.assert_close(pred, y, rtol=2e-5, atol=2e-6)
+    g = halves[0].eng.grads + halves[1].eng.grads
+    torch.testing.assert_close(g, ref.eng.grads, rtol=2e-4, atol=2e-7)
+    sd_ref, sd_h = ref.state_dict(), halves[0].state_dict()
+    for k in sd_ref:
+        if "running" in k:
+            torch.testing.assert_close(sd_h[k], sd_ref[k], rtol=1e-5, atol=1e-7)
+    # per-rank statistics would NOT match: the halves' own monolithic forward differs from the global one
+    solo = UNet(leads=2, L=L, max_batch=B // 2, device=DEV, seed=21); solo.load_state_dict(fresh.state_dict()); solo.train()
+    assert (solo(x[:B // 2]) - y[:B // 2]).abs().max().item() > 1e-3
+
+
+def test_ralenet_sync_batchnorm_two_ranks_equal_one_process():
+    """The same emulation for RA-LENet's split step (forward_begin / _end, backward_begin / _end with the two
+    BatchNorm sum exchanges): two half-batch engines reproduce the whole-batch engine."""
+    from ecg_denoise_amd import RALENet
+    from ecg_denoise_amd.dp import HipEngineAdapter
+    B, L = 8, 256
+    torch.manual_seed(1)
+    x = torch.randn(B, 2, L, device=DEV); t = torch.randn(B, 2, L, device=DEV)
+    ref = RALENet("full", leads=2, L=L, max_batch=B, device=DEV, seed=31); ref.train()
+    fresh = {k: v.clone() for k, v in ref.state_dict().items()}
+    y = ref(x); ref.loss_and_metrics(y, t); ref.backward()
+    halves = [RALENet("full", leads=2, L=L, max_batch=B // 2, device=DEV, seed=31) for _ in range(2)]
+    for h in halves:
+        h.load_state_dict(fresh); h.train()
+    ads = [HipEngineAdapter(h) for h in halves]
+    xs, ts = [x[:B // 2], x[B // 2:]], [t[:B // 2], t[B // 2:]]
+
+    def exchange(lo, hi):
+        tot = ads[0].bn_sums[lo:hi] + ads[1].bn_sums[lo:hi]
+        for a in ads:
+            a.bn_sums[lo:hi] = tot
+
+    for a, xx in zip(ads, xs):
+        a.forward_begin(xx)
+    exchange(0, 32)
+    preds = [a.forward_end(B) for a in ads]
+    for a, p, tt in zip(ads, preds, ts):
+        a.loss(p, tt, B)
+        a.backward_begin()
+    exchange(32, 64)
+    for a in ads:
+        a.backward_end(B)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(torch.cat(preds), y, rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(halves[0].eng.grads + halves[1].eng.grads, ref.eng.grads, rtol=3e-4, atol=3e-7)
+    for k, v in ref.state_dict().items():
+        if "running" in k:
+            torch.testing.assert_close(halves[0].state_dict()[k], v, rtol=1e-5, atol=1e-7)
