@@ -1048,6 +1048,17 @@ size_t attn_bwd_lds(int N, int HG, int Len) {
 
 void launch_attn_bwd(const float* qkv, const float* o_hm, const float* do_hm, const float* lse, const float* table,
                      float* gtable, float* dqkv, int N, int H, int HG, int Len, int B, hipStream_t s) {
+  static const int split_env = getenv("RAL_ATTN_SPLIT") ? atoi(getenv("RAL_ATTN_SPLIT")) : 2;   // see launch_attn_fwd
+  int split = split_env;
+  while (split > 1 && (HG % split != 0 || N % 32 != 0)) split /= 2;
+  if (split > 1) {
+    const int hg = HG / split;
+    const size_t l2 = attn_bwd_lds(N, hg, Len);
+    const int it2 = B * (H / hg);
+    RAL_SET_LDS((k_attn_bwd<2>), l2);
+    k_attn_bwd<2><<<it2 < 8192 ? it2 : 8192, 512 / split, l2, s>>>(qkv, o_hm, do_hm, lse, table, gtable, dqkv, N, H, hg, Len, B);
+    return;
+  }
   const size_t lds = attn_bwd_lds(N, HG, Len);
   const int items = B * (H / HG);
   const int grid = items < 4096 ? items : 4096;
