@@ -141,30 +141,6 @@ static inline int ld_of(int C) { return C == 8 ? 8 : C + 4; }
 template <int C> struct TTBof { static constexpr int v = (C <= 32) ? 4 : (C == 64 ? 2 : 1); };
 
 // ---------------------------------------------------------------------------------
-// acc[mi][ni] += sum_t Y[t][m0 + 16 mi + i] * X[t][n0 + 16 ni + j],  t in [0, T), T % 16 == 0
-// (weight-gradient products: both operands are LDS tiles, the contraction runs over tokens)
-template <int MI, int NI, int LAYY, int LAYX>
-RAL_DEV void gemm_yx(const float* Ys, int ldy, int m0, const float* Xs, int ldx, int n0, int T,
-                     f32x4 (&acc)[MI][NI]) {
-  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
-  for (int t0 = 0; t0 < T; t0 += 16) {
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int t = t0 + 4 * g + s;
-      float a[MI], b[NI];
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) a[mi] = Ys[xoff<LAYY>(ldy, t, m0 + 16 * mi + r)];
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) b[ni] = Xs[xoff<LAYX>(ldx, t, n0 + 16 * ni + r)];
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = mfma4(a[mi], b[ni], acc[mi][ni]);
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------
 // small math
 // Exact-erf GELU (nn.GELU default) and its derivative from ONE evaluation of
 //   erfc(z) ~= (a1 t + ... + a5 t^5) e^{-z^2},  t = 1/(1 + p z)      (Abramowitz-Stegun 7.1.26,
@@ -320,19 +296,6 @@ RAL_DEV void copy_in(float* dst, int ld, const float* __restrict__ src, int gld,
 // flat float4 copy (n4 float4s)
 RAL_DEV void copy_flat(float* dst, const float* __restrict__ src, int n4) {
   for_each_f4<4>(src, n4, [&](int i, float4 v) { reinterpret_cast<float4*>(dst)[i] = v; });
-}
-
-// column sums of an LDS tile (rows x width) added into an LDS vector cs[width] by ALL threads of the block
-// (thread = (row group, column); one LDS atomic per thread).  The bias gradients are such sums over tokens.
-template <int LAY>
-RAL_DEV void lds_colsum_add(float* cs, const float* tile, int ld, int rows, int width) {
-  const int groups = blockDim.x / width;
-  const int col = threadIdx.x % width, grp = threadIdx.x / width;
-  if (grp < groups) {
-    float s = 0.f;
-    for (int n = grp; n < rows; n += groups) s += tile[xoff<LAY>(ld, n, col)];
-    atomicAdd(cs + col, s);
-  }
 }
 
 // Parameters of one TransformerBlock inside the flat parameter (or gradient) buffer.
