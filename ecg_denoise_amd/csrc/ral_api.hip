@@ -278,7 +278,9 @@ static size_t plan_workspace(const ral_config& c, RalModel* m /* may be null: si
     a.o = tr ? take((p + "o").c_str(), E) : sh_o;
     a.lse = tr ? take((p + "lse").c_str(), E / 4) : nullptr;
     a.x1 = tr ? take((p + "x1").c_str(), E) : nullptr;
-    a.upre = tr ? take((p + "upre").c_str(), 4 * E) : nullptr;
+    // u_pre is kept only where the backward reads it: the narrow levels re-compute it (k_mlp_bwd_s)
+    const int lvl = STAGES[b / 2].level;
+    a.upre = (tr && !mlp_bwd_is_fused(CH[lvl], c.L >> lvl)) ? take((p + "upre").c_str(), 4 * E) : nullptr;
     a.out = take((p + "out").c_str(), E);
   }
   static const char* RN[8] = {"p1", "p2", "p3", "p4", "u3", "u2", "u1", "u0"};
@@ -389,7 +391,8 @@ static void run_block_fwd(RalModel* m, int bi, const float* in, bool training, c
   { ProfScope p(m, K_ATTN_FWD, s);
     launch_attn_fwd(qkv, o, training ? woff(a.lse, w0, E1 / 4) : nullptr, table, N, H, m->hg_f[l], Len, B, s); }
   { ProfScope p(m, K_MLP_FWD, s);
-    launch_mlp_fwd(C, m->nch_f[l], x, o, w, training ? woff(a.x1, w0, E1) : nullptr, training ? woff(a.upre, w0, 4 * E1) : nullptr,
+    launch_mlp_fwd(C, m->nch_f[l], x, o, w, training ? woff(a.x1, w0, E1) : nullptr,
+                   (training && !mlp_bwd_is_fused(C, N)) ? woff(a.upre, w0, 4 * E1) : nullptr,
                    woff(a.out, w0, E1), N, B, s); }
 }
 

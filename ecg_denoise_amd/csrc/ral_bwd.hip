@@ -177,13 +177,14 @@ __global__ __launch_bounds__(512) void k_mlp_bwd(const float* __restrict__ dx2, 
 // of ral_dw.hip -- which re-read u_pre and du_pre from HBM and re-compute the GELU chain and the LayerNorm --
 // disappear, and du_pre is never written.  Workgroups are persistent (a few windows each) so that the
 // accumulators are flushed with one atomic per element per workgroup.
+//   u_pre is not read either: it is re-computed chunk by chunk from LN2(x1), which is staged for dW1 anyway.
 //   hidden chunks of HC = C channels (4 chunks); LDS: dx2->dx1 | LN2(x1) | u_pre->du (->dg) | a2, each N x LD
 //   per chunk: da2 GEMM (epilogue: du, a2) -> barrier -> [dg tiles in registers, dW tile jobs] -> barrier
 //   TW = token tiles of dg per wave (N * max(C,16) / 2048)
 // =================================================================================
 template <int C, int TW>
 __global__ __launch_bounds__(512, 4) void k_mlp_bwd_s(const float* __restrict__ dx2, const float* __restrict__ x1,
-                                                      const float* __restrict__ upre, BlockP w, BlockP wt, BlockP gr,
+                                                      BlockP w, BlockP wt, BlockP gr,
                                                       float* __restrict__ dx1, float* __restrict__ do_hm, int N, int B) {
   extern __shared__ float4 smem4[];
   constexpr int LD = LDof<C>::v, HC = C, NCH = 4, LPR = C / 4;
@@ -240,7 +241,14 @@ __global__ __launch_bounds__(512, 4) void k_mlp_bwd_s(const float* __restrict__ 
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
       const int j0 = ch * HC;
-      copy_in(Us, LD, upre + (size_t)win * N * 4 * C + j0, 4 * C, N, HC);
+      // u_pre chunk = LN2(x1) W1[chunk]^T + b1, RE-COMPUTED (the forward does not store u_pre at these levels: the
+      // matrix pipe is idle here and 4E of HBM writes plus 4E of reads per block are not)
+      if (ch == 0) __syncthreads();   // Xl (and dx2) staged
+      gemm_phase<C, TTBof<C>::v, false, LAY_TOK>(w.w1 + (size_t)j0 * C, C, HC, Xl, LDB, N >> 4,
+                                                [&](int row0, int tok, f32x4 a) {
+        *reinterpret_cast<float4*>(Us + tok * LD + row0) =
+            f4add(tofloat4(a), *reinterpret_cast<const float4*>(w.b1 + j0 + row0));
+      });
       __syncthreads();
       if (le && ch == 0) {
         for (int i = threadIdx.x; i < N + 2; i += blockDim.x) {
@@ -997,21 +1005,40 @@ size_t mlp_bwd_lds(int C, int N, int nch) {
 
 // narrow levels: fused weight-gradient variant (k_mlp_bwd_s) when the window length gives each wave a whole
 // number (1, 2, 4 or 8) of dg token tiles; RAL_FUSE_DW=0 keeps the separate dW kernels
+// does the fused narrow-level kernel take (C, N)?  The forward asks too: it does not store u_pre for such blocks
 template <int C>
-static bool launch_mlp_bwd_s(const float* dx2, const float* x1, const float* upre, const BlockP& w, const BlockP& wt,
-                             const BlockP& gr, float* dx1, float* do_hm, int N, int B, hipStream_t s) {
-  // widest level that takes the fused kernel (RAL_FUSE_DW=0 disables it, 8 / 16 narrow it).  Measured at batch 2048:
-  // none 102.8k, C <= 8 103.8k, C <= 16 105.5k, C <= 32 105.8k windows/s (at C = 32 the weight-gradient MFMAs are
-  // no longer negligible on the critical stream, so the gain flattens)
+static bool mlp_bwd_s_applies(int N, int* tw_out, size_t* lds_out) {
   static const int maxc = getenv("RAL_FUSE_DW") ? atoi(getenv("RAL_FUSE_DW")) : 32;
   constexpr int MT = C >= 16 ? C / 16 : 1;
   if (C > maxc || (N * MT) % 128 != 0) return false;
   const int tw = N * MT / 128;
+  if (tw != 1 && tw != 2 && tw != 4 && tw != 8) return false;
   const int ldb = C == 16 ? C : ld_of(C);
   const size_t lds = ((size_t)2 * N * ld_of(C) + (size_t)2 * N * ldb + 2 * (N + 2) + 2 * N + 2 * C + 8) * sizeof(float);
   if (lds > 80 * 1024) return false;
+  if (tw_out) *tw_out = tw;
+  if (lds_out) *lds_out = lds;
+  return true;
+}
+bool mlp_bwd_is_fused(int C, int N) {
+  switch (C) {
+    case 8: return mlp_bwd_s_applies<8>(N, nullptr, nullptr);
+    case 16: return mlp_bwd_s_applies<16>(N, nullptr, nullptr);
+    case 32: return mlp_bwd_s_applies<32>(N, nullptr, nullptr);
+  }
+  return false;
+}
+
+template <int C>
+static bool launch_mlp_bwd_s(const float* dx2, const float* x1, const BlockP& w, const BlockP& wt,
+                             const BlockP& gr, float* dx1, float* do_hm, int N, int B, hipStream_t s) {
+  // widest level that takes the fused kernel: RAL_FUSE_DW (0 disables it, 8 / 16 narrow it).  Measured at batch 2048:
+  // none 102.8k, C <= 8 103.8k, C <= 16 105.5k, C <= 32 105.8k windows/s (at C = 32 the weight-gradient MFMAs are
+  // no longer negligible on the critical stream, so the gain flattens)
+  int tw; size_t lds;
+  if (!mlp_bwd_s_applies<C>(N, &tw, &lds)) return false;
   const int grid = B < 512 ? B : 512;
-#define GO(t) { RAL_SET_LDS((k_mlp_bwd_s<C, t>), lds); k_mlp_bwd_s<C, t><<<grid, 512, lds, s>>>(dx2, x1, upre, w, wt, gr, dx1, do_hm, N, B); return true; }
+#define GO(t) { RAL_SET_LDS((k_mlp_bwd_s<C, t>), lds); k_mlp_bwd_s<C, t><<<grid, 512, lds, s>>>(dx2, x1, w, wt, gr, dx1, do_hm, N, B); return true; }
   switch (tw) { case 1: GO(1) case 2: GO(2) case 4: GO(4) case 8: GO(8) default: return false; }
 #undef GO
 }
@@ -1020,7 +1047,7 @@ template <int C>
 static bool launch_mlp_bwd_c(int nch, const float* dx2, const float* x1, const float* upre, const BlockP& w,
                              const BlockP& wt, const BlockP& gr, float* dupre, float* dx1, float* do_hm, float* a2c0, int N, int B, hipStream_t s) {
   if constexpr (C <= 32) {
-    if (launch_mlp_bwd_s<C>(dx2, x1, upre, w, wt, gr, dx1, do_hm, N, B, s)) return true;
+    if (launch_mlp_bwd_s<C>(dx2, x1, w, wt, gr, dx1, do_hm, N, B, s)) return true;
   }
   const size_t lds = mlp_bwd_lds(C, N, nch);
   const int grid = grid_bwd(B);

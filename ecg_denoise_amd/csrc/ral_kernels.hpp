@@ -52,6 +52,7 @@ void launch_transpose_mats(const float* src, float* dst, const void* desc, int n
 
 // ---- backward (ral_bwd.hip)
 size_t mlp_bwd_lds(int C, int N, int nch);
+bool mlp_bwd_is_fused(int C, int N);   // narrow levels: fused weight gradients, u_pre re-computed (not stored by the forward)
 bool launch_mlp_bwd(int C, int nch, const float* dx2, const float* x1, const float* upre, const BlockP& w,
                     const BlockP& wt, const BlockP& gr, float* dupre, float* dx1, float* do_hm, float* a2c0, int N, int B,
                     hipStream_t s);
