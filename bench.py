@@ -51,6 +51,33 @@ def measured_traffic(kind):
         return None
 
 
+def conv_stage_roofline(dev, L):
+    """The HBM-bound conv stages of the path (north star: fraction of the HBM roofline on the U-Net stages): U-Net
+    forward at a batch large enough to leave the launch-bound regime (65 536 windows, 2 leads), stage-granular
+    algorithmic bytes (every stage tensor read and written once, skips and the residual re-read, the
+    output BatchNorm pass) over the measured forward time."""
+    import torch
+    from ecg_denoise_amd import UNet
+    B, leads = 65536, 2
+    m = UNet(leads=leads, L=L, max_batch=B, train=False, device=dev, seed=1)
+    m.eval()
+    x = torch.randn(B, leads, L, device=dev)
+    for _ in range(3):
+        m(x)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    n = 10
+    for _ in range(n):
+        m(x)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
+    w = leads * L * 4                       # bytes of one stage tensor of one window
+    alg = B * (15 + 11 + 2) * w             # 15 tensor reads (3 skips + residual included), 11 writes, output pass
+    del m, x
+    torch.cuda.empty_cache()
+    return {"bound": "hbm", "kernel": "U-Net forward, 11 conv stages + output pass (eval BatchNorm)", "achieved": round(alg / dt / 1e9, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / dt / 1e9 / HBM_PEAK_GBS, 4),
+            "windows_per_s": round(B / dt, 1), "batch": B}
+
+
 def cpu_baseline(leads, L, variant):
     """The oracle (CPU restatement of the reference op graph, parity-pinned by tests/golden) timed on the
     host cores of this box on a bounded sample: batch 32 (the reference's own batch, BASELINE config 0)."""
@@ -220,6 +247,10 @@ def main():
             res["infer_windows_per_s"] = round(infer, 1)
             res["infer_hipgraph_windows_per_s"] = round(infer_graph, 1)
         if world == 1 and not a.no_cpu:
+            try:
+                res["conv_stage_roofline"] = conv_stage_roofline(dev, a.L)
+            except Exception as exc:      # an extra, never at the expense of the headline line
+                res["conv_stage_roofline"] = {"error": str(exc)[:200]}
             res["cpu_baseline"] = cpu_baseline(a.leads, a.L, a.variant)
         print(json.dumps(res))
     if world > 1:
