@@ -34,7 +34,7 @@ def _check(res):
 
 @pytest.mark.parametrize("variant,leads,L,B", [
     ("full", 2, 512, 4), ("nra", 2, 512, 3), ("mlp", 2, 256, 4), ("full", 2, 256, 5),
-    ("full", 1, 512, 2), ("full", 2, 1024, 2), ("nra", 1, 256, 1),
+    ("full", 1, 512, 2), ("full", 2, 1024, 2), ("nra", 1, 256, 1), ("mlp", 2, 768, 3),
 ])
 def test_train_step_matches_oracle(variant, leads, L, B):
     res, _, _ = run_parity(variant, leads, L, B, DEV)
