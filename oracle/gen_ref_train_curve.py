@@ -4,7 +4,7 @@ fixture (tests/golden/g6_ref_train_curve.npz) for the SNR-improvement comparison
 import contextlib, io, os, sys, tempfile, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))   # (this file lives in oracle/)
 import gen_golden as G
 import ralenet_oracle as O
 from ecg_denoise_amd import synth

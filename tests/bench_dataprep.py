@@ -1,4 +1,5 @@
-"""Timing of the GPU windowing / noise-mixing step (ral_prep_windows) next to the oracle on the host cores."""
+"""Timing of the GPU windowing / noise-mixing step (ral_prep_windows) next to the oracle on the host cores
+(lives under tests/ because it runs the oracle; not collected by pytest).  python tests/bench_dataprep.py"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))

@@ -49,7 +49,7 @@ def test_train_loop_reproduces_reference_trace(golden_dir, tmp_path):
 def test_full_protocol_first_epochs_match_reference_curve(golden_dir, tmp_path):
     """main.py protocol (10 000 synthetic windows, 8000/2000 split, batch 32, Adam 1e-3, emb noise at 0 dB) on the
     'full' RA-LENet: the first two epochs (500 optimiser steps) must reproduce the per-epoch SNR the REFERENCE itself
-    reached on the same arrays and initial weights (g6_ref_train_curve_full.npz, tools/ref_train_curve.py) to well
+    reached on the same arrays and initial weights (g6_ref_train_curve_full.npz, oracle/gen_ref_train_curve.py) to well
     inside the 0.05 dB the north star allows; later epochs diverge chaotically (tools/snr_experiment.py)."""
     from ecg_denoise_amd import RALENet, synth
     from ecg_denoise_amd.train import train

@@ -1,7 +1,7 @@
 """SNR-improvement experiment on the synthetic ECG set: the main.py protocol — 10 000 windows,
 8000/2000 split, batch 32, Adam 1e-3, 100 epochs, emb noise at 0 dB — run through ecg_denoise_amd.train.train on
 one MI355X, compared with the per-epoch curve the REFERENCE produced on the same arrays
-(tests/golden/g6_ref_train_curve_full.npz, made by tools/ref_train_curve.py in the build container)."""
+(tests/golden/g6_ref_train_curve_full.npz, made by oracle/gen_ref_train_curve.py in the build container)."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -19,7 +19,7 @@ m = RALENet(variant, leads=2, L=256, max_batch=32, device="cuda:0", seed=777)
 
 
 def reference_curve_init(model, seed):
-    """The initial weights tools/ref_train_curve.py gave the reference model: the build's seeded init rule (one
+    """The initial weights oracle/gen_ref_train_curve.py gave the reference model: the build's seeded init rule (one
     numpy Generator, parameters visited in state_dict order) with the reference's default R-wave tables (0) and
     norm affines (1, 0); the draws those tensors consume in the rule are made and discarded."""
     import math
