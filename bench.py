@@ -1,6 +1,10 @@
 """Headline benchmark: RA-LENet training-step throughput (ECG windows/s) on MI355X.
 
-    python bench.py [--gpus N --steps K --warmup W]            (N>1: launched by torch.distributed.run)
+    python bench.py [--gpus N --steps K --warmup W]
+
+N > 1 runs one process per GPU over RCCL: either the caller starts the ranks (`python -m torch.distributed.run
+--nproc-per-node N ... bench.py --gpus N`: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment), or
+bench.py starts them itself when WORLD_SIZE is not set (child processes, never exec; rank 0's JSON line is relayed).
 
 One "step" = zero_grad -> forward -> mse/SNR/RMSE -> backward -> (all-reduce) -> Adam on one batch of
 synthetic 512-sample windows already resident in HBM.  Prints ONE JSON line (rank 0).
@@ -9,6 +13,8 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -108,20 +114,73 @@ def cpu_baseline(leads, L, variant):
                       f"(torch-CPU op graph of the reference, {cores} threads)"}
 
 
+def self_launch(n, argv):
+    """Start the n ranks of a single-node job as CHILD processes of this one (which has not touched the GPU and never
+    will), wait for all of them, relay rank 0's stdout.  Returns the exit code: non-zero if any rank failed."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
+    out, _ = procs[0].communicate()
+    codes = [p.wait() for p in procs]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
+def launcher_dry_run(a):
+    """`--dry-run-launcher`: the ranks rendezvous over gloo on the CPU, all-reduce one number and rank 0 prints a line
+    marked "dry_run".  It exercises the process launcher and the environment contract only (tests/test_bench_cpu.py);
+    nothing of the measured path runs and the line is not a benchmark result."""
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([float(rank + 1)])
+    if world > 1:
+        dist.all_reduce(t)
+        dist.barrier()
+    if os.environ.get("RAL_BENCH_FAIL_RANK") == str(rank):      # (test hook: a failing rank must fail the launcher)
+        sys.exit(3)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "local_rank": int(os.environ.get("LOCAL_RANK", "0")),
+                          "rank_sum": t.item(), "steps": a.steps, "warmup": a.warmup}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=2048, help="windows per GPU")
     ap.add_argument("--leads", type=int, default=1)
     ap.add_argument("--L", type=int, default=512)
     ap.add_argument("--variant", default="full")
     ap.add_argument("--kind", default="attn_bwd", help="kernel kind timed for the roofline object")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--infer", action="store_true", help="also time the inference forward")
+    ap.add_argument("--no-infer", action="store_true", help="skip the inference-forward leg")
     ap.add_argument("--kinds", action="store_true", help="print a per-kernel-kind time table to stderr (3 steps each)")
+    ap.add_argument("--dry-run-launcher", action="store_true", help="CPU/gloo rendezvous only: tests the process launcher")
     a = ap.parse_args()
+
+    # N > 1 and nobody started the ranks for us: start them (before torch is imported or the GPU touched)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a.gpus, sys.argv[1:]))
+    if a.dry_run_launcher:
+        return launcher_dry_run(a)
 
     import torch
     import torch.distributed as dist
@@ -201,7 +260,7 @@ def main():
     loss = out["loss"].item()
 
     infer = infer_graph = None
-    if a.infer:
+    if not a.no_infer:
         # BASELINE config 4: eval-mode forward (BatchNorm running statistics), eager and hipGraph-captured
         from ecg_denoise_amd.infer import GraphedForward
         model.eval()
@@ -212,14 +271,18 @@ def main():
         for _ in range(a.steps):
             model(x)
         sync()
-        infer = B * world * a.steps / (time.perf_counter() - t1)
+        ti = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
         gf = GraphedForward(model, B)
         gf(x); sync()
         t1 = time.perf_counter()
         for _ in range(a.steps):
             gf.graph.replay()
         sync()
-        infer_graph = B * world * a.steps / (time.perf_counter() - t1)
+        tg = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        if world > 1:          # replicas, no collective: the job's rate is set by the slowest rank
+            dist.all_reduce(ti, op=dist.ReduceOp.MAX); dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        infer = B * world * a.steps / ti.item()
+        infer_graph = B * world * a.steps / tg.item()
 
     if rank == 0:
         ksec = ms.value * 1e-3
@@ -227,7 +290,7 @@ def main():
         ach = flops / ksec / 1e12 if ksec > 0 else 0.0
         peak = VALU_F32_PEAK_TF if a.kind.startswith("attn") else MFMA_F32_PEAK_TF
         res = {
-            "metric": "ECG windows/sec (512-sample, bs2048) train",
+            "metric": f"ECG windows/sec ({a.L}-sample, bs{B}) train step; inference forward in infer_*_windows_per_s",
             "value": round(B * world * a.steps / dt, 1), "unit": "windows/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -237,7 +300,7 @@ def main():
                                    f"N(0,1) inputs seed 2023, random-init weights",
                        "global_batch": B * world, "parallelism": f"dp{world}", "sync_bn": True},
             "final_loss": round(loss, 6),
-            "roofline": {"bound": "mfma", "kernel": a.kind, "achieved": round(ach, 3), "peak": peak,
+            "roofline": {"bound": "valu" if a.kind.startswith("attn") else "mfma", "kernel": a.kind, "achieved": round(ach, 3), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": measured_traffic(a.kind),
                          "launches": int(cnt.value), "avg_launch_ms": round(ms.value / max(cnt.value, 1), 4),
                          "measured": f"hipEvent pairs on the kernel's stream over {rl_steps} serialised steps "

@@ -54,7 +54,9 @@ _SIGS = {
     "ral_forward_begin": (C.c_int, [_VP, _VP, C.c_int, _VP]),
     "ral_forward_end": (C.c_int, [_VP, _VP, C.c_int, C.c_int64, _VP]),
     "ral_loss": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int64, _VP, _VP, _VP, _VP, _VP]),
+    "ral_loss_flat": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int64, _VP, _VP, _VP, _VP, _VP]),
     "ral_backward": (C.c_int, [_VP, _VP, _VP, C.c_int, _VP]),
+    "ral_backward_input": (C.c_int, [_VP, _VP, _VP, C.c_int, _VP]),
     "ral_backward_begin": (C.c_int, [_VP, _VP, C.c_int, _VP]),
     "ral_backward_end": (C.c_int, [_VP, _VP, C.c_int, C.c_int64, _VP]),
     "ral_unet_stage_bn": (C.c_int, [C.c_int]),
@@ -72,6 +74,10 @@ _SIGS = {
     "ral_adam_flat": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
                                 C.c_float, _VP]),
     "ral_prep_windows": (C.c_int, [_VP, _VP, C.c_int64, C.c_int, C.c_int, C.c_double, _VP, _VP, _VP, _VP]),
+    "ral_stream_windows": (C.c_int, [_VP, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, _VP, _VP, _VP]),
+    "ral_stream_stitch": (C.c_int, [_VP, _VP, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, _VP, _VP]),
+    "ral_attention_forward": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, _VP]),
+    "ral_attention_backward": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, _VP]),
     "ral_set_option": (C.c_int, [_VP, C.c_char_p, C.c_int]),
     "ral_profile_select": (C.c_int, [_VP, C.c_char_p]),
     "ral_profile_read": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -212,8 +212,10 @@ struct RalModel {
   void* lanes = nullptr;   // LaneSet
   int n_lanes = 2;
   bool side_stream = true;
+  bool want_dw = true;      // false inside ral_backward_input: frozen weights, data gradients only
   int dec_lanes = 0; bool dec_side = false;   // lanes / side streams that carried the last backward (bucket events)
   hipEvent_t ev_bwd_done = nullptr;          // recorded at the end of ral_backward_end
+  bool bwd_recorded = false;
   float* paramsT = nullptr;   // transposed copies of the weight matrices (same offsets), refreshed per backward
   void* tdesc = nullptr; int tn = 0, ttotal = 0;
   const float* last_x = nullptr;
@@ -236,8 +238,12 @@ struct ProfScope {
   ProfScope(RalModel* m_, int kind, hipStream_t s_) : m(m_), s(s_), on(m_->prof_kind == kind) {
     if (!on) return;
     if (m->prof_used == m->prof_ev.size()) {
-      hipEvent_t a, b;
-      (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+      hipEvent_t a = nullptr, b = nullptr;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {   // no timing for this launch
+        if (a) (void)hipEventDestroy(a);
+        on = false;
+        return;
+      }
       m->prof_ev.push_back({a, b});
     }
     (void)hipEventRecord(m->prof_ev[m->prof_used].first, s);
@@ -309,11 +315,18 @@ static size_t env_size(const char* name, size_t dflt) {
   return v && *v ? (size_t)atoll(v) : dflt;
 }
 
+// head-group size of the attention kernels: the largest power-of-two fraction of the heads whose tiles fit the LDS budget
+static int attn_head_group(int N, int H, int Len, bool bwd) {
+  const size_t budget = bwd ? env_size("RAL_ATTN_BWD_LDS", 78 * 1024) : env_size("RAL_ATTN_FWD_LDS", 72 * 1024);
+  int hg = H;
+  while (hg > 1 && (bwd ? attn_bwd_lds(N, hg, Len) : attn_fwd_lds(N, hg, Len)) > budget) hg /= 2;
+  return hg;
+}
+
 static void choose_tiling(RalModel* m) {
   // tuning knobs (bytes of LDS a workgroup may take; fewer bytes = more hidden chunks / smaller head
   // groups but more co-resident workgroups per CU).  Environment overrides are for experiments only.
   const size_t budget = env_size("RAL_MLP_LDS", 78000);
-  const size_t budget_af = env_size("RAL_ATTN_FWD_LDS", 72 * 1024), budget_ab = env_size("RAL_ATTN_BWD_LDS", 78 * 1024);
   // split-K workgroups of the weight-gradient kernels per channel width {8,16,32,64,128}: many for the
   // narrow levels (staging latency-bound, tiny dW), few for the wide ones (the final atomics scale with it)
   static const int KS_DEFAULT[5] = {256, 256, 256, 128, 64};
@@ -329,12 +342,8 @@ static void choose_tiling(RalModel* m) {
     while (n < 4 && mlp_bwd_lds(C, N, n) > budget) n *= 2;
     m->nch_b[l] = n;
     const int Len = l < 4 ? RWLEN[l] : 0;
-    int hg = H;
-    while (hg > 1 && attn_fwd_lds(N, hg, Len) > budget_af) hg /= 2;
-    m->hg_f[l] = hg;
-    hg = H;
-    while (hg > 1 && attn_bwd_lds(N, hg, Len) > budget_ab) hg /= 2;
-    m->hg_b[l] = hg;
+    m->hg_f[l] = attn_head_group(N, H, Len, false);
+    m->hg_b[l] = attn_head_group(N, H, Len, true);
   }
 }
 
@@ -519,25 +528,27 @@ static void run_block_bwd(RalModel* m, int bi, const float* dy, const float* ext
   const int w0 = ln.w0, B = ln.B;
   hipStream_t s = ln.s;
   const int k = ln.bwd_count++ & 1;                    // temporary set of this block
-  hipStream_t sd = m->side_stream ? ln.s2 : s;         // stream of the weight-gradient kernels
-  if (m->side_stream && ln.dw_pending[k]) (void)hipStreamWaitEvent(s, ln.ev_done[k], 0);   // set k free again?
+  const bool side = m->side_stream && m->want_dw;
+  hipStream_t sd = side ? ln.s2 : s;                   // stream of the weight-gradient kernels
+  if (side && ln.dw_pending[k]) (void)hipStreamWaitEvent(s, ln.ev_done[k], 0);   // set k free again?
   const float* dyw = woff(dy, w0, E1);
   float *dupre = woff(m->dupre[k], w0, 4 * E1), *dx1 = woff(m->dx1[k], w0, E1), *dohm = woff(m->dohm[k], w0, E1),
         *dqkv = woff(m->dqkv[k], w0, 3 * E1), *a2c0 = woff(m->a2c0[k], w0, m->L);   // (per-window stride L at every level: the lanes run different levels concurrently)
   const float *x1 = woff(a.x1, w0, E1), *upre = woff(a.upre, w0, 4 * E1), *qkv = woff(a.qkv, w0, 3 * E1),
               *o = woff(a.o, w0, E1), *lse = woff(a.lse, w0, E1 / 4), *xin = woff(a.in, w0, E1);
   bool fused_mlp_dw;
-  { ProfScope p(m, K_MLP_BWD, s); fused_mlp_dw = launch_mlp_bwd(C, m->nch_b[l], dyw, x1, upre, w, wt, g, dupre, dx1, dohm, a2c0, N, B, s); }
+  { ProfScope p(m, K_MLP_BWD, s); fused_mlp_dw = launch_mlp_bwd(C, m->nch_b[l], dyw, x1, upre, w, wt, g, dupre, dx1, dohm, a2c0, N, B, m->want_dw, s); }
   { ProfScope p(m, K_ATTN_BWD, s); launch_attn_bwd(qkv, o, dohm, lse, table, gtable, dqkv, N, H, m->hg_b[l], Len, B, s); }
   { ProfScope p(m, K_QKV_BWD, s);
     launch_qkv_bwd(C, dqkv, xin, m->pe[l], dx1, woff(extra, w0, E1), w, wt, g, woff(dx, w0, E1), N, B, s); }
-  if (m->side_stream) {
+  if (!m->want_dw) return;
+  if (side) {
     (void)hipEventRecord(ln.ev_ready[k], s);
     (void)hipStreamWaitEvent(sd, ln.ev_ready[k], 0);
   }
   { ProfScope p(m, K_DW, sd);
     launch_block_dw(C, dyw, upre, w.le ? a2c0 : nullptr, dupre, x1, dx1, o, dqkv, xin, m->pe[l], w, g, N, B, m->dw_ksplit[l], fused_mlp_dw, sd); }
-  if (m->side_stream) { (void)hipEventRecord(ln.ev_done[k], sd); ln.dw_pending[k] = true; }
+  if (side) { (void)hipEventRecord(ln.ev_done[k], sd); ln.dw_pending[k] = true; }
 }
 
 // stage: grad of stage output `dy` -> grad of stage input written to `dx` (+extra). Uses `tmp` between blocks.
@@ -554,6 +565,7 @@ static void run_res_bwd(RalModel* m, int ri, const float* dy, const float* in, f
   { ProfScope p(m, K_RES_BWD, s);
     launch_resample_bwd(r.D, ri >= 4, woff(dy, ln.w0, E1), woff(in, ln.w0, E1), m->paramsT + r.w, m->params + r.lnw,
                         m->grads + r.lnw, m->grads + r.lnb, woff(dx, ln.w0, E1), T, ln.B, s); }
+  if (!m->want_dw) return;
   int lvl = 0;
   while ((8 << lvl) < r.D) ++lvl;
   hipStream_t sd = s;
@@ -581,7 +593,8 @@ static int bwd_begin(RalModel* m, const float* dy, int B, hipStream_t s) {
   launch_final_bwd(m->cfg.leads, dy, m->res_out[7], m->x0, m->params + Y.tc_w, m->grads + Y.tc_w, m->grads + Y.tc_b,
                    m->du0, m->L, B, s);
   fork_lanes(m, s);
-  if (m->side_stream)   // side streams start after the gradient buffer has been zeroed
+  const bool side = m->side_stream && m->want_dw;
+  if (side)   // side streams start after the gradient buffer has been zeroed
     for (int k = 0; k < nl; ++k) {
       (void)hipEventRecord(LS->l[k].ev_fork, LS->l[k].s);
       (void)hipStreamWaitEvent(LS->l[k].s2, LS->l[k].ev_fork, 0);
@@ -598,8 +611,8 @@ static int bwd_begin(RalModel* m, const float* dy, int B, hipStream_t s) {
   EACH_LANE(run_stage_bwd(m, 5, gy[11], nullptr, gy[10], gin[5], ln))          // g x_mid
   // the decoder's parameters (utransformer4 .. transconv: the upper half of the flat gradient buffer) have their
   // final gradients once every lane's chain and weight-gradient stream pass this point: gradient bucket 1
-  EACH_LANE((void)hipEventRecord(ln.ev_dec_main, ln.s); if (m->side_stream) (void)hipEventRecord(ln.ev_dec_side, ln.s2);)
-  m->dec_lanes = nl; m->dec_side = m->side_stream;
+  EACH_LANE((void)hipEventRecord(ln.ev_dec_main, ln.s); if (side) (void)hipEventRecord(ln.ev_dec_side, ln.s2);)
+  m->dec_lanes = nl; m->dec_side = side;
   EACH_LANE(run_stage_bwd(m, 4, gin[5], gin[5], gy[8], gin[4], ln))            // g p4 = transformer^T(g x_mid) + g x_mid
   // encoder: pm_k <- stage, skip gradients added by the first block of each stage
   EACH_LANE(run_res_bwd(m, 3, gin[4], m->act[7].out, gy[7], ln))
@@ -611,7 +624,7 @@ static int bwd_begin(RalModel* m, const float* dy, int B, hipStream_t s) {
   EACH_LANE(run_res_bwd(m, 0, gin[1], m->act[1].out, gy[1], ln))
   EACH_LANE(run_stage_bwd(m, 0, gy[1], m->du0, gy[0], gin[0], ln))             // g x0 (+ d u0)
 #undef EACH_LANE
-  if (m->side_stream)   // join the side streams into their lanes, then the lanes into s
+  if (side)   // join the side streams into their lanes, then the lanes into s
     for (int k = 0; k < nl; ++k) {
       (void)hipEventRecord(LS->l[k].ev_join, LS->l[k].s2);
       (void)hipStreamWaitEvent(LS->l[k].s, LS->l[k].ev_join, 0);
@@ -629,8 +642,8 @@ static int bwd_end(RalModel* m, float* dx, int B, int64_t global_windows, hipStr
                    m->L, B, s);
   launch_bn_affine_grads(m->bn_sums + 32, m->grads + Y.bn_w, m->grads + Y.bn_b, 8, (double)B / (double)global_windows, s);
   if (dx) launch_conv1_bwd_dx(m->cfg.leads, m->dz0, m->params + Y.conv1_w, dx, m->L, B, s);
-  if (!m->ev_bwd_done) (void)hipEventCreateWithFlags(&m->ev_bwd_done, hipEventDisableTiming);
-  (void)hipEventRecord(m->ev_bwd_done, s);
+  HIP_OK(hipEventRecord(m->ev_bwd_done, s));
+  m->bwd_recorded = true;
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -699,6 +712,27 @@ int ral_pe_table(const ral_config* cfg, int level, float* out_host, int64_t cap)
   return 0;
 }
 
+// every stream, event and allocation of a model is released here: ral_destroy and the error paths of ral_create share it
+static void destroy_model(RalModel* m) {
+  if (!m) return;
+  if (m->lanes) {
+    LaneSet* LS = reinterpret_cast<LaneSet*>(m->lanes);
+    for (int i = 0; i < MAX_LANES; ++i) {
+      Lane& ln = LS->l[i];
+      if (LS->own[i]) (void)hipStreamDestroy(LS->own[i]);
+      if (ln.s2) (void)hipStreamDestroy(ln.s2);
+      hipEvent_t evs[8] = {ln.ev_ready[0], ln.ev_ready[1], ln.ev_done[0], ln.ev_done[1], ln.ev_fork, ln.ev_join,
+                           ln.ev_dec_main, ln.ev_dec_side};
+      for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
+    }
+    delete LS;
+  }
+  for (auto& pr : m->prof_ev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  if (m->ev_bwd_done) (void)hipEventDestroy(m->ev_bwd_done);
+  if (m->slab) (void)hipFree(m->slab);
+  delete m;
+}
+
 int ral_create(const ral_config* cfg, ral_handle** out) {
   if (check_cfg(cfg)) return -1;
   if (!out) return fail("null out");
@@ -719,7 +753,8 @@ int ral_create(const ral_config* cfg, ral_handle** out) {
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&m->slab), m->slab_bytes);
   if (e != hipSuccess) {
     fail("hipMalloc(%zu bytes) failed: %s", m->slab_bytes, hipGetErrorString(e));
-    delete m; delete h;
+    m->slab = nullptr;
+    destroy_model(m); delete h;
     return -1;
   }
   plan_workspace(*cfg, m, m->slab);
@@ -736,19 +771,29 @@ int ral_create(const ral_config* cfg, ral_handle** out) {
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     const int pmode = (int)env_size("RAL_DW_PRIO", 0);   // 0 default, 1 lowest, 2 highest
     const bool low = pmode != 0;
+    // a failed creation would leave a null stream (= the legacy default stream: the fork/join ordering would silently
+    // change), so the first error fails the whole ral_create
+    hipError_t first = hipSuccess;
+    auto ok = [&](hipError_t r) { if (r != hipSuccess && first == hipSuccess) first = r; };
     for (int i = 0; i < MAX_LANES; ++i) {
       Lane& ln = LS->l[i];
-      if (i > 0) { (void)hipStreamCreateWithFlags(&LS->own[i], hipStreamNonBlocking); }
-      if (low) (void)hipStreamCreateWithPriority(&ln.s2, hipStreamNonBlocking, pmode == 2 ? prio_greatest : prio_least);
-      else (void)hipStreamCreateWithFlags(&ln.s2, hipStreamNonBlocking);
+      if (i > 0) ok(hipStreamCreateWithFlags(&LS->own[i], hipStreamNonBlocking));
+      if (low) ok(hipStreamCreateWithPriority(&ln.s2, hipStreamNonBlocking, pmode == 2 ? prio_greatest : prio_least));
+      else ok(hipStreamCreateWithFlags(&ln.s2, hipStreamNonBlocking));
       for (int k = 0; k < 2; ++k) {
-        (void)hipEventCreateWithFlags(&ln.ev_ready[k], hipEventDisableTiming);
-        (void)hipEventCreateWithFlags(&ln.ev_done[k], hipEventDisableTiming);
+        ok(hipEventCreateWithFlags(&ln.ev_ready[k], hipEventDisableTiming));
+        ok(hipEventCreateWithFlags(&ln.ev_done[k], hipEventDisableTiming));
       }
-      (void)hipEventCreateWithFlags(&ln.ev_fork, hipEventDisableTiming);
-      (void)hipEventCreateWithFlags(&ln.ev_join, hipEventDisableTiming);
-      (void)hipEventCreateWithFlags(&ln.ev_dec_main, hipEventDisableTiming);
-      (void)hipEventCreateWithFlags(&ln.ev_dec_side, hipEventDisableTiming);
+      ok(hipEventCreateWithFlags(&ln.ev_fork, hipEventDisableTiming));
+      ok(hipEventCreateWithFlags(&ln.ev_join, hipEventDisableTiming));
+      ok(hipEventCreateWithFlags(&ln.ev_dec_main, hipEventDisableTiming));
+      ok(hipEventCreateWithFlags(&ln.ev_dec_side, hipEventDisableTiming));
+    }
+    ok(hipEventCreateWithFlags(&m->ev_bwd_done, hipEventDisableTiming));
+    if (first != hipSuccess) {
+      fail("stream / event creation failed: %s", hipGetErrorString(first));
+      destroy_model(m); delete h;
+      return -1;
     }
   }
   for (int l = 0; l < 5; ++l) {
@@ -758,7 +803,7 @@ int ral_create(const ral_config* cfg, ral_handle** out) {
     e = hipMemcpy(m->pe[l], P.data(), P.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
       fail("hipMemcpy(pe) failed: %s", hipGetErrorString(e));
-      (void)hipFree(m->slab); delete m; delete h;
+      destroy_model(m); delete h;
       return -1;
     }
   }
@@ -775,7 +820,7 @@ int ral_create(const ral_config* cfg, ral_handle** out) {
     for (int r = 0; r < 8; ++r) add(m->lay.res[r].w, m->lay.res[r].D, m->lay.res[r].D);
     m->tn = (int)d.size() / 4; m->ttotal = run;
     e = hipMemcpy(m->tdesc, d.data(), d.size() * sizeof(int), hipMemcpyHostToDevice);
-    if (e != hipSuccess) { fail("hipMemcpy(tdesc) failed"); (void)hipFree(m->slab); delete m; delete h; return -1; }
+    if (e != hipSuccess) { fail("hipMemcpy(tdesc) failed: %s", hipGetErrorString(e)); destroy_model(m); delete h; return -1; }
   }
   h->m = m;
   *out = h;
@@ -784,22 +829,7 @@ int ral_create(const ral_config* cfg, ral_handle** out) {
 
 int ral_destroy(ral_handle* h) {
   if (!h) return 0;
-  if (h->m) {
-    if (h->m->lanes) {
-      LaneSet* LS = reinterpret_cast<LaneSet*>(h->m->lanes);
-      for (int i = 0; i < MAX_LANES; ++i) {
-        Lane& ln = LS->l[i];
-        if (LS->own[i]) (void)hipStreamDestroy(LS->own[i]);
-        if (ln.s2) (void)hipStreamDestroy(ln.s2);
-        for (int k = 0; k < 2; ++k) { if (ln.ev_ready[k]) (void)hipEventDestroy(ln.ev_ready[k]); if (ln.ev_done[k]) (void)hipEventDestroy(ln.ev_done[k]); }
-        if (ln.ev_fork) (void)hipEventDestroy(ln.ev_fork);
-        if (ln.ev_join) (void)hipEventDestroy(ln.ev_join);
-      }
-      delete LS;
-    }
-    if (h->m->slab) (void)hipFree(h->m->slab);
-    delete h->m;
-  }
+  destroy_model(h->m);
   if (h->u) unet_destroy(h->u);
   delete h;
   return 0;
@@ -839,6 +869,15 @@ int ral_loss(ral_handle* h, const float* pred, const float* target, int B, int64
   const int n = c.leads * c.L;
   const float gscale = (float)(2.0 / ((double)global_windows * n));
   launch_loss(pred, target, dy, snr, rmse, loss_sum, n, B, gscale, (hipStream_t)s);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int ral_loss_flat(const float* pred, const float* target, int n, int B, int64_t global_windows, float* dy, float* snr,
+                  float* rmse, double* loss_sum, ral_stream s) {
+  if (!pred || !target) return fail("ral_loss_flat: null pointer");
+  if (n <= 0 || B <= 0 || global_windows <= 0) return fail("ral_loss_flat: n, B and global_windows must be positive");
+  launch_loss(pred, target, dy, snr, rmse, loss_sum, n, B, (float)(2.0 / ((double)global_windows * n)), (hipStream_t)s);
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -902,7 +941,7 @@ int ral_grad_bucket_wait(ral_handle* h, int k, ral_stream s) {
     return 0;
   }
   if (k == 0) {
-    if (!m->ev_bwd_done) return fail("bucket 0 is available after ral_backward_end");
+    if (!m->bwd_recorded) return fail("bucket 0 is available after ral_backward_end");
     HIP_OK(hipStreamWaitEvent((hipStream_t)s, m->ev_bwd_done, 0));
     return 0;
   }
@@ -914,6 +953,18 @@ int ral_backward(ral_handle* h, const float* dy, float* dx, int B, ral_stream s)
   if (h->kind == 1) return unet_backward(h->u, dy, dx, B, (hipStream_t)s, g_err, sizeof(g_err));
   if (bwd_begin(h->m, dy, B, (hipStream_t)s)) return -1;
   return bwd_end(h->m, dx, B, B, (hipStream_t)s);
+}
+
+int ral_backward_input(ral_handle* h, const float* dy, float* dx, int B, ral_stream s) {
+  if (!h) return fail("null handle");
+  if (h->kind == 1) return fail("ral_backward_input: RA-LENet handles only");
+  if (!dx) return fail("ral_backward_input: dx is the only result, it cannot be NULL");
+  RalModel* m = h->m;
+  m->want_dw = false;
+  int rc = bwd_begin(m, dy, B, (hipStream_t)s);
+  if (!rc) rc = bwd_end(m, dx, B, B, (hipStream_t)s);
+  m->want_dw = true;
+  return rc;
 }
 
 int ral_adam_step(ral_handle* h, double lr, double beta1, double beta2, double eps, int step, float grad_scale,
@@ -992,6 +1043,53 @@ int ral_prep_windows(const float* sig, const float* noise, int64_t T, int leads,
   if (!sig || !noise || !sums || !noisy || !clean) return fail("prep_windows: null pointer");
   if (launch_prep_windows(sig, noise, (long long)T, leads, L, snr_db, sums, noisy, clean, (hipStream_t)s))
     return fail("prep_windows: need 1 <= leads <= 16 and T a positive multiple of L (T=%lld leads=%d L=%d)", (long long)T, leads, L);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int ral_stream_windows(const float* rec, int64_t R, int64_t T, int leads, int L, int hop, int64_t w0, int nw, float* win,
+                       float* stats, ral_stream s) {
+  if (!rec || !win || !stats) return fail("stream_windows: null pointer");
+  if (launch_stream_windows(rec, (long long)R, (long long)T, leads, L, hop, (long long)w0, nw, win, stats, (hipStream_t)s))
+    return fail("stream_windows: need R >= 1, T >= L, 1 <= hop <= L, L a multiple of 64 and <= 2048, a window range inside the records "
+                "(R=%lld T=%lld leads=%d L=%d hop=%d w0=%lld nw=%d)", (long long)R, (long long)T, leads, L, hop, (long long)w0, nw);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int ral_stream_stitch(const float* y, const float* stats, int64_t R, int64_t T, int leads, int L, int hop, float* out,
+                      ral_stream s) {
+  if (!y || !stats || !out) return fail("stream_stitch: null pointer");
+  if (launch_stream_stitch(y, stats, (long long)R, (long long)T, leads, L, hop, out, (hipStream_t)s))
+    return fail("stream_stitch: need R >= 1, T >= L, 1 <= hop <= L with L - hop even (R=%lld T=%lld leads=%d L=%d hop=%d)",
+                (long long)R, (long long)T, leads, L, hop);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+static int check_attn_args(int N, int H, int Len, int B) {
+  if (N < 16 || N % 16 != 0 || N > 1024) return fail("attention: N must be a multiple of 16 in [16, 1024] (got %d)", N);
+  if (H < 1 || (H & (H - 1)) != 0 || H > 32) return fail("attention: H must be a power of two <= 32 (got %d)", H);
+  if (Len < 0 || Len > N || ((N - Len) & 1)) return fail("attention: the R-wave window (Len=%d) must fit N=%d and be centred", Len, N);
+  if (B < 1) return fail("attention: B must be positive");
+  return 0;
+}
+
+int ral_attention_forward(const float* qkv, float* o, float* lse, const float* table, int N, int H, int Len, int B,
+                          ral_stream s) {
+  if (!qkv || !o) return fail("attention: null pointer");
+  if (check_attn_args(N, H, table ? Len : 0, B)) return -1;
+  launch_attn_fwd(qkv, o, lse, table, N, H, attn_head_group(N, H, table ? Len : 0, false), table ? Len : 0, B, (hipStream_t)s);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int ral_attention_backward(const float* qkv, const float* o, const float* d_o, const float* lse, const float* table,
+                           float* gtable, float* dqkv, int N, int H, int Len, int B, ral_stream s) {
+  if (!qkv || !o || !d_o || !lse || !dqkv || (table && !gtable)) return fail("attention: null pointer");
+  if (check_attn_args(N, H, table ? Len : 0, B)) return -1;
+  launch_attn_bwd(qkv, o, d_o, lse, table, gtable, dqkv, N, H, attn_head_group(N, H, table ? Len : 0, true), table ? Len : 0, B,
+                  (hipStream_t)s);
   HIP_OK(hipGetLastError());
   return 0;
 }

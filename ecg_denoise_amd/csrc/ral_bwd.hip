@@ -71,7 +71,7 @@ __global__ __launch_bounds__(512) void k_mlp_bwd(const float* __restrict__ dx2, 
         for (int i = threadIdx.x; i < N; i += blockDim.x) {
           const float c0 = lw0 * A0[i] + lw1 * A0[i + 1] + lw2 * A0[i + 2];
           C0[i] = c0;
-          a2c0[(size_t)win * N + i] = gelu_f(c0);   // fc2 input of the LE channel, for the fc2 weight-gradient kernel
+          if (a2c0) a2c0[(size_t)win * N + i] = gelu_f(c0);   // fc2 input of the LE channel, for the fc2 weight-gradient kernel
         }
         __syncthreads();
       }
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(512) void k_mlp_bwd(const float* __restrict__ dx2, 
         __syncthreads();
       }
       RAL_STAMP_AT(3);
-      copy_out(dupre + (size_t)win * N * 4 * C + j0, 4 * C, Us, LDU, N, HC);
+      if (dupre) copy_out(dupre + (size_t)win * N * 4 * C + j0, 4 * C, Us, LDU, N, HC);   // (only the fc1 weight-gradient kernel reads it)
       RAL_STAMP_AT(4);
       RAL_STAMP_AT(5);
       // dg (+)= du W1[chunk, :]
@@ -185,7 +185,8 @@ __global__ __launch_bounds__(512) void k_mlp_bwd(const float* __restrict__ dx2, 
 template <int C, int TW>
 __global__ __launch_bounds__(512, 4) void k_mlp_bwd_s(const float* __restrict__ dx2, const float* __restrict__ x1,
                                                       BlockP w, BlockP wt, BlockP gr,
-                                                      float* __restrict__ dx1, float* __restrict__ do_hm, int N, int B) {
+                                                      float* __restrict__ dx1, float* __restrict__ do_hm, int N, int B,
+                                                      int want_dw) {
   extern __shared__ float4 smem4[];
   constexpr int LD = LDof<C>::v, HC = C, NCH = 4, LPR = C / 4;
   // Xl and As are only read as B operands of the dW jobs (4-byte reads): at C = 16 they go unpadded so that two
@@ -300,8 +301,7 @@ __global__ __launch_bounds__(512, 4) void k_mlp_bwd_s(const float* __restrict__ 
       // dg += du W1[chunk, :]   (this wave's tiles, accumulated in registers over the chunks)
       gemm_wx<HC, TW, false, LAY_TOK>(wt.w1 + j0, 4 * C, gm * 16, C, Us, LD, gt0 * 16, accg);
       // dW job of this wave: contraction over its share of the window's tokens, both operands in LDS
-#ifndef RAL_EXP_NOJOBS
-      {
+      if (want_dw) {   // (frozen weights, ral_backward_input: no weight gradients)
         const float* Ap = prod ? Us : Ds;
         const float* Bp = prod ? Xl : As;
         const int tlen = N / KS;
@@ -316,7 +316,6 @@ __global__ __launch_bounds__(512, 4) void k_mlp_bwd_s(const float* __restrict__ 
           }
         }
       }
-#endif
       __syncthreads();
     }
     // dg -> LDS (over the du buffer) for the row-wise LayerNorm backward
@@ -372,6 +371,7 @@ __global__ __launch_bounds__(512, 4) void k_mlp_bwd_s(const float* __restrict__ 
   }
   if (le && threadIdx.x < 3) atomicAdd(gr.le + threadIdx.x, red[2 * C + threadIdx.x]);
   // ---- flush the weight gradients: fold the token-split partials through LDS, then one atomic per element ----
+  if (!want_dw) return;
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) bs1[ch] = rows_sum(bs1[ch]);
   bs2 = rows_sum(bs2);
@@ -1031,23 +1031,24 @@ bool mlp_bwd_is_fused(int C, int N) {
 
 template <int C>
 static bool launch_mlp_bwd_s(const float* dx2, const float* x1, const BlockP& w, const BlockP& wt,
-                             const BlockP& gr, float* dx1, float* do_hm, int N, int B, hipStream_t s) {
+                             const BlockP& gr, float* dx1, float* do_hm, int N, int B, bool want_dw, hipStream_t s) {
   // widest level that takes the fused kernel: RAL_FUSE_DW (0 disables it, 8 / 16 narrow it).  Measured at batch 2048:
   // none 102.8k, C <= 8 103.8k, C <= 16 105.5k, C <= 32 105.8k windows/s (at C = 32 the weight-gradient MFMAs are
   // no longer negligible on the critical stream, so the gain flattens)
   int tw; size_t lds;
   if (!mlp_bwd_s_applies<C>(N, &tw, &lds)) return false;
   const int grid = B < 512 ? B : 512;
-#define GO(t) { RAL_SET_LDS((k_mlp_bwd_s<C, t>), lds); k_mlp_bwd_s<C, t><<<grid, 512, lds, s>>>(dx2, x1, w, wt, gr, dx1, do_hm, N, B); return true; }
+#define GO(t) { RAL_SET_LDS((k_mlp_bwd_s<C, t>), lds); k_mlp_bwd_s<C, t><<<grid, 512, lds, s>>>(dx2, x1, w, wt, gr, dx1, do_hm, N, B, want_dw ? 1 : 0); return true; }
   switch (tw) { case 1: GO(1) case 2: GO(2) case 4: GO(4) case 8: GO(8) default: return false; }
 #undef GO
 }
 
 template <int C>
 static bool launch_mlp_bwd_c(int nch, const float* dx2, const float* x1, const float* upre, const BlockP& w,
-                             const BlockP& wt, const BlockP& gr, float* dupre, float* dx1, float* do_hm, float* a2c0, int N, int B, hipStream_t s) {
+                             const BlockP& wt, const BlockP& gr, float* dupre, float* dx1, float* do_hm, float* a2c0, int N, int B,
+                             bool want_dw, hipStream_t s) {
   if constexpr (C <= 32) {
-    if (launch_mlp_bwd_s<C>(dx2, x1, w, wt, gr, dx1, do_hm, N, B, s)) return true;
+    if (launch_mlp_bwd_s<C>(dx2, x1, w, wt, gr, dx1, do_hm, N, B, want_dw, s)) return true;
   }
   const size_t lds = mlp_bwd_lds(C, N, nch);
   const int grid = grid_bwd(B);
@@ -1060,9 +1061,11 @@ static bool launch_mlp_bwd_c(int nch, const float* dx2, const float* x1, const f
 // returns true when the fc1 / fc2 weight (and bias) gradients were produced here (narrow levels): the caller then
 // skips those two products in launch_block_dw
 bool launch_mlp_bwd(int C, int nch, const float* dx2, const float* x1, const float* upre, const BlockP& w,
-                    const BlockP& wt, const BlockP& gr, float* dupre, float* dx1, float* do_hm, float* a2c0, int N, int B, hipStream_t s) {
+                    const BlockP& wt, const BlockP& gr, float* dupre, float* dx1, float* do_hm, float* a2c0, int N, int B,
+                    bool want_dw, hipStream_t s) {
+  if (!want_dw) { dupre = nullptr; a2c0 = nullptr; }   // consumed by the weight-gradient kernels only
   switch (C) {
-#define CASE(c) case c: return launch_mlp_bwd_c<c>(nch, dx2, x1, upre, w, wt, gr, dupre, dx1, do_hm, a2c0, N, B, s);
+#define CASE(c) case c: return launch_mlp_bwd_c<c>(nch, dx2, x1, upre, w, wt, gr, dupre, dx1, do_hm, a2c0, N, B, want_dw, s);
     CASE(8) CASE(16) CASE(32) CASE(64) CASE(128)
 #undef CASE
   }

@@ -43,6 +43,10 @@ void launch_adam(float* p, const float* g, float* m, float* v, size_t n, double 
 
 int launch_prep_windows(const float* sig, const float* noise, long long T, int leads, int L, double snr_db, double* sums,
                         float* noisy, float* clean, hipStream_t s);
+int launch_stream_windows(const float* rec, long long R, long long T, int leads, int L, int hop, long long w0, int nw,
+                          float* win, float* stats, hipStream_t s);
+int launch_stream_stitch(const float* y, const float* stats, long long R, long long T, int leads, int L, int hop, float* out,
+                         hipStream_t s);
 int launch_conv13_fwd(const float* x, const float* w, const float* b, float* y, int B, int cin, int cout, int L,
                       int lrelu, hipStream_t s);
 int launch_conv13_bwd(const float* x, const float* y, const float* dy, const float* w, float* gw, float* gb,
@@ -55,7 +59,7 @@ size_t mlp_bwd_lds(int C, int N, int nch);
 bool mlp_bwd_is_fused(int C, int N);   // narrow levels: fused weight gradients, u_pre re-computed (not stored by the forward)
 bool launch_mlp_bwd(int C, int nch, const float* dx2, const float* x1, const float* upre, const BlockP& w,
                     const BlockP& wt, const BlockP& gr, float* dupre, float* dx1, float* do_hm, float* a2c0, int N, int B,
-                    hipStream_t s);
+                    bool want_dw, hipStream_t s);
 size_t attn_bwd_lds(int N, int HG, int Len);
 void launch_attn_bwd(const float* qkv, const float* o_hm, const float* do_hm, const float* lse, const float* table,
                      float* gtable, float* dqkv, int N, int H, int HG, int Len, int B, hipStream_t s);

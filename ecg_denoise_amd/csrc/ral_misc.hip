@@ -476,3 +476,77 @@ int launch_prep_windows(const float* sig, const float* noise, long long T, int l
   k_prep_mix<<<grid, 256, 0, s>>>(sig, noise, sums, T, leads, L, snr_db, noisy, clean);
   return 0;
 }
+
+// =================================================================================
+// Streaming of long records around the inference forward (BASELINE config 5).  The reference cuts the
+// 650 000-sample MIT-BIH records into fixed chunks and z-scores them (local_utils/local_utils.py:116-130, np_norm
+// :261-266); here a group of R records (R, leads, T) is cut into windows of L samples every `hop` samples (the last
+// window of a record is right-aligned), every window is z-scored per lead, and after the model the windows are
+// de-normalised and stitched back: overlapping regions keep the centre of each window, the record edges keep the
+// whole window.  One wave per (window, lead); mean and standard deviation go to a side buffer for the way back.
+// =================================================================================
+RAL_DEV void stream_geom(long long T, int L, int hop, int& n_reg, int& n) {
+  n_reg = (int)((T - L) / hop) + 1;
+  n = n_reg + (((T - L) % hop) != 0 ? 1 : 0);
+}
+
+__global__ __launch_bounds__(64) void k_stream_windows(const float* __restrict__ rec, long long T, int leads, int L, int hop,
+                                                       long long w0, float* __restrict__ win, float* __restrict__ stats) {
+  int n_reg, n;
+  stream_geom(T, L, hop, n_reg, n);
+  const int i = blockIdx.x / leads, c = blockIdx.x - i * leads;   // window of this launch, lead
+  const long long gw = w0 + i;
+  const long long r = gw / n;
+  const int k = (int)(gw - r * n);
+  const long long start = k < n_reg ? (long long)k * hop : T - L;
+  const float* src = rec + (r * leads + c) * T + start;
+  const int lane = threadIdx.x;
+  float sum = 0.f;
+  for (int l = lane; l < L; l += 64) sum += src[l];
+  const float mean = group_sum<64>(sum) / (float)L;
+  float ss = 0.f;
+  for (int l = lane; l < L; l += 64) { const float d = src[l] - mean; ss = fmaf(d, d, ss); }   // (second pass: L1 hits)
+  const float sd = fmaxf(sqrtf(group_sum<64>(ss) / (float)L), 1e-6f);   // population std, as np_norm; constant leads stay finite
+  const float inv = 1.0f / sd;
+  float* dst = win + ((size_t)i * leads + c) * L;
+  for (int l = lane; l < L; l += 64) dst[l] = (src[l] - mean) * inv;
+  if (lane == 0) { stats[(gw * leads + c) * 2] = mean; stats[(gw * leads + c) * 2 + 1] = sd; }
+}
+
+__global__ __launch_bounds__(256) void k_stream_stitch(const float* __restrict__ y, const float* __restrict__ stats, long long R,
+                                                       long long T, int leads, int L, int hop, float* __restrict__ out) {
+  int n_reg, n;
+  stream_geom(T, L, hop, n_reg, n);
+  const int h = (L - hop) >> 1;
+  const long long last_begin = n > 1 ? (long long)(n - 2) * hop + L - h : 0;   // first sample the last window keeps
+  const long long total = R * leads * T;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long rc = e / T, t = e - rc * T;
+    const long long r = rc / leads;
+    const int c = (int)(rc - r * leads);
+    int k; long long off;
+    if (n == 1 || t >= last_begin) { k = n - 1; off = t - (k < n_reg ? (long long)k * hop : T - L); }
+    else { k = t < h ? 0 : (int)((t - h) / hop); off = t - (long long)k * hop; }
+    const long long gw = r * n + k;
+    const float mean = stats[(gw * leads + c) * 2], sd = stats[(gw * leads + c) * 2 + 1];
+    out[e] = fmaf(y[(gw * leads + c) * L + off], sd, mean);
+  }
+}
+
+int launch_stream_windows(const float* rec, long long R, long long T, int leads, int L, int hop, long long w0, int nw,
+                          float* win, float* stats, hipStream_t s) {
+  if (R < 1 || leads < 1 || L < 64 || L % 64 != 0 || L > 2048 || T < L || hop < 1 || hop > L || nw < 1 || w0 < 0) return -1;
+  const long long n_reg = (T - L) / hop + 1, n = n_reg + (((T - L) % hop) != 0 ? 1 : 0);
+  if (w0 + nw > R * n) return -1;
+  k_stream_windows<<<nw * leads, 64, 0, s>>>(rec, T, leads, L, hop, w0, win, stats);
+  return 0;
+}
+
+int launch_stream_stitch(const float* y, const float* stats, long long R, long long T, int leads, int L, int hop, float* out,
+                         hipStream_t s) {
+  if (R < 1 || leads < 1 || T < L || hop < 1 || hop > L || ((L - hop) & 1)) return -1;
+  const long long total = R * leads * T;
+  const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  k_stream_stitch<<<grid, 256, 0, s>>>(y, stats, R, T, leads, L, hop, out);
+  return 0;
+}

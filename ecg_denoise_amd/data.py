@@ -106,9 +106,15 @@ def prep_windows(signal, noise, snr, L=256, stream=None):
     noisy = torch.empty(T // L, leads, L, dtype=torch.float32, device=sig.device)
     clean = torch.empty_like(noisy)
     sums = torch.empty(2 * leads + 1, dtype=torch.float64, device=sig.device)
-    s = stream if stream is not None else torch.cuda.current_stream(sig.device)
+    cur = torch.cuda.current_stream(sig.device)
+    s = stream if stream is not None else cur
+    if s != cur:
+        s.wait_stream(cur)                     # the float32 copies above were made on the current stream
     _lib.check(_lib.lib().ral_prep_windows(sig.data_ptr(), noi.data_ptr(), T, leads, L, float(snr), sums.data_ptr(),
                                            noisy.data_ptr(), clean.data_ptr(), s.cuda_stream))
+    if s != cur:                               # the caching allocator must not hand these out while `s` still uses them
+        for t in (sig, noi, sums, noisy, clean):
+            t.record_stream(s)
     return noisy, clean
 
 

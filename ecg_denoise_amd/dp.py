@@ -31,7 +31,7 @@ class HipEngineAdapter:
         self.grads = model.eng.grads
 
     def forward_begin(self, x):
-        self.x = x.contiguous()
+        self.x = self.m._check_x(x)
         self._lib.check(self._lib.lib().ral_forward_begin(self.m.eng.h, self._ptr(self.x), x.shape[0], self._stream()))
 
     def forward_end(self, global_windows):
@@ -55,6 +55,9 @@ class HipEngineAdapter:
 
     def adam(self, lr):
         self.m.step(lr)
+
+    def replica_state(self):
+        return _replica_state(self.m)
 
     # ---- gradient buckets (overlap of the all-reduce with the backward pass) ----
     def grad_buckets(self):
@@ -94,7 +97,7 @@ class UNetEngineAdapter:
 
     def forward_iter(self, x, global_windows):
         L, h = self._lib.lib(), self.m.eng.h
-        self.x = x.contiguous()
+        self.x = self.m._check_x(x)
         B = x.shape[0]
         for si in range(11):
             self._lib.check(L.ral_unet_forward_stage(h, self._ptr(self.x), B, 1, si, global_windows, self._stream()))
@@ -124,11 +127,50 @@ class UNetEngineAdapter:
     def adam(self, lr):
         self.m.step(lr)
 
+    def replica_state(self):
+        return _replica_state(self.m)
+
+
+def _replica_state(model):
+    """everything a replica owns that must be identical on every rank before the first step: flat device tensors
+    (broadcast in place) and a getter / setter for the host-side counters"""
+    e = model.eng
+    tensors = [e.params, e.state, e.adam_m, e.adam_v]
+
+    def get_counters():
+        return [model.step_count] + [e.counters[k] for k in sorted(e.counters)]
+
+    def set_counters(v):
+        model.step_count = int(v[0])
+        for k, c in zip(sorted(e.counters), v[1:]):
+            e.counters[k] = int(c)
+    return tensors, get_counters, set_counters
+
 
 class DataParallelTrainer:
-    def __init__(self, engine, group=None, sync_bn=True):
+    """`sync_state=True` (default) makes rank 0's replica the replica of every rank when the trainer is built:
+    parameters, BatchNorm running statistics, Adam moments, the step count and `num_batches_tracked` are broadcast
+    (the model constructors draw their weights from OS entropy unless given a seed, and only gradients are ever
+    all-reduced, so replicas that start apart stay apart).  Call `sync_state()` again after loading a checkpoint on
+    one rank."""
+
+    def __init__(self, engine, group=None, sync_bn=True, sync_state=True):
         self.e, self.group, self.sync_bn = engine, group, sync_bn
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if sync_state:
+            self.sync_state()
+
+    def sync_state(self, src=0):
+        if self.world <= 1 or not hasattr(self.e, "replica_state"):
+            return
+        tensors, get_counters, set_counters = self.e.replica_state()
+        # `src` is a rank of `group` (group_src), so sub-groups work without translating to global ranks
+        for t in tensors:
+            if t is not None:
+                dist.broadcast(t, group=self.group, group_src=src)
+        c = torch.tensor(get_counters(), dtype=torch.int64, device=tensors[0].device)
+        dist.broadcast(c, group=self.group, group_src=src)
+        set_counters(c.tolist())
 
     def _allreduce(self, t):
         if self.world > 1:

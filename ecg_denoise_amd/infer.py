@@ -6,10 +6,10 @@ The reference only has non-overlapping fixed-length chunking of the 650 000-samp
 into windows of the model's length with an optional overlap; every window is z-scored per lead
 (np_norm, local_utils/local_utils.py:261-266), denoised in eval mode (BatchNorm running statistics),
 de-normalised and stitched back (overlapping regions keep the centre of each window)."""
-import numpy as np
 import torch
 
 from . import _lib
+from .model import _ptr, _stream
 
 
 class GraphedForward:
@@ -41,61 +41,81 @@ class GraphedForward:
 
 
 class StreamingDenoiser:
+    """Long records through the eval-mode forward, everything on the device: `ral_stream_windows` (window gather +
+    per-window z-score, statistics kept in a side buffer), the model in batches of `batch` windows, `ral_stream_stitch`
+    (de-normalise + keep-the-centre stitching).  With `use_graph` the whole pipeline of a record group of a given
+    shape (R, leads, T) is ONE hipGraph: replaying it costs one launch per group."""
+
     def __init__(self, model, batch=4096, overlap=0, use_graph=True):
         self.model, self.L, self.leads = model, model.eng.L, model.eng.leads
         self.batch = min(batch, model.eng.max_batch)
         if overlap < 0 or overlap >= self.L or overlap % 2:
             raise _lib.RalError("overlap must be an even number of samples in [0, L)")
         self.overlap, self.hop = overlap, self.L - overlap
+        self.use_graph = use_graph
+        self.plans = {}
         model.eval()
-        self.fwd = GraphedForward(model, self.batch) if use_graph else None
 
-    def windows(self, record):
-        """record (leads, T) -> (n, leads, L) windows (last one right-aligned), start offsets"""
-        T = record.shape[-1]
+    def windows_per_record(self, T):
         if T < self.L:
             raise _lib.RalError(f"record shorter than one window ({T} < {self.L})")
-        starts = list(range(0, T - self.L + 1, self.hop))
-        if starts[-1] != T - self.L:
-            starts.append(T - self.L)
-        idx = torch.as_tensor(starts)[:, None] + torch.arange(self.L)[None, :]
-        return record[:, idx].permute(1, 0, 2).contiguous(), starts
+        n_reg = (T - self.L) // self.hop + 1
+        return n_reg + (1 if (T - self.L) % self.hop else 0)
+
+    def window_starts(self, T):
+        n_reg = (T - self.L) // self.hop + 1
+        st = [k * self.hop for k in range(n_reg)]
+        return st + ([T - self.L] if (T - self.L) % self.hop else [])
+
+    def _run(self, p):
+        """enqueue the pipeline of one record group on the current stream (captured or eager)"""
+        lib, e = _lib.lib(), self.model.eng
+        R, T, nw_all = p["R"], p["T"], p["nw"]
+        for w0 in range(0, nw_all, self.batch):
+            nw = min(self.batch, nw_all - w0)
+            _lib.check(lib.ral_stream_windows(_ptr(p["rec"]), R, T, self.leads, self.L, self.hop, w0, nw, _ptr(p["win"]),
+                                              _ptr(p["stats"]), _stream()))
+            _lib.check(lib.ral_forward(e.h, _ptr(p["win"]), _ptr(p["y"][w0:]), nw, 0, _stream()))
+        _lib.check(lib.ral_stream_stitch(_ptr(p["y"]), _ptr(p["stats"]), R, T, self.leads, self.L, self.hop, _ptr(p["out"]),
+                                         _stream()))
+
+    def _plan(self, R, T):
+        key = (R, T)
+        if key in self.plans:
+            return self.plans[key]
+        dev = self.model.eng.device
+        nw = R * self.windows_per_record(T)
+        z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
+        p = {"R": R, "T": T, "nw": nw, "rec": z(R, self.leads, T), "win": z(min(self.batch, nw), self.leads, self.L),
+             "y": z(nw, self.leads, self.L), "stats": z(nw * self.leads * 2), "out": z(R, self.leads, T), "graph": None}
+        if self.use_graph:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):          # warm-up outside capture (lazy LDS-size attributes, lane streams)
+                self._run(p)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            p["graph"] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(p["graph"]):
+                self._run(p)
+        self.plans[key] = p
+        return p
 
     @torch.no_grad()
     def denoise(self, record):
-        """record: (leads, T) float tensor/array on host or device -> denoised (leads, T) on the device"""
+        """record: (leads, T) or a group (R, leads, T), host or device -> denoised record(s) of the same shape on the
+        device (a view of the plan's output buffer: valid until the next call with the same shape)"""
         dev = self.model.eng.device
-        rec = torch.as_tensor(record, dtype=torch.float32).to(dev)
-        if rec.dim() != 2 or rec.shape[0] != self.leads:
-            raise _lib.RalError(f"expected a record of shape ({self.leads}, T)")
-        w, starts = self.windows(rec)
-        mu = w.mean(-1, keepdim=True)
-        sd = w.std(-1, unbiased=False, keepdim=True).clamp_min(1e-6)
-        w = (w - mu) / sd
-        out = torch.empty_like(w)
-        for i in range(0, w.shape[0], self.batch):
-            chunk = w[i:i + self.batch]
-            if self.fwd is not None and chunk.shape[0] == self.batch:
-                out[i:i + self.batch] = self.fwd(chunk)
-            else:
-                out[i:i + chunk.shape[0]] = self.model(chunk.contiguous())
-        out = out * sd + mu
-        # keep the centre of every window; the edges of the record keep the full window.  The sample -> (window,
-        # offset) map depends only on the record length: built once on the host, applied as one device gather
-        T = rec.shape[-1]
-        src = self._stitch_map(T, starts, dev)
-        return out.permute(1, 0, 2).reshape(self.leads, -1)[:, src]
-
-    def _stitch_map(self, T, starts, dev):
-        cache = self.__dict__.setdefault("_maps", {})
-        if T not in cache:
-            idx = np.empty(T, dtype=np.int64)
-            h = self.overlap // 2
-            for k, s in enumerate(starts):
-                a = 0 if k == 0 else h
-                b = self.L if k == len(starts) - 1 else self.L - h
-                if k == len(starts) - 1 and k > 0:
-                    a = max(h, starts[k - 1] + self.L - h - s)
-                idx[s + a:s + b] = k * self.L + np.arange(a, b)
-            cache[T] = torch.as_tensor(idx, device=dev)
-        return cache[T]
+        rec = torch.as_tensor(record, dtype=torch.float32)
+        single = rec.dim() == 2
+        if single:
+            rec = rec[None]
+        if rec.dim() != 3 or rec.shape[1] != self.leads:
+            raise _lib.RalError(f"expected a record of shape ({self.leads}, T) or (R, {self.leads}, T)")
+        p = self._plan(rec.shape[0], rec.shape[2])
+        p["rec"].copy_(rec, non_blocking=True)
+        if p["graph"] is not None:
+            p["graph"].replay()
+        else:
+            self._run(p)
+        return p["out"][0] if single else p["out"]

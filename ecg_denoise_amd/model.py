@@ -226,6 +226,14 @@ class _ModuleBase:
         _lib.check(_lib.lib().ral_backward(self.eng.h, _ptr(dy), _ptr(dx), dy.shape[0], _stream()))
         return dx
 
+    def backward_input(self, dy):
+        """d loss / d input with every weight frozen (`requires_grad = False`, ralenet_12leads.py:694-696): no weight
+        gradient is formed."""
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        _lib.check(_lib.lib().ral_backward_input(self.eng.h, _ptr(dy), _ptr(dx), dy.shape[0], _stream()))
+        return dx
+
     def zero_grad(self):
         pass  # ral_backward zeroes the flat gradient buffer itself
 
@@ -369,12 +377,19 @@ class NewRALE:
 
     __call__ = forward
 
-    def loss_and_metrics(self, pred, target, want_grad=True):
+    def loss_and_metrics(self, pred, target, want_grad=True, global_windows=None):
+        """F.mse_loss / SNR / RMSE over the flattened 12 x L windows (denoise_train.py:53,58-59) in the fused loss kernel."""
         B, n = pred.shape[0], pred[0].numel()
-        d = pred - target                      # (the fused loss kernel is sized for the inner model's windows)
-        sse = (d * d).flatten(1).sum(1); sy2 = (target * target).flatten(1).sum(1)
-        self._dy = (2.0 / (B * n)) * d if want_grad else None
-        return (sse / n).mean().double().reshape(1), 10 * torch.log10(sy2 / sse), torch.sqrt(sse / n)
+        gw = int(global_windows or B)
+        pred, target = pred.contiguous(), target.contiguous()
+        snr = torch.empty(B, dtype=torch.float32, device=pred.device)
+        rmse = torch.empty_like(snr)
+        loss_sum = torch.zeros(1, dtype=torch.float64, device=pred.device)
+        dy = torch.empty_like(pred) if want_grad else None
+        _lib.check(_lib.lib().ral_loss_flat(_ptr(pred), _ptr(target), n, B, gw, _ptr(dy), _ptr(snr), _ptr(rmse),
+                                            _ptr(loss_sum), _stream()))
+        self._dy = dy
+        return loss_sum / gw, snr, rmse
 
     def _conv_bwd(self, name, x, y, dy, lrelu, want_dx):
         dx = torch.empty_like(x) if want_dx else None
@@ -390,7 +405,7 @@ class NewRALE:
         self.grads.zero_()
         d3 = self._conv_bwd("conv4", a3, y, dy, False, True)
         dr = self._conv_bwd("conv3", r, a3, d3, True, True)
-        d2 = self.rale.backward(dr.contiguous(), want_dx=True)   # frozen weights: only the input gradient is used
+        d2 = self.rale.backward_input(dr)                        # frozen weights: input gradient only, no dW kernels
         d1 = self._conv_bwd("conv2", a1, a2, d2, True, True)
         self._conv_bwd("conv1", x, a1, d1, True, False)
 

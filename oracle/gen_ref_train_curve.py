@@ -33,7 +33,10 @@ with tempfile.TemporaryDirectory() as td:
                            use_gpu=False, model_name="ralenet", noise_name="emb", noise_intensity=0)
     finally:
         os.chdir(cwd)
-np.savez_compressed(os.path.join(ROOT, "tests", "golden", f"g6_ref_train_curve_{variant}.npz"),
+# REF_TAG names a repeat of the same run (same data, same initial weights) at another intra-op thread count: only the
+# summation order inside the BLAS / reduction kernels changes, which is what the run-to-run spread experiment needs
+tag = os.environ.get("REF_TAG", "")
+np.savez_compressed(os.path.join(ROOT, "tests", "golden", f"g6_ref_train_curve_{variant}{tag}.npz"), threads=torch.get_num_threads(),
                     train_snr=np.array(res[0]), test_snr=np.array(res[1]), train_rmse=np.array(res[2]),
                     test_rmse=np.array(res[3]), input_snr_test=np.float64(in_snr), epochs=epochs, seed=777,
                     seconds=time.time() - t0)

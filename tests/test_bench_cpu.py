@@ -1,0 +1,39 @@
+"""bench.py's own process launcher (`python bench.py --gpus N` without torch.distributed.run), proven on the CPU:
+`--dry-run-launcher` makes the ranks rendezvous over gloo and all-reduce one number instead of running the GPU step,
+so what is tested is exactly the launcher: child processes (no exec), RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set,
+rank 0's JSON line relayed, a failing rank failing the whole run."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, extra_env=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra_env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True,
+                          timeout=600)
+
+
+def test_self_launch_two_ranks_relays_rank0_line():
+    r = _run(["--gpus", "2", "--steps", "7", "--warmup", "2", "--dry-run-launcher"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]        # (gloo prints its own connection notes)
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d == {"dry_run": True, "n_gpus": 2, "local_rank": 0, "rank_sum": 3.0, "steps": 7, "warmup": 2}
+
+
+def test_self_launch_fails_when_a_rank_fails():
+    r = _run(["--gpus", "2", "--dry-run-launcher"], {"RAL_BENCH_FAIL_RANK": "1"})
+    assert r.returncode != 0
+    assert "ranks failed" in r.stderr
+
+
+def test_no_launch_when_the_ranks_were_started_for_us():
+    """WORLD_SIZE in the environment (torch.distributed.run started us): bench.py must not spawn anything."""
+    r = _run(["--gpus", "1", "--dry-run-launcher"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])["n_gpus"] == 1

@@ -96,6 +96,13 @@ class OracleEngine:
         o1 = self.grad_buckets()[1][0]
         self.grads[:o1] = torch.cat([self.gdict[k].reshape(-1) for k in self.p if k not in dec])
 
+    def replica_state(self):
+        tensors = list(self.p.values()) + list(self.m.values()) + list(self.v.values()) + list(self.running.values())
+
+        def set_counters(c):
+            self.step = int(c[0])
+        return tensors, (lambda: [self.step]), set_counters
+
     def adam(self, lr):
         self.step += 1
         off = 0
@@ -140,8 +147,15 @@ def _worker(rank, world, port, q):
     torch.set_num_threads(2)
     g = torch.Generator().manual_seed(7)
     x = torch.randn(4, 2, 256, generator=g); y = torch.randn(4, 2, 256, generator=g)
-    eng = OracleEngine("full", 2, 1234)
+    # every rank draws DIFFERENT initial weights (what the model constructors do without a seed) and rank 1 pretends to
+    # have taken steps already: the trainer must make rank 0's replica everybody's before the first step
+    eng = OracleEngine("full", 2, 1234 + 1000 * rank)
+    eng.step = 5 * rank
     tr = DataParallelTrainer(eng)
+    chk = torch.stack([sum(v.sum() for v in eng.p.values()), torch.tensor(float(eng.step), dtype=torch.float64)])
+    both = [torch.zeros_like(chk) for _ in range(world)]
+    dist.all_gather(both, chk)
+    assert all(torch.equal(b, both[0]) for b in both), "replicas differ after DataParallelTrainer.__init__"
     sh = slice(rank * 2, rank * 2 + 2)
     losses = [tr.train_step(x[sh], y[sh])["loss"].item() for _ in range(2)]
     if rank == 0:

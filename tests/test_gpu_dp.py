@@ -7,10 +7,10 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def test_early_gradient_bucket_is_final_when_its_event_fires():
+@pytest.mark.parametrize("B", [64, 256])     # 256: two lanes + weight-gradient side streams (the default schedule)
+def test_early_gradient_bucket_is_final_when_its_event_fires(B):
     from ecg_denoise_amd import RALENet
     from ecg_denoise_amd.dp import HipEngineAdapter
-    B = 64
     m = RALENet("full", leads=2, L=256, max_batch=B, device=DEV, seed=4)
     x = torch.randn(B, 2, 256, device=DEV); t = torch.randn(B, 2, 256, device=DEV)
     m.train()
