@@ -250,6 +250,115 @@ __global__ __launch_bounds__(512, (QT >= 4 ? 3 : 4)) void k_attn_fwd(const float
 }
 
 // =================================================================================
+// K2v: the same attention with one QUERY PER LANE and the keys streamed through the SCALAR path (N >= 64).
+// A wave owns 64 queries of one (window, head); key / value rows are wave-uniform, so they come in by s_load
+// (scalar cache, no LDS, no barrier, no staging pass) and enter the FMAs as SGPR operands:
+//   per key and lane:  s = q.k - m  (4 FMA, -m is the first addend)   p = exp2(s)   l += p   o += p v  (4 FMA)
+// Everything a query needs is lane-private, so there is no lane-group merge, and the output rows leave as one
+// coalesced 16-byte store per lane.  On gfx950 the fp32 MFMA shares the fp32 multipliers with the vector ALU (a tile of
+// k_attn_fwd costs its VALU time PLUS its MFMA time, tools/diag/valu_probe.hip), so doing q.k on the vector ALU costs
+// no more than the MFMA did, and the tile bookkeeping of the MFMA form disappears.
+// The softmax shift is the same Cauchy-Schwarz bound as above (exact running-max redo if a row underflows).
+// =================================================================================
+template <int W> RAL_DEV float group_max(float v) {   // max over W consecutive lanes, result in every lane
+#define RAL_DPP_MAX(CTRL) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false)))
+  if constexpr (W >= 2) RAL_DPP_MAX(0xB1);
+  if constexpr (W >= 4) RAL_DPP_MAX(0x4E);
+  if constexpr (W >= 8) RAL_DPP_MAX(0x141);
+  if constexpr (W >= 16) RAL_DPP_MAX(0x140);
+#undef RAL_DPP_MAX
+  if constexpr (W >= 32) {
+    const auto p = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(p[0]), __uint_as_float(p[1]));
+  }
+  if constexpr (W >= 64) {
+    const auto p = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(p[0]), __uint_as_float(p[1]));
+  }
+  return v;
+}
+
+template <bool BIAS>
+__global__ __launch_bounds__(256) void k_attn_fwd_v(const float* __restrict__ qkv, float* __restrict__ o_hm,
+                                                    float* __restrict__ lse, const float* __restrict__ table,
+                                                    int N, int H, int Len, int ntask) {
+  const int lane = threadIdx.x & 63;
+  const int QB = (N + 63) >> 6;
+  const int task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));   // wave-uniform by construction
+  if (task >= ntask) return;
+  const int qb = task % QB, wh = task / QB, head = wh % H, win = wh / H;
+  const int q = qb * 64 + lane, qc = q < N ? q : N - 1;
+  const size_t wbase = (size_t)win * 3 * H * N;
+  const float4* __restrict__ Q4 = reinterpret_cast<const float4*>(qkv) + wbase + (size_t)head * N;
+  const float4* __restrict__ K4 = reinterpret_cast<const float4*>(qkv) + wbase + (size_t)(H + head) * N;
+  const float4* __restrict__ V4 = reinterpret_cast<const float4*>(qkv) + wbase + (size_t)(2 * H + head) * N;
+  const float4 qv = f4scale(Q4[qc], RAL_LOG2E);
+  // max_k |k|^2 of the head: every lane takes N / 64 keys, then a wave-wide max
+  float km = 0.f;
+  for (int i = lane; i < N; i += 64) { const float4 k = K4[i]; km = fmaxf(km, f4dot(k, k)); }
+  km = group_max<64>(km);
+  float tval = 0.f, bmax = 0.f;      // R-wave table of this head, entry `lane` (2 Len - 1 <= 63 entries), log2 units
+  const int off = (N - Len) >> 1, qi = q - off;
+  if constexpr (BIAS) {
+    if (lane < 2 * Len - 1) tval = table[lane * H + head] * RAL_LOG2E;
+    bmax = group_max<64>(fmaxf(tval, 0.f));
+  }
+  const float mq = sqrtf(f4dot(qv, qv)) * sqrtf(km) * 1.0000002f + bmax;
+  const float nm = -mq;
+  float l = 0.f, o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+  auto body = [&](int kt, auto biased) {     // 4 keys; K4 / V4 rows are wave-uniform (scalar loads)
+    float4 k[4], v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { k[j] = K4[kt + j]; v[j] = V4[kt + j]; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float s = fmaf(qv.x, k[j].x, nm);
+      s = fmaf(qv.y, k[j].y, s);
+      s = fmaf(qv.z, k[j].z, s);
+      s = fmaf(qv.w, k[j].w, s);
+      if constexpr (decltype(biased)::value) {
+        const int ki = kt + j - off;                       // uniform; in the window for these chunks except at ragged ends
+        const float b = __shfl(tval, qi - ki + Len - 1);   // (lane-indexed gather of the table entry)
+        if (ki >= 0 && ki < Len && qi >= 0 && qi < Len) s += b;
+      }
+      const float p = __builtin_amdgcn_exp2f(s);
+      l += p;
+      o0 = fmaf(p, v[j].x, o0); o1 = fmaf(p, v[j].y, o1); o2 = fmaf(p, v[j].z, o2); o3 = fmaf(p, v[j].w, o3);
+    }
+  };
+  const int b0 = BIAS ? (off & ~3) : N, b1 = BIAS ? ((off + Len + 3) & ~3) : N;
+  for (int kt = 0; kt < b0; kt += 4) body(kt, std::false_type{});
+  for (int kt = b0; kt < b1; kt += 4) body(kt, std::true_type{});
+  for (int kt = b1; kt < N; kt += 4) body(kt, std::false_type{});
+  float mfin = mq;
+  if (__any(!(l > 1e-30f))) {   // a row underflowed under its bound: exact running-max recurrence for the whole wave
+    float mx = -INFINITY;
+    l = 0.f; o0 = o1 = o2 = o3 = 0.f;
+    for (int kt = 0; kt < N; ++kt) {
+      const float4 k = K4[kt], v = V4[kt];
+      float s = fmaf(qv.x, k.x, fmaf(qv.y, k.y, fmaf(qv.z, k.z, qv.w * k.w)));
+      if constexpr (BIAS) {
+        const int ki = kt - off;
+        const float b = __shfl(tval, qi - ki + Len - 1);
+        if (ki >= 0 && ki < Len && qi >= 0 && qi < Len) s += b;
+      }
+      const float mn = fmaxf(mx, s);
+      const float corr = __builtin_amdgcn_exp2f(mx - mn), p = __builtin_amdgcn_exp2f(s - mn);
+      mx = mn;
+      l = fmaf(l, corr, p);
+      o0 = fmaf(o0, corr, p * v.x); o1 = fmaf(o1, corr, p * v.y); o2 = fmaf(o2, corr, p * v.z); o3 = fmaf(o3, corr, p * v.w);
+    }
+    mfin = mx;
+  }
+  if (q < N) {
+    const float inv = 1.0f / l;
+    const size_t hq = ((size_t)win * H + head) * N + q;
+    *reinterpret_cast<float4*>(o_hm + hq * 4) = make_float4(o0 * inv, o1 * inv, o2 * inv, o3 * inv);
+    if (lse) lse[hq] = (mfin + __builtin_amdgcn_logf(l)) * RAL_LN2;   // natural-log units
+  }
+}
+
+// =================================================================================
 // K3: x1 = x + o Wp^T + bp;  g = LN2(x1);  u = g W1^T + b1;  a = GELU(u)
 //     [LE: a[:,0] = conv3(a[:,0]) over tokens; a = GELU(a)];  x2 = x1 + a W2^T + b2
 // The hidden (N x 4C) tile is processed in NCH column chunks so that long windows fit.
@@ -414,6 +523,14 @@ size_t attn_fwd_lds(int N, int HG, int Len) {
 
 void launch_attn_fwd(const float* qkv, float* o_hm, float* lse, const float* table, int N, int H, int HG, int Len,
                      int B, hipStream_t s) {
+  // N >= 64: query-per-lane kernel on the scalar path (RAL_ATTN_FWD_V=0 keeps the MFMA-tile kernel for comparison)
+  static const int vmin = getenv("RAL_ATTN_FWD_V") ? (atoi(getenv("RAL_ATTN_FWD_V")) ? atoi(getenv("RAL_ATTN_FWD_V")) : (1 << 30)) : 64;
+  if (N >= vmin && N % 4 == 0 && (!table || 2 * Len - 1 <= 64)) {
+    const int ntask = B * H * ((N + 63) / 64);
+    if (table) k_attn_fwd_v<true><<<(ntask + 3) / 4, 256, 0, s>>>(qkv, o_hm, lse, table, N, H, Len, ntask);
+    else k_attn_fwd_v<false><<<(ntask + 3) / 4, 256, 0, s>>>(qkv, o_hm, lse, table, N, H, 0, ntask);
+    return;
+  }
   // Workgroup split: 1 / SPLIT of the head group per item and 512 / SPLIT threads, so that 2 * SPLIT workgroups share
   // a CU and one's staging latency and barrier waits hide behind the others' tiles (same waves per CU, same LDS).
   // Measured at batch 2048 (fwd + bwd attention, ms per step): split 1: 7.76, split 2: 7.53 (RAL_ATTN_SPLIT).

@@ -1,0 +1,137 @@
+// VALU issue-cost probe (gfx950): cycles per wave-instruction of v_fma_f32, v_pk_fma_f32, v_exp_f32, v_mul_f32 and of the
+// attention inner-loop mixes, at 1 / 2 / 4 waves per SIMD (workgroups of 256 / 512 / 1024 threads, one per CU).
+//   hipcc --offload-arch=gfx950 -O3 -o valu_probe tools/diag/valu_probe.hip && ./valu_probe
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <vector>
+
+#define REP 64     // instructions of the measured kind per loop iteration
+#define ITERS 256
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int KIND>
+__global__ void k_probe(float* out, long long* cyc, float seed, int iters) {
+  float a[16];
+  f32x2 p[8];
+  for (int i = 0; i < 16; ++i) a[i] = seed + (float)threadIdx.x * 1e-3f + (float)i;
+  for (int i = 0; i < 8; ++i) p[i] = f32x2{a[2 * i], a[2 * i + 1]};
+  const float m = 1.0000001f, c = 1e-7f;
+  const f32x2 m2 = {m, m}, c2 = {c, c};
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  const long long t0 = __builtin_amdgcn_s_memtime();
+  const long long r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; ++it) {
+    if (KIND == 0) {          // 64 independent-ish v_fma_f32 (16 chains)
+#pragma unroll
+      for (int r = 0; r < REP / 16; ++r)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
+    } else if (KIND == 1) {   // 64 v_pk_fma_f32 (8 chains)
+#pragma unroll
+      for (int r = 0; r < REP / 8; ++r)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(m2), "v"(c2));
+    } else if (KIND == 2) {   // 64 v_exp_f32
+#pragma unroll
+      for (int r = 0; r < REP / 16; ++r)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
+    } else if (KIND == 3) {   // 64 v_pk_add_f32
+#pragma unroll
+      for (int r = 0; r < REP / 8; ++r)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(c2));
+    } else if (KIND == 4) {   // forward-tile mix, packed: 4 exp + 2 pk_add + 8 pk_fma (+1 mfma), x4
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], a[1], acc, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("v_exp_f32 %0, %0" : "+v"(a[4 + i]));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(c2));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p[2 + (i & 3)]) : "v"(m2), "v"(c2));
+      }
+    } else if (KIND == 5) {   // forward-tile mix, scalar: 4 exp + 4 add + 16 fma (+1 mfma), x4
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], a[1], acc, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("v_exp_f32 %0, %0" : "+v"(a[4 + i]));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[8 + (i & 1)]) : "v"(c));
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[10 + (i & 3)]) : "v"(m), "v"(c));
+      }
+    } else if (KIND == 6) {   // 64 v_mul_f32
+#pragma unroll
+      for (int r = 0; r < REP / 16; ++r)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+    } else if (KIND == 7) {   // 64 v_pk_mul_f32
+#pragma unroll
+      for (int r = 0; r < REP / 8; ++r)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "v"(m2));
+    } else if (KIND == 8) {   // 16 bare mfma 16x16x4 f32 (4 accumulators)
+      f32x4 ac[4] = {acc, acc, acc, acc};
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ac[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], a[i + 4], ac[i], 0, 0, 0);
+      acc = ac[0] + ac[1] + ac[2] + ac[3];
+    }
+  }
+  __syncthreads();   // every wave done: the oldest wave of a SIMD has issue priority and alone would show its solo speed
+  const long long t1 = __builtin_amdgcn_s_memtime();
+  float s = 0.f;
+  for (int i = 0; i < 16; ++i) s += a[i];
+  for (int i = 0; i < 8; ++i) s += p[i][0] + p[i][1];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s + acc[0] + acc[1] + acc[2] + acc[3];
+  const long long r1 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) { cyc[blockIdx.x] = t1 - t0; cyc[256 + blockIdx.x] = r1 - r0; }
+}
+
+template <int KIND>
+static void run(const char* name, int per_iter) {
+  float* out; long long* cyc;
+  hipMalloc(&out, 256 * 1024 * sizeof(float)); hipMalloc(&cyc, 512 * sizeof(long long));
+  printf("%-44s", name);
+  for (int threads : {64, 256, 512, 1024}) {
+    k_probe<KIND><<<256, threads>>>(out, cyc, 1.0f, ITERS);
+    k_probe<KIND><<<256, threads>>>(out, cyc, 1.0f, ITERS);
+    hipDeviceSynchronize();
+    std::vector<long long> h(512);
+    hipMemcpy(h.data(), cyc, 512 * sizeof(long long), hipMemcpyDeviceToHost);
+    double s = 0; for (int i = 0; i < 256; ++i) s += (double)h[i];
+    const double per_wave_instr = s / 256 / ITERS / per_iter;           // wall cycles per instruction of ONE wave
+    const int wps = threads >= 256 ? threads / 256 : 1;                  // waves per SIMD
+    printf("  %4d thr: %6.2f cyc/instr/wave -> %5.2f per SIMD slot", threads, per_wave_instr, per_wave_instr / wps);
+    if (threads == 1024) {   // sustained clock: the same kernel for ~20 ms (s_memtime = shader cycles, s_memrealtime = 100 MHz)
+      k_probe<KIND><<<256, threads>>>(out, cyc, 1.0f, ITERS * 400);
+      hipDeviceSynchronize();
+      hipMemcpy(h.data(), cyc, 512 * sizeof(long long), hipMemcpyDeviceToHost);
+      double c = 0, r = 0; for (int i = 0; i < 256; ++i) { c += (double)h[i]; r += (double)h[256 + i]; }
+      printf("  | sustained: %.0f us, clock %.2f GHz, %.2f cyc/slot", r / 256 / 100.0, c / r * 0.1, c / 256 / (ITERS * 400) / per_iter / wps);
+    }
+  }
+  printf("\n");
+  hipFree(out); hipFree(cyc);
+}
+
+int main() {
+  // s_memtime ticks at a fixed 100 MHz on some parts: calibrate against a known loop if the numbers look 24x too small
+  run<0>("v_fma_f32", REP);
+  run<1>("v_pk_fma_f32", REP);
+  run<2>("v_exp_f32", REP);
+  run<3>("v_pk_add_f32", REP);
+  run<6>("v_mul_f32", REP);
+  run<7>("v_pk_mul_f32", REP);
+  run<8>("v_mfma_f32_16x16x4_f32 (per mfma)", 16);
+  run<4>("fwd tile packed (per tile: 4exp 2pkadd 8pkfma 1mfma)", 4);
+  run<5>("fwd tile scalar (per tile: 4exp 4add 16fma 1mfma)", 4);
+  return 0;
+}
