@@ -208,7 +208,7 @@ struct RalModel {
   // every gradient tensor has its own buffer (no ping-pong): the weight-gradient kernels run on a side
   // stream and read them long after the data-gradient chain has moved on
   float *gy[18], *gin[9], *du0, *dz0;
-  float *dx1[2], *dohm[2], *dqkv[2], *dupre[2], *a2c0[2];     // per-block temporaries, two sets (side-stream overlap)
+  float *dx1[2], *dohm[2], *dqkv[2], *dupre[2], *a2c0[2], *astat[2];   // per-block temporaries, two sets (side-stream overlap)
   void* lanes = nullptr;   // LaneSet
   int n_lanes = 2;
   bool side_stream = true;
@@ -301,6 +301,9 @@ static size_t plan_workspace(const ral_config& c, RalModel* m /* may be null: si
       M.dx1[k] = take(("dx1_" + std::to_string(k)).c_str(), E); M.dohm[k] = take(("do_" + std::to_string(k)).c_str(), E);
       M.dqkv[k] = take(("dqkv_" + std::to_string(k)).c_str(), 3 * E); M.dupre[k] = take(("dupre_" + std::to_string(k)).c_str(), 4 * E);
       M.a2c0[k] = take(("a2c0_" + std::to_string(k)).c_str(), E / 8);
+      // attention backward scratch: (B, H, N, 2) = E / 2 floats from sweep Q to sweep KV, then (B, 2, H, 64) table-gradient
+      // partials (H <= 16 on the levels that have a table: at most 2048 floats per window)
+      M.astat[k] = take(("astat_" + std::to_string(k)).c_str(), E / 2 + (size_t)B * 2048);
     }
     M.dz0 = take("dz0", E);
     Layout L_; build_layout(c, L_);
@@ -538,7 +541,10 @@ static void run_block_bwd(RalModel* m, int bi, const float* dy, const float* ext
               *o = woff(a.o, w0, E1), *lse = woff(a.lse, w0, E1 / 4), *xin = woff(a.in, w0, E1);
   bool fused_mlp_dw;
   { ProfScope p(m, K_MLP_BWD, s); fused_mlp_dw = launch_mlp_bwd(C, m->nch_b[l], dyw, x1, upre, w, wt, g, dupre, dx1, dohm, a2c0, N, B, m->want_dw, s); }
-  { ProfScope p(m, K_ATTN_BWD, s); launch_attn_bwd(qkv, o, dohm, lse, table, gtable, dqkv, N, H, m->hg_b[l], Len, B, s); }
+  { ProfScope p(m, K_ATTN_BWD, s);
+    // (each lane's scratch: its share of the stat2 region followed by its share of the partials region)
+    float* scratch = m->astat[k] + (size_t)w0 * (E1 / 2 + 2048);
+    launch_attn_bwd(qkv, o, dohm, lse, table, gtable, dqkv, scratch, N, H, m->hg_b[l], Len, B, s); }
   { ProfScope p(m, K_QKV_BWD, s);
     launch_qkv_bwd(C, dqkv, xin, m->pe[l], dx1, woff(extra, w0, E1), w, wt, g, woff(dx, w0, E1), N, B, s); }
   if (!m->want_dw) return;
@@ -1088,8 +1094,24 @@ int ral_attention_backward(const float* qkv, const float* o, const float* d_o, c
                            float* gtable, float* dqkv, int N, int H, int Len, int B, ral_stream s) {
   if (!qkv || !o || !d_o || !lse || !dqkv || (table && !gtable)) return fail("attention: null pointer");
   if (check_attn_args(N, H, table ? Len : 0, B)) return -1;
-  launch_attn_bwd(qkv, o, d_o, lse, table, gtable, dqkv, N, H, attn_head_group(N, H, table ? Len : 0, true), table ? Len : 0, B,
-                  (hipStream_t)s);
+  // scratch of the two-sweep kernels, (B, H, N, 2) floats: kept by the library for this stateless entry point and grown
+  // on demand (a growth synchronises the device; the handle-based path owns its scratch in the workspace instead)
+  static float* scratch = nullptr;
+  static size_t scratch_floats = 0;
+  float* stat2 = nullptr;
+  if (attn_bwd_uses_stat2(N, table ? Len : 0, table != nullptr)) {
+    const size_t need = (size_t)B * H * N * 2 + (size_t)B * 2 * H * 64;
+    if (need > scratch_floats) {
+      HIP_OK(hipDeviceSynchronize());
+      if (scratch) (void)hipFree(scratch);
+      scratch = nullptr; scratch_floats = 0;
+      HIP_OK(hipMalloc(reinterpret_cast<void**>(&scratch), need * sizeof(float)));
+      scratch_floats = need;
+    }
+    stat2 = scratch;
+  }
+  launch_attn_bwd(qkv, o, d_o, lse, table, gtable, dqkv, stat2, N, H, attn_head_group(N, H, table ? Len : 0, true),
+                  table ? Len : 0, B, (hipStream_t)s);
   HIP_OK(hipGetLastError());
   return 0;
 }

@@ -8,6 +8,7 @@
 #endif
 #include "ral_device.hpp"
 #include "ral_kernels.hpp"
+#include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
 
@@ -628,6 +629,181 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd(const float* __restrict__ q
 }
 
 // =================================================================================
+// B2v: attention backward on the scalar path (N >= 64), the counterpart of k_attn_fwd_v (ral_fwd.hip): two sweeps with
+// one row per lane and the other operand wave-uniform (s_load, SGPR pairs into packed FMAs, no LDS, no barrier, no
+// lane-group merge).  P is recomputed from q, k and the saved log-sum-exp.
+//   sweep Q  (k_attn_bwd_vq):  lane = query i, uniform key j:   s, dP, dS = P (dP - delta_i),  dq_i += dS k_j
+//                              also writes (-lse_i log2 e, -delta_i) for sweep KV and the R-wave table gradient
+//   sweep KV (k_attn_bwd_vkv): lane = key j, uniform query i:   s, dP, dS,  dk_j += dS q_i,  dv_j += P do_i
+// On gfx950 the fp32 MFMA and the vector ALU share the fp32 multipliers (no overlap on a SIMD: valu_probe.hip), so the
+// S / dP tiles of k_attn_bwd cost their full 34 cycles each on top of the vector work; here they are 2 packed FMAs + 1 add
+// per 64 scores (11 cycles) and the per-tile bookkeeping, the staging pass and the merges are gone.
+// =================================================================================
+RAL_DEV float wave_shfl_or0(float v, int src) {   // v of lane `src`, 0 when src is outside the wave
+  const float r = __shfl(v, src & 63);
+  return ((unsigned)src < 64u) ? r : 0.f;
+}
+
+template <bool BIAS>
+__global__ __launch_bounds__(256) void k_attn_bwd_vq(const float* __restrict__ qkv, const float* __restrict__ o_hm,
+                                                     const float* __restrict__ do_hm, const float* __restrict__ lse,
+                                                     const float* __restrict__ table, float* __restrict__ tpart,
+                                                     float* __restrict__ dqkv, float* __restrict__ stat2,
+                                                     int N, int H, int Len, int ntask) {
+  const int lane = threadIdx.x & 63;
+  const int QB = (N + 63) >> 6;
+  const int task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (task >= ntask) return;
+  const int qb = task % QB, wh = task / QB, head = wh % H, win = wh / H;
+  const int q = qb * 64 + lane, qc = q < N ? q : N - 1;
+  const size_t wbase = (size_t)win * 3 * H * N;
+  const float4* __restrict__ Q4 = reinterpret_cast<const float4*>(qkv) + wbase + (size_t)head * N;
+  const float4* __restrict__ K4 = reinterpret_cast<const float4*>(qkv) + wbase + (size_t)(H + head) * N;
+  const float4* __restrict__ V4 = reinterpret_cast<const float4*>(qkv) + wbase + (size_t)(2 * H + head) * N;
+  const size_t hq = ((size_t)win * H + head) * N + qc;
+  const float4 qv = f4scale(Q4[qc], RAL_LOG2E);
+  const float4 dov = reinterpret_cast<const float4*>(do_hm)[hq], ov = reinterpret_cast<const float4*>(o_hm)[hq];
+  const float nl = -lse[hq] * RAL_LOG2E, nd = -f4dot(dov, ov);
+  if (q < N) *reinterpret_cast<float2*>(stat2 + hq * 2) = make_float2(nl, nd);
+  float tval = 0.f, tacc = 0.f;      // R-wave table entry `lane` of this head (log2 units) and its gradient
+  const int off = (N - Len) >> 1, qi = q - off;
+  if constexpr (BIAS) {
+    if (lane < 2 * Len - 1) tval = table[lane * H + head] * RAL_LOG2E;
+  }
+  const f32x2 q01 = {qv.x, qv.y}, q23 = {qv.z, qv.w}, d01 = {dov.x, dov.y}, d23 = {dov.z, dov.w};
+  const f32x2 nl0 = {nl, 0.f}, nd0 = {nd, 0.f};
+  f32x2 dq01 = {0.f, 0.f}, dq23 = {0.f, 0.f};
+  auto body = [&](int kt, auto biased) {
+    float4 k[4], v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { k[j] = K4[kt + j]; v[j] = V4[kt + j]; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x2 k01 = {k[j].x, k[j].y}, k23 = {k[j].z, k[j].w};
+      f32x2 t = pk_fma(q01, k01, nl0);
+      t = pk_fma(q23, k23, t);
+      f32x2 u = pk_fma(d01, f32x2{v[j].x, v[j].y}, nd0);
+      u = pk_fma(d23, f32x2{v[j].z, v[j].w}, u);
+      float s = t[0] + t[1];
+      const float dp = u[0] + u[1];
+      bool inwin = false;
+      if constexpr (decltype(biased)::value) {
+        const int ki = kt + j - off;
+        const float b = __shfl(tval, qi - ki + Len - 1);
+        inwin = ki >= 0 && ki < Len && qi >= 0 && qi < Len;
+        if (inwin) s += b;
+      }
+      const float ds = __builtin_amdgcn_exp2f(s) * dp;
+      dq01 = pk_fma(splat2(ds), k01, dq01);
+      dq23 = pk_fma(splat2(ds), k23, dq23);
+      if constexpr (decltype(biased)::value) {
+        // table entry e = qi - ki + Len - 1 lives on lane e: it takes dS from the lane whose query is e + ki - Len + 1
+        const int ki = kt + j - off;
+        tacc += wave_shfl_or0(inwin ? ds : 0.f, lane + ki - Len + 1 + off - qb * 64);
+      }
+    }
+  };
+  const int b0 = BIAS ? (off & ~3) : N, b1 = BIAS ? ((off + Len + 3) & ~3) : N;
+  const bool qwin = BIAS && (qb * 64 < off + Len) && (qb * 64 + 64 > off);     // does this query block touch the window?
+  const int e0 = qwin ? b0 : N, e1 = qwin ? b1 : N;
+  for (int kt = 0; kt < e0; kt += 4) body(kt, std::false_type{});
+  for (int kt = e0; kt < e1; kt += 4) body(kt, std::true_type{});
+  for (int kt = e1; kt < N; kt += 4) body(kt, std::false_type{});
+  if (q < N)
+    *reinterpret_cast<float4*>(dqkv + (wbase + (size_t)head * N + q) * 4) =
+        make_float4(0.5f * dq01[0], 0.5f * dq01[1], 0.5f * dq23[0], 0.5f * dq23[1]);   // q = 0.5 (h Wq^T + b)
+  if constexpr (BIAS) {
+    // The table gradient of this (window, head, query block) goes to a partial buffer, (B, 2, H, 64) floats: the
+    // window is at most 32 wide, so it touches one or two query blocks (slot 0 / 1).  k_attn_table_reduce sums the
+    // partials over the windows: a handful of atomics per table entry instead of one per window (all of a launch's
+    // adds land in the table's 7 to 63 cache lines and serialise there: measured 350 ns per add at N = 64).
+    if (qwin) tpart[(((size_t)win * 2 + (qb - off / 64)) * H + head) * 64 + lane] = tacc;
+  }
+}
+
+// gtable[e][h] += sum over windows and slots of tpart[win][slot][h][e]; grid = chunks of windows, 256 threads
+__global__ __launch_bounds__(256) void k_attn_table_reduce(const float* __restrict__ tpart, float* __restrict__ gtable,
+                                                           int H, int Len, int nslot, int B, int wpb) {
+  const int ne = 2 * Len - 1, w0 = blockIdx.x * wpb, w1 = min(B, w0 + wpb);
+  for (int i = threadIdx.x; i < H * 64; i += blockDim.x) {
+    const int h = i >> 6, e = i & 63;
+    if (e >= ne) continue;
+    float acc = 0.f;
+    for (int w = w0; w < w1; ++w)
+      for (int sl = 0; sl < nslot; ++sl) acc += tpart[(((size_t)w * 2 + sl) * H + h) * 64 + e];
+    atomicAdd(gtable + e * H + h, acc);
+  }
+}
+
+template <bool BIAS>
+__global__ __launch_bounds__(256) void k_attn_bwd_vkv(const float* __restrict__ qkv, const float* __restrict__ do_hm,
+                                                      const float* __restrict__ stat2, const float* __restrict__ table,
+                                                      float* __restrict__ dqkv, int N, int H, int Len, int ntask) {
+  const int lane = threadIdx.x & 63;
+  const int KB = (N + 63) >> 6;
+  const int task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (task >= ntask) return;
+  const int kb = task % KB, wh = task / KB, head = wh % H, win = wh / H;
+  const int kidx = kb * 64 + lane, kc = kidx < N ? kidx : N - 1;
+  const size_t wbase = (size_t)win * 3 * H * N;
+  const float4* __restrict__ Q4 = reinterpret_cast<const float4*>(qkv) + wbase + (size_t)head * N;
+  const float4* __restrict__ K4 = reinterpret_cast<const float4*>(qkv) + wbase + (size_t)(H + head) * N;
+  const float4* __restrict__ V4 = reinterpret_cast<const float4*>(qkv) + wbase + (size_t)(2 * H + head) * N;
+  const size_t hq0 = ((size_t)win * H + head) * N;
+  const float4* __restrict__ D4 = reinterpret_cast<const float4*>(do_hm) + hq0;
+  const float2* __restrict__ S2 = reinterpret_cast<const float2*>(stat2) + hq0;
+  const float4 kv = f4scale(K4[kc], RAL_LOG2E), vv = V4[kc];
+  const f32x2 k01 = {kv.x, kv.y}, k23 = {kv.z, kv.w}, v01 = {vv.x, vv.y}, v23 = {vv.z, vv.w};
+  float tval = 0.f;
+  const int off = (N - Len) >> 1, ki = kidx - off;
+  if constexpr (BIAS) {
+    if (lane < 2 * Len - 1) tval = table[lane * H + head] * RAL_LOG2E;
+  }
+  f32x2 dk01 = {0.f, 0.f}, dk23 = {0.f, 0.f}, dv01 = {0.f, 0.f}, dv23 = {0.f, 0.f};
+  auto body = [&](int qt, auto biased) {
+    float4 qr[4], dr[4];
+    float2 st[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { qr[j] = Q4[qt + j]; dr[j] = D4[qt + j]; st[j] = S2[qt + j]; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x2 qa = {qr[j].x, qr[j].y}, qb2 = {qr[j].z, qr[j].w}, da = {dr[j].x, dr[j].y}, db = {dr[j].z, dr[j].w};
+      f32x2 t = k01 * qa;
+      t = pk_fma(k23, qb2, t);
+      f32x2 u = v01 * da;
+      u = pk_fma(v23, db, u);
+      float hs = t[0] + t[1], hd = u[0] + u[1];
+      asm volatile("" : "+v"(hs), "+v"(hd));      // (keeps the two horizontal adds scalar: packed, they need three moves)
+      f32x2 sd = {hs, hd};
+      sd += f32x2{st[j].x, st[j].y};              // (s - lse, dP - delta) in one packed add with the SGPR pair
+      if constexpr (decltype(biased)::value) {
+        const int qi = qt + j - off;              // uniform
+        const float b = __shfl(tval, qi - ki + Len - 1);
+        if (ki >= 0 && ki < Len && qi >= 0 && qi < Len) sd[0] += b;
+      }
+      const float p = __builtin_amdgcn_exp2f(sd[0]);
+      const float ds = p * sd[1];
+      dk01 = pk_fma(splat2(ds), qa, dk01);
+      dk23 = pk_fma(splat2(ds), qb2, dk23);
+      dv01 = pk_fma(splat2(p), da, dv01);
+      dv23 = pk_fma(splat2(p), db, dv23);
+    }
+  };
+  const int b0 = BIAS ? (off & ~3) : N, b1 = BIAS ? ((off + Len + 3) & ~3) : N;
+  const bool kwin = BIAS && (kb * 64 < off + Len) && (kb * 64 + 64 > off);
+  const int e0 = kwin ? b0 : N, e1 = kwin ? b1 : N;
+  for (int qt = 0; qt < e0; qt += 4) body(qt, std::false_type{});
+  for (int qt = e0; qt < e1; qt += 4) body(qt, std::true_type{});
+  for (int qt = e1; qt < N; qt += 4) body(qt, std::false_type{});
+  if (kidx < N) {
+    float4* dk = reinterpret_cast<float4*>(dqkv) + wbase + (size_t)(H + head) * N + kidx;
+    float4* dv = reinterpret_cast<float4*>(dqkv) + wbase + (size_t)(2 * H + head) * N + kidx;
+    *dk = make_float4(dk01[0], dk01[1], dk23[0], dk23[1]);
+    *dv = make_float4(dv01[0], dv01[1], dv23[0], dv23[1]);
+  }
+}
+
+// =================================================================================
 // B1: QKV projection + LN1 backward:  dh = dqkv Wqkv;  dx = dx1 + sqrt(C) * LN1bwd(dh)
 //   grads: bqkv, ln1 w/b.   `extra` (optional) is added to dx (skip-connection gradient).
 // =================================================================================
@@ -1076,8 +1252,35 @@ size_t attn_bwd_lds(int N, int HG, int Len) {
   return ((size_t)4 * HG * N * 4 + (size_t)2 * HG * N + (Len > 0 ? (size_t)2 * (2 * Len - 1) * HG : 0) + 4) * sizeof(float);
 }
 
+// Window lengths [lo, hi] that take the scalar-path sweeps.  Measured at batch 2048 (tools/attn_bench.py, us per launch,
+// MFMA-tile kernel vs scalar path): N = 512: 790 / 853, 256: 446 / 464, 128: 285 / 265, 64: 208 / 155.
+// RAL_ATTN_BWD_V="lo:hi" overrides (0:0 = never).
+bool attn_bwd_uses_stat2(int N, int Len, bool table) {
+  static int lo = 64, hi = 128;
+  static const bool init = [] { if (const char* v = getenv("RAL_ATTN_BWD_V")) sscanf(v, "%d:%d", &lo, &hi); return true; }();
+  (void)init;
+  return N >= lo && N <= hi && N >= 64 && N % 4 == 0 && (!table || 2 * Len - 1 <= 64);
+}
+
 void launch_attn_bwd(const float* qkv, const float* o_hm, const float* do_hm, const float* lse, const float* table,
-                     float* gtable, float* dqkv, int N, int H, int HG, int Len, int B, hipStream_t s) {
+                     float* gtable, float* dqkv, float* stat2, int N, int H, int HG, int Len, int B, hipStream_t s) {
+  // the two scalar-path sweeps; stat2 is scratch: (B, H, N, 2) floats handed from the query sweep to the key / value
+  // sweep, followed by (B, 2, H, 64) floats of R-wave table-gradient partials
+  if (stat2 && attn_bwd_uses_stat2(N, Len, table != nullptr)) {
+    const int ntask = B * H * ((N + 63) / 64), grid = (ntask + 3) / 4;
+    if (table) {
+      float* tpart = stat2 + (size_t)B * H * N * 2;
+      const int off = (N - Len) / 2, nslot = (off + Len - 1) / 64 - off / 64 + 1;
+      k_attn_bwd_vq<true><<<grid, 256, 0, s>>>(qkv, o_hm, do_hm, lse, table, tpart, dqkv, stat2, N, H, Len, ntask);
+      k_attn_bwd_vkv<true><<<grid, 256, 0, s>>>(qkv, do_hm, stat2, table, dqkv, N, H, Len, ntask);
+      const int wpb = 32;
+      k_attn_table_reduce<<<(B + wpb - 1) / wpb, 256, 0, s>>>(tpart, gtable, H, Len, nslot, B, wpb);
+    } else {
+      k_attn_bwd_vq<false><<<grid, 256, 0, s>>>(qkv, o_hm, do_hm, lse, nullptr, nullptr, dqkv, stat2, N, H, 0, ntask);
+      k_attn_bwd_vkv<false><<<grid, 256, 0, s>>>(qkv, do_hm, stat2, nullptr, dqkv, N, H, 0, ntask);
+    }
+    return;
+  }
   static const int split_env = getenv("RAL_ATTN_SPLIT") ? atoi(getenv("RAL_ATTN_SPLIT")) : 2;   // see launch_attn_fwd
   int split = split_env;
   while (split > 1 && (HG % split != 0 || N % 32 != 0)) split /= 2;

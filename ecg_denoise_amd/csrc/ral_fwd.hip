@@ -10,6 +10,7 @@
 #endif
 #include "ral_device.hpp"
 #include "ral_kernels.hpp"
+#include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
 
@@ -253,7 +254,10 @@ __global__ __launch_bounds__(512, (QT >= 4 ? 3 : 4)) void k_attn_fwd(const float
 // K2v: the same attention with one QUERY PER LANE and the keys streamed through the SCALAR path (N >= 64).
 // A wave owns 64 queries of one (window, head); key / value rows are wave-uniform, so they come in by s_load
 // (scalar cache, no LDS, no barrier, no staging pass) and enter the FMAs as SGPR operands:
-//   per key and lane:  s = q.k - m  (4 FMA, -m is the first addend)   p = exp2(s)   l += p   o += p v  (4 FMA)
+//   per key and lane:  s = q.k - m  (2 packed FMA + 1 add, -m is the first addend)   p = exp2(s)   l += p
+//                      o += p v  (2 packed FMA)
+// Packed fp32 instructions take an SGPR PAIR at full rate (4.3 cycles per 128 FMAs), whereas v_fma_f32 with an SGPR
+// operand drops to half rate (4.2 cycles per 64, tools/diag/valu_probe.hip): every product here is a v_pk_* one.
 // Everything a query needs is lane-private, so there is no lane-group merge, and the output rows leave as one
 // coalesced 16-byte store per lane.  On gfx950 the fp32 MFMA shares the fp32 multipliers with the vector ALU (a tile of
 // k_attn_fwd costs its VALU time PLUS its MFMA time, tools/diag/valu_probe.hip), so doing q.k on the vector ALU costs
@@ -305,17 +309,18 @@ __global__ __launch_bounds__(256) void k_attn_fwd_v(const float* __restrict__ qk
   }
   const float mq = sqrtf(f4dot(qv, qv)) * sqrtf(km) * 1.0000002f + bmax;
   const float nm = -mq;
-  float l = 0.f, o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+  float l = 0.f;
+  f32x2 o01 = {0.f, 0.f}, o23 = {0.f, 0.f};
+  const f32x2 q01 = {qv.x, qv.y}, q23 = {qv.z, qv.w}, nm0 = {nm, 0.f};
   auto body = [&](int kt, auto biased) {     // 4 keys; K4 / V4 rows are wave-uniform (scalar loads)
     float4 k[4], v[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { k[j] = K4[kt + j]; v[j] = V4[kt + j]; }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      float s = fmaf(qv.x, k[j].x, nm);
-      s = fmaf(qv.y, k[j].y, s);
-      s = fmaf(qv.z, k[j].z, s);
-      s = fmaf(qv.w, k[j].w, s);
+      f32x2 t = pk_fma(q01, f32x2{k[j].x, k[j].y}, nm0);
+      t = pk_fma(q23, f32x2{k[j].z, k[j].w}, t);
+      float s = t[0] + t[1];
       if constexpr (decltype(biased)::value) {
         const int ki = kt + j - off;                       // uniform; in the window for these chunks except at ragged ends
         const float b = __shfl(tval, qi - ki + Len - 1);   // (lane-indexed gather of the table entry)
@@ -323,7 +328,8 @@ __global__ __launch_bounds__(256) void k_attn_fwd_v(const float* __restrict__ qk
       }
       const float p = __builtin_amdgcn_exp2f(s);
       l += p;
-      o0 = fmaf(p, v[j].x, o0); o1 = fmaf(p, v[j].y, o1); o2 = fmaf(p, v[j].z, o2); o3 = fmaf(p, v[j].w, o3);
+      o01 = pk_fma(splat2(p), f32x2{v[j].x, v[j].y}, o01);
+      o23 = pk_fma(splat2(p), f32x2{v[j].z, v[j].w}, o23);
     }
   };
   const int b0 = BIAS ? (off & ~3) : N, b1 = BIAS ? ((off + Len + 3) & ~3) : N;
@@ -332,8 +338,8 @@ __global__ __launch_bounds__(256) void k_attn_fwd_v(const float* __restrict__ qk
   for (int kt = b1; kt < N; kt += 4) body(kt, std::false_type{});
   float mfin = mq;
   if (__any(!(l > 1e-30f))) {   // a row underflowed under its bound: exact running-max recurrence for the whole wave
-    float mx = -INFINITY;
-    l = 0.f; o0 = o1 = o2 = o3 = 0.f;
+    float mx = -INFINITY, o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+    l = 0.f;
     for (int kt = 0; kt < N; ++kt) {
       const float4 k = K4[kt], v = V4[kt];
       float s = fmaf(qv.x, k.x, fmaf(qv.y, k.y, fmaf(qv.z, k.z, qv.w * k.w)));
@@ -349,11 +355,12 @@ __global__ __launch_bounds__(256) void k_attn_fwd_v(const float* __restrict__ qk
       o0 = fmaf(o0, corr, p * v.x); o1 = fmaf(o1, corr, p * v.y); o2 = fmaf(o2, corr, p * v.z); o3 = fmaf(o3, corr, p * v.w);
     }
     mfin = mx;
+    o01 = f32x2{o0, o1}; o23 = f32x2{o2, o3};
   }
   if (q < N) {
     const float inv = 1.0f / l;
     const size_t hq = ((size_t)win * H + head) * N + q;
-    *reinterpret_cast<float4*>(o_hm + hq * 4) = make_float4(o0 * inv, o1 * inv, o2 * inv, o3 * inv);
+    *reinterpret_cast<float4*>(o_hm + hq * 4) = make_float4(o01[0] * inv, o01[1] * inv, o23[0] * inv, o23[1] * inv);
     if (lse) lse[hq] = (mfin + __builtin_amdgcn_logf(l)) * RAL_LN2;   // natural-log units
   }
 }
@@ -523,9 +530,13 @@ size_t attn_fwd_lds(int N, int HG, int Len) {
 
 void launch_attn_fwd(const float* qkv, float* o_hm, float* lse, const float* table, int N, int H, int HG, int Len,
                      int B, hipStream_t s) {
-  // N >= 64: query-per-lane kernel on the scalar path (RAL_ATTN_FWD_V=0 keeps the MFMA-tile kernel for comparison)
-  static const int vmin = getenv("RAL_ATTN_FWD_V") ? (atoi(getenv("RAL_ATTN_FWD_V")) ? atoi(getenv("RAL_ATTN_FWD_V")) : (1 << 30)) : 64;
-  if (N >= vmin && N % 4 == 0 && (!table || 2 * Len - 1 <= 64)) {
+  // Window lengths [lo, hi] that take the query-per-lane kernel on the scalar path.  Measured at batch 2048
+  // (tools/attn_bench.py, us per launch, MFMA-tile kernel vs scalar path): N = 512: 322 / 333, 256: 184 / 172,
+  // 128: 122 / 90, 64: 91 / 51.  RAL_ATTN_FWD_V="lo:hi" overrides (0:0 = never).
+  static int vlo = 64, vhi = 256;
+  static const bool vinit = [] { if (const char* v = getenv("RAL_ATTN_FWD_V")) sscanf(v, "%d:%d", &vlo, &vhi); return true; }();
+  (void)vinit;
+  if (N >= vlo && N <= vhi && N >= 64 && N % 4 == 0 && (!table || 2 * Len - 1 <= 64)) {
     const int ntask = B * H * ((N + 63) / 64);
     if (table) k_attn_fwd_v<true><<<(ntask + 3) / 4, 256, 0, s>>>(qkv, o_hm, lse, table, N, H, Len, ntask);
     else k_attn_fwd_v<false><<<(ntask + 3) / 4, 256, 0, s>>>(qkv, o_hm, lse, table, N, H, 0, ntask);

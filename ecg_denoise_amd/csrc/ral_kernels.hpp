@@ -61,8 +61,9 @@ bool launch_mlp_bwd(int C, int nch, const float* dx2, const float* x1, const flo
                     const BlockP& wt, const BlockP& gr, float* dupre, float* dx1, float* do_hm, float* a2c0, int N, int B,
                     bool want_dw, hipStream_t s);
 size_t attn_bwd_lds(int N, int HG, int Len);
+bool attn_bwd_uses_stat2(int N, int Len, bool table);   // does launch_attn_bwd need its (B, H, N, 2) scratch for this shape?
 void launch_attn_bwd(const float* qkv, const float* o_hm, const float* do_hm, const float* lse, const float* table,
-                     float* gtable, float* dqkv, int N, int H, int HG, int Len, int B, hipStream_t s);
+                     float* gtable, float* dqkv, float* stat2, int N, int H, int HG, int Len, int B, hipStream_t s);
 size_t qkv_bwd_lds(int C, int N);
 void launch_qkv_bwd(int C, const float* dqkv, const float* x, const float* pe, const float* dx1, const float* extra,
                     const BlockP& w, const BlockP& wt, const BlockP& gr, float* dx, int N, int B, hipStream_t s);

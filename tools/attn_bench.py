@@ -76,7 +76,11 @@ def main():
     L = _lib.lib()
     tot_f = tot_b = fl_f = fl_b = 0.0
     rows = []
-    for N, H, Len, blocks in LEVELS:
+    only = os.environ.get("ATTN_ONLY", "")                 # "fwd" / "bwd": time one direction only (PMC runs)
+    levels = [LEVELS[int(i)] for i in os.environ["ATTN_LEVELS"].split(",")] if os.environ.get("ATTN_LEVELS") else LEVELS
+    for N, H, Len, blocks in levels:
+        if os.environ.get("ATTN_NOTABLE"):
+            Len = 0
         err = check(N, H, Len)
         qkv = torch.randn(B, 3 * H, N, 4, device=DEV)
         do = torch.randn(B, H, N, 4, device=DEV)
@@ -87,6 +91,9 @@ def main():
         bwd = lambda: _lib.check(L.ral_attention_backward(vp(qkv), vp(o), vp(do), vp(lse), vp(table), vp(gt), vp(dqkv), N, H, Len, B, stream()))
         out = {}
         for name, fn, mult in (("fwd", fwd, 4.0), ("bwd", bwd, 10.0)):
+            if only and name != only:
+                out[name] = (1e-9, 0.0)
+                continue
             for _ in range(3):
                 fn()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -76,6 +76,93 @@ __global__ void k_probe(float* out, long long* cyc, float seed, int iters) {
       for (int r = 0; r < REP / 8; ++r)
 #pragma unroll
         for (int i = 0; i < 8; ++i) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "v"(m2));
+    } else if (KIND == 9 || KIND == 10 || KIND == 11) {   // forward-tile VALU mix beside bf16 MFMAs: 9 = none, 10 = one 16x16x32 bf16, 11 = two
+      typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+      bf16x8 ab; for (int i = 0; i < 8; ++i) ab[i] = (__bf16)a[i];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (KIND >= 10) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, ab, acc, 0, 0, 0);
+        if (KIND >= 11) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, ab, acc, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("v_exp_f32 %0, %0" : "+v"(a[4 + i]));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(c2));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p[2 + (i & 3)]) : "v"(m2), "v"(c2));
+      }
+    } else if (KIND == 12) {   // 16 bare bf16 mfma 16x16x32
+      typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+      bf16x8 ab; for (int i = 0; i < 8; ++i) ab[i] = (__bf16)a[i];
+      f32x4 ac[4] = {acc, acc, acc, acc};
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ac[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, ab, ac[i], 0, 0, 0);
+      acc = ac[0] + ac[1] + ac[2] + ac[3];
+    } else if (KIND == 13) {   // fma with an SGPR operand
+      const float sm = __builtin_amdgcn_readfirstlane(m);
+#pragma unroll
+      for (int r = 0; r < REP / 16; ++r)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "s"(sm), "v"(c));
+    } else if (KIND == 14) {   // pk_fma with an SGPR-pair operand
+      f32x2 sm2;
+      sm2[0] = __builtin_amdgcn_readfirstlane(m); sm2[1] = __builtin_amdgcn_readfirstlane(m * 1.0000001f);
+#pragma unroll
+      for (int r = 0; r < REP / 8; ++r)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "s"(sm2), "v"(c2));
+    } else if (KIND == 17 || KIND == 18) {   // pk_fma with 16 DIFFERENT SGPR pairs (17), or the same operands as VGPR pairs (18)
+      f32x2 sp[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { sp[i][0] = __builtin_amdgcn_readfirstlane(m + i * 1e-8f); sp[i][1] = __builtin_amdgcn_readfirstlane(m - i * 1e-8f); }
+#pragma unroll
+      for (int r = 0; r < REP / 16; ++r)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          if (KIND == 17) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i & 7]) : "s"(sp[i]), "v"(c2));
+          else asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i & 7]) : "v"(sp[i]), "v"(c2));
+        }
+    } else if (KIND == 19) {   // the forward loop body of k_attn_fwd_v: 16 pk_fma (SGPR pairs) + 8 add + 4 exp, registers only
+      f32x2 sp[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { sp[i][0] = __builtin_amdgcn_readfirstlane(m + i * 1e-8f); sp[i][1] = __builtin_amdgcn_readfirstlane(m - i * 1e-8f); }
+      f32x2 t[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(t[j]) : "v"(p[0]), "s"(sp[2 * j]), "v"(c2));
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(t[j]) : "v"(p[1]), "s"(sp[2 * j + 1]));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float sv;
+        asm volatile("v_add_f32 %0, %1, %2" : "=v"(sv) : "v"(t[j][0]), "v"(t[j][1]));
+        asm volatile("v_exp_f32 %0, %0" : "+v"(sv));
+        asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[0]) : "v"(sv));
+        f32x2 pv = {sv, sv};
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p[2]) : "v"(pv), "s"(sp[8 + 2 * j]));
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p[3]) : "v"(pv), "s"(sp[9 + 2 * j]));
+      }
+    } else if (KIND == 15) {   // pk_fma, VGPR pair broadcast through op_sel (low half of src0 for both lanes)
+#pragma unroll
+      for (int r = 0; r < REP / 8; ++r)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(p[i]) : "v"(m2), "v"(c2));
+    } else if (KIND == 16) {   // roles: waves 0-3 of the workgroup issue fp32 MFMAs only, waves 4-7 (same SIMDs) the VALU mix only
+      if (((threadIdx.x >> 8) & 1) == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], a[1], acc, 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) asm volatile("v_exp_f32 %0, %0" : "+v"(a[4 + i]));
+#pragma unroll
+          for (int i = 0; i < 2; ++i) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(c2));
+#pragma unroll
+          for (int i = 0; i < 8; ++i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p[2 + (i & 3)]) : "v"(m2), "v"(c2));
+        }
+      }
     } else if (KIND == 8) {   // 16 bare mfma 16x16x4 f32 (4 accumulators)
       f32x4 ac[4] = {acc, acc, acc, acc};
 #pragma unroll
@@ -131,6 +218,17 @@ int main() {
   run<6>("v_mul_f32", REP);
   run<7>("v_pk_mul_f32", REP);
   run<8>("v_mfma_f32_16x16x4_f32 (per mfma)", 16);
+  run<12>("v_mfma_f32_16x16x32_bf16 (per mfma)", 16);
+  run<13>("v_fma_f32 with an SGPR operand", REP);
+  run<14>("v_pk_fma_f32 with an SGPR-pair operand", REP);
+  run<15>("v_pk_fma_f32 op_sel broadcast", REP);
+  run<17>("v_pk_fma_f32, 16 different SGPR pairs", REP);
+  run<18>("v_pk_fma_f32, the same as VGPR pairs", REP);
+  run<19>("k_attn_fwd_v loop body (per 4 keys)", 1);
+  run<16>("roles: 4 mfma f32 (waves 0-3) | 4 VALU tiles (4-7)", 4);
+  run<9>("fwd tile packed, no mfma", 4);
+  run<10>("fwd tile packed + 1 bf16 mfma", 4);
+  run<11>("fwd tile packed + 2 bf16 mfma", 4);
   run<4>("fwd tile packed (per tile: 4exp 2pkadd 8pkfma 1mfma)", 4);
   run<5>("fwd tile scalar (per tile: 4exp 4add 16fma 1mfma)", 4);
   return 0;
