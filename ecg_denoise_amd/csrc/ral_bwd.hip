@@ -1252,14 +1252,17 @@ size_t attn_bwd_lds(int N, int HG, int Len) {
   return ((size_t)4 * HG * N * 4 + (size_t)2 * HG * N + (Len > 0 ? (size_t)2 * (2 * Len - 1) * HG : 0) + 4) * sizeof(float);
 }
 
-// Window lengths [lo, hi] that take the scalar-path sweeps.  Measured at batch 2048 (tools/attn_bench.py, us per launch,
-// MFMA-tile kernel vs scalar path): N = 512: 790 / 853, 256: 446 / 464, 128: 285 / 265, 64: 208 / 155.
-// RAL_ATTN_BWD_V="lo:hi" overrides (0:0 = never).
+// Window lengths that take the scalar-path sweeps.  Measured at batch 2048 (tools/attn_bench.py, us per launch, MFMA-tile
+// kernel vs scalar path).  Without an R-wave table: N = 512: 790 / 853, 256: 446 / 464, 128: 285 / 265, 64: 208 / 155;
+// with one (the in-window keys cost two lane gathers each, plus the partial-sum pass): 128: 285 / 293, 64: 208 / 192.
+// So: N <= 128 without a table, N = 64 with one.  RAL_ATTN_BWD_V="lo:hi" forces a range for both cases (0:0 = never).
 bool attn_bwd_uses_stat2(int N, int Len, bool table) {
-  static int lo = 64, hi = 128;
+  static int lo = -1, hi = -1;
   static const bool init = [] { if (const char* v = getenv("RAL_ATTN_BWD_V")) sscanf(v, "%d:%d", &lo, &hi); return true; }();
   (void)init;
-  return N >= lo && N <= hi && N >= 64 && N % 4 == 0 && (!table || 2 * Len - 1 <= 64);
+  if (N < 64 || N % 4 != 0 || (table && 2 * Len - 1 > 64)) return false;
+  if (lo >= 0) return N >= lo && N <= hi;
+  return N <= (table ? 64 : 128);
 }
 
 void launch_attn_bwd(const float* qkv, const float* o_hm, const float* do_hm, const float* lse, const float* table,
