@@ -988,7 +988,11 @@ int ral_adam_step(ral_handle* h, double lr, double beta1, double beta2, double e
 }
 
 int ral_set_option(ral_handle* h, const char* key, int value) {
-  if (!h || h->kind != 0) return fail("options exist for RA-LENet handles only");
+  if (!h || !key) return fail("null handle or key");
+  if (h->kind == 1) {
+    if (unet_set_option(h->u, key, value)) return fail("unknown U-Net option %s", key);
+    return 0;
+  }
   RalModel* m = h->m;
   if (!strcmp(key, "lanes")) { m->n_lanes = value < 1 ? 1 : (value > MAX_LANES ? MAX_LANES : value); return 0; }
   if (!strcmp(key, "side_stream")) { m->side_stream = value != 0; return 0; }

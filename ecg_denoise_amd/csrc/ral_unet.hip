@@ -8,9 +8,13 @@
 // the gradient at its BatchNorm output, applies the BatchNorm-backward correction on load (needs the
 // two global sums the PRODUCING kernel accumulated), and emits the gradient at its producers'
 // BatchNorm outputs together with their sums.
+#ifdef RAL_STAMP_TU_UNET
+#define RAL_STAMP_HERE
+#endif
 #include "ral_unet.hpp"
 
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -699,6 +703,326 @@ __global__ void k_unet_bn_grads(BnGradAll u, double share) {
 }
 
 // =================================================================================
+// Fused inference forward (eval-mode BatchNorm): ONE kernel for the whole network.  A window's tensors are
+// leads*L floats each, so all eleven stages of a window live in LDS (53 KB at L = 512: three workgroups per CU);
+// HBM sees the input window once and the output window once (8 KB per window at 2 x 512 instead of ~100 KB of
+// stage-granular traffic).  The seven wide layers (8->16 ... 16->8 channels) are GEMMs on the fp32 MFMA:
+//   out[co][n] = sum_{ci,k} W[co][(ci,k)] X[n][(ci,k)]     X = im2col rows, written by the PRODUCING layer's epilogue
+// (the epilogue applies bias / LeakyReLU / BatchNorm scale-shift / skip and scatters each value to the 1-3 im2col
+// slots that read it); a transposed conv is two such GEMMs, one per output parity, over one shared row layout
+// (row m = [in[m-1], in[m]] per channel: parity 0 reads row n, parity 1 row n + 1).  The four narrow layers
+// (2->4, 4->8, 8->4, 4->2 channels) stay on the vector ALU.  Weights are re-packed into the GEMM layouts, and the
+// BatchNorm running statistics folded into (scale, shift), by k_unet_pack right before (10 528 floats).
+// Reference: model/UNet.py:46-141.
+// =================================================================================
+RAL_STAMPS_DEFINE(ral_debug_stamps_unet)
+
+namespace uinf {
+constexpr int PW2 = 0, PW3 = 512, PW4 = 2048, PW5 = 3072, PW6 = 6144, PW7 = 7168, PW8 = 9216;   // GEMM weights (M x K)
+constexpr int PW0 = 9728, PW1 = 9760, PW9 = 9856, PW10 = 9984;                                  // vector-ALU layers
+constexpr int PB = 10016;     // biases: b0@0 b1@4 b2@12 b3@28 b4@60 b5@92 b6@124 b7@156 b8@172 b9@180 b10@184
+constexpr int PS = 10208;     // BatchNorm (scale[C], shift[C]) per layer at SO[i]
+constexpr int PTOT = 10528;
+constexpr int BO[11] = {0, 4, 12, 28, 60, 92, 124, 156, 172, 180, 184};
+constexpr int SO[10] = {0, 8, 24, 56, 120, 184, 248, 280, 296, 304};
+constexpr int BNC[10] = {4, 8, 16, 32, 32, 32, 16, 8, 4, 2};
+}  // namespace uinf
+
+struct UPackArgs {
+  const float* params; const float* state; float* pk;
+  int64_t w[11], b[11], bnw[10], bnb[10], run[10];
+  int leads;
+};
+
+__global__ __launch_bounds__(256) void k_unet_pack(UPackArgs a) {   // one packed float per thread
+  using namespace uinf;
+  const float* P = a.params;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= PTOT) return;
+  const int lead16 = 16 * a.leads;
+  float v = 0.f;
+  // conv k3: PyTorch (cout, cin, 3) is already the GEMM row layout [(ci, k)]; layer 2 is padded from K = 24 to 32
+  if (i < PW3) { const int r = i >> 5, c = i & 31; v = c < 24 ? P[a.w[2] + r * 24 + c] : 0.f; }
+  else if (i < PW4) v = P[a.w[3] + (i - PW3)];
+  else if (i < PW5) v = P[a.w[4] + (i - PW4)];
+  else if (i < PW6) v = P[a.w[5] + (i - PW5)];
+  else if (i < PW7) v = P[a.w[6] + (i - PW6)];
+  // transposed conv (cin, cout, 4): out[2n] = w[..][1] in[n] + w[..][3] in[n-1];  out[2n+1] = w[..][2] in[n] + w[..][0] in[n+1]
+  // column (ci, t) of im2col row m holds in[m - 1 + t]; parity 0 reads row n, parity 1 row n + 1
+  else if (i < PW8) {
+    const int j = i - PW7, par = j / 1024, co = (j / 64) % 16, ci = (j % 64) / 2, t = j & 1;
+    v = P[a.w[7] + (ci * 16 + co) * 4 + (par == 0 ? (t ? 1 : 3) : (t ? 0 : 2))];
+  } else if (i < PW0) {
+    const int j = i - PW8, par = j / 256, co = (j / 32) % 8, ci = (j % 32) / 2, t = j & 1;
+    v = P[a.w[8] + (ci * 8 + co) * 4 + (par == 0 ? (t ? 1 : 3) : (t ? 0 : 2))];
+  }
+  else if (i < PW1) { const int j = i - PW0; v = j < 4 * a.leads * 3 ? P[a.w[0] + j] : 0.f; }
+  else if (i < PW9) v = P[a.w[1] + (i - PW1)];
+  else if (i < PW10) v = P[a.w[9] + (i - PW9)];
+  else if (i < PB) { const int j = i - PW10; v = j < lead16 ? P[a.w[10] + j] : 0.f; }
+  else if (i < PS) {
+    const int j = i - PB;
+    const int bc[11] = {4, 8, 16, 32, 32, 32, 32, 16, 8, 4, a.leads};
+    for (int l = 0; l < 11; ++l)
+      if (j >= BO[l] && j < BO[l] + bc[l]) v = P[a.b[l] + (j - BO[l])];
+  } else {
+    const int j = i - PS;
+    for (int l = 0; l < 10; ++l) {
+      const int C = l == 9 ? a.leads : BNC[l];
+      if (j >= SO[l] && j < SO[l] + 2 * C) {
+        const int c = (j - SO[l]) % C;
+        const float sc = P[a.bnw[l] + c] / sqrtf(a.state[a.run[l] + C + c] + 1e-5f);   // (as src_coeffs, NORM_RUNNING)
+        v = (j - SO[l]) < C ? sc : P[a.bnb[l] + c] - a.state[a.run[l] + c] * sc;
+      }
+    }
+  }
+  a.pk[i] = v;
+}
+
+// one 16 x 16 output tile of a GEMM layer: rows m0.. of W (M x K, global), im2col rows t0.. of Xs (LDS, stride ldx)
+template <int K, class Epi>
+RAL_DEV void uinf_tile(const float* __restrict__ W, int M, const float* Xs, int ldx, int m0, int t0, Epi epi) {
+  f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+  gemm_wx<K, 1, false, LAY_TOK>(W, K, m0, M, Xs, ldx, t0, acc);
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int row0 = m0 + 4 * g;
+  if (row0 < M) epi(row0, t0 + r, tofloat4(acc[0]));
+}
+
+RAL_DEV float4 f4lrelu(float4 v) { return make_float4(lrelu01(v.x), lrelu01(v.y), lrelu01(v.z), lrelu01(v.w)); }
+RAL_DEV float4 f4fma(float4 a, float4 b, float4 c) { return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w)); }
+
+template <int LEADS>
+__global__ __launch_bounds__(256) void k_unet_infer(const float* __restrict__ pk, const float* __restrict__ x,
+                                                    float* __restrict__ y, int L, int B) {
+  using namespace uinf;
+  extern __shared__ float4 smem4[];
+  const int N1 = L >> 1, N2 = L >> 2, N3 = L >> 3, N4 = L >> 4;
+  constexpr int LD2 = 36, LD3 = 52, LD4 = 36, LD5 = 100, LD7 = 68, LD8 = 36;   // im2col row strides (K + 4)
+  const int LP0 = N1 + 8;                      // E0c rows carry a zero halo of 4 on both sides
+  float* E0c = reinterpret_cast<float*>(smem4);          // e0, channel-major 4 x LP0 (skip of the last-but-one layer)
+  float* RA = E0c + 4 * LP0;                             // X2 (N3 x 36) | later X5 (N4 x 100)
+  float* S1 = RA + N4 * LD5;                             // e1, token-major N2 x 8
+  float* S2 = S1 + N2 * 8;                               // e2, token-major N3 x 16
+  float* RB = S2 + N3 * 16;                              // x staging (LEADS x (L + 8)) | X3 (N4 x 52) | later X7 ((N4 + 1) x 68)
+  float* S3 = RB + (N4 + 1) * LD7;                       // e3 = X4, token-major N4 x 36 | later d2, channel-major 4 x N1
+  float* RC = S3 + N4 * LD4;                             // X6 (N4 x 36) | later d1, channel-major 8 x N2
+  float* X8 = RC + N4 * LD4;                             // (N3 + 1) x 36
+  float* WV = X8 + (N3 + 1) * LD8;                       // weights of the four vector-ALU layers (PW0 .. PW10 + 32)
+  const int tid = threadIdx.x, wave = tid >> 6;
+  for (int i = tid; i < 288; i += 256) WV[i] = pk[PW0 + i];
+  for (int i = tid; i < 32; i += 256) { const int c = i >> 3, h = i & 7; E0c[c * LP0 + (h < 4 ? h : N1 + h)] = 0.f; }
+  for (int i = tid; i < 16; i += 256) { X8[i * 2] = 0.f; X8[N3 * LD8 + i * 2 + 1] = 0.f; }   // in[-1] and in[N3] of the shared rows
+  const float* wv0 = WV, *wv1 = WV + (PW1 - PW0), *wv9 = WV + (PW9 - PW0), *wv10 = WV + (PW10 - PW0);
+  const float* bias = pk + PB;
+  const float* bns = pk + PS;
+  __syncthreads();
+  RAL_STAMP_INIT();
+  for (int win = blockIdx.x; win < B; win += gridDim.x) {
+    RAL_STAMP_AT(0);
+    // ---- stage x (zero halo), clear the im2col rows of layer 2 (their K padding and the in[-1] slot must be zeros) ----
+    {
+      const int LPX = L + 8;
+      const float* xw = x + (size_t)win * LEADS * L;
+      for (int i = tid; i < LEADS * (L >> 2); i += 256) {
+        const int c = i / (L >> 2), p = (i - c * (L >> 2)) << 2;
+        *reinterpret_cast<float4*>(RB + c * LPX + 4 + p) = *reinterpret_cast<const float4*>(xw + c * L + p);
+      }
+      for (int i = tid; i < LEADS * 8; i += 256) { const int c = i >> 3, h = i & 7; RB[c * LPX + (h < 4 ? h : L + h)] = 0.f; }
+      for (int i = tid; i < (N3 * LD2) >> 2; i += 256) reinterpret_cast<float4*>(RA)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    RAL_STAMP_AT(1);
+    // ---- layer 0: Conv1d(LEADS, 4, k3, s2, p1) -> BN -> LeakyReLU -> E0c ----
+    for (int slot = tid; slot < N1; slot += 256) {      // 4 channels x N1 / 4 position quads
+      const int q = N1 >> 2, co = slot / q, l0 = (slot - co * q) << 2;
+      float acc[4] = {bias[BO[0] + co], bias[BO[0] + co], bias[BO[0] + co], bias[BO[0] + co]};
+#pragma unroll
+      for (int ci = 0; ci < LEADS; ++ci) {
+        const float* row = RB + ci * (L + 8) + 4;
+        const float* wr = wv0 + (co * LEADS + ci) * 3;
+        float xv[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) xv[t] = row[2 * l0 - 1 + t];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = fmaf(wr[0], xv[2 * j], fmaf(wr[1], xv[2 * j + 1], fmaf(wr[2], xv[2 * j + 2], acc[j])));
+      }
+      const float sc = bns[SO[0] + co], sh = bns[SO[0] + 4 + co];
+      *reinterpret_cast<float4*>(E0c + co * LP0 + 4 + l0) =
+          make_float4(lrelu01(fmaf(acc[0], sc, sh)), lrelu01(fmaf(acc[1], sc, sh)), lrelu01(fmaf(acc[2], sc, sh)), lrelu01(fmaf(acc[3], sc, sh)));
+    }
+    __syncthreads();
+    RAL_STAMP_AT(2);
+    // ---- layer 1: Conv1d(4, 8, k3, s2, p1) -> BN -> LeakyReLU -> S1 (skip) and the im2col rows of layer 2 ----
+    for (int slot = tid; slot < 2 * N2; slot += 256) {   // 8 channels x N2 / 4
+      const int q = N2 >> 2, co = slot / q, l0 = (slot - co * q) << 2;
+      float acc[4] = {bias[BO[1] + co], bias[BO[1] + co], bias[BO[1] + co], bias[BO[1] + co]};
+#pragma unroll
+      for (int ci = 0; ci < 4; ++ci) {
+        const float* row = E0c + ci * LP0 + 4;
+        const float* wr = wv1 + (co * 4 + ci) * 3;
+        float xv[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) xv[t] = row[2 * l0 - 1 + t];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = fmaf(wr[0], xv[2 * j], fmaf(wr[1], xv[2 * j + 1], fmaf(wr[2], xv[2 * j + 2], acc[j])));
+      }
+      const float sc = bns[SO[1] + co], sh = bns[SO[1] + 8 + co];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int p = l0 + j;
+        const float v = lrelu01(fmaf(acc[j], sc, sh));
+        S1[p * 8 + co] = v;
+        // consumer (k3, s2, p1) reads in[2n - 1 + k]: odd p feeds (n = (p+1)/2, k = 0) and (n = (p-1)/2, k = 2); even p (n = p/2, k = 1)
+        if (p & 1) { if (((p + 1) >> 1) < N3) RA[((p + 1) >> 1) * LD2 + co * 3] = v; RA[((p - 1) >> 1) * LD2 + co * 3 + 2] = v; }
+        else RA[(p >> 1) * LD2 + co * 3 + 1] = v;
+      }
+    }
+    for (int i = tid; i < 16; i += 256) RB[i * 3] = 0.f;          // X3 row 0, tap 0 = e2[-1] (x staging is dead)
+    __syncthreads();
+    RAL_STAMP_AT(3);
+    // ---- layer 2: Conv1d(8, 16) as GEMM 16 x 32(24) over N3 rows -> BN -> LeakyReLU -> S2 (skip), X3 ----
+    for (int u = wave; u < (N3 >> 4); u += 4)
+      uinf_tile<32>(pk + PW2, 16, RA, LD2, 0, u * 16, [&](int row0, int p, float4 a) {
+        const float4 v = f4lrelu(f4fma(f4add(a, *reinterpret_cast<const float4*>(bias + BO[2] + row0)),
+                                       *reinterpret_cast<const float4*>(bns + SO[2] + row0), *reinterpret_cast<const float4*>(bns + SO[2] + 16 + row0)));
+        *reinterpret_cast<float4*>(S2 + p * 16 + row0) = v;
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = row0 + e;
+          if (p & 1) { if (((p + 1) >> 1) < N4) RB[((p + 1) >> 1) * LD3 + c * 3] = vv[e]; RB[((p - 1) >> 1) * LD3 + c * 3 + 2] = vv[e]; }
+          else RB[(p >> 1) * LD3 + c * 3 + 1] = vv[e];
+        }
+      });
+    __syncthreads();
+    RAL_STAMP_AT(4);
+    // ---- layer 3: Conv1d(16, 32) as GEMM 32 x 48 -> BN -> LeakyReLU -> S3 (= im2col of the 1x1 conv, and the residual) ----
+    for (int u = wave; u < 2 * (N4 >> 4); u += 4)
+      uinf_tile<48>(pk + PW3, 32, RB, LD3, (u & 1) * 16, (u >> 1) * 16, [&](int row0, int p, float4 a) {
+        *reinterpret_cast<float4*>(S3 + p * LD4 + row0) =
+            f4lrelu(f4fma(f4add(a, *reinterpret_cast<const float4*>(bias + BO[3] + row0)),
+                          *reinterpret_cast<const float4*>(bns + SO[3] + row0), *reinterpret_cast<const float4*>(bns + SO[3] + 32 + row0)));
+      });
+    for (int i = tid; i < 32; i += 256) { RA[i * 3] = 0.f; RA[(N4 - 1) * LD5 + i * 3 + 2] = 0.f; }   // X5: in[-1], in[N4] (X2 is dead)
+    __syncthreads();
+    RAL_STAMP_AT(5);
+    // ---- layer 4: bottleneck.0, 1x1 conv -> LeakyReLU -> BN -> X5 (k3, s1, p1 im2col) ----
+    for (int u = wave; u < 2 * (N4 >> 4); u += 4)
+      uinf_tile<32>(pk + PW4, 32, S3, LD4, (u & 1) * 16, (u >> 1) * 16, [&](int row0, int p, float4 a) {
+        const float4 v = f4fma(f4lrelu(f4add(a, *reinterpret_cast<const float4*>(bias + BO[4] + row0))),
+                               *reinterpret_cast<const float4*>(bns + SO[4] + row0), *reinterpret_cast<const float4*>(bns + SO[4] + 32 + row0));
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = row0 + e;
+          RA[p * LD5 + c * 3 + 1] = vv[e];
+          if (p + 1 < N4) RA[(p + 1) * LD5 + c * 3] = vv[e];
+          if (p > 0) RA[(p - 1) * LD5 + c * 3 + 2] = vv[e];
+        }
+      });
+    __syncthreads();
+    RAL_STAMP_AT(6);
+    // ---- layer 5: bottleneck.3, k3 conv as GEMM 32 x 96 -> LeakyReLU -> BN -> X6 ----
+    for (int u = wave; u < 2 * (N4 >> 4); u += 4)
+      uinf_tile<96>(pk + PW5, 32, RA, LD5, (u & 1) * 16, (u >> 1) * 16, [&](int row0, int p, float4 a) {
+        *reinterpret_cast<float4*>(RC + p * LD4 + row0) =
+            f4fma(f4lrelu(f4add(a, *reinterpret_cast<const float4*>(bias + BO[5] + row0))),
+                  *reinterpret_cast<const float4*>(bns + SO[5] + row0), *reinterpret_cast<const float4*>(bns + SO[5] + 32 + row0));
+      });
+    for (int i = tid; i < 32; i += 256) { RB[i * 2] = 0.f; RB[N4 * LD7 + i * 2 + 1] = 0.f; }         // X7: in[-1], in[N4] (X3 is dead)
+    __syncthreads();
+    RAL_STAMP_AT(7);
+    // ---- layer 6: bottleneck.6, 1x1 conv, + e3 -> shared rows of the first transposed conv ----
+    for (int u = wave; u < 2 * (N4 >> 4); u += 4)
+      uinf_tile<32>(pk + PW6, 32, RC, LD4, (u & 1) * 16, (u >> 1) * 16, [&](int row0, int p, float4 a) {
+        const float4 v = f4add(f4add(a, *reinterpret_cast<const float4*>(bias + BO[6] + row0)), *reinterpret_cast<const float4*>(S3 + p * LD4 + row0));
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { RB[p * LD7 + (row0 + e) * 2 + 1] = vv[e]; RB[(p + 1) * LD7 + (row0 + e) * 2] = vv[e]; }
+      });
+    __syncthreads();
+    RAL_STAMP_AT(8);
+    // ---- layer 7: ConvTranspose1d(32, 16) = two GEMMs 16 x 64 -> BN -> LeakyReLU, + e2 -> shared rows of layer 8 ----
+    for (int u = wave; u < 2 * (N4 >> 4); u += 4) {
+      const int par = u & 1;
+      uinf_tile<64>(pk + PW7 + par * 1024, 16, RB + par * LD7, LD7, 0, (u >> 1) * 16, [&](int row0, int n, float4 a) {
+        const int j = 2 * n + par;
+        const float4 v = f4add(f4lrelu(f4fma(f4add(a, *reinterpret_cast<const float4*>(bias + BO[7] + row0)),
+                                             *reinterpret_cast<const float4*>(bns + SO[6] + row0), *reinterpret_cast<const float4*>(bns + SO[6] + 16 + row0))),
+                               *reinterpret_cast<const float4*>(S2 + j * 16 + row0));
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { X8[j * LD8 + (row0 + e) * 2 + 1] = vv[e]; X8[(j + 1) * LD8 + (row0 + e) * 2] = vv[e]; }
+      });
+    }
+    __syncthreads();
+    RAL_STAMP_AT(9);
+    // ---- layer 8: ConvTranspose1d(16, 8) = two GEMMs 8 x 32 -> BN -> LeakyReLU, + e1 -> d1 (channel-major, over X6) ----
+    for (int u = wave; u < 2 * (N3 >> 4); u += 4) {
+      const int par = u & 1;
+      uinf_tile<32>(pk + PW8 + par * 256, 8, X8 + par * LD8, LD8, 0, (u >> 1) * 16, [&](int row0, int n, float4 a) {
+        const int j = 2 * n + par;
+        const float4 v = f4add(f4lrelu(f4fma(f4add(a, *reinterpret_cast<const float4*>(bias + BO[8] + row0)),
+                                             *reinterpret_cast<const float4*>(bns + SO[7] + row0), *reinterpret_cast<const float4*>(bns + SO[7] + 8 + row0))),
+                               *reinterpret_cast<const float4*>(S1 + j * 8 + row0));
+        RC[(row0 + 0) * N2 + j] = v.x; RC[(row0 + 1) * N2 + j] = v.y; RC[(row0 + 2) * N2 + j] = v.z; RC[(row0 + 3) * N2 + j] = v.w;
+      });
+    }
+    __syncthreads();
+    RAL_STAMP_AT(10);
+    // ---- layer 9: ConvTranspose1d(8, 4) -> BN -> LeakyReLU, + e0 -> d2 (channel-major, over e3) ----
+    for (int slot = tid; slot < N1; slot += 256) {
+      const int q = N1 >> 2, co = slot / q, l0 = (slot - co * q) << 2, h = l0 >> 1;
+      float acc[4] = {bias[BO[9] + co], bias[BO[9] + co], bias[BO[9] + co], bias[BO[9] + co]};
+#pragma unroll
+      for (int ci = 0; ci < 8; ++ci) {
+        const float* row = RC + ci * N2;
+        const float* wr = wv9 + (ci * 4 + co) * 4;
+        const float x0 = h > 0 ? row[h - 1] : 0.f, x1 = row[h], x2 = row[h + 1], x3 = h + 2 < N2 ? row[h + 2] : 0.f;
+        acc[0] = fmaf(wr[1], x1, fmaf(wr[3], x0, acc[0]));
+        acc[1] = fmaf(wr[0], x2, fmaf(wr[2], x1, acc[1]));
+        acc[2] = fmaf(wr[1], x2, fmaf(wr[3], x1, acc[2]));
+        acc[3] = fmaf(wr[0], x3, fmaf(wr[2], x2, acc[3]));
+      }
+      const float sc = bns[SO[8] + co], sh = bns[SO[8] + 4 + co];
+      const float4 sk = *reinterpret_cast<const float4*>(E0c + co * LP0 + 4 + l0);
+      *reinterpret_cast<float4*>(S3 + co * N1 + l0) =
+          make_float4(lrelu01(fmaf(acc[0], sc, sh)) + sk.x, lrelu01(fmaf(acc[1], sc, sh)) + sk.y,
+                      lrelu01(fmaf(acc[2], sc, sh)) + sk.z, lrelu01(fmaf(acc[3], sc, sh)) + sk.w);
+    }
+    __syncthreads();
+    RAL_STAMP_AT(11);
+    // ---- layer 10: ConvTranspose1d(4, LEADS) -> BN -> y ----
+    float* yw = y + (size_t)win * LEADS * L;
+    for (int slot = tid; slot < LEADS * (L >> 2); slot += 256) {
+      const int q = L >> 2, co = slot / q, l0 = (slot - co * q) << 2, h = l0 >> 1;
+      float acc[4] = {bias[BO[10] + co], bias[BO[10] + co], bias[BO[10] + co], bias[BO[10] + co]};
+#pragma unroll
+      for (int ci = 0; ci < 4; ++ci) {
+        const float* row = S3 + ci * N1;
+        const float* wr = wv10 + (ci * LEADS + co) * 4;
+        const float x0 = h > 0 ? row[h - 1] : 0.f, x1 = row[h], x2 = row[h + 1], x3 = h + 2 < N1 ? row[h + 2] : 0.f;
+        acc[0] = fmaf(wr[1], x1, fmaf(wr[3], x0, acc[0]));
+        acc[1] = fmaf(wr[0], x2, fmaf(wr[2], x1, acc[1]));
+        acc[2] = fmaf(wr[1], x2, fmaf(wr[3], x1, acc[2]));
+        acc[3] = fmaf(wr[0], x3, fmaf(wr[2], x2, acc[3]));
+      }
+      const float sc = bns[SO[9] + co], sh = bns[SO[9] + LEADS + co];
+      *reinterpret_cast<float4*>(yw + co * L + l0) = make_float4(fmaf(acc[0], sc, sh), fmaf(acc[1], sc, sh), fmaf(acc[2], sc, sh), fmaf(acc[3], sc, sh));
+    }
+    __syncthreads();
+    RAL_STAMP_AT(12);
+  }
+}
+
+static size_t uinf_lds_floats(int L) {
+  const int N1 = L / 2, N2 = L / 4, N3 = L / 8, N4 = L / 16;
+  return (size_t)4 * (N1 + 8) + (size_t)N4 * 100 + (size_t)N2 * 8 + (size_t)N3 * 16 + (size_t)(N4 + 1) * 68 + (size_t)N4 * 36 * 2 +
+         (size_t)(N3 + 1) * 36 + 288;
+}
+
+// =================================================================================
 // host model
 // =================================================================================
 struct UEntry { std::string name; int kind; int64_t offset; int ndim; int64_t shape[4]; };
@@ -767,6 +1091,8 @@ struct UNetModel {
   ULayout lay;
   char* slab = nullptr;
   float* z[11];       // conv outputs: 0-3 enc, 4 a4, 5 a5, 6 r, 7-10 dec (z6..z9 in the text above)
+  float* pack = nullptr;   // fused inference: re-packed weights + folded BatchNorm coefficients (uinf::PTOT floats)
+  bool fused = true;       // eval forward as one kernel where it applies (ral_set_option "unet_fused"; RAL_UNET_FUSED=0)
   float* G[11];       // gradients at the BatchNorm outputs (same indexing; G[6] = d r)
   int C[11], Ln[11];  // channels / length of z[i]
   const float* last_x = nullptr;
@@ -802,6 +1128,8 @@ static size_t unet_plan(const ral_config& c, UNetModel* m, char* base) {
       if (m) { (pass ? m->G : m->z)[i] = base ? reinterpret_cast<float*>(base + cur) : nullptr; m->C[i] = Cs[i]; m->Ln[i] = Ls[i]; }
       cur += bytes;
     }
+  if (m) m->pack = base ? reinterpret_cast<float*>(base + cur) : nullptr;
+  cur += ((size_t)uinf::PTOT * sizeof(float) + 255) & ~size_t(255);
   return cur;
 }
 int64_t unet_workspace_bytes(const ral_config* c) { return (int64_t)unet_plan(*c, nullptr, nullptr); }
@@ -819,6 +1147,7 @@ UNetModel* unet_create(const ral_config* c, char* err, size_t cap) {
     return nullptr;
   }
   unet_plan(*c, m, m->slab);
+  m->fused = !(getenv("RAL_UNET_FUSED") && atoi(getenv("RAL_UNET_FUSED")) == 0);
   return m;
 }
 void unet_destroy(UNetModel* u) { if (u) { if (u->slab) (void)hipFree(u->slab); delete u; } }
@@ -970,7 +1299,43 @@ int unet_forward_finish(UNetModel* m, float* y, int B, int training, int64_t gwi
   return 0;
 }
 
+// The eval-mode forward as one kernel (+ the weight re-pack): windows of 256 / 512 / 768 / 1024 samples (the GEMM layers
+// need whole 16-row tiles at the deepest level and the window's tensors must fit LDS).  RAL_UNET_FUSED=0 keeps the
+// stage-by-stage path (which serves every other length, and training).
+static bool unet_infer_fused_applies(const UNetModel* m) {
+  const ral_config& c = m->pub.cfg;
+  return m->fused && c.L % 256 == 0 && c.L <= 1024;
+}
+int unet_set_option(UNetModel* m, const char* key, int value) {
+  if (!strcmp(key, "unet_fused")) { m->fused = value != 0; return 0; }
+  return -1;
+}
+
+static int unet_forward_fused(UNetModel* m, const float* x, float* y, int B, hipStream_t s, char* err, size_t cap) {
+  UNetPublic& P = m->pub;
+  if (!P.params || !P.state) { snprintf(err, cap, "ral_bind was not called"); return -1; }
+  if (B <= 0 || B > P.cfg.max_batch) { snprintf(err, cap, "batch %d outside (0, %d]", B, P.cfg.max_batch); return -1; }
+  UPackArgs a;
+  a.params = P.params; a.state = P.state; a.pk = m->pack; a.leads = P.cfg.leads;
+  for (int i = 0; i < 11; ++i) { a.w[i] = m->lay.w[i]; a.b[i] = m->lay.b[i]; }
+  for (int i = 0; i < 10; ++i) { a.bnw[i] = m->lay.bnw[i]; a.bnb[i] = m->lay.bnb[i]; a.run[i] = m->lay.run[i]; }
+  k_unet_pack<<<(uinf::PTOT + 255) / 256, 256, 0, s>>>(a);
+  const size_t lds = uinf_lds_floats(P.cfg.L) * sizeof(float);
+  const int per_cu = (int)(160 * 1024 / lds) < 1 ? 1 : (int)(160 * 1024 / lds);
+  const int grid = B < 256 * per_cu ? B : 256 * per_cu;
+  if (P.cfg.leads == 1) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_unet_infer<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    k_unet_infer<1><<<grid, 256, lds, s>>>(m->pack, x, y, P.cfg.L, B);
+  } else {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_unet_infer<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    k_unet_infer<2><<<grid, 256, lds, s>>>(m->pack, x, y, P.cfg.L, B);
+  }
+  if (hipGetLastError() != hipSuccess) { snprintf(err, cap, "U-Net fused forward launch failed"); return -1; }
+  return 0;
+}
+
 int unet_forward(UNetModel* m, const float* x, float* y, int B, int training, hipStream_t s, char* err, size_t cap) {
+  if (!training && unet_infer_fused_applies(m)) return unet_forward_fused(m, x, y, B, s, err, cap);
   for (int si = 0; si < 11; ++si)
     if (unet_forward_stage(m, x, B, training, si, B, s, err, cap)) return -1;
   return unet_forward_finish(m, y, B, training, B, s, err, cap);

@@ -31,4 +31,5 @@ int unet_backward_start(UNetModel* u, const float* dy, int B, int64_t gwin, hipS
 int unet_backward_stage(UNetModel* u, int B, int si, int64_t gwin, hipStream_t s, char* err, size_t cap);
 int unet_backward_finish(UNetModel* u, int B, int64_t gwin, hipStream_t s, char* err, size_t cap);
 int unet_stage_bn(int si);
+int unet_set_option(UNetModel* u, const char* key, int value);   // "unet_fused": eval forward as one kernel (default 1)
 UNetPublic* unet_public(UNetModel* u);
