@@ -779,14 +779,46 @@ __global__ __launch_bounds__(256) void k_unet_pack(UPackArgs a) {   // one packe
   a.pk[i] = v;
 }
 
-// one 16 x 16 output tile of a GEMM layer: rows m0.. of W (M x K, global), im2col rows t0.. of Xs (LDS, stride ldx)
-template <int K, class Epi>
-RAL_DEV void uinf_tile(const float* __restrict__ W, int M, const float* Xs, int ldx, int m0, int t0, Epi epi) {
-  f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
-  gemm_wx<K, 1, false, LAY_TOK>(W, K, m0, M, Xs, ldx, t0, acc);
+// One 16 x 16 output tile of a GEMM layer, in two halves so that the global weight-fragment loads of a layer can be
+// issued BEFORE the barrier that ends the previous layer (their L2 latency then hides behind the other waves' epilogues):
+//   uinf_frag  - the A fragments of rows m0.. of W (M x K row-major, global): K / 16 float4 per lane (k = 16 c + 4 g + s)
+//   uinf_mma   - the MFMAs against im2col rows t0.. of Xs (LDS, stride ldx); epi(row0, row index, 4 channels of that row)
+template <int K> struct UFrag { float4 w[K / 16]; };
+template <int K>
+RAL_DEV UFrag<K> uinf_frag(const float* __restrict__ W, int M, int m0) {
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  int mrow = m0 + r;
+  if (mrow >= M) mrow = M - 1;          // rows >= M are computed on a duplicate and discarded
+  UFrag<K> f;
+#pragma unroll
+  for (int c = 0; c < K / 16; ++c) f.w[c] = *reinterpret_cast<const float4*>(W + (size_t)mrow * K + c * 16 + 4 * g);
+  return f;
+}
+template <int K, class Epi>
+RAL_DEV void uinf_mma(const UFrag<K>& f, int M, const float* Xs, int ldx, int m0, int t0, Epi epi) {
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < K / 16; ++c) {
+    const float4 x4 = *reinterpret_cast<const float4*>(Xs + (t0 + r) * ldx + c * 16 + 4 * g);
+    acc = mfma4(f.w[c].x, x4.x, acc);
+    acc = mfma4(f.w[c].y, x4.y, acc);
+    acc = mfma4(f.w[c].z, x4.z, acc);
+    acc = mfma4(f.w[c].w, x4.w, acc);
+  }
   const int row0 = m0 + 4 * g;
-  if (row0 < M) epi(row0, t0 + r, tofloat4(acc[0]));
+  if (row0 < M) epi(row0, t0 + r, tofloat4(acc));
+}
+// a layer's units dealt to the 4 waves: the first unit's fragments were prefetched by the caller (pf), later ones load here
+template <int K, class WOf, class Epi>
+RAL_DEV void uinf_layer(const UFrag<K>& pf, int nunits, int M, WOf wof, Epi epi) {
+  const int wave = threadIdx.x >> 6;
+  for (int u = wave; u < nunits; u += 4) {
+    const float* W; const float* Xs; int ldx, m0, t0, tag;
+    wof(u, W, Xs, ldx, m0, t0, tag);
+    if (u == wave) uinf_mma<K>(pf, M, Xs, ldx, m0, t0, [&](int row0, int n, float4 a) { epi(tag, row0, n, a); });
+    else { const UFrag<K> f = uinf_frag<K>(W, M, m0); uinf_mma<K>(f, M, Xs, ldx, m0, t0, [&](int row0, int n, float4 a) { epi(tag, row0, n, a); }); }
+  }
 }
 
 RAL_DEV float4 f4lrelu(float4 v) { return make_float4(lrelu01(v.x), lrelu01(v.y), lrelu01(v.z), lrelu01(v.w)); }
@@ -841,9 +873,10 @@ __global__ __launch_bounds__(256) void k_unet_infer(const float* __restrict__ pk
       for (int ci = 0; ci < LEADS; ++ci) {
         const float* row = RB + ci * (L + 8) + 4;
         const float* wr = wv0 + (co * LEADS + ci) * 3;
-        float xv[9];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) xv[t] = row[2 * l0 - 1 + t];
+        // in[2 l0 - 1 .. 2 l0 + 7] as three aligned 16-byte reads (nine 4-byte reads at a lane stride of 8 floats are 8-way bank conflicts)
+        const float4 qa = *reinterpret_cast<const float4*>(row + 2 * l0 - 4), qb = *reinterpret_cast<const float4*>(row + 2 * l0),
+                     qc = *reinterpret_cast<const float4*>(row + 2 * l0 + 4);
+        const float xv[9] = {qa.w, qb.x, qb.y, qb.z, qb.w, qc.x, qc.y, qc.z, qc.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j] = fmaf(wr[0], xv[2 * j], fmaf(wr[1], xv[2 * j + 1], fmaf(wr[2], xv[2 * j + 2], acc[j])));
       }
@@ -861,9 +894,10 @@ __global__ __launch_bounds__(256) void k_unet_infer(const float* __restrict__ pk
       for (int ci = 0; ci < 4; ++ci) {
         const float* row = E0c + ci * LP0 + 4;
         const float* wr = wv1 + (co * 4 + ci) * 3;
-        float xv[9];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) xv[t] = row[2 * l0 - 1 + t];
+        // in[2 l0 - 1 .. 2 l0 + 7] as three aligned 16-byte reads (nine 4-byte reads at a lane stride of 8 floats are 8-way bank conflicts)
+        const float4 qa = *reinterpret_cast<const float4*>(row + 2 * l0 - 4), qb = *reinterpret_cast<const float4*>(row + 2 * l0),
+                     qc = *reinterpret_cast<const float4*>(row + 2 * l0 + 4);
+        const float xv[9] = {qa.w, qb.x, qb.y, qb.z, qb.w, qc.x, qc.y, qc.z, qc.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j] = fmaf(wr[0], xv[2 * j], fmaf(wr[1], xv[2 * j + 1], fmaf(wr[2], xv[2 * j + 2], acc[j])));
       }
@@ -879,96 +913,100 @@ __global__ __launch_bounds__(256) void k_unet_infer(const float* __restrict__ pk
       }
     }
     for (int i = tid; i < 16; i += 256) RB[i * 3] = 0.f;          // X3 row 0, tap 0 = e2[-1] (x staging is dead)
+    // unit -> (weights, im2col rows, row stride, first output row, first im2col row, tag) of every GEMM layer
+    auto w2 = [&](int u, const float*& W, const float*& Xs, int& ldx, int& m0, int& t0, int& tag) { W = pk + PW2; Xs = RA; ldx = LD2; m0 = 0; t0 = u * 16; tag = 0; };
+    auto w3 = [&](int u, const float*& W, const float*& Xs, int& ldx, int& m0, int& t0, int& tag) { W = pk + PW3; Xs = RB; ldx = LD3; m0 = (u & 1) * 16; t0 = (u >> 1) * 16; tag = 0; };
+    auto w4 = [&](int u, const float*& W, const float*& Xs, int& ldx, int& m0, int& t0, int& tag) { W = pk + PW4; Xs = S3; ldx = LD4; m0 = (u & 1) * 16; t0 = (u >> 1) * 16; tag = 0; };
+    auto w5 = [&](int u, const float*& W, const float*& Xs, int& ldx, int& m0, int& t0, int& tag) { W = pk + PW5; Xs = RA; ldx = LD5; m0 = (u & 1) * 16; t0 = (u >> 1) * 16; tag = 0; };
+    auto w6 = [&](int u, const float*& W, const float*& Xs, int& ldx, int& m0, int& t0, int& tag) { W = pk + PW6; Xs = RC; ldx = LD4; m0 = (u & 1) * 16; t0 = (u >> 1) * 16; tag = 0; };
+    auto w7 = [&](int u, const float*& W, const float*& Xs, int& ldx, int& m0, int& t0, int& tag) { tag = u & 1; W = pk + PW7 + tag * 1024; Xs = RB + tag * LD7; ldx = LD7; m0 = 0; t0 = (u >> 1) * 16; };
+    auto w8 = [&](int u, const float*& W, const float*& Xs, int& ldx, int& m0, int& t0, int& tag) { tag = u & 1; W = pk + PW8 + tag * 256; Xs = X8 + tag * LD8; ldx = LD8; m0 = 0; t0 = (u >> 1) * 16; };
+    const UFrag<32> f2 = uinf_frag<32>(pk + PW2, 16, 0);
     __syncthreads();
     RAL_STAMP_AT(3);
     // ---- layer 2: Conv1d(8, 16) as GEMM 16 x 32(24) over N3 rows -> BN -> LeakyReLU -> S2 (skip), X3 ----
-    for (int u = wave; u < (N3 >> 4); u += 4)
-      uinf_tile<32>(pk + PW2, 16, RA, LD2, 0, u * 16, [&](int row0, int p, float4 a) {
-        const float4 v = f4lrelu(f4fma(f4add(a, *reinterpret_cast<const float4*>(bias + BO[2] + row0)),
-                                       *reinterpret_cast<const float4*>(bns + SO[2] + row0), *reinterpret_cast<const float4*>(bns + SO[2] + 16 + row0)));
-        *reinterpret_cast<float4*>(S2 + p * 16 + row0) = v;
-        const float vv[4] = {v.x, v.y, v.z, v.w};
+    uinf_layer<32>(f2, N3 >> 4, 16, w2, [&](int, int row0, int p, float4 a) {
+      const float4 v = f4lrelu(f4fma(f4add(a, *reinterpret_cast<const float4*>(bias + BO[2] + row0)),
+                                     *reinterpret_cast<const float4*>(bns + SO[2] + row0), *reinterpret_cast<const float4*>(bns + SO[2] + 16 + row0)));
+      *reinterpret_cast<float4*>(S2 + p * 16 + row0) = v;
+      const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int c = row0 + e;
-          if (p & 1) { if (((p + 1) >> 1) < N4) RB[((p + 1) >> 1) * LD3 + c * 3] = vv[e]; RB[((p - 1) >> 1) * LD3 + c * 3 + 2] = vv[e]; }
-          else RB[(p >> 1) * LD3 + c * 3 + 1] = vv[e];
-        }
-      });
+      for (int e = 0; e < 4; ++e) {
+        const int c = row0 + e;
+        if (p & 1) { if (((p + 1) >> 1) < N4) RB[((p + 1) >> 1) * LD3 + c * 3] = vv[e]; RB[((p - 1) >> 1) * LD3 + c * 3 + 2] = vv[e]; }
+        else RB[(p >> 1) * LD3 + c * 3 + 1] = vv[e];
+      }
+    });
+    const UFrag<48> f3 = uinf_frag<48>(pk + PW3, 32, (wave & 1) * 16);
     __syncthreads();
     RAL_STAMP_AT(4);
     // ---- layer 3: Conv1d(16, 32) as GEMM 32 x 48 -> BN -> LeakyReLU -> S3 (= im2col of the 1x1 conv, and the residual) ----
-    for (int u = wave; u < 2 * (N4 >> 4); u += 4)
-      uinf_tile<48>(pk + PW3, 32, RB, LD3, (u & 1) * 16, (u >> 1) * 16, [&](int row0, int p, float4 a) {
-        *reinterpret_cast<float4*>(S3 + p * LD4 + row0) =
-            f4lrelu(f4fma(f4add(a, *reinterpret_cast<const float4*>(bias + BO[3] + row0)),
-                          *reinterpret_cast<const float4*>(bns + SO[3] + row0), *reinterpret_cast<const float4*>(bns + SO[3] + 32 + row0)));
-      });
+    uinf_layer<48>(f3, 2 * (N4 >> 4), 32, w3, [&](int, int row0, int p, float4 a) {
+      *reinterpret_cast<float4*>(S3 + p * LD4 + row0) =
+          f4lrelu(f4fma(f4add(a, *reinterpret_cast<const float4*>(bias + BO[3] + row0)),
+                        *reinterpret_cast<const float4*>(bns + SO[3] + row0), *reinterpret_cast<const float4*>(bns + SO[3] + 32 + row0)));
+    });
     for (int i = tid; i < 32; i += 256) { RA[i * 3] = 0.f; RA[(N4 - 1) * LD5 + i * 3 + 2] = 0.f; }   // X5: in[-1], in[N4] (X2 is dead)
+    const UFrag<32> f4 = uinf_frag<32>(pk + PW4, 32, (wave & 1) * 16);
     __syncthreads();
     RAL_STAMP_AT(5);
     // ---- layer 4: bottleneck.0, 1x1 conv -> LeakyReLU -> BN -> X5 (k3, s1, p1 im2col) ----
-    for (int u = wave; u < 2 * (N4 >> 4); u += 4)
-      uinf_tile<32>(pk + PW4, 32, S3, LD4, (u & 1) * 16, (u >> 1) * 16, [&](int row0, int p, float4 a) {
-        const float4 v = f4fma(f4lrelu(f4add(a, *reinterpret_cast<const float4*>(bias + BO[4] + row0))),
-                               *reinterpret_cast<const float4*>(bns + SO[4] + row0), *reinterpret_cast<const float4*>(bns + SO[4] + 32 + row0));
-        const float vv[4] = {v.x, v.y, v.z, v.w};
+    uinf_layer<32>(f4, 2 * (N4 >> 4), 32, w4, [&](int, int row0, int p, float4 a) {
+      const float4 v = f4fma(f4lrelu(f4add(a, *reinterpret_cast<const float4*>(bias + BO[4] + row0))),
+                             *reinterpret_cast<const float4*>(bns + SO[4] + row0), *reinterpret_cast<const float4*>(bns + SO[4] + 32 + row0));
+      const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int c = row0 + e;
-          RA[p * LD5 + c * 3 + 1] = vv[e];
-          if (p + 1 < N4) RA[(p + 1) * LD5 + c * 3] = vv[e];
-          if (p > 0) RA[(p - 1) * LD5 + c * 3 + 2] = vv[e];
-        }
-      });
+      for (int e = 0; e < 4; ++e) {
+        const int c = row0 + e;
+        RA[p * LD5 + c * 3 + 1] = vv[e];
+        if (p + 1 < N4) RA[(p + 1) * LD5 + c * 3] = vv[e];
+        if (p > 0) RA[(p - 1) * LD5 + c * 3 + 2] = vv[e];
+      }
+    });
+    const UFrag<96> f5 = uinf_frag<96>(pk + PW5, 32, (wave & 1) * 16);
     __syncthreads();
     RAL_STAMP_AT(6);
     // ---- layer 5: bottleneck.3, k3 conv as GEMM 32 x 96 -> LeakyReLU -> BN -> X6 ----
-    for (int u = wave; u < 2 * (N4 >> 4); u += 4)
-      uinf_tile<96>(pk + PW5, 32, RA, LD5, (u & 1) * 16, (u >> 1) * 16, [&](int row0, int p, float4 a) {
-        *reinterpret_cast<float4*>(RC + p * LD4 + row0) =
-            f4fma(f4lrelu(f4add(a, *reinterpret_cast<const float4*>(bias + BO[5] + row0))),
-                  *reinterpret_cast<const float4*>(bns + SO[5] + row0), *reinterpret_cast<const float4*>(bns + SO[5] + 32 + row0));
-      });
+    uinf_layer<96>(f5, 2 * (N4 >> 4), 32, w5, [&](int, int row0, int p, float4 a) {
+      *reinterpret_cast<float4*>(RC + p * LD4 + row0) =
+          f4fma(f4lrelu(f4add(a, *reinterpret_cast<const float4*>(bias + BO[5] + row0))),
+                *reinterpret_cast<const float4*>(bns + SO[5] + row0), *reinterpret_cast<const float4*>(bns + SO[5] + 32 + row0));
+    });
     for (int i = tid; i < 32; i += 256) { RB[i * 2] = 0.f; RB[N4 * LD7 + i * 2 + 1] = 0.f; }         // X7: in[-1], in[N4] (X3 is dead)
+    const UFrag<32> f6 = uinf_frag<32>(pk + PW6, 32, (wave & 1) * 16);
     __syncthreads();
     RAL_STAMP_AT(7);
     // ---- layer 6: bottleneck.6, 1x1 conv, + e3 -> shared rows of the first transposed conv ----
-    for (int u = wave; u < 2 * (N4 >> 4); u += 4)
-      uinf_tile<32>(pk + PW6, 32, RC, LD4, (u & 1) * 16, (u >> 1) * 16, [&](int row0, int p, float4 a) {
-        const float4 v = f4add(f4add(a, *reinterpret_cast<const float4*>(bias + BO[6] + row0)), *reinterpret_cast<const float4*>(S3 + p * LD4 + row0));
-        const float vv[4] = {v.x, v.y, v.z, v.w};
+    uinf_layer<32>(f6, 2 * (N4 >> 4), 32, w6, [&](int, int row0, int p, float4 a) {
+      const float4 v = f4add(f4add(a, *reinterpret_cast<const float4*>(bias + BO[6] + row0)), *reinterpret_cast<const float4*>(S3 + p * LD4 + row0));
+      const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { RB[p * LD7 + (row0 + e) * 2 + 1] = vv[e]; RB[(p + 1) * LD7 + (row0 + e) * 2] = vv[e]; }
-      });
+      for (int e = 0; e < 4; ++e) { RB[p * LD7 + (row0 + e) * 2 + 1] = vv[e]; RB[(p + 1) * LD7 + (row0 + e) * 2] = vv[e]; }
+    });
+    const UFrag<64> f7 = uinf_frag<64>(pk + PW7 + (wave & 1) * 1024, 16, 0);
     __syncthreads();
     RAL_STAMP_AT(8);
     // ---- layer 7: ConvTranspose1d(32, 16) = two GEMMs 16 x 64 -> BN -> LeakyReLU, + e2 -> shared rows of layer 8 ----
-    for (int u = wave; u < 2 * (N4 >> 4); u += 4) {
-      const int par = u & 1;
-      uinf_tile<64>(pk + PW7 + par * 1024, 16, RB + par * LD7, LD7, 0, (u >> 1) * 16, [&](int row0, int n, float4 a) {
-        const int j = 2 * n + par;
-        const float4 v = f4add(f4lrelu(f4fma(f4add(a, *reinterpret_cast<const float4*>(bias + BO[7] + row0)),
-                                             *reinterpret_cast<const float4*>(bns + SO[6] + row0), *reinterpret_cast<const float4*>(bns + SO[6] + 16 + row0))),
-                               *reinterpret_cast<const float4*>(S2 + j * 16 + row0));
-        const float vv[4] = {v.x, v.y, v.z, v.w};
+    uinf_layer<64>(f7, 2 * (N4 >> 4), 16, w7, [&](int par, int row0, int n, float4 a) {
+      const int j = 2 * n + par;
+      const float4 v = f4add(f4lrelu(f4fma(f4add(a, *reinterpret_cast<const float4*>(bias + BO[7] + row0)),
+                                           *reinterpret_cast<const float4*>(bns + SO[6] + row0), *reinterpret_cast<const float4*>(bns + SO[6] + 16 + row0))),
+                             *reinterpret_cast<const float4*>(S2 + j * 16 + row0));
+      const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { X8[j * LD8 + (row0 + e) * 2 + 1] = vv[e]; X8[(j + 1) * LD8 + (row0 + e) * 2] = vv[e]; }
-      });
-    }
+      for (int e = 0; e < 4; ++e) { X8[j * LD8 + (row0 + e) * 2 + 1] = vv[e]; X8[(j + 1) * LD8 + (row0 + e) * 2] = vv[e]; }
+    });
+    const UFrag<32> f8 = uinf_frag<32>(pk + PW8 + (wave & 1) * 256, 8, 0);
     __syncthreads();
     RAL_STAMP_AT(9);
     // ---- layer 8: ConvTranspose1d(16, 8) = two GEMMs 8 x 32 -> BN -> LeakyReLU, + e1 -> d1 (channel-major, over X6) ----
-    for (int u = wave; u < 2 * (N3 >> 4); u += 4) {
-      const int par = u & 1;
-      uinf_tile<32>(pk + PW8 + par * 256, 8, X8 + par * LD8, LD8, 0, (u >> 1) * 16, [&](int row0, int n, float4 a) {
-        const int j = 2 * n + par;
-        const float4 v = f4add(f4lrelu(f4fma(f4add(a, *reinterpret_cast<const float4*>(bias + BO[8] + row0)),
-                                             *reinterpret_cast<const float4*>(bns + SO[7] + row0), *reinterpret_cast<const float4*>(bns + SO[7] + 8 + row0))),
-                               *reinterpret_cast<const float4*>(S1 + j * 8 + row0));
-        RC[(row0 + 0) * N2 + j] = v.x; RC[(row0 + 1) * N2 + j] = v.y; RC[(row0 + 2) * N2 + j] = v.z; RC[(row0 + 3) * N2 + j] = v.w;
-      });
-    }
+    uinf_layer<32>(f8, 2 * (N3 >> 4), 8, w8, [&](int par, int row0, int n, float4 a) {
+      const int j = 2 * n + par;
+      const float4 v = f4add(f4lrelu(f4fma(f4add(a, *reinterpret_cast<const float4*>(bias + BO[8] + row0)),
+                                           *reinterpret_cast<const float4*>(bns + SO[7] + row0), *reinterpret_cast<const float4*>(bns + SO[7] + 8 + row0))),
+                             *reinterpret_cast<const float4*>(S1 + j * 8 + row0));
+      RC[(row0 + 0) * N2 + j] = v.x; RC[(row0 + 1) * N2 + j] = v.y; RC[(row0 + 2) * N2 + j] = v.z; RC[(row0 + 3) * N2 + j] = v.w;
+    });
     __syncthreads();
     RAL_STAMP_AT(10);
     // ---- layer 9: ConvTranspose1d(8, 4) -> BN -> LeakyReLU, + e0 -> d2 (channel-major, over e3) ----
