@@ -1254,15 +1254,16 @@ size_t attn_bwd_lds(int N, int HG, int Len) {
 
 // Window lengths that take the scalar-path sweeps.  Measured at batch 2048 (tools/attn_bench.py, us per launch, MFMA-tile
 // kernel vs scalar path).  Without an R-wave table: N = 512: 790 / 853, 256: 446 / 464, 128: 285 / 265, 64: 208 / 155;
-// with one (the in-window keys cost two lane gathers each, plus the partial-sum pass): 128: 285 / 293, 64: 208 / 192.
-// So: N <= 128 without a table, N = 64 with one.  RAL_ATTN_BWD_V="lo:hi" forces a range for both cases (0:0 = never).
+// with one (the in-window keys cost two lane gathers each, plus the partial-sum pass): 128: 285 / 293, 64: 208 / 192, and
+// inside the training step (bench.py --kinds) the N = 64 case with a table came out 2 % slower than the MFMA-tile kernel.
+// So: N <= 128 without a table, never with one.  RAL_ATTN_BWD_V="lo:hi" forces a range for both cases (0:0 = never).
 bool attn_bwd_uses_stat2(int N, int Len, bool table) {
   static int lo = -1, hi = -1;
   static const bool init = [] { if (const char* v = getenv("RAL_ATTN_BWD_V")) sscanf(v, "%d:%d", &lo, &hi); return true; }();
   (void)init;
   if (N < 64 || N % 4 != 0 || (table && 2 * Len - 1 > 64)) return false;
   if (lo >= 0) return N >= lo && N <= hi;
-  return N <= (table ? 64 : 128);
+  return !table && N <= 128;
 }
 
 void launch_attn_bwd(const float* qkv, const float* o_hm, const float* do_hm, const float* lse, const float* table,
