@@ -97,7 +97,8 @@ class OracleEngine:
         self.grads[:o1] = torch.cat([self.gdict[k].reshape(-1) for k in self.p if k not in dec])
 
     def replica_state(self):
-        tensors = list(self.p.values()) + list(self.m.values()) + list(self.v.values()) + list(self.running.values())
+        tensors = list(self.p.values()) + list(self.m.values()) + list(self.v.values()) + \
+            [t for t in self.running.values() if torch.is_tensor(t)]
 
         def set_counters(c):
             self.step = int(c[0])
