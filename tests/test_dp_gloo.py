@@ -145,7 +145,7 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sys.path.insert(0, ROOT)
     from ecg_denoise_amd.dp import DataParallelTrainer
-    torch.set_num_threads(2)
+    torch.set_num_threads(1)
     g = torch.Generator().manual_seed(7)
     x = torch.randn(4, 2, 256, generator=g); y = torch.randn(4, 2, 256, generator=g)
     # every rank draws DIFFERENT initial weights (what the model constructors do without a seed) and rank 1 pretends to
@@ -166,7 +166,7 @@ def _worker(rank, world, port, q):
 
 
 def test_two_ranks_equal_one_process_on_the_concatenated_batch():
-    torch.set_num_threads(4)
+    torch.set_num_threads(1)
     g = torch.Generator().manual_seed(7)
     x = torch.randn(4, 2, 256, generator=g); y = torch.randn(4, 2, 256, generator=g)
     # single process reference: plain oracle train steps (fp64)
