@@ -117,9 +117,10 @@ def cpu_baseline(leads, L, variant):
     from collections import OrderedDict
     import torch
     import ralenet_oracle as O
-    # intra-op threads: all host cores up to 32 (the op graph is ~21k small ATen calls per step; beyond
-    # a few dozen threads the fork/join cost of each call exceeds its work)
-    cores = min(os.cpu_count() or 1, 32)
+    # intra-op threads: the count with the highest measured throughput on the GPU box's host (256 logical cores;
+    # tools/diag/cpu_threads.py: 1 thread 40, 2: 60, 4: 74, 8: 84, 16: 78, 32: 56, 64: 26 windows/s) - the op graph is
+    # ~21k small ATen calls per step, and past 8 threads the fork/join cost of each call exceeds its work
+    cores = min(os.cpu_count() or 1, 8)
     torch.set_num_threads(cores)
     B = 32
     p = O.init_params(O.ralenet_param_shapes(variant, leads), 1)
