@@ -49,9 +49,9 @@ def kind_work(kind, L, B):
 
 
 def measured_traffic(kind):
-    """HBM bytes per launch of this kernel kind from the committed PMC run (profiles/r01_hbm_traffic.json)."""
+    """HBM bytes per launch of this kernel kind from the committed PMC run (profiles/r02_hbm_traffic.json)."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")))
         return d["per_launch_bytes"][kind]["total"]
     except Exception:
         return None

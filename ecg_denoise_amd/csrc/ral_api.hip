@@ -13,6 +13,7 @@
 #include "../../include/ralenet.h"
 #include "ral_kernels.hpp"
 #include "ral_unet.hpp"
+#include "ral_acdae.hpp"
 
 static thread_local char g_err[512] = "";
 static int fail(const char* fmt, ...) {
@@ -164,7 +165,8 @@ static bool build_layout(const ral_config& c, Layout& L) {
 static int check_cfg(const ral_config* c) {
   if (!c) return fail("null config");
   if (c->variant == RAL_UNET) return unet_check_cfg(c, g_err, sizeof(g_err));
-  if (c->variant < 0 || c->variant > RAL_UNET) return fail("unknown variant %d", c->variant);
+  if (c->variant == RAL_ACDAE) return acdae_check_cfg(c, g_err, sizeof(g_err));
+  if (c->variant < 0 || c->variant > RAL_ACDAE) return fail("unknown variant %d", c->variant);
   if (c->leads != 1 && c->leads != 2) return fail("leads must be 1 or 2 (got %d); use the 12-lead adapter above it", c->leads);
   if (c->L <= 0 || c->L % 256 != 0 || c->L > 1024) return fail("L must be a multiple of 256 and <= 1024 (got %d)", c->L);
   if (c->max_batch <= 0) return fail("max_batch must be positive");
@@ -256,9 +258,10 @@ struct ProfScope {
 };
 
 struct ral_handle {
-  int kind;  // 0 ralenet, 1 unet
+  int kind;  // 0 ralenet, 1 unet, 2 acdae
   RalModel* m;
   UNetModel* u;
+  AcdaeModel* a = nullptr;
 };
 
 static size_t plan_workspace(const ral_config& c, RalModel* m /* may be null: size only */, char* base) {
@@ -664,6 +667,7 @@ extern "C" {
 int ral_layout_count(const ral_config* cfg) {
   if (check_cfg(cfg)) return -1;
   if (cfg->variant == RAL_UNET) return unet_layout_count(cfg);
+  if (cfg->variant == RAL_ACDAE) return acdae_layout_count(cfg);
   Layout L;
   build_layout(*cfg, L);
   return (int)L.entries.size();
@@ -673,6 +677,10 @@ int ral_layout_entry(const ral_config* cfg, int idx, char* name, int name_cap, i
                      int32_t* ndim, int64_t shape[4]) {
   if (check_cfg(cfg)) return -1;
   if (cfg->variant == RAL_UNET) return unet_layout_entry(cfg, idx, name, name_cap, kind, offset, ndim, shape);
+  if (cfg->variant == RAL_ACDAE) {
+    if (acdae_layout_entry(cfg, idx, name, name_cap, kind, offset, ndim, shape)) return fail("entry %d out of range", idx);
+    return 0;
+  }
   Layout L;
   build_layout(*cfg, L);
   if (idx < 0 || idx >= (int)L.entries.size()) return fail("entry %d out of range", idx);
@@ -687,6 +695,7 @@ int ral_layout_entry(const ral_config* cfg, int idx, char* name, int name_cap, i
 int64_t ral_param_floats(const ral_config* cfg) {
   if (check_cfg(cfg)) return -1;
   if (cfg->variant == RAL_UNET) return unet_param_floats(cfg);
+  if (cfg->variant == RAL_ACDAE) return acdae_param_floats(cfg);
   Layout L;
   build_layout(*cfg, L);
   return L.nparam;
@@ -695,17 +704,19 @@ int64_t ral_param_floats(const ral_config* cfg) {
 int64_t ral_state_floats(const ral_config* cfg) {
   if (check_cfg(cfg)) return -1;
   if (cfg->variant == RAL_UNET) return unet_state_floats(cfg);
+  if (cfg->variant == RAL_ACDAE) return 0;
   return 16;
 }
 
 int64_t ral_bn_sums_doubles(const ral_config* cfg) {
   if (check_cfg(cfg)) return -1;
-  return cfg->variant == RAL_UNET ? 1280 : 64;
+  return cfg->variant == RAL_UNET ? 1280 : (cfg->variant == RAL_ACDAE ? 0 : 64);
 }
 
 int64_t ral_workspace_bytes(const ral_config* cfg) {
   if (check_cfg(cfg)) return -1;
   if (cfg->variant == RAL_UNET) return unet_workspace_bytes(cfg);
+  if (cfg->variant == RAL_ACDAE) return acdae_workspace_bytes(cfg);
   return (int64_t)plan_workspace(*cfg, nullptr, nullptr);
 }
 
@@ -743,6 +754,13 @@ int ral_create(const ral_config* cfg, ral_handle** out) {
   if (check_cfg(cfg)) return -1;
   if (!out) return fail("null out");
   ral_handle* h = new ral_handle{0, nullptr, nullptr};
+  if (cfg->variant == RAL_ACDAE) {
+    h->kind = 2;
+    h->a = acdae_create(cfg, g_err, sizeof(g_err));
+    if (!h->a) { delete h; return -1; }
+    *out = h;
+    return 0;
+  }
   if (cfg->variant == RAL_UNET) {
     h->kind = 1;
     h->u = unet_create(cfg, g_err, sizeof(g_err));
@@ -837,6 +855,7 @@ int ral_destroy(ral_handle* h) {
   if (!h) return 0;
   destroy_model(h->m);
   if (h->u) unet_destroy(h->u);
+  if (h->a) acdae_destroy(h->a);
   delete h;
   return 0;
 }
@@ -844,6 +863,7 @@ int ral_destroy(ral_handle* h) {
 int ral_bind(ral_handle* h, float* params, float* grads, float* adam_m, float* adam_v, float* state, double* bn_sums) {
   if (!h) return fail("null handle");
   if (h->kind == 1) return unet_bind(h->u, params, grads, adam_m, adam_v, state, bn_sums);
+  if (h->kind == 2) return acdae_bind(h->a, params, grads, adam_m, adam_v);
   RalModel* m = h->m;
   m->params = params; m->grads = grads; m->am = adam_m; m->av = adam_v; m->state = state; m->bn_sums = bn_sums;
   return 0;
@@ -851,12 +871,14 @@ int ral_bind(ral_handle* h, float* params, float* grads, float* adam_m, float* a
 
 int ral_forward_begin(ral_handle* h, const float* x, int B, ral_stream s) {
   if (!h) return fail("null handle");
+  if (h->kind == 2) return fail("ACDAE has no BatchNorm: use ral_forward");
   if (h->kind == 1) return fail("U-Net has one BatchNorm per layer: use ral_forward (per-rank statistics)");
   return fwd_begin(h->m, x, B, 1, (hipStream_t)s);
 }
 
 int ral_forward_end(ral_handle* h, float* y, int B, int64_t global_windows, ral_stream s) {
   if (!h) return fail("null handle");
+  if (h->kind == 2) return fail("ACDAE has no BatchNorm: use ral_forward");
   if (h->kind == 1) return fail("U-Net has one BatchNorm per layer: use ral_forward (per-rank statistics)");
   return fwd_end(h->m, y, B, global_windows, 1, (hipStream_t)s);
 }
@@ -864,6 +886,7 @@ int ral_forward_end(ral_handle* h, float* y, int B, int64_t global_windows, ral_
 int ral_forward(ral_handle* h, const float* x, float* y, int B, int training, ral_stream s) {
   if (!h) return fail("null handle");
   if (h->kind == 1) return unet_forward(h->u, x, y, B, training, (hipStream_t)s, g_err, sizeof(g_err));
+  if (h->kind == 2) return acdae_forward(h->a, x, y, B, (hipStream_t)s, g_err, sizeof(g_err));
   if (fwd_begin(h->m, x, B, training, (hipStream_t)s)) return -1;
   return fwd_end(h->m, y, B, B, training, (hipStream_t)s);
 }
@@ -871,7 +894,7 @@ int ral_forward(ral_handle* h, const float* x, float* y, int B, int training, ra
 int ral_loss(ral_handle* h, const float* pred, const float* target, int B, int64_t global_windows, float* dy,
              float* snr, float* rmse, double* loss_sum, ral_stream s) {
   if (!h) return fail("null handle");
-  const ral_config& c = h->kind == 1 ? unet_public(h->u)->cfg : h->m->cfg;
+  const ral_config& c = h->kind == 1 ? unet_public(h->u)->cfg : (h->kind == 2 ? acdae_public(h->a)->cfg : h->m->cfg);
   const int n = c.leads * c.L;
   const float gscale = (float)(2.0 / ((double)global_windows * n));
   launch_loss(pred, target, dy, snr, rmse, loss_sum, n, B, gscale, (hipStream_t)s);
@@ -890,13 +913,13 @@ int ral_loss_flat(const float* pred, const float* target, int n, int B, int64_t 
 
 int ral_backward_begin(ral_handle* h, const float* dy, int B, ral_stream s) {
   if (!h) return fail("null handle");
-  if (h->kind == 1) return fail("U-Net: use ral_backward");
+  if (h->kind != 0) return fail("U-Net / ACDAE: use ral_backward");
   return bwd_begin(h->m, dy, B, (hipStream_t)s);
 }
 
 int ral_backward_end(ral_handle* h, float* dx, int B, int64_t global_windows, ral_stream s) {
   if (!h) return fail("null handle");
-  if (h->kind == 1) return fail("U-Net: use ral_backward");
+  if (h->kind != 0) return fail("U-Net / ACDAE: use ral_backward");
   return bwd_end(h->m, dx, B, global_windows, (hipStream_t)s);
 }
 
@@ -926,7 +949,7 @@ int ral_unet_backward_finish(ral_handle* h, int B, int64_t global_windows, ral_s
 #undef UNET_ONLY
 
 int ral_grad_bucket(ral_handle* h, int k, int64_t* offset, int64_t* count) {
-  if (!h || h->kind == 1) return fail("gradient buckets: RA-LENet handles only");
+  if (!h || h->kind != 0) return fail("gradient buckets: RA-LENet handles only");
   if (k < 0 || k > 1 || !offset || !count) return fail("gradient bucket index must be 0 or 1");
   const Layout& Y = h->m->lay;
   *offset = k == 0 ? 0 : Y.dec_off;
@@ -935,7 +958,7 @@ int ral_grad_bucket(ral_handle* h, int k, int64_t* offset, int64_t* count) {
 }
 
 int ral_grad_bucket_wait(ral_handle* h, int k, ral_stream s) {
-  if (!h || h->kind == 1) return fail("gradient buckets: RA-LENet handles only");
+  if (!h || h->kind != 0) return fail("gradient buckets: RA-LENet handles only");
   RalModel* m = h->m;
   if (k == 1) {
     if (m->dec_lanes <= 0) return fail("bucket 1 is available after ral_backward_begin");
@@ -957,13 +980,14 @@ int ral_grad_bucket_wait(ral_handle* h, int k, ral_stream s) {
 int ral_backward(ral_handle* h, const float* dy, float* dx, int B, ral_stream s) {
   if (!h) return fail("null handle");
   if (h->kind == 1) return unet_backward(h->u, dy, dx, B, (hipStream_t)s, g_err, sizeof(g_err));
+  if (h->kind == 2) return acdae_backward(h->a, dy, dx, B, (hipStream_t)s, g_err, sizeof(g_err));
   if (bwd_begin(h->m, dy, B, (hipStream_t)s)) return -1;
   return bwd_end(h->m, dx, B, B, (hipStream_t)s);
 }
 
 int ral_backward_input(ral_handle* h, const float* dy, float* dx, int B, ral_stream s) {
   if (!h) return fail("null handle");
-  if (h->kind == 1) return fail("ral_backward_input: RA-LENet handles only");
+  if (h->kind != 0) return fail("ral_backward_input: RA-LENet handles only");
   if (!dx) return fail("ral_backward_input: dx is the only result, it cannot be NULL");
   RalModel* m = h->m;
   m->want_dw = false;
@@ -979,6 +1003,7 @@ int ral_adam_step(ral_handle* h, double lr, double beta1, double beta2, double e
   float *p, *g, *am, *av;
   int64_t n;
   if (h->kind == 1) { UNetPublic* u = unet_public(h->u); p = u->params; g = u->grads; am = u->am; av = u->av; n = u->nparam; }
+  else if (h->kind == 2) { AcdaePublic* u = acdae_public(h->a); p = u->params; g = u->grads; am = u->am; av = u->av; n = u->nparam; }
   else { p = h->m->params; g = h->m->grads; am = h->m->am; av = h->m->av; n = h->m->lay.nparam; }
   if (!p || !g || !am || !av) return fail("ral_bind: params/grads/adam buffers not bound");
   if (step < 1) return fail("step is 1-based");
@@ -993,6 +1018,7 @@ int ral_set_option(ral_handle* h, const char* key, int value) {
     if (unet_set_option(h->u, key, value)) return fail("unknown U-Net option %s", key);
     return 0;
   }
+  if (h->kind != 0) return fail("no options for this handle");
   RalModel* m = h->m;
   if (!strcmp(key, "lanes")) { m->n_lanes = value < 1 ? 1 : (value > MAX_LANES ? MAX_LANES : value); return 0; }
   if (!strcmp(key, "side_stream")) { m->side_stream = value != 0; return 0; }

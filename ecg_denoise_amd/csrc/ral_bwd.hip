@@ -454,7 +454,9 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd(const float* __restrict__ q
   const int off = (N - Len) >> 1;
   const int kb0 = table ? (off & ~15) : N, kb1 = table ? ((off + Len + 15) & ~15) : N;
   for (int i = threadIdx.x; i < ntab; i += blockDim.x) dtab[i] = 0.f;
+  RAL_STAMP_INIT();
   for (int item = blockIdx.x; item < B * ngrp; item += gridDim.x) {
+    RAL_STAMP_AT(20);
     const int win = item / ngrp, h0 = (item - win * ngrp) * HG;
     const float* base = qkv + (size_t)win * 3 * H * N * 4;
     float* dbase = dqkv + (size_t)win * 3 * H * N * 4;
@@ -490,6 +492,7 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd(const float* __restrict__ q
     }
     for (int i = threadIdx.x; i < ntab; i += blockDim.x) tab[i] = table[(i / HG) * H + h0 + (i % HG)] * RAL_LOG2E;
     __syncthreads();
+    RAL_STAMP_AT(21);
     const int nblk = N / (16 * QT);
     // ---------------- sweep A: dQ (query block on the lanes, loop over key tiles) ----------------
     for (int task = wave; task < HG * nblk; task += nw) {
@@ -553,6 +556,7 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd(const float* __restrict__ q
           *reinterpret_cast<float4*>(dbase + ((size_t)(h0 + hl) * N + q0 + 16 * qt + r) * 4) = f4scale(v, 0.5f);
       }
     }
+    RAL_STAMP_AT(22);
     // ---------------- sweep B: dK, dV (key block on the lanes, loop over query tiles) ----------------
     for (int task = wave; task < HG * nblk; task += nw) {
       const int hl = task / nblk, k0 = (task - hl * nblk) * 16 * QT;
@@ -616,7 +620,9 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd(const float* __restrict__ q
         }
       }
     }
+    RAL_STAMP_AT(23);
     __syncthreads();
+    RAL_STAMP_AT(24);
     if (ntab) {  // flush this item's table gradient (heads differ between items)
       for (int i = threadIdx.x; i < ntab; i += blockDim.x) {
         const float v = dtab[i];

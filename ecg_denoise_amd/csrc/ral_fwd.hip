@@ -87,10 +87,8 @@ __global__ __launch_bounds__(512, (QT >= 4 ? 3 : 4)) void k_attn_fwd(const float
   const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int off = (N - Len) >> 1;
   const int kb0 = table ? (off & ~15) : N, kb1 = table ? ((off + Len + 15) & ~15) : N;  // biased key tiles
-  RAL_STAMP_INIT();
   for (int item = blockIdx.x; item < B * ngrp; item += gridDim.x) {
     const int win = item / ngrp, h0 = (item - win * ngrp) * HG;
-    RAL_STAMP_AT(19);
     const float* base = qkv + (size_t)win * 3 * H * N * 4;
     if ((int)threadIdx.x < HG) { Kmax[threadIdx.x] = 0; if (table) Bmax[threadIdx.x] = 0.f; }
     __syncthreads();
@@ -125,7 +123,6 @@ __global__ __launch_bounds__(512, (QT >= 4 ? 3 : 4)) void k_attn_fwd(const float
         if (t > 0.f) atomicMax(reinterpret_cast<int*>(Bmax) + i % HG, __float_as_int(t));
       }
     __syncthreads();
-    RAL_STAMP_AT(20);
     const int qblocks = N / (16 * QT);
     for (int task = wave; task < HG * qblocks; task += nw) {
       const int hl = task / qblocks, q0 = (task - hl * qblocks) * 16 * QT;
@@ -142,7 +139,6 @@ __global__ __launch_bounds__(512, (QT >= 4 ? 3 : 4)) void k_attn_fwd(const float
         mq[qt] = Mq[hl * N + q] * kmx + (table ? Bmax[hl] : 0.f);
         l2[qt] = f32x2{0.f, 0.f}; o01[qt] = f32x2{0.f, 0.f}; o23[qt] = f32x2{0.f, 0.f};
       }
-      RAL_STAMP_AT(21);
       auto tile = [&](int kt, auto biased) {
         const float kf = Kh[(kt + r) * 4 + g];
         float4 v4[4];
@@ -180,7 +176,6 @@ __global__ __launch_bounds__(512, (QT >= 4 ? 3 : 4)) void k_attn_fwd(const float
       for (int kt = 0; kt < e0; kt += 16) tile(kt, std::false_type{});
       for (int kt = e0; kt < e1; kt += 16) tile(kt, std::true_type{});
       for (int kt = e1; kt < N; kt += 16) tile(kt, std::false_type{});
-      RAL_STAMP_AT(22);
       bool redo = false;
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {
@@ -197,7 +192,6 @@ __global__ __launch_bounds__(512, (QT >= 4 ? 3 : 4)) void k_attn_fwd(const float
           if (lse) lse[hq] = (mq[qt] + __builtin_amdgcn_logf(lv)) * RAL_LN2;   // natural-log units
         }
       }
-      RAL_STAMP_AT(23);
       if (__any(redo)) {   // exact running-max recurrence (lane-private state, merged at the end)
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
@@ -244,9 +238,7 @@ __global__ __launch_bounds__(512, (QT >= 4 ? 3 : 4)) void k_attn_fwd(const float
         }
       }
     }
-    RAL_STAMP_AT(24);
     __syncthreads();
-    RAL_STAMP_AT(25);
   }
 }
 
@@ -387,7 +379,9 @@ __global__ __launch_bounds__(512) void k_mlp_fwd(const float* __restrict__ x, co
   float lw0 = 0.f, lw1 = 0.f, lw2 = 0.f;
   if (le) { lw0 = w.le[0]; lw1 = w.le[1]; lw2 = w.le[2]; }
   if (threadIdx.x == 0) { A0[0] = 0.f; A0[N + 1] = 0.f; }   // zero halo of the LE conv (never overwritten)
+  RAL_STAMP_INIT();
   for (int win = blockIdx.x; win < B; win += gridDim.x) {
+    RAL_STAMP_AT(0);
     const size_t wo = (size_t)win * N * C;
     {   // x (token-major -> padded rows) and o (head-major, flat) staged in one pass: 4 loads in flight per thread
       const float4* gx = reinterpret_cast<const float4*>(x + wo);
@@ -408,6 +402,7 @@ __global__ __launch_bounds__(512) void k_mlp_fwd(const float* __restrict__ x, co
       }
     }
     __syncthreads();
+    RAL_STAMP_AT(1);
     // ---- attention output projection + residual (x1 goes to HBM straight from the epilogue registers) ----
     float* x1w = x1_out ? x1_out + wo : nullptr;
     gemm_phase<C, TTBof<C>::v, false, LAY_HM>(w.wp, C, C, Gs, N, N >> 4, [&](int row0, int tok, f32x4 a) {
@@ -417,6 +412,7 @@ __global__ __launch_bounds__(512) void k_mlp_fwd(const float* __restrict__ x, co
       if (x1w) *reinterpret_cast<float4*>(x1w + (size_t)tok * C + row0) = v;
     });
     __syncthreads();
+    RAL_STAMP_AT(2);
     // ---- LN2 ----
     {
       const float4 gam = *reinterpret_cast<const float4*>(w.ln2w + cq);
@@ -429,6 +425,7 @@ __global__ __launch_bounds__(512) void k_mlp_fwd(const float* __restrict__ x, co
       }
     }
     __syncthreads();
+    RAL_STAMP_AT(3);
     float* upw = upre_out ? upre_out + (size_t)win * N * 4 * C : nullptr;
     float* x2w = x2_out + wo;
 #pragma unroll 1
@@ -448,11 +445,13 @@ __global__ __launch_bounds__(512) void k_mlp_fwd(const float* __restrict__ x, co
         *reinterpret_cast<float4*>(Us + tok * LDU + row0) = h;
       });
       __syncthreads();
+      RAL_STAMP_AT(4);
       if (le && ch == 0) {
         for (int n = threadIdx.x; n < N; n += blockDim.x)
           Us[n * LDU] = gelu_f(lw0 * A0[n] + lw1 * A0[n + 1] + lw2 * A0[n + 2]);
         __syncthreads();
       }
+      RAL_STAMP_AT(5);
       gemm_phase<HC, TTBof<C>::v, false, LAY_TOK>(w.w2 + j0, 4 * C, C, Us, LDU, N >> 4,
                                                   [&](int row0, int tok, f32x4 a) {
         float4* px = reinterpret_cast<float4*>(Xs + tok * LD + row0);
@@ -462,6 +461,7 @@ __global__ __launch_bounds__(512) void k_mlp_fwd(const float* __restrict__ x, co
         else *px = v;
       });
       __syncthreads();
+      RAL_STAMP_AT(6);
     }
   }
 }

@@ -284,6 +284,15 @@ class UNet(_ModuleBase):
         super().__init__("unet", leads, L, max_batch, train, device, seed)
 
 
+class ACDAE(_ModuleBase):
+    """model/ACDAE.py::ACDAE (main.py:66-68): the attention-based convolutional denoising auto-encoder the reference
+    compares against - Conv1d / MaxPool / LeakyReLU encoder, ConvTranspose1d / linear Upsample / LeakyReLU / ECA decoder
+    with additive skips, 2 leads, no BatchNorm (train and eval forward are the same function)."""
+
+    def __init__(self, L=512, max_batch=32, train=True, device="cuda:0", seed=None):
+        super().__init__("acdae", 2, L, max_batch, train, device, seed)
+
+
 class NewRALE:
     """model/ralenet_12leads.py::newrale — 12-lead adapter around a pretrained, frozen RA-LENet
     (Transfer_learning.py:71-75): Conv1d 12->6->2 (k13, LeakyReLU 0.01), RA-LENet, Conv1d 2->6->12.

@@ -1,6 +1,8 @@
 """Round-2 additions to the golden fixtures (build container only; imports the REFERENCE from /root/reference through
 oracle/gen_golden.py's recipe).  Writes, next to the round-1 fixtures:
 
+  tests/golden/g3_acdae_l2_L512.npz   the ACDAE comparison baseline (model/ACDAE.py:62-86) at (4, 2, 512): outputs, loss,
+                                      gradient summaries, three Adam steps (gen_golden.model_case)
   tests/golden/g3_newrale_L1024.npz   BASELINE config 4 at its stated window: `newrale` (ralenet_12leads.py:680-709)
                                       around the reference `transformer.ralenet(high_level_enhence=True)` patched to
                                       L = 1024 (PE max_len, rwattn.whole_length: SURVEY 8c), input (2, 12, 1024):
@@ -48,6 +50,17 @@ def main():
         out["y_eval"] = nr(x).numpy()
     np.savez_compressed(os.path.join(G.OUT, "g3_newrale_L1024.npz"), **out)
     print("g3_newrale_L1024: loss", loss.item(), "snr", out["snr"], "rmse", out["rmse"])
+
+    # ---- ACDAE (model/ACDAE.py), the comparison baseline of SURVEY 8f-4: (4, 2, 512), same recipe as the G3 cases ----
+    import importlib
+    ac = importlib.import_module("model.ACDAE")
+    m = ac.ACDAE()
+    p = O.init_params(O.acdae_param_shapes(), 1234)
+    assert list(p.keys()) == [k for k, _ in m.named_parameters()], "state_dict order"
+    m.load_state_dict(p)
+    gg = torch.Generator().manual_seed(2023)
+    x = torch.randn(4, 2, 512, generator=gg); tgt = torch.randn(4, 2, 512, generator=gg)
+    G.model_case("g3_acdae_l2_L512", m, p, x, tgt, [])
 
 
 if __name__ == "__main__":

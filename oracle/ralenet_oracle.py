@@ -320,6 +320,49 @@ def unet_forward(p, x, training=True, bn=None):
     return x
 
 
+# --------------------------------------------------------------------------- ACDAE (comparison baseline)
+ACDAE_CH = [2, 16, 32, 64, 128]
+ACDAE_KS = [13, 7, 7, 7]
+
+
+def acdae_param_shapes():
+    """model/ACDAE.py:62-73 in state_dict order: the four encoder convs, then per decoder block the transposed conv
+    and the ECA's bias-free 3-tap conv over the channel axis."""
+    d = OrderedDict()
+    for i in range(4):
+        d[f"EncList.{i}.conv.weight"] = (ACDAE_CH[i + 1], ACDAE_CH[i], ACDAE_KS[i])
+        d[f"EncList.{i}.conv.bias"] = (ACDAE_CH[i + 1],)
+    for i in range(4):
+        cin, cout, k = ACDAE_CH[4 - i], ACDAE_CH[3 - i], ACDAE_KS[3 - i]
+        d[f"DecList.{i}.conv.weight"] = (cin, cout, k)
+        d[f"DecList.{i}.conv.bias"] = (cout,)
+        d[f"DecList.{i}.ECA.conv.weight"] = (1, 1, 3)
+    return d
+
+
+def acdae_forward(p, x):
+    """model/ACDAE.py:75-86.  EncBlock (:25-39): Conv1d('same') -> MaxPool1d(2) -> LeakyReLU(0.01).  DecBlock (:42-59):
+    ConvTranspose1d(stride 1, pad (k-1)/2) -> Upsample(x2, linear, align_corners=False) -> LeakyReLU -> ECA (:10-22:
+    channel means -> conv k3 over the channel axis, no bias -> sigmoid -> scale).  Skips are added after the ECA."""
+    feats = []
+    for i in range(4):
+        k = ACDAE_KS[i]
+        x = F.conv1d(x, p[f"EncList.{i}.conv.weight"], p[f"EncList.{i}.conv.bias"], padding=(k - 1) // 2)
+        x = F.leaky_relu(F.max_pool1d(x, 2), 0.01)
+        if i < 3:
+            feats.append(x)
+    for i in range(4):
+        k = ACDAE_KS[3 - i]
+        x = F.conv_transpose1d(x, p[f"DecList.{i}.conv.weight"], p[f"DecList.{i}.conv.bias"], padding=(k - 1) // 2)
+        x = F.leaky_relu(F.interpolate(x, scale_factor=2, mode="linear", align_corners=False), 0.01)
+        m = x.mean(-1, keepdim=True)                                             # (B, C, 1)
+        z = F.conv1d(m.transpose(-1, -2), p[f"DecList.{i}.ECA.conv.weight"], padding=1).transpose(-1, -2)
+        x = x * torch.sigmoid(z)
+        if i < 3:
+            x = x + feats[2 - i]
+    return x
+
+
 # --------------------------------------------------------------------------- newrale
 def newrale_param_shapes():
     d = OrderedDict()

@@ -155,6 +155,30 @@ def test_unet_whole_model(golden_dir):
     np.testing.assert_allclose(a1n[keep], g["adam1_norm"][keep], rtol=1e-5)
 
 
+def test_acdae(golden_dir):
+    """the ACDAE restatement against the reference's own outputs, gradients and Adam trajectory"""
+    g = load(golden_dir, "g3_acdae_l2_L512")
+    p = O.init_params(O.acdae_param_shapes(), 1234)
+    assert [str(k) for k in g["keys"]] == list(p.keys())
+    x = torch.tensor(g["x"]); tgt = torch.tensor(g["target"])
+    m = OrderedDict((k, torch.zeros_like(v)) for k, v in p.items())
+    v = OrderedDict((k, torch.zeros_like(t)) for k, t in p.items())
+    fwd = lambda pp, xx: O.acdae_forward(pp, xx)
+    losses = []
+    for s_ in (1, 2, 3):
+        r = O.train_step(p, x, tgt, fwd, m, v, s_)
+        losses.append(r["loss"].item())
+        if s_ == 1:
+            assert rel(r["pred"].numpy(), g["y_train"]) < 5e-6
+            assert rel(r["pred"].numpy(), g["y_eval"]) < 5e-6          # no BatchNorm: train == eval
+            gn, gs = summarize(r["grads"])
+            np.testing.assert_allclose(gn, g["grad_norm"], rtol=2e-4, atol=1e-9)
+            assert rel(gs, g["grad_samp"]) < 2e-4
+            a1n, _ = summarize(p)
+            np.testing.assert_allclose(a1n, g["adam1_norm"], rtol=1e-4)
+    np.testing.assert_allclose(losses, g["adam_losses"], rtol=2e-4)
+
+
 def test_newrale(golden_dir):
     g = load(golden_dir, "g3_newrale_L256")
     p = O.init_params(O.ralenet_param_shapes("full", 2), 1234)

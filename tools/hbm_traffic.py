@@ -9,7 +9,9 @@ import collections, csv, json, sys
 
 KIND_OF = {"k_qkv_fwd": "qkv_fwd", "k_attn_fwd": "attn_fwd", "k_mlp_fwd": "mlp_fwd", "k_resample_fwd": "resample_fwd",
            "k_resample_bwd": "resample_bwd", "k_dw": "dw", "k_mlp_bwd": "mlp_bwd", "k_mlp_bwd_s": "mlp_bwd",
-           "k_attn_bwd": "attn_bwd", "k_qkv_bwd": "qkv_bwd"}
+           "k_attn_bwd": "attn_bwd", "k_qkv_bwd": "qkv_bwd", "k_attn_fwd_v": "attn_fwd", "k_attn_bwd_vq": "attn_bwd",
+           "k_attn_bwd_vkv": "attn_bwd", "k_attn_table_reduce": "attn_bwd",
+           "k_unet_infer": "unet_infer_fused", "k_unet_fwd_t": "unet_fwd_stage", "k_unet_out": "unet_fwd_stage"}
 
 
 def family(name):
