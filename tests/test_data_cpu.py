@@ -34,3 +34,18 @@ def test_generator_is_deterministic_and_r_peak_is_central():
     assert np.array_equal(a, b) and np.array_equal(ca, cb)
     centre = np.abs(ca[:, 0, 256 - 40:256 + 40]).max(-1)         # one R peak sits in the central eighth
     assert np.all(centre >= 0.9 * np.abs(ca[:, 0]).max(-1))
+
+
+def test_scoring_functions_match_reference_arithmetic():
+    """test_cls.py:14-29 on a hand-checkable case: labels 1 1 1 0 0 0, predictions 1 1 0 1 0 0 -> TP 2, FP 1, FN 1"""
+    import torch
+    from ecg_denoise_amd import scoring
+    label = torch.tensor([1, 1, 1, 0, 0, 0])
+    logits = torch.tensor([[0., 1.], [0., 2.], [1., 0.], [0., 1.], [3., 0.], [1., 0.]])
+    assert scoring.acc(logits, label) == 4 / 6
+    assert scoring.precision(logits, label) == 2 / 3
+    assert scoring.f1_score(logits, label) == 2 / (2 + 0.5 * 2)
+    loader = [(torch.zeros(3, 2, 8), label[:3]), (torch.zeros(3, 2, 8), label[3:])]
+    it = iter([logits[:3], logits[3:]])
+    a, p, f = scoring.score_denoiser(lambda d: next(it), None, loader, "cpu")
+    assert (a, p, f) == (4 / 6, 2 / 3, 2 / 3)
