@@ -199,3 +199,17 @@ def test_metrics(golden_dir):
     np.testing.assert_allclose(O.rmse(y, pred).numpy(), g["rmse"], rtol=1e-6)
     np.testing.assert_allclose(O.snr(y, 0.9 * y).numpy(), 20.0, atol=1e-4)
     np.testing.assert_allclose(g["snr_09"], 20.0, atol=1e-4)
+
+
+def test_reference_run_to_run_spread_fixtures(golden_dir):
+    """What the three 100-epoch curves of the REFERENCE say about its own repeatability (same data, same initial weights,
+    only the intra-op thread count = summation order differs; oracle/gen_ref_train_curve.py): identical to 1e-3 dB for
+    two epochs, apart by more than 0.1 dB from epoch 3, 0.55 dB apart at the end.  The north star's "within 0.05 dB of
+    the reference" is therefore testable for the first ~500 optimiser steps only; after that the bar is the reference's
+    own spread (tests/test_gpu_train_loop.py)."""
+    c = np.stack([load(golden_dir, f"g6_ref_train_curve_full{t}")["test_snr"] for t in ("", "_t2", "_t3")])
+    assert c.shape == (3, 100)
+    assert np.ptp(c[:, :2], axis=0).max() < 1e-3
+    assert np.ptp(c[:, 2]) > 0.1
+    assert np.ptp(c[:, -1]) > 0.4
+    assert 0.2 < np.ptp(c[:, -10:].mean(1)) < 0.6

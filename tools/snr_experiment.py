@@ -12,6 +12,7 @@ from ecg_denoise_amd.train import train
 epochs = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 variant = sys.argv[2] if len(sys.argv) > 2 else "full"
 init_seed = int(sys.argv[3]) if len(sys.argv) > 3 else 777   # 777 = the seed of the reference curve fixture
+run_tag = sys.argv[4] if len(sys.argv) > 4 else ""           # repeats of one configuration (the fp32 atomics make runs differ)
 noisy, clean = synth.make_dataset(10000, 2, 256, "emb", 0.0, seed=2023)
 (trn, trc), (ten, tec) = synth.split_8000_2000(noisy, clean)
 batches = lambda a, b: [(a[i:i + 32], b[i:i + 32]) for i in range(0, len(a), 32)]
@@ -61,6 +62,6 @@ if os.path.exists(ref_path):
     out["mean_last10_db"] = float(np.mean(res[1][n - 10:n])); out["reference_mean_last10_db"] = float(np.mean(g["test_snr"][n - 10:n]))
     out["first5_delta_db"] = [round(res[1][i] - float(g["test_snr"][i]), 4) for i in range(min(5, n))]
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"snr_experiment_{variant}_seed{init_seed}.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"snr_experiment_{variant}_seed{init_seed}{run_tag}.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if "curve" not in k}))
 print("test SNR by epoch (every 10th):", [round(v, 3) for v in res[1][9::10]])
