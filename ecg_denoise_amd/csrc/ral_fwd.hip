@@ -69,7 +69,7 @@ RAL_STAMPS_DEFINE(ral_debug_stamps_fwd)
 // is known before the sweep.  -m[q] is fed to the MFMA as its C operand, so the tile comes out
 // as s - m <= 0 ready for exp2 with no VALU subtract, no max and no rescale.  If a row's bound is
 // so loose that every term underflows (row sum < 1e-30) the task is redone with the exact
-// running-max recurrence (never seen on real data; exercised by tests/test_gpu_parity.py).
+// running-max recurrence (never seen on real data; forced by tests/test_gpu_configs.py::test_attention_forward_exact_fallback).
 template <int QT>
 __global__ __launch_bounds__(512, (QT >= 4 ? 3 : 4)) void k_attn_fwd(const float* __restrict__ qkv, float* __restrict__ o_hm,
                                                   float* __restrict__ lse, const float* __restrict__ table,
