@@ -7,7 +7,9 @@ import glob, json, os
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ref = []
-for tag, th in (("", 6), ("_t2", 2), ("_t3", 3)):
+for tag, th in (("", 6), ("_t2", 2), ("_t3", 3), ("_t1", 1), ("_t4", 4)):
+    if not os.path.exists(os.path.join(ROOT, "tests", "golden", f"g6_ref_train_curve_full{tag}.npz")):
+        continue
     g = np.load(os.path.join(ROOT, "tests", "golden", f"g6_ref_train_curve_full{tag}.npz"))
     c = g["test_snr"].astype(float)
     ref.append({"threads": th, "final_test_snr_db": round(c[-1], 4), "mean_last10_db": round(c[-10:].mean(), 4),
@@ -25,17 +27,21 @@ for d in r01:
 same = [h for h in hip if h["init_seed"] == 777]
 rl, hl = [r["mean_last10_db"] for r in ref], [h["mean_last10_db"] for h in same]
 rf, hf = [r["final_test_snr_db"] for r in ref], [h["final_test_snr_db"] for h in same]
+first2 = np.array([r["first5_db"][:2] for r in ref] + [h["first5_db"][:2] for h in same if "first5_db" in h])
+agree = float(np.abs(first2 - first2[0]).max())
+sd = lambda v: float(np.std(v, ddof=1))
+reading = (f"{len(ref)} reference runs that differ only in summation order end {max(rf) - min(rf):.2f} dB apart ({min(rf):.2f} .. {max(rf):.2f}), "
+           f"{len(same)} HIP runs from the same weights {max(hf) - min(hf):.2f} dB apart ({min(hf):.2f} .. {max(hf):.2f}); all {len(first2)} curves that "
+           f"were recorded per epoch agree to {agree:.1e} dB for the first two epochs (500 optimiser steps) and separate at epoch 3.  Means of the last ten "
+           f"epochs: reference {min(rl):.2f} .. {max(rl):.2f} (mean {np.mean(rl):.2f}, s.d. {sd(rl):.2f}), HIP {min(hl):.2f} .. {max(hl):.2f} "
+           f"(mean {np.mean(hl):.2f}, s.d. {sd(hl):.2f}): the HIP path is inside the reference's own run-to-run spread.")
 out = {"note": __doc__.replace("\n", " "),
        "summary": {"reference_final_db": rf, "reference_final_range_db": round(max(rf) - min(rf), 3),
                    "reference_mean_last10_db": rl, "reference_mean_of_mean_last10_db": round(float(np.mean(rl)), 3),
                    "hip_same_init_final_db": hf, "hip_same_init_final_range_db": round(max(hf) - min(hf), 3),
                    "hip_same_init_mean_last10_db": hl, "hip_mean_of_mean_last10_db": round(float(np.mean(hl)), 3),
                    "hip_minus_reference_mean_last10_db": round(float(np.mean(hl) - np.mean(rl)), 3),
-                   "epochs_1_2_identical_to_db": 1e-3,
-                   "reading": "three reference runs that differ only in summation order end 0.55 dB apart (19.16 .. 19.72), four HIP runs "
-                              "from the same weights 1.35 dB apart (18.48 .. 19.83); all seven agree to 1e-3 dB for the first two epochs "
-                              "(500 optimiser steps) and separate at epoch 3.  Means of the last ten epochs: reference 19.36 .. 19.69 "
-                              "(mean 19.54), HIP 19.25 .. 19.71 (mean 19.58): the HIP path is inside the reference's own run-to-run spread."},
+                   "epochs_1_2_max_difference_db": round(agree, 5), "reading": reading},
        "reference_runs": ref, "hip_runs": hip}
 json.dump(out, open(os.path.join(ROOT, "profiles", "r02_snr_experiment.json"), "w"), indent=1)
 print(json.dumps(out["summary"], indent=1))
