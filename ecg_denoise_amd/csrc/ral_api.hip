@@ -214,11 +214,13 @@ struct RalModel {
   void* lanes = nullptr;   // LaneSet
   int n_lanes = 2;
   bool side_stream = true;
+  int qkv_bf16 = 64;          // narrowest width whose q/k/v projection runs as bf16 x 3 on the bf16 matrix cores (0 = none)
   bool want_dw = true;      // false inside ral_backward_input: frozen weights, data gradients only
   int dec_lanes = 0; bool dec_side = false;   // lanes / side streams that carried the last backward (bucket events)
   hipEvent_t ev_bwd_done = nullptr;          // recorded at the end of ral_backward_end
   bool bwd_recorded = false;
   float* paramsT = nullptr;   // transposed copies of the weight matrices (same offsets), refreshed per backward
+  unsigned short* wqkv_b[18] = {nullptr};   // bf16 x 3 planes of Wqkv for the blocks whose projection runs on the bf16 matrix cores
   void* tdesc = nullptr; int tn = 0, ttotal = 0;
   const float* last_x = nullptr;
   int last_B = 0;
@@ -291,6 +293,10 @@ static size_t plan_workspace(const ral_config& c, RalModel* m /* may be null: si
     const int lvl = STAGES[b / 2].level;
     a.upre = (tr && !mlp_bwd_is_fused(CH[lvl], c.L >> lvl)) ? take((p + "upre").c_str(), 4 * E) : nullptr;
     a.out = take((p + "out").c_str(), E);
+  }
+  for (int b = 0; b < 18; ++b) {
+    const int Cb = CH[STAGES[b / 2].level];
+    M.wqkv_b[b] = qkv_fwd_uses_bf16(Cb) ? reinterpret_cast<unsigned short*>(take(("wqkvb" + std::to_string(b)).c_str(), (size_t)3 * 3 * Cb * Cb / 2 + 4)) : nullptr;
   }
   static const char* RN[8] = {"p1", "p2", "p3", "p4", "u3", "u2", "u1", "u0"};
   for (int r = 0; r < 8; ++r) M.res_out[r] = take(RN[r], E);
@@ -402,7 +408,7 @@ static void run_block_fwd(RalModel* m, int bi, const float* in, bool training, c
   const float* x = woff(in, w0, E1);
   float* qkv = woff(a.qkv, w0, 3 * E1);
   float* o = woff(a.o, w0, E1);
-  { ProfScope p(m, K_QKV_FWD, s); launch_qkv_fwd(C, x, m->pe[l], w, qkv, N, B, s); }
+  { ProfScope p(m, K_QKV_FWD, s); launch_qkv_fwd(C, x, m->pe[l], w, (m->qkv_bf16 > 0 && C >= m->qkv_bf16) ? m->wqkv_b[bi] : nullptr, qkv, N, B, s); }
   { ProfScope p(m, K_ATTN_FWD, s);
     launch_attn_fwd(qkv, o, training ? woff(a.lse, w0, E1 / 4) : nullptr, table, N, H, m->hg_f[l], Len, B, s); }
   { ProfScope p(m, K_MLP_FWD, s);
@@ -480,6 +486,11 @@ static int fwd_end(RalModel* m, float* y, int B, int64_t global_windows, int tra
     launch_bn_apply8(m->a0, m->ss, m->x0, (size_t)B * m->L, s);
   }
   const bool tr = training != 0;
+  for (int b = 0; b < 18; ++b)      // bf16 x 3 planes of the projection weights that run on the bf16 matrix cores
+    if (m->wqkv_b[b] && m->qkv_bf16 > 0 && CH[STAGES[b / 2].level] >= m->qkv_bf16) {
+      const int Cb = CH[STAGES[b / 2].level];
+      launch_split_planes(m->params + Y.blk[b].wqkv, m->wqkv_b[b], (size_t)3 * Cb * Cb, s);
+    }
   const int nl = plan_lanes(m, B, s);
   fork_lanes(m, s);
   LaneSet* LS = lanes_of(m);
@@ -831,6 +842,7 @@ int ral_create(const ral_config* cfg, ral_handle** out) {
       return -1;
     }
   }
+  if (const char* v = getenv("RAL_QKV_BF16")) m->qkv_bf16 = atoi(v);
   if (cfg->train) {
     m->side_stream = getenv("RAL_NO_SIDE_STREAM") == nullptr;
     std::vector<int> d;
@@ -1022,6 +1034,7 @@ int ral_set_option(ral_handle* h, const char* key, int value) {
   RalModel* m = h->m;
   if (!strcmp(key, "lanes")) { m->n_lanes = value < 1 ? 1 : (value > MAX_LANES ? MAX_LANES : value); return 0; }
   if (!strcmp(key, "side_stream")) { m->side_stream = value != 0; return 0; }
+  if (!strcmp(key, "qkv_bf16")) { m->qkv_bf16 = value; return 0; }
   return fail("unknown option %s", key);
 }
 

@@ -131,6 +131,73 @@ RAL_DEV void gemm_phase(const float* __restrict__ W, int ldw, int M, const float
   else gemm_phase_t<K, 1, WT, LAY>(W, ldw, M, Xs, ldx, ntiles, epi);
 }
 
+// ---------------------------------------------------------------------------------
+// fp32 products on the bf16 matrix cores (pilot: the QKV projection of the wide levels).
+// x = x1 + x2 + x3 with three bf16 pieces carries the 24 significant bits of an fp32 value (x - x1 and x - x1 - x2 are
+// exact in fp32); the six piece products whose weight is >= 2^-16 (W1X1, W1X2, W2X1, W1X3, W2X2, W3X1), accumulated in
+// fp32 by v_mfma_f32_16x16x32_bf16, reproduce the fp32 product to ~2^-22 relative - 6 x 16 matrix-core cycles per
+// 16 x 16 x 32 instead of 8 x 34.5 cycles of the fp32 MFMA, which runs on the vector ALU's multipliers.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+struct Bf3 { __bf16 a, b, c; };
+RAL_DEV Bf3 bf16_split3(float x) {
+  Bf3 r;
+  r.a = (__bf16)x;
+  const float e1 = x - (float)r.a;
+  r.b = (__bf16)e1;
+  r.c = (__bf16)(e1 - (float)r.b);
+  return r;
+}
+// row stride (bf16 elements) of a K-contiguous bf16 tile of width K: + 8 keeps the 16-byte fragment reads of 16
+// consecutive rows on distinct banks
+constexpr int ldb_of(int K) { return K + 8; }
+
+// acc[mi][tt] += W[m0 + 16 mi .., :K] x X[t0 + 16 tt .., :K]^T from three bf16 planes each: Wb[p] (rows of K, row-major,
+// global, plane stride wplane elements), Xb[p] (LDS rows of ldx elements, plane stride xplane).  K % 32 == 0.  An
+// MT x TT register block: (MT + TT) x 3 fragment loads of 16 bytes feed MT * TT * 6 MFMAs - with 2 x 4 the LDS sees 14
+// bytes per cycle per SIMD of its 32 and the vector L1 7 of its 16 (one 16 x 16 x 32 bf16 MFMA issues in 18.7 cycles,
+// tools/diag/valu_probe.hip), where a 1 x 2 block would need 27 and 14.
+template <int K, int MT, int TT>
+RAL_DEV void gemm_wx_b3(const __bf16* __restrict__ Wb, size_t wplane, int m0, const __bf16* Xb, int xplane, int ldx,
+                        int t0, f32x4 (&acc)[MT][TT]) {
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  auto mma6 = [&](const bf16x8 (&a)[3], const bf16x8& b1, const bf16x8& b2, const bf16x8& b3, f32x4& c) {   // smallest terms first
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b1, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b2, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b3, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b1, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b2, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b1, c, 0, 0, 0);
+  };
+  // weight fragments of chunk kc + 1 are requested before the MFMAs of chunk kc (the loop stays rolled: unrolled, hipcc
+  // hoists every chunk's loads to the top and spills)
+  bf16x8 a[MT][3], an[MT][3];
+  const __bf16* wp = Wb + (size_t)(m0 + r) * K + 8 * g;
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) an[mi][p] = *reinterpret_cast<const bf16x8*>(wp + p * wplane + (size_t)mi * 16 * K);
+#pragma unroll 1
+  for (int kc = 0; kc < K / 32; ++kc) {
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) a[mi][p] = an[mi][p];
+    const int kn = kc + 1 < K / 32 ? kc + 1 : kc;
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) an[mi][p] = *reinterpret_cast<const bf16x8*>(wp + p * wplane + (size_t)mi * 16 * K + kn * 32);
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+      const int xo = (t0 + 16 * tt + r) * ldx + kc * 32 + 8 * g;
+      const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(Xb + xo), b2 = *reinterpret_cast<const bf16x8*>(Xb + xplane + xo),
+                   b3 = *reinterpret_cast<const bf16x8*>(Xb + 2 * xplane + xo);
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) mma6(a[mi], b1, b2, b3, acc[mi][tt]);
+    }
+  }
+}
+
 // row stride (floats) of a token-major LDS tile of width C: +4 breaks the power-of-two stride for the
 // b128 fragment reads; the 8-wide level keeps its rows dense so that 1024-sample windows still fit
 template <int C> struct LDof { static constexpr int v = (C == 8) ? 8 : C + 4; };

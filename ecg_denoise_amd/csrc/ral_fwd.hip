@@ -49,6 +49,90 @@ __global__ __launch_bounds__(256) void k_qkv_fwd(const float* __restrict__ x, co
 }
 
 // =================================================================================
+// K1b (wide levels, C >= 64): the same projection with the GEMM on the bf16 matrix cores - LayerNorm output and weights as
+// three bf16 pieces each, six piece products per term (gemm_wx_b3, ral_device.hpp): fp32-accurate to ~2^-22, 2.9 x fewer
+// matrix cycles than the fp32 MFMA.  wb: the three bf16 planes of Wqkv (3C x C each, plane stride `wplane`), written by
+// k_split_planes from the fp32 parameters before the forward pass.
+// =================================================================================
+// A workgroup takes GT consecutive tokens of the batch at a time (whole windows or whole parts of one: N | GT or GT | N)
+// so that every weight fragment it fetches meets 4 token tiles.
+template <int C, int GT>
+__global__ __launch_bounds__(256) void k_qkv_fwd_b(const float* __restrict__ x, const float* __restrict__ pe,
+                                                      BlockP w, const __bf16* __restrict__ wb, size_t wplane,
+                                                      float* __restrict__ qkv, int N, int B) {
+  extern __shared__ float4 smem4[];
+  __bf16* Hb = reinterpret_cast<__bf16*>(smem4);          // 3 planes x GT x LDB
+  constexpr int LDB = ldb_of(C), LPR = C / 4, RPP = 256 / LPR, TT = 4;
+  constexpr int MT = (3 * C / 16) % 8 == 0 ? 2 : 1;   // whole rounds of (m-block) units over the four waves
+  constexpr int xplane = GT * LDB;
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  const float sqrtC = sqrtf((float)C);
+  const int cq = (threadIdx.x % LPR) * 4;
+  const float4 gam = *reinterpret_cast<const float4*>(w.ln1w + cq);
+  const float4 bet = *reinterpret_cast<const float4*>(w.ln1b + cq);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const long total = (long)B * N;
+  const int ngroups = (int)((total + GT - 1) / GT);
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const long g0 = (long)grp * GT;
+#pragma unroll 4
+    for (int row = threadIdx.x / LPR; row < GT; row += RPP) {
+      const long gt = g0 + row < total ? g0 + row : total - 1;
+      const int tok = (int)(gt % N);
+      float4 v = *reinterpret_cast<const float4*>(x + gt * C + cq);
+      const float4 p = *reinterpret_cast<const float4*>(pe + tok * C + cq);
+      v = f4add(f4scale(v, sqrtC), p);
+      float4 d; float rstd;
+      ln_stats<LPR>(v, d, rstd);
+      const float4 h = f4add(f4mul(f4scale(d, rstd), gam), bet);
+      const Bf3 s0 = bf16_split3(h.x), s1 = bf16_split3(h.y), s2 = bf16_split3(h.z), s3 = bf16_split3(h.w);
+      *reinterpret_cast<bf16x4*>(Hb + row * LDB + cq) = bf16x4{s0.a, s1.a, s2.a, s3.a};
+      *reinterpret_cast<bf16x4*>(Hb + xplane + row * LDB + cq) = bf16x4{s0.b, s1.b, s2.b, s3.b};
+      *reinterpret_cast<bf16x4*>(Hb + 2 * xplane + row * LDB + cq) = bf16x4{s0.c, s1.c, s2.c, s3.c};
+    }
+    __syncthreads();
+    constexpr int MU = 3 * C / (16 * MT), TU = GT / (16 * TT);
+    for (int u = wave; u < MU * TU; u += 4) {
+      const int mu = u % MU, tu = u / MU;
+      f32x4 acc[MT][TT];
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) acc[mi][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      gemm_wx_b3<C, MT, TT>(wb, wplane, mu * MT * 16, Hb, xplane, LDB, tu * TT * 16, acc);
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) {
+        const int row0 = (mu * MT + mi) * 16 + 4 * g;
+        const float4 bias = *reinterpret_cast<const float4*>(w.bqkv + row0);
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+          const long gt = g0 + (tu * TT + tt) * 16 + r;
+          if (gt < total) {
+            const long win = gt / N;
+            const int tok = (int)(gt - win * N);
+            float4 v = f4add(tofloat4(acc[mi][tt]), bias);
+            if (row0 < C) v = f4scale(v, 0.5f);  // q * head_dim^-0.5, head_dim = 4
+            *reinterpret_cast<float4*>(qkv + win * 3 * N * C + ((size_t)(row0 >> 2) * N + tok) * 4) = v;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// fp32 matrix (n elements) -> three bf16 planes (plane stride n)
+__global__ void k_split_planes(const float* __restrict__ src, __bf16* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const Bf3 s3 = bf16_split3(src[i]);
+    dst[i] = s3.a; dst[n + i] = s3.b; dst[2 * n + i] = s3.c;
+  }
+}
+void launch_split_planes(const float* src, void* dst, size_t n, hipStream_t s) {
+  k_split_planes<<<(int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024), 256, 0, s>>>(src, reinterpret_cast<__bf16*>(dst), n);
+}
+
+// =================================================================================
 // K2: softmax(q k^T + bias) v per (window, head); full N x N, head_dim 4.  Nothing
 // N x N is ever stored.  S^T tiles come from the fp32 MFMA with the KEY on the row and
 // the QUERY on the lane column: a lane owns one query and four keys per tile, so the
@@ -515,7 +599,23 @@ __global__ void k_add(const float* __restrict__ a, const float* __restrict__ b, 
 // =================================================================================
 static inline int grid_for(int items) { return items < 4096 ? items : 4096; }
 
-void launch_qkv_fwd(int C, const float* x, const float* pe, const BlockP& w, float* qkv, int N, int B, hipStream_t s) {
+// widths whose projection has a bf16 x 3 kernel (the caller passes the weight planes to choose it)
+bool qkv_fwd_uses_bf16(int C) { return C == 64 || C == 128; }
+
+void launch_qkv_fwd(int C, const float* x, const float* pe, const BlockP& w, const void* wb, float* qkv, int N, int B, hipStream_t s) {
+  if (wb && qkv_fwd_uses_bf16(C) && N % 16 == 0) {
+    const size_t wplane = (size_t)3 * C * C;
+    const __bf16* wbp = reinterpret_cast<const __bf16*>(wb);
+    auto go = [&](auto kern, int GT) {
+      const size_t ldsb = (size_t)3 * GT * ldb_of(C) * 2;
+      RAL_SET_LDS(kern, ldsb);
+      const long ngroups = ((long)B * N + GT - 1) / GT;
+      const int wgs = (int)(160 * 1024 / (ldsb + 1024)) * 256;   // what fits the CUs at once
+      kern<<<(int)(ngroups < wgs ? ngroups : wgs), 256, ldsb, s>>>(x, pe, w, wbp, wplane, qkv, N, B);
+    };
+    if (C == 64 && (N % 64 == 0 || 64 % N == 0)) { go(k_qkv_fwd_b<64, 64>, 64); return; }
+    if (C == 128 && (N % 64 == 0 || 64 % N == 0)) { go(k_qkv_fwd_b<128, 64>, 64); return; }
+  }
   const size_t lds = (size_t)N * ld_of(C) * sizeof(float);
   switch (C) {
 #define CASE(c) case c: k_qkv_fwd<c><<<grid_for(B), 256, lds, s>>>(x, pe, w, qkv, N, B); break;

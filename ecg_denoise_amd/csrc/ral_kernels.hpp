@@ -16,7 +16,10 @@
   } while (0)
 
 // ---- forward (ral_fwd.hip)
-void launch_qkv_fwd(int C, const float* x, const float* pe, const BlockP& w, float* qkv, int N, int B, hipStream_t s);
+// wb: three bf16 planes of Wqkv (launch_split_planes) for the levels where qkv_fwd_uses_bf16(C), else ignored / null
+bool qkv_fwd_uses_bf16(int C);
+void launch_split_planes(const float* src, void* dst, size_t n, hipStream_t s);
+void launch_qkv_fwd(int C, const float* x, const float* pe, const BlockP& w, const void* wb, float* qkv, int N, int B, hipStream_t s);
 size_t attn_fwd_lds(int N, int HG, int Len);
 void launch_attn_fwd(const float* qkv, float* o_hm, float* lse, const float* table, int N, int H, int HG, int Len,
                      int B, hipStream_t s);

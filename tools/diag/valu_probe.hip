@@ -163,6 +163,16 @@ __global__ void k_probe(float* out, long long* cyc, float seed, int iters) {
           for (int i = 0; i < 8; ++i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p[2 + (i & 3)]) : "v"(m2), "v"(c2));
         }
       }
+    } else if (KIND == 20) {   // 16 bf16 MFMAs 16x16x32 forced by inline asm (4 independent accumulators, operands in registers)
+      typedef short s16x8 __attribute__((ext_vector_type(8)));
+      s16x8 ab;
+      for (int i = 0; i < 8; ++i) ab[i] = (short)(__float_as_uint(a[i]) >> 16);
+      f32x4 ac[4] = {acc, acc, acc, acc};
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %1, %0" : "+v"(ac[i]) : "v"(ab));
+      acc = ac[0] + ac[1] + ac[2] + ac[3];
     } else if (KIND == 8) {   // 16 bare mfma 16x16x4 f32 (4 accumulators)
       f32x4 ac[4] = {acc, acc, acc, acc};
 #pragma unroll
@@ -219,6 +229,7 @@ int main() {
   run<7>("v_pk_mul_f32", REP);
   run<8>("v_mfma_f32_16x16x4_f32 (per mfma)", 16);
   run<12>("v_mfma_f32_16x16x32_bf16 (per mfma)", 16);
+  run<20>("v_mfma_f32_16x16x32_bf16, asm-forced (per mfma)", 16);
   run<13>("v_fma_f32 with an SGPR operand", REP);
   run<14>("v_pk_fma_f32 with an SGPR-pair operand", REP);
   run<15>("v_pk_fma_f32 op_sel broadcast", REP);
