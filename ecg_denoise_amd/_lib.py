@@ -79,6 +79,7 @@ _SIGS = {
     "ral_attention_forward": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, _VP]),
     "ral_attention_backward": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, _VP]),
     "ral_set_option": (C.c_int, [_VP, C.c_char_p, C.c_int]),
+    "ral_wavelet_denoise": (C.c_int, [_VP, _VP, C.c_int64, C.c_int, C.c_float, _VP]),
     "ral_profile_select": (C.c_int, [_VP, C.c_char_p]),
     "ral_profile_read": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "ral_pe_table": (C.c_int, [C.POINTER(RalConfig), C.c_int, _VP, C.c_int64]),

@@ -1116,6 +1116,15 @@ int ral_stream_stitch(const float* y, const float* stats, int64_t R, int64_t T, 
   return 0;
 }
 
+int ral_wavelet_denoise(const float* x, float* y, int64_t rows, int L, float threshold, ral_stream s) {
+  if (!x || !y) return fail("wavelet_denoise: null pointer");
+  if (!(threshold >= 0.f)) return fail("wavelet_denoise: the threshold factor must be non-negative (got %g)", (double)threshold);
+  if (launch_wavelet_denoise(x, y, (long long)rows, L, threshold, (hipStream_t)s))
+    return fail("wavelet_denoise: need rows >= 0 and an even record length <= 8192 (rows=%lld L=%d)", (long long)rows, L);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
 static int check_attn_args(int N, int H, int Len, int B) {
   if (N < 16 || N % 16 != 0 || N > 1024) return fail("attention: N must be a multiple of 16 in [16, 1024] (got %d)", N);
   if (H < 1 || (H & (H - 1)) != 0 || H > 32) return fail("attention: H must be a power of two <= 32 (got %d)", H);

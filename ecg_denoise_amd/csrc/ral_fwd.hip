@@ -75,7 +75,6 @@ __global__ __launch_bounds__(256) void k_qkv_fwd_b(const float* __restrict__ x, 
   const int ngroups = (int)((total + GT - 1) / GT);
   for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const long g0 = (long)grp * GT;
-#pragma unroll 4
     for (int row = threadIdx.x / LPR; row < GT; row += RPP) {
       const long gt = g0 + row < total ? g0 + row : total - 1;
       const int tok = (int)(gt % N);

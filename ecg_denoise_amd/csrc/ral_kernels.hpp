@@ -87,3 +87,6 @@ void launch_block_dw(int C, const float* dx2, const float* upre, const float* a2
 void set_dw_lds_budget(size_t bytes);
 void launch_resample_dw(int D, bool sep, const float* dy, const float* x, const float* lnw, const float* lnb,
                         float* dW, int T, int B, int ksplit, hipStream_t s);
+
+// db8 wavelet-threshold baseline (ral_wavelet.hip); non-zero = rejected arguments
+int launch_wavelet_denoise(const float* x, float* y, long long rows, int L, float threshold, hipStream_t s);
