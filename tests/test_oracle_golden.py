@@ -213,3 +213,36 @@ def test_reference_run_to_run_spread_fixtures(golden_dir):
     assert np.ptp(c[:, 2]) > 0.1
     assert np.ptp(c[:, -1]) > 0.4
     assert 0.2 < np.ptp(c[:, -10:].mean(1)) < 0.6
+
+
+def test_danet_oracle_matches_reference_golden(golden_dir):
+    """oracle/danet_oracle.py against the reference's model/DAM.py::Seq2Seq2 (fixture made by oracle/gen_golden_danet.py):
+    eval output, train output, loss, every parameter gradient, every running statistic after one training forward -
+    including the DAM's shared fcn, whose BatchNorm statistics are updated twice per forward."""
+    import danet_oracle as D
+    g = np.load(os.path.join(golden_dir, "g3_danet_L512.npz"))
+    x = torch.from_numpy(g["x"]).double(); tgt = torch.from_numpy(g["target"]).double()
+    st = D.init_state(4321, dtype=torch.float64)
+    with torch.no_grad():
+        ye = D.danet_forward(st, x, training=False)
+    assert rel(ye.numpy(), g["y_eval"]) < 1e-5
+    params = OrderedDict((k, v.requires_grad_(True)) for k, v in st.items() if D.is_param(k) and ".dam.fcn2." not in k)
+    y = D.danet_forward(st, x, training=True)
+    loss = torch.nn.functional.mse_loss(y, tgt)
+    loss.backward()
+    assert rel(y.detach().numpy(), g["y_train"]) < 1e-5
+    assert abs(loss.item() - float(g["loss"])) < 1e-5 * float(g["loss"])
+    for k, p in params.items():
+        if k.endswith((".fcn.0.bias", ".fcn.3.bias", ".fcn1.0.bias", ".fcn1.3.bias")):
+            # a bias in front of a batch-statistics BatchNorm has no gradient: the reference holds fp32 rounding noise
+            assert np.abs(g["grad_" + k]).max() < 1e-5 and np.abs(p.grad.numpy()).max() < 1e-12, k
+        else:
+            assert rel(p.grad.numpy(), g["grad_" + k]) < 2e-4, k
+    n = 0
+    for k in st:
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert rel(st[k].numpy(), g["after_" + k]) < 1e-5, k
+            n += 1
+        if k.endswith("num_batches_tracked"):
+            assert int(st[k]) == int(g["after_" + k]) == (2 if ".dam.fcn" in k else 1), k
+    assert n == 2 * (4 * 3 + 4 * 3 + 3 * 4)
