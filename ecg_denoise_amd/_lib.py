@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RAL_LIB_PATH") or os.path.join(HERE, "libralenet.so")   # override: diagnostic builds only
 CSRC = os.path.join(HERE, "csrc")
 
-VARIANTS = {"nra": 0, "full": 1, "mlp": 2, "unet": 3, "acdae": 4}
+VARIANTS = {"nra": 0, "full": 1, "mlp": 2, "unet": 3, "acdae": 4, "danet": 5}
 KIND_PARAM, KIND_STATE, KIND_COUNTER, KIND_INDEX = 0, 1, 2, 3
 
 

@@ -14,6 +14,7 @@
 #include "ral_kernels.hpp"
 #include "ral_unet.hpp"
 #include "ral_acdae.hpp"
+#include "ral_danet.hpp"
 
 static thread_local char g_err[512] = "";
 static int fail(const char* fmt, ...) {
@@ -166,7 +167,8 @@ static int check_cfg(const ral_config* c) {
   if (!c) return fail("null config");
   if (c->variant == RAL_UNET) return unet_check_cfg(c, g_err, sizeof(g_err));
   if (c->variant == RAL_ACDAE) return acdae_check_cfg(c, g_err, sizeof(g_err));
-  if (c->variant < 0 || c->variant > RAL_ACDAE) return fail("unknown variant %d", c->variant);
+  if (c->variant == RAL_DANET) return danet_check_cfg(c, g_err, sizeof(g_err));
+  if (c->variant < 0 || c->variant > RAL_DANET) return fail("unknown variant %d", c->variant);
   if (c->leads != 1 && c->leads != 2) return fail("leads must be 1 or 2 (got %d); use the 12-lead adapter above it", c->leads);
   if (c->L <= 0 || c->L % 256 != 0 || c->L > 1024) return fail("L must be a multiple of 256 and <= 1024 (got %d)", c->L);
   if (c->max_batch <= 0) return fail("max_batch must be positive");
@@ -260,10 +262,11 @@ struct ProfScope {
 };
 
 struct ral_handle {
-  int kind;  // 0 ralenet, 1 unet, 2 acdae
+  int kind;  // 0 ralenet, 1 unet, 2 acdae, 3 danet
   RalModel* m;
   UNetModel* u;
   AcdaeModel* a = nullptr;
+  DanetModel* d = nullptr;
 };
 
 static size_t plan_workspace(const ral_config& c, RalModel* m /* may be null: size only */, char* base) {
@@ -679,6 +682,7 @@ int ral_layout_count(const ral_config* cfg) {
   if (check_cfg(cfg)) return -1;
   if (cfg->variant == RAL_UNET) return unet_layout_count(cfg);
   if (cfg->variant == RAL_ACDAE) return acdae_layout_count(cfg);
+  if (cfg->variant == RAL_DANET) return danet_layout_count(cfg);
   Layout L;
   build_layout(*cfg, L);
   return (int)L.entries.size();
@@ -690,6 +694,10 @@ int ral_layout_entry(const ral_config* cfg, int idx, char* name, int name_cap, i
   if (cfg->variant == RAL_UNET) return unet_layout_entry(cfg, idx, name, name_cap, kind, offset, ndim, shape);
   if (cfg->variant == RAL_ACDAE) {
     if (acdae_layout_entry(cfg, idx, name, name_cap, kind, offset, ndim, shape)) return fail("entry %d out of range", idx);
+    return 0;
+  }
+  if (cfg->variant == RAL_DANET) {
+    if (danet_layout_entry(cfg, idx, name, name_cap, kind, offset, ndim, shape)) return fail("entry %d out of range", idx);
     return 0;
   }
   Layout L;
@@ -707,6 +715,7 @@ int64_t ral_param_floats(const ral_config* cfg) {
   if (check_cfg(cfg)) return -1;
   if (cfg->variant == RAL_UNET) return unet_param_floats(cfg);
   if (cfg->variant == RAL_ACDAE) return acdae_param_floats(cfg);
+  if (cfg->variant == RAL_DANET) return danet_param_floats(cfg);
   Layout L;
   build_layout(*cfg, L);
   return L.nparam;
@@ -716,11 +725,13 @@ int64_t ral_state_floats(const ral_config* cfg) {
   if (check_cfg(cfg)) return -1;
   if (cfg->variant == RAL_UNET) return unet_state_floats(cfg);
   if (cfg->variant == RAL_ACDAE) return 0;
+  if (cfg->variant == RAL_DANET) return danet_state_floats(cfg);
   return 16;
 }
 
 int64_t ral_bn_sums_doubles(const ral_config* cfg) {
   if (check_cfg(cfg)) return -1;
+  if (cfg->variant == RAL_DANET) return 0;     // (its batch sums live in its own workspace)
   return cfg->variant == RAL_UNET ? 1280 : (cfg->variant == RAL_ACDAE ? 0 : 64);
 }
 
@@ -728,6 +739,7 @@ int64_t ral_workspace_bytes(const ral_config* cfg) {
   if (check_cfg(cfg)) return -1;
   if (cfg->variant == RAL_UNET) return unet_workspace_bytes(cfg);
   if (cfg->variant == RAL_ACDAE) return acdae_workspace_bytes(cfg);
+  if (cfg->variant == RAL_DANET) return danet_workspace_bytes(cfg);
   return (int64_t)plan_workspace(*cfg, nullptr, nullptr);
 }
 
@@ -764,11 +776,18 @@ static void destroy_model(RalModel* m) {
 int ral_create(const ral_config* cfg, ral_handle** out) {
   if (check_cfg(cfg)) return -1;
   if (!out) return fail("null out");
-  ral_handle* h = new ral_handle{0, nullptr, nullptr};
+  ral_handle* h = new ral_handle();
   if (cfg->variant == RAL_ACDAE) {
     h->kind = 2;
     h->a = acdae_create(cfg, g_err, sizeof(g_err));
     if (!h->a) { delete h; return -1; }
+    *out = h;
+    return 0;
+  }
+  if (cfg->variant == RAL_DANET) {
+    h->kind = 3;
+    h->d = danet_create(cfg, g_err, sizeof(g_err));
+    if (!h->d) { delete h; return -1; }
     *out = h;
     return 0;
   }
@@ -868,6 +887,7 @@ int ral_destroy(ral_handle* h) {
   destroy_model(h->m);
   if (h->u) unet_destroy(h->u);
   if (h->a) acdae_destroy(h->a);
+  if (h->d) danet_destroy(h->d);
   delete h;
   return 0;
 }
@@ -876,6 +896,7 @@ int ral_bind(ral_handle* h, float* params, float* grads, float* adam_m, float* a
   if (!h) return fail("null handle");
   if (h->kind == 1) return unet_bind(h->u, params, grads, adam_m, adam_v, state, bn_sums);
   if (h->kind == 2) return acdae_bind(h->a, params, grads, adam_m, adam_v);
+  if (h->kind == 3) return danet_bind(h->d, params, grads, adam_m, adam_v, state);
   RalModel* m = h->m;
   m->params = params; m->grads = grads; m->am = adam_m; m->av = adam_v; m->state = state; m->bn_sums = bn_sums;
   return 0;
@@ -884,14 +905,14 @@ int ral_bind(ral_handle* h, float* params, float* grads, float* adam_m, float* a
 int ral_forward_begin(ral_handle* h, const float* x, int B, ral_stream s) {
   if (!h) return fail("null handle");
   if (h->kind == 2) return fail("ACDAE has no BatchNorm: use ral_forward");
-  if (h->kind == 1) return fail("U-Net has one BatchNorm per layer: use ral_forward (per-rank statistics)");
+  if (h->kind == 1 || h->kind == 3) return fail("U-Net / DANet have a BatchNorm per layer: use ral_forward (per-rank statistics)");
   return fwd_begin(h->m, x, B, 1, (hipStream_t)s);
 }
 
 int ral_forward_end(ral_handle* h, float* y, int B, int64_t global_windows, ral_stream s) {
   if (!h) return fail("null handle");
   if (h->kind == 2) return fail("ACDAE has no BatchNorm: use ral_forward");
-  if (h->kind == 1) return fail("U-Net has one BatchNorm per layer: use ral_forward (per-rank statistics)");
+  if (h->kind == 1 || h->kind == 3) return fail("U-Net / DANet have a BatchNorm per layer: use ral_forward (per-rank statistics)");
   return fwd_end(h->m, y, B, global_windows, 1, (hipStream_t)s);
 }
 
@@ -899,6 +920,7 @@ int ral_forward(ral_handle* h, const float* x, float* y, int B, int training, ra
   if (!h) return fail("null handle");
   if (h->kind == 1) return unet_forward(h->u, x, y, B, training, (hipStream_t)s, g_err, sizeof(g_err));
   if (h->kind == 2) return acdae_forward(h->a, x, y, B, (hipStream_t)s, g_err, sizeof(g_err));
+  if (h->kind == 3) return danet_forward(h->d, x, y, B, training, (hipStream_t)s, g_err, sizeof(g_err));
   if (fwd_begin(h->m, x, B, training, (hipStream_t)s)) return -1;
   return fwd_end(h->m, y, B, B, training, (hipStream_t)s);
 }
@@ -906,7 +928,8 @@ int ral_forward(ral_handle* h, const float* x, float* y, int B, int training, ra
 int ral_loss(ral_handle* h, const float* pred, const float* target, int B, int64_t global_windows, float* dy,
              float* snr, float* rmse, double* loss_sum, ral_stream s) {
   if (!h) return fail("null handle");
-  const ral_config& c = h->kind == 1 ? unet_public(h->u)->cfg : (h->kind == 2 ? acdae_public(h->a)->cfg : h->m->cfg);
+  const ral_config& c = h->kind == 1 ? unet_public(h->u)->cfg
+                        : (h->kind == 2 ? acdae_public(h->a)->cfg : (h->kind == 3 ? danet_public(h->d)->cfg : h->m->cfg));
   const int n = c.leads * c.L;
   const float gscale = (float)(2.0 / ((double)global_windows * n));
   launch_loss(pred, target, dy, snr, rmse, loss_sum, n, B, gscale, (hipStream_t)s);
@@ -993,6 +1016,7 @@ int ral_backward(ral_handle* h, const float* dy, float* dx, int B, ral_stream s)
   if (!h) return fail("null handle");
   if (h->kind == 1) return unet_backward(h->u, dy, dx, B, (hipStream_t)s, g_err, sizeof(g_err));
   if (h->kind == 2) return acdae_backward(h->a, dy, dx, B, (hipStream_t)s, g_err, sizeof(g_err));
+  if (h->kind == 3) return danet_backward(h->d, dy, dx, B, (hipStream_t)s, g_err, sizeof(g_err));
   if (bwd_begin(h->m, dy, B, (hipStream_t)s)) return -1;
   return bwd_end(h->m, dx, B, B, (hipStream_t)s);
 }
@@ -1016,6 +1040,7 @@ int ral_adam_step(ral_handle* h, double lr, double beta1, double beta2, double e
   int64_t n;
   if (h->kind == 1) { UNetPublic* u = unet_public(h->u); p = u->params; g = u->grads; am = u->am; av = u->av; n = u->nparam; }
   else if (h->kind == 2) { AcdaePublic* u = acdae_public(h->a); p = u->params; g = u->grads; am = u->am; av = u->av; n = u->nparam; }
+  else if (h->kind == 3) { DanetPublic* u = danet_public(h->d); p = u->params; g = u->grads; am = u->am; av = u->av; n = u->nparam; }
   else { p = h->m->params; g = h->m->grads; am = h->m->am; av = h->m->av; n = h->m->lay.nparam; }
   if (!p || !g || !am || !av) return fail("ral_bind: params/grads/adam buffers not bound");
   if (step < 1) return fail("step is 1-based");

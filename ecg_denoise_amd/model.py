@@ -156,6 +156,8 @@ class _ModuleBase:
         rng = np.random.default_rng(seed)
         host = np.zeros(self.eng.nparam, dtype=np.float32)
         fan = None
+        # a 1-D parameter next to a running_mean buffer is a BatchNorm affine
+        bn_prefix = {e["name"][:-len("running_mean")] for e in self.eng.entries if e["name"].endswith(".running_mean")}
         for e in self.eng.entries:
             if e["kind"] != _lib.KIND_PARAM:
                 continue
@@ -164,7 +166,8 @@ class _ModuleBase:
             if "relative_position_bias_table" in name:
                 a = np.zeros(n)
             elif len(shp) == 1 and (".norm" in name or ".bn." in name or name.startswith("conv1.2.")
-                                    or name.startswith("bottleneck.2.") or name.startswith("bottleneck.5.")):
+                                    or name.startswith("bottleneck.2.") or name.startswith("bottleneck.5.")
+                                    or name[:name.rfind(".") + 1] in bn_prefix):
                 a = np.ones(n) if name.endswith("weight") else np.zeros(n)
             elif len(shp) >= 2:
                 fan = int(np.prod(shp[1:]))
@@ -291,6 +294,40 @@ class ACDAE(_ModuleBase):
 
     def __init__(self, L=512, max_batch=32, train=True, device="cuda:0", seed=None):
         super().__init__("acdae", 2, L, max_batch, train, device, seed)
+
+
+class DANet(_ModuleBase):
+    """model/DAM.py::Seq2Seq2 (main.py:67-68, test_cls.py:81-83), the "DANet" the reference compares against: four
+    strided-conv encoder cells and four transposed-conv decoder cells, each conv -> APReLU -> BatchNorm1d, the first
+    three decoder cells followed by a DAM (channel + spatial attention), decoder inputs = previous output + encoder
+    feature.  36 BatchNorms; the two inside each DAM belong to ONE fcn that is applied to two batches per forward
+    (`fcn1` and `fcn2` are the same modules): their state_dict entries appear under both names, their running
+    statistics take two momentum updates per training forward and `num_batches_tracked` advances by 2."""
+
+    def __init__(self, L=512, max_batch=32, train=True, device="cuda:0", seed=None, leads=2):
+        super().__init__("danet", leads, L, max_batch, train, device, seed)      # (2 output channels: leads must be 2)
+
+    def named_parameters(self):
+        for k, v in super().named_parameters():
+            if ".dam.fcn2." not in k:          # torch lists a shared parameter once, under its first name
+                yield k, v
+
+    def named_grads(self):
+        return OrderedDict((k, v) for k, v in super().named_grads().items() if ".dam.fcn2." not in k)
+
+    def num_parameters(self):
+        return sum(int(np.prod(e["shape"])) for e in self.eng.entries
+                   if e["kind"] == _lib.KIND_PARAM and ".dam.fcn2." not in e["name"])
+
+    def forward(self, x):
+        y = super().forward(x)
+        if self.training:
+            for k in self.eng.counters:
+                if ".dam.fcn" in k:
+                    self.eng.counters[k] += 1   # the second batch through the shared fcn
+        return y
+
+    __call__ = forward
 
 
 class NewRALE:

@@ -50,6 +50,28 @@ def test_layout_matches_reference_state_dict(variant, leads, golden_dir):
         assert total == {"nra": 1086800, "full": 1087282, "mlp": 1087228}[variant]
 
 
+def test_danet_layout_matches_reference_state_dict(golden_dir):
+    """every state_dict entry of the reference's Seq2Seq2, in its order (the fixture's gradient keys are the reference's
+    named_parameters(), its after_* keys the buffers); fcn2.* alias fcn1.*; bad configurations are rejected"""
+    import danet_oracle as D
+    cfg = _lib.make_config("danet", 2, 512, 4, 1)
+    ent = _lib.layout(cfg)
+    shapes = D.danet_state_shapes()
+    assert [(e["name"], tuple(e["shape"])) for e in ent] == [(k, tuple(s)) for k, s in shapes.items()]
+    g = np.load(os.path.join(golden_dir, "g3_danet_L512.npz"))
+    ref_params = [k[5:] for k in g.files if k.startswith("grad_")]
+    assert ref_params == [e["name"] for e in ent if e["kind"] == _lib.KIND_PARAM and ".dam.fcn2." not in e["name"]]
+    assert sorted(k[6:] for k in g.files if k.startswith("after_")) == sorted(e["name"] for e in ent if e["kind"] != _lib.KIND_PARAM)
+    off = {e["name"]: (e["kind"], e["offset"]) for e in ent}
+    for k in off:
+        if ".dam.fcn2." in k:
+            assert off[k] == off[k.replace(".dam.fcn2.", ".dam.fcn1.")]
+    assert sum(int(np.prod(e["shape"])) for e in ent if e["kind"] == _lib.KIND_PARAM and ".dam.fcn2." not in e["name"]) == 18009
+    for leads, L in ((1, 512), (2, 520), (2, 16)):
+        bad = _lib.make_config("danet", leads, L, 4, 1)
+        assert _lib.lib().ral_layout_count(C.byref(bad)) == -1
+
+
 def test_pe_table_matches_reference(golden_dir):
     g = np.load(os.path.join(golden_dir, "pe_tables.npz"))
     for lvl, Cc in enumerate(O.CHANNELS):

@@ -1,0 +1,108 @@
+"""DANet baseline (model/DAM.py::Seq2Seq2) on the GPU, through the C ABI, against the reference-generated fixture
+(tests/golden/g3_danet_L512.npz, oracle/gen_golden_danet.py) and against the fp64 oracle at a larger batch.
+Tolerances: forward 1e-5, gradients 1e-4 relative L2 vs fp64 (2e-4 vs the reference's own fp32 numbers)."""
+import os
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+import danet_oracle as D
+from parity_util import rel
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ZERO_GRAD = (".fcn.0.bias", ".fcn.3.bias", ".fcn1.0.bias", ".fcn1.3.bias")   # biases in front of a batch-statistics BatchNorm
+
+
+def _model(st, B, L=512, train=True, leads=2):
+    from ecg_denoise_amd import DANet
+    m = DANet(L=L, max_batch=B, train=train, device=DEV, leads=leads)
+    m.load_state_dict(st)
+    return m
+
+
+def test_danet_matches_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g3_danet_L512.npz"))
+    st = D.init_state(4321)
+    x = torch.from_numpy(g["x"]).to(DEV); tgt = torch.from_numpy(g["target"]).to(DEV)
+    m = _model(st, x.shape[0])
+    assert m.num_parameters() == 18009 and list(m.state_dict().keys()) == list(st.keys())
+    m.eval()
+    assert rel(m(x).cpu().numpy(), g["y_eval"]) < 1e-5
+    m.train()
+    y = m(x)
+    assert rel(y.cpu().numpy(), g["y_train"]) < 1e-5
+    loss, snr, rmse = m.loss_and_metrics(y, tgt)
+    assert abs(loss.item() - float(g["loss"])) < 1e-5 * float(g["loss"])
+    m.backward()
+    grads = m.named_grads()
+    assert [k for k, _ in m.named_parameters()] == [k[5:] for k in g.files if k.startswith("grad_")]
+    for k, v in grads.items():
+        if k.endswith(ZERO_GRAD):
+            assert v.abs().max().item() < 1e-5, k
+        else:
+            assert rel(v.cpu().numpy(), g["grad_" + k]) < 2e-4, k
+    sd = m.state_dict()
+    for k in sd:
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert rel(sd[k].cpu().numpy(), g["after_" + k]) < 1e-5, k
+        if k.endswith("num_batches_tracked"):
+            assert int(sd[k]) == int(g["after_" + k]), k
+
+
+@pytest.mark.parametrize("B,L,leads", [(64, 512, 2), (37, 256, 2), (16, 1024, 2)])
+def test_danet_matches_fp64_oracle(B, L, leads):
+    st64 = D.init_state(99, leads=leads, dtype=torch.float64)
+    st32 = OrderedDict((k, v.clone().float() if v.dtype.is_floating_point else v.clone()) for k, v in st64.items())
+    gg = torch.Generator().manual_seed(B)
+    x = torch.randn(B, leads, L, generator=gg); tgt = torch.randn(B, leads, L, generator=gg)
+    m = _model(st32, B, L, leads=leads)
+    m.eval()
+    with torch.no_grad():
+        ye = D.danet_forward(st64, x.double(), training=False)
+    assert rel(m(x.to(DEV)).cpu().numpy(), ye.numpy()) < 1e-5
+    m.train()
+    xd = x.double().requires_grad_(True)
+    params = OrderedDict((k, v.requires_grad_(True)) for k, v in st64.items() if D.is_param(k) and ".dam.fcn2." not in k)
+    y64 = D.danet_forward(st64, xd, training=True)
+    loss64 = torch.nn.functional.mse_loss(y64, tgt.double())
+    loss64.backward()
+    y = m(x.to(DEV))
+    assert rel(y.cpu().numpy(), y64.detach().numpy()) < 1e-5
+    loss, _, _ = m.loss_and_metrics(y, tgt.to(DEV))
+    assert abs(loss.item() - loss64.item()) < 1e-5 * loss64.item()
+    dx = m.backward(want_dx=True)
+    assert rel(dx.cpu().numpy(), xd.grad.numpy()) < 1e-4
+    for k, v in m.named_grads().items():
+        if k.endswith(ZERO_GRAD):
+            assert v.abs().max().item() < 1e-5, k
+        else:
+            assert rel(v.cpu().numpy(), params[k].grad.numpy()) < 1e-4, k
+    sd = m.state_dict()
+    for k in sd:
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert rel(sd[k].cpu().numpy(), st64[k].numpy()) < 1e-5, k
+    # three Adam steps stay on the oracle's trajectory
+    opt = torch.optim.Adam(list(params.values()), lr=1e-3)
+    for _ in range(3):
+        opt.step(); opt.zero_grad(); m.step()
+        y64 = D.danet_forward(st64, x.double(), training=True)
+        torch.nn.functional.mse_loss(y64, tgt.double()).backward()
+        y = m(x.to(DEV)); m.loss_and_metrics(y, tgt.to(DEV)); m.backward()
+    assert rel(y.cpu().numpy(), y64.detach().numpy()) < 2e-5
+    for k, v in m.named_parameters():
+        if not k.endswith(ZERO_GRAD):     # (Adam turns the rounding noise of a zero gradient into +-lr steps, in both)
+            assert rel(v.cpu().numpy(), params[k].detach().numpy()) < 1e-5, k
+
+
+def test_danet_full_batch_runs_and_is_deterministic_in_eval():
+    st = D.init_state(5)
+    m = _model(st, 2048, train=False)
+    m.eval()
+    x = torch.randn(2048, 2, 512, device=DEV)
+    y1 = m(x).clone(); y2 = m(x)
+    assert torch.equal(y1, y2) and torch.isfinite(y1).all()
+    # windows are independent in eval mode: a slice gives the same rows
+    assert torch.equal(m(x[100:164].contiguous()), y1[100:164])
