@@ -106,3 +106,28 @@ def test_danet_full_batch_runs_and_is_deterministic_in_eval():
     assert torch.equal(y1, y2) and torch.isfinite(y1).all()
     # windows are independent in eval mode: a slice gives the same rows
     assert torch.equal(m(x[100:164].contiguous()), y1[100:164])
+
+
+def test_danet_trains_through_the_harness_and_checkpoint_round_trips(tmp_path):
+    """main.py:67-68 path: Seq2Seq2 through the same train() harness as the other models; the loss goes down, and the
+    checkpoint it writes (reference key set, fcn2 aliases and int64 counters included) restores the eval output"""
+    from ecg_denoise_amd import DANet, synth
+    from ecg_denoise_amd.train import train
+    noisy, clean = synth.make_dataset(96, 2, 256, "emb", 0.0, seed=5)
+    bat = lambda a, b, bs: [(a[i:i + bs], b[i:i + bs]) for i in range(0, len(a), bs)]
+    m = DANet(L=256, max_batch=32, device=DEV, seed=3)
+    res = train(epochs=10, model=m, batch_size=32, train_loader=bat(noisy[:64], clean[:64], 32), test_loader=bat(noisy[64:], clean[64:], 32),
+                use_gpu=True, model_name="Seq2Seq2", noise_name="emb", noise_intensity=0, out_dir=str(tmp_path), log=lambda *_: None)
+    tl, _ = train.last_losses
+    assert tl[-1] < tl[0] and all(np.isfinite(res[1]))
+    ck = tmp_path / "model_save" / "Seq2Seq2" / "Seq2Seq2_9_emb_intensity0.pth"
+    assert ck.exists()
+    sd = torch.load(ck, map_location="cpu")
+    assert list(sd.keys()) == list(D.danet_state_shapes().keys())
+    assert int(sd["dec.DecoderList.0.dam.fcn1.1.num_batches_tracked"]) == 2 * int(sd["dec.DecoderList.0.bn.num_batches_tracked"])
+    assert torch.equal(sd["dec.DecoderList.1.dam.fcn2.3.weight"], sd["dec.DecoderList.1.dam.fcn1.3.weight"])
+    m2 = DANet(L=256, max_batch=32, device=DEV, seed=77)
+    m2.load_state_dict(sd)
+    x = torch.as_tensor(noisy[64:96]).float().to(DEV)
+    m.eval(); m2.eval()
+    assert torch.equal(m(x), m2(x))

@@ -32,6 +32,7 @@ python3 tools/attn_bench.py > $O/attn_bench.log 2>&1
 [ -x tools/diag/valu_probe ] && ./tools/diag/valu_probe > $O/valu_probe.log 2>&1
 python3 bench.py --steps 50 --warmup 5 --kinds > $O/bench.json 2> $O/bench_kinds.log
 python3 tools/config_bench.py > $O/config_bench.log 2>&1
+python3 tools/baselines_bench.py > $O/baselines_bench.log 2>&1
 # keep only the csv summaries (the merged directory is capped at 64 MiB)
 find $O -name "*agent_info.csv" -delete
 du -sh $O

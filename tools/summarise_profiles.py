@@ -25,7 +25,8 @@ copy("ks_serial/*/*kernel_stats.csv", "kernel_stats_serialised_b2048.csv")
 copy("unet_ks/*/*kernel_stats.csv", "unet_kernel_stats_b2048.csv")
 copy("unet_staged_ks/*/*kernel_stats.csv", "unet_staged_kernel_stats_b2048.csv")
 for src, name in (("attn_bench.log", "attn_bench.jsonl"), ("valu_probe.log", "valu_probe.txt"), ("bench.json", "bench.json"),
-                  ("bench_kinds.log", "bench_kinds.txt"), ("config_bench.log", "config_bench.jsonl")):
+                  ("bench_kinds.log", "bench_kinds.txt"), ("config_bench.log", "config_bench.jsonl"),
+                  ("baselines_bench.log", "baselines_bench.jsonl")):
     if os.path.exists(os.path.join(SRC, src)):
         lines = [l for l in open(os.path.join(SRC, src)) if "amdgpu.ids" not in l]
         open(os.path.join(DST, f"{R}_{name}"), "w").writelines(lines)
