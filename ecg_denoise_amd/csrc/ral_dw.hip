@@ -67,7 +67,7 @@ RAL_DEV void issue_then_store(LD ld, ST st, IN inner) {
 template <int M, int NC, int MS, int NS, int LAYY, int XF>
 // (Y, X, pe and a2c0 are deliberately NOT __restrict__: loads the compiler can prove invariant are sunk across the
 // compiler barrier of the staging code, next to their stores, which costs one HBM round trip per load)
-__global__ __launch_bounds__(512, 4) void k_dw(const float* Y, const float* X, const float* pe,
+__global__ __launch_bounds__(512, 2) void k_dw(const float* Y, const float* X, const float* pe,
                                                const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                const float* a2c0, float* dW, float* dB, int N, int TC, int B) {
   extern __shared__ float4 smem4[];
@@ -116,6 +116,9 @@ __global__ __launch_bounds__(512, 4) void k_dw(const float* Y, const float* X, c
     const int n4y = TC * (MS / 4), n4x = TC * (NS / 4);
     auto load_y = [&](int u) -> float4 {
       const int j = min(tid + u * NPROD, n4y - 1);
+#ifdef RAL_DW_NOLOAD   // diagnostic: no HBM traffic
+      return make_float4(1e-3f * j, 0.f, 1.f, 2.f);
+#endif
       if constexpr (YHM) {
         const int q = j / TC, t = j - q * TC;
         return *reinterpret_cast<const float4*>(Yw + ((size_t)(mb / 4 + q) * N + t0 + t) * 4);
@@ -139,6 +142,10 @@ __global__ __launch_bounds__(512, 4) void k_dw(const float* Y, const float* X, c
       const int j = (tid + u * NPROD) & (n4x - 1);
       XLoad o;
       o.p = make_float4(0.f, 0.f, 0.f, 0.f); o.c = 0.f;
+#ifdef RAL_DW_NOLOAD
+      o.v = make_float4(1e-3f * j, 0.5f, 1.f, 2.f);
+      return o;
+#endif
       if constexpr (XHM) {
         const int q = j / TC, t = j - q * TC;
         o.v = *reinterpret_cast<const float4*>(Xw + ((size_t)(nb / 4 + q) * N + t0 + t) * 4);
@@ -160,11 +167,20 @@ __global__ __launch_bounds__(512, 4) void k_dw(const float* Y, const float* X, c
       } else {
         const int row = j / (NS / 4), c = (j - row * (NS / 4)) * 4;
         float4 a = o.v;
+#ifdef RAL_DW_NOXF     // diagnostic: no LayerNorm / GELU re-computation
+        if constexpr (false) {
+#else
         if constexpr (XF == XF_A2) {
+#endif
           a.x = gelu_f(a.x); a.y = gelu_f(a.y); a.z = gelu_f(a.z); a.w = gelu_f(a.w);
           if (a2c0 != nullptr) { a.x = gelu_f(a.x); a.y = gelu_f(a.y); a.z = gelu_f(a.z); a.w = gelu_f(a.w); }
           a.x = (le0 && c == 0) ? o.c : a.x;
-        } else {  // LayerNorm family: a row is NC/4 consecutive lanes
+        }
+#ifdef RAL_DW_NOXF
+        else if constexpr (false) {
+#else
+        else {  // LayerNorm family: a row is NC/4 consecutive lanes
+#endif
           constexpr int LPR = NC / 4;
           if constexpr (XF == XF_LNPE) a = f4add(f4scale(a, sqrtf((float)NC)), o.p);
           float4 d; float rstd;
@@ -206,15 +222,41 @@ __global__ __launch_bounds__(512, 4) void k_dw(const float* Y, const float* X, c
   // so a chunk's HBM round trip overlaps a whole consumer phase instead of sitting in front of every barrier.
   if (producer) {
     if (nci > 0) {
-      Pack p;
-      issue(0, p);
-      commit(0, buf0, p);
-      issue(nci > 1 ? 1 : 0, p);
-      __syncthreads();
-      for (int ci = 0; ci < nci; ++ci) {
-        if (ci + 1 < nci) commit(ci + 1, (ci & 1) ? buf0 : buf1, p);
-        issue(ci + 2 < nci ? ci + 2 : nci - 1, p);   // (past the end: a harmless re-read, no branch around the loads)
+      if constexpr (XF == XF_A2) {
+        // GELU-heavy operand (fc2's input is re-computed from u_pre): two chunks in flight.  While the consumers work
+        // on chunk ci the producer commits chunk ci + 1 (requested TWO iterations ago) and requests chunk ci + 3, so
+        // a chunk's HBM round trip has a whole iteration to complete.  With one chunk in flight the load latency, the
+        // transform and the consumers' MFMAs (which share the producer's SIMD) ADD UP here - measured with the
+        // `RAL_DW_NOLOAD / NOXF / NOMFMA` variants of this kernel: 154 us = 55 + 53 + 45 at C = 128; this ordering
+        // brings it to 132 us.  The LayerNorm operands did not gain (their packs are larger) and keep one chunk.
+        Pack pa, pb;
+        const int last = nci - 1;
+        issue(0, pa);
+        commit(0, buf0, pa);
+        issue(last < 1 ? last : 1, pa);
+        issue(last < 2 ? last : 2, pb);
         __syncthreads();
+        for (int ci = 0; ci < nci; ci += 2) {
+          if (ci + 1 < nci) commit(ci + 1, buf1, pa);
+          issue(ci + 3 < nci ? ci + 3 : last, pa);     // (past the end: a harmless re-read, no branch around the loads)
+          __syncthreads();
+          if (ci + 1 < nci) {
+            if (ci + 2 < nci) commit(ci + 2, buf0, pb);
+            issue(ci + 4 < nci ? ci + 4 : last, pb);
+            __syncthreads();
+          }
+        }
+      } else {
+        Pack p;
+        issue(0, p);
+        commit(0, buf0, p);
+        issue(nci > 1 ? 1 : 0, p);
+        __syncthreads();
+        for (int ci = 0; ci < nci; ++ci) {
+          if (ci + 1 < nci) commit(ci + 1, (ci & 1) ? buf0 : buf1, p);
+          issue(ci + 2 < nci ? ci + 2 : nci - 1, p);   // (past the end: a harmless re-read, no branch around the loads)
+          __syncthreads();
+        }
       }
     } else {
       __syncthreads();
@@ -261,7 +303,11 @@ __global__ __launch_bounds__(512, 4) void k_dw(const float* Y, const float* X, c
 #pragma unroll
           for (int i = 0; i < MI; ++i)
 #pragma unroll
+#ifdef RAL_DW_NOMFMA   // diagnostic: what the kernel costs without its matrix work (operands still read)
+            for (int j = 0; j < NI; ++j) acc[i][j][0] += a[i] + b[j];
+#else
             for (int j = 0; j < NI; ++j) acc[i][j] = mfma4(a[i], b[j], acc[i][j]);
+#endif
         }
       }
     }
