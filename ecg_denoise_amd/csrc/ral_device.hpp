@@ -20,7 +20,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define RAL_DEV __device__ __forceinline__
 
 RAL_DEV f32x4 mfma4(float a, float b, f32x4 c) {
+#ifdef RAL_NOGEMM   // diagnostic builds (make VARIANT=nogemm EXTRA=-DRAL_NOGEMM): what a kernel costs without its
+  return c;         // matrix work AND the operand fetches that only feed it (the compiler drops them as dead)
+#else
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+#endif
 }
 
 // Activation tile layouts (global memory and LDS use the same two forms):
@@ -214,6 +218,10 @@ template <int C> struct TTBof { static constexpr int v = (C <= 32) ? 4 : (C == 6
 // |error| <= 1.5e-7 absolute = fp32 rounding level): ~15 VALU instructions with one v_rcp and one
 // v_exp, against ~45 for libm erff + expf with both of its branches taken by a divergent wave.
 RAL_DEV void gelu_pair(float x, float& g, float& dg) {
+#ifdef RAL_NOGELU   // diagnostic builds: what a kernel costs without its GELU evaluations
+  g = x; dg = 1.f;
+  return;
+#endif
   const float ax = fabsf(x);
   const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
   const float e = __builtin_amdgcn_exp2f(x * x * (-0.5f * 1.4426950408889634f));   // exp(-x^2/2)

@@ -303,7 +303,7 @@ __global__ __launch_bounds__(512, 2) void k_dw(const float* Y, const float* X, c
 #pragma unroll
           for (int i = 0; i < MI; ++i)
 #pragma unroll
-#ifdef RAL_DW_NOMFMA   // diagnostic: what the kernel costs without its matrix work (operands still read)
+#if defined(RAL_DW_NOMFMA) && !defined(RAL_NOGEMM)   // diagnostic: without its matrix work (operands still read)
             for (int j = 0; j < NI; ++j) acc[i][j][0] += a[i] + b[j];
 #else
             for (int j = 0; j < NI; ++j) acc[i][j] = mfma4(a[i], b[j], acc[i][j]);
