@@ -72,14 +72,16 @@ def test_full_protocol_first_epochs_match_reference_curve(golden_dir, tmp_path):
 
 
 def test_full_protocol_end_of_training_inside_the_reference_spread(golden_dir, tmp_path):
-    """The whole 100-epoch main.py protocol (64 s on one MI355X) against the reference's own run-to-run spread: the three
-    reference fixtures (same data, same initial weights, intra-op thread counts 6 / 2 / 3, i.e. three summation orders:
-    g6_ref_train_curve_full{,_t2,_t3}.npz) end with last-ten-epoch means 19.36 .. 19.69 dB (mean 19.54) after agreeing to
-    1e-3 dB for two epochs; the HIP path from the same weights must land in that band (+- the band's own width; four
-    recorded HIP runs: 19.25 .. 19.71, profiles/r02_snr_experiment.json)."""
+    """The whole 100-epoch main.py protocol (64 s on one MI355X) against the reference's own run-to-run spread: the
+    reference fixtures (same data, same initial weights, intra-op thread counts 6 / 2 / 3 / 4, i.e. different summation
+    orders: g6_ref_train_curve_full*.npz) end with last-ten-epoch means 19.36 .. 19.69 dB (mean 19.57) after agreeing to
+    1e-3 dB for two epochs; the HIP path from the same weights must land in that band (+- the band's own width; twelve
+    recorded HIP runs: 19.25 .. 19.71, mean 19.58, profiles/r02_snr_experiment.json)."""
     from ecg_denoise_amd import RALENet, synth
     from ecg_denoise_amd.train import train
-    refs = [np.load(os.path.join(golden_dir, f"g6_ref_train_curve_full{t}.npz")) for t in ("", "_t2", "_t3")]
+    import glob
+    refs = [np.load(f) for f in sorted(glob.glob(os.path.join(golden_dir, "g6_ref_train_curve_full*.npz")))]
+    assert len(refs) >= 4
     last10 = np.array([r["test_snr"][-10:].mean() for r in refs])
     noisy, clean = synth.make_dataset(10000, 2, 256, "emb", 0.0, seed=2023)
     (trn, trc), (ten, tec) = synth.split_8000_2000(noisy, clean)

@@ -202,13 +202,15 @@ def test_metrics(golden_dir):
 
 
 def test_reference_run_to_run_spread_fixtures(golden_dir):
-    """What the three 100-epoch curves of the REFERENCE say about its own repeatability (same data, same initial weights,
+    """What the 100-epoch curves of the REFERENCE (thread counts 6 / 2 / 3 / 4 ...) say about its own repeatability (same data, same initial weights,
     only the intra-op thread count = summation order differs; oracle/gen_ref_train_curve.py): identical to 1e-3 dB for
     two epochs, apart by more than 0.1 dB from epoch 3, 0.55 dB apart at the end.  The north star's "within 0.05 dB of
     the reference" is therefore testable for the first ~500 optimiser steps only; after that the bar is the reference's
     own spread (tests/test_gpu_train_loop.py)."""
-    c = np.stack([load(golden_dir, f"g6_ref_train_curve_full{t}")["test_snr"] for t in ("", "_t2", "_t3")])
-    assert c.shape == (3, 100)
+    import glob
+    files = sorted(glob.glob(os.path.join(golden_dir, "g6_ref_train_curve_full*.npz")))
+    c = np.stack([np.load(f)["test_snr"] for f in files])
+    assert c.shape[0] >= 4 and c.shape[1] == 100
     assert np.ptp(c[:, :2], axis=0).max() < 1e-3
     assert np.ptp(c[:, 2]) > 0.1
     assert np.ptp(c[:, -1]) > 0.4
