@@ -219,11 +219,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 and world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} needs WORLD_SIZE={a.gpus} (launch with torch.distributed.run)")
+    if os.environ.get("RAL_BENCH_SHARE_GPU"):    # test hook: every rank on device 0 (tests/test_gpu_dp_procs.py)
+        local = 0
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        backend = os.environ.get("RAL_BENCH_BACKEND", "nccl")   # "gloo": the same hook (RCCL needs one device per rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(dev))
+        else:
+            dist.init_process_group(backend)
 
     B = a.batch
     model = RALENet(a.variant, leads=a.leads, L=a.L, max_batch=B, train=True, device=dev, seed=2023)

@@ -1,0 +1,83 @@
+"""Two real PROCESSES, one engine each, on the box's single GPU: the data-parallel trainer of ecg_denoise_amd/dp.py with
+gloo collectives on device tensors (tests/dp_gpu_worker.py) must end where one process on the whole batch ends - same
+losses, same parameters, same BatchNorm running statistics - although the two ranks START from different weights (the
+trainer broadcasts rank 0's replica).  Then `bench.py --gpus 2` itself, ranks sharing the GPU the same way."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from parity_util import rel
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _launch(argv, extra_env=None, n=2, script="tests/dp_gpu_worker.py"):
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, script)] + argv, env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    return outs
+
+
+@pytest.mark.parametrize("kind", ["ralenet", "unet"])
+def test_two_processes_equal_one_process(kind, tmp_path):
+    from ecg_denoise_amd import RALENet, UNet
+    steps = 3
+    out = str(tmp_path / "dp")
+    _launch([out, kind, str(steps)])
+    r0, r1 = torch.load(out + ".rank0"), torch.load(out + ".rank1")
+    for k in r0["state"]:                       # the replicas stay identical
+        assert torch.equal(r0["state"][k], r1["state"][k]), k
+    assert r0["losses"] == r1["losses"] and r0["step_count"] == r1["step_count"] == steps
+    # one process, whole batch, rank 0's initial weights
+    Bg, L = 128, 256
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(Bg, 2, L, generator=g).cuda(); t = torch.randn(Bg, 2, L, generator=g).cuda()
+    if kind == "unet":
+        m = UNet(leads=2, L=L, max_batch=Bg, device="cuda:0", seed=100)
+    else:
+        m = RALENet("full", leads=2, L=L, max_batch=Bg, device="cuda:0", seed=100)
+        for k, v in m.named_parameters():
+            if "relative_position_bias_table" in k:
+                v.copy_(0.1 * torch.randn(v.shape, generator=torch.Generator().manual_seed(5)).cuda())
+    m.train()
+    losses = [m.train_step(x, t)["loss"].item() for _ in range(steps)]
+    assert np.allclose(losses, r0["losses"], rtol=2e-5), (losses, r0["losses"])
+    sd = m.state_dict()
+    for k, v in sd.items():
+        if kind == "unet" and (k.endswith("conv.bias") or k.endswith("running_mean")):
+            continue    # a bias in front of a batch-statistics BatchNorm has zero gradient: Adam steps on rounding noise
+                        # (and the running mean behind it follows); nothing else depends on it
+        if v.dtype.is_floating_point:
+            assert rel(r0["state"][k].numpy(), v.cpu().numpy()) < 5e-5, k
+        else:
+            assert torch.equal(r0["state"][k], v.cpu()), k
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py --gpus 2 end to end (self-launch, replica broadcast, timed region with barriers, MAX over ranks, the
+    inference leg), the two ranks sharing this box's GPU over gloo: one JSON line with n_gpus = 2 and the job total"""
+    env = dict(os.environ, RAL_BENCH_BACKEND="gloo", RAL_BENCH_SHARE_GPU="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--batch", "256", "--no-cpu"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout + p.stderr
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 512 and d["scaling"] == "weak"
+    assert d["value"] > 0 and abs(d["value"] - 512 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+    assert np.isfinite(d["final_loss"]) and d["infer_windows_per_s"] > 0
