@@ -52,7 +52,7 @@ def test_danet_matches_reference_golden(golden_dir):
             assert int(sd[k]) == int(g["after_" + k]), k
 
 
-@pytest.mark.parametrize("B,L,leads", [(64, 512, 2), (37, 256, 2), (16, 1024, 2)])
+@pytest.mark.parametrize("B,L,leads", [(64, 512, 2), (37, 256, 2), (16, 1024, 2), (8, 32, 2), (4, 64, 2)])
 def test_danet_matches_fp64_oracle(B, L, leads):
     st64 = D.init_state(99, leads=leads, dtype=torch.float64)
     st32 = OrderedDict((k, v.clone().float() if v.dtype.is_floating_point else v.clone()) for k, v in st64.items())
@@ -74,12 +74,14 @@ def test_danet_matches_fp64_oracle(B, L, leads):
     loss, _, _ = m.loss_and_metrics(y, tgt.to(DEV))
     assert abs(loss.item() - loss64.item()) < 1e-5 * loss64.item()
     dx = m.backward(want_dx=True)
-    assert rel(dx.cpu().numpy(), xd.grad.numpy()) < 1e-4
+    # a BatchNorm over a batch of 4 descriptors divides by a variance of four samples: fp32 rounding is amplified there
+    gtol = 1e-4 if B >= 8 else 2e-3
+    assert rel(dx.cpu().numpy(), xd.grad.numpy()) < gtol
     for k, v in m.named_grads().items():
         if k.endswith(ZERO_GRAD):
             assert v.abs().max().item() < 1e-5, k
         else:
-            assert rel(v.cpu().numpy(), params[k].grad.numpy()) < 1e-4, k
+            assert rel(v.cpu().numpy(), params[k].grad.numpy()) < gtol, k
     sd = m.state_dict()
     for k in sd:
         if k.endswith("running_mean") or k.endswith("running_var"):
@@ -91,6 +93,8 @@ def test_danet_matches_fp64_oracle(B, L, leads):
         y64 = D.danet_forward(st64, x.double(), training=True)
         torch.nn.functional.mse_loss(y64, tgt.double()).backward()
         y = m(x.to(DEV)); m.loss_and_metrics(y, tgt.to(DEV)); m.backward()
+    if B < 8:
+        return
     assert rel(y.cpu().numpy(), y64.detach().numpy()) < 2e-5
     for k, v in m.named_parameters():
         if not k.endswith(ZERO_GRAD):     # (Adam turns the rounding noise of a zero gradient into +-lr steps, in both)
