@@ -460,6 +460,22 @@ __global__ __launch_bounds__(256) void k_unet_bwd(Stage st, int B) {
   }
 }
 
+// weight-gradient tile of slot s (of `slots` per workgroup), rotated by the workgroup index: the workgroups of a launch
+// finish together, and without the rotation every one of them would start its flush on the same addresses
+RAL_DEV int dw_tile(int s, int slots) { return (s + (int)blockIdx.x) % slots; }
+
+// LDS atomic add of the sum over groups of `w` consecutive lanes (w = 1: every lane adds its own value; w in {8, 16,
+// 32, 64}: the group's first lane adds the group sum - same-address LDS atomics of a wave execute one after the other)
+RAL_DEV void seg_atomic(float* addr, float v, int w) {
+  if (w == 1) { atomicAdd(addr, v); return; }
+  const int lane = threadIdx.x & 63;
+  if (w == 64) v = group_sum<64>(v);
+  else if (w == 32) v = group_sum<32>(v);
+  else if (w == 16) v = group_sum<16>(v);
+  else v = group_sum<8>(v);
+  if ((lane & (w - 1)) == 0) atomicAdd(addr, v);
+}
+
 // ---------------------------------------------------------------------------------
 // backward stage, specialised (same template parameters as k_unet_fwd_t).  Per window:
 //   1. input tile (BatchNorm + LeakyReLU + skip applied on load) and the gradient tile at the conv output
@@ -509,6 +525,18 @@ __global__ __launch_bounds__(256) void k_unet_bwd_t(Stage st, int B) {
   }
   __syncthreads();
   const int nin = CIN * lin, nout = COUT * lout;
+  // lanes of a wave that hold the same output channel in the staging loop below (lout / 4 consecutive threads, when
+  // that is a power of two and every wave of the loop is full): their sums are combined before the LDS atomic
+  const int gq = lout >> 2;
+  const int segw = ((gq & (gq - 1)) == 0 && gq >= 8 && (nout >> 2) % 64 == 0) ? (gq < 64 ? gq : 64) : 1;
+  // weight-gradient accumulator tiles of this wave (16 output channels x 16 (ci, k) pairs each)
+  // wide layers (both channel counts >= 16) run their two products on the fp32 MFMA; the narrow ones, whose tiles would be
+  // mostly padding, keep the scalar loops
+  constexpr bool UNET_BWD_MFMA = CIN >= 16 && COUT >= 16;
+  constexpr int DW_MT = (COUT + 15) / 16, DW_NT = (CIN * KS + 15) / 16, DW_TPW = (DW_MT * DW_NT + 3) / 4;
+  f32x4 dwacc[DW_TPW];
+#pragma unroll
+  for (int ti = 0; ti < DW_TPW; ++ti) dwacc[ti] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int win = blockIdx.x; win < B; win += gridDim.x) {
     const float* za = st.a.z + (size_t)win * nin;
     const float* zb = st.b.z ? st.b.z + (size_t)win * nin : nullptr;
@@ -544,7 +572,7 @@ __global__ __launch_bounds__(256) void k_unet_bwd_t(Stage st, int B) {
         }
       }
       *reinterpret_cast<float4*>(dc + c * LPO + HALO + p) = make_float4(g[0], g[1], g[2], g[3]);
-      atomicAdd(gbs + c, (g[0] + g[1]) + (g[2] + g[3]));
+      seg_atomic(gbs + c, (g[0] + g[1]) + (g[2] + g[3]), segw);
       if (st.r.z && st.r.G) {   // residual operand lrelu(BN(z_r)) was added to the output: its gradient is Gout * lrelu'
         const float4 zr = *reinterpret_cast<const float4*>(st.r.z + o);
         const float zrr[4] = {zr.x, zr.y, zr.z, zr.w}, gg[4] = {g4.x, g4.y, g4.z, g4.w};
@@ -559,121 +587,219 @@ __global__ __launch_bounds__(256) void k_unet_bwd_t(Stage st, int B) {
         float4 outv = make_float4(gr[0], gr[1], gr[2], gr[3]);
         if (st.r.accumulate) outv = f4add(outv, *dst);
         *dst = outv;
-        atomicAdd(sr + c, s1); atomicAdd(sr + MAXC + c, s2);
+        seg_atomic(sr + c, s1, segw); seg_atomic(sr + MAXC + c, s2, segw);
       }
     }
     __syncthreads();
-    // ---- input gradient ----
+    // gradient epilogue of one (input channel, 4 positions) unit: activation derivative, store (to one or two producers),
+    // and the unit's contributions to the BatchNorm-backward sums
+    auto emit = [&](int ci, int p0, const float (&acc)[4], bool valid, float& s1a, float& s2a, float& s1b, float& s2b) {
+      const size_t o = (size_t)win * nin + (size_t)(valid ? ci : 0) * lin + (valid ? p0 : 0);
+      s1a = 0.f; s2a = 0.f; s1b = 0.f; s2b = 0.f;
+      if (valid) {
+        const float4 z4 = *reinterpret_cast<const float4*>(za + (size_t)ci * lin + p0);
+        const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
+        const float s = ca[ci], h = ca[CIN + ci], mu = ca[2 * CIN + ci], rs = ca[3 * CIN + ci];
+        float ga[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          ga[j] = (st.a.act == ACT_LRELU && zz[j] * s + h <= 0.f) ? 0.01f * acc[j] : acc[j];
+          s1a += ga[j]; s2a += ga[j] * (zz[j] - mu) * rs;
+        }
+        float4* dst = reinterpret_cast<float4*>(st.a.G + o);
+        float4 outv = make_float4(ga[0], ga[1], ga[2], ga[3]);
+        if (st.a.accumulate) outv = f4add(outv, *dst);
+        *dst = outv;
+      }
+      if (valid && zb && st.b.G) {
+        const float4 z4 = *reinterpret_cast<const float4*>(zb + (size_t)ci * lin + p0);
+        const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
+        const float s = cb[ci], h = cb[CIN + ci], mu = cb[2 * CIN + ci], rs = cb[3 * CIN + ci];
+        float gb4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          gb4[j] = (zz[j] * s + h <= 0.f) ? 0.01f * acc[j] : acc[j];
+          s1b += gb4[j]; s2b += gb4[j] * (zz[j] - mu) * rs;
+        }
+        float4* dst = reinterpret_cast<float4*>(st.b.G + o);
+        float4 outv = make_float4(gb4[0], gb4[1], gb4[2], gb4[3]);
+        if (st.b.accumulate) outv = f4add(outv, *dst);
+        *dst = outv;
+      }
+    };
+    // ---- input gradient: d_in[ci][p] = sum over (co, k) of W(co, ci, k) * D(co, k, p) as fp32-MFMA tiles of 16 positions
+    // x 16 input channels, K = COUT * KS in steps of 4; both operands are gathered from the LDS tiles by index (the zero
+    // halos of `dc` cover the taps that fall outside), so no im2col copy exists.  A lane ends with 4 consecutive
+    // positions of one input channel - the unit the epilogue below (activation derivative, BatchNorm-backward sums,
+    // store) works on.
     if (st.a.G) {
-      const int q = lin >> 2;
-      for (int slot = threadIdx.x; slot < CIN * q; slot += blockDim.x) {
-        const int ci = slot / q, p0 = (slot - ci * q) << 2;
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (UNET_BWD_MFMA) {
+        constexpr int KTOT = COUT * KS, CT = (CIN + 15) / 16;
+        const int lane = threadIdx.x & 63, r = lane & 15, g4 = lane >> 4, wave = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+        const int ptiles = (lin + 15) >> 4;
+        for (int tile = wave; tile < ptiles * CT; tile += nwv) {
+          const int pt = tile / CT, n0 = pt << 4, m0 = (tile - pt * CT) << 4;
+          const int pos = n0 + r, cib = m0 + r;
+          const bool pok = pos < lin, cok = cib < CIN;
+          f32x4 accv = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
-        for (int co = 0; co < COUT; ++co) {
-          const float* row = dc + co * LPO + HALO;
-          if constexpr (MODE == 0) {         // out[l] = sum_k w[k] in[2l-1+k]
-            const float* wr = ws + (co * CIN + ci) * 3;
-            const float w0 = wr[0], w1 = wr[1], w2 = wr[2];
-            const int h = p0 >> 1;
-            const float d0 = row[h], d1 = row[h + 1], d2 = row[h + 2];
-            acc[0] = fmaf(w1, d0, acc[0]);
-            acc[1] = fmaf(w0, d1, fmaf(w2, d0, acc[1]));
-            acc[2] = fmaf(w1, d1, acc[2]);
-            acc[3] = fmaf(w0, d2, fmaf(w2, d1, acc[3]));
-          } else if constexpr (MODE == 1 && KS == 3) {   // out[l] = sum_k w[k] in[l-1+k]  =>  d_in[p] = sum_k w[k] dc[p+1-k]
-            const float* wr = ws + (co * CIN + ci) * 3;
-            const float w0 = wr[0], w1 = wr[1], w2 = wr[2];
-            float d[6];
-#pragma unroll
-            for (int t = 0; t < 6; ++t) d[t] = row[p0 - 1 + t];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = fmaf(w0, d[j + 2], fmaf(w1, d[j + 1], fmaf(w2, d[j], acc[j])));
-          } else if constexpr (MODE == 1) {
-            const float w0 = ws[co * CIN + ci];
-            const float4 d = *reinterpret_cast<const float4*>(row + p0);
-            acc[0] = fmaf(w0, d.x, acc[0]); acc[1] = fmaf(w0, d.y, acc[1]); acc[2] = fmaf(w0, d.z, acc[2]); acc[3] = fmaf(w0, d.w, acc[3]);
-          } else {                           // d_in[i] = sum_k w[ci][co][k] dc[2i-1+k]
-            const float* wr = ws + (ci * COUT + co) * 4;
-            const float w0 = wr[0], w1 = wr[1], w2 = wr[2], w3 = wr[3];
-            float d[10];
-#pragma unroll
-            for (int t = 0; t < 10; ++t) d[t] = row[2 * p0 - 1 + t];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              acc[j] = fmaf(w0, d[2 * j], fmaf(w1, d[2 * j + 1], fmaf(w2, d[2 * j + 2], fmaf(w3, d[2 * j + 3], acc[j]))));
+          for (int kk0 = 0; kk0 < KTOT; kk0 += 4) {
+            const int kk = kk0 + g4, co = kk / KS, k = kk - co * KS;
+            const bool kok = (KTOT % 4 == 0) || kk < KTOT;
+            float av = 0.f, bv = 0.f;
+            if (pok && kok) {
+              if constexpr (MODE == 1) av = dc[co * LPO + HALO + pos + (KS - 1) / 2 - k];
+              else if constexpr (MODE == 0) { const int t = pos + 1 - k; av = (t & 1) ? 0.f : dc[co * LPO + HALO + (t >> 1)]; }
+              else av = dc[co * LPO + HALO + 2 * pos - 1 + k];
+            }
+            if (cok && kok) bv = (MODE == 2) ? ws[(cib * COUT + co) * KS + k] : ws[(co * CIN + cib) * KS + k];
+            accv = mfma4(av, bv, accv);
+          }
+          const float acc[4] = {accv[0], accv[1], accv[2], accv[3]};
+          float s1a, s2a, s1b, s2b;
+          emit(cib, n0 + 4 * g4, acc, cok && n0 + 4 * g4 < lin, s1a, s2a, s1b, s2b);
+          // the sums of a channel are added up across the four position groups of the tile (lanes r, r + 16, r + 32,
+          // r + 48) before ONE LDS atomic per channel and tile: same-address LDS atomics of a wave run one after the other
+          const int ci = cib;
+          s1a = rows_sum(s1a); s2a = rows_sum(s2a);
+          if (g4 == 0 && cok && st.a.bsums) { atomicAdd(sa + ci, s1a); atomicAdd(sa + MAXC + ci, s2a); }
+          if (zb && st.b.G) {
+            s1b = rows_sum(s1b); s2b = rows_sum(s2b);
+            if (g4 == 0 && cok) { atomicAdd(sb + ci, s1b); atomicAdd(sb + MAXC + ci, s2b); }
           }
         }
-        const size_t o = (size_t)win * nin + (size_t)ci * lin + p0;
-        {
-          const float4 z4 = *reinterpret_cast<const float4*>(za + (size_t)ci * lin + p0);
-          const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
-          const float s = ca[ci], h = ca[CIN + ci], mu = ca[2 * CIN + ci], rs = ca[3 * CIN + ci];
-          float ga[4], s1 = 0.f, s2 = 0.f;
+      } else {
+        const int q = lin >> 2;
+        for (int slot = threadIdx.x; slot < CIN * q; slot += blockDim.x) {
+          const int ci = slot / q, p0 = (slot - ci * q) << 2;
+          float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+          for (int co = 0; co < COUT; ++co) {
+            const float* row = dc + co * LPO + HALO;
+            if constexpr (MODE == 0) {         // out[l] = sum_k w[k] in[2l-1+k]
+              const float* wr = ws + (co * CIN + ci) * 3;
+              const float w0 = wr[0], w1 = wr[1], w2 = wr[2];
+              const int h = p0 >> 1;
+              const float d0 = row[h], d1 = row[h + 1], d2 = row[h + 2];
+              acc[0] = fmaf(w1, d0, acc[0]);
+              acc[1] = fmaf(w0, d1, fmaf(w2, d0, acc[1]));
+              acc[2] = fmaf(w1, d1, acc[2]);
+              acc[3] = fmaf(w0, d2, fmaf(w2, d1, acc[3]));
+            } else if constexpr (MODE == 1 && KS == 3) {   // out[l] = sum_k w[k] in[l-1+k]  =>  d_in[p] = sum_k w[k] dc[p+1-k]
+              const float* wr = ws + (co * CIN + ci) * 3;
+              const float w0 = wr[0], w1 = wr[1], w2 = wr[2];
+              float d[6];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            ga[j] = (st.a.act == ACT_LRELU && zz[j] * s + h <= 0.f) ? 0.01f * acc[j] : acc[j];
-            s1 += ga[j]; s2 += ga[j] * (zz[j] - mu) * rs;
-          }
-          float4* dst = reinterpret_cast<float4*>(st.a.G + o);
-          float4 outv = make_float4(ga[0], ga[1], ga[2], ga[3]);
-          if (st.a.accumulate) outv = f4add(outv, *dst);
-          *dst = outv;
-          if (st.a.bsums) { atomicAdd(sa + ci, s1); atomicAdd(sa + MAXC + ci, s2); }
-        }
-        if (zb && st.b.G) {
-          const float4 z4 = *reinterpret_cast<const float4*>(zb + (size_t)ci * lin + p0);
-          const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
-          const float s = cb[ci], h = cb[CIN + ci], mu = cb[2 * CIN + ci], rs = cb[3 * CIN + ci];
-          float gb4[4], s1 = 0.f, s2 = 0.f;
+              for (int t = 0; t < 6; ++t) d[t] = row[p0 - 1 + t];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            gb4[j] = (zz[j] * s + h <= 0.f) ? 0.01f * acc[j] : acc[j];
-            s1 += gb4[j]; s2 += gb4[j] * (zz[j] - mu) * rs;
+              for (int j = 0; j < 4; ++j) acc[j] = fmaf(w0, d[j + 2], fmaf(w1, d[j + 1], fmaf(w2, d[j], acc[j])));
+            } else if constexpr (MODE == 1) {
+              const float w0 = ws[co * CIN + ci];
+              const float4 d = *reinterpret_cast<const float4*>(row + p0);
+              acc[0] = fmaf(w0, d.x, acc[0]); acc[1] = fmaf(w0, d.y, acc[1]); acc[2] = fmaf(w0, d.z, acc[2]); acc[3] = fmaf(w0, d.w, acc[3]);
+            } else {                           // d_in[i] = sum_k w[ci][co][k] dc[2i-1+k]
+              const float* wr = ws + (ci * COUT + co) * 4;
+              const float w0 = wr[0], w1 = wr[1], w2 = wr[2], w3 = wr[3];
+              float d[10];
+#pragma unroll
+              for (int t = 0; t < 10; ++t) d[t] = row[2 * p0 - 1 + t];
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                acc[j] = fmaf(w0, d[2 * j], fmaf(w1, d[2 * j + 1], fmaf(w2, d[2 * j + 2], fmaf(w3, d[2 * j + 3], acc[j]))));
+            }
           }
-          float4* dst = reinterpret_cast<float4*>(st.b.G + o);
-          float4 outv = make_float4(gb4[0], gb4[1], gb4[2], gb4[3]);
-          if (st.b.accumulate) outv = f4add(outv, *dst);
-          *dst = outv;
-          atomicAdd(sb + ci, s1); atomicAdd(sb + MAXC + ci, s2);
+          float s1a, s2a, s1b, s2b;
+          emit(ci, p0, acc, true, s1a, s2a, s1b, s2b);
+          if (st.a.bsums) { atomicAdd(sa + ci, s1a); atomicAdd(sa + MAXC + ci, s2a); }
+          if (zb && st.b.G) { atomicAdd(sb + ci, s1b); atomicAdd(sb + MAXC + ci, s2b); }
         }
       }
     }
-    // ---- weight gradient: unit = (co, ci, chunk of output positions) ----
-    {
-      constexpr int CH = 32;
-      const int nchunk = (lout + CH - 1) / CH;
-      for (int u = threadIdx.x; u < COUT * CIN * nchunk; u += blockDim.x) {
-        const int pair = u / nchunk, chn = u - pair * nchunk;
-        const int co = pair / CIN, ci = pair - co * CIN;
-        const int l0 = chn * CH, l1 = (l0 + CH < lout) ? l0 + CH : lout;
-        const float* dr = dc + co * LPO + HALO;
-        const float* ir = in + ci * LP + HALO;
-        float g[KS];
+    if constexpr (UNET_BWD_MFMA) {
+      // ---- weight gradient: gw(co, ci, k) += sum_p dc[co][p] * I(ci, k, p) as MFMA tiles of 16 output channels x 16
+      // (ci, k) pairs, K = output positions in steps of 4; the tiles a wave owns stay in its accumulators across the
+      // windows of the workgroup (flushed after the window loop).
+      {
+        const int lane = threadIdx.x & 63, r = lane & 15, g4 = lane >> 4, wave = threadIdx.x >> 6, nwv = blockDim.x >> 6;
 #pragma unroll
-        for (int k = 0; k < KS; ++k) g[k] = 0.f;
-        for (int l = l0; l < l1; ++l) {
-          const float d = dr[l];
-          if constexpr (MODE == 0) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) g[k] = fmaf(d, ir[2 * l - 1 + k], g[k]);
-          } else if constexpr (MODE == 1) {
-#pragma unroll
-            for (int k = 0; k < KS; ++k) g[k] = fmaf(d, ir[l - (KS - 1) / 2 + k], g[k]);
-          } else {   // out[j] += w[k] in[i], j = 2i-1+k  =>  gw[k] += dc[j] in[(j+1-k)/2] for matching parity
-            const int k0 = (l + 1) & 1, i0 = (l + 1 - k0) >> 1;
-            g[k0] = fmaf(d, ir[i0], g[k0]);         // inactive taps of this parity keep their value
-            g[k0 + 2] = fmaf(d, ir[i0 - 1], g[k0 + 2]);
+        for (int ti = 0; ti < DW_TPW; ++ti) {
+          const int tile = dw_tile(wave + ti * nwv, DW_TPW * nwv);
+          if (tile >= DW_MT * DW_NT) continue;
+          const int m0 = (tile / DW_NT) << 4, n0 = (tile % DW_NT) << 4;
+          const int co = m0 + r, nn = n0 + r, ci = nn / KS, k = nn - ci * KS;
+          const bool cook = co < COUT, nok = nn < CIN * KS;
+          const float* dr = dc + (cook ? co : 0) * LPO + HALO;
+          const float* ir = in + (nok ? ci : 0) * LP + HALO;
+          f32x4 accw = dwacc[ti];
+          for (int q0 = 0; q0 < lout; q0 += 4) {
+            const int pp = q0 + g4;
+            const bool pk = pp < lout;
+            float av = 0.f, bv = 0.f;
+            if (cook && pk) av = dr[pp];
+            if (nok && pk) {
+              if constexpr (MODE == 1) bv = ir[pp - (KS - 1) / 2 + k];
+              else if constexpr (MODE == 0) bv = ir[2 * pp - 1 + k];
+              else { const int t = pp + 1 - k; bv = (t & 1) ? 0.f : ir[t >> 1]; }
+            }
+            accw = mfma4(av, bv, accw);
           }
+          dwacc[ti] = accw;
         }
-        float* gd = (MODE == 2) ? gws + (ci * COUT + co) * KS : gws + (co * CIN + ci) * KS;
+      }
+    } else {
+      // ---- weight gradient: unit = (co, ci, chunk of output positions) ----
+      {
+        constexpr int CH = 32;
+        const int nchunk = (lout + CH - 1) / CH;
+        for (int u = threadIdx.x; u < COUT * CIN * nchunk; u += blockDim.x) {
+          const int pair = u / nchunk, chn = u - pair * nchunk;
+          const int co = pair / CIN, ci = pair - co * CIN;
+          const int l0 = chn * CH, l1 = (l0 + CH < lout) ? l0 + CH : lout;
+          const float* dr = dc + co * LPO + HALO;
+          const float* ir = in + ci * LP + HALO;
+          float g[KS];
 #pragma unroll
-        for (int k = 0; k < KS; ++k) atomicAdd(gd + k, g[k]);
+          for (int k = 0; k < KS; ++k) g[k] = 0.f;
+          for (int l = l0; l < l1; ++l) {
+            const float d = dr[l];
+            if constexpr (MODE == 0) {
+#pragma unroll
+              for (int k = 0; k < 3; ++k) g[k] = fmaf(d, ir[2 * l - 1 + k], g[k]);
+            } else if constexpr (MODE == 1) {
+#pragma unroll
+              for (int k = 0; k < KS; ++k) g[k] = fmaf(d, ir[l - (KS - 1) / 2 + k], g[k]);
+            } else {   // out[j] += w[k] in[i], j = 2i-1+k  =>  gw[k] += dc[j] in[(j+1-k)/2] for matching parity
+              const int k0 = (l + 1) & 1, i0 = (l + 1 - k0) >> 1;
+              g[k0] = fmaf(d, ir[i0], g[k0]);         // inactive taps of this parity keep their value
+              g[k0 + 2] = fmaf(d, ir[i0 - 1], g[k0 + 2]);
+            }
+          }
+          float* gd = (MODE == 2) ? gws + (ci * COUT + co) * KS : gws + (co * CIN + ci) * KS;
+#pragma unroll
+          for (int k = 0; k < KS; ++k) atomicAdd(gd + k, g[k]);
+        }
       }
     }
     __syncthreads();
   }
-  for (int i = threadIdx.x; i < nw; i += blockDim.x) atomicAdd(st.gw + i, gws[i]);
+  if constexpr (!UNET_BWD_MFMA) {
+    for (int i = threadIdx.x; i < nw; i += blockDim.x) atomicAdd(st.gw + i, gws[i]);
+  } else {   // weight-gradient tiles: lane (r, g) holds rows co = m0 + 4 g + v of column nn = n0 + r
+    const int lane = threadIdx.x & 63, r = lane & 15, g4 = lane >> 4, wave = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+#pragma unroll
+    for (int ti = 0; ti < DW_TPW; ++ti) {
+      const int tile = dw_tile(wave + ti * nwv, DW_TPW * nwv);
+      if (tile >= DW_MT * DW_NT) continue;
+      const int m0 = (tile / DW_NT) << 4, n0 = (tile % DW_NT) << 4, nn = n0 + r;
+      if (nn >= CIN * KS) continue;
+      const int ci = nn / KS, k = nn - ci * KS;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int co = m0 + 4 * g4 + v;
+        if (co < COUT) atomicAdd(st.gw + ((MODE == 2) ? (ci * COUT + co) * KS + k : co * CIN * KS + nn), dwacc[ti][v]);
+      }
+    }
+  }
   if ((int)threadIdx.x < COUT) atomicAdd(st.gb + threadIdx.x, gbs[threadIdx.x]);
   if ((int)threadIdx.x < CIN) {
     if (st.a.G && st.a.bsums) {
@@ -1439,7 +1565,11 @@ int unet_backward_stage(UNetModel* m, int B, int si, int64_t gwin, hipStream_t s
   UNetPublic& P = m->pub;
   if (B != m->last_B) { snprintf(err, cap, "backward batch %d != forward batch %d", B, m->last_B); return -1; }
   if (si < 0 || si > 10) { snprintf(err, cap, "U-Net stage %d outside [0, 10]", si); return -1; }
-  const int grid = B < 1024 ? B : 1024;
+  // every workgroup ends with ~2 000 global atomics (its share of dW, db and the BatchNorm-backward sums): the chip retires
+  // ~75 of them per ns, so 1024 workgroups spend 30 us per launch on them alone.  Measured train step at batch 2048 with
+  // 1024 / 512 / 384 workgroups: 1.23 / 1.08 / 1.12 ms (RAL_UNET_BWD_GRID)
+  static const int gmax = getenv("RAL_UNET_BWD_GRID") ? atoi(getenv("RAL_UNET_BWD_GRID")) : 512;
+  const int grid = B < gmax ? B : gmax;
   // consumers run in reverse order; an encoder tensor's gradient is first WRITTEN by its decoder-side consumer
   // (skip / residual, accumulate = 0) and later ACCUMULATED by the next encoder / bottleneck stage (accumulate = 1)
   Stage st = make_stage(m, si, m->last_x, true, true, B, (double)gwin);
