@@ -596,7 +596,10 @@ __global__ void k_add(const float* __restrict__ a, const float* __restrict__ b, 
 // =================================================================================
 // host launchers
 // =================================================================================
-static inline int grid_for(int items) { return items < 4096 ? items : 4096; }
+static inline int grid_for(int items) {
+  static const int gmax = getenv("RAL_GRID_FWD") ? atoi(getenv("RAL_GRID_FWD")) : 4096;
+  return items < gmax ? items : gmax;
+}
 
 // widths whose projection has a bf16 x 3 kernel (the caller passes the weight planes to choose it)
 bool qkv_fwd_uses_bf16(int C) { return C == 64 || C == 128; }
