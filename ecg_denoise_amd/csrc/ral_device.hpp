@@ -251,7 +251,22 @@ RAL_DEV float swap32_add(float v) {   // v[lane] + v[lane ^ 32]
   const auto p = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   return __uint_as_float(p[0]) + __uint_as_float(p[1]);
 }
-RAL_DEV float rows_sum(float v) { return swap32_add(swap16_add(v)); }   // over the 4 rows of 16 lanes (same column)
+RAL_DEV float rows_sum(float v) { return swap32_add(swap16_add(v)); }
+// 4 x 4 transpose between registers and the four 16-lane rows of a wave: in, register j of lane (r, g) holds E(j, g);
+// out, register j of lane (r, g) holds E(g, j).  (v_permlane32_swap a, b: a = [a.lanes 0-31, b.lanes 0-31], b =
+// [a.lanes 32-63, b.lanes 32-63]; v_permlane16_swap likewise inside each half.)
+RAL_DEV void rows_transpose4(float (&v)[4]) {
+  auto sw32 = [](float& a, float& b) {
+    const auto p = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(p[0]); b = __uint_as_float(p[1]);
+  };
+  auto sw16 = [](float& a, float& b) {
+    const auto p = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(p[0]); b = __uint_as_float(p[1]);
+  };
+  sw32(v[0], v[2]); sw32(v[1], v[3]);
+  sw16(v[0], v[1]); sw16(v[2], v[3]);
+}   // over the 4 rows of 16 lanes (same column)
 template <int W>
 RAL_DEV float group_sum(float v) {  // sum over W consecutive lanes (W power of two <= 64), result in every lane
   if constexpr (W >= 2) v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]

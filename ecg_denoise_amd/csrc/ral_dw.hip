@@ -354,17 +354,34 @@ __global__ __launch_bounds__(512, 2) void k_dw(const float* Y, const float* X, c
     }
   }
   if (kw == 0) {
+    if constexpr (NI == 4 && MS % 16 == 0 && NS % 64 == 0) {
+      // Global float atomics run at the memory side at a fixed byte rate, and at full rate only for wave-instructions
+      // that cover 256 contiguous bytes; a 16 x 16 accumulator register as it stands covers four 64-byte pieces of
+      // four rows (4 x slower).  The four column tiles of a wave are therefore transposed against the four lane rows
+      // first (two lane-swap steps): then one instruction adds 64 consecutive floats of one row of dW.
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        const int n = n0 + 16 * j + r;
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int m = m0 + 16 * i + 4 * g + q;
-          if (m < MS && n < NS) atomicAdd(dW + (size_t)(mb + m) * NC + nb + n, acc[i][j][q]);
+          float v[4] = {acc[i][0][q], acc[i][1][q], acc[i][2][q], acc[i][3][q]};
+          rows_transpose4(v);            // v[row]: row m0 + 16 i + 4 row + q, column n0 + 16 g + r
+#pragma unroll
+          for (int row = 0; row < 4; ++row)
+            atomicAdd(dW + (size_t)(mb + m0 + 16 * i + 4 * row + q) * NC + nb + n0 + 16 * g + r, v[row]);
         }
-      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const int n = n0 + 16 * j + r;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int m = m0 + 16 * i + 4 * g + q;
+            if (m < MS && n < NS) atomicAdd(dW + (size_t)(mb + m) * NC + nb + n, acc[i][j][q]);
+          }
+        }
+    }
   }
 }
 
