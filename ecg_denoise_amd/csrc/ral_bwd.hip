@@ -401,6 +401,11 @@ __global__ __launch_bounds__(512, 4) void k_mlp_bwd_s(const float* __restrict__ 
       }
     }
   }
+  // The tiles go through the LDS as the two whole matrices (dW1 4C x C, dW2 C x 4C: 8 C^2 floats behind the fold region)
+  // and leave it with consecutive threads adding consecutive floats: global float atomics run at full rate only for
+  // 256 contiguous bytes per wave-instruction, and a 16 x 16 accumulator register is four 64-byte pieces of four rows.
+  float* stg = Ds + 6656;   // (the fold region is at most 3 x 2 x 1104 floats; the launcher sizes the LDS for 6656 + 8 C^2)
+  if constexpr (KS > 1) __syncthreads();   // (the fold region is read above)
   if (kpart == 0) {
     const int col = nj * 16 + r;
 #pragma unroll
@@ -410,13 +415,18 @@ __global__ __launch_bounds__(512, 4) void k_mlp_bwd_s(const float* __restrict__ 
       for (int q = 0; q < 4; ++q) {
         const int row = mi * 16 + 4 * g + q;
         if (row < C && col < C) {
-          if (prod) atomicAdd(gr.w1 + (size_t)(j0 + row) * C + col, accw[ch][q]);       // dW1[hidden][c]
-          else atomicAdd(gr.w2 + (size_t)row * 4 * C + j0 + col, accw[ch][q]);          // dW2[c][hidden]
+          if (prod) stg[(j0 + row) * C + col] = accw[ch][q];                 // dW1[hidden][c]
+          else stg[4 * C * C + row * 4 * C + j0 + col] = accw[ch][q];         // dW2[c][hidden]
         }
       }
       if (prod && nj == 0 && g == 0 && mi * 16 + r < C) atomicAdd(gr.b1 + j0 + mi * 16 + r, bs1[ch]);
     }
     if (!prod && nj == 0 && g == 0 && mi * 16 + r < C) atomicAdd(gr.b2 + mi * 16 + r, bs2);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 4 * C * C; i += blockDim.x) {
+    atomicAdd(gr.w1 + i, stg[i]);
+    atomicAdd(gr.w2 + i, stg[4 * C * C + i]);
   }
 }
 
@@ -1202,8 +1212,10 @@ static bool mlp_bwd_s_applies(int N, int* tw_out, size_t* lds_out) {
   const int tw = N * MT / 128;
   if (tw != 1 && tw != 2 && tw != 4 && tw != 8) return false;
   const int ldb = C == 16 ? C : ld_of(C);
-  const size_t lds = ((size_t)2 * N * ld_of(C) + (size_t)2 * N * ldb + 2 * (N + 2) + 2 * N + 2 * C + 8) * sizeof(float);
+  size_t lds = ((size_t)2 * N * ld_of(C) + (size_t)2 * N * ldb + 2 * (N + 2) + 2 * N + 2 * C + 8) * sizeof(float);
   if (lds > 80 * 1024) return false;
+  const size_t flush = ((size_t)6656 + 8 * C * C) * sizeof(float);   // fold region + the two staged weight-gradient matrices
+  if (lds < flush) lds = flush;
   if (tw_out) *tw_out = tw;
   if (lds_out) *lds_out = lds;
   return true;
