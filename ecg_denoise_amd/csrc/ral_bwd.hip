@@ -405,7 +405,7 @@ __global__ __launch_bounds__(512, 4) void k_mlp_bwd_s(const float* __restrict__ 
   // and leave it with consecutive threads adding consecutive floats: global float atomics run at full rate only for
   // 256 contiguous bytes per wave-instruction, and a 16 x 16 accumulator register is four 64-byte pieces of four rows.
   float* stg = Ds + 6656;   // (the fold region is at most 3 x 2 x 1104 floats; the launcher sizes the LDS for 6656 + 8 C^2)
-  if constexpr (KS > 1) __syncthreads();   // (the fold region is read above)
+  __syncthreads();   // (the fold region and, at short windows, the small-gradient array `red` overlap the staging area and are read above)
   if (kpart == 0) {
     const int col = nj * 16 + r;
 #pragma unroll
