@@ -1437,7 +1437,8 @@ int unet_forward_stage(UNetModel* m, const float* x, int B, int training, int si
     if (training) (void)hipMemsetAsync(P.bn_sums, 0, 1280 * sizeof(double), s);
   } else if (x != m->last_x || B != m->last_B) { snprintf(err, cap, "U-Net stages must follow stage 0 of the same batch"); return -1; }
   static const int fgmax = getenv("RAL_UNET_FWD_GRID") ? atoi(getenv("RAL_UNET_FWD_GRID")) : 512;   // (train forward at batch 2048: 0.31 / 0.27 / 0.29 / 0.41 ms with 256 / 512 / 1024 / 2048 workgroups)
-  const int grid = B < fgmax ? B : fgmax;
+  const int gcap = training ? fgmax : 1024;    // (eval stages have no BatchNorm sums to flush: more workgroups are better)
+  const int grid = B < gcap ? B : gcap;
   Stage st = make_stage(m, si, x, training != 0, false, B, (double)gwin);
   if (!training) st.sums_out = nullptr;
   if (!launch_unet_fwd_fast(st, si, P.cfg.leads, B, grid, s)) k_unet_fwd<<<grid, 256, fwd_lds(st), s>>>(st, B);
