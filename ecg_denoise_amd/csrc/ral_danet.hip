@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -855,7 +856,8 @@ int danet_forward(DanetModel* m, const float* x, float* y, int B, int training, 
   if (!P.params || !P.state) { snprintf(err, cap, "ral_bind was not called"); return -1; }
   if (B <= 0 || B > P.cfg.max_batch) { snprintf(err, cap, "batch %d outside (0, %d]", B, P.cfg.max_batch); return -1; }
   if (training && B < 2) { snprintf(err, cap, "DANet: a training forward needs at least 2 windows (BatchNorm over the batch of descriptors)"); return -1; }
-  const int grid = B < 1024 ? B : 1024;
+  static const int gf = getenv("RAL_DANET_GRID_F") ? atoi(getenv("RAL_DANET_GRID_F")) : 1024;
+  const int grid = B < gf ? B : gf;
   if (training) (void)hipMemsetAsync(m->sums, 0, sizeof(double) * 8 * S_CELL, st);
   m->last_x = x; m->last_B = B; m->last_training = training != 0;
   for (int i = 0; i < 8; ++i) {
@@ -895,7 +897,8 @@ int danet_backward(DanetModel* m, const float* dy, float* dx, int B, hipStream_t
   DanetPublic& P = m->pub;
   if (!P.cfg.train || !P.grads) { snprintf(err, cap, "DANet backward needs train=1 and a bound gradient buffer"); return -1; }
   if (B != m->last_B || !m->last_training) { snprintf(err, cap, "DANet backward needs a training forward of the same batch first"); return -1; }
-  const int grid = B < 512 ? B : 512;
+  static const int gb = getenv("RAL_DANET_GRID_B") ? atoi(getenv("RAL_DANET_GRID_B")) : 1024;   // (train step at batch 2048: 3.84 / 3.58 / 4.43 ms with 512 / 1024 / 2048)
+  const int grid = B < gb ? B : gb;
   (void)hipMemsetAsync(P.grads, 0, (size_t)m->lay.nparam * sizeof(float), st);
   for (int i = 0; i < 8; ++i) (void)hipMemsetAsync(m->sums + (size_t)i * S_CELL + T_D2, 0, sizeof(double) * (S_CELL - T_D2), st);
   for (int i = 7; i >= 0; --i) {
