@@ -73,8 +73,8 @@ def test_full_protocol_first_epochs_match_reference_curve(golden_dir, tmp_path):
 
 def test_full_protocol_end_of_training_inside_the_reference_spread(golden_dir, tmp_path):
     """The whole 100-epoch main.py protocol (64 s on one MI355X) against the reference's own run-to-run spread: the
-    reference fixtures (same data, same initial weights, intra-op thread counts 6 / 2 / 3 / 4, i.e. different summation
-    orders: g6_ref_train_curve_full*.npz) end with last-ten-epoch means 19.36 .. 19.69 dB (mean 19.57) after agreeing to
+    reference fixtures (same data, same initial weights, intra-op thread counts 6 / 2 / 3 / 4 / 1, i.e. different summation
+    orders: g6_ref_train_curve_full*.npz) end with last-ten-epoch means 19.36 .. 19.69 dB (mean 19.56) after agreeing to
     1e-3 dB for two epochs; the HIP path from the same weights must land in that band (+- the band's own width; twelve
     recorded HIP runs: 19.25 .. 19.71, mean 19.58, profiles/r02_snr_experiment.json)."""
     from ecg_denoise_amd import RALENet, synth

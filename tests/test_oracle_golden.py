@@ -202,7 +202,7 @@ def test_metrics(golden_dir):
 
 
 def test_reference_run_to_run_spread_fixtures(golden_dir):
-    """What the 100-epoch curves of the REFERENCE (thread counts 6 / 2 / 3 / 4 ...) say about its own repeatability (same data, same initial weights,
+    """What the 100-epoch curves of the REFERENCE (thread counts 6 / 2 / 3 / 4 / 1) say about its own repeatability (same data, same initial weights,
     only the intra-op thread count = summation order differs; oracle/gen_ref_train_curve.py): identical to 1e-3 dB for
     two epochs, apart by more than 0.1 dB from epoch 3, 0.55 dB apart at the end.  The north star's "within 0.05 dB of
     the reference" is therefore testable for the first ~500 optimiser steps only; after that the bar is the reference's
