@@ -13,10 +13,11 @@
 //   k_acd_dec_fwd   transposed conv -> LDS -> upsample + LeakyReLU (stored: the ECA input) -> means -> scale -> + skip
 //   k_acd_dec_bwd   ECA backward, LeakyReLU', upsample adjoint -> dT (stored), input gradient (correlation with W)
 //   k_acd_enc_bwd   (main + skip) gradient -> LeakyReLU', un-pool -> dC (stored), input gradient
-//   k_acd_dw        weight / bias gradients of one conv: dW[co][ci][k] = sum over windows and positions of Y X, one
-//                   (8 x 8 channel block, window range) per workgroup, two accumulators per thread, atomics at the end
+//   k_acd_dw_m      weight / bias gradients of one conv: dW[co][ci][k] = sum over windows and positions of Y X as an
+//                   fp32-MFMA GEMM with index-gathered operands (k_acd_dw: the scalar form, kept for 2 output channels)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -398,6 +399,83 @@ __global__ __launch_bounds__(256) void k_acd_dw(const float* __restrict__ Y, con
   if (gb && cx0 == 0 && (int)threadIdx.x < ny * 8) atomicAdd(gb + cy0 + (threadIdx.x >> 3), bacc);
 }
 
+// ---------------------------------------------------------------------------------
+// The same weight gradient as an fp32-MFMA GEMM (output channels >= 16): M = output channel, N = (input channel, tap)
+// pairs, K = positions, summed over windows.  A workgroup owns 16 output channels x up to 16 column tiles (four per wave,
+// in accumulators across its window range); both operands are gathered from the staged rows by index (the tap shift is
+// part of the B operand's address; the zero halo covers the borders).  grid: (row tiles x column-tile groups, splits).
+// ---------------------------------------------------------------------------------
+template <int KS, bool CONVT>
+__global__ __launch_bounds__(256) void k_acd_dw_m(const float* __restrict__ Y, const float* __restrict__ X,
+                                                  float* __restrict__ gw, float* __restrict__ gb, int CY, int CX, int L,
+                                                  int B, int NG) {
+  extern __shared__ float4 smem4[];
+  constexpr int PAD = (KS - 1) / 2, HALO = 8, TPW = 4;
+  const int LP = L + 2 * HALO;
+  const int NN = CX * KS, NT = (NN + 15) >> 4;
+  const int mt = blockIdx.x / NG, ng = blockIdx.x - mt * NG;
+  const int m0 = mt * 16;
+  const int t0 = ng * 4 * TPW, t1 = min(NT, t0 + 4 * TPW);          // column tiles of this workgroup
+  const int cx0 = (t0 * 16) / KS, cx1 = min(CX, ((t1 * 16 - 1) / KS) + 1), nxr = cx1 - cx0;   // input channels they touch
+  float* ys = reinterpret_cast<float*>(smem4);      // 16 x L
+  float* xs = ys + 16 * L;                          // nxr x LP, zero halo
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < nxr * 2 * HALO; i += blockDim.x) {
+    const int c = i / (2 * HALO), h = i % (2 * HALO);
+    xs[c * LP + (h < HALO ? h : L + h)] = 0.f;
+  }
+  f32x4 acc[TPW];
+  int xoff[TPW];                                    // LDS offset of this lane's (input channel, tap) column, -1 if none
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nn = (t0 + wave + 4 * t) * 16 + r;
+    const int cx = nn / KS, k = nn - cx * KS;
+    xoff[t] = (t0 + wave + 4 * t < t1 && nn < NN) ? (cx - cx0) * LP + HALO + (CONVT ? PAD - k : k - PAD) : -1;
+  }
+  float bsum = 0.f;
+  const int wpb = (B + gridDim.y - 1) / gridDim.y, w0 = blockIdx.y * wpb, w1 = min(B, w0 + wpb);
+  const int ny = min(16, CY - m0);
+  for (int win = w0; win < w1; ++win) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < ny * (L >> 2); i += blockDim.x) {
+      const int c = i / (L >> 2), p = (i - c * (L >> 2)) << 2;
+      *reinterpret_cast<float4*>(ys + c * L + p) = *reinterpret_cast<const float4*>(Y + ((size_t)win * CY + m0 + c) * L + p);
+    }
+    for (int i = threadIdx.x; i < nxr * (L >> 2); i += blockDim.x) {
+      const int c = i / (L >> 2), p = (i - c * (L >> 2)) << 2;
+      *reinterpret_cast<float4*>(xs + c * LP + HALO + p) = *reinterpret_cast<const float4*>(X + ((size_t)win * CX + cx0 + c) * L + p);
+    }
+    __syncthreads();
+    const float* yr = ys + (r < ny ? r : 0) * L;
+    for (int p0 = 0; p0 < L; p0 += 4) {
+      const float av = r < ny ? yr[p0 + g] : 0.f;
+      bsum += av;
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) {
+        const float bv = xoff[t] >= 0 ? xs[xoff[t] + p0 + g] : 0.f;
+        acc[t] = mfma4(av, bv, acc[t]);
+      }
+    }
+  }
+  // lane (r, g) of tile t holds rows m0 + 4 g + v of column nn = (t0 + wave + 4 t) 16 + r
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int nn = (t0 + wave + 4 * t) * 16 + r;
+    if (xoff[t] < 0) continue;
+    const int cx = nn / KS, k = nn - cx * KS;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int cy = m0 + 4 * g + v;
+      if (cy < CY) atomicAdd(gw + (CONVT ? ((size_t)cx * CY + cy) * KS + k : (size_t)cy * NN + nn), acc[t][v]);
+    }
+  }
+  if (gb && ng == 0 && wave == 0) {                 // bias gradient: row sums of Y (lane (r, g) saw positions g, g + 4, ...)
+    bsum = rows_sum(bsum);
+    if (g == 0 && r < ny) atomicAdd(gb + m0 + r, bsum);
+  }
+}
+
 }  // namespace
 
 // =================================================================================
@@ -556,6 +634,18 @@ static void launch_acd_dw(const float* Yg, const float* Xg, float* gw, float* gb
   int splits = 2048 / nblk;                      // ~2048 workgroups per launch
   if (splits < 1) splits = 1;
   if (splits > B) splits = B;
+  static const bool mfma_on = getenv("RAL_ACDAE_DW_MFMA") == nullptr || atoi(getenv("RAL_ACDAE_DW_MFMA")) != 0;
+  if (mfma_on && CY >= 16) {
+    const int NT = (CX * KS + 15) / 16, NG = (NT + 15) / 16, MT = (CY + 15) / 16;
+    const int cxr = (16 * 16) / KS + 2 < CX ? (16 * 16) / KS + 2 : CX;          // input-channel rows a column group touches
+    const size_t l2 = ((size_t)16 * L + (size_t)cxr * (L + 16)) * sizeof(float);
+    int sp = 512 / (MT * NG);
+    if (sp < 1) sp = 1;
+    if (sp > B) sp = B;
+    ACD_LDS((k_acd_dw_m<KS, CONVT>), l2);
+    k_acd_dw_m<KS, CONVT><<<dim3(MT * NG, sp), 256, l2, st>>>(Yg, Xg, gw, gb, CY, CX, L, B, NG);
+    return;
+  }
   ACD_LDS((k_acd_dw<KS, CONVT>), lds);
   k_acd_dw<KS, CONVT><<<dim3(nblk, splits), 256, lds, st>>>(Yg, Xg, gw, gb, CY, CX, L, B);
 }
