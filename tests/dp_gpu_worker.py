@@ -41,7 +41,8 @@ def main():
         losses.append(tr.train_step(xl, tl)["loss"].item())
     torch.cuda.synchronize()
     sd = {k: v.cpu() for k, v in m.state_dict().items()}
-    torch.save({"state": sd, "losses": losses, "step_count": m.step_count}, f"{out}.rank{rank}")
+    grads = {k: v.cpu().clone() for k, v in m.named_grads().items()}      # the all-reduced (global-batch) gradient of the last step
+    torch.save({"state": sd, "grads": grads, "losses": losses, "step_count": m.step_count}, f"{out}.rank{rank}")
     dist.barrier()
     dist.destroy_process_group()
 

@@ -36,7 +36,12 @@ def _launch(argv, extra_env=None, n=2, script="tests/dp_gpu_worker.py"):
 @pytest.mark.parametrize("kind", ["ralenet", "unet"])
 def test_two_processes_equal_one_process(kind, tmp_path):
     from ecg_denoise_amd import RALENet, UNet
-    steps = 3
+    # U-Net: ONE optimiser step, and the comparison is made on the all-reduced GRADIENT of that step.  Adam divides every
+    # gradient component by its own magnitude (g / (|g| + 1e-8) on the first step), so for the components near 1e-7 the
+    # rounding noise of the float atomics (1e-5 of a tensor's largest component against the fp64 oracle,
+    # tools/diag/unet_comp.py) is several per cent of a step: two runs of the SAME single-process model differ by that
+    # much in a few parameter components (tools/diag/unet_det.py), and the parameter comparison below allows for it.
+    steps = 1 if kind == "unet" else 3
     out = str(tmp_path / "dp")
     _launch([out, kind, str(steps)])
     r0, r1 = torch.load(out + ".rank0"), torch.load(out + ".rank1")
@@ -57,12 +62,19 @@ def test_two_processes_equal_one_process(kind, tmp_path):
     m.train()
     losses = [m.train_step(x, t)["loss"].item() for _ in range(steps)]
     assert np.allclose(losses, r0["losses"], rtol=2e-5), (losses, r0["losses"])
+    if kind == "unet":
+        for k, gk in m.named_grads().items():
+            if not k.endswith("conv.bias"):
+                gk = gk.cpu().numpy()
+                assert np.abs(r0["grads"][k].numpy() - gk).max() <= 3e-5 * np.abs(gk).max(), k
     sd = m.state_dict()
     for k, v in sd.items():
         if kind == "unet" and (k.endswith("conv.bias") or k.endswith("running_mean")):
             continue    # a bias in front of a batch-statistics BatchNorm has zero gradient: Adam steps on rounding noise
                         # (and the running mean behind it follows); nothing else depends on it
-        if v.dtype.is_floating_point:
+        if v.dtype.is_floating_point and kind == "unet" and not k.endswith("running_var"):
+            assert np.abs(r0["state"][k].numpy() - v.cpu().numpy()).max() < 1e-4, k     # a tenth of the step (lr = 1e-3)
+        elif v.dtype.is_floating_point:
             assert rel(r0["state"][k].numpy(), v.cpu().numpy()) < 5e-5, k
         else:
             assert torch.equal(r0["state"][k], v.cpu()), k
