@@ -42,6 +42,7 @@ const int DEC_CH[4] = {16, 8, 4, 2}, DEC_K[4] = {4, 4, 18, 18}, DEC_P[4] = {1, 1
 constexpr float BN_EPS = 1e-5f, BN_MOM = 0.1f;
 constexpr int NT = 256;           // threads per workgroup
 constexpr int MAXC = 64;          // widest descriptor (2 x 32)
+constexpr int CH = 12;            // zero halo of the conv tiles in LDS (>= 9 = the widest tap reach, multiple of 4)
 // sum-buffer slots of a cell (doubles): forward column sums, then the sums of the BatchNorm backwards
 enum { S_AH1 = 0, S_AH2 = 128, S_BN = 192, S_DH1 = 256, S_DH2 = 384, T_D2 = 512, T_D1 = 640, T_BN = 768, T_A2 = 832, T_A1 = 896, S_CELL = 1024 };
 
@@ -83,42 +84,44 @@ RAL_DEV float wave_max(float v) {
 // k_dn_conv: in0 (+ in1) (B, cin, lin) -> z (B, c, lout), desc (B, 2c) = [mean_L max(z,0); mean_L min(z,0)],
 //            h1 (B, dh) = W0 desc + b0, column sums of h1
 // ---------------------------------------------------------------------------------
+template <int K, bool TR>
 __global__ __launch_bounds__(NT) void k_dn_conv(const float* __restrict__ in0, const float* __restrict__ in1,
                                                 const float* __restrict__ w, const float* __restrict__ bias, Geo G, Fcn F,
                                                 float* __restrict__ z, float* __restrict__ desc, float* __restrict__ h1,
                                                 double* sums, int B) {
   extern __shared__ float sm[];
-  float* xs = sm;                        // cin x lin
-  float* zs = xs + G.cin * G.lin;        // c x lout
+  const int LP = G.lin + 2 * CH;         // input rows carry a zero halo of CH on both sides: no tap needs a bounds check
+  float* xs = sm;                        // cin x LP
+  float* zs = xs + G.cin * LP;           // c x lout
   float* ds = zs + G.c * G.lout;         // 2c
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nin = G.cin * G.lin, nz = G.c * G.lout;
+  for (int i = tid; i < G.cin * 2 * CH; i += NT) { const int c = i / (2 * CH), h = i - c * 2 * CH; xs[c * LP + (h < CH ? h : G.lin + h)] = 0.f; }
   double s1 = 0, s2 = 0;                 // column sums of h1 (thread j < dh owns column j)
   for (int win = blockIdx.x; win < B; win += gridDim.x) {
     __syncthreads();
-    for (int i = tid; i < nin; i += NT) xs[i] = in0[(size_t)win * nin + i] + (in1 ? in1[(size_t)win * nin + i] : 0.f);
+    for (int i = tid; i < nin; i += NT) {
+      const int c = i / G.lin, l = i - c * G.lin;
+      xs[c * LP + CH + l] = in0[(size_t)win * nin + i] + (in1 ? in1[(size_t)win * nin + i] : 0.f);
+    }
     __syncthreads();
     for (int o = tid; o < nz; o += NT) {
       const int co = o / G.lout, l = o - co * G.lout;
       float acc = bias[co];
-      if (!G.tr) {     // out[co][l] = sum_ci sum_k w[co][ci][k] in[ci][2 l + k - p]
+      if constexpr (!TR) {   // out[co][l] = sum_ci sum_k w[co][ci][k] in[ci][2 l + k - p]
         for (int ci = 0; ci < G.cin; ++ci) {
-          const float* wr = w + ((size_t)co * G.cin + ci) * G.k;
-          const float* row = xs + ci * G.lin;
-          for (int k = 0; k < G.k; ++k) {
-            const int s = 2 * l + k - G.p;
-            if (s >= 0 && s < G.lin) acc = fmaf(wr[k], row[s], acc);
-          }
+          const float* wr = w + ((size_t)co * G.cin + ci) * K;
+          const float* row = xs + ci * LP + CH + 2 * l - G.p;
+#pragma unroll
+          for (int k = 0; k < K; ++k) acc = fmaf(wr[k], row[k], acc);
         }
-      } else {         // out[co][t] = sum_ci sum_{k = t + p - 2 s} w[ci][co][k] in[ci][s]
-        const int k0 = (l + G.p) & 1;
+      } else {               // out[co][t] = sum_ci sum_{k = t + p - 2 s} w[ci][co][k] in[ci][s]: the taps of t's parity
+        const int k0 = (l + G.p) & 1, s0 = (l + G.p - k0) >> 1;
         for (int ci = 0; ci < G.cin; ++ci) {
-          const float* wr = w + ((size_t)ci * G.c + co) * G.k;
-          const float* row = xs + ci * G.lin;
-          for (int k = k0; k < G.k; k += 2) {
-            const int s = (l + G.p - k) >> 1;
-            if (l + G.p - k >= 0 && s < G.lin) acc = fmaf(wr[k], row[s], acc);
-          }
+          const float* wr = w + ((size_t)ci * G.c + co) * K + k0;
+          const float* row = xs + ci * LP + CH + s0;
+#pragma unroll
+          for (int kk = 0; kk < K / 2; ++kk) acc = fmaf(wr[2 * kk], row[-kk], acc);
         }
       }
       zs[o] = acc;
@@ -599,6 +602,7 @@ __global__ __launch_bounds__(NT) void k_dn_act_b(float* __restrict__ dxo, const 
 //   dh1 = BN1 backward(dy1); dW0 += dh1 (x) desc; ddesc = W0^T dh1 = [dP; dN];
 //   dz = da (z > 0 ? 1 : alpha) + (z > 0 ? dP : dN) / lout;  dW, db of the conv;  din -> gi0 (and gi1) unless null
 // ---------------------------------------------------------------------------------
+template <int K, bool TR>
 __global__ __launch_bounds__(NT) void k_dn_conv_b(const float* __restrict__ da, const float* __restrict__ z,
                                                   const float* __restrict__ in0, const float* __restrict__ in1,
                                                   const float* __restrict__ w, float* dw, float* dbias, Geo G,
@@ -607,16 +611,19 @@ __global__ __launch_bounds__(NT) void k_dn_conv_b(const float* __restrict__ da, 
                                                   const float* __restrict__ desc, Fcn F, float* __restrict__ gi0,
                                                   float* __restrict__ gi1, int B) {
   extern __shared__ float sm[];
-  float* xs = sm;                          // cin x lin
-  float* dzs = xs + G.cin * G.lin;         // c x lout
-  float* aw = dzs + G.c * G.lout;          // conv weight accumulator (c cin k)
+  const int LP = G.lin + 2 * CH, LPO = G.lout + 2 * CH;   // both tiles carry a zero halo: no tap needs a bounds check
+  float* xs = sm;                          // cin x LP
+  float* dzs = xs + G.cin * LP;            // c x LPO
+  float* aw = dzs + G.c * LPO;             // conv weight accumulator (c cin k)
   float* ab = aw + G.c * G.cin * G.k;      // c
   float* aw0 = ab + G.c;                   // dh x din
   float* ab0 = aw0 + F.dh * F.din;         // dh
   __shared__ float mean1[MAXC], rstd1[MAXC], m1[MAXC], m2[MAXC], mean2[MAXC], rstd2[MAXC], dh1s[MAXC], dsc[MAXC], al[MAXC], dd[MAXC];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, C = G.c;
-  const int nin = G.cin * G.lin, nz = C * G.lout, nw = C * G.cin * G.k;
+  const int nin = G.cin * G.lin, nz = C * G.lout, nw = C * G.cin * K;
   for (int i = tid; i < nw + C + F.dh * F.din + F.dh; i += NT) aw[i] = 0.f;
+  for (int i = tid; i < G.cin * 2 * CH; i += NT) { const int c = i / (2 * CH), h = i - c * 2 * CH; xs[c * LP + (h < CH ? h : G.lin + h)] = 0.f; }
+  for (int i = tid; i < C * 2 * CH; i += NT) { const int c = i / (2 * CH), h = i - c * 2 * CH; dzs[c * LPO + (h < CH ? h : G.lout + h)] = 0.f; }
   if (tid < F.dh) {
     bn_stat(sums1, F.dh, tid, B, 1, nullptr, nullptr, mean1[tid], rstd1[tid]);
     m1[tid] = (float)(t1[tid] / B); m2[tid] = (float)(t1[F.dh + tid] / B);
@@ -625,7 +632,10 @@ __global__ __launch_bounds__(NT) void k_dn_conv_b(const float* __restrict__ da, 
   if (tid < C) bn_stat(sums2, C, tid, B, 1, nullptr, nullptr, mean2[tid], rstd2[tid]);
   for (int win = blockIdx.x; win < B; win += gridDim.x) {
     __syncthreads();
-    for (int i = tid; i < nin; i += NT) xs[i] = in0[(size_t)win * nin + i] + (in1 ? in1[(size_t)win * nin + i] : 0.f);
+    for (int i = tid; i < nin; i += NT) {
+      const int c = i / G.lin, l = i - c * G.lin;
+      xs[c * LP + CH + l] = in0[(size_t)win * nin + i] + (in1 ? in1[(size_t)win * nin + i] : 0.f);
+    }
     if (tid < F.dh) {
       const size_t o = (size_t)win * F.dh + tid;
       const float hh = (h1[o] - mean1[tid]) * rstd1[tid];
@@ -642,28 +652,28 @@ __global__ __launch_bounds__(NT) void k_dn_conv_b(const float* __restrict__ da, 
     }
     __syncthreads();
     for (int o = tid; o < nz; o += NT) {
-      const int c = o / G.lout;
+      const int c = o / G.lout, l = o - c * G.lout;
       const float v = z[(size_t)win * nz + o], d = da[(size_t)win * nz + o];
-      dzs[o] = v > 0.f ? d + dd[c] : fmaf(d, al[c], dd[C + c]);
+      dzs[c * LPO + CH + l] = v > 0.f ? d + dd[c] : fmaf(d, al[c], dd[C + c]);
     }
     __syncthreads();
     // bias and weight gradients: thread-owned accumulator entries
     for (int c = wave; c < C; c += NT / 64) {
       float s = 0.f;
-      for (int l = lane; l < G.lout; l += 64) s += dzs[c * G.lout + l];
+      for (int l = lane; l < G.lout; l += 64) s += dzs[c * LPO + CH + l];
       s = wave_sum(s);
       if (lane == 0) ab[c] += s;
     }
     for (int i = tid; i < nw; i += NT) {
       float s = 0.f;
-      if (!G.tr) {       // w[co][ci][k]: sum_l dz[co][l] in[ci][2 l + k - p]
-        const int co = i / (G.cin * G.k), r = i - co * G.cin * G.k, ci = r / G.k, k = r - ci * G.k;
-        const float* dr = dzs + co * G.lout; const float* xr = xs + ci * G.lin;
-        for (int l = 0; l < G.lout; ++l) { const int sx = 2 * l + k - G.p; if (sx >= 0 && sx < G.lin) s = fmaf(dr[l], xr[sx], s); }
-      } else {           // w[ci][co][k]: sum_s in[ci][s] dz[co][2 s + k - p]
-        const int ci = i / (C * G.k), r = i - ci * C * G.k, co = r / G.k, k = r - co * G.k;
-        const float* dr = dzs + co * G.lout; const float* xr = xs + ci * G.lin;
-        for (int sx = 0; sx < G.lin; ++sx) { const int t = 2 * sx + k - G.p; if (t >= 0 && t < G.lout) s = fmaf(xr[sx], dr[t], s); }
+      if constexpr (!TR) {   // w[co][ci][k]: sum_l dz[co][l] in[ci][2 l + k - p]
+        const int co = i / (G.cin * K), r = i - co * G.cin * K, ci = r / K, k = r - ci * K;
+        const float* dr = dzs + co * LPO + CH; const float* xr = xs + ci * LP + CH + k - G.p;
+        for (int l = 0; l < G.lout; ++l) s = fmaf(dr[l], xr[2 * l], s);
+      } else {               // w[ci][co][k]: sum_s in[ci][s] dz[co][2 s + k - p]
+        const int ci = i / (C * K), r = i - ci * C * K, co = r / K, k = r - co * K;
+        const float* dr = dzs + co * LPO + CH + k - G.p; const float* xr = xs + ci * LP + CH;
+        for (int sx = 0; sx < G.lin; ++sx) s = fmaf(xr[sx], dr[2 * sx], s);
       }
       aw[i] += s;
     }
@@ -672,16 +682,18 @@ __global__ __launch_bounds__(NT) void k_dn_conv_b(const float* __restrict__ da, 
       for (int o = tid; o < nin; o += NT) {
         const int ci = o / G.lin, sx = o - ci * G.lin;
         float s = 0.f;
-        if (!G.tr) {     // din[ci][s] = sum_co sum_{k = s + p - 2 l} w[co][ci][k] dz[co][l]
-          const int k0 = (sx + G.p) & 1;
+        if constexpr (!TR) {   // din[ci][s] = sum_co sum_{k = s + p - 2 l} w[co][ci][k] dz[co][l]: the taps of s's parity
+          const int k0 = (sx + G.p) & 1, l0 = (sx + G.p - k0) >> 1;
           for (int co = 0; co < C; ++co) {
-            const float* wr = w + ((size_t)co * G.cin + ci) * G.k; const float* dr = dzs + co * G.lout;
-            for (int k = k0; k < G.k; k += 2) { const int l2 = sx + G.p - k; if (l2 >= 0 && (l2 >> 1) < G.lout) s = fmaf(wr[k], dr[l2 >> 1], s); }
+            const float* wr = w + ((size_t)co * G.cin + ci) * K + k0; const float* dr = dzs + co * LPO + CH + l0;
+#pragma unroll
+            for (int kk = 0; kk < (K + 1) / 2; ++kk) if (k0 + 2 * kk < K) s = fmaf(wr[2 * kk], dr[-kk], s);
           }
-        } else {         // din[ci][s] = sum_co sum_k w[ci][co][k] dz[co][2 s + k - p]
+        } else {               // din[ci][s] = sum_co sum_k w[ci][co][k] dz[co][2 s + k - p]
           for (int co = 0; co < C; ++co) {
-            const float* wr = w + ((size_t)ci * C + co) * G.k; const float* dr = dzs + co * G.lout;
-            for (int k = 0; k < G.k; ++k) { const int t = 2 * sx + k - G.p; if (t >= 0 && t < G.lout) s = fmaf(wr[k], dr[t], s); }
+            const float* wr = w + ((size_t)ci * C + co) * K; const float* dr = dzs + co * LPO + CH + 2 * sx - G.p;
+#pragma unroll
+            for (int k = 0; k < K; ++k) s = fmaf(wr[k], dr[k], s);
           }
         }
         gi0[(size_t)win * nin + o] = s;
@@ -870,10 +882,14 @@ int danet_forward(DanetModel* m, const float* x, float* y, int B, int training, 
     const float* in1 = i >= 5 ? m->out[7 - i] : nullptr;     // decoder cells 1..3 add encoder features 2, 1, 0
     float* out = i == 7 ? y : m->out[i];
     const size_t nz = (size_t)G.c * G.lout;
-    const size_t l1 = ((size_t)G.cin * G.lin + nz + 2 * G.c) * sizeof(float);
-    set_lds(k_dn_conv, l1);
-    k_dn_conv<<<grid, NT, l1, st>>>(in0, in1, P.params + K.cw, P.params + K.cb, G, Fa, m->z[i], m->desc[i], m->h1[i],
-                                     training ? S + S_AH1 : nullptr, B);
+    const size_t l1 = ((size_t)G.cin * (G.lin + 2 * CH) + nz + 2 * G.c) * sizeof(float);
+    auto conv = [&](auto kern) {
+      set_lds(kern, l1);
+      kern<<<grid, NT, l1, st>>>(in0, in1, P.params + K.cw, P.params + K.cb, G, Fa, m->z[i], m->desc[i], m->h1[i],
+                                 training ? S + S_AH1 : nullptr, B);
+    };
+    if (G.k == 17) conv(k_dn_conv<17, false>); else if (G.k == 3) conv(k_dn_conv<3, false>);
+    else if (G.k == 4) conv(k_dn_conv<4, true>); else conv(k_dn_conv<18, true>);
     k_dn_fcn_mid<<<grid, NT, 0, st>>>(m->h1[i], S + S_AH1, Fa, m->h2[i], training ? S + S_AH2 : nullptr, 1, B, training);
     k_dn_act<<<grid, NT, 0, st>>>(m->z[i], m->h2[i], S + S_AH2, Fa, G, m->a[i], training ? S + S_BN : nullptr, B, training);
     Fcn Fd = Fa;
@@ -936,10 +952,15 @@ int danet_backward(DanetModel* m, const float* dy, float* dx, int B, hipStream_t
     const float* in1 = i >= 5 ? m->out[7 - i] : nullptr;
     float* gi0 = i == 0 ? dx : m->g[i - 1];
     float* gi1 = i >= 5 ? m->gs[7 - i] : nullptr;
-    const size_t l5 = ((size_t)G.cin * G.lin + nz + (size_t)G.c * G.cin * G.k + G.c + (size_t)Fa.dh * Fa.din + Fa.dh) * sizeof(float);
-    set_lds(k_dn_conv_b, l5);
-    k_dn_conv_b<<<grid, NT, l5, st>>>(work, m->z[i], in0, in1, P.params + K.cw, P.grads + K.cw, P.grads + K.cb, G, m->dy1[i], S + T_A1,
-                                       m->h1[i], S + S_AH1, m->h2[i], S + S_AH2, m->desc[i], Fa, gi0, gi1, B);
+    const size_t l5 = ((size_t)G.cin * (G.lin + 2 * CH) + (size_t)G.c * (G.lout + 2 * CH) + (size_t)G.c * G.cin * G.k + G.c +
+                       (size_t)Fa.dh * Fa.din + Fa.dh) * sizeof(float);
+    auto convb = [&](auto kern) {
+      set_lds(kern, l5);
+      kern<<<grid, NT, l5, st>>>(work, m->z[i], in0, in1, P.params + K.cw, P.grads + K.cw, P.grads + K.cb, G, m->dy1[i], S + T_A1,
+                                 m->h1[i], S + S_AH1, m->h2[i], S + S_AH2, m->desc[i], Fa, gi0, gi1, B);
+    };
+    if (G.k == 17) convb(k_dn_conv_b<17, false>); else if (G.k == 3) convb(k_dn_conv_b<3, false>);
+    else if (G.k == 4) convb(k_dn_conv_b<4, true>); else convb(k_dn_conv_b<18, true>);
   }
   if (hipGetLastError() != hipSuccess) { snprintf(err, cap, "DANet backward launch failed"); return -1; }
   return 0;
