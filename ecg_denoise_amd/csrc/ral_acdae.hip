@@ -83,6 +83,70 @@ __global__ __launch_bounds__(256) void k_acd_enc_fwd(const float* __restrict__ i
 }
 
 // ---------------------------------------------------------------------------------
+// The same encoder block with the convolution on the fp32 MFMA (input channels >= 16): rows = positions, columns = 32
+// output channels of this workgroup (blockIdx.y), K = (input channel, tap) pairs; the A operand is gathered from the
+// zero-haloed input tile by index, the B operand from the workgroup's slice of the weights, staged in LDS once.  A lane
+// ends with four consecutive positions of one output channel: the two pooling pairs of the epilogue.
+// ---------------------------------------------------------------------------------
+template <int KS>
+__global__ __launch_bounds__(256) void k_acd_enc_fwd_m(const float* __restrict__ in, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ e,
+                                                       unsigned char* __restrict__ am, int CIN, int COUT, int Lin, int B) {
+  extern __shared__ float4 smem4[];
+  constexpr int PAD = (KS - 1) / 2, HALO = 8, CB = 32;
+  const int LP = Lin + 2 * HALO, Lo = Lin >> 1, KT = CIN * KS;
+  float* xs = reinterpret_cast<float*>(smem4);      // CIN x LP
+  float* ws = xs + CIN * LP;                        // CB x KT
+  const int cb0 = blockIdx.y * CB;
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < CIN * 2 * HALO; i += blockDim.x) {
+    const int c = i / (2 * HALO), h = i % (2 * HALO);
+    xs[c * LP + (h < HALO ? h : Lin + h)] = 0.f;
+  }
+  for (int i = threadIdx.x; i < CB * KT; i += blockDim.x) ws[i] = w[(size_t)cb0 * KT + i];
+  const int ptiles = Lin >> 4;
+  for (int win = blockIdx.x; win < B; win += gridDim.x) {
+    __syncthreads();
+    const float* xw = in + (size_t)win * CIN * Lin;
+    for (int i = threadIdx.x; i < CIN * (Lin >> 2); i += blockDim.x) {
+      const int c = i / (Lin >> 2), p = (i - c * (Lin >> 2)) << 2;
+      *reinterpret_cast<float4*>(xs + c * LP + HALO + p) = *reinterpret_cast<const float4*>(xw + c * Lin + p);
+    }
+    __syncthreads();
+    for (int pt = wave; pt < ptiles; pt += 4) {           // a wave: 16 positions x both column tiles (one A gather feeds two MFMAs)
+      const int p0 = pt << 4;
+      const float* arow = xs + HALO - PAD + p0 + r;      // + ci LP + k
+      const float* brow = ws + r * KT;                   // + kk (second tile: + 16 KT)
+      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      int ci = 0, k = g;                                  // this lane's (input channel, tap) of the current step
+      if (k >= KS) { k -= KS; ci = 1; }
+      // (KT is a multiple of 16: the channel counts are multiples of 16.)  Four steps per trip: their operand reads are
+      // issued before the first MFMA needs one.
+      for (int kk = g; kk < KT + g; kk += 16) {
+        float av[4], b0[4], b1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          av[u] = arow[ci * LP + k]; b0[u] = brow[kk + 4 * u]; b1[u] = brow[16 * KT + kk + 4 * u];
+          k += 4;
+          if (k >= KS) { k -= KS; ++ci; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { acc[0] = mfma4(av[u], b0[u], acc[0]); acc[1] = mfma4(av[u], b1[u], acc[1]); }
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int co = cb0 + 16 * t + r, l0 = p0 + 4 * g;   // positions l0 .. l0 + 3 of channel co
+        const float b = bias[co];
+        const size_t o = ((size_t)win * COUT + co) * Lo + (l0 >> 1);
+        const bool s0 = acc[t][1] > acc[t][0], s1 = acc[t][3] > acc[t][2];   // MaxPool1d(2): the FIRST element wins a tie
+        *reinterpret_cast<float2*>(e + o) = make_float2(lrelu01((s0 ? acc[t][1] : acc[t][0]) + b), lrelu01((s1 ? acc[t][3] : acc[t][2]) + b));
+        am[o] = s0; am[o + 1] = s1;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // decoder block forward.  in: (B, CIN, Lin) -> a: (B, COUT, 2 Lin) = LeakyReLU(upsample(convT(in))),
 //   s: (B, COUT) ECA scale, out: (B, COUT, 2 Lin) = a * s (+ skip)
 // ---------------------------------------------------------------------------------
@@ -610,7 +674,14 @@ int acdae_forward(AcdaeModel* m, const float* x, float* y, int B, hipStream_t st
   for (int i = 0; i < 4; ++i) {
     const int cin = ACH[i], cout = ACH[i + 1], lin = L >> i;
     const size_t lds = (size_t)cin * (lin + 16) * sizeof(float);
+    static const bool enc_mfma = getenv("RAL_ACDAE_ENC_MFMA") == nullptr || atoi(getenv("RAL_ACDAE_ENC_MFMA")) != 0;
     if (AKS[i] == 13) { ACD_LDS(k_acd_enc_fwd<13>, lds); k_acd_enc_fwd<13><<<grid, 256, lds, st>>>(in, P.params + Y.ew[i], P.params + Y.eb[i], m->e[i], m->am[i], cin, cout, lin, B); }
+    else if (enc_mfma && cin >= 16 && cout % 32 == 0 && lin % 16 == 0) {
+      const size_t l2 = lds + (size_t)32 * cin * 7 * sizeof(float);
+      const int gx = B < 512 ? B : 512;
+      ACD_LDS(k_acd_enc_fwd_m<7>, l2);
+      k_acd_enc_fwd_m<7><<<dim3(gx, cout / 32), 256, l2, st>>>(in, P.params + Y.ew[i], P.params + Y.eb[i], m->e[i], m->am[i], cin, cout, lin, B);
+    }
     else { ACD_LDS(k_acd_enc_fwd<7>, lds); k_acd_enc_fwd<7><<<grid, 256, lds, st>>>(in, P.params + Y.ew[i], P.params + Y.eb[i], m->e[i], m->am[i], cin, cout, lin, B); }
     in = m->e[i];
   }
