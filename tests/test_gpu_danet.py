@@ -135,3 +135,42 @@ def test_danet_trains_through_the_harness_and_checkpoint_round_trips(tmp_path):
     x = torch.as_tensor(noisy[64:96]).float().to(DEV)
     m.eval(); m2.eval()
     assert torch.equal(m(x), m2(x))
+
+
+def test_danet_bench_batch_matches_fp64_oracle():
+    """BASELINE batch (2048 x 2 x 512): the BatchNorms of the descriptor nets average over 2048 windows here and every
+    kernel runs its multi-window loop.  Output, loss and running statistics against the fp64 oracle at the usual 1e-5.
+    Gradients: with ~2 M ReLU inputs and ~1 M max-pool decisions per pass, a few of them sit within fp32 rounding of their
+    kink (tools/diag/danet_big.py finds the window: a pre-activation of 2e-6), fp32 and fp64 take different branches
+    there and the gradient of that window changes by a finite amount - which the batch statistics then spread thinly over
+    every window.  So: the input gradient of all but a handful of windows to 1e-3 (median 2e-4), the whole tensors to 1e-2
+    (a wrong multi-window loop or a lost partial sum would be off by O(1))."""
+    B, L = 2048, 512
+    st64 = D.init_state(7, dtype=torch.float64)
+    st32 = OrderedDict((k, v.clone().float() if v.dtype.is_floating_point else v.clone()) for k, v in st64.items())
+    gg = torch.Generator().manual_seed(11)
+    x = torch.randn(B, 2, L, generator=gg); tgt = torch.randn(B, 2, L, generator=gg)
+    xd = x.double().requires_grad_(True)
+    params = OrderedDict((k, v.requires_grad_(True)) for k, v in st64.items() if D.is_param(k) and ".dam.fcn2." not in k)
+    y64 = D.danet_forward(st64, xd, training=True)
+    loss64 = torch.nn.functional.mse_loss(y64, tgt.double())
+    loss64.backward()
+    m = _model(st32, B, L)
+    m.train()
+    y = m(x.to(DEV))
+    assert rel(y.cpu().numpy(), y64.detach().numpy()) < 1e-5
+    loss, _, _ = m.loss_and_metrics(y, tgt.to(DEV))
+    assert abs(loss.item() - loss64.item()) < 1e-5 * loss64.item()
+    dx = m.backward(want_dx=True).cpu().double()
+    e = ((dx - xd.grad).flatten(1).norm(dim=1) / xd.grad.flatten(1).norm(dim=1)).numpy()
+    assert np.median(e) < 2e-4 and (e > 1e-3).sum() <= 6, (np.median(e), np.sort(e)[-8:])
+    assert rel(dx.numpy(), xd.grad.numpy()) < 1e-2
+    for k, v in m.named_grads().items():
+        if k.endswith(ZERO_GRAD):
+            assert v.abs().max().item() < 1e-5, k
+        else:
+            assert rel(v.cpu().numpy(), params[k].grad.numpy()) < 1e-2, k
+    sd = m.state_dict()
+    for k in sd:
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert rel(sd[k].cpu().numpy(), st64[k].numpy()) < 1e-5, k
