@@ -80,3 +80,36 @@ def test_acdae_trains_through_the_harness(tmp_path):
     tl, _ = train.last_losses
     assert tl[-1] < tl[0] and all(np.isfinite(res[1]))
     assert (tmp_path / "model_save" / "ACDAE" / "ACDAE_9_emb_intensity0.pth").exists()
+
+
+def test_acdae_bench_batch_is_the_sum_of_its_halves():
+    """BASELINE batch (2048 x 2 x 512).  ACDAE has no BatchNorm, so windows are independent: the forward of a slice is the
+    slice of the forward bit for bit, the input gradient likewise, and the parameter gradients of the whole batch are the
+    sum of the gradients of its two halves (same upstream gradient) - which exercises the multi-window loops and the
+    split-K accumulation of the MFMA weight-gradient kernel at full size.  64 windows of it also against the fp64 oracle."""
+    from ecg_denoise_amd import ACDAE
+    B, L = 2048, 512
+    p32 = O.init_params(O.acdae_param_shapes(), 77)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, 2, L, generator=g).to(DEV)
+    dy = (torch.randn(B, 2, L, generator=g) / (B * 2 * L)).to(DEV)
+    m = ACDAE(L=L, max_batch=B, device=DEV); m.load_state_dict(p32); m.train()
+    y = m(x).clone()
+    dx = m.backward(dy, want_dx=True).clone()
+    gw = OrderedDict((k, v.clone()) for k, v in m.named_grads().items())
+    h = ACDAE(L=L, max_batch=B // 2, device=DEV); h.load_state_dict(p32); h.train()
+    parts = []
+    for lo in (0, B // 2):
+        yh = h(x[lo:lo + B // 2].contiguous())
+        assert torch.equal(yh, y[lo:lo + B // 2])
+        dxh = h.backward(dy[lo:lo + B // 2].contiguous(), want_dx=True)
+        assert torch.equal(dxh, dx[lo:lo + B // 2])
+        parts.append(OrderedDict((k, v.clone()) for k, v in h.named_grads().items()))
+    for k in gw:
+        s2 = parts[0][k].double() + parts[1][k].double()
+        assert rel(gw[k].double().cpu().numpy(), s2.cpu().numpy()) < 2e-6, k
+    # a slice against the oracle
+    n = 64
+    p = OrderedDict((k, v.double()) for k, v in p32.items())
+    yo = O.acdae_forward(p, x[:n].cpu().double())
+    assert rel(y[:n].cpu().numpy(), yo.numpy()) < 1e-5
