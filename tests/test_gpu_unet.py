@@ -85,3 +85,28 @@ def test_unet_against_reference_golden(golden_dir):
     m2.train()
     losses = [m2.train_step(x, tgt)["loss"].item() for _ in range(3)]
     np.testing.assert_allclose(losses, g["adam_losses"], rtol=5e-4)
+
+
+def test_unet_bench_batch_matches_fp64_oracle():
+    """BASELINE batch (2048 x 2 x 512): every stage kernel runs its multi-window loop (512 workgroups), the wide layers'
+    MFMA gradient products accumulate over four windows per workgroup, and the BatchNorm statistics are sums over 2048
+    windows.  Output, loss and running statistics at the usual 1e-5; gradients at 1e-3 (LeakyReLU has a kink at 0: with
+    ~50 M activations a few sit within fp32 rounding of it and take the other slope in fp64)."""
+    m, y, loss, p, bn, yo, lo, grads, x, tgt = _run(2, 512, 2048, seed=4321)
+    assert rel(y.cpu().numpy(), yo.detach().numpy()) < 1e-5
+    assert abs(loss.item() - lo.item()) < 1e-5 * abs(lo.item())
+    ng = m.named_grads()
+    bad = {}
+    for (k, _), gr in zip(p.items(), grads):
+        if gr.norm().item() < 1e-9:                   # zero gradient in front of a batch-statistics BatchNorm
+            if float(np.abs(ng[k].cpu().numpy()).max()) > 2e-5:
+                bad[k] = "nonzero"
+            continue
+        e = rel(ng[k].cpu().numpy(), gr.numpy())
+        if e > 1e-3:
+            bad[k] = e
+    assert not bad, bad
+    sd = m.state_dict()
+    for k in O.UNET_BN:
+        np.testing.assert_allclose(sd[k + ".running_mean"].cpu().numpy(), bn[k]["running_mean"].numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(sd[k + ".running_var"].cpu().numpy(), bn[k]["running_var"].numpy(), rtol=1e-5, atol=1e-6)
