@@ -1189,7 +1189,8 @@ __global__ void k_conv1_bwd_dx(const float* __restrict__ dz, const float* __rest
 // (LayerNorm affines, biases, local-enhancement taps: 5 C .. 8 C floats) to global memory with atomics and pays its
 // set-up once, so fewer, longer-lived workgroups win well before the CUs run out of work.  Measured at batch 2048 (two
 // lanes of 1024 windows), training step with 1024 workgroups everywhere: 18.12 ms; k_qkv_bwd at 256: 17.81; k_resample_bwd
-// at 256: 17.95; k_mlp_bwd at 512: 18.06; all three: 17.45 ms.  (RAL_GRID_QKVB / RESB / MLPB / ATTNB override.)
+// at 256: 17.95; k_mlp_bwd at 512: 18.06; all three: 17.45 ms; k_mlp_bwd_s: flat between 384 and 512, slower above.
+// (RAL_GRID_QKVB / RESB / MLPB / MLPS / ATTNB override.)
 static inline int env_grid(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 static inline int cap(int items, int gmax) { return items < gmax ? items : gmax; }
 static inline int ew_grid(size_t n, int per = 256) {
@@ -1237,7 +1238,8 @@ static bool launch_mlp_bwd_s(const float* dx2, const float* x1, const BlockP& w,
   // no longer negligible on the critical stream, so the gain flattens)
   int tw; size_t lds;
   if (!mlp_bwd_s_applies<C>(N, &tw, &lds)) return false;
-  const int grid = B < 512 ? B : 512;
+  static const int gs = env_grid("RAL_GRID_MLPS", 512);
+  const int grid = cap(B, gs);
 #define GO(t) { RAL_SET_LDS((k_mlp_bwd_s<C, t>), lds); k_mlp_bwd_s<C, t><<<grid, 512, lds, s>>>(dx2, x1, w, wt, gr, dx1, do_hm, N, B, want_dw ? 1 : 0); return true; }
   switch (tw) { case 1: GO(1) case 2: GO(2) case 4: GO(4) case 8: GO(8) default: return false; }
 #undef GO
