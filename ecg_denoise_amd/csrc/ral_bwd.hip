@@ -824,9 +824,14 @@ __global__ __launch_bounds__(256) void k_attn_bwd_vkv(const float* __restrict__ 
 //   grads: bqkv, ln1 w/b.   `extra` (optional) is added to dx (skip-connection gradient).
 // =================================================================================
 template <int C>
-__global__ __launch_bounds__(512) void k_qkv_bwd(const float* __restrict__ dqkv, const float* __restrict__ x,
-                                                 const float* __restrict__ pe, const float* __restrict__ dx1,
-                                                 const float* __restrict__ extra, BlockP w, BlockP wt, BlockP gr,
+// (dqkv, x, dx1 and extra are deliberately NOT __restrict__: see k_dw - loads the compiler can prove invariant are sunk
+// across the compiler barrier of the prefetch, next to their uses, which puts the HBM round trip back in front of them)
+#ifndef RAL_QKVB_MINB
+#define RAL_QKVB_MINB 1
+#endif
+__global__ __launch_bounds__(512, RAL_QKVB_MINB) void k_qkv_bwd(const float* dqkv, const float* x,
+                                                 const float* __restrict__ pe, const float* dx1,
+                                                 const float* extra, BlockP w, BlockP wt, BlockP gr,
                                                  float* __restrict__ dx, int N, int B) {
   extern __shared__ float4 smem4[];
   constexpr int LD = LDof<C>::v, LPR = C / 4;
@@ -839,10 +844,75 @@ __global__ __launch_bounds__(512) void k_qkv_bwd(const float* __restrict__ dqkv,
   const float4 gam1 = *reinterpret_cast<const float4*>(w.ln1w + cq);
   float4 dgam = make_float4(0.f, 0.f, 0.f, 0.f), dbet = make_float4(0.f, 0.f, 0.f, 0.f);
   const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  // One workgroup per CU is resident next to the weight-gradient kernels, so nothing else hides this kernel's HBM round
+  // trips: the next window's operands are requested under the current window's LayerNorm phase.  NQ float4 of dqkv and
+  // NR rows of x / dx1 / extra per thread are kept in flight (the BASELINE shapes have N C = 4096: NQ = 6, NR = 2 cover
+  // a whole window); longer windows stage their remainder the plain way.
+  constexpr int NQ = 6, NR = 2;
+  const int n4 = N * 3 * C / 4;
+  const bool pfq = n4 <= NQ * (int)blockDim.x;
+  const int rbase = threadIdx.x / LPR;
+  const float* const ex = extra ? extra : dx1;   // any readable address: no branch around a load
+  // (plain arrays filled through by-value lambdas: a struct handed to a lambda by reference ends up in scratch memory)
+  auto row_off = [&](int win, int u) -> size_t {
+    return (size_t)win * N * C + (size_t)min(rbase + u * RPP, N - 1) * C + cq;
+  };
+  auto ld4 = [&](const float* base, size_t o) -> float4 { return *reinterpret_cast<const float4*>(base + o); };
+  auto ld_dq = [&](int win, int u) -> float4 {
+    return reinterpret_cast<const float4*>(dqkv + (size_t)win * N * 3 * C)[min((int)threadIdx.x + u * (int)blockDim.x, n4 - 1)];
+  };
+  auto st_dq = [&](int u, float4 v) {
+    const int i = threadIdx.x + u * blockDim.x;
+    if (i < n4) reinterpret_cast<float4*>(DQ)[i] = v;
+  };
+  float4 pe4[NR];
+#pragma unroll
+  for (int u = 0; u < NR; ++u) pe4[u] = *reinterpret_cast<const float4*>(pe + min(rbase + u * RPP, N - 1) * C + cq);
+  auto ln_row = [&](size_t wo, int row, float4 v, float4 p, float4 d1, float4 e) {
+    v = f4add(f4scale(v, sqrtC), p);
+    float4 d; float rstd;
+    ln_stats<LPR>(v, d, rstd);
+    const float4 xh = f4scale(d, rstd);
+    const float4 dh = *reinterpret_cast<const float4*>(Dh + row * LD + cq);
+    const float4 dyh = f4mul(dh, gam1);
+    constexpr float invC = 1.0f / C;
+    const float m1 = group_sum<LPR>(f4hsum(dyh)) * invC;
+    const float m2 = group_sum<LPR>(f4dot(dyh, xh)) * invC;
+    const float k = rstd * sqrtC;
+    float4 out = make_float4(k * (dyh.x - m1 - xh.x * m2), k * (dyh.y - m1 - xh.y * m2),
+                             k * (dyh.z - m1 - xh.z * m2), k * (dyh.w - m1 - xh.w * m2));
+    out = f4add(out, d1);
+    if (extra) out = f4add(out, e);
+    *reinterpret_cast<float4*>(dx + wo + (size_t)row * C + cq) = out;
+    dgam = f4add(dgam, f4mul(dh, xh));
+    dbet = f4add(dbet, dh);
+  };
+
+  float4 rx[NR], rd[NR], re[NR];
+#pragma unroll
+  for (int u = 0; u < NR; ++u) rx[u] = rd[u] = re[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  {
+    const int win0 = blockIdx.x;
+    if (win0 < B) {
+#pragma unroll
+      for (int u = 0; u < NR; ++u) {
+        const size_t o = row_off(win0, u);
+        rx[u] = ld4(x, o); rd[u] = ld4(dx1, o); re[u] = ld4(ex, o);
+      }
+      if (pfq) {
+        float4 q[NQ];
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) q[u] = ld_dq(win0, u);
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) st_dq(u, q[u]);
+      } else {
+        copy_flat(DQ, dqkv + (size_t)win0 * N * 3 * C, n4);
+      }
+    }
+    __syncthreads();
+  }
   for (int win = blockIdx.x; win < B; win += gridDim.x) {
     const size_t wo = (size_t)win * N * C;
-    copy_flat(DQ, dqkv + 3 * wo, N * 3 * C / 4);
-    __syncthreads();
     // dh[t][c] = sum_m dqkv[t][m] Wqkv[m][c]   (K = 3C split as C (q rows) + 2C (kv rows))
     {
       auto run = [&](auto ttb_tag) {
@@ -869,28 +939,40 @@ __global__ __launch_bounds__(512) void k_qkv_bwd(const float* __restrict__ dqkv,
       else if ((nt & 1) == 0) run(std::integral_constant<int, 2>{});
       else run(std::integral_constant<int, 1>{});
     }
-    __syncthreads();
-    for (int row = threadIdx.x / LPR; row < N; row += RPP) {
-      float4 v = *reinterpret_cast<const float4*>(x + wo + (size_t)row * C + cq);
-      const float4 p = *reinterpret_cast<const float4*>(pe + row * C + cq);
-      v = f4add(f4scale(v, sqrtC), p);
-      float4 d; float rstd;
-      ln_stats<LPR>(v, d, rstd);
-      const float4 xh = f4scale(d, rstd);
-      const float4 dh = *reinterpret_cast<const float4*>(Dh + row * LD + cq);
-      const float4 dyh = f4mul(dh, gam1);
-      constexpr float invC = 1.0f / C;
-      const float m1 = group_sum<LPR>(f4hsum(dyh)) * invC;
-      const float m2 = group_sum<LPR>(f4dot(dyh, xh)) * invC;
-      const float k = rstd * sqrtC;
-      float4 out = make_float4(k * (dyh.x - m1 - xh.x * m2), k * (dyh.y - m1 - xh.y * m2),
-                               k * (dyh.z - m1 - xh.z * m2), k * (dyh.w - m1 - xh.w * m2));
-      out = f4add(out, *reinterpret_cast<const float4*>(dx1 + wo + (size_t)row * C + cq));
-      if (extra) out = f4add(out, *reinterpret_cast<const float4*>(extra + wo + (size_t)row * C + cq));
-      *reinterpret_cast<float4*>(dx + wo + (size_t)row * C + cq) = out;
-      dgam = f4add(dgam, f4mul(dh, xh));
-      dbet = f4add(dbet, dh);
+    __syncthreads();   // Dh complete, DQ free
+    const int nxt = win + gridDim.x;
+    const bool more = nxt < B;
+    const int pw = more ? nxt : win;   // (past the end: a harmless re-read, no branch around the loads)
+    float4 q[NQ], nx[NR], nd[NR], ne[NR];
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) q[u] = ld_dq(pw, u);
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+      const size_t o = row_off(pw, u);
+      nx[u] = ld4(x, o); nd[u] = ld4(dx1, o); ne[u] = ld4(ex, o);
     }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+      const int row = rbase + u * RPP;
+      if (row < N) ln_row(wo, row, rx[u], pe4[u], rd[u], re[u]);
+    }
+    for (int row = rbase + NR * RPP; row < N; row += RPP) {
+      const size_t o = wo + (size_t)row * C + cq;
+      ln_row(wo, row, *reinterpret_cast<const float4*>(x + o), *reinterpret_cast<const float4*>(pe + row * C + cq),
+             *reinterpret_cast<const float4*>(dx1 + o), *reinterpret_cast<const float4*>(ex + o));
+    }
+    if (more) {
+      if (pfq) {
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) st_dq(u, q[u]);
+      } else {
+        copy_flat(DQ, dqkv + (size_t)nxt * N * 3 * C, n4);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NR; ++u) { rx[u] = nx[u]; rd[u] = nd[u]; re[u] = ne[u]; }
     __syncthreads();
   }
   for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) red[i] = 0.f;
