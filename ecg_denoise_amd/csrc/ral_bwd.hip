@@ -443,12 +443,17 @@ RAL_DEV f32x2 splat2(float v) { return f32x2{v, v}; }
 #define RAL_LOG2E 1.4426950408889634f
 #define RAL_LN2 0.6931471805599453f
 
-template <int QT>
+// NT > 0: the window length as a compile-time constant (short windows: a task's sweep is 2-4 iterations, so its set-up,
+// loop control and epilogue weigh as much as its tiles; with N known they unroll and their index arithmetic folds);
+// TAB = false: no R-wave table (its bounds and branches fold away).
+template <int QT, int NT = 0, bool TAB = true>
 __global__ __launch_bounds__(512, 4) void k_attn_bwd(const float* __restrict__ qkv, const float* __restrict__ o_hm,
                                                   const float* __restrict__ do_hm, const float* __restrict__ lse,
                                                   const float* __restrict__ table, float* __restrict__ gtable,
-                                                  float* __restrict__ dqkv, int N, int H, int HG, int Len, int B) {
+                                                  float* __restrict__ dqkv, int N_rt, int H, int HG, int Len, int B) {
   extern __shared__ float4 smem4[];
+  const int N = NT ? NT : N_rt;
+  if constexpr (!TAB) { table = nullptr; Len = 0; }
   float* Qs = reinterpret_cast<float*>(smem4);  // q * log2(e)
   float* Ks = Qs + HG * N * 4;
   float* Vs = Ks + HG * N * 4;
@@ -481,6 +486,9 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd(const float* __restrict__ q
       const float4* go = reinterpret_cast<const float4*>(o_hm) + hq0;
       const int n4 = HG * N, bd = blockDim.x;
       int i = threadIdx.x;
+#ifdef RAL_ATTNB_NOSTAGE   // diagnostic: no staging loads (the tiles work on whatever the LDS holds)
+      i = n4;
+#endif
       for (; i + bd < n4; i += 2 * bd) {
         const float4 q0 = gq[i], q1 = gq[i + bd], k0 = gk[i], k1 = gk[i + bd], v0 = gv[i], v1 = gv[i + bd];
         const float4 d0 = gd[i], d1 = gd[i + bd], o0 = go[i], o1 = go[i + bd];
@@ -503,7 +511,11 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd(const float* __restrict__ q
     for (int i = threadIdx.x; i < ntab; i += blockDim.x) tab[i] = table[(i / HG) * H + h0 + (i % HG)] * RAL_LOG2E;
     __syncthreads();
     RAL_STAMP_AT(21);
+#ifdef RAL_ATTNB_NOSWEEP   // diagnostic: staging only
+    const int nblk = 0;
+#else
     const int nblk = N / (16 * QT);
+#endif
     // ---------------- sweep A: dQ (query block on the lanes, loop over key tiles) ----------------
     for (int task = wave; task < HG * nblk; task += nw) {
       const int hl = task / nblk, q0 = (task - hl * nblk) * 16 * QT;
@@ -555,9 +567,17 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd(const float* __restrict__ q
       };
       const bool qbias = table && (q0 < off + Len) && (q0 + 16 * QT > off);
       const int e0 = qbias ? kb0 : N, e1 = qbias ? kb1 : N;
-      for (int kt = 0; kt < e0; kt += 16) tileA(kt, std::false_type{});
-      for (int kt = e0; kt < e1; kt += 16) tileA(kt, std::true_type{});
-      for (int kt = e1; kt < N; kt += 16) tileA(kt, std::false_type{});
+      if constexpr (NT > 0 && NT <= 64) {   // compile-time trip count: unrolled, the table variant chosen per tile (wave-uniform)
+#pragma unroll
+        for (int kt = 0; kt < NT; kt += 16) {
+          if (TAB && kt >= e0 && kt < e1) tileA(kt, std::true_type{});
+          else tileA(kt, std::false_type{});
+        }
+      } else {
+        for (int kt = 0; kt < e0; kt += 16) tileA(kt, std::false_type{});
+        for (int kt = e0; kt < e1; kt += 16) tileA(kt, std::true_type{});
+        for (int kt = e1; kt < N; kt += 16) tileA(kt, std::false_type{});
+      }
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {
         float4 v = make_float4(dq01[qt][0], dq01[qt][1], dq23[qt][0], dq23[qt][1]);
@@ -614,9 +634,17 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd(const float* __restrict__ q
       };
       const bool kbias = table && (k0 < off + Len) && (k0 + 16 * QT > off);
       const int e0 = kbias ? kb0 : N, e1 = kbias ? kb1 : N;
-      for (int qt = 0; qt < e0; qt += 16) tileB(qt, std::false_type{});
-      for (int qt = e0; qt < e1; qt += 16) tileB(qt, std::true_type{});
-      for (int qt = e1; qt < N; qt += 16) tileB(qt, std::false_type{});
+      if constexpr (NT > 0 && NT <= 64) {
+#pragma unroll
+        for (int qt = 0; qt < NT; qt += 16) {
+          if (TAB && qt >= e0 && qt < e1) tileB(qt, std::true_type{});
+          else tileB(qt, std::false_type{});
+        }
+      } else {
+        for (int qt = 0; qt < e0; qt += 16) tileB(qt, std::false_type{});
+        for (int qt = e0; qt < e1; qt += 16) tileB(qt, std::true_type{});
+        for (int qt = e1; qt < N; qt += 16) tileB(qt, std::false_type{});
+      }
 #pragma unroll
       for (int t = 0; t < QT; ++t) {
         float4 vk = make_float4(dk01[t][0], dk01[t][1], dk23[t][0], dk23[t][1]);
@@ -1401,8 +1429,17 @@ void launch_attn_bwd(const float* qkv, const float* o_hm, const float* do_hm, co
     const int hg = HG / split;
     const size_t l2 = attn_bwd_lds(N, hg, Len);
     const int it2 = B * (H / hg);
+    static const bool nt_off = getenv("RAL_ATTNB_NT0") != nullptr;   // experiment knob: run-time window length everywhere
+    const int grid2 = cap(it2, env_grid("RAL_GRID_ATTNB", 8192));
+#define NTCASE(n, tab) { RAL_SET_LDS((k_attn_bwd<2, n, tab>), l2); \
+      k_attn_bwd<2, n, tab><<<grid2, 512 / split, l2, s>>>(qkv, o_hm, do_hm, lse, table, gtable, dqkv, N, H, hg, Len, B); return; }
+    if (!nt_off) {
+      if (N == 32 && !table) NTCASE(32, false)
+      if (N == 64 && table) NTCASE(64, true)
+    }
+#undef NTCASE
     RAL_SET_LDS((k_attn_bwd<2>), l2);
-    k_attn_bwd<2><<<cap(it2, env_grid("RAL_GRID_ATTNB", 8192)), 512 / split, l2, s>>>(qkv, o_hm, do_hm, lse, table, gtable, dqkv, N, H, hg, Len, B);
+    k_attn_bwd<2><<<grid2, 512 / split, l2, s>>>(qkv, o_hm, do_hm, lse, table, gtable, dqkv, N, H, hg, Len, B);
     return;
   }
   const size_t lds = attn_bwd_lds(N, HG, Len);
