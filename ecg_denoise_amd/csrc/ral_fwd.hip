@@ -153,11 +153,15 @@ RAL_STAMPS_DEFINE(ral_debug_stamps_fwd)
 // as s - m <= 0 ready for exp2 with no VALU subtract, no max and no rescale.  If a row's bound is
 // so loose that every term underflows (row sum < 1e-30) the task is redone with the exact
 // running-max recurrence (never seen on real data; forced by tests/test_gpu_configs.py::test_attention_forward_exact_fallback).
-template <int QT>
+// NT > 0: window length as a compile-time constant, TAB = false: no R-wave table (short windows: a task is 2-4 tiles, its
+// set-up and loop control weigh as much as the tiles - see k_attn_bwd)
+template <int QT, int NT = 0, bool TAB = true>
 __global__ __launch_bounds__(512, (QT >= 4 ? 3 : 4)) void k_attn_fwd(const float* __restrict__ qkv, float* __restrict__ o_hm,
                                                   float* __restrict__ lse, const float* __restrict__ table,
-                                                  int N, int H, int HG, int Len, int B) {
+                                                  int N_rt, int H, int HG, int Len, int B) {
   extern __shared__ float4 smem4[];
+  const int N = NT ? NT : N_rt;
+  if constexpr (!TAB) { table = nullptr; Len = 0; }
   float* Qs = reinterpret_cast<float*>(smem4);
   float* Ks = Qs + HG * N * 4;
   float* Vs = Ks + HG * N * 4;
@@ -653,6 +657,12 @@ void launch_attn_fwd(const float* qkv, float* o_hm, float* lse, const float* tab
   if (split > 1) {
     const int hg = HG / split;
     const size_t l2 = attn_fwd_lds(N, hg, Len);
+    static const bool nt_off = getenv("RAL_ATTNF_NT0") != nullptr;   // experiment knob: run-time window length everywhere
+    if (N == 32 && !table && !nt_off) {
+      RAL_SET_LDS((k_attn_fwd<2, 32, false>), l2);
+      k_attn_fwd<2, 32, false><<<grid_for(B * (H / hg)), 512 / split, l2, s>>>(qkv, o_hm, lse, table, N, H, hg, Len, B);
+      return;
+    }
     RAL_SET_LDS((k_attn_fwd<2>), l2);
     k_attn_fwd<2><<<grid_for(B * (H / hg)), 512 / split, l2, s>>>(qkv, o_hm, lse, table, N, H, hg, Len, B);
     return;
