@@ -343,7 +343,7 @@ static void choose_tiling(RalModel* m) {
   // groups but more co-resident workgroups per CU).  Environment overrides are for experiments only.
   const size_t budget = env_size("RAL_MLP_LDS", 78000);
   // split-K workgroups of a fully sliced weight-gradient product per channel width {8,16,32,64,128} (products with
-  // fewer slices get more, up to RAL_DW_MINWG workgroups per launch - see ral_dw.hip for why that is 128)
+  // fewer slices get more, up to RAL_DW_MINWG workgroups per launch - see ral_dw.hip for why that is 192)
   static const int KS_DEFAULT[5] = {128, 128, 128, 64, 32};
   for (int l = 0; l < 5; ++l) m->dw_ksplit[l] = KS_DEFAULT[l];
   if (const char* v = getenv("RAL_DW_KSPLIT")) sscanf(v, "%d,%d,%d,%d,%d", &m->dw_ksplit[0], &m->dw_ksplit[1], &m->dw_ksplit[2], &m->dw_ksplit[3], &m->dw_ksplit[4]);
