@@ -1300,6 +1300,10 @@ __global__ void k_conv1_bwd_dx(const float* __restrict__ dz, const float* __rest
 // set-up once, so fewer, longer-lived workgroups win well before the CUs run out of work.  Measured at batch 2048 (two
 // lanes of 1024 windows), training step with 1024 workgroups everywhere: 18.12 ms; k_qkv_bwd at 256: 17.81; k_resample_bwd
 // at 256: 17.95; k_mlp_bwd at 512: 18.06; all three: 17.45 ms; k_mlp_bwd_s: flat between 384 and 512, slower above.
+// Re-measured once k_qkv_bwd prefetched its operands and the weight-gradient launches had grown to 192 workgroups (same
+// box, ms per step): k_qkv_bwd at 128: 17.22, 160: 17.13, 192: 17.12, 224: 17.84 (1024 windows over 224 workgroups leave
+// a ragged last round), 256: 17.29 - the CUs it leaves free go to the weight-gradient kernels running beside it; then
+// k_mlp_bwd_s at 256: 17.11, 320: 17.08, 384: 16.99, 448: 17.02, 512: 17.04.
 // (RAL_GRID_QKVB / RESB / MLPB / MLPS / ATTNB override.)
 static inline int env_grid(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 static inline int cap(int items, int gmax) { return items < gmax ? items : gmax; }
@@ -1348,7 +1352,7 @@ static bool launch_mlp_bwd_s(const float* dx2, const float* x1, const BlockP& w,
   // no longer negligible on the critical stream, so the gain flattens)
   int tw; size_t lds;
   if (!mlp_bwd_s_applies<C>(N, &tw, &lds)) return false;
-  static const int gs = env_grid("RAL_GRID_MLPS", 512);
+  static const int gs = env_grid("RAL_GRID_MLPS", 384);
   const int grid = cap(B, gs);
 #define GO(t) { RAL_SET_LDS((k_mlp_bwd_s<C, t>), lds); k_mlp_bwd_s<C, t><<<grid, 512, lds, s>>>(dx2, x1, w, wt, gr, dx1, do_hm, N, B, want_dw ? 1 : 0); return true; }
   switch (tw) { case 1: GO(1) case 2: GO(2) case 4: GO(4) case 8: GO(8) default: return false; }
@@ -1460,7 +1464,7 @@ size_t qkv_bwd_lds(int C, int N) { return ((size_t)N * 3 * C + (size_t)N * ld_of
 void launch_qkv_bwd(int C, const float* dqkv, const float* x, const float* pe, const float* dx1, const float* extra,
                     const BlockP& w, const BlockP& wt, const BlockP& gr, float* dx, int N, int B, hipStream_t s) {
   const size_t lds = qkv_bwd_lds(C, N);
-  static const int gq = env_grid("RAL_GRID_QKVB", 256);
+  static const int gq = env_grid("RAL_GRID_QKVB", 192);
   const int grid = cap(B, gq);
   switch (C) {
 #define CASE(c) case c: RAL_SET_LDS((k_qkv_bwd<c>), lds); \

@@ -36,7 +36,7 @@ constexpr int dw_tile_floats(int w, bool hm, int tc) { return hm ? (w / 4) * (tc
 #endif
 // Workgroups of a weight-gradient launch.  These kernels run on side streams UNDER the data-gradient chain, and every
 // workgroup ends with its slice's worth of global atomics: measured at batch 2048, launches of >= 256 workgroups give the
-// fastest weight-gradient kernels on an empty GPU (3.65 ms per step serialised, against 5.0 ms with 128) but the slower
+// fastest weight-gradient kernels on an empty GPU (3.65 ms per step serialised, 3.74 with 192, 5.0 with 128) but the slower
 // training step - they take the CUs and the atomic throughput the chain needs.  Training step by this constant (same
 // box, ms): 96: 17.48, 128: 17.37, 160: 17.23, 192: 17.21, 224: 17.31, 256: 17.63.  (Before the chain kernels of
 // the narrow levels got faster the optimum was 128.)
