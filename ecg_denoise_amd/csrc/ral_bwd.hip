@@ -446,8 +446,11 @@ RAL_DEV f32x2 splat2(float v) { return f32x2{v, v}; }
 // NT > 0: the window length as a compile-time constant (short windows: a task's sweep is 2-4 iterations, so its set-up,
 // loop control and epilogue weigh as much as its tiles; with N known they unroll and their index arithmetic folds);
 // TAB = false: no R-wave table (its bounds and branches fold away).
+#ifndef RAL_ATTNB_WPE
+#define RAL_ATTNB_WPE 4   // waves per SIMD the register budget is sized for (3 = 168 registers, no spills: N = 128 257 vs 250 us, equal elsewhere)
+#endif
 template <int QT, int NT = 0, bool TAB = true>
-__global__ __launch_bounds__(512, 4) void k_attn_bwd(const float* __restrict__ qkv, const float* __restrict__ o_hm,
+__global__ __launch_bounds__(512, RAL_ATTNB_WPE) void k_attn_bwd(const float* __restrict__ qkv, const float* __restrict__ o_hm,
                                                   const float* __restrict__ do_hm, const float* __restrict__ lse,
                                                   const float* __restrict__ table, float* __restrict__ gtable,
                                                   float* __restrict__ dqkv, int N_rt, int H, int HG, int Len, int B) {
