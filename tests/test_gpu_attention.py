@@ -1,0 +1,86 @@
+"""The attention operator on its own (ral_attention_forward / ral_attention_backward through the C-ABI) against an fp64
+torch autograd restatement of `softmax(q k^T + R-wave bias) v` (raletransformer.py:299-316; bias table :534-558), one case
+per kernel variant the launcher can pick:
+  * N = 512 / 256 / 128 with a table: the generic MFMA-tile kernels (k_attn_fwd<2> / k_attn_fwd_v, k_attn_bwd<2, 0, true>)
+  * N = 64 with a table and N = 32 without: the compile-time-window-length instantiations
+  * N = 128 / 64 without a table: the scalar-path backward sweeps (k_attn_bwd_vq / _vkv)
+  * N = 48 (L = 768 windows): QT = 1, no workgroup split
+Batches that are not a multiple of anything (5, 3) and B = 700 (persistent workgroups take several items)."""
+import ctypes as C
+
+import pytest
+import torch
+
+from ecg_denoise_amd import _lib
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _vp(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _bias_full(table, Len, N):
+    H = table.shape[1]
+    b = torch.zeros(H, N, N, dtype=table.dtype)
+    off = (N - Len) // 2
+    i = torch.arange(Len)
+    idx = i[:, None] - i[None, :] + Len - 1
+    b[:, off:off + Len, off:off + Len] = table[idx].permute(2, 0, 1)
+    return b
+
+
+def _case(N, H, Len, B, seed):
+    g = torch.Generator().manual_seed(seed)
+    qkv = torch.randn(B, 3 * H, N, 4, generator=g)
+    qkv[:, :H] *= 0.5
+    table = 0.5 * torch.randn(2 * Len - 1, H, generator=g) if Len else None
+    do = torch.randn(B, H, N, 4, generator=g)
+    q, k, v = (t.double().requires_grad_(True) for t in (qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]))
+    tb = table.double().requires_grad_(True) if Len else None
+    s = q @ k.transpose(-1, -2)
+    if Len:
+        s = s + _bias_full(tb, Len, N)[None]
+    o_ref = torch.softmax(s, -1) @ v
+    lse_ref = torch.logsumexp(s, -1)
+    gr = torch.autograd.grad((o_ref * do.double()).sum(), [q, k, v] + ([tb] if Len else []))
+    qd, dod = qkv.to(DEV), do.to(DEV)
+    td = table.to(DEV) if Len else None
+    o = torch.empty(B, H, N, 4, device=DEV)
+    lse = torch.empty(B, H, N, device=DEV)
+    dqkv = torch.full_like(qd, float("nan"))           # every element must be written
+    gt = torch.zeros_like(td) if Len else None
+    L = _lib.lib()
+    _lib.check(L.ral_attention_forward(_vp(qd), _vp(o), _vp(lse), _vp(td), N, H, Len, B, _stream()))
+    _lib.check(L.ral_attention_backward(_vp(qd), _vp(o), _vp(dod), _vp(lse), _vp(td), _vp(gt), _vp(dqkv), N, H, Len, B, _stream()))
+    torch.cuda.synchronize()
+    rel = lambda a, b: ((a.double().cpu() - b).norm() / b.norm()).item()
+    errs = {"o": rel(o, o_ref.detach()), "lse": rel(lse, lse_ref.detach()),
+            "dq": rel(dqkv[:, :H], 0.5 * gr[0]),       # q = 0.5 (h Wq^T + b): the operator's dq carries the 0.5
+            "dk": rel(dqkv[:, H:2 * H], gr[1]), "dv": rel(dqkv[:, 2 * H:], gr[2])}
+    if Len:
+        errs["dtable"] = rel(gt, gr[3])
+    return errs
+
+
+@pytest.mark.parametrize("N,H,Len,B", [
+    (512, 2, 32, 3), (256, 4, 16, 5), (128, 8, 8, 5), (64, 16, 4, 5), (32, 32, 0, 5),   # the five levels of a 512-sample window
+    (128, 8, 0, 3), (64, 16, 0, 5),                                                      # the same lengths without a table
+    (48, 8, 8, 3), (1024, 2, 64, 1),                                                     # L = 768 and L = 1024 top levels
+])
+def test_attention_operator_against_fp64(N, H, Len, B):
+    errs = _case(N, H, Len, B, seed=N + Len)
+    assert all(e == e and e < 2e-5 for e in errs.values()), errs    # fp32 tolerance; NaN = an element left unwritten
+
+
+@pytest.mark.parametrize("N,H,Len", [(64, 16, 4), (32, 32, 0)])
+def test_attention_operator_many_windows(N, H, Len):
+    """More windows than workgroup slots at the short levels: workgroups loop over several items, the R-wave table gradient
+    is accumulated across all of them."""
+    errs = _case(N, H, Len, 700, seed=7)
+    assert all(e == e and e < 2e-5 for e in errs.values()), errs
