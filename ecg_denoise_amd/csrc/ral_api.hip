@@ -192,6 +192,22 @@ static void fill_pe(float* P, int n, int C) {
 // ---------------------------------------------------------------------------------
 struct BlockAct { float *in, *qkv, *o, *lse, *x1, *upre, *out; };
 
+// Sets of per-block backward temporaries (dx1, do, dqkv, du_pre, ...): block i of a lane's chain may start once the
+// weight-gradient kernels of block i - dw_sets() have finished with theirs.  At the wide levels a block's four
+// weight-gradient launches take about as long as its chain, so with two sets the chain waits for them; with more it runs
+// ahead and the side stream catches up under the narrow levels, whose weight gradients are fused into the chain kernels.
+// Measured at batch 2048 (ms per step): 2 sets 17.09, 3: 17.08, 4: 17.04, 6: 17.00, 8: 16.99; a set is 9.6 E floats
+// (0.32 GB at batch 2048).  RAL_DW_SETS overrides (2 .. MAX_SETS).
+#define MAX_SETS 8
+static int dw_sets() {
+  static const int n = [] {
+    const char* v = getenv("RAL_DW_SETS");
+    int k = v ? atoi(v) : 6;
+    return k < 2 ? 2 : (k > MAX_SETS ? MAX_SETS : k);
+  }();
+  return n;
+}
+
 struct RalModel {
   ral_config cfg;
   Layout lay;
@@ -212,7 +228,7 @@ struct RalModel {
   // every gradient tensor has its own buffer (no ping-pong): the weight-gradient kernels run on a side
   // stream and read them long after the data-gradient chain has moved on
   float *gy[18], *gin[9], *du0, *dz0;
-  float *dx1[2], *dohm[2], *dqkv[2], *dupre[2], *a2c0[2], *astat[2];   // per-block temporaries, two sets (side-stream overlap)
+  float *dx1[MAX_SETS], *dohm[MAX_SETS], *dqkv[MAX_SETS], *dupre[MAX_SETS], *a2c0[MAX_SETS], *astat[MAX_SETS];   // per-block temporaries, dw_sets() sets (side-stream overlap)
   void* lanes = nullptr;   // LaneSet
   int n_lanes = 2;
   bool side_stream = true;
@@ -309,7 +325,7 @@ static size_t plan_workspace(const ral_config& c, RalModel* m /* may be null: si
     for (int i = 0; i < 9; ++i) M.gin[i] = take(("gin" + std::to_string(i)).c_str(), E);
     M.gy[9] = M.gin[5];   // x_mid = transformer(x4) + x4: the stage-4 output gradient IS g x_mid
     M.du0 = take("du0", E);
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < dw_sets(); ++k) {
       M.dx1[k] = take(("dx1_" + std::to_string(k)).c_str(), E); M.dohm[k] = take(("do_" + std::to_string(k)).c_str(), E);
       M.dqkv[k] = take(("dqkv_" + std::to_string(k)).c_str(), 3 * E); M.dupre[k] = take(("dupre_" + std::to_string(k)).c_str(), 4 * E);
       M.a2c0[k] = take(("a2c0_" + std::to_string(k)).c_str(), E / 8);
@@ -380,9 +396,9 @@ static BlockP block_ptrs(const BlockOff& o, float* base) {
 struct Lane {
   int w0 = 0, B = 0;
   hipStream_t s = nullptr, s2 = nullptr;     // chain stream, weight-gradient side stream
-  hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}, ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_ready[MAX_SETS] = {}, ev_done[MAX_SETS] = {}, ev_fork = nullptr, ev_join = nullptr;
   hipEvent_t ev_dec_main = nullptr, ev_dec_side = nullptr;   // decoder half of the gradients complete (this lane)
-  bool dw_pending[2] = {false, false};
+  bool dw_pending[MAX_SETS] = {};
   int bwd_count = 0;
 };
 #define MAX_LANES 4
@@ -443,7 +459,8 @@ static int plan_lanes(RalModel* m, int B, hipStream_t s) {
     Lane& ln = L->l[i];
     ln.w0 = i * (B / n); ln.B = B / n;
     ln.s = i == 0 ? s : L->own[i];
-    ln.bwd_count = 0; ln.dw_pending[0] = ln.dw_pending[1] = false;
+    ln.bwd_count = 0;
+    for (int k = 0; k < MAX_SETS; ++k) ln.dw_pending[k] = false;
   }
   L->n = n;
   return n;
@@ -547,7 +564,7 @@ static void run_block_bwd(RalModel* m, int bi, const float* dy, const float* ext
   }
   const int w0 = ln.w0, B = ln.B;
   hipStream_t s = ln.s;
-  const int k = ln.bwd_count++ & 1;                    // temporary set of this block
+  const int k = ln.bwd_count++ % dw_sets();            // temporary set of this block
   const bool side = m->side_stream && m->want_dw;
   hipStream_t sd = side ? ln.s2 : s;                   // stream of the weight-gradient kernels
   if (side && ln.dw_pending[k]) (void)hipStreamWaitEvent(s, ln.ev_done[k], 0);   // set k free again?
@@ -761,9 +778,12 @@ static void destroy_model(RalModel* m) {
       Lane& ln = LS->l[i];
       if (LS->own[i]) (void)hipStreamDestroy(LS->own[i]);
       if (ln.s2) (void)hipStreamDestroy(ln.s2);
-      hipEvent_t evs[8] = {ln.ev_ready[0], ln.ev_ready[1], ln.ev_done[0], ln.ev_done[1], ln.ev_fork, ln.ev_join,
-                           ln.ev_dec_main, ln.ev_dec_side};
+      hipEvent_t evs[4] = {ln.ev_fork, ln.ev_join, ln.ev_dec_main, ln.ev_dec_side};
       for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
+      for (int k = 0; k < MAX_SETS; ++k) {
+        if (ln.ev_ready[k]) (void)hipEventDestroy(ln.ev_ready[k]);
+        if (ln.ev_done[k]) (void)hipEventDestroy(ln.ev_done[k]);
+      }
     }
     delete LS;
   }
@@ -834,7 +854,7 @@ int ral_create(const ral_config* cfg, ral_handle** out) {
       if (i > 0) ok(hipStreamCreateWithFlags(&LS->own[i], hipStreamNonBlocking));
       if (low) ok(hipStreamCreateWithPriority(&ln.s2, hipStreamNonBlocking, pmode == 2 ? prio_greatest : prio_least));
       else ok(hipStreamCreateWithFlags(&ln.s2, hipStreamNonBlocking));
-      for (int k = 0; k < 2; ++k) {
+      for (int k = 0; k < MAX_SETS; ++k) {
         ok(hipEventCreateWithFlags(&ln.ev_ready[k], hipEventDisableTiming));
         ok(hipEventCreateWithFlags(&ln.ev_done[k], hipEventDisableTiming));
       }
