@@ -60,4 +60,7 @@ for tag, key in (("unet", "fused"), ("unet_staged", "staged")):
     pick = (lambda n: "k_unet_infer" in n or "k_unet_pack" in n) if key == "fused" else (lambda n: "k_unet_fwd_t" in n or n.startswith("k_unet_out"))
     out[key] = {n: {"fetch_bytes": int(f[n]), "write_bytes": int(w.get(n, 0))} for n in sorted(f) if pick(n)}
 json.dump(out, open(os.path.join(DST, f"{R}_unet_hbm_traffic.json"), "w"), indent=1)
+# one default-schedule step as a timeline: who is the critical path (lane chains or weight-gradient side streams)
+with open(os.path.join(DST, f"{R}_step_timeline.txt"), "w") as fo:
+    subprocess.check_call([py, os.path.join(ROOT, "tools", "diag", "step_timeline.py"), os.path.join(SRC, "ks_default")], stdout=fo)
 print("written:", sorted(os.path.basename(p) for p in glob.glob(os.path.join(DST, f"{R}_*"))))
