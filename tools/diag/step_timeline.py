@@ -1,8 +1,8 @@
 """Timeline of one training step in the DEFAULT schedule from a rocprofv3 kernel trace (tools/collect_profiles.sh writes
 gpurun_out/<round>/ks_default/*/*_kernel_trace.csv): per hardware queue (two lane chains + two weight-gradient side
 streams) the kernel count, first start, last end and summed kernel time; how long 0 / 1 / 2 / 3 / 4 kernels were in flight;
-and when the side streams finish relative to the chains (a tail there would mean the weight-gradient kernels are the
-critical path).
+when the side streams finish relative to the chains (a tail there would mean the weight-gradient kernels are the
+critical path), and the gaps between consecutive kernels of a queue.
 
     python tools/diag/step_timeline.py gpurun_out/r02/ks_default [step_index]
 """
@@ -36,6 +36,15 @@ def main():
         role = "weight-gradient side stream" if len(dw) > len(rs) // 2 else "lane chain"
         print(f"queue {q} ({role}): {len(rs):3d} kernels, first start {ms(rs[0]['s']):7.3f}, last end "
               f"{ms(max(r['e'] for r in rs)):7.3f}, summed kernel time {busy:7.3f} ms; last kernel {rs[-1]['n'][:44]}")
+    # gaps between consecutive kernels of one queue.  rocprofv3 makes back-to-back kernels of a queue abut (no gap), so what
+    # shows up here are the long ones: a kernel whose first wave had to wait - for an event of another stream, or (the
+    # common case at the wide levels) for LDS / registers that the other lane's workgroups still hold
+    for q, rs in sorted(queues.items()):
+        rs = sorted(rs, key=lambda r: r["s"])
+        gaps = sorted((b["s"] - a["e"]) / 1e3 for a, b in zip(rs, rs[1:]) if b["s"] > a["e"])
+        if gaps:
+            print(f"queue {q}: {len(gaps)} gaps between consecutive kernels, {sum(gaps) / 1e3:.3f} ms in all, median "
+                  f"{gaps[len(gaps) // 2]:.1f} us, {sum(1 for g in gaps if g > 20)} longer than 20 us (waits for another stream's event or for CU resources)")
     pts = sorted([(r["s"], 1) for r in step] + [(r["e"], -1) for r in step])
     c, k, last = Counter(), 0, pts[0][0]
     for t, dlt in pts:
