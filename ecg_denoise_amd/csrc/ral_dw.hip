@@ -43,6 +43,8 @@ constexpr int dw_tile_floats(int w, bool hm, int tc) { return hm ? (w / 4) * (tc
 #ifndef RAL_DW_MINWG
 #define RAL_DW_MINWG 192
 #endif
+// (LDS of a workgroup's two staging buffers; smaller chunks co-reside more easily with the chain kernels' workgroups but
+// were measured slower on the step: RAL_DW_LDS = 40 000: 17.74 ms, 24 000: 18.01 ms against 17.04 at the full 76 KB)
 #ifndef RAL_DW_LDS_BYTES
 #define RAL_DW_LDS_BYTES (76 * 1024)
 #endif
