@@ -1,21 +1,26 @@
 """Headline benchmark: RA-LENet training-step throughput (ECG windows/s) on MI355X.
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W] [--config ralenet|unet|newrale]
 
 N > 1 runs one process per GPU over RCCL: either the caller starts the ranks (`python -m torch.distributed.run
 --nproc-per-node N ... bench.py --gpus N`: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment), or
 bench.py starts them itself when WORLD_SIZE is not set (child processes, never exec; rank 0's JSON line is relayed).
 
-One "step" = zero_grad -> forward -> mse/SNR/RMSE -> backward -> (all-reduce) -> Adam on one batch of
-synthetic 512-sample windows already resident in HBM.  Prints ONE JSON line (rank 0).
+One "step" = zero_grad -> forward -> mse/SNR/RMSE -> backward -> (all-reduce) -> Adam on one batch of synthetic windows
+already resident in HBM.  Prints ONE JSON line (rank 0).  Workloads (`--config`):
+  ralenet (default)  BASELINE config 2 / 3: RA-LENet "full", 1 lead x 512 samples, 2048 windows per GPU
+  unet               the conv U-Net of the same path (UNet.py), 2 leads x 512 samples, 2048 windows per GPU
+  newrale            BASELINE config 4: 12 leads x 1024 samples through the transfer-learning adapter, 256 windows per GPU
 """
 import argparse
 import ctypes as C
 import json
 import os
+import signal
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -26,17 +31,20 @@ BLOCKS_PER_LEVEL = [2, 4, 4, 4, 4]
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3     # fp32-input MFMA peak (the dtype every contraction here runs in)
 VALU_F32_PEAK_TF = 157.3
+KINDS = ("qkv_fwd", "attn_fwd", "mlp_fwd", "resample_fwd", "mlp_bwd", "attn_bwd", "qkv_bwd", "dw", "resample_bwd")
 
 
-def kind_work(kind, L, B):
-    """Algorithmic FLOPs of all launches of one kernel kind in a train step."""
+def kind_work(kind, L, B, executed=False):
+    """Algorithmic FLOPs of all launches of one kernel kind in a train step.  Attention backward:
+    SURVEY 8d's count is 2 x forward = 8 N^2 C per block (dV, dP, dK, dQ); the kernel also re-computes S (nothing N x N is
+    stored), which `executed=True` adds (10 N^2 C) - a design cost, not work the reference asks for."""
     fl = 0.0
     for lvl, nb in enumerate(BLOCKS_PER_LEVEL):
         N, Cc = L >> lvl, CH[lvl]
         if kind == "attn_fwd":
             fl += nb * 4.0 * N * N * Cc * B                 # QK^T + PV, mul+add
         elif kind == "attn_bwd":
-            fl += nb * 2.5 * 4.0 * N * N * Cc * B           # S, dP, dV, dK, dQ: 5 products (S, dP counted once)
+            fl += nb * (10.0 if executed else 8.0) * N * N * Cc * B
         elif kind == "mlp_fwd":
             fl += nb * 2.0 * N * Cc * Cc * 9 * B            # proj C*C + fc1 4C*C + fc2 4C*C
         elif kind == "mlp_bwd":
@@ -48,24 +56,46 @@ def kind_work(kind, L, B):
     return fl
 
 
-def measured_traffic(kind):
-    """HBM bytes per launch of this kernel kind from the committed PMC run (profiles/r02_hbm_traffic.json)."""
+def _profile_json(name):
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")))
-        return d["per_launch_bytes"][kind]["total"]
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
     except Exception:
         return None
 
 
+def measured_traffic(kind):
+    """HBM bytes per launch of this kernel kind from the committed PMC run (newest profiles/rNN_hbm_traffic.json)."""
+    for name in ("r03_hbm_traffic.json", "r02_hbm_traffic.json"):
+        d = _profile_json(name)
+        if d and kind in d.get("per_launch_bytes", {}):
+            return d["per_launch_bytes"][kind]["total"]
+    return None
+
+
+def unet_fused_traffic():
+    """(bytes per launch of the fused U-Net inference kernel at batch 2048 from the committed PMC run, file name)"""
+    for name in ("r03_unet_hbm_traffic.json", "r02_unet_hbm_traffic.json"):
+        d = _profile_json(name)
+        if d:
+            f = d.get("fused", {})
+            tot = sum(v["fetch_bytes"] + v["write_bytes"] for v in f.values())
+            if tot:
+                return tot, name
+    return None, None
+
+
 def conv_stage_roofline(dev, L, B=2048):
     """The HBM-bound conv stages of the path (north star: fraction of the HBM roofline on the U-Net stages at batch
-    2048 x 512): U-Net eval forward, 2 leads, at the STATED batch.  Byte convention = SURVEY 8d's stage-granular count:
-    every conv reads its input tensor and writes its output tensor once (11 x 2), the three decoder skips and the
-    bottleneck residual are re-read (+ 4): 26 tensors of leads * L floats per window.  Two figures:
-      `achieved` / `frac`: the product path - the whole forward fused into ONE kernel (all stage tensors stay in LDS), timed
-        as hipGraph replays; its stage-granular-equivalent rate, with the HBM bytes it really moves next to it;
-      `staged`: the stage-by-stage path (11 conv launches + the output BatchNorm pass: what training runs) at the same
-        batch, 27 tensors with that extra pass, where every stage tensor does make the HBM round trip."""
+    2048 x 512): U-Net eval forward, 2 leads, at the STATED batch.
+      `achieved` / `frac` (top level) = the STAGED path, where every stage tensor really makes its HBM round trip: 11 conv
+        launches + the output BatchNorm pass, SURVEY 8d's stage-granular count (every conv reads its input and writes its
+        output once, the three decoder skips and the bottleneck residual are re-read: 26 tensors, + 1 for the extra pass)
+        over the measured time.  This is the figure that is comparable with the 8 TB/s peak.
+      `fused`: the product path for inference - the whole forward in ONE kernel, stage tensors in LDS.  It is NOT an
+        HBM-bound kernel, so it carries no fraction of the HBM peak: its HBM rate uses the bytes it really moves (PMC
+        FETCH + WRITE of the committed profile, scaled by batch), its bound is the fp32 MFMA / latency (`mfma_frac` =
+        0.76 MFLOP per window over the time against 157.3 TF/s); `stage_equivalent_GBps` (26 tensors per window over the
+        time) is kept only as the speed-up over a staged implementation."""
     import torch
     from ecg_denoise_amd import UNet, _lib
     leads = 2
@@ -94,25 +124,33 @@ def conv_stage_roofline(dev, L, B=2048):
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e-3 / n
     out = {"bound": "hbm", "batch": B, "unit": "GB/s", "peak": HBM_PEAK_GBS}
-    _lib.check(_lib.lib().ral_set_option(m.eng.h, b"unet_fused", 1))
-    dt = graph_time()
-    out.update({"kernel": "U-Net eval forward fused into one kernel (k_unet_pack + k_unet_infer), hipGraph replay",
-                "achieved": round(B * 26 * w / dt / 1e9, 1), "frac": round(B * 26 * w / dt / 1e9 / HBM_PEAK_GBS, 4),
-                "tensors_per_window": 26, "us_per_forward": round(dt * 1e6, 1), "windows_per_s": round(B / dt, 1),
-                "hbm_bytes_moved_per_window": 2 * w, "hbm_GBps_moved": round(B * 2 * w / dt / 1e9, 1)})
     _lib.check(_lib.lib().ral_set_option(m.eng.h, b"unet_fused", 0))
     dt = graph_time()
-    out["staged"] = {"kernel": "stage by stage: 11 conv launches + output BatchNorm pass, hipGraph replay",
-                     "achieved": round(B * 27 * w / dt / 1e9, 1), "frac": round(B * 27 * w / dt / 1e9 / HBM_PEAK_GBS, 4),
-                     "tensors_per_window": 27, "us_per_forward": round(dt * 1e6, 1), "windows_per_s": round(B / dt, 1)}
+    out.update({"kernel": "U-Net eval forward stage by stage: 11 conv launches + output BatchNorm pass, hipGraph replay",
+                "achieved": round(B * 27 * w / dt / 1e9, 1), "frac": round(B * 27 * w / dt / 1e9 / HBM_PEAK_GBS, 4),
+                "tensors_per_window": 27, "us_per_forward": round(dt * 1e6, 1), "windows_per_s": round(B / dt, 1)})
+    _lib.check(_lib.lib().ral_set_option(m.eng.h, b"unet_fused", 1))
+    dt = graph_time()
+    moved, src = unet_fused_traffic()       # bytes per launch at batch 2048 (PMC), or None
+    moved_pw = moved / 2048.0 if moved else None
+    flop_pw = 0.76e6 * (L / 512.0)
+    out["fused"] = {"kernel": "whole forward in one kernel (k_unet_pack + k_unet_infer), hipGraph replay",
+                    "bound": "mfma/latency", "us_per_forward": round(dt * 1e6, 1), "windows_per_s": round(B / dt, 1),
+                    "mfma_TFLOPs": round(B * flop_pw / dt / 1e12, 2), "mfma_frac": round(B * flop_pw / dt / 1e12 / MFMA_F32_PEAK_TF, 4),
+                    "hbm_bytes_moved_per_window": round(moved_pw) if moved_pw else None, "hbm_bytes_source": src,
+                    "hbm_GBps_moved": round(B * moved_pw / dt / 1e9, 1) if moved_pw else None,
+                    "stage_equivalent_GBps": round(B * 26 * w / dt / 1e9, 1)}
     del m, x
     torch.cuda.empty_cache()
     return out
 
 
-def cpu_baseline(leads, L, variant):
-    """The oracle (CPU restatement of the reference op graph, parity-pinned by tests/golden) timed on the
-    host cores of this box on a bounded sample: batch 32 (the reference's own batch, BASELINE config 0)."""
+def cpu_baseline(leads, L, variant, big_batch=256):
+    """The oracle (CPU restatement of the reference op graph, parity-pinned by tests/golden) timed on the host cores of
+    this box on bounded samples: batch 32 (the reference's own batch, BASELINE config 0) is `value`; `large_batch` is the
+    same op graph at a batch that amortises the per-call overhead (SURVEY 8d asks for the bench batch 2048: one such
+    step materialises ~50 GB of attention probabilities and takes ~25 s, so the default run times batch 256 and
+    tools/cpu_baseline_big.py records the 2048 figure in profiles/)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from collections import OrderedDict
     import torch
@@ -121,29 +159,42 @@ def cpu_baseline(leads, L, variant):
     # tools/diag/cpu_threads.py: 1 thread 40, 2: 60, 4: 74, 8: 84, 16: 78, 32: 56, 64: 26 windows/s) - the op graph is
     # ~21k small ATen calls per step, and past 8 threads the fork/join cost of each call exceeds its work
     cores = min(os.cpu_count() or 1, 8)
-    torch.set_num_threads(cores)
+
+    def run(B, threads, budget, max_steps):
+        torch.set_num_threads(threads)
+        p = O.init_params(O.ralenet_param_shapes(variant, leads), 1)
+        g = torch.Generator().manual_seed(2023)
+        x = torch.randn(B, leads, L, generator=g); tgt = torch.randn(B, leads, L, generator=g)
+        m = OrderedDict((k, torch.zeros_like(v)) for k, v in p.items())
+        v = OrderedDict((k, torch.zeros_like(t)) for k, t in p.items())
+        bn = O.new_bn_state()
+        fwd = lambda pp, xx: O.ralenet_forward(pp, xx, variant, True, bn)
+        O.train_step(p, x, tgt, fwd, m, v, 1)
+        n, t0 = 0, time.time()
+        while time.time() - t0 < budget and n < max_steps:
+            O.train_step(p, x, tgt, fwd, m, v, n + 2)
+            n += 1
+        return n, time.time() - t0
     B = 32
-    p = O.init_params(O.ralenet_param_shapes(variant, leads), 1)
-    g = torch.Generator().manual_seed(2023)
-    x = torch.randn(B, leads, L, generator=g); tgt = torch.randn(B, leads, L, generator=g)
-    m = OrderedDict((k, torch.zeros_like(v)) for k, v in p.items())
-    v = OrderedDict((k, torch.zeros_like(t)) for k, t in p.items())
-    bn = O.new_bn_state()
-    fwd = lambda pp, xx: O.ralenet_forward(pp, xx, variant, True, bn)
-    O.train_step(p, x, tgt, fwd, m, v, 1)
-    n, t0 = 0, time.time()
-    while time.time() - t0 < 10.0 and n < 40:
-        O.train_step(p, x, tgt, fwd, m, v, n + 2)
-        n += 1
-    dt = time.time() - t0
-    return {"value": round(B * n / dt, 2), "unit": "windows/s", "cores": cores, "kind": "port",
-            "sample": f"{n} train steps of the CPU oracle at batch {B} x {leads} x {L} fp32 "
-                      f"(torch-CPU op graph of the reference, {cores} threads)"}
+    n, dt = run(B, cores, 10.0, 40)
+    res = {"value": round(B * n / dt, 2), "unit": "windows/s", "cores": cores, "kind": "port",
+           "sample": f"{n} train steps of the CPU oracle at batch {B} x {leads} x {L} fp32 "
+                     f"(torch-CPU op graph of the reference, {cores} threads)"}
+    if big_batch:
+        th = min(os.cpu_count() or 1, 32)      # large tensors: more threads pay (the per-call fork/join is amortised)
+        try:
+            n2, dt2 = run(big_batch, th, 8.0, 3)
+            res["large_batch"] = {"value": round(big_batch * n2 / dt2, 2), "batch": big_batch, "cores": th,
+                                  "sample": f"{n2} train steps at batch {big_batch} x {leads} x {L}"}
+        except Exception as exc:
+            res["large_batch"] = {"error": str(exc)[:200]}
+    return res
 
 
 def self_launch(n, argv):
     """Start the n ranks of a single-node job as CHILD processes of this one (which has not touched the GPU and never
-    will), wait for all of them, relay rank 0's stdout.  Returns the exit code: non-zero if any rank failed."""
+    will), relay rank 0's stdout.  All children are polled: the first rank that exits non-zero (or a SIGTERM / Ctrl-C to
+    this process) terminates the others, so a failed or deadlocked job ends instead of hanging.  Returns the exit code."""
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -154,11 +205,37 @@ def self_launch(n, argv):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
-    out, _ = procs[0].communicate()
-    codes = [p.wait() for p in procs]
-    sys.stdout.write(out)
+    out = []
+    reader = threading.Thread(target=lambda: out.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+
+    def stop_all(*_):
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+    old = signal.signal(signal.SIGTERM, lambda *_: (stop_all(), sys.exit(143)))
+    bad = []
+    try:
+        while any(p.poll() is None for p in procs):
+            bad = [(r, p.returncode) for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+            if bad:
+                stop_all()
+                break
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        stop_all()
+        raise
+    finally:
+        signal.signal(signal.SIGTERM, old)
+    for p in procs:
+        try:
+            p.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    reader.join(timeout=10)
+    sys.stdout.write("".join(o or "" for o in out))
     sys.stdout.flush()
-    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    bad = bad or [(r, p.returncode) for r, p in enumerate(procs) if p.returncode != 0]
     if bad:
         print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
         return 1
@@ -178,8 +255,10 @@ def launcher_dry_run(a):
     if world > 1:
         dist.all_reduce(t)
         dist.barrier()
-    if os.environ.get("RAL_BENCH_FAIL_RANK") == str(rank):      # (test hook: a failing rank must fail the launcher)
+    if a.test_fail_rank == rank:          # a failing rank must fail the launcher
         sys.exit(3)
+    if a.test_hang_rank == rank:          # a rank that never finishes: the launcher must end it when another one fails
+        time.sleep(3600)
     if rank == 0:
         print(json.dumps({"dry_run": True, "n_gpus": world, "local_rank": int(os.environ.get("LOCAL_RANK", "0")),
                           "rank_sum": t.item(), "steps": a.steps, "warmup": a.warmup}))
@@ -187,20 +266,56 @@ def launcher_dry_run(a):
         dist.destroy_process_group()
 
 
+def build_workload(a, dev, rank):
+    """-> dict(model, inner (the RA-LENet handle kernels are profiled on, or None), trainer, x, tgt, B, leads, L, text)"""
+    import torch
+    from ecg_denoise_amd import NewRALE, RALENet, UNet
+    from ecg_denoise_amd.dp import DataParallelTrainer, HipEngineAdapter, NewRALEEngineAdapter, UNetEngineAdapter
+    g = torch.Generator().manual_seed(2023 + rank)
+    if a.config == "newrale":
+        B, leads, L = a.batch or 256, 12, a.L or 1024
+        inner = RALENet(a.variant, leads=2, L=L, max_batch=B, train=True, device=dev, seed=2023)
+        model = NewRALE(inner, seed=2024)
+        eng = NewRALEEngineAdapter(model)
+        text = (f"newrale (12-lead adapter around a frozen RA-LENet '{a.variant}', ralenet_12leads.py:680-709) train step, "
+                f"12-lead {L}-sample windows, batch {B}/GPU")
+    elif a.config == "unet":
+        B, leads, L = a.batch or 2048, a.leads or 2, a.L or 512
+        model = inner_none = UNet(leads=leads, L=L, max_batch=B, train=True, device=dev, seed=2023)
+        inner, eng = None, UNetEngineAdapter(model)
+        text = f"U-Net (UNet.py:96-141) train step, {leads}-lead {L}-sample windows, batch {B}/GPU"
+    else:
+        B, leads, L = a.batch or 2048, a.leads or 1, a.L or 512
+        model = inner = RALENet(a.variant, leads=leads, L=L, max_batch=B, train=True, device=dev, seed=2023)
+        eng = HipEngineAdapter(model)
+        text = f"RA-LENet '{a.variant}' train step, {leads}-lead {L}-sample windows, batch {B}/GPU"
+    x = torch.randn(B, leads, L, generator=g).to(dev)
+    tgt = torch.randn(B, leads, L, generator=g).to(dev)
+    model.train()
+    return {"model": model, "inner": inner, "trainer": DataParallelTrainer(eng), "x": x, "tgt": tgt, "B": B, "leads": leads,
+            "L": L, "text": text + " (fwd+mse/SNR/RMSE+bwd+Adam), N(0,1) inputs seed 2023, random-init weights"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=2048, help="windows per GPU")
-    ap.add_argument("--leads", type=int, default=1)
-    ap.add_argument("--L", type=int, default=512)
+    ap.add_argument("--config", default="ralenet", choices=("ralenet", "unet", "newrale"))
+    ap.add_argument("--batch", type=int, default=0, help="windows per GPU (default: the config's stated batch)")
+    ap.add_argument("--leads", type=int, default=0)
+    ap.add_argument("--L", type=int, default=0)
     ap.add_argument("--variant", default="full")
     ap.add_argument("--kind", default="attn_bwd", help="kernel kind timed for the roofline object")
-    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline and the other N = 1 extras")
     ap.add_argument("--no-infer", action="store_true", help="skip the inference-forward leg")
     ap.add_argument("--kinds", action="store_true", help="print a per-kernel-kind time table to stderr (3 steps each)")
     ap.add_argument("--dry-run-launcher", action="store_true", help="CPU/gloo rendezvous only: tests the process launcher")
+    # test hooks (tests/test_gpu_dp_procs.py, tests/test_bench_cpu.py): never part of a measurement
+    ap.add_argument("--test-share-gpu", action="store_true", help="every rank on device 0 (a box with one GPU)")
+    ap.add_argument("--test-backend", default="nccl", help="collective backend; gloo when ranks share a device")
+    ap.add_argument("--test-fail-rank", type=int, default=-1)
+    ap.add_argument("--test-hang-rank", type=int, default=-1)
     a = ap.parse_args()
 
     # N > 1 and nobody started the ranks for us: start them (before torch is imported or the GPU touched)
@@ -211,33 +326,27 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from ecg_denoise_amd import RALENet, _lib
-    from ecg_denoise_amd.dp import DataParallelTrainer, HipEngineAdapter
+    from ecg_denoise_amd import _lib
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 and world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} needs WORLD_SIZE={a.gpus} (launch with torch.distributed.run)")
-    if os.environ.get("RAL_BENCH_SHARE_GPU"):    # test hook: every rank on device 0 (tests/test_gpu_dp_procs.py)
+    if a.test_share_gpu:
         local = 0
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("RAL_BENCH_BACKEND", "nccl")   # "gloo": the same hook (RCCL needs one device per rank)
-        if backend == "nccl":
+        if a.test_backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device(dev))
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(a.test_backend)
 
-    B = a.batch
-    model = RALENet(a.variant, leads=a.leads, L=a.L, max_batch=B, train=True, device=dev, seed=2023)
-    g = torch.Generator().manual_seed(2023 + rank)
-    x = torch.randn(B, a.leads, a.L, generator=g).to(dev)
-    tgt = torch.randn(B, a.leads, a.L, generator=g).to(dev)
-    trainer = DataParallelTrainer(HipEngineAdapter(model))
-    model.train()
+    W = build_workload(a, dev, rank)
+    model, inner, trainer, x, tgt, B, L = W["model"], W["inner"], W["trainer"], W["x"], W["tgt"], W["B"], W["L"]
+    Lk, Bk = L, B                         # shape the profiled RA-LENet kernels see (newrale: the inner (B, 2, L) model)
 
     def sync():
         torch.cuda.synchronize()
@@ -245,47 +354,59 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # world == 1 and U-Net: the fused entry points (ral_forward / ral_backward); the stage-by-stage adapter is the
+    # data-parallel form (one reduction per BatchNorm layer)
+    step = (lambda: model.train_step(x, tgt)) if (world == 1 and a.config == "unet") else (lambda: trainer.train_step(x, tgt))
     for _ in range(a.warmup):
-        trainer.train_step(x, tgt)
+        step()
     sync()
     lib = _lib.lib()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = trainer.train_step(x, tgt)
+    ev[0].record()
+    for i in range(a.steps):
+        out = step()
+        ev[i + 1].record()
     sync()
     dt = time.perf_counter() - t0
+    per_step = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(a.steps))
+    median_ms = per_step[len(per_step) // 2] if per_step else None
+
     # roofline leg: the same step with the kernels serialised (one lane, no side stream), so that the hipEvent
     # pair around each launch of the selected kernel measures that kernel alone, not its share of a busy GPU
     rl_steps = max(3, a.steps // 4)
     ms, cnt = C.c_double(), C.c_int64()
-    if rank == 0 or world > 1:
-        _lib.check(lib.ral_set_option(model.eng.h, b"lanes", 1))
-        _lib.check(lib.ral_set_option(model.eng.h, b"side_stream", 0))
-        trainer.train_step(x, tgt)
+    if inner is not None:
+        h = inner.eng.h
+        _lib.check(lib.ral_set_option(h, b"lanes", 1))
+        _lib.check(lib.ral_set_option(h, b"side_stream", 0))
+        step()
         sync()
-        _lib.check(lib.ral_profile_select(model.eng.h, a.kind.encode()))
+        _lib.check(lib.ral_profile_select(h, a.kind.encode()))
         for _ in range(rl_steps):
-            trainer.train_step(x, tgt)
+            step()
         sync()
-        _lib.check(lib.ral_profile_read(model.eng.h, C.byref(ms), C.byref(cnt)))
-        _lib.check(lib.ral_profile_select(model.eng.h, b""))
-        if a.kinds and rank == 0:
+        _lib.check(lib.ral_profile_read(h, C.byref(ms), C.byref(cnt)))
+        _lib.check(lib.ral_profile_select(h, b""))
+        if a.kinds:                        # every rank runs the steps (they contain collectives); rank 0 prints
             tot = 0.0
-            for kind in ("qkv_fwd", "attn_fwd", "mlp_fwd", "resample_fwd", "mlp_bwd", "attn_bwd", "qkv_bwd", "dw", "resample_bwd"):
-                _lib.check(lib.ral_profile_select(model.eng.h, kind.encode()))
+            for kind in KINDS:
+                _lib.check(lib.ral_profile_select(h, kind.encode()))
                 for _ in range(3):
-                    trainer.train_step(x, tgt)
+                    step()
                 sync()
                 ms2, cnt2 = C.c_double(), C.c_int64()
-                _lib.check(lib.ral_profile_read(model.eng.h, C.byref(ms2), C.byref(cnt2)))
-                w = kind_work(kind, a.L, B)
+                _lib.check(lib.ral_profile_read(h, C.byref(ms2), C.byref(cnt2)))
+                w = kind_work(kind, Lk, Bk)
                 tot += ms2.value / 3
-                print(f"  {kind:14s} {ms2.value/3:8.3f} ms/step  {cnt2.value//3:4d} launches  "
-                      f"{(w / (ms2.value / 3 * 1e-3) / 1e12) if w else 0:7.2f} TF/s", file=sys.stderr)
-            print(f"  sum of kinds   {tot:8.3f} ms/step (serialised)", file=sys.stderr)
-            _lib.check(lib.ral_profile_select(model.eng.h, b""))
-        _lib.check(lib.ral_set_option(model.eng.h, b"lanes", int(os.environ.get("RAL_LANES", "2"))))
-        _lib.check(lib.ral_set_option(model.eng.h, b"side_stream", 0 if os.environ.get("RAL_NO_SIDE_STREAM") else 1))
+                if rank == 0:
+                    print(f"  {kind:14s} {ms2.value/3:8.3f} ms/step  {cnt2.value//3:4d} launches  "
+                          f"{(w / (ms2.value / 3 * 1e-3) / 1e12) if w and ms2.value else 0:7.2f} TF/s", file=sys.stderr)
+            if rank == 0:
+                print(f"  sum of kinds   {tot:8.3f} ms/step (serialised)", file=sys.stderr)
+            _lib.check(lib.ral_profile_select(h, b""))
+        _lib.check(lib.ral_set_option(h, b"lanes", int(os.environ.get("RAL_LANES", "2"))))
+        _lib.check(lib.ral_set_option(h, b"side_stream", 0 if os.environ.get("RAL_NO_SIDE_STREAM") else 1))
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -293,8 +414,8 @@ def main():
     loss = out["loss"].item()
 
     infer = infer_graph = None
-    if not a.no_infer:
-        # BASELINE config 4: eval-mode forward (BatchNorm running statistics), eager and hipGraph-captured
+    if not a.no_infer and a.config != "newrale":
+        # BASELINE config 5's kernel path: eval-mode forward (BatchNorm running statistics), eager and hipGraph-captured
         from ecg_denoise_amd.infer import GraphedForward
         model.eval()
         for _ in range(2):
@@ -316,38 +437,74 @@ def main():
             dist.all_reduce(ti, op=dist.ReduceOp.MAX); dist.all_reduce(tg, op=dist.ReduceOp.MAX)
         infer = B * world * a.steps / ti.item()
         infer_graph = B * world * a.steps / tg.item()
+        model.train()
 
     if rank == 0:
-        ksec = ms.value * 1e-3
-        flops = kind_work(a.kind, a.L, B) * rl_steps
-        ach = flops / ksec / 1e12 if ksec > 0 else 0.0
-        peak = VALU_F32_PEAK_TF if a.kind.startswith("attn") else MFMA_F32_PEAK_TF
         res = {
-            "metric": f"ECG windows/sec ({a.L}-sample, bs{B}) train step; inference forward in infer_*_windows_per_s",
+            "metric": f"ECG windows/sec ({L}-sample, bs{B}) train step; inference forward in infer_*_windows_per_s",
             "value": round(B * world * a.steps / dt, 1), "unit": "windows/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "median_ms_per_step_hipevent": round(median_ms, 3) if median_ms else None,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"RA-LENet '{a.variant}' train step (fwd+mse/SNR/RMSE+bwd+Adam), "
-                                   f"{a.leads}-lead {a.L}-sample windows, batch {B}/GPU, "
-                                   f"N(0,1) inputs seed 2023, random-init weights",
-                       "global_batch": B * world, "parallelism": f"dp{world}", "sync_bn": True},
+            "config": {"workload": W["text"], "global_batch": B * world, "parallelism": f"dp{world}", "sync_bn": True},
             "final_loss": round(loss, 6),
-            "roofline": {"bound": "valu" if a.kind.startswith("attn") else "mfma", "kernel": a.kind, "achieved": round(ach, 3), "peak": peak,
-                         "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": measured_traffic(a.kind),
-                         "launches": int(cnt.value), "avg_launch_ms": round(ms.value / max(cnt.value, 1), 4),
-                         "measured": f"hipEvent pairs on the kernel's stream over {rl_steps} serialised steps "
-                                     "(lanes=1, no side stream) run right after the timed region"},
         }
+        if inner is not None:
+            ksec = ms.value * 1e-3
+            ach = kind_work(a.kind, Lk, Bk) * rl_steps / ksec / 1e12 if ksec > 0 else 0.0
+            peak = VALU_F32_PEAK_TF if a.kind.startswith("attn") else MFMA_F32_PEAK_TF
+            res["roofline"] = {"bound": "mfma", "kernel": a.kind, "achieved": round(ach, 3), "peak": peak,
+                               "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                               "traffic": measured_traffic(a.kind) if a.config == "ralenet" else None,
+                               "launches": int(cnt.value), "avg_launch_ms": round(ms.value / max(cnt.value, 1), 4),
+                               "flop_count": "algorithmic (SURVEY 8d)",
+                               "measured": f"hipEvent pairs on the kernel's stream over {rl_steps} serialised steps "
+                                           "(lanes=1, no side stream) run right after the timed region"}
+            if a.kind == "attn_bwd":       # the S re-computation counted as well (what the kernel executes per visit once)
+                ach10 = kind_work(a.kind, Lk, Bk, True) * rl_steps / ksec / 1e12 if ksec > 0 else 0.0
+                res["roofline"]["flop_count"] = "8 N^2 C per block (SURVEY 8d: 2 x forward); with the S re-computation (10 N^2 C) in *_incl_recompute"
+                res["roofline"]["achieved_incl_recompute"] = round(ach10, 3)
+                res["roofline"]["frac_incl_recompute"] = round(ach10 / peak, 4)
+        else:
+            # U-Net: every kernel of the step is an HBM-bound conv stage; stage-granular bytes of SURVEY 8d per window
+            # (forward with batch statistics 147 KB + backward 200 KB at 2 leads x 512 samples) over the whole step
+            by = 347e3 * (W["leads"] * L) / 1024.0
+            ach = by * B * world * a.steps / dt / 1e9 / world
+            res["roofline"] = {"bound": "hbm", "kernel": "whole U-Net train step (all conv stages)", "achieved": round(ach, 1),
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                               "measured": "stage-granular algorithmic bytes per window (SURVEY 8d) x windows / step time, per GPU"}
         if infer is not None:
             res["infer_windows_per_s"] = round(infer, 1)
             res["infer_hipgraph_windows_per_s"] = round(infer_graph, 1)
-        if world == 1 and not a.no_cpu:
+        if world == 1 and not a.no_cpu and a.config == "ralenet":
+            # the reference-parity shape next to the single-lead headline ("also report leads = 2")
             try:
-                res["conv_stage_roofline"] = conv_stage_roofline(dev, a.L)
+                del model, trainer, W
+                torch.cuda.empty_cache()
+                from ecg_denoise_amd import RALENet
+                m2 = RALENet(a.variant, leads=2, L=L, max_batch=B, train=True, device=dev, seed=2023)
+                x2 = torch.randn(B, 2, L, device=dev); t2 = torch.randn(B, 2, L, device=dev)
+                m2.train()
+                for _ in range(3):
+                    m2.train_step(x2, t2)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(10):
+                    m2.train_step(x2, t2)
+                torch.cuda.synchronize()
+                d2 = (time.perf_counter() - t1) / 10
+                res["leads2"] = {"value": round(B / d2, 1), "unit": "windows/s", "ms_per_step": round(d2 * 1e3, 3),
+                                 "workload": f"the same step on 2-lead windows (the reference's own shape), batch {B}, 10 steps"}
+                del m2, x2, t2
+                torch.cuda.empty_cache()
+            except Exception as exc:
+                res["leads2"] = {"error": str(exc)[:200]}
+            try:
+                res["conv_stage_roofline"] = conv_stage_roofline(dev, L)
             except Exception as exc:      # an extra, never at the expense of the headline line
                 res["conv_stage_roofline"] = {"error": str(exc)[:200]}
-            res["cpu_baseline"] = cpu_baseline(a.leads, a.L, a.variant)
+            res["cpu_baseline"] = cpu_baseline(a.leads or 1, L, a.variant)
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

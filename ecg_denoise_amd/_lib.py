@@ -58,6 +58,8 @@ _SIGS = {
     "ral_backward": (C.c_int, [_VP, _VP, _VP, C.c_int, _VP]),
     "ral_backward_input": (C.c_int, [_VP, _VP, _VP, C.c_int, _VP]),
     "ral_backward_begin": (C.c_int, [_VP, _VP, C.c_int, _VP]),
+    "ral_backward_input_begin": (C.c_int, [_VP, _VP, C.c_int, _VP]),
+    "ral_backward_input_end": (C.c_int, [_VP, _VP, C.c_int, C.c_int64, _VP]),
     "ral_backward_end": (C.c_int, [_VP, _VP, C.c_int, C.c_int64, _VP]),
     "ral_unet_stage_bn": (C.c_int, [C.c_int]),
     "ral_unet_forward_stage": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int64, _VP]),
@@ -77,7 +79,9 @@ _SIGS = {
     "ral_stream_windows": (C.c_int, [_VP, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, _VP, _VP, _VP]),
     "ral_stream_stitch": (C.c_int, [_VP, _VP, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, _VP, _VP]),
     "ral_attention_forward": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, _VP]),
-    "ral_attention_backward": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, _VP]),
+    "ral_attention_backward_scratch_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ral_attention_backward": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                         C.c_int, _VP]),
     "ral_set_option": (C.c_int, [_VP, C.c_char_p, C.c_int]),
     "ral_wavelet_denoise": (C.c_int, [_VP, _VP, C.c_int64, C.c_int, C.c_float, _VP]),
     "ral_profile_select": (C.c_int, [_VP, C.c_char_p]),

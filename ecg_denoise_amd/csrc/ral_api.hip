@@ -32,6 +32,23 @@ extern "C" const char* ral_last_error(void) { return g_err; }
     if (e_ != hipSuccess) return fail("%s failed: %s", #expr, hipGetErrorString(e_));        \
   } while (0)
 
+// Event records / stream waits of the fork-join scheduler: a failed one would silently drop an ordering edge (a race,
+// not an error), so the first failure is remembered and the entry point that issued it returns it (sched_check).
+static thread_local hipError_t g_sched_err = hipSuccess;
+static thread_local const char* g_sched_what = "";
+#define EV(expr)                                                                             \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess && g_sched_err == hipSuccess) { g_sched_err = e_; g_sched_what = #expr; } \
+  } while (0)
+static int sched_check() {
+  if (g_sched_err == hipSuccess) return 0;
+  const hipError_t e = g_sched_err;
+  g_sched_err = hipSuccess;
+  return fail("stream scheduling: %s failed: %s (an ordering edge was lost: the results of this call are undefined)",
+              g_sched_what, hipGetErrorString(e));
+}
+
 // ---------------------------------------------------------------------------------
 // layout
 // ---------------------------------------------------------------------------------
@@ -268,11 +285,11 @@ struct ProfScope {
       }
       m->prof_ev.push_back({a, b});
     }
-    (void)hipEventRecord(m->prof_ev[m->prof_used].first, s);
+    EV(hipEventRecord(m->prof_ev[m->prof_used].first, s));
   }
   ~ProfScope() {
     if (!on) return;
-    (void)hipEventRecord(m->prof_ev[m->prof_used].second, s);
+    EV(hipEventRecord(m->prof_ev[m->prof_used].second, s));
     m->prof_used++;
   }
 };
@@ -469,14 +486,14 @@ static int plan_lanes(RalModel* m, int B, hipStream_t s) {
 static void fork_lanes(RalModel* m, hipStream_t s) {     // lanes 1.. start after everything queued on s so far
   LaneSet* L = lanes_of(m);
   if (L->n < 2) return;
-  (void)hipEventRecord(L->l[0].ev_fork, s);
-  for (int i = 1; i < L->n; ++i) (void)hipStreamWaitEvent(L->l[i].s, L->l[0].ev_fork, 0);
+  EV(hipEventRecord(L->l[0].ev_fork, s));
+  for (int i = 1; i < L->n; ++i) EV(hipStreamWaitEvent(L->l[i].s, L->l[0].ev_fork, 0));
 }
 static void join_lanes(RalModel* m, hipStream_t s) {     // s continues after every lane has finished
   LaneSet* L = lanes_of(m);
   for (int i = 1; i < L->n; ++i) {
-    (void)hipEventRecord(L->l[i].ev_join, L->l[i].s);
-    (void)hipStreamWaitEvent(s, L->l[i].ev_join, 0);
+    EV(hipEventRecord(L->l[i].ev_join, L->l[i].s));
+    EV(hipStreamWaitEvent(s, L->l[i].ev_join, 0));
   }
 }
 
@@ -540,7 +557,7 @@ static int fwd_end(RalModel* m, float* y, int B, int64_t global_windows, int tra
   }
   join_lanes(m, s);
   HIP_OK(hipGetLastError());
-  return 0;
+  return sched_check();
 }
 
 // ---------------------------------------------------------------------------------
@@ -567,7 +584,7 @@ static void run_block_bwd(RalModel* m, int bi, const float* dy, const float* ext
   const int k = ln.bwd_count++ % dw_sets();            // temporary set of this block
   const bool side = m->side_stream && m->want_dw;
   hipStream_t sd = side ? ln.s2 : s;                   // stream of the weight-gradient kernels
-  if (side && ln.dw_pending[k]) (void)hipStreamWaitEvent(s, ln.ev_done[k], 0);   // set k free again?
+  if (side && ln.dw_pending[k]) EV(hipStreamWaitEvent(s, ln.ev_done[k], 0));   // set k free again?
   const float* dyw = woff(dy, w0, E1);
   float *dupre = woff(m->dupre[k], w0, 4 * E1), *dx1 = woff(m->dx1[k], w0, E1), *dohm = woff(m->dohm[k], w0, E1),
         *dqkv = woff(m->dqkv[k], w0, 3 * E1), *a2c0 = woff(m->a2c0[k], w0, m->L);   // (per-window stride L at every level: the lanes run different levels concurrently)
@@ -583,12 +600,12 @@ static void run_block_bwd(RalModel* m, int bi, const float* dy, const float* ext
     launch_qkv_bwd(C, dqkv, xin, m->pe[l], dx1, woff(extra, w0, E1), w, wt, g, woff(dx, w0, E1), N, B, s); }
   if (!m->want_dw) return;
   if (side) {
-    (void)hipEventRecord(ln.ev_ready[k], s);
-    (void)hipStreamWaitEvent(sd, ln.ev_ready[k], 0);
+    EV(hipEventRecord(ln.ev_ready[k], s));
+    EV(hipStreamWaitEvent(sd, ln.ev_ready[k], 0));
   }
   { ProfScope p(m, K_DW, sd);
     launch_block_dw(C, dyw, upre, w.le ? a2c0 : nullptr, dupre, x1, dx1, o, dqkv, xin, m->pe[l], w, g, N, B, m->dw_ksplit[l], fused_mlp_dw, sd); }
-  if (side) { (void)hipEventRecord(ln.ev_done[k], sd); ln.dw_pending[k] = true; }
+  if (side) { EV(hipEventRecord(ln.ev_done[k], sd)); ln.dw_pending[k] = true; }
 }
 
 // stage: grad of stage output `dy` -> grad of stage input written to `dx` (+extra). Uses `tmp` between blocks.
@@ -610,8 +627,8 @@ static void run_res_bwd(RalModel* m, int ri, const float* dy, const float* in, f
   while ((8 << lvl) < r.D) ++lvl;
   hipStream_t sd = s;
   if (m->side_stream) {   // dy was produced on s: fork the weight-gradient product to the side stream
-    (void)hipEventRecord(ln.ev_fork, s);
-    (void)hipStreamWaitEvent(ln.s2, ln.ev_fork, 0);
+    EV(hipEventRecord(ln.ev_fork, s));
+    EV(hipStreamWaitEvent(ln.s2, ln.ev_fork, 0));
     sd = ln.s2;
   }
   launch_resample_dw(r.D, ri >= 4, woff(dy, ln.w0, E1), woff(in, ln.w0, E1), m->params + r.lnw, m->params + r.lnb,
@@ -636,8 +653,8 @@ static int bwd_begin(RalModel* m, const float* dy, int B, hipStream_t s) {
   const bool side = m->side_stream && m->want_dw;
   if (side)   // side streams start after the gradient buffer has been zeroed
     for (int k = 0; k < nl; ++k) {
-      (void)hipEventRecord(LS->l[k].ev_fork, LS->l[k].s);
-      (void)hipStreamWaitEvent(LS->l[k].s2, LS->l[k].ev_fork, 0);
+      EV(hipEventRecord(LS->l[k].ev_fork, LS->l[k].s));
+      EV(hipStreamWaitEvent(LS->l[k].s2, LS->l[k].ev_fork, 0));
     }
 #define EACH_LANE(stmt) for (int k_ = 0; k_ < nl; ++k_) { Lane& ln = LS->l[k_]; stmt; }
   // decoder: ps_k <- stage <- (u = ps(.) + p)
@@ -651,7 +668,7 @@ static int bwd_begin(RalModel* m, const float* dy, int B, hipStream_t s) {
   EACH_LANE(run_stage_bwd(m, 5, gy[11], nullptr, gy[10], gin[5], ln))          // g x_mid
   // the decoder's parameters (utransformer4 .. transconv: the upper half of the flat gradient buffer) have their
   // final gradients once every lane's chain and weight-gradient stream pass this point: gradient bucket 1
-  EACH_LANE((void)hipEventRecord(ln.ev_dec_main, ln.s); if (side) (void)hipEventRecord(ln.ev_dec_side, ln.s2);)
+  EACH_LANE(EV(hipEventRecord(ln.ev_dec_main, ln.s)); if (side) EV(hipEventRecord(ln.ev_dec_side, ln.s2));)
   m->dec_lanes = nl; m->dec_side = side;
   EACH_LANE(run_stage_bwd(m, 4, gin[5], gin[5], gy[8], gin[4], ln))            // g p4 = transformer^T(g x_mid) + g x_mid
   // encoder: pm_k <- stage, skip gradients added by the first block of each stage
@@ -666,13 +683,13 @@ static int bwd_begin(RalModel* m, const float* dy, int B, hipStream_t s) {
 #undef EACH_LANE
   if (side)   // join the side streams into their lanes, then the lanes into s
     for (int k = 0; k < nl; ++k) {
-      (void)hipEventRecord(LS->l[k].ev_join, LS->l[k].s2);
-      (void)hipStreamWaitEvent(LS->l[k].s, LS->l[k].ev_join, 0);
+      EV(hipEventRecord(LS->l[k].ev_join, LS->l[k].s2));
+      EV(hipStreamWaitEvent(LS->l[k].s, LS->l[k].ev_join, 0));
     }
   join_lanes(m, s);
   launch_bn8_bwd_stats(gin[0], m->a0, m->ss, m->bn_sums + 32, (size_t)B * m->L, s);
   HIP_OK(hipGetLastError());
-  return 0;
+  return sched_check();
 }
 
 static int bwd_end(RalModel* m, float* dx, int B, int64_t global_windows, hipStream_t s) {
@@ -1053,6 +1070,23 @@ int ral_backward_input(ral_handle* h, const float* dy, float* dx, int B, ral_str
   return rc;
 }
 
+int ral_backward_input_begin(ral_handle* h, const float* dy, int B, ral_stream s) {
+  if (!h) return fail("null handle");
+  if (h->kind != 0) return fail("ral_backward_input_begin: RA-LENet handles only");
+  RalModel* m = h->m;
+  m->want_dw = false;
+  const int rc = bwd_begin(m, dy, B, (hipStream_t)s);
+  m->want_dw = true;
+  return rc;
+}
+
+int ral_backward_input_end(ral_handle* h, float* dx, int B, int64_t global_windows, ral_stream s) {
+  if (!h) return fail("null handle");
+  if (h->kind != 0) return fail("ral_backward_input_end: RA-LENet handles only");
+  if (!dx) return fail("ral_backward_input_end: dx is the only result, it cannot be NULL");
+  return bwd_end(h->m, dx, B, global_windows, (hipStream_t)s);
+}
+
 int ral_adam_step(ral_handle* h, double lr, double beta1, double beta2, double eps, int step, float grad_scale,
                   ral_stream s) {
   if (!h) return fail("null handle");
@@ -1187,28 +1221,25 @@ int ral_attention_forward(const float* qkv, float* o, float* lse, const float* t
   return 0;
 }
 
+int64_t ral_attention_backward_scratch_floats(int N, int H, int Len, int has_table, int B) {
+  if (check_attn_args(N, H, has_table ? Len : 0, B)) return -1;
+  if (!attn_bwd_uses_stat2(N, has_table ? Len : 0, has_table != 0)) return 0;
+  return (int64_t)B * H * N * 2 + (int64_t)B * 2 * H * 64;
+}
+
 int ral_attention_backward(const float* qkv, const float* o, const float* d_o, const float* lse, const float* table,
-                           float* gtable, float* dqkv, int N, int H, int Len, int B, ral_stream s) {
+                           float* gtable, float* dqkv, float* scratch, int64_t scratch_floats, int N, int H, int Len,
+                           int B, ral_stream s) {
   if (!qkv || !o || !d_o || !lse || !dqkv || (table && !gtable)) return fail("attention: null pointer");
   if (check_attn_args(N, H, table ? Len : 0, B)) return -1;
-  // scratch of the two-sweep kernels, (B, H, N, 2) floats: kept by the library for this stateless entry point and grown
-  // on demand (a growth synchronises the device; the handle-based path owns its scratch in the workspace instead)
-  static float* scratch = nullptr;
-  static size_t scratch_floats = 0;
-  float* stat2 = nullptr;
-  if (attn_bwd_uses_stat2(N, table ? Len : 0, table != nullptr)) {
-    const size_t need = (size_t)B * H * N * 2 + (size_t)B * 2 * H * 64;
-    if (need > scratch_floats) {
-      HIP_OK(hipDeviceSynchronize());
-      if (scratch) (void)hipFree(scratch);
-      scratch = nullptr; scratch_floats = 0;
-      HIP_OK(hipMalloc(reinterpret_cast<void**>(&scratch), need * sizeof(float)));
-      scratch_floats = need;
-    }
-    stat2 = scratch;
-  }
-  launch_attn_bwd(qkv, o, d_o, lse, table, gtable, dqkv, stat2, N, H, attn_head_group(N, H, table ? Len : 0, true),
-                  table ? Len : 0, B, (hipStream_t)s);
+  // scratch of the two-sweep scalar-path kernels ((B, H, N, 2) floats + table-gradient partials): owned by the caller,
+  // so the entry point holds no state, never allocates and can be captured into a hipGraph
+  const int64_t need = ral_attention_backward_scratch_floats(N, H, Len, table != nullptr, B);
+  if (need > 0 && (!scratch || scratch_floats < need))
+    return fail("attention backward: this shape needs %lld floats of scratch (ral_attention_backward_scratch_floats), got %lld",
+                (long long)need, (long long)(scratch ? scratch_floats : 0));
+  launch_attn_bwd(qkv, o, d_o, lse, table, gtable, dqkv, need > 0 ? scratch : nullptr, N, H,
+                  attn_head_group(N, H, table ? Len : 0, true), table ? Len : 0, B, (hipStream_t)s);
   HIP_OK(hipGetLastError());
   return 0;
 }

@@ -967,13 +967,19 @@ __global__ __launch_bounds__(256, 2) void k_unet_infer(const float* __restrict__
   float* RC = S3 + N4 * LD4;                             // X6 (N4 x 36) | later d1, channel-major 8 x N2
   float* X8 = RC + N4 * LD4;                             // (N3 + 1) x 36
   float* WV = X8 + (N3 + 1) * LD8;                       // weights of the four vector-ALU layers (PW0 .. PW10 + 32)
+  // biases and BatchNorm (scale, shift) pairs of all layers (PB .. PTOT, 512 floats).  They are read in the epilogues
+  // through the LDS, not from `pk`: hipcc hoists every loop-invariant global load out of the window loop, and with the
+  // 21 weight-fragment quads of the seven GEMM layers already living in registers across windows the ~20 epilogue quads
+  // went to scratch memory (156 bytes per lane: 20 MB of spill stores per launch, more than the kernel's output)
+  float* CB = WV + 288;
   const int tid = threadIdx.x, wave = tid >> 6;
   for (int i = tid; i < 288; i += 256) WV[i] = pk[PW0 + i];
+  for (int i = tid; i < PTOT - PB; i += 256) CB[i] = pk[PB + i];
   for (int i = tid; i < 32; i += 256) { const int c = i >> 3, h = i & 7; E0c[c * LP0 + (h < 4 ? h : N1 + h)] = 0.f; }
   for (int i = tid; i < 16; i += 256) { X8[i * 2] = 0.f; X8[N3 * LD8 + i * 2 + 1] = 0.f; }   // in[-1] and in[N3] of the shared rows
   const float* wv0 = WV, *wv1 = WV + (PW1 - PW0), *wv9 = WV + (PW9 - PW0), *wv10 = WV + (PW10 - PW0);
-  const float* bias = pk + PB;
-  const float* bns = pk + PS;
+  const float* bias = CB;
+  const float* bns = CB + (PS - PB);
   __syncthreads();
   RAL_STAMP_INIT();
   for (int win = blockIdx.x; win < B; win += gridDim.x) {
@@ -1089,7 +1095,11 @@ __global__ __launch_bounds__(256, 2) void k_unet_infer(const float* __restrict__
         if (p > 0) RA[(p - 1) * LD5 + c * 3 + 2] = vv[e];
       }
     });
-    const UFrag<96> f5 = uinf_frag<96>(pk + PW5, 32, (wave & 1) * 16);
+    // (the largest fragment, 24 registers: re-loaded per window - an opaque pointer keeps hipcc from hoisting it out of
+    // the window loop next to the other six layers' fragments, which is what pushed the kernel over 256 registers)
+    const float* pk5 = pk + PW5;
+    asm volatile("" : "+s"(pk5));
+    const UFrag<96> f5 = uinf_frag<96>(pk5, 32, (wave & 1) * 16);
     __syncthreads();
     RAL_STAMP_AT(6);
     // ---- layer 5: bottleneck.3, k3 conv as GEMM 32 x 96 -> LeakyReLU -> BN -> X6 ----
@@ -1183,7 +1193,7 @@ __global__ __launch_bounds__(256, 2) void k_unet_infer(const float* __restrict__
 static size_t uinf_lds_floats(int L) {
   const int N1 = L / 2, N2 = L / 4, N3 = L / 8, N4 = L / 16;
   return (size_t)4 * (N1 + 8) + (size_t)N4 * 100 + (size_t)N2 * 8 + (size_t)N3 * 16 + (size_t)(N4 + 1) * 68 + (size_t)N4 * 36 * 2 +
-         (size_t)(N3 + 1) * 36 + 288;
+         (size_t)(N3 + 1) * 36 + 288 + (uinf::PTOT - uinf::PB);
 }
 
 // =================================================================================

@@ -9,6 +9,8 @@ Collectives per step (torch.distributed; backend "nccl" is RCCL over xGMI on ROC
      encoder backward kernels run (`ral_grad_bucket` / `ral_grad_bucket_wait`); the other half follows the stem
   4. the scalar loss (reporting only)
 No collective touches activations; inference needs none (replicas).
+`NewRALEEngineAdapter` runs the 12-lead transfer-learning model the same way: the frozen inner RA-LENet is cut at the same
+two reduction points (its BatchNorm still uses batch statistics), only the 8.8 KB adapter gradient is all-reduced.
 U-Net (a BatchNorm after every conv): `UNetEngineAdapter` cuts the step at every layer, 10 + 10 reductions of 64
 doubles per step, for exact global-batch statistics.
 
@@ -129,6 +131,72 @@ class UNetEngineAdapter:
 
     def replica_state(self):
         return _replica_state(self.m)
+
+
+class NewRALEEngineAdapter:
+    """The 12-lead transfer-learning model (`newrale`, ralenet_12leads.py:680-709; caller Transfer_learning.py:71-82)
+    under data parallelism - BASELINE config 4.  Only the 2 210 adapter parameters train, but the frozen inner RA-LENet
+    is left in train mode by `model.train()` (denoise_train.py:44), so its stem BatchNorm normalises with BATCH
+    statistics and keeps updating its running ones (quirk A16).  For the N-rank step to be the single-process step on
+    the concatenated batch the inner model is therefore cut exactly like a trainable one:
+      forward : conv1, conv2, inner stem conv   -> all-reduce of 16 doubles (sum x, sum x^2)  -> rest, conv3, conv4
+      backward: conv4, conv3, inner data-gradient chain (`ral_backward_input_begin`: no weight-gradient kernels)
+                -> all-reduce of 16 doubles (sum dy, sum dy x^) -> stem input gradient, conv2, conv1
+      then ONE all-reduce of the 8.8 KB adapter gradient and the flat Adam kernel on the adapter buffer.
+    Replica state = adapter parameters and moments AND the inner model's parameters and running statistics."""
+
+    def __init__(self, model):
+        import ctypes as C
+        from . import _lib
+        from .model import _ptr, _stream
+        self.m, self._lib, self._ptr, self._stream, self._C = model, _lib, _ptr, _stream, C
+        self.inner = model.rale
+        self.bn_sums = self.inner.eng.bn_sums
+        self.grads = model.grads
+
+    def forward_begin(self, x):
+        self.a2 = self.m._forward_pre(x)
+        self.inner._x = self.a2
+        self._lib.check(self._lib.lib().ral_forward_begin(self.inner.eng.h, self._ptr(self.a2), self.a2.shape[0],
+                                                          self._stream()))
+
+    def forward_end(self, global_windows):
+        r = torch.empty_like(self.a2)
+        self._lib.check(self._lib.lib().ral_forward_end(self.inner.eng.h, self._ptr(r), self.a2.shape[0], global_windows,
+                                                        self._stream()))
+        for k in self.inner.eng.counters:
+            self.inner.eng.counters[k] += 1
+        return self.m._forward_post(r)
+
+    def loss(self, pred, target, global_windows):
+        return self.m.loss_and_metrics(pred, target, True, global_windows)
+
+    def backward_begin(self):
+        self.dr = self.m._backward_pre()
+        self._lib.check(self._lib.lib().ral_backward_input_begin(self.inner.eng.h, self._ptr(self.dr), self.dr.shape[0],
+                                                                 self._stream()))
+
+    def backward_end(self, global_windows):
+        d2 = torch.empty_like(self.dr)
+        self._lib.check(self._lib.lib().ral_backward_input_end(self.inner.eng.h, self._ptr(d2), self.dr.shape[0],
+                                                               global_windows, self._stream()))
+        self.m._backward_post(d2)
+
+    def adam(self, lr):
+        self.m.step(lr)
+
+    def replica_state(self):
+        m, ie = self.m, self.inner.eng
+        tensors = [m.params, m.adam_m, m.adam_v, ie.params, ie.state]
+
+        def get_counters():
+            return [m.step_count] + [ie.counters[k] for k in sorted(ie.counters)]
+
+        def set_counters(v):
+            m.step_count = int(v[0])
+            for k, c in zip(sorted(ie.counters), v[1:]):
+                ie.counters[k] = int(c)
+        return tensors, get_counters, set_counters
 
 
 def _replica_state(model):

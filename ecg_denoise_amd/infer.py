@@ -46,8 +46,9 @@ class StreamingDenoiser:
     (de-normalise + keep-the-centre stitching).  With `use_graph` the whole pipeline of a record group of a given
     shape (R, leads, T) is ONE hipGraph: replaying it costs one launch per group."""
 
-    def __init__(self, model, batch=4096, overlap=0, use_graph=True):
+    def __init__(self, model, batch=4096, overlap=0, use_graph=True, max_plans=4):
         self.model, self.L, self.leads = model, model.eng.L, model.eng.leads
+        self.max_plans = max(1, int(max_plans))      # plans (buffers + hipGraph per record-group shape) kept, LRU
         self.batch = min(batch, model.eng.max_batch)
         if overlap < 0 or overlap >= self.L or overlap % 2:
             raise _lib.RalError("overlap must be an even number of samples in [0, L)")
@@ -82,7 +83,10 @@ class StreamingDenoiser:
     def _plan(self, R, T):
         key = (R, T)
         if key in self.plans:
+            self.plans[key] = self.plans.pop(key)       # most recently used last
             return self.plans[key]
+        while len(self.plans) >= self.max_plans:        # drop the least recently used shape (its buffers and graph)
+            self.plans.pop(next(iter(self.plans)))
         dev = self.model.eng.device
         nw = R * self.windows_per_record(T)
         z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
@@ -102,9 +106,10 @@ class StreamingDenoiser:
         return p
 
     @torch.no_grad()
-    def denoise(self, record):
+    def denoise(self, record, copy=True):
         """record: (leads, T) or a group (R, leads, T), host or device -> denoised record(s) of the same shape on the
-        device (a view of the plan's output buffer: valid until the next call with the same shape)"""
+        device.  The result is a fresh tensor; `copy=False` returns a view of the plan's output buffer instead, which the
+        next call with the same shape overwrites (throughput loops that consume each result before the next call)."""
         dev = self.model.eng.device
         rec = torch.as_tensor(record, dtype=torch.float32)
         single = rec.dim() == 2
@@ -118,4 +123,5 @@ class StreamingDenoiser:
             p["graph"].replay()
         else:
             self._run(p)
-        return p["out"][0] if single else p["out"]
+        out = p["out"][0] if single else p["out"]
+        return out.clone() if copy else out

@@ -409,17 +409,25 @@ class NewRALE:
                                                  x.shape[1], cout, x.shape[2], int(lrelu), _stream()))
         return y
 
-    def forward(self, x):
+    # forward and backward are written as (adapter convs in front) / (inner RA-LENet) / (adapter convs behind) so that the
+    # data-parallel adapter (dp.NewRALEEngineAdapter) can cut the inner model at its BatchNorm reduction points
+    def _forward_pre(self, x):
         x = x.contiguous()
         if x.dim() != 3 or x.shape[1] != 12 or x.shape[2] != self.L or not x.is_cuda:
             raise _lib.RalError(f"expected a HIP tensor (B, 12, {self.L}), got {tuple(x.shape)}")
         a1 = self._conv("conv1", x, 6, True)
         a2 = self._conv("conv2", a1, 2, True)
-        r = self.rale.forward(a2)
+        self._saved = [x, a1, a2]
+        return a2
+
+    def _forward_post(self, r):
         a3 = self._conv("conv3", r, 6, True)
         y = self._conv("conv4", a3, 12, False)
-        self._saved = (x, a1, a2, r, a3, y)
+        self._saved += [r, a3, y]
         return y
+
+    def forward(self, x):
+        return self._forward_post(self.rale.forward(self._forward_pre(x)))
 
     __call__ = forward
 
@@ -445,20 +453,26 @@ class NewRALE:
                                                   x.shape[1], y.shape[1], x.shape[2], int(lrelu), _stream()))
         return dx
 
-    def backward(self, dy=None):
+    def _backward_pre(self, dy=None):
         dy = (self._dy if dy is None else dy).contiguous()
         x, a1, a2, r, a3, y = self._saved
         self.grads.zero_()
         d3 = self._conv_bwd("conv4", a3, y, dy, False, True)
-        dr = self._conv_bwd("conv3", r, a3, d3, True, True)
-        d2 = self.rale.backward_input(dr)                        # frozen weights: input gradient only, no dW kernels
+        return self._conv_bwd("conv3", r, a3, d3, True, True)
+
+    def _backward_post(self, d2):
+        x, a1, a2, r, a3, y = self._saved
         d1 = self._conv_bwd("conv2", a1, a2, d2, True, True)
         self._conv_bwd("conv1", x, a1, d1, True, False)
 
-    def step(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def backward(self, dy=None):
+        dr = self._backward_pre(dy)
+        self._backward_post(self.rale.backward_input(dr))        # frozen weights: input gradient only, no dW kernels
+
+    def step(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
         self.step_count += 1
         _lib.check(_lib.lib().ral_adam_flat(_ptr(self.params), _ptr(self.grads), _ptr(self.adam_m), _ptr(self.adam_v),
-                                            self.params.numel(), lr, betas[0], betas[1], eps, self.step_count, 1.0,
+                                            self.params.numel(), lr, betas[0], betas[1], eps, self.step_count, grad_scale,
                                             _stream()))
 
     def train_step(self, x, target, lr=1e-3):

@@ -6,23 +6,27 @@ and reproduce the reference's arithmetic (argmax over dim 1, counts as Python fl
 import torch
 
 
+def confusion(pred, label):
+    """(tp, fp, fn, tn) of the argmax decision against binary labels (1 = V beat), counted in one pass: the four cells are
+    the histogram of 2 * label + decision."""
+    d = torch.argmax(pred, dim=1).long()
+    cells = torch.bincount(2 * label.long().reshape(-1) + d.reshape(-1), minlength=4).tolist()
+    tn, fp, fn, tp = (float(c) for c in cells[:4])
+    return tp, fp, fn, tn
+
+
 def acc(pred, label):
-    p = torch.argmax(pred, dim=1)
-    return torch.sum(p == label).item() / len(label)
+    tp, fp, fn, tn = confusion(pred, label)
+    return (tp + tn) / len(label)
 
 
 def precision(pred, label):
-    p = torch.argmax(pred, dim=1)
-    tp = torch.sum(p * label).item()
-    fp = torch.sum(p * (1 - label)).item()
-    return tp / (tp + fp)
+    tp, fp, _, _ = confusion(pred, label)
+    return tp / (tp + fp)              # (no zero-division guard, as the reference: a classifier that never says V raises)
 
 
 def f1_score(pred, label):
-    p = torch.argmax(pred, dim=1)
-    tp = torch.sum(p * label).item()
-    fp = torch.sum(p * (1 - label)).item()
-    fn = torch.sum((1 - p) * label).item()
+    tp, fp, fn, _ = confusion(pred, label)
     return tp / (tp + 0.5 * (fp + fn))
 
 
@@ -36,5 +40,5 @@ def score_denoiser(classifier, denoiser, loader, device):
             if denoiser is not None:
                 data = denoiser(data.contiguous())
             preds.append(classifier(data)); labels.append(torch.as_tensor(label).long().to(device))
-    p, l = torch.cat(preds), torch.cat(labels)
-    return acc(p, l), precision(p, l), f1_score(p, l)
+    tp, fp, fn, tn = confusion(torch.cat(preds), torch.cat(labels))
+    return (tp + tn) / (tp + fp + fn + tn), tp / (tp + fp), tp / (tp + 0.5 * (fp + fn))

@@ -18,15 +18,19 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from ecg_denoise_amd import RALENet, UNet
-    from ecg_denoise_amd.dp import DataParallelTrainer, HipEngineAdapter, UNetEngineAdapter
-    Bg, L = 128, 256
+    from ecg_denoise_amd import NewRALE, RALENet, UNet
+    from ecg_denoise_amd.dp import DataParallelTrainer, HipEngineAdapter, NewRALEEngineAdapter, UNetEngineAdapter
+    Bg, L, leads = (16, 1024, 12) if kind == "newrale" else (128, 256, 2)
     g = torch.Generator().manual_seed(77)
-    x = torch.randn(Bg, 2, L, generator=g); t = torch.randn(Bg, 2, L, generator=g)
+    x = torch.randn(Bg, leads, L, generator=g); t = torch.randn(Bg, leads, L, generator=g)
     sh = Bg // world
     xl, tl = x[rank * sh:(rank + 1) * sh].cuda(), t[rank * sh:(rank + 1) * sh].cuda()
     # every rank draws DIFFERENT initial weights: the trainer must make rank 0's the job's
-    if kind == "unet":
+    if kind == "newrale":      # BASELINE config 4: 12 leads x 1024 samples, frozen inner RA-LENet + trainable adapter
+        inner = RALENet("full", leads=2, L=L, max_batch=sh, device="cuda:0", seed=100 + rank)
+        m = NewRALE(inner, seed=200 + rank)
+        tr = DataParallelTrainer(NewRALEEngineAdapter(m))
+    elif kind == "unet":
         m = UNet(leads=2, L=L, max_batch=sh, device="cuda:0", seed=100 + rank)
         tr = DataParallelTrainer(UNetEngineAdapter(m))
     else:

@@ -27,9 +27,19 @@ def test_self_launch_two_ranks_relays_rank0_line():
 
 
 def test_self_launch_fails_when_a_rank_fails():
-    r = _run(["--gpus", "2", "--dry-run-launcher"], {"RAL_BENCH_FAIL_RANK": "1"})
+    r = _run(["--gpus", "2", "--dry-run-launcher", "--test-fail-rank", "1"])
     assert r.returncode != 0
     assert "ranks failed" in r.stderr
+
+
+def test_self_launch_ends_the_other_ranks_when_one_fails():
+    """rank 1 fails while rank 0 would run for an hour (a deadlocked collective looks like this): the launcher must
+    terminate rank 0 and return promptly instead of hanging in wait()"""
+    import time
+    t0 = time.time()
+    r = _run(["--gpus", "2", "--dry-run-launcher", "--test-fail-rank", "1", "--test-hang-rank", "0"])
+    assert r.returncode != 0 and "ranks failed" in r.stderr
+    assert time.time() - t0 < 120
 
 
 def test_no_launch_when_the_ranks_were_started_for_us():

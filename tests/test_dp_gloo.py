@@ -187,3 +187,126 @@ def test_two_ranks_equal_one_process_on_the_concatenated_batch():
         if k.endswith("to_kv.bias"):
             continue   # key-bias gradient is pure rounding noise (softmax shift invariance)
         np.testing.assert_allclose(params[k], p[k].numpy(), rtol=1e-6, atol=1e-9, err_msg=k)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE config 4: the 12-lead transfer-learning model (`newrale`) under data parallelism
+# ---------------------------------------------------------------------------------------------------------------------
+class OracleNewRALEEngine:
+    """Same call surface as dp.NewRALEEngineAdapter, fp64 torch-CPU arithmetic: adapter convs with autograd, the FROZEN
+    inner RA-LENet cut at its stem BatchNorm (which still normalises with batch statistics and updates its running
+    ones: reference quirk A16, ralenet_12leads.py:694-696 + denoise_train.py:44)."""
+
+    def __init__(self, seed_adapter, seed_inner, variant="full"):
+        self.variant = variant
+        self.pa = OrderedDict((k, v.double()) for k, v in O.init_params(O.newrale_param_shapes(), seed_adapter).items())
+        self.p = OrderedDict((k, v.double()) for k, v in O.init_params(O.ralenet_param_shapes(variant, 2), seed_inner).items())
+        self.m = OrderedDict((k, torch.zeros_like(v)) for k, v in self.pa.items())
+        self.v = OrderedDict((k, torch.zeros_like(v)) for k, v in self.pa.items())
+        self.bn_sums = torch.zeros(64, dtype=torch.float64)
+        self.grads = torch.zeros(sum(v.numel() for v in self.pa.values()), dtype=torch.float64)
+        self.running = O.new_bn_state(8, torch.float64)
+        self.tracked = torch.zeros(1, dtype=torch.float64)
+        self.step = 0
+
+    def forward_begin(self, x):
+        self.leaf = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in self.pa.items())
+        a = F.leaky_relu(F.conv1d(x.double(), self.leaf["conv1.weight"], self.leaf["conv1.bias"], padding=6), 0.01)
+        a2 = F.leaky_relu(F.conv1d(a, self.leaf["conv2.weight"], self.leaf["conv2.bias"], padding=6), 0.01)
+        self.L = x.shape[2]
+        self.a0 = F.leaky_relu(F.conv1d(a2, self.p["conv1.0.weight"], self.p["conv1.0.bias"], padding=1), 0.2)
+        self.bn_sums[:8] = self.a0.detach().sum((0, 2)); self.bn_sums[8:16] = (self.a0.detach() ** 2).sum((0, 2))
+
+    def forward_end(self, G):
+        cnt = G * self.L
+        mean = self.bn_sums[:8] / cnt
+        var = self.bn_sums[8:16] / cnt - mean ** 2
+        self.rstd, self.cnt = 1.0 / torch.sqrt(var + 1e-5), cnt
+        self.running["running_mean"].mul_(0.9).add_(0.1 * mean)
+        self.running["running_var"].mul_(0.9).add_(0.1 * var * cnt / (cnt - 1))
+        self.tracked += 1
+        self.xhat = (self.a0.detach() - mean[None, :, None]) * self.rstd[None, :, None]
+        self.x0 = (self.xhat * self.p["conv1.2.weight"][None, :, None] + self.p["conv1.2.bias"][None, :, None]).requires_grad_(True)
+        r = _rest_of_network(dict(self.p), self.x0, self.variant)
+        a3 = F.leaky_relu(F.conv1d(r, self.leaf["conv3.weight"], self.leaf["conv3.bias"], padding=6), 0.01)
+        self.pred = F.conv1d(a3, self.leaf["conv4.weight"], self.leaf["conv4.bias"], padding=6)
+        return self.pred.detach()
+
+    def loss(self, pred, target, G):
+        self.l = ((self.pred - target.double()) ** 2).sum() / (G * target[0].numel())
+        return self.l.detach().reshape(1), O.snr(target.double(), pred), O.rmse(target.double(), pred)
+
+    def backward_begin(self):
+        late = ["conv3.weight", "conv3.bias", "conv4.weight", "conv4.bias"]
+        gs = torch.autograd.grad(self.l, [self.x0] + [self.leaf[k] for k in late])
+        self.gx0, self.gd = gs[0], dict(zip(late, gs[1:]))
+        self.bn_sums[32:40] = self.gx0.sum((0, 2)); self.bn_sums[40:48] = (self.gx0 * self.xhat).sum((0, 2))
+
+    def backward_end(self, G):
+        gam = self.p["conv1.2.weight"]
+        s1, s2 = self.bn_sums[32:40] / self.cnt, self.bn_sums[40:48] / self.cnt
+        da = gam[None, :, None] * self.rstd[None, :, None] * (self.gx0 - s1[None, :, None] - self.xhat * s2[None, :, None])
+        early = ["conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias"]
+        self.gd.update(zip(early, torch.autograd.grad(self.a0, [self.leaf[k] for k in early], da)))
+        self.grads[:] = torch.cat([self.gd[k].reshape(-1) for k in self.pa])
+
+    def adam(self, lr):
+        self.step += 1
+        off, g = 0, OrderedDict()
+        for k, v in self.pa.items():
+            g[k] = self.grads[off:off + v.numel()].view_as(v); off += v.numel()
+        O.adam_step(self.pa, g, self.m, self.v, self.step, lr)
+
+    def replica_state(self):
+        tensors = list(self.pa.values()) + list(self.m.values()) + list(self.v.values()) + list(self.p.values()) + \
+            [self.running["running_mean"], self.running["running_var"], self.tracked]
+
+        def set_counters(c):
+            self.step = int(c[0])
+        return tensors, (lambda: [self.step]), set_counters
+
+
+def _worker_newrale(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from ecg_denoise_amd.dp import DataParallelTrainer
+    torch.set_num_threads(1)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(4, 12, 256, generator=g); y = torch.randn(4, 12, 256, generator=g)
+    eng = OracleNewRALEEngine(77 + 10 * rank, 1234 + 1000 * rank)      # ranks start from different adapters AND inner models
+    tr = DataParallelTrainer(eng)
+    sh = slice(rank * 2, rank * 2 + 2)
+    losses = [tr.train_step(x[sh], y[sh])["loss"].item() for _ in range(2)]
+    if rank == 0:
+        q.put((losses, {k: v.numpy() for k, v in eng.pa.items()}, {k: v.numpy() for k, v in eng.running.items() if torch.is_tensor(v)},
+               float(eng.tracked)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_newrale_two_ranks_equal_one_process_on_the_concatenated_batch():
+    """BASELINE config 4's split: two ranks x 2 twelve-lead windows == one process on the 4 windows, including the inner
+    model's BatchNorm running statistics (the frozen inner model still trains those)."""
+    torch.set_num_threads(1)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(4, 12, 256, generator=g).double(); y = torch.randn(4, 12, 256, generator=g).double()
+    pa = OrderedDict((k, v.double()) for k, v in O.init_params(O.newrale_param_shapes(), 77).items())
+    p = OrderedDict((k, v.double()) for k, v in O.init_params(O.ralenet_param_shapes("full", 2), 1234).items())
+    m = OrderedDict((k, torch.zeros_like(v)) for k, v in pa.items()); v = OrderedDict((k, torch.zeros_like(t)) for k, t in pa.items())
+    bn = O.new_bn_state(8, torch.float64)
+    fwd = lambda pp, xx: O.newrale_forward(pp, p, xx, "full", True, bn)
+    ref_losses = [O.train_step(pa, x, y, fwd, m, v, s)["loss"].item() for s in (1, 2)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_newrale, args=(r, 2, port, q)) for r in range(2)]
+    [pr.start() for pr in procs]
+    losses, params, running, tracked = q.get(timeout=600)
+    [pr.join(60) for pr in procs]
+    np.testing.assert_allclose(losses, ref_losses, rtol=1e-9)
+    for k in pa:
+        np.testing.assert_allclose(params[k], pa[k].numpy(), rtol=1e-6, atol=1e-9, err_msg=k)
+    np.testing.assert_allclose(running["running_mean"], bn["running_mean"].numpy(), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(running["running_var"], bn["running_var"].numpy(), rtol=1e-9)
+    assert tracked == bn["num_batches_tracked"] == 2

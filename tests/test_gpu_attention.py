@@ -57,7 +57,11 @@ def _case(N, H, Len, B, seed):
     gt = torch.zeros_like(td) if Len else None
     L = _lib.lib()
     _lib.check(L.ral_attention_forward(_vp(qd), _vp(o), _vp(lse), _vp(td), N, H, Len, B, _stream()))
-    _lib.check(L.ral_attention_backward(_vp(qd), _vp(o), _vp(dod), _vp(lse), _vp(td), _vp(gt), _vp(dqkv), N, H, Len, B, _stream()))
+    ns = L.ral_attention_backward_scratch_floats(N, H, Len, int(bool(Len)), B)
+    assert ns >= 0, L.ral_last_error()
+    scratch = torch.empty(max(ns, 1), device=DEV)      # caller-owned: the entry point keeps no state
+    _lib.check(L.ral_attention_backward(_vp(qd), _vp(o), _vp(dod), _vp(lse), _vp(td), _vp(gt), _vp(dqkv), _vp(scratch), ns,
+                                        N, H, Len, B, _stream()))
     torch.cuda.synchronize()
     rel = lambda a, b: ((a.double().cpu() - b).norm() / b.norm()).item()
     errs = {"o": rel(o, o_ref.detach()), "lse": rel(lse, lse_ref.detach()),
@@ -84,3 +88,19 @@ def test_attention_operator_many_windows(N, H, Len):
     is accumulated across all of them."""
     errs = _case(N, H, Len, 700, seed=7)
     assert all(e == e and e < 2e-5 for e in errs.values()), errs
+
+
+def test_attention_backward_rejects_missing_scratch():
+    """a shape that runs as two launches needs caller scratch; without it the call fails instead of allocating"""
+    L = _lib.lib()
+    N, H, B = 64, 16, 4
+    ns = L.ral_attention_backward_scratch_floats(N, H, 0, 0, B)
+    assert ns > 0
+    qkv = torch.randn(B, 3 * H, N, 4, device=DEV)
+    o = torch.empty(B, H, N, 4, device=DEV); lse = torch.empty(B, H, N, device=DEV); dqkv = torch.empty_like(qkv)
+    _lib.check(L.ral_attention_forward(_vp(qkv), _vp(o), _vp(lse), None, N, H, 0, B, _stream()))
+    rc = L.ral_attention_backward(_vp(qkv), _vp(o), _vp(o), _vp(lse), None, None, _vp(dqkv), None, 0, N, H, 0, B, _stream())
+    assert rc != 0 and b"scratch" in L.ral_last_error()
+    small = torch.empty(ns - 1, device=DEV)
+    rc = L.ral_attention_backward(_vp(qkv), _vp(o), _vp(o), _vp(lse), None, None, _vp(dqkv), _vp(small), ns - 1, N, H, 0, B, _stream())
+    assert rc != 0

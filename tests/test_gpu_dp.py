@@ -131,3 +131,50 @@ def test_ralenet_sync_batchnorm_two_ranks_equal_one_process():
     for k, v in ref.state_dict().items():
         if "running" in k:
             torch.testing.assert_close(halves[0].state_dict()[k], v, rtol=1e-5, atol=1e-7)
+
+
+def test_newrale_sync_batchnorm_two_ranks_equal_one_process():
+    """BASELINE config 4's split on one GPU: two half-batch `newrale` engines (12 leads x 1024 samples) driven through
+    dp.NewRALEEngineAdapter with the inner model's BatchNorm sums added where the all-reduces sit reproduce the
+    whole-batch model: outputs, adapter gradients (sum of the two), and the frozen inner model's running statistics."""
+    from ecg_denoise_amd import NewRALE, RALENet
+    from ecg_denoise_amd.dp import NewRALEEngineAdapter
+    B, L = 8, 1024
+    torch.manual_seed(3)
+    x = torch.randn(B, 12, L, device=DEV); t = torch.randn(B, 12, L, device=DEV)
+
+    def make(batch):
+        inner = RALENet("full", leads=2, L=L, max_batch=batch, device=DEV, seed=41)
+        for k, v in inner.named_parameters():
+            if "relative_position_bias_table" in k:
+                v.copy_(0.2 * torch.randn(v.shape, generator=torch.Generator().manual_seed(9)).to(DEV))
+        return NewRALE(inner, seed=42).train()
+    ref = make(B)
+    y = ref(x); ref.loss_and_metrics(y, t); ref.backward()
+    halves = [make(B // 2) for _ in range(2)]
+    ads = [NewRALEEngineAdapter(h) for h in halves]
+    xs, ts = [x[:B // 2], x[B // 2:]], [t[:B // 2], t[B // 2:]]
+
+    def exchange(lo, hi):
+        tot = ads[0].bn_sums[lo:hi] + ads[1].bn_sums[lo:hi]
+        for a in ads:
+            a.bn_sums[lo:hi] = tot
+    for a, xx in zip(ads, xs):
+        a.forward_begin(xx)
+    exchange(0, 32)
+    preds = [a.forward_end(B) for a in ads]
+    for a, p, tt in zip(ads, preds, ts):
+        a.loss(p, tt, B)
+        a.backward_begin()
+    exchange(32, 64)
+    for a in ads:
+        a.backward_end(B)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(torch.cat(preds), y, rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(halves[0].grads + halves[1].grads, ref.grads, rtol=3e-4, atol=3e-7)
+    for k, v in ref.rale.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            torch.testing.assert_close(halves[0].rale.state_dict()[k], v, rtol=1e-5, atol=1e-7)
+    # per-rank statistics would NOT reproduce the whole batch
+    solo = make(B // 2)
+    assert (solo(xs[0]) - y[:B // 2]).abs().max().item() > 1e-4

@@ -83,13 +83,71 @@ def test_two_processes_equal_one_process(kind, tmp_path):
 def test_bench_two_ranks_on_one_gpu():
     """bench.py --gpus 2 end to end (self-launch, replica broadcast, timed region with barriers, MAX over ranks, the
     inference leg), the two ranks sharing this box's GPU over gloo: one JSON line with n_gpus = 2 and the job total"""
-    env = dict(os.environ, RAL_BENCH_BACKEND="gloo", RAL_BENCH_SHARE_GPU="1")
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                        "--batch", "256", "--no-cpu"], env=env, capture_output=True, text=True, timeout=900)
-    assert p.returncode == 0, p.stdout + p.stderr
-    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, p.stdout
-    d = json.loads(lines[0])
+    d = _bench(["--batch", "256"])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 512 and d["scaling"] == "weak"
     assert d["value"] > 0 and abs(d["value"] - 512 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
     assert np.isfinite(d["final_loss"]) and d["infer_windows_per_s"] > 0
+    assert d["roofline"]["kernel"] == "attn_bwd" and d["roofline"]["frac"] > 0
+
+
+def _bench(extra):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--no-cpu", "--test-backend", "gloo", "--test-share-gpu"] + extra, capture_output=True, text=True,
+                       timeout=900)
+    assert p.returncode == 0, p.stdout + p.stderr
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_unet_two_ranks_on_one_gpu():
+    """`bench.py --config unet --gpus 2`: the per-layer sync-BatchNorm form of the U-Net step, two ranks on this GPU"""
+    d = _bench(["--config", "unet", "--batch", "256"])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 512 and "U-Net" in d["config"]["workload"]
+    assert d["value"] > 0 and np.isfinite(d["final_loss"]) and d["roofline"]["bound"] == "hbm"
+
+
+def test_bench_newrale_two_ranks_on_one_gpu():
+    """`bench.py --config newrale --gpus 2` (BASELINE config 4's split: 12 leads x 1024 samples, frozen inner model cut at
+    its BatchNorm sums, adapter gradient all-reduced), two ranks on this GPU"""
+    d = _bench(["--config", "newrale", "--batch", "16"])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 32 and "newrale" in d["config"]["workload"]
+    assert d["value"] > 0 and np.isfinite(d["final_loss"])
+    assert d["roofline"]["kernel"] == "attn_bwd" and d["roofline"]["launches"] > 0
+
+
+def test_bench_kinds_with_two_ranks_does_not_deadlock():
+    """`--kinds` used to run its extra (collective-bearing) steps on rank 0 only"""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "128",
+                        "--no-cpu", "--no-infer", "--kinds", "--test-backend", "gloo", "--test-share-gpu"], capture_output=True,
+                       text=True, timeout=900)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "sum of kinds" in p.stderr
+
+
+def test_newrale_two_processes_equal_one_process(tmp_path):
+    """BASELINE config 4's data-parallel split with two real processes at (B, 12, 1024): the ranks start from different
+    adapters AND different inner models, end three optimiser steps with identical replicas, and those equal one process
+    on the whole batch - losses, adapter parameters, and the frozen inner model's BatchNorm running statistics."""
+    from ecg_denoise_amd import NewRALE, RALENet
+    steps, Bg, L = 3, 16, 1024
+    out = str(tmp_path / "dp")
+    _launch([out, "newrale", str(steps)])
+    r0, r1 = torch.load(out + ".rank0"), torch.load(out + ".rank1")
+    for k in r0["state"]:
+        assert torch.equal(r0["state"][k], r1["state"][k]), k
+    assert r0["losses"] == r1["losses"] and r0["step_count"] == r1["step_count"] == steps
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(Bg, 12, L, generator=g).cuda(); t = torch.randn(Bg, 12, L, generator=g).cuda()
+    m = NewRALE(RALENet("full", leads=2, L=L, max_batch=Bg, device="cuda:0", seed=100), seed=200).train()
+    losses = [m.train_step(x, t)["loss"].item() for _ in range(steps)]
+    assert np.allclose(losses, r0["losses"], rtol=2e-5), (losses, r0["losses"])
+    for k, v in m.state_dict().items():
+        if v.dtype.is_floating_point:
+            if k.startswith("rale.") and "running" not in k:
+                assert torch.equal(r0["state"][k], v.cpu()), k          # frozen: bit for bit rank 0's initial weights
+            else:
+                assert np.abs(r0["state"][k].numpy() - v.cpu().numpy()).max() < 1e-4, k
+        else:
+            assert torch.equal(r0["state"][k], v.cpu()), k
+    assert int(r0["state"]["rale.conv1.2.num_batches_tracked"]) == steps

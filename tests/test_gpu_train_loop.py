@@ -74,9 +74,10 @@ def test_full_protocol_first_epochs_match_reference_curve(golden_dir, tmp_path):
 def test_full_protocol_end_of_training_inside_the_reference_spread(golden_dir, tmp_path):
     """The whole 100-epoch main.py protocol (64 s on one MI355X) against the reference's own run-to-run spread: the
     reference fixtures (same data, same initial weights, intra-op thread counts 6 / 2 / 3 / 4 / 1, i.e. different summation
-    orders: g6_ref_train_curve_full*.npz) end with last-ten-epoch means 19.36 .. 19.69 dB (mean 19.56) after agreeing to
-    1e-3 dB for two epochs; the HIP path from the same weights must land in that band (+- the band's own width; twelve
-    recorded HIP runs: 19.25 .. 19.71, mean 19.58, profiles/r02_snr_experiment.json)."""
+    orders: g6_ref_train_curve_full*.npz) end with last-ten-epoch means 19.36 .. 19.69 dB (mean 19.56, s.d. 0.14) after
+    agreeing to 1e-3 dB for two epochs.  Twelve recorded HIP runs from the same weights: mean 19.58, s.d. 0.14
+    (profiles/r02_snr_experiment.json).  The bar: the mean of TWO HIP runs (s.d. 0.10) inside the reference band widened
+    by one reference standard deviation, and within 0.3 dB (two and a half combined s.d.) of the reference mean."""
     from ecg_denoise_amd import RALENet, synth
     from ecg_denoise_amd.train import train
     import glob
@@ -85,18 +86,22 @@ def test_full_protocol_end_of_training_inside_the_reference_spread(golden_dir, t
     last10 = np.array([r["test_snr"][-10:].mean() for r in refs])
     noisy, clean = synth.make_dataset(10000, 2, 256, "emb", 0.0, seed=2023)
     (trn, trc), (ten, tec) = synth.split_8000_2000(noisy, clean)
-    m = RALENet("full", leads=2, L=256, max_batch=32, device="cuda:0")
     sd = O.init_params(O.ralenet_param_shapes("full", 2), int(refs[0]["seed"]))
     for k in sd:
         if "relative_position_bias_table" in k:
             sd[k].zero_()
         elif ".norm" in k or k.startswith("conv1.2."):
             sd[k].fill_(1.0 if k.endswith("weight") else 0.0)
-    m.load_state_dict(sd, strict=False)
-    res = train(epochs=100, model=m, batch_size=32, train_loader=batches(trn, trc, 32), test_loader=batches(ten, tec, 32),
-                use_gpu=True, model_name="ralenet", noise_name="emb", noise_intensity=0, out_dir=str(tmp_path),
-                log=lambda *_: None)
-    mine = float(np.mean(res[1][-10:]))
-    width = float(last10.max() - last10.min())
-    assert last10.min() - width <= mine <= last10.max() + width, (mine, last10)
-    assert abs(mine - last10.mean()) < 0.5
+    runs = []
+    for r in range(2):
+        m = RALENet("full", leads=2, L=256, max_batch=32, device="cuda:0")
+        m.load_state_dict(sd, strict=False)
+        res = train(epochs=100, model=m, batch_size=32, train_loader=batches(trn, trc, 32), test_loader=batches(ten, tec, 32),
+                    use_gpu=True, model_name="ralenet", noise_name="emb", noise_intensity=0, out_dir=str(tmp_path / str(r)),
+                    log=lambda *_: None)
+        runs.append(float(np.mean(res[1][-10:])))
+        del m
+    mine = float(np.mean(runs))
+    s = float(last10.std(ddof=1))
+    assert last10.min() - s <= mine <= last10.max() + s, (runs, last10)
+    assert abs(mine - last10.mean()) < 0.3, (runs, last10)

@@ -59,7 +59,9 @@ def check(N, H, Len):
     dqkv = torch.empty_like(qd); gt = torch.zeros_like(td) if Len else None
     L = _lib.lib()
     _lib.check(L.ral_attention_forward(vp(qd), vp(o), vp(lse), vp(td), N, H, Len, B, stream()))
-    _lib.check(L.ral_attention_backward(vp(qd), vp(o), vp(dod), vp(lse), vp(td), vp(gt), vp(dqkv), N, H, Len, B, stream()))
+    ns = L.ral_attention_backward_scratch_floats(N, H, Len, int(bool(Len)), B)
+    sc = torch.empty(max(ns, 1), device=DEV)
+    _lib.check(L.ral_attention_backward(vp(qd), vp(o), vp(dod), vp(lse), vp(td), vp(gt), vp(dqkv), vp(sc), ns, N, H, Len, B, stream()))
     torch.cuda.synchronize()
     rel = lambda a, b: ((a.double().cpu() - b).norm() / b.norm()).item()
     errs = {"o": rel(o, o_ref.detach()), "lse": rel(lse, lse_ref.detach()),
@@ -88,7 +90,9 @@ def main():
         gt = torch.zeros_like(table) if Len else None
         o = torch.empty(B, H, N, 4, device=DEV); lse = torch.empty(B, H, N, device=DEV); dqkv = torch.empty_like(qkv)
         fwd = lambda: _lib.check(L.ral_attention_forward(vp(qkv), vp(o), vp(lse), vp(table), N, H, Len, B, stream()))
-        bwd = lambda: _lib.check(L.ral_attention_backward(vp(qkv), vp(o), vp(do), vp(lse), vp(table), vp(gt), vp(dqkv), N, H, Len, B, stream()))
+        ns = L.ral_attention_backward_scratch_floats(N, H, Len, int(bool(Len)), B)
+        sc = torch.empty(max(ns, 1), device=DEV)
+        bwd = lambda: _lib.check(L.ral_attention_backward(vp(qkv), vp(o), vp(do), vp(lse), vp(table), vp(gt), vp(dqkv), vp(sc), ns, N, H, Len, B, stream()))
         out = {}
         for name, fn, mult in (("fwd", fwd, 4.0), ("bwd", bwd, 10.0)):
             if only and name != only:
