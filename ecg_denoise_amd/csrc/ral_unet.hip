@@ -33,6 +33,7 @@ struct Src {            // one input operand of a stage: act(norm(z))
   const double* sums;   // fwd sums of its BatchNorm (sum[C], sumsq[C]) or null
   const float* gamma; const float* beta; const float* running;  // running: mean[C], var[C]
   int norm, act;
+  int nrep;             // `sums` is spread over nrep replicas of 64 doubles (1: the record itself)
   // backward outputs for this operand: gradient at its BatchNorm output (+ its two sums)
   float* G; double* bsums; int accumulate;
 };
@@ -47,17 +48,45 @@ struct Stage {
   // backward
   const float* Gout; const double* bsums_out; const float* gamma_out; int type;
   float* gw; float* gb;
+  float* part; int64_t part_stride; int part_w, part_b;   // per-workgroup gradient partial rows (null: atomics into gw / gb)
+  int nrep;             // replicas of every record this stage ADDS to (sums_out forward; a / b / r .bsums backward) and of
+                        // bsums_out: workgroup w adds to replica w % nrep.  A same-address atomic chain costs ~30 ns per link
+                        // on MI355X: 512 workgroups adding to ONE record were 15 us of a 20 us stage
 };
 
 RAL_DEV float lrelu01(float v) { return v > 0.f ? v : 0.01f * v; }
 
+// One BatchNorm record (S1[MAXC], S2[MAXC] doubles) that may be spread over `nrep` replicas of 64 doubles -> out64 (LDS).
+// All 256 threads of the workgroup take part: every load of the fold is in flight at once (thread t: entry t & 63 of the
+// replicas (t >> 6) + 4 j), the four partial rows meet in LDS.
+RAL_DEV void fold_record(const double* rec, int nrep, double* out64) {
+  __shared__ double fold_tmp[4 * 64];
+  const int t = threadIdx.x, idx = t & 63, q = t >> 6;
+  if (t < 256) {
+    double v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int k = q + 4 * j; v[j] = rec[(size_t)(k < nrep ? k : 0) * 64 + idx]; }   // (branch-free: clamped)
+    double sum = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sum += (q + 4 * j < nrep) ? v[j] : 0.0;
+    fold_tmp[q * 64 + idx] = sum;
+  }
+  __syncthreads();
+  if (t < 64) out64[t] = (fold_tmp[t] + fold_tmp[64 + t]) + (fold_tmp[128 + t] + fold_tmp[192 + t]);
+  __syncthreads();
+}
+#define UNET_MAXREP 16
+
 // scale/shift (and mean/rstd) of one operand's BatchNorm into LDS: ss[0:C] scale, [C:2C] shift, [2C:3C] mean, [3C:4C] rstd
+// (called by all threads of the workgroup: it contains barriers)
 RAL_DEV void src_coeffs(const Src& s, int C, double count, float* ss) {
+  __shared__ double rec[64];
+  if (s.norm == NORM_BATCH) fold_record(s.sums, s.nrep, rec);
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float mean = 0.f, rstd = 1.f, sc = 1.f, sh = 0.f;
     if (s.norm == NORM_BATCH) {
-      const double m = s.sums[c] / count;
-      double var = s.sums[MAXC + c] / count - m * m;
+      const double m = rec[c] / count;
+      double var = rec[MAXC + c] / count - m * m;
       if (var < 0.0) var = 0.0;
       mean = (float)m; rstd = (float)(1.0 / sqrt(var + 1e-5));
     } else if (s.norm == NORM_RUNNING) {
@@ -66,6 +95,7 @@ RAL_DEV void src_coeffs(const Src& s, int C, double count, float* ss) {
     if (s.norm != NORM_NONE) { sc = s.gamma[c] * rstd; sh = s.beta[c] - mean * sc; }
     ss[c] = sc; ss[C + c] = sh; ss[2 * C + c] = mean; ss[3 * C + c] = rstd;
   }
+  __syncthreads();      // (rec is reused by the next call)
 }
 
 RAL_DEV float src_value(const Src& s, const float* ss, int C, int c, float z) {
@@ -135,8 +165,9 @@ __global__ __launch_bounds__(256) void k_unet_fwd(Stage st, int B) {
     __syncthreads();
   }
   if (st.sums_out && (int)threadIdx.x < st.cout) {
-    atomicAdd(st.sums_out + threadIdx.x, (double)red[threadIdx.x]);
-    atomicAdd(st.sums_out + MAXC + threadIdx.x, (double)red[MAXC + threadIdx.x]);
+    double* rec = st.sums_out + (size_t)(blockIdx.x % st.nrep) * 64;
+    atomicAdd(rec + threadIdx.x, (double)red[threadIdx.x]);
+    atomicAdd(rec + MAXC + threadIdx.x, (double)red[MAXC + threadIdx.x]);
   }
 }
 
@@ -147,20 +178,24 @@ __global__ __launch_bounds__(256) void k_unet_fwd(Stage st, int B) {
 // with two atomics per thread.  MODE 0: Conv1d(k3, s2, p1); 1: Conv1d(k1 | k3, s1, same); 2: ConvTranspose1d(k4, s2, p1)
 // ---------------------------------------------------------------------------------
 template <int CIN, int COUT, int KS, int MODE>
-__global__ __launch_bounds__(256) void k_unet_fwd_t(Stage st, int B) {
+__global__ __launch_bounds__(256) void k_unet_fwd_t(Stage st, int B, int WP) {
+  // A workgroup takes WP CONSECUTIVE windows per pass (one pass per workgroup at the launch sizes used): their inputs are
+  // one contiguous block of global memory, requested with every load of the pass in flight at once - a window at a time
+  // costs one memory round trip per window, which at 4 windows per workgroup was most of a stage's time.
   extern __shared__ float4 smem4[];
   constexpr int HALO = 4;                       // 16-byte aligned zero halo on both sides of every input row
-  const int lin = st.lin, lout = st.lout, LP = lin + 2 * HALO;
-  float* in = reinterpret_cast<float*>(smem4);  // CIN x LP
-  float* ws = in + CIN * LP;
   constexpr int nw = CIN * COUT * KS;
+  const int lin = st.lin, lout = st.lout, LP = lin + 2 * HALO;
+  float* in = reinterpret_cast<float*>(smem4);  // WP x CIN x LP
+  float* rt = in + WP * CIN * LP;               // residual operand (already lrelu(BN(z))): WP x COUT x lout, when st.r.z
+  float* ws = rt + (st.r.z ? WP * COUT * lout : 0);
   float* bs = ws + nw;
   float* ca = bs + MAXC; float* cb = ca + 4 * MAXC; float* cr = cb + 4 * MAXC;
   float* red = cr + 4 * MAXC;
-  for (int i = threadIdx.x; i < nw; i += blockDim.x) ws[i] = st.w[i];
+  copy_flat(ws, st.w, nw >> 2);
   for (int i = threadIdx.x; i < COUT; i += blockDim.x) bs[i] = st.bias[i];
   for (int i = threadIdx.x; i < 2 * MAXC; i += blockDim.x) red[i] = 0.f;
-  for (int i = threadIdx.x; i < CIN * 2 * HALO; i += blockDim.x) {   // halos stay zero for every window
+  for (int i = threadIdx.x; i < WP * CIN * 2 * HALO; i += blockDim.x) {   // halos stay zero for every pass
     const int c = i / (2 * HALO), h = i % (2 * HALO);
     in[c * LP + (h < HALO ? h : lin + h)] = 0.f;
   }
@@ -168,73 +203,94 @@ __global__ __launch_bounds__(256) void k_unet_fwd_t(Stage st, int B) {
   if (st.b.z) src_coeffs(st.b, CIN, st.count_b, cb);
   if (st.r.z) src_coeffs(st.r, COUT, st.count_r, cr);
   __syncthreads();
-  const int nin = CIN * lin, nout = COUT * lout, q = lout >> 2, nslots = COUT * q;
-  for (int win = blockIdx.x; win < B; win += gridDim.x) {
-    const float* za = st.a.z + (size_t)win * nin;
-    const float* zb = st.b.z ? st.b.z + (size_t)win * nin : nullptr;
-    for (int i = threadIdx.x; i < (nin >> 2); i += blockDim.x) {
-      const int e = i << 2, c = e / lin, p = e - c * lin;
-      float4 v = *reinterpret_cast<const float4*>(za + e);
+  const int nin = CIN * lin, nout = COUT * lout, q = lout >> 2, nslots = COUT * q, nin4 = nin >> 2, nout4 = nout >> 2;
+  const bool a_lrelu = st.a.act == ACT_LRELU;
+  for (int w0 = blockIdx.x * WP; w0 < B; w0 += gridDim.x * WP) {
+    const int nwin = (B - w0) < WP ? (B - w0) : WP;
+    const float4* za = reinterpret_cast<const float4*>(st.a.z + (size_t)w0 * nin);
+    const float4* zb = st.b.z ? reinterpret_cast<const float4*>(st.b.z + (size_t)w0 * nin) : nullptr;
+    auto put = [&](int i, float4 v, float4 u) {
+      const int wi = i / nin4, e = (i - wi * nin4) << 2, c = e / lin, p = e - c * lin;
       const float sa = ca[c], ha = ca[CIN + c];
       v = make_float4(v.x * sa + ha, v.y * sa + ha, v.z * sa + ha, v.w * sa + ha);
-      if (st.a.act == ACT_LRELU) v = make_float4(lrelu01(v.x), lrelu01(v.y), lrelu01(v.z), lrelu01(v.w));
+      if (a_lrelu) v = make_float4(lrelu01(v.x), lrelu01(v.y), lrelu01(v.z), lrelu01(v.w));
       if (zb) {
-        const float4 u = *reinterpret_cast<const float4*>(zb + e);
         const float sb = cb[c], hb = cb[CIN + c];
         v.x += lrelu01(u.x * sb + hb); v.y += lrelu01(u.y * sb + hb); v.z += lrelu01(u.z * sb + hb); v.w += lrelu01(u.w * sb + hb);
       }
-      *reinterpret_cast<float4*>(in + c * LP + HALO + p) = v;
+      *reinterpret_cast<float4*>(in + (wi * CIN + c) * LP + HALO + p) = v;
+    };
+    {
+      constexpr int U = 4;
+      const int n4 = nwin * nin4, bd = blockDim.x;
+      int i = threadIdx.x;
+      for (; i + (U - 1) * bd < n4; i += U * bd) {
+        float4 v[U], u[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) v[k] = za[i + k * bd];
+        if (zb) {
+#pragma unroll
+          for (int k = 0; k < U; ++k) u[k] = zb[i + k * bd];
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) put(i + k * bd, v[k], u[k]);
+      }
+      for (; i < n4; i += bd) put(i, za[i], zb ? zb[i] : make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+    if (st.r.z) {
+      for_each_f4<4>(st.r.z + (size_t)w0 * nout, nwin * nout4, [&](int i, float4 zr) {
+        const int e = (i % nout4) << 2, c = e / lout;
+        const float sr = cr[c], hr = cr[COUT + c];
+        reinterpret_cast<float4*>(rt)[i] = make_float4(lrelu01(zr.x * sr + hr), lrelu01(zr.y * sr + hr), lrelu01(zr.z * sr + hr), lrelu01(zr.w * sr + hr));
+      });
     }
     __syncthreads();
-    for (int slot = threadIdx.x; slot < nslots; slot += blockDim.x) {
-      const int co = slot / q, l0 = (slot - co * q) << 2;
+    for (int slot = threadIdx.x; slot < nwin * nslots; slot += blockDim.x) {
+      const int wi = slot / nslots, sl = slot - wi * nslots, co = sl / q, l0 = (sl - co * q) << 2;
       float acc[4] = {bs[co], bs[co], bs[co], bs[co]};
 #pragma unroll 4
       for (int ci = 0; ci < CIN; ++ci) {
-        const float* row = in + ci * LP + HALO;
+        const float* row = in + (wi * CIN + ci) * LP + HALO;
         if constexpr (MODE == 0) {                      // out[l] = sum_k w[k] in[2l - 1 + k]
           const float* wr = ws + (co * CIN + ci) * 3;
-          const float w0 = wr[0], w1 = wr[1], w2 = wr[2];
-          float x[9];
+          const float w0_ = wr[0], w1 = wr[1], w2 = wr[2];
+          // in[2 l0 - 1 .. 2 l0 + 7] as three aligned 16-byte reads (nine 4-byte reads at a lane stride of 8 floats are bank conflicts)
+          const float4 qa = *reinterpret_cast<const float4*>(row + 2 * l0 - 4), qb = *reinterpret_cast<const float4*>(row + 2 * l0),
+                       qc = *reinterpret_cast<const float4*>(row + 2 * l0 + 4);
+          const float x[9] = {qa.w, qb.x, qb.y, qb.z, qb.w, qc.x, qc.y, qc.z, qc.w};
 #pragma unroll
-          for (int t = 0; t < 9; ++t) x[t] = row[2 * l0 - 1 + t];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[j] = fmaf(w0, x[2 * j], fmaf(w1, x[2 * j + 1], fmaf(w2, x[2 * j + 2], acc[j])));
+          for (int j = 0; j < 4; ++j) acc[j] = fmaf(w0_, x[2 * j], fmaf(w1, x[2 * j + 1], fmaf(w2, x[2 * j + 2], acc[j])));
         } else if constexpr (MODE == 1 && KS == 3) {    // out[l] = sum_k w[k] in[l - 1 + k]
           const float* wr = ws + (co * CIN + ci) * 3;
-          const float w0 = wr[0], w1 = wr[1], w2 = wr[2];
-          float x[6];
+          const float w0_ = wr[0], w1 = wr[1], w2 = wr[2];
+          const float4 qb = *reinterpret_cast<const float4*>(row + l0);
+          const float x[6] = {row[l0 - 1], qb.x, qb.y, qb.z, qb.w, row[l0 + 4]};
 #pragma unroll
-          for (int t = 0; t < 6; ++t) x[t] = row[l0 - 1 + t];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[j] = fmaf(w0, x[j], fmaf(w1, x[j + 1], fmaf(w2, x[j + 2], acc[j])));
+          for (int j = 0; j < 4; ++j) acc[j] = fmaf(w0_, x[j], fmaf(w1, x[j + 1], fmaf(w2, x[j + 2], acc[j])));
         } else if constexpr (MODE == 1) {               // 1x1
-          const float w0 = ws[co * CIN + ci];
+          const float w0_ = ws[co * CIN + ci];
           const float4 x = *reinterpret_cast<const float4*>(row + l0);
-          acc[0] = fmaf(w0, x.x, acc[0]); acc[1] = fmaf(w0, x.y, acc[1]); acc[2] = fmaf(w0, x.z, acc[2]); acc[3] = fmaf(w0, x.w, acc[3]);
+          acc[0] = fmaf(w0_, x.x, acc[0]); acc[1] = fmaf(w0_, x.y, acc[1]); acc[2] = fmaf(w0_, x.z, acc[2]); acc[3] = fmaf(w0_, x.w, acc[3]);
         } else {                                        // ConvTranspose1d: out[j] += w[ci][co][k] in[i], j = 2i - 1 + k
           const float* wr = ws + (ci * COUT + co) * 4;
-          const float w0 = wr[0], w1 = wr[1], w2 = wr[2], w3 = wr[3];
+          const float w0_ = wr[0], w1 = wr[1], w2 = wr[2], w3 = wr[3];
           const int h = l0 >> 1;
           const float x0 = row[h - 1], x1 = row[h], x2 = row[h + 1], x3 = row[h + 2];
           acc[0] = fmaf(w1, x1, fmaf(w3, x0, acc[0]));
-          acc[1] = fmaf(w0, x2, fmaf(w2, x1, acc[1]));
+          acc[1] = fmaf(w0_, x2, fmaf(w2, x1, acc[1]));
           acc[2] = fmaf(w1, x2, fmaf(w3, x1, acc[2]));
-          acc[3] = fmaf(w0, x3, fmaf(w2, x2, acc[3]));
+          acc[3] = fmaf(w0_, x3, fmaf(w2, x2, acc[3]));
         }
       }
       if (st.post_lrelu) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j] = lrelu01(acc[j]);
       }
-      const size_t o = (size_t)win * nout + (size_t)co * lout + l0;
       if (st.r.z) {
-        const float4 zr = *reinterpret_cast<const float4*>(st.r.z + o);
-        const float sr = cr[co], hr = cr[COUT + co];
-        acc[0] += lrelu01(zr.x * sr + hr); acc[1] += lrelu01(zr.y * sr + hr);
-        acc[2] += lrelu01(zr.z * sr + hr); acc[3] += lrelu01(zr.w * sr + hr);
+        const float4 rr = *reinterpret_cast<const float4*>(rt + (size_t)wi * nout + (size_t)co * lout + l0);
+        acc[0] += rr.x; acc[1] += rr.y; acc[2] += rr.z; acc[3] += rr.w;
       }
-      *reinterpret_cast<float4*>(st.out + o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      *reinterpret_cast<float4*>(st.out + (size_t)(w0 + wi) * nout + (size_t)co * lout + l0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
       if (st.sums_out) {
         atomicAdd(red + co, (acc[0] + acc[1]) + (acc[2] + acc[3]));
         atomicAdd(red + MAXC + co, (acc[0] * acc[0] + acc[1] * acc[1]) + (acc[2] * acc[2] + acc[3] * acc[3]));
@@ -243,8 +299,9 @@ __global__ __launch_bounds__(256) void k_unet_fwd_t(Stage st, int B) {
     __syncthreads();
   }
   if (st.sums_out && (int)threadIdx.x < COUT) {
-    atomicAdd(st.sums_out + threadIdx.x, (double)red[threadIdx.x]);
-    atomicAdd(st.sums_out + MAXC + threadIdx.x, (double)red[MAXC + threadIdx.x]);
+    double* rec = st.sums_out + (size_t)(blockIdx.x % st.nrep) * 64;
+    atomicAdd(rec + threadIdx.x, (double)red[threadIdx.x]);
+    atomicAdd(rec + MAXC + threadIdx.x, (double)red[MAXC + threadIdx.x]);
   }
 }
 
@@ -259,14 +316,19 @@ __global__ void k_unet_out(Src s, float* __restrict__ y, int C, int L, double co
   }
 }
 
-struct BnUpd { const double* sums; float* running; int C; double count; };
+// `sums` is the record the statistics come from, in nrep replicas; `final` (the caller-visible bn_sums record) receives the
+// folded sums when they were kept in replicas
+struct BnUpd { const double* sums; double* final_; float* running; int C; double count; int nrep; };
 struct BnUpdAll { BnUpd l[10]; };
 __global__ void k_unet_running(BnUpdAll u) {
   const BnUpd& b = u.l[blockIdx.x];
   const int c = threadIdx.x;
   if (c >= b.C) return;
-  const double m = b.sums[c] / b.count;
-  double var = b.sums[MAXC + c] / b.count - m * m;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < b.nrep; ++k) { s1 += b.sums[(size_t)k * 64 + c]; s2 += b.sums[(size_t)k * 64 + MAXC + c]; }
+  if (b.final_ != b.sums) { b.final_[c] = s1; b.final_[MAXC + c] = s2; }
+  const double m = s1 / b.count;
+  double var = s2 / b.count - m * m;
   if (var < 0.0) var = 0.0;
   b.running[c] = 0.9f * b.running[c] + 0.1f * (float)m;
   b.running[b.C + c] = 0.9f * b.running[b.C + c] + 0.1f * (float)(b.count > 1.0 ? var * b.count / (b.count - 1.0) : var);
@@ -274,7 +336,7 @@ __global__ void k_unet_running(BnUpdAll u) {
 
 // sums of the gradient at a BatchNorm output: S1 = sum G, S2 = sum G * zhat   (used for the last layer)
 __global__ __launch_bounds__(256) void k_unet_gsums(const float* __restrict__ G, Src s, int C, int L, double count,
-                                                    double* __restrict__ bsums, size_t total) {
+                                                    double* __restrict__ bsums, int nrep, size_t total) {
   __shared__ float ss[4 * MAXC];
   __shared__ float red[2 * MAXC];
   src_coeffs(s, C, count, ss);
@@ -287,8 +349,9 @@ __global__ __launch_bounds__(256) void k_unet_gsums(const float* __restrict__ G,
   }
   __syncthreads();
   if ((int)threadIdx.x < C) {
-    atomicAdd(bsums + threadIdx.x, (double)red[threadIdx.x]);
-    atomicAdd(bsums + MAXC + threadIdx.x, (double)red[MAXC + threadIdx.x]);
+    double* rec = bsums + (size_t)(blockIdx.x % nrep) * 64;
+    atomicAdd(rec + threadIdx.x, (double)red[threadIdx.x]);
+    atomicAdd(rec + MAXC + threadIdx.x, (double)red[MAXC + threadIdx.x]);
   }
 }
 
@@ -314,14 +377,15 @@ __global__ __launch_bounds__(256) void k_unet_bwd(Stage st, int B) {
   if (st.r.z) src_coeffs(st.r, st.cout, st.count_r, cr);
   // BN-backward coefficients of THIS stage's output: co_[c] = gamma*rstd, [C+c] = S1/n, [2C+c] = S2/n, mean/rstd after
   if (st.type != TY_PLAIN) {
-    Src o; o.norm = NORM_BATCH; o.sums = st.sums_out; o.gamma = st.gamma_out; o.beta = st.gamma_out; o.act = ACT_NONE;
+    Src o; o.norm = NORM_BATCH; o.sums = st.sums_out; o.nrep = 1; o.gamma = st.gamma_out; o.beta = st.gamma_out; o.act = ACT_NONE;
     float* tmp = gbs + MAXC;  // 4*MAXC scratch
     src_coeffs(o, st.cout, st.count, tmp);
-    __syncthreads();
+    __shared__ double brec[64];
+    fold_record(st.bsums_out, st.nrep, brec);
     for (int c = threadIdx.x; c < st.cout; c += blockDim.x) {
       co_[c] = st.gamma_out[c] * tmp[3 * st.cout + c];
-      co_[MAXC + c] = (float)(st.bsums_out[c] / st.count);
-      co_[2 * MAXC + c] = (float)(st.bsums_out[MAXC + c] / st.count);
+      co_[MAXC + c] = (float)(brec[c] / st.count);
+      co_[2 * MAXC + c] = (float)(brec[MAXC + c] / st.count);
       co_[3 * MAXC + c] = tmp[2 * st.cout + c];                         // mean
       gbs[5 * MAXC + c] = tmp[3 * st.cout + c];                          // rstd
     }
@@ -446,17 +510,20 @@ __global__ __launch_bounds__(256) void k_unet_bwd(Stage st, int B) {
   if ((int)threadIdx.x < st.cout) atomicAdd(st.gb + threadIdx.x, gbs[threadIdx.x]);
   if ((int)threadIdx.x < st.cin) {
     if (st.a.G && st.a.bsums) {
-      atomicAdd(st.a.bsums + threadIdx.x, (double)sa[threadIdx.x]);
-      atomicAdd(st.a.bsums + MAXC + threadIdx.x, (double)sa[MAXC + threadIdx.x]);
+      double* rec = st.a.bsums + (size_t)(blockIdx.x % st.nrep) * 64;
+      atomicAdd(rec + threadIdx.x, (double)sa[threadIdx.x]);
+      atomicAdd(rec + MAXC + threadIdx.x, (double)sa[MAXC + threadIdx.x]);
     }
     if (st.b.z && st.b.G) {
-      atomicAdd(st.b.bsums + threadIdx.x, (double)sb[threadIdx.x]);
-      atomicAdd(st.b.bsums + MAXC + threadIdx.x, (double)sb[MAXC + threadIdx.x]);
+      double* rec = st.b.bsums + (size_t)(blockIdx.x % st.nrep) * 64;
+      atomicAdd(rec + threadIdx.x, (double)sb[threadIdx.x]);
+      atomicAdd(rec + MAXC + threadIdx.x, (double)sb[MAXC + threadIdx.x]);
     }
   }
   if (st.r.z && st.r.G && (int)threadIdx.x < st.cout) {
-    atomicAdd(st.r.bsums + threadIdx.x, (double)sr[threadIdx.x]);
-    atomicAdd(st.r.bsums + MAXC + threadIdx.x, (double)sr[MAXC + threadIdx.x]);
+    double* rec = st.r.bsums + (size_t)(blockIdx.x % st.nrep) * 64;
+    atomicAdd(rec + threadIdx.x, (double)sr[threadIdx.x]);
+    atomicAdd(rec + MAXC + threadIdx.x, (double)sr[MAXC + threadIdx.x]);
   }
 }
 
@@ -477,355 +544,378 @@ RAL_DEV void seg_atomic(float* addr, float v, int w) {
 }
 
 // ---------------------------------------------------------------------------------
-// backward stage, specialised (same template parameters as k_unet_fwd_t).  Per window:
-//   1. input tile (BatchNorm + LeakyReLU + skip applied on load) and the gradient tile at the conv output
-//      (BatchNorm-backward correction applied on load) go to zero-haloed LDS rows;
-//   2. input gradient: a thread produces 4 consecutive positions of one input channel and emits the gradients at
-//      the producers' BatchNorm outputs (+ their per-channel sums);
-//   3. weight gradient: a thread owns one (co, ci) pair and a 32-position chunk, all KS taps in registers;
-//      partial sums are accumulated in an LDS copy of the weight tensor and flushed once per workgroup.
+// backward stage, specialised (same template parameters as k_unet_fwd_t).  A workgroup takes WP consecutive windows
+// per pass (one pass at the launch sizes used) and touches global memory in ONE batched load phase:
+//   1. load phase, every load of the pass in flight at once: the input operand(s) - kept twice in zero-haloed LDS rows,
+//      transformed (BatchNorm + LeakyReLU + skip: the conv operand) and raw (the epilogue's activation derivative and
+//      z-hat) -, the old value of a gradient tensor that is accumulated into, and the gradient at the conv output with
+//      its BatchNorm-backward correction applied (+ bias gradient, + the residual operand's gradient);
+//   2. input gradient d_in[ci][p] = sum over (co, k) W(co, ci, k) D(co, k, p) as fp32-MFMA tiles of 16 positions x 16
+//      input channels (padded), both operands gathered from the LDS tiles by index (zero halos cover the taps outside;
+//      no im2col copy); a lane ends with 4 consecutive positions of one input channel, the unit of the epilogue
+//      (activation derivative, BatchNorm-backward sums of the producers, store) - which reads LDS only;
+//   3. weight gradient gw(co, ci, k) += sum_p D[co][p] I(ci, k, p) as MFMA tiles of 16 output channels x 16 (ci, k)
+//      pairs (padded), K = output positions; layers with fewer than four tiles split the positions over the waves.  The
+//      accumulators live in registers across all windows of the workgroup.
+// Every layer runs on the matrix pipe, the narrow ones with mostly-padding tiles: the FLOPs are free here (0.76 MFLOP
+// per window), what the scalar loops they replace cost was LDS bank conflicts and same-address LDS atomics.
+// The workgroup's weight / bias gradient partial leaves as plain stores into ITS row of a scratch matrix
+// (st.part: workgroups x parameters), folded by k_unet_fold after the last stage - no global atomics except the 2 x C
+// BatchNorm-backward sums the NEXT stage needs.  (st.part == nullptr: atomics straight into the gradient buffer.)
 // ---------------------------------------------------------------------------------
 template <int CIN, int COUT, int KS, int MODE>
-__global__ __launch_bounds__(256) void k_unet_bwd_t(Stage st, int B) {
+__global__ __launch_bounds__(256) void k_unet_bwd_t(Stage st, int B, int WP) {
   extern __shared__ float4 smem4[];
   constexpr int HALO = 4, nw = CIN * COUT * KS;
   const int lin = st.lin, lout = st.lout, LP = lin + 2 * HALO, LPO = lout + 2 * HALO;
-  float* in = reinterpret_cast<float*>(smem4);   // CIN x LP
-  float* dc = in + CIN * LP;                     // COUT x LPO
-  float* ws = dc + COUT * LPO;                   // weights
-  float* gws = ws + nw;                          // weight-gradient accumulators
+  const bool has_b = st.b.z != nullptr, want_din = st.a.G != nullptr;
+  const bool acc_a = want_din && st.a.accumulate != 0;
+  float* in = reinterpret_cast<float*>(smem4);                        // WP x CIN x LP   conv operand
+  float* zra = in + WP * CIN * LP;                                    // WP x CIN x LP   raw z of operand a (want_din)
+  float* aux = zra + (want_din ? WP * CIN * LP : 0);                  // WP x CIN x LP   raw z of operand b | old G_a
+  float* dc = aux + ((has_b || acc_a) ? WP * CIN * LP : 0);           // WP x COUT x LPO gradient at the conv output
+  float* ws = dc + WP * COUT * LPO;              // weights
+  float* gws = ws + nw;                          // weight-gradient partial of the workgroup
   float* ca = gws + nw; float* cb = ca + 4 * MAXC; float* cr = cb + 4 * MAXC; float* co_ = cr + 4 * MAXC;
   float* sa = co_ + 5 * MAXC; float* sb = sa + 2 * MAXC; float* sr = sb + 2 * MAXC;
   float* gbs = sr + 2 * MAXC;                    // MAXC bias grads + 4*MAXC scratch
-  for (int i = threadIdx.x; i < nw; i += blockDim.x) { ws[i] = st.w[i]; gws[i] = 0.f; }
+  copy_flat(ws, st.w, nw >> 2);
+  for (int i = threadIdx.x; i < nw; i += blockDim.x) gws[i] = 0.f;
   for (int i = threadIdx.x; i < 7 * MAXC; i += blockDim.x) sa[i] = 0.f;   // sa, sb, sr, gbs[0:MAXC]
-  for (int i = threadIdx.x; i < CIN * 2 * HALO; i += blockDim.x) {
+  for (int i = threadIdx.x; i < WP * CIN * 2 * HALO; i += blockDim.x) {
     const int c = i / (2 * HALO), h = i % (2 * HALO);
     in[c * LP + (h < HALO ? h : lin + h)] = 0.f;
   }
-  for (int i = threadIdx.x; i < COUT * 2 * HALO; i += blockDim.x) {
+  for (int i = threadIdx.x; i < WP * COUT * 2 * HALO; i += blockDim.x) {
     const int c = i / (2 * HALO), h = i % (2 * HALO);
     dc[c * LPO + (h < HALO ? h : lout + h)] = 0.f;
   }
   src_coeffs(st.a, CIN, st.count_a, ca);
-  if (st.b.z) src_coeffs(st.b, CIN, st.count_b, cb);
+  if (has_b) src_coeffs(st.b, CIN, st.count_b, cb);
   if (st.r.z) src_coeffs(st.r, COUT, st.count_r, cr);
   if (st.type != TY_PLAIN) {   // BN-backward coefficients of this stage's output
-    Src o; o.norm = NORM_BATCH; o.sums = st.sums_out; o.gamma = st.gamma_out; o.beta = st.gamma_out; o.act = ACT_NONE;
+    Src o; o.norm = NORM_BATCH; o.sums = st.sums_out; o.nrep = 1; o.gamma = st.gamma_out; o.beta = st.gamma_out; o.act = ACT_NONE;
     float* tmp = gbs + MAXC;
     src_coeffs(o, COUT, st.count, tmp);
-    __syncthreads();
+    __shared__ double brec[64];
+    fold_record(st.bsums_out, st.nrep, brec);
     for (int c = threadIdx.x; c < COUT; c += blockDim.x) {
       co_[c] = st.gamma_out[c] * tmp[3 * COUT + c];                      // gamma * rstd
-      co_[MAXC + c] = (float)(st.bsums_out[c] / st.count);               // mean(G)
-      co_[2 * MAXC + c] = (float)(st.bsums_out[MAXC + c] / st.count);    // mean(G * zhat)
+      co_[MAXC + c] = (float)(brec[c] / st.count);                       // mean(G)
+      co_[2 * MAXC + c] = (float)(brec[MAXC + c] / st.count);            // mean(G * zhat)
       co_[3 * MAXC + c] = tmp[2 * COUT + c];                             // mean
       co_[4 * MAXC + c] = tmp[3 * COUT + c];                             // rstd
     }
   }
   __syncthreads();
-  const int nin = CIN * lin, nout = COUT * lout;
+  const int nin = CIN * lin, nout = COUT * lout, nin4 = nin >> 2, nout4 = nout >> 2;
+  const bool a_lrelu = st.a.act == ACT_LRELU;
   // lanes of a wave that hold the same output channel in the staging loop below (lout / 4 consecutive threads, when
   // that is a power of two and every wave of the loop is full): their sums are combined before the LDS atomic
   const int gq = lout >> 2;
-  const int segw = ((gq & (gq - 1)) == 0 && gq >= 8 && (nout >> 2) % 64 == 0) ? (gq < 64 ? gq : 64) : 1;
-  // weight-gradient accumulator tiles of this wave (16 output channels x 16 (ci, k) pairs each)
-  // wide layers (both channel counts >= 16) run their two products on the fp32 MFMA; the narrow ones, whose tiles would be
-  // mostly padding, keep the scalar loops
-  constexpr bool UNET_BWD_MFMA = CIN >= 16 && COUT >= 16;
-  constexpr int DW_MT = (COUT + 15) / 16, DW_NT = (CIN * KS + 15) / 16, DW_TPW = (DW_MT * DW_NT + 3) / 4;
+  const int segw = ((gq & (gq - 1)) == 0 && gq >= 8 && nout4 % 64 == 0) ? (gq < 64 ? gq : 64) : 1;
+  const int lane = threadIdx.x & 63, r = lane & 15, g4 = lane >> 4, wave = threadIdx.x >> 6;
+  // weight-gradient work units of the workgroup: (tile, position range); layers with fewer than four tiles split the
+  // output positions KSPLIT ways so that every wave has one
+  constexpr int DW_MT = (COUT + 15) / 16, DW_NT = (CIN * KS + 15) / 16, DW_NU = DW_MT * DW_NT;
+  constexpr int KSPLIT = DW_NU >= 4 ? 1 : (4 + DW_NU - 1) / DW_NU, DW_UNITS = DW_NU * KSPLIT, DW_TPW = (DW_UNITS + 3) / 4;
+  const int kchunk = (((lout + 3) >> 2) + KSPLIT - 1) / KSPLIT * 4;     // output positions per split (multiple of 4)
   f32x4 dwacc[DW_TPW];
 #pragma unroll
   for (int ti = 0; ti < DW_TPW; ++ti) dwacc[ti] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int win = blockIdx.x; win < B; win += gridDim.x) {
-    const float* za = st.a.z + (size_t)win * nin;
-    const float* zb = st.b.z ? st.b.z + (size_t)win * nin : nullptr;
-    for (int i = threadIdx.x; i < (nin >> 2); i += blockDim.x) {
-      const int e = i << 2, c = e / lin, p = e - c * lin;
-      float4 v = *reinterpret_cast<const float4*>(za + e);
-      const float s = ca[c], h = ca[CIN + c];
-      v = make_float4(v.x * s + h, v.y * s + h, v.z * s + h, v.w * s + h);
-      if (st.a.act == ACT_LRELU) v = make_float4(lrelu01(v.x), lrelu01(v.y), lrelu01(v.z), lrelu01(v.w));
-      if (zb) {
-        const float4 u = *reinterpret_cast<const float4*>(zb + e);
-        const float s2 = cb[c], h2 = cb[CIN + c];
-        v.x += lrelu01(u.x * s2 + h2); v.y += lrelu01(u.y * s2 + h2); v.z += lrelu01(u.z * s2 + h2); v.w += lrelu01(u.w * s2 + h2);
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int w0 = blockIdx.x * WP; w0 < B; w0 += gridDim.x * WP) {
+    const int nwin = (B - w0) < WP ? (B - w0) : WP;
+    // ---- load phase ----
+    {
+      const float4* za = reinterpret_cast<const float4*>(st.a.z + (size_t)w0 * nin);
+      const float4* zx = has_b ? reinterpret_cast<const float4*>(st.b.z + (size_t)w0 * nin)
+                               : (acc_a ? reinterpret_cast<const float4*>(st.a.G + (size_t)w0 * nin) : nullptr);
+      auto put = [&](int i, float4 v, float4 u) {
+        const int wi = i / nin4, e = (i - wi * nin4) << 2, c = e / lin, p = e - c * lin;
+        const int o = (wi * CIN + c) * LP + HALO + p;
+        if (want_din) *reinterpret_cast<float4*>(zra + o) = v;
+        if (zx) *reinterpret_cast<float4*>(aux + o) = u;
+        const float s = ca[c], h = ca[CIN + c];
+        v = make_float4(v.x * s + h, v.y * s + h, v.z * s + h, v.w * s + h);
+        if (a_lrelu) v = make_float4(lrelu01(v.x), lrelu01(v.y), lrelu01(v.z), lrelu01(v.w));
+        if (has_b) {
+          const float s2 = cb[c], h2 = cb[CIN + c];
+          v.x += lrelu01(u.x * s2 + h2); v.y += lrelu01(u.y * s2 + h2); v.z += lrelu01(u.z * s2 + h2); v.w += lrelu01(u.w * s2 + h2);
+        }
+        *reinterpret_cast<float4*>(in + o) = v;
+      };
+      constexpr int U = 4;
+      const int n4 = nwin * nin4, bd = blockDim.x;
+      int i = threadIdx.x;
+      for (; i + (U - 1) * bd < n4; i += U * bd) {
+        float4 v[U], u[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) v[k] = za[i + k * bd];
+        if (zx) {
+#pragma unroll
+          for (int k = 0; k < U; ++k) u[k] = zx[i + k * bd];
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) put(i + k * bd, v[k], u[k]);
       }
-      *reinterpret_cast<float4*>(in + c * LP + HALO + p) = v;
+      for (; i < n4; i += bd) put(i, za[i], zx ? zx[i] : zero4);
     }
-    // gradient at the conv output (+ bias gradient, + gradient of the residual operand)
-    for (int i = threadIdx.x; i < (nout >> 2); i += blockDim.x) {
-      const int e = i << 2, c = e / lout, p = e - c * lout;
-      const size_t o = (size_t)win * nout + e;
-      const float4 g4 = *reinterpret_cast<const float4*>(st.Gout + o);
-      float g[4] = {g4.x, g4.y, g4.z, g4.w};
-      if (st.type != TY_PLAIN) {
-        const float4 z4 = *reinterpret_cast<const float4*>(st.out + o);
-        const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
-        const float k = co_[c], m1 = co_[MAXC + c], m2 = co_[2 * MAXC + c], mu = co_[3 * MAXC + c], rs = co_[4 * MAXC + c];
+    {   // gradient at the conv output (+ bias gradient, + gradient of the residual operand)
+      const float4* G4 = reinterpret_cast<const float4*>(st.Gout + (size_t)w0 * nout);
+      const float4* Z4 = st.type != TY_PLAIN ? reinterpret_cast<const float4*>(st.out + (size_t)w0 * nout) : nullptr;
+      const bool has_r = st.r.z && st.r.G;
+      const float4* R4 = has_r ? reinterpret_cast<const float4*>(st.r.z + (size_t)w0 * nout) : nullptr;
+      float4* RG4 = has_r ? reinterpret_cast<float4*>(st.r.G + (size_t)w0 * nout) : nullptr;
+      auto putg = [&](int i, float4 g4v, float4 z4, float4 zr) {
+        const int wi = i / nout4, e = (i - wi * nout4) << 2, c = e / lout, p = e - c * lout;
+        float g[4] = {g4v.x, g4v.y, g4v.z, g4v.w};
+        if (Z4) {
+          const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
+          const float k = co_[c], m1 = co_[MAXC + c], m2 = co_[2 * MAXC + c], mu = co_[3 * MAXC + c], rs = co_[4 * MAXC + c];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float zh = (zz[j] - mu) * rs;
-          float v = k * (g[j] - m1 - zh * m2);
-          if (st.type == TY_ABN && zz[j] <= 0.f) v *= 0.01f;   // stored tensor is lrelu(conv)
-          g[j] = v;
+          for (int j = 0; j < 4; ++j) {
+            const float zh = (zz[j] - mu) * rs;
+            float v = k * (g[j] - m1 - zh * m2);
+            if (st.type == TY_ABN && zz[j] <= 0.f) v *= 0.01f;   // stored tensor is lrelu(conv)
+            g[j] = v;
+          }
         }
-      }
-      *reinterpret_cast<float4*>(dc + c * LPO + HALO + p) = make_float4(g[0], g[1], g[2], g[3]);
-      seg_atomic(gbs + c, (g[0] + g[1]) + (g[2] + g[3]), segw);
-      if (st.r.z && st.r.G) {   // residual operand lrelu(BN(z_r)) was added to the output: its gradient is Gout * lrelu'
-        const float4 zr = *reinterpret_cast<const float4*>(st.r.z + o);
-        const float zrr[4] = {zr.x, zr.y, zr.z, zr.w}, gg[4] = {g4.x, g4.y, g4.z, g4.w};
-        const float s = cr[c], h = cr[COUT + c], mu = cr[2 * COUT + c], rs = cr[3 * COUT + c];
-        float gr[4], s1 = 0.f, s2 = 0.f;
+        *reinterpret_cast<float4*>(dc + (wi * COUT + c) * LPO + HALO + p) = make_float4(g[0], g[1], g[2], g[3]);
+        seg_atomic(gbs + c, (g[0] + g[1]) + (g[2] + g[3]), segw);
+        if (has_r) {   // residual operand lrelu(BN(z_r)) was added to the output: its gradient is Gout * lrelu'
+          const float zrr[4] = {zr.x, zr.y, zr.z, zr.w}, gg[4] = {g4v.x, g4v.y, g4v.z, g4v.w};
+          const float s = cr[c], h = cr[COUT + c], mu = cr[2 * COUT + c], rs = cr[3 * COUT + c];
+          float gr[4], s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          gr[j] = (zrr[j] * s + h <= 0.f) ? 0.01f * gg[j] : gg[j];
-          s1 += gr[j]; s2 += gr[j] * (zrr[j] - mu) * rs;
+          for (int j = 0; j < 4; ++j) {
+            gr[j] = (zrr[j] * s + h <= 0.f) ? 0.01f * gg[j] : gg[j];
+            s1 += gr[j]; s2 += gr[j] * (zrr[j] - mu) * rs;
+          }
+          float4 outv = make_float4(gr[0], gr[1], gr[2], gr[3]);
+          if (st.r.accumulate) outv = f4add(outv, RG4[i]);
+          RG4[i] = outv;
+          seg_atomic(sr + c, s1, segw); seg_atomic(sr + MAXC + c, s2, segw);
         }
-        float4* dst = reinterpret_cast<float4*>(st.r.G + o);
-        float4 outv = make_float4(gr[0], gr[1], gr[2], gr[3]);
-        if (st.r.accumulate) outv = f4add(outv, *dst);
-        *dst = outv;
-        seg_atomic(sr + c, s1, segw); seg_atomic(sr + MAXC + c, s2, segw);
+      };
+      constexpr int U = 4;
+      const int n4 = nwin * nout4, bd = blockDim.x;
+      int i = threadIdx.x;
+      for (; i + (U - 1) * bd < n4; i += U * bd) {
+        float4 gv[U], zv[U], rv[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) gv[k] = G4[i + k * bd];
+        if (Z4) {
+#pragma unroll
+          for (int k = 0; k < U; ++k) zv[k] = Z4[i + k * bd];
+        }
+        if (has_r) {
+#pragma unroll
+          for (int k = 0; k < U; ++k) rv[k] = R4[i + k * bd];
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) putg(i + k * bd, gv[k], zv[k], rv[k]);
       }
+      for (; i < n4; i += bd) putg(i, G4[i], Z4 ? Z4[i] : zero4, has_r ? R4[i] : zero4);
     }
     __syncthreads();
-    // gradient epilogue of one (input channel, 4 positions) unit: activation derivative, store (to one or two producers),
-    // and the unit's contributions to the BatchNorm-backward sums
-    auto emit = [&](int ci, int p0, const float (&acc)[4], bool valid, float& s1a, float& s2a, float& s1b, float& s2b) {
-      const size_t o = (size_t)win * nin + (size_t)(valid ? ci : 0) * lin + (valid ? p0 : 0);
-      s1a = 0.f; s2a = 0.f; s1b = 0.f; s2b = 0.f;
-      if (valid) {
-        const float4 z4 = *reinterpret_cast<const float4*>(za + (size_t)ci * lin + p0);
-        const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
-        const float s = ca[ci], h = ca[CIN + ci], mu = ca[2 * CIN + ci], rs = ca[3 * CIN + ci];
-        float ga[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          ga[j] = (st.a.act == ACT_LRELU && zz[j] * s + h <= 0.f) ? 0.01f * acc[j] : acc[j];
-          s1a += ga[j]; s2a += ga[j] * (zz[j] - mu) * rs;
-        }
-        float4* dst = reinterpret_cast<float4*>(st.a.G + o);
-        float4 outv = make_float4(ga[0], ga[1], ga[2], ga[3]);
-        if (st.a.accumulate) outv = f4add(outv, *dst);
-        *dst = outv;
-      }
-      if (valid && zb && st.b.G) {
-        const float4 z4 = *reinterpret_cast<const float4*>(zb + (size_t)ci * lin + p0);
-        const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
-        const float s = cb[ci], h = cb[CIN + ci], mu = cb[2 * CIN + ci], rs = cb[3 * CIN + ci];
-        float gb4[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          gb4[j] = (zz[j] * s + h <= 0.f) ? 0.01f * acc[j] : acc[j];
-          s1b += gb4[j]; s2b += gb4[j] * (zz[j] - mu) * rs;
-        }
-        float4* dst = reinterpret_cast<float4*>(st.b.G + o);
-        float4 outv = make_float4(gb4[0], gb4[1], gb4[2], gb4[3]);
-        if (st.b.accumulate) outv = f4add(outv, *dst);
-        *dst = outv;
-      }
-    };
-    // ---- input gradient: d_in[ci][p] = sum over (co, k) of W(co, ci, k) * D(co, k, p) as fp32-MFMA tiles of 16 positions
-    // x 16 input channels, K = COUT * KS in steps of 4; both operands are gathered from the LDS tiles by index (the zero
-    // halos of `dc` cover the taps that fall outside), so no im2col copy exists.  A lane ends with 4 consecutive
-    // positions of one input channel - the unit the epilogue below (activation derivative, BatchNorm-backward sums,
-    // store) works on.
-    if (st.a.G) {
-      if constexpr (UNET_BWD_MFMA) {
-        constexpr int KTOT = COUT * KS, CT = (CIN + 15) / 16;
-        const int lane = threadIdx.x & 63, r = lane & 15, g4 = lane >> 4, wave = threadIdx.x >> 6, nwv = blockDim.x >> 6;
-        const int ptiles = (lin + 15) >> 4;
-        for (int tile = wave; tile < ptiles * CT; tile += nwv) {
-          const int pt = tile / CT, n0 = pt << 4, m0 = (tile - pt * CT) << 4;
-          const int pos = n0 + r, cib = m0 + r;
-          const bool pok = pos < lin, cok = cib < CIN;
-          f32x4 accv = {0.f, 0.f, 0.f, 0.f};
+    // ---- input gradient ----
+    if (want_din) {
+      constexpr int KTOT = COUT * KS, CT = (CIN + 15) / 16;
+      const int ptiles = (lin + 15) >> 4;
+      for (int tile = wave; tile < nwin * ptiles * CT; tile += 4) {
+        const int wi = tile / (ptiles * CT), t2 = tile - wi * ptiles * CT, pt = t2 / CT, n0 = pt << 4, m0 = (t2 - pt * CT) << 4;
+        const int pos = n0 + r, cib = m0 + r;
+        const bool pok = pos < lin, cok = cib < CIN;
+        const float* dcw = dc + wi * COUT * LPO;
+        f32x4 accv = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
-          for (int kk0 = 0; kk0 < KTOT; kk0 += 4) {
-            const int kk = kk0 + g4, co = kk / KS, k = kk - co * KS;
-            const bool kok = (KTOT % 4 == 0) || kk < KTOT;
-            float av = 0.f, bv = 0.f;
-            if (pok && kok) {
-              if constexpr (MODE == 1) av = dc[co * LPO + HALO + pos + (KS - 1) / 2 - k];
-              else if constexpr (MODE == 0) { const int t = pos + 1 - k; av = (t & 1) ? 0.f : dc[co * LPO + HALO + (t >> 1)]; }
-              else av = dc[co * LPO + HALO + 2 * pos - 1 + k];
-            }
-            if (cok && kok) bv = (MODE == 2) ? ws[(cib * COUT + co) * KS + k] : ws[(co * CIN + cib) * KS + k];
-            accv = mfma4(av, bv, accv);
+        for (int kk0 = 0; kk0 < KTOT; kk0 += 4) {
+          const int kk = kk0 + g4, co = kk / KS, k = kk - co * KS;
+          const bool kok = (KTOT % 4 == 0) || kk < KTOT;
+          float av = 0.f, bv = 0.f;
+          if (pok && kok) {
+            if constexpr (MODE == 1) av = dcw[co * LPO + HALO + pos + (KS - 1) / 2 - k];
+            else if constexpr (MODE == 0) { const int t = pos + 1 - k; av = (t & 1) ? 0.f : dcw[co * LPO + HALO + (t >> 1)]; }
+            else av = dcw[co * LPO + HALO + 2 * pos - 1 + k];
           }
+          if (cok && kok) bv = (MODE == 2) ? ws[(cib * COUT + co) * KS + k] : ws[(co * CIN + cib) * KS + k];
+          accv = mfma4(av, bv, accv);
+        }
+        // epilogue of the lane's (input channel cib, positions p0 .. p0 + 3): activation derivative, store (to one or two
+        // producers), contributions to their BatchNorm-backward sums - all operands from the LDS
+        const int p0 = n0 + 4 * g4;
+        const bool valid = cok && p0 < lin;
+        float s1a = 0.f, s2a = 0.f, s1b = 0.f, s2b = 0.f;
+        if (valid) {
+          const int o = (wi * CIN + cib) * LP + HALO + p0;
+          const size_t og = (size_t)(w0 + wi) * nin + (size_t)cib * lin + p0;
           const float acc[4] = {accv[0], accv[1], accv[2], accv[3]};
-          float s1a, s2a, s1b, s2b;
-          emit(cib, n0 + 4 * g4, acc, cok && n0 + 4 * g4 < lin, s1a, s2a, s1b, s2b);
-          // the sums of a channel are added up across the four position groups of the tile (lanes r, r + 16, r + 32,
-          // r + 48) before ONE LDS atomic per channel and tile: same-address LDS atomics of a wave run one after the other
-          const int ci = cib;
-          s1a = rows_sum(s1a); s2a = rows_sum(s2a);
-          if (g4 == 0 && cok && st.a.bsums) { atomicAdd(sa + ci, s1a); atomicAdd(sa + MAXC + ci, s2a); }
-          if (zb && st.b.G) {
-            s1b = rows_sum(s1b); s2b = rows_sum(s2b);
-            if (g4 == 0 && cok) { atomicAdd(sb + ci, s1b); atomicAdd(sb + MAXC + ci, s2b); }
+          const float4 z4 = *reinterpret_cast<const float4*>(zra + o);
+          const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
+          const float s = ca[cib], h = ca[CIN + cib], mu = ca[2 * CIN + cib], rs = ca[3 * CIN + cib];
+          float ga[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            ga[j] = (a_lrelu && zz[j] * s + h <= 0.f) ? 0.01f * acc[j] : acc[j];
+            s1a += ga[j]; s2a += ga[j] * (zz[j] - mu) * rs;
+          }
+          float4 outv = make_float4(ga[0], ga[1], ga[2], ga[3]);
+          if (acc_a) outv = f4add(outv, *reinterpret_cast<const float4*>(aux + o));
+          *reinterpret_cast<float4*>(st.a.G + og) = outv;
+          if (has_b && st.b.G) {
+            const float4 y4 = *reinterpret_cast<const float4*>(aux + o);
+            const float yy[4] = {y4.x, y4.y, y4.z, y4.w};
+            const float sB = cb[cib], hB = cb[CIN + cib], muB = cb[2 * CIN + cib], rsB = cb[3 * CIN + cib];
+            float gb4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              gb4[j] = (yy[j] * sB + hB <= 0.f) ? 0.01f * acc[j] : acc[j];
+              s1b += gb4[j]; s2b += gb4[j] * (yy[j] - muB) * rsB;
+            }
+            float4 ob = make_float4(gb4[0], gb4[1], gb4[2], gb4[3]);
+            if (st.b.accumulate) ob = f4add(ob, *reinterpret_cast<const float4*>(st.b.G + og));
+            *reinterpret_cast<float4*>(st.b.G + og) = ob;
           }
         }
-      } else {
-        const int q = lin >> 2;
-        for (int slot = threadIdx.x; slot < CIN * q; slot += blockDim.x) {
-          const int ci = slot / q, p0 = (slot - ci * q) << 2;
-          float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-          for (int co = 0; co < COUT; ++co) {
-            const float* row = dc + co * LPO + HALO;
-            if constexpr (MODE == 0) {         // out[l] = sum_k w[k] in[2l-1+k]
-              const float* wr = ws + (co * CIN + ci) * 3;
-              const float w0 = wr[0], w1 = wr[1], w2 = wr[2];
-              const int h = p0 >> 1;
-              const float d0 = row[h], d1 = row[h + 1], d2 = row[h + 2];
-              acc[0] = fmaf(w1, d0, acc[0]);
-              acc[1] = fmaf(w0, d1, fmaf(w2, d0, acc[1]));
-              acc[2] = fmaf(w1, d1, acc[2]);
-              acc[3] = fmaf(w0, d2, fmaf(w2, d1, acc[3]));
-            } else if constexpr (MODE == 1 && KS == 3) {   // out[l] = sum_k w[k] in[l-1+k]  =>  d_in[p] = sum_k w[k] dc[p+1-k]
-              const float* wr = ws + (co * CIN + ci) * 3;
-              const float w0 = wr[0], w1 = wr[1], w2 = wr[2];
-              float d[6];
-#pragma unroll
-              for (int t = 0; t < 6; ++t) d[t] = row[p0 - 1 + t];
-#pragma unroll
-              for (int j = 0; j < 4; ++j) acc[j] = fmaf(w0, d[j + 2], fmaf(w1, d[j + 1], fmaf(w2, d[j], acc[j])));
-            } else if constexpr (MODE == 1) {
-              const float w0 = ws[co * CIN + ci];
-              const float4 d = *reinterpret_cast<const float4*>(row + p0);
-              acc[0] = fmaf(w0, d.x, acc[0]); acc[1] = fmaf(w0, d.y, acc[1]); acc[2] = fmaf(w0, d.z, acc[2]); acc[3] = fmaf(w0, d.w, acc[3]);
-            } else {                           // d_in[i] = sum_k w[ci][co][k] dc[2i-1+k]
-              const float* wr = ws + (ci * COUT + co) * 4;
-              const float w0 = wr[0], w1 = wr[1], w2 = wr[2], w3 = wr[3];
-              float d[10];
-#pragma unroll
-              for (int t = 0; t < 10; ++t) d[t] = row[2 * p0 - 1 + t];
-#pragma unroll
-              for (int j = 0; j < 4; ++j)
-                acc[j] = fmaf(w0, d[2 * j], fmaf(w1, d[2 * j + 1], fmaf(w2, d[2 * j + 2], fmaf(w3, d[2 * j + 3], acc[j]))));
-            }
-          }
-          float s1a, s2a, s1b, s2b;
-          emit(ci, p0, acc, true, s1a, s2a, s1b, s2b);
-          if (st.a.bsums) { atomicAdd(sa + ci, s1a); atomicAdd(sa + MAXC + ci, s2a); }
-          if (zb && st.b.G) { atomicAdd(sb + ci, s1b); atomicAdd(sb + MAXC + ci, s2b); }
+        // the sums of a channel are added up across the four position groups of the tile (lanes r, r + 16, r + 32,
+        // r + 48) before ONE LDS atomic per channel and tile: same-address LDS atomics of a wave run one after the other
+        s1a = rows_sum(s1a); s2a = rows_sum(s2a);
+        if (g4 == 0 && cok && st.a.bsums) { atomicAdd(sa + cib, s1a); atomicAdd(sa + MAXC + cib, s2a); }
+        if (has_b && st.b.G) {
+          s1b = rows_sum(s1b); s2b = rows_sum(s2b);
+          if (g4 == 0 && cok) { atomicAdd(sb + cib, s1b); atomicAdd(sb + MAXC + cib, s2b); }
         }
       }
     }
-    if constexpr (UNET_BWD_MFMA) {
-      // ---- weight gradient: gw(co, ci, k) += sum_p dc[co][p] * I(ci, k, p) as MFMA tiles of 16 output channels x 16
-      // (ci, k) pairs, K = output positions in steps of 4; the tiles a wave owns stay in its accumulators across the
-      // windows of the workgroup (flushed after the window loop).
-      {
-        const int lane = threadIdx.x & 63, r = lane & 15, g4 = lane >> 4, wave = threadIdx.x >> 6, nwv = blockDim.x >> 6;
-#pragma unroll
-        for (int ti = 0; ti < DW_TPW; ++ti) {
-          const int tile = dw_tile(wave + ti * nwv, DW_TPW * nwv);
-          if (tile >= DW_MT * DW_NT) continue;
-          const int m0 = (tile / DW_NT) << 4, n0 = (tile % DW_NT) << 4;
-          const int co = m0 + r, nn = n0 + r, ci = nn / KS, k = nn - ci * KS;
-          const bool cook = co < COUT, nok = nn < CIN * KS;
-          const float* dr = dc + (cook ? co : 0) * LPO + HALO;
-          const float* ir = in + (nok ? ci : 0) * LP + HALO;
-          f32x4 accw = dwacc[ti];
-          for (int q0 = 0; q0 < lout; q0 += 4) {
-            const int pp = q0 + g4;
-            const bool pk = pp < lout;
-            float av = 0.f, bv = 0.f;
-            if (cook && pk) av = dr[pp];
-            if (nok && pk) {
-              if constexpr (MODE == 1) bv = ir[pp - (KS - 1) / 2 + k];
-              else if constexpr (MODE == 0) bv = ir[2 * pp - 1 + k];
-              else { const int t = pp + 1 - k; bv = (t & 1) ? 0.f : ir[t >> 1]; }
-            }
-            accw = mfma4(av, bv, accw);
-          }
-          dwacc[ti] = accw;
-        }
-      }
-    } else {
-      // ---- weight gradient: unit = (co, ci, chunk of output positions) ----
-      {
-        constexpr int CH = 32;
-        const int nchunk = (lout + CH - 1) / CH;
-        for (int u = threadIdx.x; u < COUT * CIN * nchunk; u += blockDim.x) {
-          const int pair = u / nchunk, chn = u - pair * nchunk;
-          const int co = pair / CIN, ci = pair - co * CIN;
-          const int l0 = chn * CH, l1 = (l0 + CH < lout) ? l0 + CH : lout;
-          const float* dr = dc + co * LPO + HALO;
-          const float* ir = in + ci * LP + HALO;
-          float g[KS];
-#pragma unroll
-          for (int k = 0; k < KS; ++k) g[k] = 0.f;
-          for (int l = l0; l < l1; ++l) {
-            const float d = dr[l];
-            if constexpr (MODE == 0) {
-#pragma unroll
-              for (int k = 0; k < 3; ++k) g[k] = fmaf(d, ir[2 * l - 1 + k], g[k]);
-            } else if constexpr (MODE == 1) {
-#pragma unroll
-              for (int k = 0; k < KS; ++k) g[k] = fmaf(d, ir[l - (KS - 1) / 2 + k], g[k]);
-            } else {   // out[j] += w[k] in[i], j = 2i-1+k  =>  gw[k] += dc[j] in[(j+1-k)/2] for matching parity
-              const int k0 = (l + 1) & 1, i0 = (l + 1 - k0) >> 1;
-              g[k0] = fmaf(d, ir[i0], g[k0]);         // inactive taps of this parity keep their value
-              g[k0 + 2] = fmaf(d, ir[i0 - 1], g[k0 + 2]);
-            }
-          }
-          float* gd = (MODE == 2) ? gws + (ci * COUT + co) * KS : gws + (co * CIN + ci) * KS;
-#pragma unroll
-          for (int k = 0; k < KS; ++k) atomicAdd(gd + k, g[k]);
-        }
-      }
-    }
-    __syncthreads();
-  }
-  if constexpr (!UNET_BWD_MFMA) {
-    for (int i = threadIdx.x; i < nw; i += blockDim.x) atomicAdd(st.gw + i, gws[i]);
-  } else {   // weight-gradient tiles: lane (r, g) holds rows co = m0 + 4 g + v of column nn = n0 + r
-    const int lane = threadIdx.x & 63, r = lane & 15, g4 = lane >> 4, wave = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+    // ---- weight gradient ----
 #pragma unroll
     for (int ti = 0; ti < DW_TPW; ++ti) {
-      const int tile = dw_tile(wave + ti * nwv, DW_TPW * nwv);
-      if (tile >= DW_MT * DW_NT) continue;
-      const int m0 = (tile / DW_NT) << 4, n0 = (tile % DW_NT) << 4, nn = n0 + r;
-      if (nn >= CIN * KS) continue;
-      const int ci = nn / KS, k = nn - ci * KS;
+      const int unit = wave + ti * 4;
+      if (unit >= DW_UNITS) continue;
+      const int tile = unit / KSPLIT, ks = unit - tile * KSPLIT;
+      const int m0 = (tile / DW_NT) << 4, n0 = (tile % DW_NT) << 4;
+      const int co = m0 + r, nn = n0 + r, ci = nn / KS, k = nn - ci * KS;
+      const bool cook = co < COUT, nok = nn < CIN * KS;
+      const int q_lo = ks * kchunk, q_hi = (q_lo + kchunk) < lout ? (q_lo + kchunk) : lout;
+      f32x4 accw = dwacc[ti];
+      for (int wi = 0; wi < nwin; ++wi) {
+        const float* dr = dc + (wi * COUT + (cook ? co : 0)) * LPO + HALO;
+        const float* ir = in + (wi * CIN + (nok ? ci : 0)) * LP + HALO;
+        for (int q0 = q_lo; q0 < q_hi; q0 += 4) {
+          const int pp = q0 + g4;
+          const bool pk = pp < q_hi;
+          float av = 0.f, bv = 0.f;
+          if (cook && pk) av = dr[pp];
+          if (nok && pk) {
+            if constexpr (MODE == 1) bv = ir[pp - (KS - 1) / 2 + k];
+            else if constexpr (MODE == 0) bv = ir[2 * pp - 1 + k];
+            else { const int t = pp + 1 - k; bv = (t & 1) ? 0.f : ir[t >> 1]; }
+          }
+          accw = mfma4(av, bv, accw);
+        }
+      }
+      dwacc[ti] = accw;
+    }
+    __syncthreads();
+  }
+  // ---- the workgroup's partial sums leave ----
+  // weight-gradient tiles: lane (r, g) holds rows co = m0 + 4 g + v of column nn = n0 + r; position splits of one tile meet
+  // in the LDS copy of the weight tensor
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int co = m0 + 4 * g4 + v;
-        if (co < COUT) atomicAdd(st.gw + ((MODE == 2) ? (ci * COUT + co) * KS + k : co * CIN * KS + nn), dwacc[ti][v]);
+  for (int ti = 0; ti < DW_TPW; ++ti) {
+    const int unit = wave + ti * 4;
+    if (unit >= DW_UNITS) continue;
+    const int tile = unit / KSPLIT;
+    const int m0 = (tile / DW_NT) << 4, n0 = (tile % DW_NT) << 4, nn = n0 + r;
+    if (nn >= CIN * KS) continue;
+    const int ci = nn / KS, k = nn - ci * KS;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int co = m0 + 4 * g4 + v;
+      if (co < COUT) {
+        float* dst = gws + ((MODE == 2) ? (ci * COUT + co) * KS + k : co * CIN * KS + nn);
+        if (KSPLIT == 1) *dst = dwacc[ti][v]; else atomicAdd(dst, dwacc[ti][v]);
       }
     }
   }
-  if ((int)threadIdx.x < COUT) atomicAdd(st.gb + threadIdx.x, gbs[threadIdx.x]);
+  __syncthreads();
+  if (st.part) {
+    float* row = st.part + (size_t)blockIdx.x * st.part_stride;
+    for (int i = threadIdx.x; i < (nw >> 2); i += blockDim.x)
+      reinterpret_cast<float4*>(row + st.part_w)[i] = reinterpret_cast<const float4*>(gws)[i];
+    if ((int)threadIdx.x < COUT) row[st.part_b + threadIdx.x] = gbs[threadIdx.x];
+  } else {
+    for (int i = threadIdx.x; i < nw; i += blockDim.x) atomicAdd(st.gw + i, gws[i]);
+    if ((int)threadIdx.x < COUT) atomicAdd(st.gb + threadIdx.x, gbs[threadIdx.x]);
+  }
   if ((int)threadIdx.x < CIN) {
     if (st.a.G && st.a.bsums) {
-      atomicAdd(st.a.bsums + threadIdx.x, (double)sa[threadIdx.x]);
-      atomicAdd(st.a.bsums + MAXC + threadIdx.x, (double)sa[MAXC + threadIdx.x]);
+      double* rec = st.a.bsums + (size_t)(blockIdx.x % st.nrep) * 64;
+      atomicAdd(rec + threadIdx.x, (double)sa[threadIdx.x]);
+      atomicAdd(rec + MAXC + threadIdx.x, (double)sa[MAXC + threadIdx.x]);
     }
     if (st.b.z && st.b.G) {
-      atomicAdd(st.b.bsums + threadIdx.x, (double)sb[threadIdx.x]);
-      atomicAdd(st.b.bsums + MAXC + threadIdx.x, (double)sb[MAXC + threadIdx.x]);
+      double* rec = st.b.bsums + (size_t)(blockIdx.x % st.nrep) * 64;
+      atomicAdd(rec + threadIdx.x, (double)sb[threadIdx.x]);
+      atomicAdd(rec + MAXC + threadIdx.x, (double)sb[MAXC + threadIdx.x]);
     }
   }
   if (st.r.z && st.r.G && (int)threadIdx.x < COUT) {
-    atomicAdd(st.r.bsums + threadIdx.x, (double)sr[threadIdx.x]);
-    atomicAdd(st.r.bsums + MAXC + threadIdx.x, (double)sr[MAXC + threadIdx.x]);
+    double* rec = st.r.bsums + (size_t)(blockIdx.x % st.nrep) * 64;
+    atomicAdd(rec + threadIdx.x, (double)sr[threadIdx.x]);
+    atomicAdd(rec + MAXC + threadIdx.x, (double)sr[MAXC + threadIdx.x]);
   }
 }
 
-// BatchNorm affine gradients of all layers from the backward sums: g_gamma = S2, g_beta = S1
-struct BnGrad { const double* bsums; float* gw; float* gb; int C; };
+// Fold of the per-workgroup weight / bias gradient partials (rows x stride scratch matrix written by k_unet_bwd_t) into the
+// gradient buffer: a workgroup owns 64 consecutive columns of the conv-parameter column list `cols`, its four waves take a
+// quarter of the rows each (256-byte row pieces), the quarters meet in LDS.  Fixed summation order: the conv gradients
+// are bit-for-bit reproducible run to run.  The last workgroup writes the BatchNorm affine gradients from the backward
+// sums (g_gamma = S2, g_beta = S1).
+// `bsums`: the backward record in nrep replicas; `final_`: the caller-visible bn_sums record, written when they differ
+struct BnGrad { const double* bsums; double* final_; float* gw; float* gb; int C; int nrep; };
 struct BnGradAll { BnGrad l[10]; };
+RAL_DEV void bn_affine_grads(const BnGrad& b, int c, double share) {
+  if (c >= b.C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < b.nrep; ++k) { s1 += b.bsums[(size_t)k * 64 + c]; s2 += b.bsums[(size_t)k * 64 + MAXC + c]; }
+  if (b.final_ != b.bsums) { b.final_[c] = s1; b.final_[MAXC + c] = s2; }
+  b.gb[c] = (float)(s1 * share); b.gw[c] = (float)(s2 * share);
+}
+__global__ __launch_bounds__(256) void k_unet_fold(const float* __restrict__ part, int64_t stride, int rows, const int* __restrict__ cols,
+                                                   int ncols, float* __restrict__ grads, BnGradAll u, double share) {
+  if (blockIdx.x == gridDim.x - 1) {
+    for (int t = threadIdx.x; t < 10 * MAXC; t += blockDim.x) bn_affine_grads(u.l[t / MAXC], t % MAXC, share);
+    return;
+  }
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + lane;
+  const int col = j < ncols ? cols[j] : -1;
+  float acc = 0.f;
+  if (col >= 0) {
+    const int r0 = (int)((int64_t)rows * wave / 4), r1 = (int)((int64_t)rows * (wave + 1) / 4);
+    int rr = r0;
+    for (; rr + 8 <= r1; rr += 8) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = part[(size_t)(rr + k) * stride + col];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc += v[k];
+    }
+    for (; rr < r1; ++rr) acc += part[(size_t)rr * stride + col];
+  }
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && col >= 0) grads[col] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+// BatchNorm affine gradients of all layers from the backward sums: g_gamma = S2, g_beta = S1 (the path without the fold)
 // `share` = local / global windows: under data parallelism the sums are global and the later gradient all-reduce adds
 // the ranks' copies, so each rank contributes its share
 __global__ void k_unet_bn_grads(BnGradAll u, double share) {
-  const BnGrad& b = u.l[blockIdx.x];
-  const int c = threadIdx.x;
-  if (c < b.C) { b.gb[c] = (float)(b.bsums[c] * share); b.gw[c] = (float)(b.bsums[MAXC + c] * share); }
+  bn_affine_grads(u.l[blockIdx.x], threadIdx.x, share);
 }
 
 // =================================================================================
@@ -1271,7 +1361,16 @@ struct UNetModel {
   float* G[11];       // gradients at the BatchNorm outputs (same indexing; G[6] = d r)
   int C[11], Ln[11];  // channels / length of z[i]
   const float* last_x = nullptr;
+  const float* last_dy = nullptr;   // gradient at the output BatchNorm = the caller's dy (read by the last stage's backward)
   int last_B = 0;
+  // weight / bias gradient partials of the backward stage kernels: one row of `part_stride` floats (the flat parameter
+  // layout) per workgroup, folded by k_unet_fold; `cols` = the flat offsets of all conv weights and biases
+  float* part = nullptr; int64_t part_stride = 0; int part_rows_max = 0;
+  int* cols = nullptr; int ncols = 0;
+  bool fold = false; int bwd_rows = 0;
+  // replicas of the BatchNorm records for the one-call forward / backward (see Stage::nrep): [fwd | bwd][10][UNET_MAXREP][64]
+  double* rep = nullptr;
+  int nrep_f = 1, nrep_b = 1;     // replicas the current forward / backward pass adds to (1: straight into bn_sums)
 };
 
 int unet_check_cfg(const ral_config* c, char* err, size_t cap) {
@@ -1292,6 +1391,7 @@ int unet_layout_entry(const ral_config* c, int idx, char* name, int name_cap, in
 }
 int64_t unet_param_floats(const ral_config* c) { ULayout L; ubuild(*c, L); return L.nparam; }
 int64_t unet_state_floats(const ral_config* c) { ULayout L; ubuild(*c, L); return L.nstate; }
+#define UNET_PART_ROWS 1024   // most workgroups a backward stage is ever launched with
 static size_t unet_plan(const ral_config& c, UNetModel* m, char* base) {
   const int ch[5] = {c.leads, 4, 8, 16, 32};
   const int Cs[11] = {4, 8, 16, 32, 32, 32, 32, 16, 8, 4, ch[0]};
@@ -1305,6 +1405,17 @@ static size_t unet_plan(const ral_config& c, UNetModel* m, char* base) {
     }
   if (m) m->pack = base ? reinterpret_cast<float*>(base + cur) : nullptr;
   cur += ((size_t)uinf::PTOT * sizeof(float) + 255) & ~size_t(255);
+  if (c.train) {
+    ULayout Y; ubuild(c, Y);
+    const int64_t stride = (Y.nparam + 63) & ~int64_t(63);
+    const int rows = c.max_batch < UNET_PART_ROWS ? c.max_batch : UNET_PART_ROWS;
+    if (m) { m->part = base ? reinterpret_cast<float*>(base + cur) : nullptr; m->part_stride = stride; m->part_rows_max = rows; }
+    cur += ((size_t)rows * stride * sizeof(float) + 255) & ~size_t(255);
+    if (m) m->cols = base ? reinterpret_cast<int*>(base + cur) : nullptr;
+    cur += ((size_t)Y.nparam * sizeof(int) + 255) & ~size_t(255);
+    if (m) m->rep = base ? reinterpret_cast<double*>(base + cur) : nullptr;
+    cur += (size_t)2 * 10 * UNET_MAXREP * 64 * sizeof(double);
+  }
   return cur;
 }
 int64_t unet_workspace_bytes(const ral_config* c) { return (int64_t)unet_plan(*c, nullptr, nullptr); }
@@ -1323,6 +1434,26 @@ UNetModel* unet_create(const ral_config* c, char* err, size_t cap) {
   }
   unet_plan(*c, m, m->slab);
   m->fused = !(getenv("RAL_UNET_FUSED") && atoi(getenv("RAL_UNET_FUSED")) == 0);
+  if (c->train) {
+    // the specialised backward kernels (all of them apply when every level's length is a multiple of 4) leave their
+    // weight-gradient partials in scratch rows; otherwise some stage runs the generic kernel and everything stays atomic
+    m->fold = c->L % 64 == 0 && !(getenv("RAL_UNET_FOLD") && atoi(getenv("RAL_UNET_FOLD")) == 0);
+    std::vector<int> cols;
+    const int ch[5] = {c->leads, 4, 8, 16, 32};
+    const int Cs[11] = {4, 8, 16, 32, 32, 32, 32, 16, 8, 4, ch[0]};
+    const int Ci[11] = {ch[0], 4, 8, 16, 32, 32, 32, 32, 16, 8, 4};
+    const int Ks[11] = {3, 3, 3, 3, 1, 3, 1, 4, 4, 4, 4};
+    for (int si = 0; si < 11; ++si) {
+      for (int i = 0; i < Cs[si] * Ci[si] * Ks[si]; ++i) cols.push_back((int)m->lay.w[si] + i);
+      for (int i = 0; i < Cs[si]; ++i) cols.push_back((int)m->lay.b[si] + i);
+    }
+    m->ncols = (int)cols.size();
+    if (hipMemcpy(m->cols, cols.data(), cols.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+      snprintf(err, cap, "hipMemcpy(cols) failed");
+      (void)hipFree(m->slab); delete m;
+      return nullptr;
+    }
+  }
   return m;
 }
 void unet_destroy(UNetModel* u) { if (u) { if (u->slab) (void)hipFree(u->slab); delete u; } }
@@ -1335,6 +1466,8 @@ int unet_bind(UNetModel* u, float* params, float* grads, float* am, float* av, f
 // BatchNorm index feeding each z tensor (z index -> bn index), -1: none (z[6] = r)
 static const int BN_OF_Z[11] = {0, 1, 2, 3, 4, 5, -1, 6, 7, 8, 9};
 
+static double* unet_rep(UNetModel* m, int dir, int bi) { return m->rep + ((size_t)(dir * 10 + bi) * UNET_MAXREP) * 64; }
+
 static Src make_src(UNetModel* m, int zi, int act, bool training, bool with_grad, int accumulate) {
   Src s; memset(&s, 0, sizeof(s));
   const UNetPublic& P = m->pub;
@@ -1342,10 +1475,14 @@ static Src make_src(UNetModel* m, int zi, int act, bool training, bool with_grad
   const int bi = BN_OF_Z[zi];
   if (bi >= 0) {
     s.norm = training ? NORM_BATCH : NORM_RUNNING;
-    s.sums = P.bn_sums ? P.bn_sums + 128 * bi : nullptr;
+    // forward statistics: the stages of a running one-call forward read the replicas their producers add to; everything
+    // after it (and every stage-by-stage caller) reads the folded record in bn_sums
+    const bool frep = !with_grad && m->nrep_f > 1;
+    s.sums = frep ? unet_rep(m, 0, bi) : (P.bn_sums ? P.bn_sums + 128 * bi : nullptr);
+    s.nrep = frep ? m->nrep_f : 1;
     s.gamma = P.params + m->lay.bnw[bi]; s.beta = P.params + m->lay.bnb[bi];
     s.running = P.state + m->lay.run[bi];
-    if (with_grad) s.bsums = P.bn_sums + 128 * bi + 64;
+    if (with_grad) s.bsums = m->nrep_b > 1 ? unet_rep(m, 1, bi) : P.bn_sums + 128 * bi + 64;
   } else {
     s.norm = NORM_NONE;
   }
@@ -1372,7 +1509,9 @@ static Stage make_stage(UNetModel* m, int si, const float* x, bool training, boo
   s.w = P.params + Y.w[si]; s.bias = P.params + Y.b[si];
   s.out = m->z[si]; s.cout = m->C[si]; s.lout = m->Ln[si];
   const int bo = BN_OF_Z[si];
-  s.sums_out = (bo >= 0 && P.bn_sums) ? P.bn_sums + 128 * bo : nullptr;
+  // (forward: the record this stage adds to, in nrep replicas; backward: the folded forward record of its output)
+  s.nrep = bwd ? m->nrep_b : m->nrep_f;
+  s.sums_out = (bo >= 0 && P.bn_sums) ? ((!bwd && m->nrep_f > 1) ? unet_rep(m, 0, bo) : P.bn_sums + 128 * bo) : nullptr;
   s.count = cnt_of(si);
   s.stride = 1; s.pad = 0; s.mode = CONV;
   if (si <= 3) {                      // encoder: Conv1d(k3, s2, p1) -> BN -> LeakyReLU
@@ -1402,9 +1541,11 @@ static Stage make_stage(UNetModel* m, int si, const float* x, bool training, boo
   }
   if (bwd) {
     s.Gout = m->G[si];
-    s.bsums_out = bo >= 0 ? P.bn_sums + 128 * bo + 64 : nullptr;
+    s.bsums_out = bo >= 0 ? (m->nrep_b > 1 ? unet_rep(m, 1, bo) : P.bn_sums + 128 * bo + 64) : nullptr;
     s.gamma_out = bo >= 0 ? P.params + Y.bnw[bo] : nullptr;
     s.gw = P.grads + Y.w[si]; s.gb = P.grads + Y.b[si];
+    if (si == 10) s.Gout = m->last_dy;        // the gradient at the output BatchNorm is the caller's dy itself
+    if (m->fold) { s.part = m->part; s.part_stride = m->part_stride; s.part_w = (int)Y.w[si]; s.part_b = (int)Y.b[si]; }
   }
   return s;
 }
@@ -1413,8 +1554,14 @@ static Stage make_stage(UNetModel* m, int si, const float* x, bool training, boo
 // residual operand r of the specialised kernel is always lrelu(BN(z)) (bottleneck.6 + x); main operand act is a runtime flag
 template <int CIN, int COUT, int KS, int MODE>
 static void launch_fwd_t(const Stage& st, int B, int grid, hipStream_t s) {
-  const size_t lds = ((size_t)CIN * (st.lin + 8) + (size_t)CIN * COUT * KS + MAXC + 12 * MAXC + 2 * MAXC + 8) * sizeof(float);
-  k_unet_fwd_t<CIN, COUT, KS, MODE><<<grid, 256, lds, s>>>(st, B);
+  // windows per workgroup pass: all of a workgroup's windows at once (up to 4), so the grid is B / WP workgroups
+  int WP = (B + grid - 1) / grid;
+  if (WP > 4) WP = 4;
+  if (WP < 1) WP = 1;
+  const int g2 = (B + WP - 1) / WP < grid ? (B + WP - 1) / WP : grid;
+  const size_t lds = ((size_t)WP * CIN * (st.lin + 8) + (st.r.z ? (size_t)WP * COUT * st.lout : 0) + (size_t)CIN * COUT * KS + MAXC +
+                      12 * MAXC + 2 * MAXC + 8) * sizeof(float);
+  k_unet_fwd_t<CIN, COUT, KS, MODE><<<g2, 256, lds, s>>>(st, B, WP);
 }
 
 static bool launch_unet_fwd_fast(const Stage& st, int si, int leads, int B, int grid, hipStream_t s) {
@@ -1444,7 +1591,10 @@ int unet_forward_stage(UNetModel* m, const float* x, int B, int training, int si
   if (training && (!P.cfg.train || !P.bn_sums)) { snprintf(err, cap, "training forward needs train=1 and bn_sums"); return -1; }
   if (si == 0) {
     m->last_x = x; m->last_B = B;
-    if (training) (void)hipMemsetAsync(P.bn_sums, 0, 1280 * sizeof(double), s);
+    if (training) {
+      if (m->nrep_f > 1) (void)hipMemsetAsync(unet_rep(m, 0, 0), 0, (size_t)10 * UNET_MAXREP * 64 * sizeof(double), s);
+      else (void)hipMemsetAsync(P.bn_sums, 0, 1280 * sizeof(double), s);
+    }
   } else if (x != m->last_x || B != m->last_B) { snprintf(err, cap, "U-Net stages must follow stage 0 of the same batch"); return -1; }
   static const int fgmax = getenv("RAL_UNET_FWD_GRID") ? atoi(getenv("RAL_UNET_FWD_GRID")) : 512;   // (train forward at batch 2048: 0.31 / 0.27 / 0.29 / 0.41 ms with 256 / 512 / 1024 / 2048 workgroups)
   const int gcap = training ? fgmax : 1024;    // (eval stages have no BatchNorm sums to flush: more workgroups are better)
@@ -1468,10 +1618,12 @@ int unet_forward_finish(UNetModel* m, float* y, int B, int training, int64_t gwi
     for (int zi = 0, k = 0; zi < 11; ++zi) {
       const int bi = BN_OF_Z[zi];
       if (bi < 0) continue;
-      u.l[k++] = BnUpd{P.bn_sums + 128 * bi, P.state + m->lay.run[bi], m->C[zi], (double)gwin * m->Ln[zi]};
+      u.l[k++] = BnUpd{m->nrep_f > 1 ? unet_rep(m, 0, bi) : P.bn_sums + 128 * bi, P.bn_sums + 128 * bi, P.state + m->lay.run[bi],
+                       m->C[zi], (double)gwin * m->Ln[zi], m->nrep_f};
     }
-    k_unet_running<<<10, MAXC, 0, s>>>(u);
+    k_unet_running<<<10, MAXC, 0, s>>>(u);     // (also folds the replicas into bn_sums: what the backward pass reads)
   }
+  m->nrep_f = 1;
   if (hipGetLastError() != hipSuccess) { snprintf(err, cap, "U-Net forward launch failed"); return -1; }
   return 0;
 }
@@ -1520,37 +1672,54 @@ static int unet_forward_fused(UNetModel* m, const float* x, float* y, int B, hip
   return 0;
 }
 
+static int unet_nrep() {
+  static const int n = [] { const char* v = getenv("RAL_UNET_NREP"); int k = v ? atoi(v) : UNET_MAXREP; return k < 1 ? 1 : (k > UNET_MAXREP ? UNET_MAXREP : k); }();
+  return n;
+}
+
 int unet_forward(UNetModel* m, const float* x, float* y, int B, int training, hipStream_t s, char* err, size_t cap) {
   if (!training && unet_infer_fused_applies(m)) return unet_forward_fused(m, x, y, B, s, err, cap);
+  m->nrep_f = (training && m->pub.cfg.train) ? unet_nrep() : 1;
   for (int si = 0; si < 11; ++si)
-    if (unet_forward_stage(m, x, B, training, si, B, s, err, cap)) return -1;
-  return unet_forward_finish(m, y, B, training, B, s, err, cap);
+    if (unet_forward_stage(m, x, B, training, si, B, s, err, cap)) { m->nrep_f = 1; return -1; }
+  const int rc = unet_forward_finish(m, y, B, training, B, s, err, cap);
+  m->nrep_f = 1;
+  return rc;
 }
 
 int unet_stage_bn(int si) { return (si >= 0 && si <= 10) ? BN_OF_Z[si] : -1; }
 
 
 template <int CIN, int COUT, int KS, int MODE>
-static void launch_bwd_t(const Stage& st, int B, int grid, hipStream_t s) {
-  const size_t lds = ((size_t)CIN * (st.lin + 8) + (size_t)COUT * (st.lout + 8) + (size_t)2 * CIN * COUT * KS + 17 * MAXC + 6 * MAXC +
-                      5 * MAXC + 8) * sizeof(float);
-  k_unet_bwd_t<CIN, COUT, KS, MODE><<<grid, 256, lds, s>>>(st, B);
+static void launch_bwd_t(const Stage& st, int B, int grid, int wp_req, hipStream_t s) {
+  const bool want_din = st.a.G != nullptr, third = st.b.z != nullptr || (want_din && st.a.accumulate);
+  auto lds_of = [&](int WP) {
+    return ((size_t)WP * CIN * (st.lin + 8) * (1 + (want_din ? 1 : 0) + (third ? 1 : 0)) + (size_t)WP * COUT * (st.lout + 8) +
+            (size_t)2 * CIN * COUT * KS + 28 * MAXC + 8) * sizeof(float);
+  };
+  int WP = (B + grid - 1) / grid;                 // windows per workgroup
+  if (WP > wp_req) WP = wp_req;
+  while (WP > 1 && lds_of(WP) > 80 * 1024) --WP;  // two workgroups per CU
+  const size_t lds = lds_of(WP);
+  static size_t cur = 0;                          // (one per instantiation)
+  if (lds > cur) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_unet_bwd_t<CIN, COUT, KS, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); cur = lds; }
+  k_unet_bwd_t<CIN, COUT, KS, MODE><<<grid, 256, lds, s>>>(st, B, WP);
 }
 
-static bool launch_unet_bwd_fast(const Stage& st, int si, int leads, int B, int grid, hipStream_t s) {
+static bool launch_unet_bwd_fast(const Stage& st, int si, int leads, int B, int grid, int wp, hipStream_t s) {
   if (st.lout % 4 || st.lin % 4) return false;
   switch (si) {
-    case 0: if (leads == 1) launch_bwd_t<1, 4, 3, 0>(st, B, grid, s); else launch_bwd_t<2, 4, 3, 0>(st, B, grid, s); return true;
-    case 1: launch_bwd_t<4, 8, 3, 0>(st, B, grid, s); return true;
-    case 2: launch_bwd_t<8, 16, 3, 0>(st, B, grid, s); return true;
-    case 3: launch_bwd_t<16, 32, 3, 0>(st, B, grid, s); return true;
-    case 4: launch_bwd_t<32, 32, 1, 1>(st, B, grid, s); return true;
-    case 5: launch_bwd_t<32, 32, 3, 1>(st, B, grid, s); return true;
-    case 6: launch_bwd_t<32, 32, 1, 1>(st, B, grid, s); return true;
-    case 7: launch_bwd_t<32, 16, 4, 2>(st, B, grid, s); return true;
-    case 8: launch_bwd_t<16, 8, 4, 2>(st, B, grid, s); return true;
-    case 9: launch_bwd_t<8, 4, 4, 2>(st, B, grid, s); return true;
-    case 10: if (leads == 1) launch_bwd_t<4, 1, 4, 2>(st, B, grid, s); else launch_bwd_t<4, 2, 4, 2>(st, B, grid, s); return true;
+    case 0: if (leads == 1) launch_bwd_t<1, 4, 3, 0>(st, B, grid, wp, s); else launch_bwd_t<2, 4, 3, 0>(st, B, grid, wp, s); return true;
+    case 1: launch_bwd_t<4, 8, 3, 0>(st, B, grid, wp, s); return true;
+    case 2: launch_bwd_t<8, 16, 3, 0>(st, B, grid, wp, s); return true;
+    case 3: launch_bwd_t<16, 32, 3, 0>(st, B, grid, wp, s); return true;
+    case 4: launch_bwd_t<32, 32, 1, 1>(st, B, grid, wp, s); return true;
+    case 5: launch_bwd_t<32, 32, 3, 1>(st, B, grid, wp, s); return true;
+    case 6: launch_bwd_t<32, 32, 1, 1>(st, B, grid, wp, s); return true;
+    case 7: launch_bwd_t<32, 16, 4, 2>(st, B, grid, wp, s); return true;
+    case 8: launch_bwd_t<16, 8, 4, 2>(st, B, grid, wp, s); return true;
+    case 9: launch_bwd_t<8, 4, 4, 2>(st, B, grid, wp, s); return true;
+    case 10: if (leads == 1) launch_bwd_t<4, 1, 4, 2>(st, B, grid, wp, s); else launch_bwd_t<4, 2, 4, 2>(st, B, grid, wp, s); return true;
   }
   return false;
 }
@@ -1561,14 +1730,17 @@ int unet_backward_start(UNetModel* m, const float* dy, int B, int64_t gwin, hipS
   UNetPublic& P = m->pub;
   if (!P.cfg.train || !P.grads || !P.bn_sums) { snprintf(err, cap, "backward needs train=1, grads and bn_sums bound"); return -1; }
   if (B != m->last_B) { snprintf(err, cap, "backward batch %d != forward batch %d", B, m->last_B); return -1; }
-  (void)hipMemsetAsync(P.grads, 0, (size_t)m->lay.nparam * sizeof(float), s);
-  for (int bi = 0; bi < 10; ++bi) (void)hipMemsetAsync(P.bn_sums + 128 * bi + 64, 0, 64 * sizeof(double), s);
-  // last layer: gradient at BN9's output is dy itself
+  // with the fold every gradient entry is WRITTEN by k_unet_fold; the atomic path accumulates into a zeroed buffer
+  if (!m->fold) (void)hipMemsetAsync(P.grads, 0, (size_t)m->lay.nparam * sizeof(float), s);
+  // the ten backward halves [64, 128) of the 128-double BatchNorm records, one strided fill
+  if (m->nrep_b > 1) (void)hipMemsetAsync(unet_rep(m, 1, 0), 0, (size_t)10 * UNET_MAXREP * 64 * sizeof(double), s);
+  else (void)hipMemset2DAsync(P.bn_sums + 64, 128 * sizeof(double), 0, 64 * sizeof(double), 10, s);
+  m->last_dy = dy;
+  m->bwd_rows = 0;
   const size_t total = (size_t)B * m->C[10] * m->Ln[10];
-  (void)hipMemcpyAsync(m->G[10], dy, total * sizeof(float), hipMemcpyDeviceToDevice, s);
   Src o = make_src(m, 10, ACT_NONE, true, false, 0);
   k_unet_gsums<<<(int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024), 256, 0, s>>>(
-      dy, o, m->C[10], m->Ln[10], (double)gwin * m->Ln[10], P.bn_sums + 128 * 9 + 64, total);
+      dy, o, m->C[10], m->Ln[10], (double)gwin * m->Ln[10], m->nrep_b > 1 ? unet_rep(m, 1, 9) : P.bn_sums + 128 * 9 + 64, m->nrep_b, total);
   if (hipGetLastError() != hipSuccess) { snprintf(err, cap, "U-Net backward launch failed"); return -1; }
   return 0;
 }
@@ -1580,8 +1752,12 @@ int unet_backward_stage(UNetModel* m, int B, int si, int64_t gwin, hipStream_t s
   // every workgroup ends with ~2 000 global atomics (its share of dW, db and the BatchNorm-backward sums): the chip retires
   // ~75 of them per ns, so 1024 workgroups spend 30 us per launch on them alone.  Measured train step at batch 2048 with
   // 1024 / 512 / 384 workgroups: 1.23 / 1.08 / 1.12 ms (RAL_UNET_BWD_GRID)
-  static const int gmax = getenv("RAL_UNET_BWD_GRID") ? atoi(getenv("RAL_UNET_BWD_GRID")) : 512;
+  static const int gmax0 = getenv("RAL_UNET_BWD_GRID") ? atoi(getenv("RAL_UNET_BWD_GRID")) : 512;
+  static const int wp = getenv("RAL_UNET_BWD_WP") ? atoi(getenv("RAL_UNET_BWD_WP")) : 2;
+  const int gmax = (m->fold && gmax0 > m->part_rows_max) ? m->part_rows_max : gmax0;
   const int grid = B < gmax ? B : gmax;
+  if (m->last_dy == nullptr) { snprintf(err, cap, "U-Net backward stages must follow ral_unet_backward_start"); return -1; }
+  m->bwd_rows = grid;                             // (the same for every stage of a backward pass: it depends on B only)
   // consumers run in reverse order; an encoder tensor's gradient is first WRITTEN by its decoder-side consumer
   // (skip / residual, accumulate = 0) and later ACCUMULATED by the next encoder / bottleneck stage (accumulate = 1)
   Stage st = make_stage(m, si, m->last_x, true, true, B, (double)gwin);
@@ -1589,7 +1765,7 @@ int unet_backward_stage(UNetModel* m, int B, int si, int64_t gwin, hipStream_t s
   const size_t lds = bwd_lds(st);
   static size_t cur = 0;
   if (lds > cur) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_unet_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); cur = lds; }
-  if (!launch_unet_bwd_fast(st, si, P.cfg.leads, B, grid, s)) k_unet_bwd<<<grid, 256, lds, s>>>(st, B);
+  if (!launch_unet_bwd_fast(st, si, P.cfg.leads, B, grid, wp < 1 ? 1 : wp, s)) k_unet_bwd<<<grid, 256, lds, s>>>(st, B);
   if (hipGetLastError() != hipSuccess) { snprintf(err, cap, "U-Net backward launch failed"); return -1; }
   return 0;
 }
@@ -1598,16 +1774,28 @@ int unet_backward_finish(UNetModel* m, int B, int64_t gwin, hipStream_t s, char*
   UNetPublic& P = m->pub;
   BnGradAll u;
   for (int bi = 0; bi < 10; ++bi)
-    u.l[bi] = BnGrad{P.bn_sums + 128 * bi + 64, P.grads + m->lay.bnw[bi], P.grads + m->lay.bnb[bi], m->lay.bnC[bi]};
-  k_unet_bn_grads<<<10, MAXC, 0, s>>>(u, (double)B / (double)gwin);
+    u.l[bi] = BnGrad{m->nrep_b > 1 ? unet_rep(m, 1, bi) : P.bn_sums + 128 * bi + 64, P.bn_sums + 128 * bi + 64,
+                     P.grads + m->lay.bnw[bi], P.grads + m->lay.bnb[bi], m->lay.bnC[bi], m->nrep_b};
+  if (m->fold) {
+    if (m->bwd_rows <= 0) { snprintf(err, cap, "U-Net backward finish without its stages"); return -1; }
+    k_unet_fold<<<(m->ncols + 63) / 64 + 1, 256, 0, s>>>(m->part, m->part_stride, m->bwd_rows, m->cols, m->ncols, P.grads, u,
+                                                        (double)B / (double)gwin);
+  } else {
+    k_unet_bn_grads<<<10, MAXC, 0, s>>>(u, (double)B / (double)gwin);
+  }
+  m->last_dy = nullptr;
+  m->nrep_b = 1;
   if (hipGetLastError() != hipSuccess) { snprintf(err, cap, "U-Net backward launch failed"); return -1; }
   return 0;
 }
 
 int unet_backward(UNetModel* m, const float* dy, float* dx, int B, hipStream_t s, char* err, size_t cap) {
   if (dx) { snprintf(err, cap, "U-Net input gradient is not provided"); return -1; }
-  if (unet_backward_start(m, dy, B, B, s, err, cap)) return -1;
+  m->nrep_b = unet_nrep();
+  if (unet_backward_start(m, dy, B, B, s, err, cap)) { m->nrep_b = 1; return -1; }
   for (int si = 10; si >= 0; --si)
-    if (unet_backward_stage(m, B, si, B, s, err, cap)) return -1;
-  return unet_backward_finish(m, B, B, s, err, cap);
+    if (unet_backward_stage(m, B, si, B, s, err, cap)) { m->nrep_b = 1; return -1; }
+  const int rc = unet_backward_finish(m, B, B, s, err, cap);
+  m->nrep_b = 1;
+  return rc;
 }
