@@ -57,32 +57,53 @@ struct Stage {
 RAL_DEV float lrelu01(float v) { return v > 0.f ? v : 0.01f * v; }
 
 // One BatchNorm record (S1[MAXC], S2[MAXC] doubles) that may be spread over `nrep` replicas of 64 doubles -> out64 (LDS).
-// All 256 threads of the workgroup take part: every load of the fold is in flight at once (thread t: entry t & 63 of the
-// replicas (t >> 6) + 4 j), the four partial rows meet in LDS.
-RAL_DEV void fold_record(const double* rec, int nrep, double* out64) {
+// All 256 threads of the workgroup take part (thread t: entry t & 63 of the replicas (t >> 6) + 4 j), the four partial rows
+// meet in LDS.  Split in two so that a kernel can REQUEST every record it needs (and its weights) before it waits for the
+// first: hipcc waits for a load right before its first use, so loads issued back to back share one memory round trip.
+struct FoldLd { double v[4]; };
+RAL_DEV FoldLd fold_load(const double* rec, int nrep) {
+  const int t = threadIdx.x & 255, idx = t & 63, q = t >> 6;
+  FoldLd f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const int k = q + 4 * j; f.v[j] = rec[(size_t)(k < nrep ? k : 0) * 64 + idx]; }   // (branch-free: clamped)
+  return f;
+}
+RAL_DEV void fold_finish(const FoldLd& f, int nrep, double* out64) {
   __shared__ double fold_tmp[4 * 64];
   const int t = threadIdx.x, idx = t & 63, q = t >> 6;
   if (t < 256) {
-    double v[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { const int k = q + 4 * j; v[j] = rec[(size_t)(k < nrep ? k : 0) * 64 + idx]; }   // (branch-free: clamped)
     double sum = 0.0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) sum += (q + 4 * j < nrep) ? v[j] : 0.0;
+    for (int j = 0; j < 4; ++j) sum += (q + 4 * j < nrep) ? f.v[j] : 0.0;
     fold_tmp[q * 64 + idx] = sum;
   }
   __syncthreads();
   if (t < 64) out64[t] = (fold_tmp[t] + fold_tmp[64 + t]) + (fold_tmp[128 + t] + fold_tmp[192 + t]);
   __syncthreads();
 }
+RAL_DEV void fold_record(const double* rec, int nrep, double* out64) { fold_finish(fold_load(rec, nrep), nrep, out64); }
 #define UNET_MAXREP 16
 
 // scale/shift (and mean/rstd) of one operand's BatchNorm into LDS: ss[0:C] scale, [C:2C] shift, [2C:3C] mean, [3C:4C] rstd
-// (called by all threads of the workgroup: it contains barriers)
-RAL_DEV void src_coeffs(const Src& s, int C, double count, float* ss) {
+// (called by all threads of the workgroup: it contains barriers).  `pre`: the record's loads, requested earlier by
+// src_request (any address works for an operand without batch statistics: the values are not used)
+struct SrcReq { FoldLd f; float gamma, beta, rmean, rvar; };
+RAL_DEV SrcReq src_request(const Src& s, int C, const void* any) {
+  SrcReq q;
+  q.f = fold_load(s.norm == NORM_BATCH ? s.sums : reinterpret_cast<const double*>(any), s.norm == NORM_BATCH ? s.nrep : 1);
+  const int c = (int)threadIdx.x < C ? (int)threadIdx.x : 0;          // (channel of this thread, clamped: C <= MAXC threads use it)
+  const float* fa = reinterpret_cast<const float*>(any);
+  q.gamma = (s.norm != NORM_NONE ? s.gamma : fa)[c];
+  q.beta = (s.norm != NORM_NONE ? s.beta : fa)[c];
+  q.rmean = (s.norm == NORM_RUNNING ? s.running : fa)[c];
+  q.rvar = (s.norm == NORM_RUNNING ? s.running + C : fa)[c];
+  return q;
+}
+RAL_DEV void src_coeffs(const Src& s, int C, double count, float* ss, const SrcReq& pre) {
   __shared__ double rec[64];
-  if (s.norm == NORM_BATCH) fold_record(s.sums, s.nrep, rec);
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+  if (s.norm == NORM_BATCH) fold_finish(pre.f, s.nrep, rec);
+  const int c = threadIdx.x;
+  if (c < C) {
     float mean = 0.f, rstd = 1.f, sc = 1.f, sh = 0.f;
     if (s.norm == NORM_BATCH) {
       const double m = rec[c] / count;
@@ -90,13 +111,14 @@ RAL_DEV void src_coeffs(const Src& s, int C, double count, float* ss) {
       if (var < 0.0) var = 0.0;
       mean = (float)m; rstd = (float)(1.0 / sqrt(var + 1e-5));
     } else if (s.norm == NORM_RUNNING) {
-      mean = s.running[c]; rstd = 1.0f / sqrtf(s.running[C + c] + 1e-5f);
+      mean = pre.rmean; rstd = 1.0f / sqrtf(pre.rvar + 1e-5f);
     }
-    if (s.norm != NORM_NONE) { sc = s.gamma[c] * rstd; sh = s.beta[c] - mean * sc; }
+    if (s.norm != NORM_NONE) { sc = pre.gamma * rstd; sh = pre.beta - mean * sc; }
     ss[c] = sc; ss[C + c] = sh; ss[2 * C + c] = mean; ss[3 * C + c] = rstd;
   }
   __syncthreads();      // (rec is reused by the next call)
 }
+RAL_DEV void src_coeffs(const Src& s, int C, double count, float* ss) { src_coeffs(s, C, count, ss, src_request(s, C, s.z)); }
 
 RAL_DEV float src_value(const Src& s, const float* ss, int C, int c, float z) {
   float v = z * ss[c] + ss[C + c];
@@ -171,6 +193,22 @@ __global__ __launch_bounds__(256) void k_unet_fwd(Stage st, int B) {
   }
 }
 
+// weight-gradient tile of slot s (of `slots` per workgroup), rotated by the workgroup index: the workgroups of a launch
+// finish together, and without the rotation every one of them would start its flush on the same addresses
+RAL_DEV int dw_tile(int s, int slots) { return (s + (int)blockIdx.x) % slots; }
+
+// LDS atomic add of the sum over groups of `w` consecutive lanes (w = 1: every lane adds its own value; w in {8, 16,
+// 32, 64}: the group's first lane adds the group sum - same-address LDS atomics of a wave execute one after the other)
+RAL_DEV void seg_atomic(float* addr, float v, int w) {
+  if (w == 1) { atomicAdd(addr, v); return; }
+  const int lane = threadIdx.x & 63;
+  if (w == 64) v = group_sum<64>(v);
+  else if (w == 32) v = group_sum<32>(v);
+  else if (w == 16) v = group_sum<16>(v);
+  else v = group_sum<8>(v);
+  if ((lane & (w - 1)) == 0) atomicAdd(addr, v);
+}
+
 // ---------------------------------------------------------------------------------
 // forward stage, specialised: channel counts, kernel size and conv type are template parameters, every
 // thread produces 4 consecutive positions of one output channel from registers (inputs of a channel are
@@ -192,19 +230,38 @@ __global__ __launch_bounds__(256) void k_unet_fwd_t(Stage st, int B, int WP) {
   float* bs = ws + nw;
   float* ca = bs + MAXC; float* cb = ca + 4 * MAXC; float* cr = cb + 4 * MAXC;
   float* red = cr + 4 * MAXC;
-  copy_flat(ws, st.w, nw >> 2);
-  for (int i = threadIdx.x; i < COUT; i += blockDim.x) bs[i] = st.bias[i];
+  // every global load of the prologue is requested before the first is waited for: the BatchNorm records of the
+  // operands, the weights (at most 3 float4 per thread) and the bias
+  const SrcReq la = src_request(st.a, CIN, st.w), lb = src_request(st.b.z ? st.b : st.a, CIN, st.w),
+               lr = src_request(st.r.z ? st.r : st.a, st.r.z ? COUT : CIN, st.w);
+  float4 wv[(nw / 4 + 255) / 256];
+#pragma unroll
+  for (int k = 0; k < (nw / 4 + 255) / 256; ++k) {
+    const int i = threadIdx.x + k * 256;
+    wv[k] = reinterpret_cast<const float4*>(st.w)[i < nw / 4 ? i : 0];
+  }
+  const float bv = st.bias[threadIdx.x < COUT ? threadIdx.x : 0];
+#pragma unroll
+  for (int k = 0; k < (nw / 4 + 255) / 256; ++k) {
+    const int i = threadIdx.x + k * 256;
+    if (i < nw / 4) reinterpret_cast<float4*>(ws)[i] = wv[k];
+  }
+  if ((int)threadIdx.x < COUT) bs[threadIdx.x] = bv;
   for (int i = threadIdx.x; i < 2 * MAXC; i += blockDim.x) red[i] = 0.f;
   for (int i = threadIdx.x; i < WP * CIN * 2 * HALO; i += blockDim.x) {   // halos stay zero for every pass
     const int c = i / (2 * HALO), h = i % (2 * HALO);
     in[c * LP + (h < HALO ? h : lin + h)] = 0.f;
   }
-  src_coeffs(st.a, CIN, st.count_a, ca);
-  if (st.b.z) src_coeffs(st.b, CIN, st.count_b, cb);
-  if (st.r.z) src_coeffs(st.r, COUT, st.count_r, cr);
+  src_coeffs(st.a, CIN, st.count_a, ca, la);
+  if (st.b.z) src_coeffs(st.b, CIN, st.count_b, cb, lb);
+  if (st.r.z) src_coeffs(st.r, COUT, st.count_r, cr, lr);
   __syncthreads();
   const int nin = CIN * lin, nout = COUT * lout, q = lout >> 2, nslots = COUT * q, nin4 = nin >> 2, nout4 = nout >> 2;
   const bool a_lrelu = st.a.act == ACT_LRELU;
+  // lanes of a wave that hold the same output channel in the compute loop (q consecutive slots, when q is a power of two
+  // and every wave of the loop is full): their sums are combined before the LDS atomic - same-address LDS atomics of a
+  // wave execute one after the other
+  const int segw = ((q & (q - 1)) == 0 && q >= 8 && nslots % 64 == 0) ? (q < 64 ? q : 64) : 1;
   for (int w0 = blockIdx.x * WP; w0 < B; w0 += gridDim.x * WP) {
     const int nwin = (B - w0) < WP ? (B - w0) : WP;
     const float4* za = reinterpret_cast<const float4*>(st.a.z + (size_t)w0 * nin);
@@ -292,8 +349,8 @@ __global__ __launch_bounds__(256) void k_unet_fwd_t(Stage st, int B, int WP) {
       }
       *reinterpret_cast<float4*>(st.out + (size_t)(w0 + wi) * nout + (size_t)co * lout + l0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
       if (st.sums_out) {
-        atomicAdd(red + co, (acc[0] + acc[1]) + (acc[2] + acc[3]));
-        atomicAdd(red + MAXC + co, (acc[0] * acc[0] + acc[1] * acc[1]) + (acc[2] * acc[2] + acc[3] * acc[3]));
+        seg_atomic(red + co, (acc[0] + acc[1]) + (acc[2] + acc[3]), segw);
+        seg_atomic(red + MAXC + co, (acc[0] * acc[0] + acc[1] * acc[1]) + (acc[2] * acc[2] + acc[3] * acc[3]), segw);
       }
     }
     __syncthreads();
@@ -334,7 +391,9 @@ __global__ void k_unet_running(BnUpdAll u) {
   b.running[b.C + c] = 0.9f * b.running[b.C + c] + 0.1f * (float)(b.count > 1.0 ? var * b.count / (b.count - 1.0) : var);
 }
 
-// sums of the gradient at a BatchNorm output: S1 = sum G, S2 = sum G * zhat   (used for the last layer)
+// sums of the gradient at a BatchNorm output: S1 = sum G, S2 = sum G * zhat   (used for the last layer).  One wave per
+// (window, channel) row of L floats (L a multiple of 4): 16-byte loads, four of each operand in flight per lane, a wave-level
+// sum, then one LDS atomic per row and sum.
 __global__ __launch_bounds__(256) void k_unet_gsums(const float* __restrict__ G, Src s, int C, int L, double count,
                                                     double* __restrict__ bsums, int nrep, size_t total) {
   __shared__ float ss[4 * MAXC];
@@ -342,10 +401,31 @@ __global__ __launch_bounds__(256) void k_unet_gsums(const float* __restrict__ G,
   src_coeffs(s, C, count, ss);
   for (int i = threadIdx.x; i < 2 * MAXC; i += blockDim.x) red[i] = 0.f;
   __syncthreads();
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)((i / L) % C);
-    const float g = G[i], zh = (s.z[i] - ss[2 * C + c]) * ss[3 * C + c];
-    atomicAdd(red + c, g); atomicAdd(red + MAXC + c, g * zh);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, L4 = L >> 2;
+  const size_t rows = total / L;
+  for (size_t row = (size_t)blockIdx.x * 4 + wave; row < rows; row += (size_t)gridDim.x * 4) {
+    const int c = (int)(row % C);
+    const float4* g4 = reinterpret_cast<const float4*>(G + row * L);
+    const float4* z4 = reinterpret_cast<const float4*>(s.z + row * L);
+    const float mu = ss[2 * C + c], rs = ss[3 * C + c];
+    float s1 = 0.f, s2 = 0.f;
+    auto take = [&](float4 g, float4 z) {
+      s1 += f4hsum(g);
+      s2 += g.x * ((z.x - mu) * rs) + g.y * ((z.y - mu) * rs) + g.z * ((z.z - mu) * rs) + g.w * ((z.w - mu) * rs);
+    };
+    int i = lane;
+    for (; i + 3 * 64 < L4; i += 4 * 64) {
+      float4 gv[4], zv[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) gv[k] = g4[i + k * 64];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) zv[k] = z4[i + k * 64];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) take(gv[k], zv[k]);
+    }
+    for (; i < L4; i += 64) take(g4[i], z4[i]);
+    s1 = group_sum<64>(s1); s2 = group_sum<64>(s2);
+    if (lane == 0) { atomicAdd(red + c, s1); atomicAdd(red + MAXC + c, s2); }
   }
   __syncthreads();
   if ((int)threadIdx.x < C) {
@@ -527,22 +607,6 @@ __global__ __launch_bounds__(256) void k_unet_bwd(Stage st, int B) {
   }
 }
 
-// weight-gradient tile of slot s (of `slots` per workgroup), rotated by the workgroup index: the workgroups of a launch
-// finish together, and without the rotation every one of them would start its flush on the same addresses
-RAL_DEV int dw_tile(int s, int slots) { return (s + (int)blockIdx.x) % slots; }
-
-// LDS atomic add of the sum over groups of `w` consecutive lanes (w = 1: every lane adds its own value; w in {8, 16,
-// 32, 64}: the group's first lane adds the group sum - same-address LDS atomics of a wave execute one after the other)
-RAL_DEV void seg_atomic(float* addr, float v, int w) {
-  if (w == 1) { atomicAdd(addr, v); return; }
-  const int lane = threadIdx.x & 63;
-  if (w == 64) v = group_sum<64>(v);
-  else if (w == 32) v = group_sum<32>(v);
-  else if (w == 16) v = group_sum<16>(v);
-  else v = group_sum<8>(v);
-  if ((lane & (w - 1)) == 0) atomicAdd(addr, v);
-}
-
 // ---------------------------------------------------------------------------------
 // backward stage, specialised (same template parameters as k_unet_fwd_t).  A workgroup takes WP consecutive windows
 // per pass (one pass at the launch sizes used) and touches global memory in ONE batched load phase:
@@ -563,10 +627,22 @@ RAL_DEV void seg_atomic(float* addr, float v, int w) {
 // (st.part: workgroups x parameters), folded by k_unet_fold after the last stage - no global atomics except the 2 x C
 // BatchNorm-backward sums the NEXT stage needs.  (st.part == nullptr: atomics straight into the gradient buffer.)
 // ---------------------------------------------------------------------------------
+// phase stamps of ONE instantiation (diagnostic builds: make STAMP=1 STAMPTU=UNET STAMPSEL='CIN==4&&COUT==2&&MODE==2';
+// tools/diag/stamp_unet_bwd.py): slots 16.. = prologue, load phase, input gradient, weight gradient, flush
+#if defined(RAL_STAMP) && defined(RAL_STAMP_HERE) && defined(UNET_STAMP_SEL)
+#define UB_STAMP(i) do { if ((UNET_STAMP_SEL) && blockIdx.x == 0 && threadIdx.x == 0) { const long long t_ = clock64(); \
+    atomicAdd(&g_ral_stamps[i], (unsigned long long)(t_ - ub_prev_)); ub_prev_ = t_; } } while (0)
+#define UB_STAMP_INIT() long long ub_prev_ = clock64()
+#else
+#define UB_STAMP(i) do {} while (0)
+#define UB_STAMP_INIT() do {} while (0)
+#endif
+#define UNET_BWD_THREADS 512
 template <int CIN, int COUT, int KS, int MODE>
-__global__ __launch_bounds__(256) void k_unet_bwd_t(Stage st, int B, int WP) {
+__global__ __launch_bounds__(UNET_BWD_THREADS, 2) void k_unet_bwd_t(Stage st, int B, int WP) {
   extern __shared__ float4 smem4[];
-  constexpr int HALO = 4, nw = CIN * COUT * KS;
+  UB_STAMP_INIT();
+  constexpr int HALO = 4, nw = CIN * COUT * KS, NT = UNET_BWD_THREADS, NWAVE = NT / 64;
   const int lin = st.lin, lout = st.lout, LP = lin + 2 * HALO, LPO = lout + 2 * HALO;
   const bool has_b = st.b.z != nullptr, want_din = st.a.G != nullptr;
   const bool acc_a = want_din && st.a.accumulate != 0;
@@ -579,28 +655,44 @@ __global__ __launch_bounds__(256) void k_unet_bwd_t(Stage st, int B, int WP) {
   float* ca = gws + nw; float* cb = ca + 4 * MAXC; float* cr = cb + 4 * MAXC; float* co_ = cr + 4 * MAXC;
   float* sa = co_ + 5 * MAXC; float* sb = sa + 2 * MAXC; float* sr = sb + 2 * MAXC;
   float* gbs = sr + 2 * MAXC;                    // MAXC bias grads + 4*MAXC scratch
-  copy_flat(ws, st.w, nw >> 2);
-  for (int i = threadIdx.x; i < nw; i += blockDim.x) gws[i] = 0.f;
-  for (int i = threadIdx.x; i < 7 * MAXC; i += blockDim.x) sa[i] = 0.f;   // sa, sb, sr, gbs[0:MAXC]
-  for (int i = threadIdx.x; i < WP * CIN * 2 * HALO; i += blockDim.x) {
+  // every global load of the prologue is requested before the first is waited for: the BatchNorm records and affine
+  // parameters of the operands and of this stage's output (forward statistics and backward sums) and the weights
+  Src o; o.norm = st.type != TY_PLAIN ? NORM_BATCH : NORM_NONE; o.sums = st.sums_out; o.nrep = 1; o.gamma = st.gamma_out; o.beta = st.gamma_out; o.act = ACT_NONE;
+  const SrcReq la = src_request(st.a, CIN, st.w), lb = src_request(has_b ? st.b : st.a, CIN, st.w),
+               lr = src_request(st.r.z ? st.r : st.a, st.r.z ? COUT : CIN, st.w), lo = src_request(o, COUT, st.w);
+  const FoldLd lbo = fold_load(st.type != TY_PLAIN ? st.bsums_out : reinterpret_cast<const double*>(st.w), st.type != TY_PLAIN ? st.nrep : 1);
+  constexpr int NWV = (nw / 4 + NT - 1) / NT;
+  float4 wv[NWV];
+#pragma unroll
+  for (int k = 0; k < NWV; ++k) {
+    const int i = threadIdx.x + k * NT;
+    wv[k] = reinterpret_cast<const float4*>(st.w)[i < nw / 4 ? i : 0];
+  }
+#pragma unroll
+  for (int k = 0; k < NWV; ++k) {
+    const int i = threadIdx.x + k * NT;
+    if (i < nw / 4) reinterpret_cast<float4*>(ws)[i] = wv[k];
+  }
+  for (int i = threadIdx.x; i < nw; i += NT) gws[i] = 0.f;
+  for (int i = threadIdx.x; i < 7 * MAXC; i += NT) sa[i] = 0.f;   // sa, sb, sr, gbs[0:MAXC]
+  for (int i = threadIdx.x; i < WP * CIN * 2 * HALO; i += NT) {
     const int c = i / (2 * HALO), h = i % (2 * HALO);
     in[c * LP + (h < HALO ? h : lin + h)] = 0.f;
   }
-  for (int i = threadIdx.x; i < WP * COUT * 2 * HALO; i += blockDim.x) {
+  for (int i = threadIdx.x; i < WP * COUT * 2 * HALO; i += NT) {
     const int c = i / (2 * HALO), h = i % (2 * HALO);
     dc[c * LPO + (h < HALO ? h : lout + h)] = 0.f;
   }
-  src_coeffs(st.a, CIN, st.count_a, ca);
-  if (has_b) src_coeffs(st.b, CIN, st.count_b, cb);
-  if (st.r.z) src_coeffs(st.r, COUT, st.count_r, cr);
+  src_coeffs(st.a, CIN, st.count_a, ca, la);
+  if (has_b) src_coeffs(st.b, CIN, st.count_b, cb, lb);
+  if (st.r.z) src_coeffs(st.r, COUT, st.count_r, cr, lr);
   if (st.type != TY_PLAIN) {   // BN-backward coefficients of this stage's output
-    Src o; o.norm = NORM_BATCH; o.sums = st.sums_out; o.nrep = 1; o.gamma = st.gamma_out; o.beta = st.gamma_out; o.act = ACT_NONE;
     float* tmp = gbs + MAXC;
-    src_coeffs(o, COUT, st.count, tmp);
+    src_coeffs(o, COUT, st.count, tmp, lo);
     __shared__ double brec[64];
-    fold_record(st.bsums_out, st.nrep, brec);
-    for (int c = threadIdx.x; c < COUT; c += blockDim.x) {
-      co_[c] = st.gamma_out[c] * tmp[3 * COUT + c];                      // gamma * rstd
+    fold_finish(lbo, st.nrep, brec);
+    for (int c = threadIdx.x; c < COUT; c += NT) {
+      co_[c] = lo.gamma * tmp[3 * COUT + c];                             // gamma * rstd   (lo.gamma: this thread's channel)
       co_[MAXC + c] = (float)(brec[c] / st.count);                       // mean(G)
       co_[2 * MAXC + c] = (float)(brec[MAXC + c] / st.count);            // mean(G * zhat)
       co_[3 * MAXC + c] = tmp[2 * COUT + c];                             // mean
@@ -615,132 +707,128 @@ __global__ __launch_bounds__(256) void k_unet_bwd_t(Stage st, int B, int WP) {
   const int gq = lout >> 2;
   const int segw = ((gq & (gq - 1)) == 0 && gq >= 8 && nout4 % 64 == 0) ? (gq < 64 ? gq : 64) : 1;
   const int lane = threadIdx.x & 63, r = lane & 15, g4 = lane >> 4, wave = threadIdx.x >> 6;
-  // weight-gradient work units of the workgroup: (tile, position range); layers with fewer than four tiles split the
+  // weight-gradient work units of the workgroup: (tile, position range); layers with fewer tiles than waves split the
   // output positions KSPLIT ways so that every wave has one
   constexpr int DW_MT = (COUT + 15) / 16, DW_NT = (CIN * KS + 15) / 16, DW_NU = DW_MT * DW_NT;
-  constexpr int KSPLIT = DW_NU >= 4 ? 1 : (4 + DW_NU - 1) / DW_NU, DW_UNITS = DW_NU * KSPLIT, DW_TPW = (DW_UNITS + 3) / 4;
-  const int kchunk = (((lout + 3) >> 2) + KSPLIT - 1) / KSPLIT * 4;     // output positions per split (multiple of 4)
+  constexpr int KSPLIT = DW_NU >= NWAVE ? 1 : (NWAVE + DW_NU - 1) / DW_NU, DW_UNITS = DW_NU * KSPLIT, DW_TPW = (DW_UNITS + NWAVE - 1) / NWAVE;
+  const int kchunk = (((lout + 15) >> 4) + KSPLIT - 1) / KSPLIT * 16;   // output positions per split (multiple of 16)
   f32x4 dwacc[DW_TPW];
 #pragma unroll
   for (int ti = 0; ti < DW_TPW; ++ti) dwacc[ti] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool has_r = st.r.z && st.r.G;
+  const bool has_z = st.type != TY_PLAIN;
+  UB_STAMP(16);
   for (int w0 = blockIdx.x * WP; w0 < B; w0 += gridDim.x * WP) {
     const int nwin = (B - w0) < WP ? (B - w0) : WP;
-    // ---- load phase ----
+    // ---- load phase: all five streams of a chunk (NT x 2 float4 of each) are requested before any is used ----
+    const float4* za = reinterpret_cast<const float4*>(st.a.z + (size_t)w0 * nin);
+    const float4* zx = has_b ? reinterpret_cast<const float4*>(st.b.z + (size_t)w0 * nin)
+                             : (acc_a ? reinterpret_cast<const float4*>(st.a.G + (size_t)w0 * nin) : nullptr);
+    const float4* G4 = reinterpret_cast<const float4*>(st.Gout + (size_t)w0 * nout);
+    const float4* Z4 = has_z ? reinterpret_cast<const float4*>(st.out + (size_t)w0 * nout) : nullptr;
+    const float4* R4 = has_r ? reinterpret_cast<const float4*>(st.r.z + (size_t)w0 * nout) : nullptr;
+    float4* RG4 = has_r ? reinterpret_cast<float4*>(st.r.G + (size_t)w0 * nout) : nullptr;
+    auto put = [&](int i, float4 v, float4 u) {
+      const int wi = i / nin4, e = (i - wi * nin4) << 2, c = e / lin, p = e - c * lin;
+      const int oo = (wi * CIN + c) * LP + HALO + p;
+      if (want_din) *reinterpret_cast<float4*>(zra + oo) = v;
+      if (zx) *reinterpret_cast<float4*>(aux + oo) = u;
+      const float s_ = ca[c], h = ca[CIN + c];
+      v = make_float4(v.x * s_ + h, v.y * s_ + h, v.z * s_ + h, v.w * s_ + h);
+      if (a_lrelu) v = make_float4(lrelu01(v.x), lrelu01(v.y), lrelu01(v.z), lrelu01(v.w));
+      if (has_b) {
+        const float s2 = cb[c], h2 = cb[CIN + c];
+        v.x += lrelu01(u.x * s2 + h2); v.y += lrelu01(u.y * s2 + h2); v.z += lrelu01(u.z * s2 + h2); v.w += lrelu01(u.w * s2 + h2);
+      }
+      *reinterpret_cast<float4*>(in + oo) = v;
+    };
+    auto putg = [&](int i, float4 g4v, float4 z4, float4 zr) {
+      const int wi = i / nout4, e = (i - wi * nout4) << 2, c = e / lout, p = e - c * lout;
+      float g[4] = {g4v.x, g4v.y, g4v.z, g4v.w};
+      if (has_z) {
+        const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
+        const float k = co_[c], m1 = co_[MAXC + c], m2 = co_[2 * MAXC + c], mu = co_[3 * MAXC + c], rs = co_[4 * MAXC + c];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float zh = (zz[j] - mu) * rs;
+          float v = k * (g[j] - m1 - zh * m2);
+          if (st.type == TY_ABN && zz[j] <= 0.f) v *= 0.01f;   // stored tensor is lrelu(conv)
+          g[j] = v;
+        }
+      }
+      *reinterpret_cast<float4*>(dc + (wi * COUT + c) * LPO + HALO + p) = make_float4(g[0], g[1], g[2], g[3]);
+      seg_atomic(gbs + c, (g[0] + g[1]) + (g[2] + g[3]), segw);
+      if (has_r) {   // residual operand lrelu(BN(z_r)) was added to the output: its gradient is Gout * lrelu'
+        const float zrr[4] = {zr.x, zr.y, zr.z, zr.w}, gg[4] = {g4v.x, g4v.y, g4v.z, g4v.w};
+        const float s_ = cr[c], h = cr[COUT + c], mu = cr[2 * COUT + c], rs = cr[3 * COUT + c];
+        float gr[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          gr[j] = (zrr[j] * s_ + h <= 0.f) ? 0.01f * gg[j] : gg[j];
+          s1 += gr[j]; s2 += gr[j] * (zrr[j] - mu) * rs;
+        }
+        float4 outv = make_float4(gr[0], gr[1], gr[2], gr[3]);
+        if (st.r.accumulate) outv = f4add(outv, RG4[i]);
+        RG4[i] = outv;
+        seg_atomic(sr + c, s1, segw); seg_atomic(sr + MAXC + c, s2, segw);
+      }
+    };
     {
-      const float4* za = reinterpret_cast<const float4*>(st.a.z + (size_t)w0 * nin);
-      const float4* zx = has_b ? reinterpret_cast<const float4*>(st.b.z + (size_t)w0 * nin)
-                               : (acc_a ? reinterpret_cast<const float4*>(st.a.G + (size_t)w0 * nin) : nullptr);
-      auto put = [&](int i, float4 v, float4 u) {
-        const int wi = i / nin4, e = (i - wi * nin4) << 2, c = e / lin, p = e - c * lin;
-        const int o = (wi * CIN + c) * LP + HALO + p;
-        if (want_din) *reinterpret_cast<float4*>(zra + o) = v;
-        if (zx) *reinterpret_cast<float4*>(aux + o) = u;
-        const float s = ca[c], h = ca[CIN + c];
-        v = make_float4(v.x * s + h, v.y * s + h, v.z * s + h, v.w * s + h);
-        if (a_lrelu) v = make_float4(lrelu01(v.x), lrelu01(v.y), lrelu01(v.z), lrelu01(v.w));
-        if (has_b) {
-          const float s2 = cb[c], h2 = cb[CIN + c];
-          v.x += lrelu01(u.x * s2 + h2); v.y += lrelu01(u.y * s2 + h2); v.z += lrelu01(u.z * s2 + h2); v.w += lrelu01(u.w * s2 + h2);
-        }
-        *reinterpret_cast<float4*>(in + o) = v;
-      };
-      constexpr int U = 4;
-      const int n4 = nwin * nin4, bd = blockDim.x;
-      int i = threadIdx.x;
-      for (; i + (U - 1) * bd < n4; i += U * bd) {
-        float4 v[U], u[U];
+      constexpr int U = 2;
+      const int na = nwin * nin4, ng = nwin * nout4;                   // float4 per stream (equal here: every tensor of a window
+      const int nmax = na > ng ? na : ng;                              //  has leads * L floats; kept general)
+      for (int i0 = 0; i0 < nmax; i0 += U * NT) {
+        float4 va[U], vx[U], vg[U], vz[U], vr[U];
+        int ia[U], ig[U];
 #pragma unroll
-        for (int k = 0; k < U; ++k) v[k] = za[i + k * bd];
-        if (zx) {
-#pragma unroll
-          for (int k = 0; k < U; ++k) u[k] = zx[i + k * bd];
+        for (int k = 0; k < U; ++k) {
+          const int i = i0 + k * NT + (int)threadIdx.x;
+          ia[k] = i < na ? i : -1; ig[k] = i < ng ? i : -1;
+          const int ja = i < na ? i : 0, jg = i < ng ? i : 0;            // (clamped: no lane-predicated loads)
+          va[k] = za[ja];
+          vx[k] = (zx ? zx : za)[ja];
+          vg[k] = G4[jg];
+          vz[k] = (has_z ? Z4 : G4)[jg];
+          vr[k] = (has_r ? R4 : G4)[jg];
         }
 #pragma unroll
-        for (int k = 0; k < U; ++k) put(i + k * bd, v[k], u[k]);
+        for (int k = 0; k < U; ++k) {
+          if (ia[k] >= 0) put(ia[k], va[k], vx[k]);
+          if (ig[k] >= 0) putg(ig[k], vg[k], vz[k], vr[k]);
+        }
       }
-      for (; i < n4; i += bd) put(i, za[i], zx ? zx[i] : zero4);
-    }
-    {   // gradient at the conv output (+ bias gradient, + gradient of the residual operand)
-      const float4* G4 = reinterpret_cast<const float4*>(st.Gout + (size_t)w0 * nout);
-      const float4* Z4 = st.type != TY_PLAIN ? reinterpret_cast<const float4*>(st.out + (size_t)w0 * nout) : nullptr;
-      const bool has_r = st.r.z && st.r.G;
-      const float4* R4 = has_r ? reinterpret_cast<const float4*>(st.r.z + (size_t)w0 * nout) : nullptr;
-      float4* RG4 = has_r ? reinterpret_cast<float4*>(st.r.G + (size_t)w0 * nout) : nullptr;
-      auto putg = [&](int i, float4 g4v, float4 z4, float4 zr) {
-        const int wi = i / nout4, e = (i - wi * nout4) << 2, c = e / lout, p = e - c * lout;
-        float g[4] = {g4v.x, g4v.y, g4v.z, g4v.w};
-        if (Z4) {
-          const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
-          const float k = co_[c], m1 = co_[MAXC + c], m2 = co_[2 * MAXC + c], mu = co_[3 * MAXC + c], rs = co_[4 * MAXC + c];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float zh = (zz[j] - mu) * rs;
-            float v = k * (g[j] - m1 - zh * m2);
-            if (st.type == TY_ABN && zz[j] <= 0.f) v *= 0.01f;   // stored tensor is lrelu(conv)
-            g[j] = v;
-          }
-        }
-        *reinterpret_cast<float4*>(dc + (wi * COUT + c) * LPO + HALO + p) = make_float4(g[0], g[1], g[2], g[3]);
-        seg_atomic(gbs + c, (g[0] + g[1]) + (g[2] + g[3]), segw);
-        if (has_r) {   // residual operand lrelu(BN(z_r)) was added to the output: its gradient is Gout * lrelu'
-          const float zrr[4] = {zr.x, zr.y, zr.z, zr.w}, gg[4] = {g4v.x, g4v.y, g4v.z, g4v.w};
-          const float s = cr[c], h = cr[COUT + c], mu = cr[2 * COUT + c], rs = cr[3 * COUT + c];
-          float gr[4], s1 = 0.f, s2 = 0.f;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            gr[j] = (zrr[j] * s + h <= 0.f) ? 0.01f * gg[j] : gg[j];
-            s1 += gr[j]; s2 += gr[j] * (zrr[j] - mu) * rs;
-          }
-          float4 outv = make_float4(gr[0], gr[1], gr[2], gr[3]);
-          if (st.r.accumulate) outv = f4add(outv, RG4[i]);
-          RG4[i] = outv;
-          seg_atomic(sr + c, s1, segw); seg_atomic(sr + MAXC + c, s2, segw);
-        }
-      };
-      constexpr int U = 4;
-      const int n4 = nwin * nout4, bd = blockDim.x;
-      int i = threadIdx.x;
-      for (; i + (U - 1) * bd < n4; i += U * bd) {
-        float4 gv[U], zv[U], rv[U];
-#pragma unroll
-        for (int k = 0; k < U; ++k) gv[k] = G4[i + k * bd];
-        if (Z4) {
-#pragma unroll
-          for (int k = 0; k < U; ++k) zv[k] = Z4[i + k * bd];
-        }
-        if (has_r) {
-#pragma unroll
-          for (int k = 0; k < U; ++k) rv[k] = R4[i + k * bd];
-        }
-#pragma unroll
-        for (int k = 0; k < U; ++k) putg(i + k * bd, gv[k], zv[k], rv[k]);
-      }
-      for (; i < n4; i += bd) putg(i, G4[i], Z4 ? Z4[i] : zero4, has_r ? R4[i] : zero4);
     }
     __syncthreads();
+    UB_STAMP(17);
     // ---- input gradient ----
     if (want_din) {
-      constexpr int KTOT = COUT * KS, CT = (CIN + 15) / 16;
+      constexpr int KTOT = COUT * KS, CT = (CIN + 15) / 16, KST = (KTOT + 3) / 4;
       const int ptiles = (lin + 15) >> 4;
-      for (int tile = wave; tile < nwin * ptiles * CT; tile += 4) {
+      for (int tile = wave; tile < nwin * ptiles * CT; tile += NWAVE) {
         const int wi = tile / (ptiles * CT), t2 = tile - wi * ptiles * CT, pt = t2 / CT, n0 = pt << 4, m0 = (t2 - pt * CT) << 4;
         const int pos = n0 + r, cib = m0 + r;
         const bool pok = pos < lin, cok = cib < CIN;
         const float* dcw = dc + wi * COUT * LPO;
         f32x4 accv = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-        for (int kk0 = 0; kk0 < KTOT; kk0 += 4) {
-          const int kk = kk0 + g4, co = kk / KS, k = kk - co * KS;
-          const bool kok = (KTOT % 4 == 0) || kk < KTOT;
-          float av = 0.f, bv = 0.f;
-          if (pok && kok) {
-            if constexpr (MODE == 1) av = dcw[co * LPO + HALO + pos + (KS - 1) / 2 - k];
-            else if constexpr (MODE == 0) { const int t = pos + 1 - k; av = (t & 1) ? 0.f : dcw[co * LPO + HALO + (t >> 1)]; }
-            else av = dcw[co * LPO + HALO + 2 * pos - 1 + k];
+        // operands of four k-steps are fetched together, then their MFMAs issue back to back (one LDS latency per four)
+#pragma unroll 1
+        for (int ks0 = 0; ks0 < KST; ks0 += 4) {
+          float av[4], bv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int kk = (ks0 + u) * 4 + g4, co = kk / KS, k = kk - co * KS;
+            const bool kok = kk < KTOT;
+            av[u] = 0.f; bv[u] = 0.f;
+            if (pok && kok) {
+              if constexpr (MODE == 1) av[u] = dcw[co * LPO + HALO + pos + (KS - 1) / 2 - k];
+              else if constexpr (MODE == 0) { const int t = pos + 1 - k; av[u] = (t & 1) ? 0.f : dcw[co * LPO + HALO + (t >> 1)]; }
+              else av[u] = dcw[co * LPO + HALO + 2 * pos - 1 + k];
+            }
+            if (cok && kok) bv[u] = (MODE == 2) ? ws[(cib * COUT + co) * KS + k] : ws[(co * CIN + cib) * KS + k];
           }
-          if (cok && kok) bv = (MODE == 2) ? ws[(cib * COUT + co) * KS + k] : ws[(co * CIN + cib) * KS + k];
-          accv = mfma4(av, bv, accv);
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (ks0 + u < KST) accv = mfma4(av[u], bv[u], accv);
         }
         // epilogue of the lane's (input channel cib, positions p0 .. p0 + 3): activation derivative, store (to one or two
         // producers), contributions to their BatchNorm-backward sums - all operands from the LDS
@@ -748,23 +836,23 @@ __global__ __launch_bounds__(256) void k_unet_bwd_t(Stage st, int B, int WP) {
         const bool valid = cok && p0 < lin;
         float s1a = 0.f, s2a = 0.f, s1b = 0.f, s2b = 0.f;
         if (valid) {
-          const int o = (wi * CIN + cib) * LP + HALO + p0;
+          const int oo = (wi * CIN + cib) * LP + HALO + p0;
           const size_t og = (size_t)(w0 + wi) * nin + (size_t)cib * lin + p0;
           const float acc[4] = {accv[0], accv[1], accv[2], accv[3]};
-          const float4 z4 = *reinterpret_cast<const float4*>(zra + o);
+          const float4 z4 = *reinterpret_cast<const float4*>(zra + oo);
           const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
-          const float s = ca[cib], h = ca[CIN + cib], mu = ca[2 * CIN + cib], rs = ca[3 * CIN + cib];
+          const float s_ = ca[cib], h = ca[CIN + cib], mu = ca[2 * CIN + cib], rs = ca[3 * CIN + cib];
           float ga[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            ga[j] = (a_lrelu && zz[j] * s + h <= 0.f) ? 0.01f * acc[j] : acc[j];
+            ga[j] = (a_lrelu && zz[j] * s_ + h <= 0.f) ? 0.01f * acc[j] : acc[j];
             s1a += ga[j]; s2a += ga[j] * (zz[j] - mu) * rs;
           }
           float4 outv = make_float4(ga[0], ga[1], ga[2], ga[3]);
-          if (acc_a) outv = f4add(outv, *reinterpret_cast<const float4*>(aux + o));
+          if (acc_a) outv = f4add(outv, *reinterpret_cast<const float4*>(aux + oo));
           *reinterpret_cast<float4*>(st.a.G + og) = outv;
           if (has_b && st.b.G) {
-            const float4 y4 = *reinterpret_cast<const float4*>(aux + o);
+            const float4 y4 = *reinterpret_cast<const float4*>(aux + oo);
             const float yy[4] = {y4.x, y4.y, y4.z, y4.w};
             const float sB = cb[cib], hB = cb[CIN + cib], muB = cb[2 * CIN + cib], rsB = cb[3 * CIN + cib];
             float gb4[4];
@@ -788,10 +876,11 @@ __global__ __launch_bounds__(256) void k_unet_bwd_t(Stage st, int B, int WP) {
         }
       }
     }
+    UB_STAMP(18);
     // ---- weight gradient ----
 #pragma unroll
     for (int ti = 0; ti < DW_TPW; ++ti) {
-      const int unit = wave + ti * 4;
+      const int unit = wave + ti * NWAVE;
       if (unit >= DW_UNITS) continue;
       const int tile = unit / KSPLIT, ks = unit - tile * KSPLIT;
       const int m0 = (tile / DW_NT) << 4, n0 = (tile % DW_NT) << 4;
@@ -802,29 +891,38 @@ __global__ __launch_bounds__(256) void k_unet_bwd_t(Stage st, int B, int WP) {
       for (int wi = 0; wi < nwin; ++wi) {
         const float* dr = dc + (wi * COUT + (cook ? co : 0)) * LPO + HALO;
         const float* ir = in + (wi * CIN + (nok ? ci : 0)) * LP + HALO;
-        for (int q0 = q_lo; q0 < q_hi; q0 += 4) {
-          const int pp = q0 + g4;
-          const bool pk = pp < q_hi;
-          float av = 0.f, bv = 0.f;
-          if (cook && pk) av = dr[pp];
-          if (nok && pk) {
-            if constexpr (MODE == 1) bv = ir[pp - (KS - 1) / 2 + k];
-            else if constexpr (MODE == 0) bv = ir[2 * pp - 1 + k];
-            else { const int t = pp + 1 - k; bv = (t & 1) ? 0.f : ir[t >> 1]; }
+        // 16 output positions per iteration: the eight operand reads first, then four MFMAs back to back
+#pragma unroll 1
+        for (int q0 = q_lo; q0 < q_hi; q0 += 16) {
+          float av[4], bv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int pp = q0 + 4 * u + g4;
+            const bool pk = pp < q_hi;
+            av[u] = (cook && pk) ? dr[pp] : 0.f;
+            bv[u] = 0.f;
+            if (nok && pk) {
+              if constexpr (MODE == 1) bv[u] = ir[pp - (KS - 1) / 2 + k];
+              else if constexpr (MODE == 0) bv[u] = ir[2 * pp - 1 + k];
+              else { const int t = pp + 1 - k; bv[u] = (t & 1) ? 0.f : ir[t >> 1]; }
+            }
           }
-          accw = mfma4(av, bv, accw);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) accw = mfma4(av[u], bv[u], accw);
         }
       }
       dwacc[ti] = accw;
     }
+    UB_STAMP(19);
     __syncthreads();
+    UB_STAMP(20);
   }
   // ---- the workgroup's partial sums leave ----
   // weight-gradient tiles: lane (r, g) holds rows co = m0 + 4 g + v of column nn = n0 + r; position splits of one tile meet
   // in the LDS copy of the weight tensor
 #pragma unroll
   for (int ti = 0; ti < DW_TPW; ++ti) {
-    const int unit = wave + ti * 4;
+    const int unit = wave + ti * NWAVE;
     if (unit >= DW_UNITS) continue;
     const int tile = unit / KSPLIT;
     const int m0 = (tile / DW_NT) << 4, n0 = (tile % DW_NT) << 4, nn = n0 + r;
@@ -842,11 +940,11 @@ __global__ __launch_bounds__(256) void k_unet_bwd_t(Stage st, int B, int WP) {
   __syncthreads();
   if (st.part) {
     float* row = st.part + (size_t)blockIdx.x * st.part_stride;
-    for (int i = threadIdx.x; i < (nw >> 2); i += blockDim.x)
+    for (int i = threadIdx.x; i < (nw >> 2); i += NT)
       reinterpret_cast<float4*>(row + st.part_w)[i] = reinterpret_cast<const float4*>(gws)[i];
     if ((int)threadIdx.x < COUT) row[st.part_b + threadIdx.x] = gbs[threadIdx.x];
   } else {
-    for (int i = threadIdx.x; i < nw; i += blockDim.x) atomicAdd(st.gw + i, gws[i]);
+    for (int i = threadIdx.x; i < nw; i += NT) atomicAdd(st.gw + i, gws[i]);
     if ((int)threadIdx.x < COUT) atomicAdd(st.gb + threadIdx.x, gbs[threadIdx.x]);
   }
   if ((int)threadIdx.x < CIN) {
@@ -866,6 +964,7 @@ __global__ __launch_bounds__(256) void k_unet_bwd_t(Stage st, int B, int WP) {
     atomicAdd(rec + threadIdx.x, (double)sr[threadIdx.x]);
     atomicAdd(rec + MAXC + threadIdx.x, (double)sr[MAXC + threadIdx.x]);
   }
+  UB_STAMP(21);
 }
 
 // Fold of the per-workgroup weight / bias gradient partials (rows x stride scratch matrix written by k_unet_bwd_t) into the
@@ -1703,7 +1802,7 @@ static void launch_bwd_t(const Stage& st, int B, int grid, int wp_req, hipStream
   const size_t lds = lds_of(WP);
   static size_t cur = 0;                          // (one per instantiation)
   if (lds > cur) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_unet_bwd_t<CIN, COUT, KS, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); cur = lds; }
-  k_unet_bwd_t<CIN, COUT, KS, MODE><<<grid, 256, lds, s>>>(st, B, WP);
+  k_unet_bwd_t<CIN, COUT, KS, MODE><<<grid, UNET_BWD_THREADS, lds, s>>>(st, B, WP);
 }
 
 static bool launch_unet_bwd_fast(const Stage& st, int si, int leads, int B, int grid, int wp, hipStream_t s) {
@@ -1739,7 +1838,8 @@ int unet_backward_start(UNetModel* m, const float* dy, int B, int64_t gwin, hipS
   m->bwd_rows = 0;
   const size_t total = (size_t)B * m->C[10] * m->Ln[10];
   Src o = make_src(m, 10, ACT_NONE, true, false, 0);
-  k_unet_gsums<<<(int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024), 256, 0, s>>>(
+  const size_t grows = (total / m->Ln[10] + 3) / 4;      // one wave per (window, channel) row
+  k_unet_gsums<<<(int)(grows < 512 ? grows : 512), 256, 0, s>>>(
       dy, o, m->C[10], m->Ln[10], (double)gwin * m->Ln[10], m->nrep_b > 1 ? unet_rep(m, 1, 9) : P.bn_sums + 128 * 9 + 64, m->nrep_b, total);
   if (hipGetLastError() != hipSuccess) { snprintf(err, cap, "U-Net backward launch failed"); return -1; }
   return 0;
