@@ -165,8 +165,10 @@ __global__ __launch_bounds__(512) void k_mlp_bwd(const float* __restrict__ dx2, 
   }
   __syncthreads();
   if ((int)threadIdx.x < C) {
+#ifndef RAL_NOVECATOMICS   // (diagnostic build: what the same-address chains of the small-vector gradients cost)
     atomicAdd(gr.ln2w + threadIdx.x, red[threadIdx.x]);
     atomicAdd(gr.ln2b + threadIdx.x, red[C + threadIdx.x]);
+#endif
   }
   if (le && threadIdx.x < 3) atomicAdd(gr.le + threadIdx.x, red[2 * C + threadIdx.x]);
 }
@@ -367,8 +369,10 @@ __global__ __launch_bounds__(512, 4) void k_mlp_bwd_s(const float* __restrict__ 
   }
   __syncthreads();
   if ((int)threadIdx.x < C) {
+#ifndef RAL_NOVECATOMICS   // (diagnostic build: what the same-address chains of the small-vector gradients cost)
     atomicAdd(gr.ln2w + threadIdx.x, red[threadIdx.x]);
     atomicAdd(gr.ln2b + threadIdx.x, red[C + threadIdx.x]);
+#endif
   }
   if (le && threadIdx.x < 3) atomicAdd(gr.le + threadIdx.x, red[2 * C + threadIdx.x]);
   // ---- flush the weight gradients: fold the token-split partials through LDS, then one atomic per element ----
@@ -1012,8 +1016,10 @@ __global__ __launch_bounds__(512, RAL_QKVB_MINB) void k_qkv_bwd(const float* dqk
   lds_add4(red, C + cq, dbet);
   __syncthreads();
   if ((int)threadIdx.x < C) {
+#ifndef RAL_NOVECATOMICS
     atomicAdd(gr.ln1w + threadIdx.x, red[threadIdx.x]);
     atomicAdd(gr.ln1b + threadIdx.x, red[C + threadIdx.x]);
+#endif
   }
 }
 
@@ -1079,8 +1085,10 @@ __global__ __launch_bounds__(256) void k_resample_bwd(const float* __restrict__ 
   lds_add4(red, D + cq, dbet);
   __syncthreads();
   if ((int)threadIdx.x < D) {
+#ifndef RAL_NOVECATOMICS
     atomicAdd(g_lnw + threadIdx.x, red[threadIdx.x]);
     atomicAdd(g_lnb + threadIdx.x, red[D + threadIdx.x]);
+#endif
   }
 }
 

@@ -60,38 +60,53 @@ RAL_DEV float lrelu01(float v) { return v > 0.f ? v : 0.01f * v; }
 // All 256 threads of the workgroup take part (thread t: entry t & 63 of the replicas (t >> 6) + 4 j), the four partial rows
 // meet in LDS.  Split in two so that a kernel can REQUEST every record it needs (and its weights) before it waits for the
 // first: hipcc waits for a load right before its first use, so loads issued back to back share one memory round trip.
-struct FoldLd { double v[4]; };
+#define UNET_MAXREP 16
+// A record is folded by ONE wave (lane = entry, all replicas requested at once, the sum kept in registers until
+// fold_store writes it to the record's LDS slot): wave w of the workgroup takes record w, so the records of a kernel's
+// prologue are folded side by side and ONE barrier makes all of them visible (fold_rec(slot)[0..63]).
+#define UNET_FOLD_SLOTS 5
+struct FoldLd { double v[UNET_MAXREP]; };
 RAL_DEV FoldLd fold_load(const double* rec, int nrep) {
-  const int t = threadIdx.x & 255, idx = t & 63, q = t >> 6;
+  const int idx = threadIdx.x & 63;
   FoldLd f;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) { const int k = q + 4 * j; f.v[j] = rec[(size_t)(k < nrep ? k : 0) * 64 + idx]; }   // (branch-free: clamped)
+  for (int k = 0; k < UNET_MAXREP; ++k) f.v[k] = rec[(size_t)(k < nrep ? k : 0) * 64 + idx];   // (branch-free: clamped)
   return f;
 }
-RAL_DEV void fold_finish(const FoldLd& f, int nrep, double* out64) {
-  __shared__ double fold_tmp[4 * 64];
-  const int t = threadIdx.x, idx = t & 63, q = t >> 6;
-  if (t < 256) {
-    double sum = 0.0;
+RAL_DEV double* fold_rec(int slot) { __shared__ double rec[UNET_FOLD_SLOTS][64]; return rec[slot]; }
+RAL_DEV void fold_store(const FoldLd& f, int nrep, int slot) {
+  double sum = 0.0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) sum += (q + 4 * j < nrep) ? f.v[j] : 0.0;
-    fold_tmp[q * 64 + idx] = sum;
-  }
+  for (int k = 0; k < UNET_MAXREP; ++k) sum += (k < nrep) ? f.v[k] : 0.0;
+  fold_rec(slot)[threadIdx.x & 63] = sum;
+}
+// the wave's record among up to five (null = none): pointer and replica count by wave index
+struct FoldPick { const double* rec; int nrep; };
+RAL_DEV FoldPick fold_pick(const double* r0, int n0, const double* r1, int n1, const double* r2, int n2, const double* r3, int n3,
+                           const double* r4, int n4, const void* any) {
+  const int w = threadIdx.x >> 6;
+  FoldPick p;
+  p.rec = w == 0 ? r0 : (w == 1 ? r1 : (w == 2 ? r2 : (w == 3 ? r3 : (w == 4 ? r4 : nullptr))));
+  p.nrep = w == 0 ? n0 : (w == 1 ? n1 : (w == 2 ? n2 : (w == 3 ? n3 : (w == 4 ? n4 : 1))));
+  if (!p.rec) { p.rec = reinterpret_cast<const double*>(any); p.nrep = 0; }      // (nrep 0: loads a valid address, stores 0)
+  return p;
+}
+RAL_DEV void fold_record(const double* rec, int nrep, double* out64) {   // one record on its own (barriers inside)
+  if (threadIdx.x < 64) fold_store(fold_load(rec, nrep), nrep, 0);
   __syncthreads();
-  if (t < 64) out64[t] = (fold_tmp[t] + fold_tmp[64 + t]) + (fold_tmp[128 + t] + fold_tmp[192 + t]);
+  if (threadIdx.x < 64) out64[threadIdx.x] = fold_rec(0)[threadIdx.x];
   __syncthreads();
 }
-RAL_DEV void fold_record(const double* rec, int nrep, double* out64) { fold_finish(fold_load(rec, nrep), nrep, out64); }
-#define UNET_MAXREP 16
 
-// scale/shift (and mean/rstd) of one operand's BatchNorm into LDS: ss[0:C] scale, [C:2C] shift, [2C:3C] mean, [3C:4C] rstd
-// (called by all threads of the workgroup: it contains barriers).  `pre`: the record's loads, requested earlier by
-// src_request (any address works for an operand without batch statistics: the values are not used)
-struct SrcReq { FoldLd f; float gamma, beta, rmean, rvar; };
+// scale/shift (and mean/rstd) of one operand's BatchNorm into LDS: ss[0:C] scale, [C:2C] shift, [2C:3C] mean, [3C:4C] rstd.
+// src_request: the affine parameters of channel (thread & 63), requested early (any valid address serves an operand without
+// them: the values are not used).  src_coeffs_slot: the coefficients from the folded record in `slot`, computed by the
+// 64-thread group `grp` of the workgroup (no barrier: the caller places one).
+struct SrcReq { float gamma, beta, rmean, rvar; };
+RAL_DEV const double* src_rec(const Src& s) { return s.norm == NORM_BATCH ? s.sums : nullptr; }
 RAL_DEV SrcReq src_request(const Src& s, int C, const void* any) {
   SrcReq q;
-  q.f = fold_load(s.norm == NORM_BATCH ? s.sums : reinterpret_cast<const double*>(any), s.norm == NORM_BATCH ? s.nrep : 1);
-  const int c = (int)threadIdx.x < C ? (int)threadIdx.x : 0;          // (channel of this thread, clamped: C <= MAXC threads use it)
+  const int c = (int)(threadIdx.x & 63) < C ? (int)(threadIdx.x & 63) : 0;
   const float* fa = reinterpret_cast<const float*>(any);
   q.gamma = (s.norm != NORM_NONE ? s.gamma : fa)[c];
   q.beta = (s.norm != NORM_NONE ? s.beta : fa)[c];
@@ -99,11 +114,10 @@ RAL_DEV SrcReq src_request(const Src& s, int C, const void* any) {
   q.rvar = (s.norm == NORM_RUNNING ? s.running + C : fa)[c];
   return q;
 }
-RAL_DEV void src_coeffs(const Src& s, int C, double count, float* ss, const SrcReq& pre) {
-  __shared__ double rec[64];
-  if (s.norm == NORM_BATCH) fold_finish(pre.f, s.nrep, rec);
-  const int c = threadIdx.x;
-  if (c < C) {
+RAL_DEV void src_coeffs_slot(const Src& s, int C, double count, float* ss, const SrcReq& pre, int slot, int grp) {
+  const int c = (int)threadIdx.x - 64 * grp;
+  if (c >= 0 && c < C) {
+    const double* rec = fold_rec(slot);
     float mean = 0.f, rstd = 1.f, sc = 1.f, sh = 0.f;
     if (s.norm == NORM_BATCH) {
       const double m = rec[c] / count;
@@ -116,9 +130,14 @@ RAL_DEV void src_coeffs(const Src& s, int C, double count, float* ss, const SrcR
     if (s.norm != NORM_NONE) { sc = pre.gamma * rstd; sh = pre.beta - mean * sc; }
     ss[c] = sc; ss[C + c] = sh; ss[2 * C + c] = mean; ss[3 * C + c] = rstd;
   }
-  __syncthreads();      // (rec is reused by the next call)
 }
-RAL_DEV void src_coeffs(const Src& s, int C, double count, float* ss) { src_coeffs(s, C, count, ss, src_request(s, C, s.z)); }
+RAL_DEV void src_coeffs(const Src& s, int C, double count, float* ss) {   // one operand on its own (barriers inside)
+  const SrcReq pre = src_request(s, C, s.z);
+  if (s.norm == NORM_BATCH && threadIdx.x < 64) fold_store(fold_load(s.sums, s.nrep), s.nrep, 0);
+  __syncthreads();
+  src_coeffs_slot(s, C, count, ss, pre, 0, 0);
+  __syncthreads();
+}
 
 RAL_DEV float src_value(const Src& s, const float* ss, int C, int c, float z) {
   float v = z * ss[c] + ss[C + c];
@@ -234,6 +253,9 @@ __global__ __launch_bounds__(256) void k_unet_fwd_t(Stage st, int B, int WP) {
   // operands, the weights (at most 3 float4 per thread) and the bias
   const SrcReq la = src_request(st.a, CIN, st.w), lb = src_request(st.b.z ? st.b : st.a, CIN, st.w),
                lr = src_request(st.r.z ? st.r : st.a, st.r.z ? COUT : CIN, st.w);
+  const FoldPick fp = fold_pick(src_rec(st.a), st.a.nrep, st.b.z ? src_rec(st.b) : nullptr, st.b.nrep,
+                                st.r.z ? src_rec(st.r) : nullptr, st.r.nrep, nullptr, 1, nullptr, 1, st.w);
+  const FoldLd fl = fold_load(fp.rec, fp.nrep);        // (wave w: record w)
   float4 wv[(nw / 4 + 255) / 256];
 #pragma unroll
   for (int k = 0; k < (nw / 4 + 255) / 256; ++k) {
@@ -252,9 +274,11 @@ __global__ __launch_bounds__(256) void k_unet_fwd_t(Stage st, int B, int WP) {
     const int c = i / (2 * HALO), h = i % (2 * HALO);
     in[c * LP + (h < HALO ? h : lin + h)] = 0.f;
   }
-  src_coeffs(st.a, CIN, st.count_a, ca, la);
-  if (st.b.z) src_coeffs(st.b, CIN, st.count_b, cb, lb);
-  if (st.r.z) src_coeffs(st.r, COUT, st.count_r, cr, lr);
+  if ((threadIdx.x >> 6) < 3) fold_store(fl, fp.nrep, threadIdx.x >> 6);
+  __syncthreads();
+  src_coeffs_slot(st.a, CIN, st.count_a, ca, la, 0, 0);          // (each operand by its own 64-thread group)
+  if (st.b.z) src_coeffs_slot(st.b, CIN, st.count_b, cb, lb, 1, 1);
+  if (st.r.z) src_coeffs_slot(st.r, COUT, st.count_r, cr, lr, 2, 2);
   __syncthreads();
   const int nin = CIN * lin, nout = COUT * lout, q = lout >> 2, nslots = COUT * q, nin4 = nin >> 2, nout4 = nout >> 2;
   const bool a_lrelu = st.a.act == ACT_LRELU;
@@ -660,7 +684,9 @@ __global__ __launch_bounds__(UNET_BWD_THREADS, 2) void k_unet_bwd_t(Stage st, in
   Src o; o.norm = st.type != TY_PLAIN ? NORM_BATCH : NORM_NONE; o.sums = st.sums_out; o.nrep = 1; o.gamma = st.gamma_out; o.beta = st.gamma_out; o.act = ACT_NONE;
   const SrcReq la = src_request(st.a, CIN, st.w), lb = src_request(has_b ? st.b : st.a, CIN, st.w),
                lr = src_request(st.r.z ? st.r : st.a, st.r.z ? COUT : CIN, st.w), lo = src_request(o, COUT, st.w);
-  const FoldLd lbo = fold_load(st.type != TY_PLAIN ? st.bsums_out : reinterpret_cast<const double*>(st.w), st.type != TY_PLAIN ? st.nrep : 1);
+  const FoldPick fp = fold_pick(src_rec(st.a), st.a.nrep, has_b ? src_rec(st.b) : nullptr, st.b.nrep, st.r.z ? src_rec(st.r) : nullptr, st.r.nrep,
+                                st.type != TY_PLAIN ? st.sums_out : nullptr, 1, st.type != TY_PLAIN ? st.bsums_out : nullptr, st.nrep, st.w);
+  const FoldLd fl = fold_load(fp.rec, fp.nrep);        // (wave w: record w)
   constexpr int NWV = (nw / 4 + NT - 1) / NT;
   float4 wv[NWV];
 #pragma unroll
@@ -683,20 +709,25 @@ __global__ __launch_bounds__(UNET_BWD_THREADS, 2) void k_unet_bwd_t(Stage st, in
     const int c = i / (2 * HALO), h = i % (2 * HALO);
     dc[c * LPO + (h < HALO ? h : lout + h)] = 0.f;
   }
-  src_coeffs(st.a, CIN, st.count_a, ca, la);
-  if (has_b) src_coeffs(st.b, CIN, st.count_b, cb, lb);
-  if (st.r.z) src_coeffs(st.r, COUT, st.count_r, cr, lr);
-  if (st.type != TY_PLAIN) {   // BN-backward coefficients of this stage's output
-    float* tmp = gbs + MAXC;
-    src_coeffs(o, COUT, st.count, tmp, lo);
-    __shared__ double brec[64];
-    fold_finish(lbo, st.nrep, brec);
-    for (int c = threadIdx.x; c < COUT; c += NT) {
-      co_[c] = lo.gamma * tmp[3 * COUT + c];                             // gamma * rstd   (lo.gamma: this thread's channel)
+  if ((threadIdx.x >> 6) < UNET_FOLD_SLOTS) fold_store(fl, fp.nrep, threadIdx.x >> 6);
+  __syncthreads();
+  src_coeffs_slot(st.a, CIN, st.count_a, ca, la, 0, 0);          // (each record by its own 64-thread group)
+  if (has_b) src_coeffs_slot(st.b, CIN, st.count_b, cb, lb, 1, 1);
+  if (st.r.z) src_coeffs_slot(st.r, COUT, st.count_r, cr, lr, 2, 2);
+  if (st.type != TY_PLAIN) {   // BN-backward coefficients of this stage's output, by thread group 3
+    const int c = (int)threadIdx.x - 192;
+    if (c >= 0 && c < COUT) {
+      const double* rec = fold_rec(3);
+      const double* brec = fold_rec(4);
+      const double m = rec[c] / st.count;
+      double var = rec[MAXC + c] / st.count - m * m;
+      if (var < 0.0) var = 0.0;
+      const float rstd = (float)(1.0 / sqrt(var + 1e-5));
+      co_[c] = lo.gamma * rstd;                                          // gamma * rstd
       co_[MAXC + c] = (float)(brec[c] / st.count);                       // mean(G)
       co_[2 * MAXC + c] = (float)(brec[MAXC + c] / st.count);            // mean(G * zhat)
-      co_[3 * MAXC + c] = tmp[2 * COUT + c];                             // mean
-      co_[4 * MAXC + c] = tmp[3 * COUT + c];                             // rstd
+      co_[3 * MAXC + c] = (float)m;                                      // mean
+      co_[4 * MAXC + c] = rstd;                                          // rstd
     }
   }
   __syncthreads();

@@ -2,9 +2,9 @@
 # Round profile collection on the GPU box (one gpurun call): rocprofv3 kernel statistics of the bench.py step in the
 # default and in the serialised schedule, the HBM-traffic and SQ counter passes (every --pmc pass is its own run with
 # --kernel-trace only), the same for the U-Net forward, plus the attention and VALU micro-benchmarks.
-#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r02'
+#   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r03'
 # Everything lands under gpurun_out/<round>/; tools/summarise_profiles.py turns it into profiles/<round>_*.
-R=${1:-r02}
+R=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$R
@@ -31,8 +31,19 @@ unset RAL_UNET_FUSED
 python3 tools/attn_bench.py > $O/attn_bench.log 2>&1
 [ -x tools/diag/valu_probe ] && ./tools/diag/valu_probe > $O/valu_probe.log 2>&1
 python3 bench.py --steps 50 --warmup 5 --kinds > $O/bench.json 2> $O/bench_kinds.log
+python3 bench.py --config newrale --no-cpu > $O/bench_newrale.json 2> $O/bench_newrale.err
+python3 bench.py --config unet --no-cpu > $O/bench_unet.json 2> $O/bench_unet.err
 python3 tools/config_bench.py > $O/config_bench.log 2>&1
 python3 tools/baselines_bench.py > $O/baselines_bench.log 2>&1
+# U-Net TRAIN step: kernel trace (timeline of one step) and statistics
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/unet_train_ks -- python3 tools/unet_bench.py > $O/unet_train_ks.log 2>&1
+python3 tools/diag/unet_timeline.py $O/unet_train_ks 20 > $O/unet_train_timeline.txt 2>&1
+# data-parallel step, two ranks sharing this GPU (gloo on device tensors): kernel + memory-copy trace of both ranks - does the
+# early gradient bucket's reduction start before the backward pass has ended?
+rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $O/dp2_trace -- python3 bench.py --gpus 2 --steps 4 --warmup 2 --batch 1024 --no-cpu --no-infer --test-backend gloo --test-share-gpu > $O/dp2_trace.log 2>&1
+python3 tools/diag/dp_overlap.py $O/dp2_trace > $O/dp2_overlap.txt 2>&1
+# the CPU baseline at the bench batch (SURVEY 8d ii)
+python3 tools/cpu_baseline_big.py 2048 8 32 64 > $O/cpu_baseline_b2048.json 2> $O/cpu_baseline_b2048.err
 # keep only the csv summaries (the merged directory is capped at 64 MiB)
 find $O -name "*agent_info.csv" -delete
 du -sh $O
