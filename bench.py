@@ -324,6 +324,9 @@ def main():
     if a.dry_run_launcher:
         return launcher_dry_run(a)
 
+    # more hardware queues than the default 4, before the HIP runtime initialises: the data-parallel communication stream
+    # must not share a queue with a compute chain (ecg_denoise_amd/__init__.py; no effect on the single-GPU step)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import torch.distributed as dist
     from ecg_denoise_amd import _lib

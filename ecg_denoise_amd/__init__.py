@@ -4,4 +4,15 @@ Python here is host glue only: device memory and streams come from PyTorch-ROCm,
 arithmetic runs in hand-written HIP kernels behind the C ABI of include/ralenet.h."""
 from ._lib import RalError, build  # noqa: F401
 from .baselines import wavelet_denoise  # noqa: F401
+import os as _os
+
+# The step uses four HIP streams of its own (two micro-batch chains and their weight-gradient side streams); a data-parallel
+# rank adds a communication stream (and RCCL its own).  ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4)
+# and a queue runs its packets in order, so with the default the communication stream SHARES a queue with a chain and the
+# "early" gradient bucket's all-reduce starts only when that chain has drained - after the backward pass instead of
+# half-way through it (measured, tools/diag/bucket_overlap.py: 100 % vs 51 % of the backward pass).  The variable is read
+# when the HIP runtime initialises, i.e. it must be set before the first GPU call of the process: importing this package
+# first does that; a caller that initialises the GPU earlier sets it itself.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 from .model import ACDAE, DANet, NewRALE, RALENet, UNet, ralenet  # noqa: F401

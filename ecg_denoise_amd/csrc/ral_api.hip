@@ -1035,9 +1035,10 @@ int ral_grad_bucket_wait(ral_handle* h, int k, ral_stream s) {
   if (k == 1) {
     if (m->dec_lanes <= 0) return fail("bucket 1 is available after ral_backward_begin");
     LaneSet* LS = lanes_of(m);
+    static const int dbg = getenv("RAL_BUCKET_WAIT") ? atoi(getenv("RAL_BUCKET_WAIT")) : 3;   // diagnostic: 1 chains only, 2 side streams only, 0 none
     for (int i = 0; i < m->dec_lanes; ++i) {
-      HIP_OK(hipStreamWaitEvent((hipStream_t)s, LS->l[i].ev_dec_main, 0));
-      if (m->dec_side) HIP_OK(hipStreamWaitEvent((hipStream_t)s, LS->l[i].ev_dec_side, 0));
+      if (dbg & 1) HIP_OK(hipStreamWaitEvent((hipStream_t)s, LS->l[i].ev_dec_main, 0));
+      if (m->dec_side && (dbg & 2)) HIP_OK(hipStreamWaitEvent((hipStream_t)s, LS->l[i].ev_dec_side, 0));
     }
     return 0;
   }

@@ -151,3 +151,18 @@ def test_newrale_two_processes_equal_one_process(tmp_path):
         else:
             assert torch.equal(r0["state"][k], v.cpu()), k
     assert int(r0["state"]["rale.conv1.2.num_batches_tracked"]) == steps
+
+
+def test_early_gradient_bucket_runs_under_the_backward_pass():
+    """Overlap, not just ordering: work enqueued on the trainer's communication stream behind `ral_grad_bucket_wait(1)` (where
+    the early bucket's all-reduce goes) must RUN about half-way through the backward pass, not after it.  With ROCm's default
+    of 4 hardware queues the communication stream shares a queue with a compute chain and runs at 100 % of the pass; the
+    package raises GPU_MAX_HW_QUEUES to 8 before the runtime initialises (own process: the variable is read at HIP init)."""
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "diag", "bucket_overlap.py"), "events"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    import re
+    fr = [int(m.group(1)) for m in re.finditer(r"= (\d+) % \.\.", p.stdout)]
+    assert len(fr) >= 4, p.stdout
+    assert all(30 <= f <= 75 for f in fr), p.stdout
