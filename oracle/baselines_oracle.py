@@ -4,22 +4,24 @@ by the product path).
   wavelet_denoise   local_utils/denoisefunc.py:7-33 - per 1-D record: pywt.wavedec(data, 'db8', level=dwt_max_level),
                     soft threshold of every detail band at 0.04 * max(band), pywt.waverec.
 
-`pywt` (PyWavelets; the reference pins no version, its requirements list just the package) is NOT in this image, so this
-restatement follows PyWavelets' published algorithm (pywt/_extensions/c/convolution.template.c: downsampling_convolution
-with MODE_SYMMETRIC, upsampling_convolution_valid_sf; pywt/_multilevel.py: wavedec / waverec; pywt/_thresholding.py:
-soft) and the db8 filter bank as PyWavelets tabulates it.  PARITY UNPINNED against pywt itself: what pins it here are
-the properties tests/test_baselines_cpu.py checks - the tabulated filter equals an independent spectral factorisation of
-the order-8 Daubechies polynomial to 1e-12, the bank is orthonormal with 8 vanishing moments, band lengths follow
-floor((n + 15) / 2), and decomposition followed by reconstruction is the identity to 1e-12.
+The restatement follows PyWavelets' algorithm (pywt/_extensions/c/convolution.template.c: downsampling_convolution with
+MODE_SYMMETRIC, upsampling_convolution_valid_sf; pywt/_multilevel.py: wavedec / waverec; pywt/_thresholding.py: soft) and
+the db8 filter bank as PyWavelets tabulates it.  PINNED since round 3: `pywt` is not importable by the image's Python
+3.10, but a second interpreter of the build container (/opt/conda/bin/python3.9) has PyWavelets 1.1.1, and
+oracle/gen_golden_wavelet.py runs the REFERENCE function there: tests/golden/g8_wavelet.npz holds its outputs for 2-D and
+3-D inputs of four lengths, and the pieces (filter bank, dwt_max_level, wavedec bands incl. odd band lengths, waverec,
+soft threshold).  tests/test_oracle_golden.py replays them against this file (1e-12); tests/test_baselines_cpu.py keeps
+the property checks (spectral factorisation of the Daubechies polynomial, orthonormality, vanishing moments, band
+geometry, perfect reconstruction).
 """
 import numpy as np
 
 # pywt.Wavelet('db8').dec_lo
 DB8_DEC_LO = np.array([
-    -0.00011747678400228192, 0.0006754494059985568, -0.0003917403729959771, -0.00487035299301066,
-    0.008746094047015655, 0.013981027917015516, -0.04408825393106472, -0.01736930100202211,
-    0.128747426620186, 0.00047248457399797254, -0.2840155429624281, -0.015829105256023893,
-    0.5853546836548691, 0.6756307362980128, 0.3128715909144659, 0.05441584224308161])
+    -0.00011747678412476953, 0.0006754494064505693, -0.00039174037337694705, -0.004870352993451574,
+    0.008746094047405777, 0.013981027917398282, -0.044088253930794755, -0.017369301001807547,
+    0.12874742662047847, 0.0004724845739132828, -0.2840155429615469, -0.015829105256349306,
+    0.5853546836542067, 0.6756307362972898, 0.31287159091429995, 0.05441584224310401])
 F = DB8_DEC_LO.size
 DB8_DEC_HI = np.array([(-1.0) ** (j + 1) * DB8_DEC_LO[F - 1 - j] for j in range(F)])   # quadrature mirror
 DB8_REC_LO = DB8_DEC_LO[::-1].copy()

@@ -1,5 +1,8 @@
 """db8 wavelet-threshold baseline on the GPU (ral_wavelet_denoise, through the C ABI) against the fp64 oracle
-(oracle/baselines_oracle.py, the reference's denoisefunc.py:7-33 protocol).  fp32 tolerance 1e-5 relative L2."""
+(oracle/baselines_oracle.py, the reference's denoisefunc.py:7-33 protocol) and against the reference function's own outputs
+on PyWavelets (tests/golden/g8_wavelet.npz).  fp32 tolerance 1e-5 relative L2."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -58,3 +61,15 @@ def test_wavelet_denoise_rejects_bad_arguments():
         wavelet_denoise(np.zeros(512, np.float32))
     with pytest.raises(RalError):
         wavelet_denoise(np.zeros((2, 512), np.float32), threshold=-1.0)
+
+
+def test_wavelet_denoise_matches_the_reference_function_golden(golden_dir):
+    """the reference's `wavelet_denoise` on PyWavelets 1.1.1 (oracle/gen_golden_wavelet.py): 2-D inputs of three even
+    lengths, the 3-D input and the float32 input (the kernel takes even record lengths)"""
+    from ecg_denoise_amd import wavelet_denoise
+    g = np.load(os.path.join(golden_dir, "g8_wavelet.npz"))
+    for kx, ky in (("x_256", "y_256"), ("x_300", "y_300"), ("x_512", "y_512"), ("x_1024", "y_1024"), ("x3_512", "y3_512"),
+                   ("x32_512", "y32_512")):
+        y = wavelet_denoise(g[kx].astype(np.float32))
+        assert y.shape == g[ky].shape
+        assert _rel(y.astype(np.float64), g[ky].astype(np.float64)) < 1e-5, kx

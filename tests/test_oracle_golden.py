@@ -248,3 +248,33 @@ def test_danet_oracle_matches_reference_golden(golden_dir):
         if k.endswith("num_batches_tracked"):
             assert int(st[k]) == int(g["after_" + k]) == (2 if ".dam.fcn" in k else 1), k
     assert n == 2 * (4 * 3 + 4 * 3 + 3 * 4)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# wavelet-threshold baseline: the oracle against the reference function run on PyWavelets 1.1.1 (oracle/gen_golden_wavelet.py)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_wavelet_oracle_matches_the_reference_function_on_pywavelets(golden_dir):
+    import baselines_oracle as W
+    g = np.load(os.path.join(golden_dir, "g8_wavelet.npz"))
+    assert str(g["pywt_version"]) == "1.1.1"
+    # the pieces, one by one
+    for k, mine in (("dec_lo", W.DB8_DEC_LO), ("dec_hi", W.DB8_DEC_HI), ("rec_lo", W.DB8_REC_LO), ("rec_hi", W.DB8_REC_HI)):
+        assert np.array_equal(g[k], mine), k
+    assert [W.dwt_max_level(int(n)) for n in g["maxlev_n"]] == [int(v) for v in g["maxlev"]]
+    co = W.wavedec(g["x_512"][0], 5)
+    assert [len(c) for c in co] == [int(v) for v in g["bands_len"]]                 # 30 30 46 77 139 263
+    assert np.abs(np.concatenate(co) - g["bands_flat"]).max() < 1e-12              # boundary mode = half-sample symmetric
+    assert np.abs(W.waverec(co) - g["waverec"]).max() < 1e-12
+    co = W.wavedec(g["x_300"][1], 4)                                               # odd band lengths on the way down
+    assert [len(c) for c in co] == [int(v) for v in g["bands300_len"]]
+    assert np.abs(np.concatenate(co) - g["bands300_flat"]).max() < 1e-12
+    assert np.abs(W.waverec(co) - g["waverec300"]).max() < 1e-12
+    assert np.array_equal(W.threshold_soft(g["thr_in"], 0.5), g["thr_out"])
+    # the whole function (denoisefunc.py:7-33): 2-D inputs of four lengths, a 3-D input, a float32 input
+    for n in (256, 300, 512, 1024):
+        assert np.abs(W.wavelet_denoise(g[f"x_{n}"]) - g[f"y_{n}"]).max() < 1e-12, n
+    assert np.abs(W.wavelet_denoise(g["x3_512"]) - g["y3_512"]).max() < 1e-12
+    assert g["y32_512"].dtype == np.float32                                        # (pywt computes float32 inputs in float32)
+    assert np.abs(W.wavelet_denoise(g["x32_512"]) - g["y32_512"]).max() < 5e-6
+    # documented divergence: a record whose detail bands are exactly zero is NaN in pywt (0 / 0 in its soft threshold)
+    assert np.isnan(g["y_zero"]).all() and np.array_equal(W.wavelet_denoise(np.zeros((1, 512))), np.zeros((1, 512)))
