@@ -1000,8 +1000,8 @@ __global__ __launch_bounds__(UNET_BWD_THREADS, 2) void k_unet_bwd_t(Stage st, in
 
 // Fold of the per-workgroup weight / bias gradient partials (rows x stride scratch matrix written by k_unet_bwd_t) into the
 // gradient buffer: a workgroup owns 64 consecutive columns of the conv-parameter column list `cols`, its four waves take a
-// quarter of the rows each (256-byte row pieces), the quarters meet in LDS.  Fixed summation order: the conv gradients
-// are bit-for-bit reproducible run to run.  The last workgroup writes the BatchNorm affine gradients from the backward
+// quarter of the rows each (256-byte row pieces), the quarters meet in LDS (a fixed summation order; the partials themselves
+// still carry the order of their workgroup's LDS atomics).  The last workgroup writes the BatchNorm affine gradients from the backward
 // sums (g_gamma = S2, g_beta = S1).
 // `bsums`: the backward record in nrep replicas; `final_`: the caller-visible bn_sums record, written when they differ
 struct BnGrad { const double* bsums; double* final_; float* gw; float* gb; int C; int nrep; };
@@ -1727,7 +1727,8 @@ int unet_forward_stage(UNetModel* m, const float* x, int B, int training, int si
     }
   } else if (x != m->last_x || B != m->last_B) { snprintf(err, cap, "U-Net stages must follow stage 0 of the same batch"); return -1; }
   static const int fgmax = getenv("RAL_UNET_FWD_GRID") ? atoi(getenv("RAL_UNET_FWD_GRID")) : 512;   // (train forward at batch 2048: 0.31 / 0.27 / 0.29 / 0.41 ms with 256 / 512 / 1024 / 2048 workgroups)
-  const int gcap = training ? fgmax : 1024;    // (eval stages have no BatchNorm sums to flush: more workgroups are better)
+  static const int egmax = getenv("RAL_UNET_EVAL_GRID") ? atoi(getenv("RAL_UNET_EVAL_GRID")) : 1024;
+  const int gcap = training ? fgmax : egmax;   // (eval stages have no BatchNorm sums to flush: more workgroups are better)
   const int grid = B < gcap ? B : gcap;
   Stage st = make_stage(m, si, x, training != 0, false, B, (double)gwin);
   if (!training) st.sums_out = nullptr;

@@ -33,7 +33,10 @@ def _run(leads, L, B, seed=1234):
     return m, y, loss, p, bn, yo, lo, grads, x, tgt
 
 
-@pytest.mark.parametrize("leads,L,B", [(2, 512, 4), (1, 256, 3), (2, 1024, 2)])
+# (2, 48, 5): a level length that is not a multiple of 4 -> generic stage kernels, gradient atomics instead of the fold;
+# (2, 320, 3): fold path, stage-by-stage eval forward (the fused kernel takes multiples of 256 only);
+# (2, 64, 1025): more windows than workgroup slots with a ragged last pass (1 window of 2), short levels (4 samples)
+@pytest.mark.parametrize("leads,L,B", [(2, 512, 4), (1, 256, 3), (2, 1024, 2), (2, 48, 5), (2, 320, 3), (2, 64, 1025)])
 def test_unet_train_step_matches_oracle(leads, L, B):
     m, y, loss, p, bn, yo, lo, grads, x, tgt = _run(leads, L, B)
     assert rel(y.cpu().numpy(), yo.detach().numpy()) < 1e-5
@@ -110,3 +113,19 @@ def test_unet_bench_batch_matches_fp64_oracle():
     for k in O.UNET_BN:
         np.testing.assert_allclose(sd[k + ".running_mean"].cpu().numpy(), bn[k]["running_mean"].numpy(), rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(sd[k + ".running_var"].cpu().numpy(), bn[k]["running_var"].numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_unet_backward_twice_gives_the_same_gradients():
+    """two backward passes after one forward (replica records and scratch rows are re-initialised per pass): the gradients
+    agree to the rounding noise of the in-kernel float atomics (LDS sums of position splits, BatchNorm-backward sums)"""
+    from ecg_denoise_amd import UNet
+    B, L = 1024, 512
+    m = UNet(leads=2, L=L, max_batch=B, device=DEV, seed=5)
+    x = torch.randn(B, 2, L, device=DEV); t = torch.randn(B, 2, L, device=DEV)
+    m.train()
+    y = m(x); m.loss_and_metrics(y, t)
+    m.backward(); g1 = {k: v.clone() for k, v in m.named_grads().items()}
+    m.backward(); g2 = m.named_grads()
+    for k in g1:
+        if g1[k].double().norm().item() > 1e-7:          # (zero-gradient biases in front of a BatchNorm are pure noise)
+            assert rel(g2[k].cpu().numpy(), g1[k].cpu().numpy()) < 1e-5, k
