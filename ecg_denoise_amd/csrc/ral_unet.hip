@@ -234,8 +234,11 @@ RAL_DEV void seg_atomic(float* addr, float v, int w) {
 // read once from the zero-haloed LDS row and reused by the 4 outputs), per-channel statistics go to LDS
 // with two atomics per thread.  MODE 0: Conv1d(k3, s2, p1); 1: Conv1d(k1 | k3, s1, same); 2: ConvTranspose1d(k4, s2, p1)
 // ---------------------------------------------------------------------------------
+#ifndef UNET_FWD_THREADS
+#define UNET_FWD_THREADS 512
+#endif
 template <int CIN, int COUT, int KS, int MODE>
-__global__ __launch_bounds__(256) void k_unet_fwd_t(Stage st, int B, int WP) {
+__global__ __launch_bounds__(UNET_FWD_THREADS) void k_unet_fwd_t(Stage st, int B, int WP) {
   // A workgroup takes WP CONSECUTIVE windows per pass (one pass per workgroup at the launch sizes used): their inputs are
   // one contiguous block of global memory, requested with every load of the pass in flight at once - a window at a time
   // costs one memory round trip per window, which at 4 windows per workgroup was most of a stage's time.
@@ -256,16 +259,17 @@ __global__ __launch_bounds__(256) void k_unet_fwd_t(Stage st, int B, int WP) {
   const FoldPick fp = fold_pick(src_rec(st.a), st.a.nrep, st.b.z ? src_rec(st.b) : nullptr, st.b.nrep,
                                 st.r.z ? src_rec(st.r) : nullptr, st.r.nrep, nullptr, 1, nullptr, 1, st.w);
   const FoldLd fl = fold_load(fp.rec, fp.nrep);        // (wave w: record w)
-  float4 wv[(nw / 4 + 255) / 256];
+  constexpr int NTF = UNET_FWD_THREADS, NWVF = (nw / 4 + NTF - 1) / NTF;
+  float4 wv[NWVF];
 #pragma unroll
-  for (int k = 0; k < (nw / 4 + 255) / 256; ++k) {
-    const int i = threadIdx.x + k * 256;
+  for (int k = 0; k < NWVF; ++k) {
+    const int i = threadIdx.x + k * NTF;
     wv[k] = reinterpret_cast<const float4*>(st.w)[i < nw / 4 ? i : 0];
   }
   const float bv = st.bias[threadIdx.x < COUT ? threadIdx.x : 0];
 #pragma unroll
-  for (int k = 0; k < (nw / 4 + 255) / 256; ++k) {
-    const int i = threadIdx.x + k * 256;
+  for (int k = 0; k < NWVF; ++k) {
+    const int i = threadIdx.x + k * NTF;
     if (i < nw / 4) reinterpret_cast<float4*>(ws)[i] = wv[k];
   }
   if ((int)threadIdx.x < COUT) bs[threadIdx.x] = bv;
@@ -301,29 +305,32 @@ __global__ __launch_bounds__(256) void k_unet_fwd_t(Stage st, int B, int WP) {
       }
       *reinterpret_cast<float4*>(in + (wi * CIN + c) * LP + HALO + p) = v;
     };
-    {
-      constexpr int U = 4;
-      const int n4 = nwin * nin4, bd = blockDim.x;
-      int i = threadIdx.x;
-      for (; i + (U - 1) * bd < n4; i += U * bd) {
-        float4 v[U], u[U];
+    {   // all streams of a chunk (2 float4 per thread and stream) requested before any is used; indices past the end are
+        // clamped (no lane-predicated loads) and only their consumption is skipped
+      constexpr int U = 2;
+      const int na = nwin * nin4, nr = st.r.z ? nwin * nout4 : 0, nmax = na > nr ? na : nr, bd = blockDim.x;
+      const float4* zr = st.r.z ? reinterpret_cast<const float4*>(st.r.z + (size_t)w0 * nout) : za;
+      for (int i0 = 0; i0 < nmax; i0 += U * bd) {
+        float4 v[U], u[U], rr[U];
 #pragma unroll
-        for (int k = 0; k < U; ++k) v[k] = za[i + k * bd];
-        if (zb) {
-#pragma unroll
-          for (int k = 0; k < U; ++k) u[k] = zb[i + k * bd];
+        for (int k = 0; k < U; ++k) {
+          const int i = i0 + k * bd + (int)threadIdx.x, ja = i < na ? i : 0, jr = i < nr ? i : 0;
+          v[k] = za[ja];
+          u[k] = (zb ? zb : za)[ja];
+          rr[k] = zr[jr];
         }
 #pragma unroll
-        for (int k = 0; k < U; ++k) put(i + k * bd, v[k], u[k]);
+        for (int k = 0; k < U; ++k) {
+          const int i = i0 + k * bd + (int)threadIdx.x;
+          if (i < na) put(i, v[k], u[k]);
+          if (i < nr) {
+            const int e = (i % nout4) << 2, c = e / lout;
+            const float sr = cr[c], hr = cr[COUT + c];
+            const float4 z4 = rr[k];
+            reinterpret_cast<float4*>(rt)[i] = make_float4(lrelu01(z4.x * sr + hr), lrelu01(z4.y * sr + hr), lrelu01(z4.z * sr + hr), lrelu01(z4.w * sr + hr));
+          }
+        }
       }
-      for (; i < n4; i += bd) put(i, za[i], zb ? zb[i] : make_float4(0.f, 0.f, 0.f, 0.f));
-    }
-    if (st.r.z) {
-      for_each_f4<4>(st.r.z + (size_t)w0 * nout, nwin * nout4, [&](int i, float4 zr) {
-        const int e = (i % nout4) << 2, c = e / lout;
-        const float sr = cr[c], hr = cr[COUT + c];
-        reinterpret_cast<float4*>(rt)[i] = make_float4(lrelu01(zr.x * sr + hr), lrelu01(zr.y * sr + hr), lrelu01(zr.z * sr + hr), lrelu01(zr.w * sr + hr));
-      });
     }
     __syncthreads();
     for (int slot = threadIdx.x; slot < nwin * nslots; slot += blockDim.x) {
@@ -386,24 +393,11 @@ __global__ __launch_bounds__(256) void k_unet_fwd_t(Stage st, int B, int WP) {
   }
 }
 
-// final: y = BN9(z9) elementwise;  also running-stat updates of all layers
-__global__ void k_unet_out(Src s, float* __restrict__ y, int C, int L, double count, size_t total) {
-  __shared__ float ss[4 * MAXC];
-  src_coeffs(s, C, count, ss);
-  __syncthreads();
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)((i / L) % C);
-    y[i] = s.z[i] * ss[c] + ss[C + c];
-  }
-}
-
 // `sums` is the record the statistics come from, in nrep replicas; `final` (the caller-visible bn_sums record) receives the
 // folded sums when they were kept in replicas
 struct BnUpd { const double* sums; double* final_; float* running; int C; double count; int nrep; };
 struct BnUpdAll { BnUpd l[10]; };
-__global__ void k_unet_running(BnUpdAll u) {
-  const BnUpd& b = u.l[blockIdx.x];
-  const int c = threadIdx.x;
+RAL_DEV void unet_running_update(const BnUpd& b, int c) {
   if (c >= b.C) return;
   double s1 = 0.0, s2 = 0.0;
   for (int k = 0; k < b.nrep; ++k) { s1 += b.sums[(size_t)k * 64 + c]; s2 += b.sums[(size_t)k * 64 + MAXC + c]; }
@@ -413,6 +407,27 @@ __global__ void k_unet_running(BnUpdAll u) {
   if (var < 0.0) var = 0.0;
   b.running[c] = 0.9f * b.running[c] + 0.1f * (float)m;
   b.running[b.C + c] = 0.9f * b.running[b.C + c] + 0.1f * (float)(b.count > 1.0 ? var * b.count / (b.count - 1.0) : var);
+}
+
+// final: y = BN9(z9) elementwise; in training its first workgroups also update the running statistics of the ten layers
+// (and leaves the folded sums in the caller-visible records)
+__global__ void k_unet_out(Src s, float* __restrict__ y, int C, int L, double count, size_t total, BnUpdAll u, int do_running) {
+  __shared__ float ss[4 * MAXC];
+  src_coeffs(s, C, count, ss);
+  __syncthreads();
+  if (do_running) {      // layer b by workgroup b (the grid has at least ten: the launcher sees to it), beside its share of y
+    for (int b = blockIdx.x; b < 10; b += gridDim.x)
+      if ((int)threadIdx.x < MAXC) unet_running_update(u.l[b], threadIdx.x);
+  }
+  const float4* z4 = reinterpret_cast<const float4*>(s.z);
+  float4* y4 = reinterpret_cast<float4*>(y);
+  const size_t n4 = total >> 2;                     // (L is a multiple of 16: rows are whole float4s)
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(((i << 2) / L) % C);
+    const float sc = ss[c], sh = ss[C + c];
+    const float4 v = z4[i];
+    y4[i] = make_float4(v.x * sc + sh, v.y * sc + sh, v.z * sc + sh, v.w * sc + sh);
+  }
 }
 
 // sums of the gradient at a BatchNorm output: S1 = sum G, S2 = sum G * zhat   (used for the last layer).  One wave per
@@ -1501,6 +1516,7 @@ struct UNetModel {
   // replicas of the BatchNorm records for the one-call forward / backward (see Stage::nrep): [fwd | bwd][10][UNET_MAXREP][64]
   double* rep = nullptr;
   int nrep_f = 1, nrep_b = 1;     // replicas the current forward / backward pass adds to (1: straight into bn_sums)
+  bool rep_bwd_clean = false;     // the backward half of `rep` was zeroed by the forward pass's fill and not used since
 };
 
 int unet_check_cfg(const ral_config* c, char* err, size_t cap) {
@@ -1691,7 +1707,7 @@ static void launch_fwd_t(const Stage& st, int B, int grid, hipStream_t s) {
   const int g2 = (B + WP - 1) / WP < grid ? (B + WP - 1) / WP : grid;
   const size_t lds = ((size_t)WP * CIN * (st.lin + 8) + (st.r.z ? (size_t)WP * COUT * st.lout : 0) + (size_t)CIN * COUT * KS + MAXC +
                       12 * MAXC + 2 * MAXC + 8) * sizeof(float);
-  k_unet_fwd_t<CIN, COUT, KS, MODE><<<g2, 256, lds, s>>>(st, B, WP);
+  k_unet_fwd_t<CIN, COUT, KS, MODE><<<g2, UNET_FWD_THREADS, lds, s>>>(st, B, WP);
 }
 
 static bool launch_unet_fwd_fast(const Stage& st, int si, int leads, int B, int grid, hipStream_t s) {
@@ -1722,13 +1738,14 @@ int unet_forward_stage(UNetModel* m, const float* x, int B, int training, int si
   if (si == 0) {
     m->last_x = x; m->last_B = B;
     if (training) {
-      if (m->nrep_f > 1) (void)hipMemsetAsync(unet_rep(m, 0, 0), 0, (size_t)10 * UNET_MAXREP * 64 * sizeof(double), s);
+      // (one fill for both halves of the replica records: the backward pass of this step finds its half zeroed)
+      if (m->nrep_f > 1) { (void)hipMemsetAsync(unet_rep(m, 0, 0), 0, (size_t)2 * 10 * UNET_MAXREP * 64 * sizeof(double), s); m->rep_bwd_clean = true; }
       else (void)hipMemsetAsync(P.bn_sums, 0, 1280 * sizeof(double), s);
     }
   } else if (x != m->last_x || B != m->last_B) { snprintf(err, cap, "U-Net stages must follow stage 0 of the same batch"); return -1; }
   static const int fgmax = getenv("RAL_UNET_FWD_GRID") ? atoi(getenv("RAL_UNET_FWD_GRID")) : 512;   // (train forward at batch 2048: 0.31 / 0.27 / 0.29 / 0.41 ms with 256 / 512 / 1024 / 2048 workgroups)
-  static const int egmax = getenv("RAL_UNET_EVAL_GRID") ? atoi(getenv("RAL_UNET_EVAL_GRID")) : 1024;
-  const int gcap = training ? fgmax : egmax;   // (eval stages have no BatchNorm sums to flush: more workgroups are better)
+  static const int egmax = getenv("RAL_UNET_EVAL_GRID") ? atoi(getenv("RAL_UNET_EVAL_GRID")) : 512;   // (stage-by-stage eval forward at batch 2048: 173 / 158 / 177 us with 256 / 512 / 1024 workgroups)
+  const int gcap = training ? fgmax : egmax;
   const int grid = B < gcap ? B : gcap;
   Stage st = make_stage(m, si, x, training != 0, false, B, (double)gwin);
   if (!training) st.sums_out = nullptr;
@@ -1742,18 +1759,20 @@ int unet_forward_finish(UNetModel* m, float* y, int B, int training, int64_t gwi
   if (B != m->last_B) { snprintf(err, cap, "finish batch %d != stage batch %d", B, m->last_B); return -1; }
   Src o = make_src(m, 10, ACT_NONE, training != 0, false, 0);
   const size_t total = (size_t)B * m->C[10] * m->Ln[10];
-  k_unet_out<<<(int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048), 256, 0, s>>>(o, y, m->C[10], m->Ln[10],
-                                                                                          (double)gwin * m->Ln[10], total);
+  BnUpdAll u;
+  memset(&u, 0, sizeof(u));
   if (training) {
-    BnUpdAll u;
     for (int zi = 0, k = 0; zi < 11; ++zi) {
       const int bi = BN_OF_Z[zi];
       if (bi < 0) continue;
       u.l[k++] = BnUpd{m->nrep_f > 1 ? unet_rep(m, 0, bi) : P.bn_sums + 128 * bi, P.bn_sums + 128 * bi, P.state + m->lay.run[bi],
                        m->C[zi], (double)gwin * m->Ln[zi], m->nrep_f};
     }
-    k_unet_running<<<10, MAXC, 0, s>>>(u);     // (also folds the replicas into bn_sums: what the backward pass reads)
   }
+  // (the running update reads the layers' complete records: every stage kernel has finished; the output layer's record is
+  // read by this kernel's own coefficient fold, not written)
+  k_unet_out<<<(int)((total / 4 + 255) / 256 < 1024 ? (total / 4 + 255) / 256 : 1024), 256, 0, s>>>(o, y, m->C[10], m->Ln[10],
+                                                                                               (double)gwin * m->Ln[10], total, u, training ? 1 : 0);
   m->nrep_f = 1;
   if (hipGetLastError() != hipSuccess) { snprintf(err, cap, "U-Net forward launch failed"); return -1; }
   return 0;
@@ -1864,8 +1883,10 @@ int unet_backward_start(UNetModel* m, const float* dy, int B, int64_t gwin, hipS
   // with the fold every gradient entry is WRITTEN by k_unet_fold; the atomic path accumulates into a zeroed buffer
   if (!m->fold) (void)hipMemsetAsync(P.grads, 0, (size_t)m->lay.nparam * sizeof(float), s);
   // the ten backward halves [64, 128) of the 128-double BatchNorm records, one strided fill
-  if (m->nrep_b > 1) (void)hipMemsetAsync(unet_rep(m, 1, 0), 0, (size_t)10 * UNET_MAXREP * 64 * sizeof(double), s);
-  else (void)hipMemset2DAsync(P.bn_sums + 64, 128 * sizeof(double), 0, 64 * sizeof(double), 10, s);
+  if (m->nrep_b > 1) {
+    if (!m->rep_bwd_clean) (void)hipMemsetAsync(unet_rep(m, 1, 0), 0, (size_t)10 * UNET_MAXREP * 64 * sizeof(double), s);
+    m->rep_bwd_clean = false;
+  } else (void)hipMemset2DAsync(P.bn_sums + 64, 128 * sizeof(double), 0, 64 * sizeof(double), 10, s);
   m->last_dy = dy;
   m->bwd_rows = 0;
   const size_t total = (size_t)B * m->C[10] * m->Ln[10];
