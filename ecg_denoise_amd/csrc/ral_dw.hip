@@ -75,7 +75,10 @@ RAL_DEV void issue_then_store(LD ld, ST st, IN inner) {
 template <int M, int NC, int MS, int NS, int LAYY, int XF>
 // (Y, X, pe and a2c0 are deliberately NOT __restrict__: loads the compiler can prove invariant are sunk across the
 // compiler barrier of the staging code, next to their stores, which costs one HBM round trip per load)
-__global__ __launch_bounds__(512, 2) void k_dw(const float* Y, const float* X, const float* pe,
+#ifndef RAL_DW_WPE
+#define RAL_DW_WPE 2      // workgroups per CU the register budget is sized for (1: 256 registers, for RAL_DW_SLICE = 256 experiments)
+#endif
+__global__ __launch_bounds__(512, RAL_DW_WPE) void k_dw(const float* Y, const float* X, const float* pe,
                                                const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                const float* a2c0, float* dW, float* dB, int N, int TC, int B) {
   extern __shared__ float4 smem4[];
