@@ -75,6 +75,29 @@ RAL_DEV float wave_sum(float v) {
   for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
   return v;
 }
+// sum over groups of `w` consecutive lanes (w a power of two in [1, 64], every lane of the wave active), result in all lanes
+RAL_DEV float seg_sum(float v, int w) {
+  switch (w) {
+    case 64: return group_sum<64>(v);
+    case 32: return group_sum<32>(v);
+    case 16: return group_sum<16>(v);
+    case 8: return group_sum<8>(v);
+    case 4: return group_sum<4>(v);
+    case 2: return group_sum<2>(v);
+    default: return v;
+  }
+}
+RAL_DEV float hsum4(float4 v) { return (v.x + v.y) + (v.z + v.w); }
+RAL_DEV int ec_of(int tid, int C) { return tid % C; }
+// items of V floats (V = 4: 16-byte accesses; V = 1 for level lengths that are not a multiple of 4: value in .x, rest 0)
+template <int V> RAL_DEV float4 ldv(const float* p, int i) {
+  if constexpr (V == 4) return reinterpret_cast<const float4*>(p)[i];
+  else return make_float4(p[i], 0.f, 0.f, 0.f);
+}
+template <int V> RAL_DEV void stv(float* p, int i, float4 v) {
+  if constexpr (V == 4) reinterpret_cast<float4*>(p)[i] = v;
+  else p[i] = v.x;
+}
 RAL_DEV float wave_max(float v) {
   for (int s = 32; s > 0; s >>= 1) v = fmaxf(v, __shfl_xor(v, s));
   return v;
@@ -150,67 +173,132 @@ __global__ __launch_bounds__(NT) void k_dn_conv(const float* __restrict__ in0, c
 // k_dn_fcn_mid: h2 = W3 relu(BN1(h1)) + b3 for `np` paths (path p at h1 + p B dh, sums + p 2 dh, ...); column sums of h2;
 // workgroup 0 applies the running-statistic update of BN1 (path by path: the shared DAM fcn sees two batches).
 // ---------------------------------------------------------------------------------
+// One WAVE per window, four windows of a wave in flight, no block barrier inside the window loop: these kernels move
+// 64 floats per window, so their time was one memory round trip and two barriers per window and, at 1024 workgroups,
+// a 1024-link same-address chain of double atomics per column sum (25 us for half a megabyte).  Lane l < np dh stages
+// relu(BN1(h1)) of (path, j) in the wave's LDS row; lane l < np dout forms column l of the second Linear from it.
+constexpr int DWIN = 4;                 // windows per wave and pass
+constexpr int DLD = 65;                 // LDS row stride of W3 (dout x dh, dh <= 64): odd, so that 32 rows hit 32 banks
 __global__ __launch_bounds__(NT) void k_dn_fcn_mid(const float* __restrict__ h1, const double* sums1, Fcn F,
                                                    float* __restrict__ h2, double* sums2, int np, int B, int training) {
-  __shared__ float rs[2][MAXC], mean1[2][MAXC], rstd1[2][MAXC];
-  const int tid = threadIdx.x;
+  __shared__ float w3s[32 * DLD], mean1[2][MAXC], rstd1[2][MAXC], g1s[MAXC], b1s[MAXC];
+  __shared__ float rs[NT / 64][DWIN][2 * MAXC];      // per wave and window: relu(BN1(h1)), both paths
+  __shared__ double red[NT / 64][2][MAXC];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < np * F.dh; i += NT) {
     const int p = i / F.dh, j = i - p * F.dh;
     bn_stat(sums1 + p * 2 * F.dh, F.dh, j, B, training, F.bn1.rm, F.bn1.rv, mean1[p][j], rstd1[p][j]);
   }
+  if (tid < F.dh) { g1s[tid] = F.bn1.g[tid]; b1s[tid] = F.bn1.b[tid]; }
+  for (int i = tid; i < F.dout * F.dh; i += NT) w3s[(i / F.dh) * DLD + i % F.dh] = F.w3[i];
   if (training && blockIdx.x == 0 && tid < F.dh)
     for (int p = 0; p < np; ++p) bn_running(sums1 + p * 2 * F.dh, F.dh, tid, B, F.bn1.rm, F.bn1.rv);
-  double s1 = 0, s2 = 0;      // thread (p, c) = tid owns column c of path p
-  const int pc = tid / F.dout, cc = tid - pc * F.dout;
-  for (int win = blockIdx.x; win < B; win += gridDim.x) {
-    __syncthreads();
-    for (int i = tid; i < np * F.dh; i += NT) {
-      const int p = i / F.dh, j = i - p * F.dh;
-      const float v = F.bn1.g[j] * (h1[((size_t)p * B + win) * F.dh + j] - mean1[p][j]) * rstd1[p][j] + F.bn1.b[j];
-      rs[p][j] = fmaxf(v, 0.f);
+  __syncthreads();
+  const int nin = np * F.dh, nout = np * F.dout;
+  const int pi = lane / F.dh, ji = lane - pi * F.dh;          // this lane's input element (lane < nin)
+  const int pc = lane / F.dout, cc = lane - pc * F.dout;      // this lane's output column (lane < nout)
+  const float b3 = lane < nout ? F.b3[cc] : 0.f;
+  double s1 = 0, s2 = 0;
+  const int nwv = gridDim.x * (NT / 64);
+  for (int w0 = (blockIdx.x * (NT / 64) + wave) * DWIN; w0 < B; w0 += nwv * DWIN) {
+    float v[DWIN];
+#pragma unroll
+    for (int q = 0; q < DWIN; ++q) {               // the four loads first (clamped: no lane-predicated loads)
+      const int win = w0 + q < B ? w0 + q : B - 1;
+      v[q] = h1[((size_t)(lane < nin ? pi : 0) * B + win) * F.dh + (lane < nin ? ji : 0)];
     }
+#pragma unroll
+    for (int q = 0; q < DWIN; ++q)
+      if (lane < nin) rs[wave][q][pi * MAXC + ji] = fmaxf(g1s[ji] * (v[q] - mean1[pi][ji]) * rstd1[pi][ji] + b1s[ji], 0.f);
+    __builtin_amdgcn_wave_barrier();               // (the wave's own LDS writes are ordered before its reads)
+    if (lane < nout) {
+#pragma unroll
+      for (int q = 0; q < DWIN; ++q) {
+        if (w0 + q >= B) break;
+        float acc = b3;
+        const float* r = rs[wave][q] + pc * MAXC;
+        const float* wr = w3s + cc * DLD;
+        for (int j = 0; j < F.dh; ++j) acc = fmaf(wr[j], r[j], acc);
+        h2[((size_t)pc * B + w0 + q) * F.dout + cc] = acc;
+        s1 += acc; s2 += (double)acc * acc;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (sums2) {                                     // the four waves' column sums meet in LDS: one atomic pair per column and workgroup
+    if (lane < nout) { red[wave][0][lane] = s1; red[wave][1][lane] = s2; }
     __syncthreads();
-    if (pc < np) {
-      float acc = F.b3[cc];
-      for (int j = 0; j < F.dh; ++j) acc = fmaf(F.w3[cc * F.dh + j], rs[pc][j], acc);
-      h2[((size_t)pc * B + win) * F.dout + cc] = acc;
-      s1 += acc; s2 += (double)acc * acc;
+    if (tid < nout) {
+      double a1 = 0, a2 = 0;
+      for (int w = 0; w < NT / 64; ++w) { a1 += red[w][0][tid]; a2 += red[w][1][tid]; }
+      const int p = tid / F.dout, c = tid - p * F.dout;
+      atomicAdd(sums2 + p * 2 * F.dout + c, a1); atomicAdd(sums2 + p * 2 * F.dout + F.dout + c, a2);
     }
   }
-  if (sums2 && pc < np) { atomicAdd(sums2 + pc * 2 * F.dout + cc, s1); atomicAdd(sums2 + pc * 2 * F.dout + F.dout + cc, s2); }
 }
 
 // ---------------------------------------------------------------------------------
 // k_dn_act: alpha = sigmoid(BN2(h2)); a = max(z, 0) + alpha min(z, 0); per-channel sums of a; BN2 running update
 // ---------------------------------------------------------------------------------
+// Elementwise kernels of the cell: a workgroup takes EW consecutive windows per pass - one contiguous block of every tensor,
+// requested as 16-byte loads with all loads of the pass in flight - and a lane's four values belong to ONE channel row
+// (lout is a multiple of 4), so the per-channel sums are wave-level segment sums in front of one LDS atomic per row piece.
+// (A wave per channel row with 4-byte loads paid one memory round trip per 64 floats.)
+constexpr int EW = 4;                              // windows per workgroup and pass
+template <int V>
 __global__ __launch_bounds__(NT) void k_dn_act(const float* __restrict__ z, const float* __restrict__ h2, const double* sums2,
                                                Fcn F, Geo G, float* __restrict__ a, double* sumsa, int B, int training) {
-  __shared__ float mean2[MAXC], rstd2[MAXC], al[MAXC];
-  __shared__ double acc1[MAXC], acc2[MAXC];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ float mean2[MAXC], rstd2[MAXC], g2s[MAXC], b2s[MAXC], al[EW][MAXC];
+  __shared__ float acc1[MAXC], acc2[MAXC];
+  const int tid = threadIdx.x;
   if (tid < G.c) {
     bn_stat(sums2, G.c, tid, B, training, F.bn2.rm, F.bn2.rv, mean2[tid], rstd2[tid]);
-    acc1[tid] = 0; acc2[tid] = 0;
+    g2s[tid] = F.bn2.g[tid]; b2s[tid] = F.bn2.b[tid];
+    acc1[tid] = 0.f; acc2[tid] = 0.f;
     if (training && blockIdx.x == 0) bn_running(sums2, G.c, tid, B, F.bn2.rm, F.bn2.rv);
   }
-  const int nz = G.c * G.lout;
-  for (int win = blockIdx.x; win < B; win += gridDim.x) {
+  const int nz = G.c * G.lout, n4w = nz / V, q4 = G.lout / V;          // items per window / per channel row
+  const int segw = ((q4 & (q4 - 1)) == 0 && (EW * n4w) % 64 == 0) ? (q4 < 64 ? q4 : 64) : 1;
+  double t1 = 0, t2 = 0;                                                // (thread c < C: running totals of channel c)
+  for (int w0 = blockIdx.x * EW; w0 < B; w0 += gridDim.x * EW) {
+    const int nwin = (B - w0) < EW ? (B - w0) : EW, n4 = nwin * n4w;
+    const float* z4 = z + (size_t)w0 * nz;
+    float* a4 = a + (size_t)w0 * nz;
     __syncthreads();
-    if (tid < G.c) al[tid] = sigm(F.bn2.g[tid] * (h2[(size_t)win * G.c + tid] - mean2[tid]) * rstd2[tid] + F.bn2.b[tid]);
-    __syncthreads();
-    for (int c = wave; c < G.c; c += NT / 64) {
-      float s1 = 0.f, s2 = 0.f;
-      for (int l = lane; l < G.lout; l += 64) {
-        const size_t o = (size_t)win * nz + c * G.lout + l;
-        const float v = z[o], r = v > 0.f ? v : al[c] * v;
-        a[o] = r; s1 += r; s2 += r * r;
-      }
-      s1 = wave_sum(s1); s2 = wave_sum(s2);
-      if (lane == 0) { acc1[c] += s1; acc2[c] += s2; }   // (channel c is always this wave's)
+    if (tid < EW * G.c) {
+      const int q = tid / G.c, c = tid - q * G.c, win = w0 + q < B ? w0 + q : B - 1;
+      al[q][c] = sigm(g2s[c] * (h2[(size_t)win * G.c + c] - mean2[c]) * rstd2[c] + b2s[c]);
     }
+    for (int i0 = 0; i0 < n4; i0 += 4 * NT) {
+      float4 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const int i = i0 + k * NT + tid; v[k] = ldv<V>(z4, i < n4 ? i : 0); }
+      __syncthreads();                                                   // (al of this pass; uniform: n4 is)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = i0 + k * NT + tid;
+        float s1 = 0.f, s2 = 0.f;
+        int c = 0;
+        if (i < n4) {
+          const int q = i / n4w, e = i - q * n4w;
+          c = e / q4;
+          const float al_ = al[q][c];
+          float4 r = v[k];
+          r.x = r.x > 0.f ? r.x : al_ * r.x; r.y = r.y > 0.f ? r.y : al_ * r.y;
+          r.z = r.z > 0.f ? r.z : al_ * r.z; r.w = r.w > 0.f ? r.w : al_ * r.w;
+          stv<V>(a4, i, r);
+          s1 = hsum4(r); s2 = (r.x * r.x + r.y * r.y) + (r.z * r.z + r.w * r.w);
+        }
+        if (sumsa) {
+          if (segw > 1) { s1 = seg_sum(s1, segw); s2 = seg_sum(s2, segw); if ((tid & (segw - 1)) == 0 && i < n4) { atomicAdd(acc1 + c, s1); atomicAdd(acc2 + c, s2); } }
+          else if (i < n4) { atomicAdd(acc1 + c, s1); atomicAdd(acc2 + c, s2); }
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < G.c) { t1 += acc1[tid]; t2 += acc2[tid]; acc1[tid] = 0.f; acc2[tid] = 0.f; }
   }
-  __syncthreads();
-  if (sumsa && tid < G.c) { atomicAdd(sumsa + tid, acc1[tid]); atomicAdd(sumsa + G.c + tid, acc2[tid]); }
+  if (sumsa && tid < G.c) { atomicAdd(sumsa + tid, t1); atomicAdd(sumsa + G.c + tid, t2); }
 }
 
 // x = BN(a) of one window into LDS (scale / shift per channel precomputed)
@@ -397,15 +485,19 @@ __global__ __launch_bounds__(NT) void k_dn_dam_b(const float* dout /* may alias 
 //   dh2 = g2 rstd2 (dy2 - mean(dy2) - h2hat mean(dy2 h2hat));  dW3 += dh2 (x) r;  db3 += dh2;  dr = W3^T dh2;
 //   dy1 = dr [BN1(h1) > 0]  (stored, (np, B, dh)) and its BatchNorm-backward sums;  workgroup 0: dg2, dbeta2 from the sums.
 // ---------------------------------------------------------------------------------
+// (one wave per window, four windows in flight, as k_dn_fcn_mid: the window loop has no block barrier; a wave keeps its share
+// of dW3 in registers - entry e = lane + 64 k of the (dout x dh) matrix - and the four waves meet in the LDS accumulator)
 __global__ __launch_bounds__(NT) void k_dn_fcn_bmid(const float* __restrict__ dy2, const double* t2, const float* __restrict__ h2,
                                                     const double* sums2, const float* __restrict__ h1, const double* sums1,
                                                     Fcn F, float* __restrict__ dy1, double* t1, int np, int B) {
   extern __shared__ float sm[];
   float* aw3 = sm;                          // dout x dh accumulator
   float* ab3 = aw3 + F.dout * F.dh;         // dout
-  __shared__ float mean1[2][MAXC], rstd1[2][MAXC], mean2[2][MAXC], rstd2[2][MAXC], m1[2][MAXC], m2[2][MAXC];
-  __shared__ float rs[2][MAXC], bnv[2][MAXC], dh2s[2][MAXC];
-  const int tid = threadIdx.x;
+  __shared__ float w3s[32 * DLD], mean1[2][MAXC], rstd1[2][MAXC], mean2[2][MAXC], rstd2[2][MAXC], m1[2][MAXC], m2[2][MAXC];
+  __shared__ float g1s[MAXC], b1s[MAXC], g2s[MAXC];
+  __shared__ float rs[NT / 64][DWIN][2 * MAXC], dh2w[NT / 64][DWIN][MAXC];     // per wave and window: relu(BN1(h1)); dh2 (path p at 32 p)
+  __shared__ double red[NT / 64][2][MAXC];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < F.dout * F.dh + F.dout; i += NT) aw3[i] = 0.f;
   for (int i = tid; i < np * F.dh; i += NT) {
     const int p = i / F.dh, j = i - p * F.dh;
@@ -417,42 +509,86 @@ __global__ __launch_bounds__(NT) void k_dn_fcn_bmid(const float* __restrict__ dy
     m1[p][c] = (float)(t2[p * 2 * F.dout + c] / B); m2[p][c] = (float)(t2[p * 2 * F.dout + F.dout + c] / B);
     if (blockIdx.x == 0) { atomicAdd(F.bn2.db + c, (float)t2[p * 2 * F.dout + c]); atomicAdd(F.bn2.dg + c, (float)t2[p * 2 * F.dout + F.dout + c]); }
   }
-  double q1 = 0, q2 = 0;       // thread (path, j): sums of dy1, dy1 * h1hat
-  const int pj = tid / F.dh, jj = tid - pj * F.dh;
-  for (int win = blockIdx.x; win < B; win += gridDim.x) {
-    __syncthreads();
-    for (int i = tid; i < np * F.dh; i += NT) {
-      const int p = i / F.dh, j = i - p * F.dh;
-      const float v = F.bn1.g[j] * (h1[((size_t)p * B + win) * F.dh + j] - mean1[p][j]) * rstd1[p][j] + F.bn1.b[j];
-      bnv[p][j] = v; rs[p][j] = fmaxf(v, 0.f);
+  if (tid < F.dh) { g1s[tid] = F.bn1.g[tid]; b1s[tid] = F.bn1.b[tid]; }
+  if (tid < F.dout) g2s[tid] = F.bn2.g[tid];
+  for (int i = tid; i < F.dout * F.dh; i += NT) w3s[(i / F.dh) * DLD + i % F.dh] = F.w3[i];
+  __syncthreads();
+  const int nin = np * F.dh, nout = np * F.dout, nent = (F.dout * F.dh + 63) / 64;
+  const int pi = lane / F.dh, ji = lane - pi * F.dh;          // this lane's hidden element (lane < nin)
+  const int pc = lane / F.dout, cc = lane - pc * F.dout;      // this lane's output column (lane < nout)
+  float accw[32];                                             // dW3 entries lane + 64 k (dout dh <= 2048)
+#pragma unroll
+  for (int k = 0; k < 32; ++k) accw[k] = 0.f;
+  float accb = 0.f;
+  double q1 = 0, q2 = 0;       // lane (path, j): sums of dy1, dy1 * h1hat
+  const int nwv = gridDim.x * (NT / 64);
+  for (int w0 = (blockIdx.x * (NT / 64) + wave) * DWIN; w0 < B; w0 += nwv * DWIN) {
+    float v1[DWIN], v2[DWIN], vd[DWIN];
+#pragma unroll
+    for (int q = 0; q < DWIN; ++q) {               // all twelve loads first (clamped: no lane-predicated loads)
+      const int win = w0 + q < B ? w0 + q : B - 1;
+      v1[q] = h1[((size_t)(lane < nin ? pi : 0) * B + win) * F.dh + (lane < nin ? ji : 0)];
+      const size_t o = ((size_t)(lane < nout ? pc : 0) * B + win) * F.dout + (lane < nout ? cc : 0);
+      v2[q] = h2[o]; vd[q] = dy2[o];
     }
-    for (int i = tid; i < np * F.dout; i += NT) {
-      const int p = i / F.dout, c = i - p * F.dout;
-      const size_t o = ((size_t)p * B + win) * F.dout + c;
-      const float hh = (h2[o] - mean2[p][c]) * rstd2[p][c];
-      dh2s[p][c] = F.bn2.g[c] * rstd2[p][c] * (dy2[o] - m1[p][c] - hh * m2[p][c]);
+    float hh1[DWIN]; bool pos[DWIN];
+#pragma unroll
+    for (int q = 0; q < DWIN; ++q) {
+      if (lane < nin) {
+        hh1[q] = (v1[q] - mean1[pi][ji]) * rstd1[pi][ji];
+        const float bnv = g1s[ji] * (v1[q] - mean1[pi][ji]) * rstd1[pi][ji] + b1s[ji];
+        pos[q] = bnv > 0.f;
+        rs[wave][q][pi * MAXC + ji] = fmaxf(bnv, 0.f);
+      }
+      if (lane < nout) {
+        const float hh = (v2[q] - mean2[pc][cc]) * rstd2[pc][cc];
+        const float d2 = (w0 + q < B) ? g2s[cc] * rstd2[pc][cc] * (vd[q] - m1[pc][cc] - hh * m2[pc][cc]) : 0.f;   // (past the end: no contribution)
+        dh2w[wave][q][pc * 32 + cc] = d2;
+        accb += d2;
+      }
     }
-    __syncthreads();
-    for (int i = tid; i < F.dout * F.dh; i += NT) {
-      const int c = i / F.dh, j = i - c * F.dh;
-      float v = dh2s[0][c] * rs[0][j];
-      if (np > 1) v = fmaf(dh2s[1][c], rs[1][j], v);
-      aw3[i] += v;
+    __builtin_amdgcn_wave_barrier();               // (the wave's own LDS writes are ordered before its reads)
+#pragma unroll
+    for (int q = 0; q < DWIN; ++q) {
+      if (w0 + q >= B) break;
+      if (lane < nin) {
+        float dr = 0.f;
+        const float* d2 = dh2w[wave][q] + pi * 32;
+        for (int c = 0; c < F.dout; ++c) dr = fmaf(w3s[c * DLD + ji], d2[c], dr);
+        const float d = pos[q] ? dr : 0.f;
+        dy1[((size_t)pi * B + w0 + q) * F.dh + ji] = d;
+        q1 += d; q2 += (double)d * hh1[q];
+      }
+#pragma unroll
+      for (int k = 0; k < 32; ++k) {
+        const int e = lane + 64 * k;
+        if (k < nent && e < F.dout * F.dh) {
+          const int c = e / F.dh, j = e - c * F.dh;
+          float t = dh2w[wave][q][c] * rs[wave][q][j];
+          if (np > 1) t = fmaf(dh2w[wave][q][32 + c], rs[wave][q][MAXC + j], t);
+          accw[k] += t;
+        }
+      }
     }
-    if (tid < F.dout) ab3[tid] += dh2s[0][tid] + (np > 1 ? dh2s[1][tid] : 0.f);
-    if (pj < np) {
-      float dr = 0.f;
-      for (int c = 0; c < F.dout; ++c) dr = fmaf(F.w3[c * F.dh + jj], dh2s[pj][c], dr);
-      const float d = bnv[pj][jj] > 0.f ? dr : 0.f;
-      dy1[((size_t)pj * B + win) * F.dh + jj] = d;
-      const float hh = (h1[((size_t)pj * B + win) * F.dh + jj] - mean1[pj][jj]) * rstd1[pj][jj];
-      q1 += d; q2 += (double)d * hh;
-    }
+    __builtin_amdgcn_wave_barrier();
   }
+  // the four waves meet in the LDS accumulators, then one atomic per entry and workgroup
+#pragma unroll
+  for (int k = 0; k < 32; ++k) {
+    const int e = lane + 64 * k;
+    if (k < nent && e < F.dout * F.dh) atomicAdd(aw3 + e, accw[k]);
+  }
+  if (lane < nout) atomicAdd(ab3 + cc, accb);
+  if (lane < nin) { red[wave][0][lane] = q1; red[wave][1][lane] = q2; }
   __syncthreads();
   flush(F.dw3, aw3, F.dout * F.dh, tid);
   flush(F.db3, ab3, F.dout, tid);
-  if (pj < np) { atomicAdd(t1 + pj * 2 * F.dh + jj, q1); atomicAdd(t1 + pj * 2 * F.dh + F.dh + jj, q2); }
+  if (tid < nin) {
+    double a1 = 0, a2 = 0;
+    for (int w = 0; w < NT / 64; ++w) { a1 += red[w][0][tid]; a2 += red[w][1][tid]; }
+    const int p = tid / F.dh, j = tid - p * F.dh;
+    atomicAdd(t1 + p * 2 * F.dh + j, a1); atomicAdd(t1 + p * 2 * F.dh + F.dh + j, a2);
+  }
 }
 
 // BN1 backward + first Linear backward of one window and path: dh1 -> LDS accumulators, returns d input[i] for thread i
@@ -556,45 +692,68 @@ __global__ __launch_bounds__(NT) void k_dn_bn_b(const float* g0 /* may alias dxo
 //   da = g rstd (dxo - mean(dxo) - ahat mean(dxo ahat)) (stored in place of dxo);  dalpha[c] = sum_l da min(z, 0);
 //   dy2 = dalpha alpha (1 - alpha) (B, C) and its BatchNorm-backward sums;  workgroup 0: dg, dbeta of the cell's BatchNorm.
 // ---------------------------------------------------------------------------------
+template <int V>
 __global__ __launch_bounds__(NT) void k_dn_act_b(float* __restrict__ dxo, const float* __restrict__ a, const float* __restrict__ z,
                                                  const double* sumsa, const double* tbn, Bn bn, Geo G,
                                                  const float* __restrict__ h2, const double* sums2, Fcn F,
                                                  float* __restrict__ dy2, double* t2, int B) {
-  __shared__ float mean[MAXC], rstd[MAXC], k1[MAXC], k2[MAXC], mean2[MAXC], rstd2[MAXC], dal[MAXC];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, C = G.c, nz = C * G.lout;
+  __shared__ float mean[MAXC], rstd[MAXC], k1[MAXC], k2[MAXC], grs[MAXC], mean2[MAXC], rstd2[MAXC], g2s[MAXC], b2s[MAXC], dal[EW][MAXC];
+  const int tid = threadIdx.x, C = G.c, nz = C * G.lout, n4w = nz / V, q4 = G.lout / V;
   const double cnt = (double)B * G.lout;
   if (tid < C) {
     bn_stat(sumsa, C, tid, cnt, 1, nullptr, nullptr, mean[tid], rstd[tid]);
     k1[tid] = (float)(tbn[tid] / cnt); k2[tid] = (float)(tbn[C + tid] / cnt);
+    grs[tid] = bn.g[tid] * rstd[tid];
     bn_stat(sums2, C, tid, B, 1, nullptr, nullptr, mean2[tid], rstd2[tid]);
+    g2s[tid] = F.bn2.g[tid]; b2s[tid] = F.bn2.b[tid];
     if (blockIdx.x == 0) { atomicAdd(bn.db + tid, (float)tbn[tid]); atomicAdd(bn.dg + tid, (float)tbn[C + tid]); }
   }
-  double q1 = 0, q2 = 0;
-  for (int win = blockIdx.x; win < B; win += gridDim.x) {
+  const int segw = ((q4 & (q4 - 1)) == 0 && (EW * n4w) % 64 == 0) ? (q4 < 64 ? q4 : 64) : 1;
+  double q1 = 0, q2 = 0;                       // thread (window slot, c): sums of dy2, dy2 * h2hat of channel c
+  for (int w0 = blockIdx.x * EW; w0 < B; w0 += gridDim.x * EW) {
+    const int nwin = (B - w0) < EW ? (B - w0) : EW, n4 = nwin * n4w;
+    float* d4 = dxo + (size_t)w0 * nz;
+    const float* a4 = a + (size_t)w0 * nz;
+    const float* z4 = z + (size_t)w0 * nz;
     __syncthreads();
-    for (int c = wave; c < C; c += NT / 64) {
-      float s = 0.f;
-      const float gr = bn.g[c] * rstd[c];
-      for (int l = lane; l < G.lout; l += 64) {
-        const size_t o = (size_t)win * nz + c * G.lout + l;
-        const float ah = (a[o] - mean[c]) * rstd[c];
-        const float d = gr * (dxo[o] - k1[c] - ah * k2[c]);
-        dxo[o] = d;
-        s = fmaf(d, fminf(z[o], 0.f), s);
+    if (tid < EW * C) dal[tid / C][tid % C] = 0.f;
+    // this thread's (window, channel) of the epilogue: its h2 value is requested with the pass's other loads
+    const int eq = tid / C, ec = tid - eq * C;
+    const float h2v = h2[(size_t)((tid < EW * C && w0 + eq < B) ? w0 + eq : w0) * C + (tid < EW * C ? ec : 0)];
+    __syncthreads();
+    for (int i0 = 0; i0 < n4; i0 += 2 * NT) {
+      float4 dv[2], av[2], zv[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) { const int i = i0 + k * NT + tid, j = i < n4 ? i : 0; dv[k] = ldv<V>(d4, j); av[k] = ldv<V>(a4, j); zv[k] = ldv<V>(z4, j); }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int i = i0 + k * NT + tid;
+        float sv = 0.f;
+        int q = 0, c = 0;
+        if (i < n4) {
+          q = i / n4w; const int e = i - q * n4w;
+          c = e / q4;
+          const float mu = mean[c], rs = rstd[c], gr = grs[c], kk1 = k1[c], kk2 = k2[c];
+          float4 d;
+          d.x = gr * (dv[k].x - kk1 - (av[k].x - mu) * rs * kk2); d.y = gr * (dv[k].y - kk1 - (av[k].y - mu) * rs * kk2);
+          d.z = gr * (dv[k].z - kk1 - (av[k].z - mu) * rs * kk2); d.w = gr * (dv[k].w - kk1 - (av[k].w - mu) * rs * kk2);
+          stv<V>(d4, i, d);
+          sv = fmaf(d.x, fminf(zv[k].x, 0.f), fmaf(d.y, fminf(zv[k].y, 0.f), fmaf(d.z, fminf(zv[k].z, 0.f), d.w * fminf(zv[k].w, 0.f))));
+        }
+        if (segw > 1) { sv = seg_sum(sv, segw); if ((tid & (segw - 1)) == 0 && i < n4) atomicAdd(&dal[q][c], sv); }
+        else if (i < n4) atomicAdd(&dal[q][c], sv);
       }
-      s = wave_sum(s);
-      if (lane == 0) dal[c] = s;
     }
     __syncthreads();
-    if (tid < C) {
-      const float hh = (h2[(size_t)win * C + tid] - mean2[tid]) * rstd2[tid];
-      const float al = sigm(fmaf(F.bn2.g[tid], hh, F.bn2.b[tid]));
-      const float d = dal[tid] * al * (1.f - al);
-      dy2[(size_t)win * C + tid] = d;
+    if (tid < EW * C && w0 + eq < B) {
+      const float hh = (h2v - mean2[ec]) * rstd2[ec];
+      const float al = sigm(fmaf(g2s[ec], hh, b2s[ec]));
+      const float d = dal[eq][ec] * al * (1.f - al);
+      dy2[(size_t)(w0 + eq) * C + ec] = d;
       q1 += d; q2 += (double)d * hh;
     }
   }
-  if (tid < C) { atomicAdd(t2 + tid, q1); atomicAdd(t2 + C + tid, q2); }
+  if (tid < EW * C) { atomicAdd(t2 + ec_of(tid, C), q1); atomicAdd(t2 + C + ec_of(tid, C), q2); }
 }
 
 // ---------------------------------------------------------------------------------
@@ -870,6 +1029,10 @@ int danet_forward(DanetModel* m, const float* x, float* y, int B, int training, 
   if (training && B < 2) { snprintf(err, cap, "DANet: a training forward needs at least 2 windows (BatchNorm over the batch of descriptors)"); return -1; }
   static const int gf = getenv("RAL_DANET_GRID_F") ? atoi(getenv("RAL_DANET_GRID_F")) : 1024;
   const int grid = B < gf ? B : gf;
+  static const int gdesc = getenv("RAL_DANET_GRID_D") ? atoi(getenv("RAL_DANET_GRID_D")) : 256;   // descriptor-level kernels: a wave per window,
+  const int gridd = (B + 15) / 16 < gdesc ? (B + 15) / 16 : gdesc;                                   // 16 windows per workgroup and pass
+  static const int gact = getenv("RAL_DANET_GRID_A") ? atoi(getenv("RAL_DANET_GRID_A")) : 256;    // elementwise kernels: EW = 4 windows per pass
+  const int grida = (B + 3) / 4 < gact ? (B + 3) / 4 : gact;
   if (training) (void)hipMemsetAsync(m->sums, 0, sizeof(double) * 8 * S_CELL, st);
   m->last_x = x; m->last_B = B; m->last_training = training != 0;
   for (int i = 0; i < 8; ++i) {
@@ -890,15 +1053,16 @@ int danet_forward(DanetModel* m, const float* x, float* y, int B, int training, 
     };
     if (G.k == 17) conv(k_dn_conv<17, false>); else if (G.k == 3) conv(k_dn_conv<3, false>);
     else if (G.k == 4) conv(k_dn_conv<4, true>); else conv(k_dn_conv<18, true>);
-    k_dn_fcn_mid<<<grid, NT, 0, st>>>(m->h1[i], S + S_AH1, Fa, m->h2[i], training ? S + S_AH2 : nullptr, 1, B, training);
-    k_dn_act<<<grid, NT, 0, st>>>(m->z[i], m->h2[i], S + S_AH2, Fa, G, m->a[i], training ? S + S_BN : nullptr, B, training);
+    k_dn_fcn_mid<<<gridd, NT, 0, st>>>(m->h1[i], S + S_AH1, Fa, m->h2[i], training ? S + S_AH2 : nullptr, 1, B, training);
+    if (G.lout % 4 == 0) k_dn_act<4><<<grida, NT, 0, st>>>(m->z[i], m->h2[i], S + S_AH2, Fa, G, m->a[i], training ? S + S_BN : nullptr, B, training);
+    else k_dn_act<1><<<grida, NT, 0, st>>>(m->z[i], m->h2[i], S + S_AH2, Fa, G, m->a[i], training ? S + S_BN : nullptr, B, training);
     Fcn Fd = Fa;
     if (G.dam) {
       Fd = mk_fcn(P, K.dam);
       const size_t l2 = nz * sizeof(float);
       set_lds(k_dn_dam1, l2);
       k_dn_dam1<<<grid, NT, l2, st>>>(m->a[i], S + S_BN, bn, Fd, G, m->pool[i], m->dh1[i], training ? S + S_DH1 : nullptr, B, training);
-      k_dn_fcn_mid<<<grid, NT, 0, st>>>(m->dh1[i], S + S_DH1, Fd, m->dh2[i], training ? S + S_DH2 : nullptr, 2, B, training);
+      k_dn_fcn_mid<<<gridd, NT, 0, st>>>(m->dh1[i], S + S_DH1, Fd, m->dh2[i], training ? S + S_DH2 : nullptr, 2, B, training);
     }
     const size_t l3 = (nz + G.lout) * sizeof(float);
     set_lds(k_dn_out, l3);
@@ -915,8 +1079,13 @@ int danet_backward(DanetModel* m, const float* dy, float* dx, int B, hipStream_t
   if (B != m->last_B || !m->last_training) { snprintf(err, cap, "DANet backward needs a training forward of the same batch first"); return -1; }
   static const int gb = getenv("RAL_DANET_GRID_B") ? atoi(getenv("RAL_DANET_GRID_B")) : 1024;   // (train step at batch 2048: 3.84 / 3.58 / 4.43 ms with 512 / 1024 / 2048)
   const int grid = B < gb ? B : gb;
+  static const int gdesc = getenv("RAL_DANET_GRID_D") ? atoi(getenv("RAL_DANET_GRID_D")) : 256;   // descriptor-level kernels (see danet_forward)
+  const int gridd = (B + 15) / 16 < gdesc ? (B + 15) / 16 : gdesc;
+  static const int gact = getenv("RAL_DANET_GRID_A") ? atoi(getenv("RAL_DANET_GRID_A")) : 256;    // elementwise kernels (see danet_forward)
+  const int grida = (B + 3) / 4 < gact ? (B + 3) / 4 : gact;
   (void)hipMemsetAsync(P.grads, 0, (size_t)m->lay.nparam * sizeof(float), st);
-  for (int i = 0; i < 8; ++i) (void)hipMemsetAsync(m->sums + (size_t)i * S_CELL + T_D2, 0, sizeof(double) * (S_CELL - T_D2), st);
+  // the backward halves [T_D2, S_CELL) of the eight cells' sum records: one strided fill
+  (void)hipMemset2DAsync(m->sums + T_D2, sizeof(double) * S_CELL, 0, sizeof(double) * (S_CELL - T_D2), 8, st);
   for (int i = 7; i >= 0; --i) {
     const CellOff& K = m->lay.cell[i];
     const Geo& G = K.g;
@@ -937,17 +1106,18 @@ int danet_backward(DanetModel* m, const float* dy, float* dx, int B, hipStream_t
       k_dn_dam_b<<<grid, NT, l1, st>>>(g0, m->a[i], S + S_BN, bn, G, m->dh2[i], S + S_DH2, Fd, P.params + K.saw, P.params + K.sab,
                                         P.grads + K.saw, P.grads + K.sab, work, m->ddy2[i], S + T_D2, B);
       const size_t l2 = ((size_t)Fd.dout * Fd.dh + Fd.dout) * sizeof(float);
-      k_dn_fcn_bmid<<<grid, NT, l2, st>>>(m->ddy2[i], S + T_D2, m->dh2[i], S + S_DH2, m->dh1[i], S + S_DH1, Fd, m->ddy1[i], S + T_D1, 2, B);
+      k_dn_fcn_bmid<<<gridd, NT, l2, st>>>(m->ddy2[i], S + T_D2, m->dh2[i], S + S_DH2, m->dh1[i], S + S_DH1, Fd, m->ddy1[i], S + T_D1, 2, B);
       g0 = work; g1 = nullptr;
     }
     const size_t l3 = (nz + (G.dam ? (size_t)Fd.dh * Fd.din + Fd.dh : 0)) * sizeof(float);
     set_lds(k_dn_bn_b, l3);
     k_dn_bn_b<<<grid, NT, l3, st>>>(g0, g1, m->a[i], S + S_BN, bn, G, m->ddy1[i], S + T_D1, m->dh1[i], S + S_DH1, m->pool[i], Fd,
                                      work, S + T_BN, B);
-    k_dn_act_b<<<grid, NT, 0, st>>>(work, m->a[i], m->z[i], S + S_BN, S + T_BN, bn, G, m->h2[i], S + S_AH2, Fa, m->dy2[i], S + T_A2, B);
+    if (G.lout % 4 == 0) k_dn_act_b<4><<<grida, NT, 0, st>>>(work, m->a[i], m->z[i], S + S_BN, S + T_BN, bn, G, m->h2[i], S + S_AH2, Fa, m->dy2[i], S + T_A2, B);
+    else k_dn_act_b<1><<<grida, NT, 0, st>>>(work, m->a[i], m->z[i], S + S_BN, S + T_BN, bn, G, m->h2[i], S + S_AH2, Fa, m->dy2[i], S + T_A2, B);
     const size_t l4 = ((size_t)Fa.dout * Fa.dh + Fa.dout) * sizeof(float);
     set_lds(k_dn_fcn_bmid, l4);
-    k_dn_fcn_bmid<<<grid, NT, l4, st>>>(m->dy2[i], S + T_A2, m->h2[i], S + S_AH2, m->h1[i], S + S_AH1, Fa, m->dy1[i], S + T_A1, 1, B);
+    k_dn_fcn_bmid<<<gridd, NT, l4, st>>>(m->dy2[i], S + T_A2, m->h2[i], S + S_AH2, m->h1[i], S + S_AH1, Fa, m->dy1[i], S + T_A1, 1, B);
     const float* in0 = i == 0 ? m->last_x : m->out[i - 1];
     const float* in1 = i >= 5 ? m->out[7 - i] : nullptr;
     float* gi0 = i == 0 ? dx : m->g[i - 1];
