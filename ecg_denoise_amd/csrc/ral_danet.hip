@@ -303,6 +303,16 @@ __global__ __launch_bounds__(NT) void k_dn_act(const float* __restrict__ z, cons
 
 // x = BN(a) of one window into LDS (scale / shift per channel precomputed)
 RAL_DEV void load_bn(const float* __restrict__ a, float* xs, const float* sc, const float* sh, int c, int lout, int tid) {
+  if ((lout & 3) == 0) {     // 16-byte accesses: a lane's four values share a channel
+    const float4* a4 = reinterpret_cast<const float4*>(a);
+    for (int i = tid; i < (c * lout) >> 2; i += NT) {
+      const int ch = (i << 2) / lout;
+      const float4 v = a4[i];
+      const float s = sc[ch], h = sh[ch];
+      reinterpret_cast<float4*>(xs)[i] = make_float4(fmaf(v.x, s, h), fmaf(v.y, s, h), fmaf(v.z, s, h), fmaf(v.w, s, h));
+    }
+    return;
+  }
   for (int o = tid; o < c * lout; o += NT) { const int ch = o / lout; xs[o] = fmaf(a[o], sc[ch], sh[ch]); }
 }
 
@@ -631,7 +641,8 @@ __global__ __launch_bounds__(NT) void k_dn_bn_b(const float* g0 /* may alias dxo
   }
   for (int win = blockIdx.x; win < B; win += gridDim.x) {
     __syncthreads();
-    for (int o = tid; o < nz; o += NT) xs[o] = a[(size_t)win * nz + o];
+    if ((G.lout & 3) == 0) { for (int i = tid; i < (nz >> 2); i += NT) reinterpret_cast<float4*>(xs)[i] = reinterpret_cast<const float4*>(a + (size_t)win * nz)[i]; }
+    else for (int o = tid; o < nz; o += NT) xs[o] = a[(size_t)win * nz + o];
     if (G.dam)
       for (int i = tid; i < 2 * C; i += NT) {
         const int p = i / C, j = i - p * C;
@@ -654,6 +665,45 @@ __global__ __launch_bounds__(NT) void k_dn_bn_b(const float* g0 /* may alias dxo
         dpool[p][k] = d;
       }
       __syncthreads();
+    }
+    // fast path: a thread per 16-byte item of the window, a channel row = q4 consecutive lanes of one wave (segmented
+    // arg-max and sums by lane exchanges); otherwise a wave per channel row
+    const int q4 = G.lout >> 2, n4w = nz >> 2;
+    const bool rowfast = (G.lout & 3) == 0 && q4 <= 64 && (q4 & (q4 - 1)) == 0 && n4w % 64 == 0;
+    if (rowfast) {
+      const float4* g04 = reinterpret_cast<const float4*>(g0 + (size_t)win * nz);
+      const float4* g14 = g1 ? reinterpret_cast<const float4*>(g1 + (size_t)win * nz) : nullptr;
+      float4* d4 = reinterpret_cast<float4*>(dxo + (size_t)win * nz);
+      for (int i0 = 0; i0 < n4w; i0 += NT) {
+        const int i = i0 + tid;                    // (n4w is a multiple of 64: whole waves are in or out)
+        if (i < n4w) {
+          const int c = i / q4, l0 = (i - c * q4) << 2;
+          float4 d = g04[i];
+          if (g14) d = f4add(d, g14[i]);
+          const float4 xv = reinterpret_cast<const float4*>(xs)[i];
+          if (G.dam) {
+            const bool up = bn.g[c] * rstd[c] >= 0.f;
+            const float x4[4] = {up ? xv.x : -xv.x, up ? xv.y : -xv.y, up ? xv.z : -xv.z, up ? xv.w : -xv.w};
+            float best = x4[0]; int bi = l0;
+#pragma unroll
+            for (int e = 1; e < 4; ++e) if (x4[e] > best) { best = x4[e]; bi = l0 + e; }
+            for (int sft = q4 >> 1; sft > 0; sft >>= 1) {
+              const float ob = __shfl_xor(best, sft); const int oi = __shfl_xor(bi, sft);
+              if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            }
+            const float dm = dpool[0][c] / G.lout, dx_ = dpool[1][c];
+            d.x += dm + (l0 == bi ? dx_ : 0.f); d.y += dm + (l0 + 1 == bi ? dx_ : 0.f);
+            d.z += dm + (l0 + 2 == bi ? dx_ : 0.f); d.w += dm + (l0 + 3 == bi ? dx_ : 0.f);
+          }
+          d4[i] = d;
+          const float mu = mean[c], rs_ = rstd[c];
+          float s1 = hsum4(d);
+          float s2 = fmaf(d.x, (xv.x - mu) * rs_, fmaf(d.y, (xv.y - mu) * rs_, fmaf(d.z, (xv.z - mu) * rs_, d.w * ((xv.w - mu) * rs_))));
+          s1 = seg_sum(s1, q4); s2 = seg_sum(s2, q4);
+          if ((tid & (q4 - 1)) == 0) { acc1[c] += s1; acc2[c] += s2; }      // (channel c's row has one leader lane per window)
+        }
+      }
+      continue;
     }
     for (int c = wave; c < C; c += NT / 64) {
       // x = sc a + sh is increasing in a when g * rstd > 0: the window maximum of x sits at the max (min) of a
@@ -1083,6 +1133,8 @@ int danet_backward(DanetModel* m, const float* dy, float* dx, int B, hipStream_t
   const int gridd = (B + 15) / 16 < gdesc ? (B + 15) / 16 : gdesc;
   static const int gact = getenv("RAL_DANET_GRID_A") ? atoi(getenv("RAL_DANET_GRID_A")) : 256;    // elementwise kernels (see danet_forward)
   const int grida = (B + 3) / 4 < gact ? (B + 3) / 4 : gact;
+  static const int gwin = getenv("RAL_DANET_GRID_W") ? atoi(getenv("RAL_DANET_GRID_W")) : 512;   // window-at-a-time kernels with column-sum flushes (train step at batch 2048: 2.33 / 2.23 / 2.26 / 2.44 ms with 1024 / 512 / 256 / 128)
+  const int gridw = B < gwin ? B : gwin;
   (void)hipMemsetAsync(P.grads, 0, (size_t)m->lay.nparam * sizeof(float), st);
   // the backward halves [T_D2, S_CELL) of the eight cells' sum records: one strided fill
   (void)hipMemset2DAsync(m->sums + T_D2, sizeof(double) * S_CELL, 0, sizeof(double) * (S_CELL - T_D2), 8, st);
@@ -1103,7 +1155,7 @@ int danet_backward(DanetModel* m, const float* dy, float* dx, int B, hipStream_t
       Fd = mk_fcn(P, K.dam);
       const size_t l1 = (2 * nz + 3 * G.lout) * sizeof(float);
       set_lds(k_dn_dam_b, l1);
-      k_dn_dam_b<<<grid, NT, l1, st>>>(g0, m->a[i], S + S_BN, bn, G, m->dh2[i], S + S_DH2, Fd, P.params + K.saw, P.params + K.sab,
+      k_dn_dam_b<<<gridw, NT, l1, st>>>(g0, m->a[i], S + S_BN, bn, G, m->dh2[i], S + S_DH2, Fd, P.params + K.saw, P.params + K.sab,
                                         P.grads + K.saw, P.grads + K.sab, work, m->ddy2[i], S + T_D2, B);
       const size_t l2 = ((size_t)Fd.dout * Fd.dh + Fd.dout) * sizeof(float);
       k_dn_fcn_bmid<<<gridd, NT, l2, st>>>(m->ddy2[i], S + T_D2, m->dh2[i], S + S_DH2, m->dh1[i], S + S_DH1, Fd, m->ddy1[i], S + T_D1, 2, B);
@@ -1111,7 +1163,7 @@ int danet_backward(DanetModel* m, const float* dy, float* dx, int B, hipStream_t
     }
     const size_t l3 = (nz + (G.dam ? (size_t)Fd.dh * Fd.din + Fd.dh : 0)) * sizeof(float);
     set_lds(k_dn_bn_b, l3);
-    k_dn_bn_b<<<grid, NT, l3, st>>>(g0, g1, m->a[i], S + S_BN, bn, G, m->ddy1[i], S + T_D1, m->dh1[i], S + S_DH1, m->pool[i], Fd,
+    k_dn_bn_b<<<gridw, NT, l3, st>>>(g0, g1, m->a[i], S + S_BN, bn, G, m->ddy1[i], S + T_D1, m->dh1[i], S + S_DH1, m->pool[i], Fd,
                                      work, S + T_BN, B);
     if (G.lout % 4 == 0) k_dn_act_b<4><<<grida, NT, 0, st>>>(work, m->a[i], m->z[i], S + S_BN, S + T_BN, bn, G, m->h2[i], S + S_AH2, Fa, m->dy2[i], S + T_A2, B);
     else k_dn_act_b<1><<<grida, NT, 0, st>>>(work, m->a[i], m->z[i], S + S_BN, S + T_BN, bn, G, m->h2[i], S + S_AH2, Fa, m->dy2[i], S + T_A2, B);
