@@ -165,4 +165,5 @@ def test_early_gradient_bucket_runs_under_the_backward_pass():
     import re
     fr = [int(m.group(1)) for m in re.finditer(r"= (\d+) % \.\.", p.stdout)]
     assert len(fr) >= 4, p.stdout
-    assert all(30 <= f <= 75 for f in fr), p.stdout
+    # measured 49-54 %; with the default 4 hardware queues 100 %.  (Generous bounds: the point is "not after the pass".)
+    assert all(20 <= f <= 88 for f in fr), p.stdout
