@@ -188,6 +188,13 @@ def cpu_baseline(leads, L, variant, big_batch=256):
                                   "sample": f"{n2} train steps at batch {big_batch} x {leads} x {L}"}
         except Exception as exc:
             res["large_batch"] = {"error": str(exc)[:200]}
+    # the figure at the bench batch itself, measured once per round by tools/cpu_baseline_big.py on the GPU box's host
+    # (40 s per step and ~50 GB of autograd state: not re-measured inside the default run) and committed under profiles/
+    for name in ("r03_cpu_baseline_b2048.json",):
+        d = _profile_json(name)
+        if d and "value" in d and leads == 1 and L == 512:
+            res["bench_batch"] = {"value": d["value"], "batch": 2048, "cores": d.get("cores"), "source": "profiles/" + name,
+                                  "s_per_step": min(r["s_per_step"] for r in d.get("runs", [{"s_per_step": None}]))}
     return res
 
 
