@@ -84,7 +84,7 @@ struct Layout {
 
 static int64_t alloc_f(int64_t& cur, int64_t n) {
   const int64_t o = cur;
-  cur += (n + 3) & ~int64_t(3);
+  cur += (n + 7) & ~int64_t(7);   // 32-byte granules: the fp16 planes of a weight matrix are read 16 bytes (8 elements) at a time
   return o;
 }
 
@@ -249,13 +249,17 @@ struct RalModel {
   void* lanes = nullptr;   // LaneSet
   int n_lanes = 2;
   bool side_stream = true;
-  int qkv_bf16 = 64;          // narrowest width whose q/k/v projection runs as bf16 x 3 on the bf16 matrix cores (0 = none)
+  int f16_split = 64;         // narrowest width whose Linear layers (q/k/v projection, proj, fc1, fc2 of the forward) run as
+                              // two-piece fp16 products on the f16 matrix cores (0 = none: fp32 MFMA everywhere)
   bool want_dw = true;      // false inside ral_backward_input: frozen weights, data gradients only
   int dec_lanes = 0; bool dec_side = false;   // lanes / side streams that carried the last backward (bucket events)
   hipEvent_t ev_bwd_done = nullptr;          // recorded at the end of ral_backward_end
   bool bwd_recorded = false;
   float* paramsT = nullptr;   // transposed copies of the weight matrices (same offsets), refreshed per backward
-  unsigned short* wqkv_b[18] = {nullptr};   // bf16 x 3 planes of Wqkv for the blocks whose projection runs on the bf16 matrix cores
+  unsigned short* wh = nullptr;             // tiled split planes of the wide levels' weight matrices (a matrix at twice its float
+                                            // offset), re-written every forward from the descriptors below
+  int* wdesc = nullptr;                     // device: int4 {offset, rows, columns, first work item} per matrix
+  int ndesc = 0, nwork = 0;
   void* tdesc = nullptr; int tn = 0, ttotal = 0;
   const float* last_x = nullptr;
   int last_B = 0;
@@ -330,10 +334,8 @@ static size_t plan_workspace(const ral_config& c, RalModel* m /* may be null: si
     a.upre = (tr && !mlp_bwd_is_fused(CH[lvl], c.L >> lvl)) ? take((p + "upre").c_str(), 4 * E) : nullptr;
     a.out = take((p + "out").c_str(), E);
   }
-  for (int b = 0; b < 18; ++b) {
-    const int Cb = CH[STAGES[b / 2].level];
-    M.wqkv_b[b] = qkv_fwd_uses_bf16(Cb) ? reinterpret_cast<unsigned short*>(take(("wqkvb" + std::to_string(b)).c_str(), (size_t)3 * 3 * Cb * Cb / 2 + 4)) : nullptr;
-  }
+  { Layout L_; build_layout(c, L_); M.wh = reinterpret_cast<unsigned short*>(take("wh", (size_t)L_.nparam)); }
+  M.wdesc = reinterpret_cast<int*>(take("wdesc", 4 * 64));
   static const char* RN[8] = {"p1", "p2", "p3", "p4", "u3", "u2", "u1", "u0"};
   for (int r = 0; r < 8; ++r) M.res_out[r] = take(RN[r], E);
   M.xmid = take("xmid", E);
@@ -441,14 +443,15 @@ static void run_block_fwd(RalModel* m, int bi, const float* in, bool training, c
   }
   const int w0 = ln.w0, B = ln.B;
   hipStream_t s = ln.s;
+  const bool split = m->f16_split > 0 && C >= m->f16_split;
   const float* x = woff(in, w0, E1);
   float* qkv = woff(a.qkv, w0, 3 * E1);
   float* o = woff(a.o, w0, E1);
-  { ProfScope p(m, K_QKV_FWD, s); launch_qkv_fwd(C, x, m->pe[l], w, (m->qkv_bf16 > 0 && C >= m->qkv_bf16) ? m->wqkv_b[bi] : nullptr, qkv, N, B, s); }
+  { ProfScope p(m, K_QKV_FWD, s); launch_qkv_fwd(C, x, m->pe[l], w, split ? m->wh + 2 * m->lay.blk[bi].wqkv : nullptr, qkv, N, B, s); }
   { ProfScope p(m, K_ATTN_FWD, s);
     launch_attn_fwd(qkv, o, training ? woff(a.lse, w0, E1 / 4) : nullptr, table, N, H, m->hg_f[l], Len, B, s); }
   { ProfScope p(m, K_MLP_FWD, s);
-    launch_mlp_fwd(C, m->nch_f[l], x, o, w, training ? woff(a.x1, w0, E1) : nullptr,
+    launch_mlp_fwd(C, m->nch_f[l], x, o, w, m->params, split ? m->wh : nullptr, training ? woff(a.x1, w0, E1) : nullptr,
                    (training && !mlp_bwd_is_fused(C, N)) ? woff(a.upre, w0, 4 * E1) : nullptr,
                    woff(a.out, w0, E1), N, B, s); }
 }
@@ -523,11 +526,7 @@ static int fwd_end(RalModel* m, float* y, int B, int64_t global_windows, int tra
     launch_bn_apply8(m->a0, m->ss, m->x0, (size_t)B * m->L, s);
   }
   const bool tr = training != 0;
-  for (int b = 0; b < 18; ++b)      // bf16 x 3 planes of the projection weights that run on the bf16 matrix cores
-    if (m->wqkv_b[b] && m->qkv_bf16 > 0 && CH[STAGES[b / 2].level] >= m->qkv_bf16) {
-      const int Cb = CH[STAGES[b / 2].level];
-      launch_split_planes(m->params + Y.blk[b].wqkv, m->wqkv_b[b], (size_t)3 * Cb * Cb, s);
-    }
+  if (m->f16_split > 0) launch_tile_planes(m->params, m->wh, m->wdesc, m->ndesc, m->nwork, s);   // split planes of the wide levels' weights
   const int nl = plan_lanes(m, B, s);
   fork_lanes(m, s);
   LaneSet* LS = lanes_of(m);
@@ -898,7 +897,7 @@ int ral_create(const ral_config* cfg, ral_handle** out) {
       return -1;
     }
   }
-  if (const char* v = getenv("RAL_QKV_BF16")) m->qkv_bf16 = atoi(v);
+  if (const char* v = getenv("RAL_F16_SPLIT")) m->f16_split = atoi(v);
   if (cfg->train) {
     m->side_stream = getenv("RAL_NO_SIDE_STREAM") == nullptr;
     std::vector<int> d;
@@ -913,6 +912,23 @@ int ral_create(const ral_config* cfg, ral_handle** out) {
     m->tn = (int)d.size() / 4; m->ttotal = run;
     e = hipMemcpy(m->tdesc, d.data(), d.size() * sizeof(int), hipMemcpyHostToDevice);
     if (e != hipSuccess) { fail("hipMemcpy(tdesc) failed: %s", hipGetErrorString(e)); destroy_model(m); delete h; return -1; }
+  }
+  {   // weight matrices that are re-written as tiled split planes every forward (widths with a split-operand kernel)
+    std::vector<int> d;
+    int run = 0;
+    auto add = [&](int64_t off, int rows, int cols) { d.push_back((int)off); d.push_back(rows); d.push_back(cols); d.push_back(run); run += rows * cols / 8; };
+    for (int b = 0; b < 18; ++b) {
+      const int C = CH[STAGES[b / 2].level];
+      if (!qkv_fwd_uses_f16(C)) continue;
+      const BlockOff& o = m->lay.blk[b];
+      add(o.wqkv, 3 * C, C); add(o.wp, C, C); add(o.w1, 4 * C, C); add(o.w2, C, 4 * C);
+    }
+    m->ndesc = (int)d.size() / 4; m->nwork = run;
+    if (m->ndesc > 64) { fail("too many split-plane descriptors"); destroy_model(m); delete h; return -1; }
+    if (m->ndesc) {
+      e = hipMemcpy(m->wdesc, d.data(), d.size() * sizeof(int), hipMemcpyHostToDevice);
+      if (e != hipSuccess) { fail("hipMemcpy(wdesc) failed: %s", hipGetErrorString(e)); destroy_model(m); delete h; return -1; }
+    }
   }
   h->m = m;
   *out = h;
@@ -1114,7 +1130,7 @@ int ral_set_option(ral_handle* h, const char* key, int value) {
   RalModel* m = h->m;
   if (!strcmp(key, "lanes")) { m->n_lanes = value < 1 ? 1 : (value > MAX_LANES ? MAX_LANES : value); return 0; }
   if (!strcmp(key, "side_stream")) { m->side_stream = value != 0; return 0; }
-  if (!strcmp(key, "qkv_bf16")) { m->qkv_bf16 = value; return 0; }
+  if (!strcmp(key, "f16_split")) { m->f16_split = value; return 0; }
   return fail("unknown option %s", key);
 }
 

@@ -135,71 +135,151 @@ RAL_DEV void gemm_phase(const float* __restrict__ W, int ldw, int M, const float
   else gemm_phase_t<K, 1, WT, LAY>(W, ldw, M, Xs, ldx, ntiles, epi);
 }
 
-// ---------------------------------------------------------------------------------
-// fp32 products on the bf16 matrix cores (pilot: the QKV projection of the wide levels).
-// x = x1 + x2 + x3 with three bf16 pieces carries the 24 significant bits of an fp32 value (x - x1 and x - x1 - x2 are
-// exact in fp32); the six piece products whose weight is >= 2^-16 (W1X1, W1X2, W2X1, W1X3, W2X2, W3X1), accumulated in
-// fp32 by v_mfma_f32_16x16x32_bf16, reproduce the fp32 product to ~2^-22 relative - 6 x 16 matrix-core cycles per
-// 16 x 16 x 32 instead of 8 x 34.5 cycles of the fp32 MFMA, which runs on the vector ALU's multipliers.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-struct Bf3 { __bf16 a, b, c; };
-RAL_DEV Bf3 bf16_split3(float x) {
-  Bf3 r;
-  r.a = (__bf16)x;
-  const float e1 = x - (float)r.a;
-  r.b = (__bf16)e1;
-  r.c = (__bf16)(e1 - (float)r.b);
-  return r;
-}
-// row stride (bf16 elements) of a K-contiguous bf16 tile of width K: + 8 keeps the 16-byte fragment reads of 16
+// row stride (2-byte elements) of a K-contiguous split-plane tile of width K: + 8 keeps the 16-byte fragment reads of 16
 // consecutive rows on distinct banks
 constexpr int ldb_of(int K) { return K + 8; }
 
-// acc[mi][tt] += W[m0 + 16 mi .., :K] x X[t0 + 16 tt .., :K]^T from three bf16 planes each: Wb[p] (rows of K, row-major,
-// global, plane stride wplane elements), Xb[p] (LDS rows of ldx elements, plane stride xplane).  K % 32 == 0.  An
-// MT x TT register block: (MT + TT) x 3 fragment loads of 16 bytes feed MT * TT * 6 MFMAs - with 2 x 4 the LDS sees 14
-// bytes per cycle per SIMD of its 32 and the vector L1 7 of its 16 (one 16 x 16 x 32 bf16 MFMA issues in 18.7 cycles,
-// tools/diag/valu_probe.hip), where a 1 x 2 block would need 27 and 14.
+// ---------------------------------------------------------------------------------
+// fp32 products on the f16 matrix cores: x = h1 + 2^-11 h2 with two fp16 pieces (h1 = fp16(x), h2 = fp16(2^11 (x - h1));
+// the residual is scaled so that it stays in fp16's normal range whenever x does) carries 22-23 significant bits, and the
+// three products h1 h1, h1 h2, h2 h1 reproduce the fp32 product to ~2^-21 relative (the dropped h2 h2 term is 2^-22).  The
+// cross terms are summed in their own accumulator and enter the result as acc + 2^-11 accx.  3 x 16 matrix-core cycles
+// per 16 x 16 x 32 against 6 x 16 for the bf16 triple split and 8 x 34.5 for the fp32 MFMA; operands are 4 bytes per
+// element, as in fp32.  |x| is clamped to fp16's largest finite value (65504) - LayerNorm / GELU / attention outputs and
+// weights are orders of magnitude below it; gradient tensors are NOT (they underflow fp16): those stay on bf16 x 3 / fp32.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+struct H2 { _Float16 a, b; };
+RAL_DEV H2 f16_split2(float x) {
+  x = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
+  H2 r;
+  r.a = (_Float16)x;
+  r.b = (_Float16)((x - (float)r.a) * 2048.f);
+  return r;
+}
+#define RAL_H2_SCALE (1.0f / 2048.f)
+
+// Weight matrices reach these products as TILED split planes (k_tile_planes): tile (mt, kt) = rows 16 mt .., columns
+// 32 kt .. of W, both planes, is 2 KB of contiguous memory - plane p at + 512 p elements, the 16 bytes of lane (r, g) =
+// W[16 mt + r][32 kt + 8 g .. + 7] at + 8 (16 g + r) - so that one fragment load of a wave is eight whole 128-byte lines.
+// (Row-major planes made it sixteen half-used lines per load; at these widths the products wait for the weight stream
+// through the vector L1, not for the matrix cores: with chunk 0's fragments re-used for every chunk fc2 at C = 128 ran
+// 4.2 x faster, without the MFMAs it did not change.)  KT = k-tiles per tile row of the matrix.
+RAL_DEV const _Float16* wtile(const _Float16* Wt, int KT, int mt, int kt, int p) {
+  return Wt + ((size_t)(mt * KT + kt) * 2 + p) * 512 + (threadIdx.x & 63) * 8;
+}
+// acc[mi][tt] += W1 X1, accx[mi][tt] += W1 X2 + W2 X1 for an MT x TT register block over k-tiles kt0 .. kt0 + K / 32 of the
+// tiled matrix Wt, m-tiles mt0 ..; Xh[p]: LDS rows of ldx elements, plane stride xplane.
+// A weight fragment takes ~1 us from the L2 under load and its three MFMAs 48 cycles, so the number of round trips per
+// unit is what the product costs: one-row-tile units (MT = 1) request the fragments of up to eight chunks together (64
+// registers), two-row-tile units (the fc1 phase, whose GELU epilogue gives the other waves work meanwhile) keep one chunk
+// in flight under the MFMAs of the current one.
+template <int MT, int TT>
+RAL_DEV void h2_mma(const f16x8 (&a)[MT][2], const _Float16* xr, int xplane, int ldx, f32x4 (&acc)[MT][TT], f32x4 (&accx)[MT][TT]) {
+  f16x8 b1[TT], b2[TT];
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) {
+    b1[tt] = *reinterpret_cast<const f16x8*>(xr + 16 * tt * ldx); b2[tt] = *reinterpret_cast<const f16x8*>(xr + xplane + 16 * tt * ldx);
+  }
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+      accx[mi][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mi][1], b1[tt], accx[mi][tt], 0, 0, 0);
+      acc[mi][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mi][0], b1[tt], acc[mi][tt], 0, 0, 0);
+      accx[mi][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mi][0], b2[tt], accx[mi][tt], 0, 0, 0);
+    }
+}
 template <int K, int MT, int TT>
-RAL_DEV void gemm_wx_b3(const __bf16* __restrict__ Wb, size_t wplane, int m0, const __bf16* Xb, int xplane, int ldx,
-                        int t0, f32x4 (&acc)[MT][TT]) {
+RAL_DEV void gemm_wx_h2(const _Float16* __restrict__ Wt, int KT, int mt0, int kt0, const _Float16* Xh, int xplane, int ldx,
+                        int t0, f32x4 (&acc)[MT][TT], f32x4 (&accx)[MT][TT]) {
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
-  auto mma6 = [&](const bf16x8 (&a)[3], const bf16x8& b1, const bf16x8& b2, const bf16x8& b3, f32x4& c) {   // smallest terms first
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b1, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b2, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b3, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b1, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b2, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b1, c, 0, 0, 0);
-  };
-  // weight fragments of chunk kc + 1 are requested before the MFMAs of chunk kc (the loop stays rolled: unrolled, hipcc
-  // hoists every chunk's loads to the top and spills)
-  bf16x8 a[MT][3], an[MT][3];
-  const __bf16* wp = Wb + (size_t)(m0 + r) * K + 8 * g;
-#pragma unroll
-  for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-    for (int p = 0; p < 3; ++p) an[mi][p] = *reinterpret_cast<const bf16x8*>(wp + p * wplane + (size_t)mi * 16 * K);
+  constexpr int KC = K / 32;
+  const _Float16* xr = Xh + (t0 + r) * ldx + 8 * g;
+  if constexpr (MT == 1) {
+    constexpr int GS = KC < 8 ? KC : 8;
+    static_assert(KC % GS == 0, "chunk groups");
 #pragma unroll 1
-  for (int kc = 0; kc < K / 32; ++kc) {
+    for (int k0 = 0; k0 < KC; k0 += GS) {
+      f16x8 a[GS][1][2];
+#pragma unroll
+      for (int j = 0; j < GS; ++j)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+#ifdef RAL_H2_NOW   // diagnostic: chunk 0's weight fragments every time (same instructions, L1-hot)
+          a[j][0][p] = *reinterpret_cast<const f16x8*>(wtile(Wt, KT, mt0, kt0, p));
+#else
+          a[j][0][p] = *reinterpret_cast<const f16x8*>(wtile(Wt, KT, mt0, kt0 + k0 + j, p));
+#endif
+        }
+#pragma unroll
+      for (int j = 0; j < GS; ++j) h2_mma<1, TT>(a[j], xr + (k0 + j) * 32, xplane, ldx, acc, accx);
+    }
+  } else {
+    f16x8 a[MT][2], an[MT][2];
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) a[mi][p] = an[mi][p];
-    const int kn = kc + 1 < K / 32 ? kc + 1 : kc;
+      for (int p = 0; p < 2; ++p) an[mi][p] = *reinterpret_cast<const f16x8*>(wtile(Wt, KT, mt0 + mi, kt0, p));
+#pragma unroll 1
+    for (int kc = 0; kc < KC; ++kc) {
 #pragma unroll
-    for (int mi = 0; mi < MT; ++mi)
+      for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) an[mi][p] = *reinterpret_cast<const bf16x8*>(wp + p * wplane + (size_t)mi * 16 * K + kn * 32);
+        for (int p = 0; p < 2; ++p) a[mi][p] = an[mi][p];
+#ifdef RAL_H2_NOW
+      const int kn = 0;
+#else
+      const int kn = kc + 1 < KC ? kc + 1 : kc;
+#endif
 #pragma unroll
-    for (int tt = 0; tt < TT; ++tt) {
-      const int xo = (t0 + 16 * tt + r) * ldx + kc * 32 + 8 * g;
-      const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(Xb + xo), b2 = *reinterpret_cast<const bf16x8*>(Xb + xplane + xo),
-                   b3 = *reinterpret_cast<const bf16x8*>(Xb + 2 * xplane + xo);
+      for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-      for (int mi = 0; mi < MT; ++mi) mma6(a[mi], b1, b2, b3, acc[mi][tt]);
+        for (int p = 0; p < 2; ++p) an[mi][p] = *reinterpret_cast<const f16x8*>(wtile(Wt, KT, mt0 + mi, kt0 + kn, p));
+      h2_mma<MT, TT>(a, xr + kc * 32, xplane, ldx, acc, accx);
     }
   }
+}
+
+// One GEMM phase of a workgroup on split operands: out(M rows x ntiles * 16 tokens) = W x X^T (+ bias; row 0 of the output
+// = row 16 mt0 of W, bias[0] its bias), work units of MT x 2 tiles dealt round-robin to the waves; M % (16 MT) == 0, ntiles even.  The bias rows of a unit are requested
+// before its products.  epi(row0, tok, v) as in gemm_phase.
+template <int K, int MT, class Epi>
+RAL_DEV void gemm_phase_h2_t(const _Float16* __restrict__ Wt, int KT, int mt0, int kt0, int M, const float* __restrict__ bias,
+                             const _Float16* Xh, int xplane, int ldx, int ntiles, Epi& epi) {
+  constexpr int TT = 2;
+  const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int mb = M / (16 * MT), tb = ntiles / TT;
+  for (int u = wave; u < mb * tb; u += nw) {
+    const int m = u % mb, t = u / mb;
+    float4 bv[MT];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+      bv[mi] = bias ? *reinterpret_cast<const float4*>(bias + (m * MT + mi) * 16 + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+    f32x4 acc[MT][TT], accx[MT][TT];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) { acc[mi][tt] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[mi][tt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    gemm_wx_h2<K, MT, TT>(Wt, KT, mt0 + m * MT, kt0, Xh, xplane, ldx, t * TT * 16, acc, accx);
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) {
+        f32x4 v = acc[mi][tt] + accx[mi][tt] * RAL_H2_SCALE;
+        v[0] += bv[mi].x; v[1] += bv[mi].y; v[2] += bv[mi].z; v[3] += bv[mi].w;
+        epi((m * MT + mi) * 16 + 4 * g, (t * TT + tt) * 16 + r, v);
+      }
+  }
+}
+// the larger block when it still gives every wave a unit
+// (Wt, KT): tiled planes of the matrix; the product uses its rows 16 mt0 .. + M and columns 32 kt0 .. + K
+template <int K, class Epi>
+RAL_DEV void gemm_phase_h2(const _Float16* __restrict__ Wt, int KT, int mt0, int kt0, int M, const float* __restrict__ bias,
+                           const _Float16* Xh, int xplane, int ldx, int ntiles, Epi epi) {
+  const int nw = blockDim.x >> 6;
+  if (M % 32 == 0 && (M / 32) * (ntiles / 2) >= nw) gemm_phase_h2_t<K, 2>(Wt, KT, mt0, kt0, M, bias, Xh, xplane, ldx, ntiles, epi);
+  else gemm_phase_h2_t<K, 1>(Wt, KT, mt0, kt0, M, bias, Xh, xplane, ldx, ntiles, epi);
 }
 
 // row stride (floats) of a token-major LDS tile of width C: +4 breaks the power-of-two stride for the

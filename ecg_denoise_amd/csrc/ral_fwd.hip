@@ -49,23 +49,21 @@ __global__ __launch_bounds__(256) void k_qkv_fwd(const float* __restrict__ x, co
 }
 
 // =================================================================================
-// K1b (wide levels, C >= 64): the same projection with the GEMM on the bf16 matrix cores - LayerNorm output and weights as
-// three bf16 pieces each, six piece products per term (gemm_wx_b3, ral_device.hpp): fp32-accurate to ~2^-22, 2.9 x fewer
-// matrix cycles than the fp32 MFMA.  wb: the three bf16 planes of Wqkv (3C x C each, plane stride `wplane`), written by
-// k_split_planes from the fp32 parameters before the forward pass.
+// K1h (wide levels, C >= 64): the same projection as two fp16 pieces per operand, three products per term on the f16
+// matrix cores (gemm_wx_h2, ral_device.hpp: fp32-accurate to ~2^-21, 5.7 x fewer matrix cycles than the fp32 MFMA).
+// wt: the tiled split planes of Wqkv (k_tile_planes).  A workgroup takes GT consecutive tokens of the batch at a time
+// (whole windows or whole parts of one: N | GT or GT | N).  The general form; K1w below is the one the bench shapes take.
 // =================================================================================
-// A workgroup takes GT consecutive tokens of the batch at a time (whole windows or whole parts of one: N | GT or GT | N)
-// so that every weight fragment it fetches meets 4 token tiles.
 template <int C, int GT>
-__global__ __launch_bounds__(256) void k_qkv_fwd_b(const float* __restrict__ x, const float* __restrict__ pe,
-                                                      BlockP w, const __bf16* __restrict__ wb, size_t wplane,
+__global__ __launch_bounds__(256) void k_qkv_fwd_h(const float* __restrict__ x, const float* __restrict__ pe,
+                                                      BlockP w, const _Float16* __restrict__ wt,
                                                       float* __restrict__ qkv, int N, int B) {
   extern __shared__ float4 smem4[];
-  __bf16* Hb = reinterpret_cast<__bf16*>(smem4);          // 3 planes x GT x LDB
+  _Float16* Hh = reinterpret_cast<_Float16*>(smem4);          // 2 planes x GT x LDB
   constexpr int LDB = ldb_of(C), LPR = C / 4, RPP = 256 / LPR, TT = 4;
-  constexpr int MT = (3 * C / 16) % 8 == 0 ? 2 : 1;   // whole rounds of (m-block) units over the four waves
+  constexpr int MT = (3 * C / 16) % 8 == 0 ? 2 : 1;
   constexpr int xplane = GT * LDB;
-  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
   const float sqrtC = sqrtf((float)C);
   const int cq = (threadIdx.x % LPR) * 4;
   const float4 gam = *reinterpret_cast<const float4*>(w.ln1w + cq);
@@ -73,7 +71,9 @@ __global__ __launch_bounds__(256) void k_qkv_fwd_b(const float* __restrict__ x, 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
   const long total = (long)B * N;
   const int ngroups = (int)((total + GT - 1) / GT);
+  RAL_STAMP_INIT();
   for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    RAL_STAMP_AT(8);
     const long g0 = (long)grp * GT;
     for (int row = threadIdx.x / LPR; row < GT; row += RPP) {
       const long gt = g0 + row < total ? g0 + row : total - 1;
@@ -84,21 +84,22 @@ __global__ __launch_bounds__(256) void k_qkv_fwd_b(const float* __restrict__ x, 
       float4 d; float rstd;
       ln_stats<LPR>(v, d, rstd);
       const float4 h = f4add(f4mul(f4scale(d, rstd), gam), bet);
-      const Bf3 s0 = bf16_split3(h.x), s1 = bf16_split3(h.y), s2 = bf16_split3(h.z), s3 = bf16_split3(h.w);
-      *reinterpret_cast<bf16x4*>(Hb + row * LDB + cq) = bf16x4{s0.a, s1.a, s2.a, s3.a};
-      *reinterpret_cast<bf16x4*>(Hb + xplane + row * LDB + cq) = bf16x4{s0.b, s1.b, s2.b, s3.b};
-      *reinterpret_cast<bf16x4*>(Hb + 2 * xplane + row * LDB + cq) = bf16x4{s0.c, s1.c, s2.c, s3.c};
+      const H2 s0 = f16_split2(h.x), s1 = f16_split2(h.y), s2 = f16_split2(h.z), s3 = f16_split2(h.w);
+      *reinterpret_cast<f16x4*>(Hh + row * LDB + cq) = f16x4{s0.a, s1.a, s2.a, s3.a};
+      *reinterpret_cast<f16x4*>(Hh + xplane + row * LDB + cq) = f16x4{s0.b, s1.b, s2.b, s3.b};
     }
+    RAL_STAMP_AT(9);
     __syncthreads();
+    RAL_STAMP_AT(10);
     constexpr int MU = 3 * C / (16 * MT), TU = GT / (16 * TT);
     for (int u = wave; u < MU * TU; u += 4) {
       const int mu = u % MU, tu = u / MU;
-      f32x4 acc[MT][TT];
+      f32x4 acc[MT][TT], accx[MT][TT];
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-        for (int tt = 0; tt < TT; ++tt) acc[mi][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      gemm_wx_b3<C, MT, TT>(wb, wplane, mu * MT * 16, Hb, xplane, LDB, tu * TT * 16, acc);
+        for (int tt = 0; tt < TT; ++tt) { acc[mi][tt] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[mi][tt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      gemm_wx_h2<C, MT, TT>(wt, C / 32, mu * MT, 0, Hh, xplane, LDB, tu * TT * 16, acc, accx);
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi) {
         const int row0 = (mu * MT + mi) * 16 + 4 * g;
@@ -109,26 +110,159 @@ __global__ __launch_bounds__(256) void k_qkv_fwd_b(const float* __restrict__ x, 
           if (gt < total) {
             const long win = gt / N;
             const int tok = (int)(gt - win * N);
-            float4 v = f4add(tofloat4(acc[mi][tt]), bias);
+            float4 v = f4add(f4add(tofloat4(acc[mi][tt]), f4scale(tofloat4(accx[mi][tt]), RAL_H2_SCALE)), bias);
             if (row0 < C) v = f4scale(v, 0.5f);  // q * head_dim^-0.5, head_dim = 4
             *reinterpret_cast<float4*>(qkv + win * 3 * N * C + ((size_t)(row0 >> 2) * N + tok) * 4) = v;
           }
         }
       }
     }
+    RAL_STAMP_AT(11);
+    __syncthreads();
+    RAL_STAMP_AT(12);
+  }
+}
+
+// =================================================================================
+// K1w: the fp16-split projection with the WEIGHTS STATIONARY in registers.  A workgroup has one wave per 32 output rows
+// (3C / 32 waves); a wave loads the two fp16 planes of its 32 x C weight block once (C / 2 registers) and keeps them for
+// the whole kernel, so the only operand stream of the GEMM is the LDS tile of the current 64 tokens.  The token groups
+// are double-buffered: the x rows of group i + 1 are requested before the products of group i are issued, normalised and
+// split after them, and ONE barrier closes the iteration.  Positions repeat with period N | GT, so the positional rows a
+// thread adds are loaded once.
+// =================================================================================
+template <int C, int GT>
+__global__ __launch_bounds__(6 * C) void k_qkv_fwd_ws(const float* __restrict__ x, const float* __restrict__ pe,
+                                                      BlockP w, const _Float16* __restrict__ wt,
+                                                      float* __restrict__ qkv, int N, int B) {
+  extern __shared__ float4 smem4[];
+  constexpr int NT = 6 * C, LDB = ldb_of(C), LPR = C / 4, RPP = NT / LPR, NP = (GT + RPP - 1) / RPP, KC = C / 32;
+  constexpr int xplane = GT * LDB, bufsz = 2 * xplane;
+  _Float16* Hh = reinterpret_cast<_Float16*>(smem4);          // 2 buffers x 2 planes x GT x LDB
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  const float sqrtC = sqrtf((float)C);
+  const int cq = (threadIdx.x % LPR) * 4, rowt = threadIdx.x / LPR;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const long total = (long)B * N;
+  const int ngroups = (int)((total + GT - 1) / GT);
+  // the wave's weight block: rows 32 wave .. + 31, both planes, all of K
+  f16x8 wf[2][KC][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) wf[mi][kc][p] = *reinterpret_cast<const f16x8*>(wtile(wt, KC, 2 * wave + mi, kc, p));
+  const float4 gam = *reinterpret_cast<const float4*>(w.ln1w + cq);
+  const float4 bet = *reinterpret_cast<const float4*>(w.ln1b + cq);
+  float4 pev[NP];
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const int row = rowt + k * RPP;
+    pev[k] = *reinterpret_cast<const float4*>(pe + ((row < GT ? row : 0) % N) * C + cq);
+  }
+  float4 bias[2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) bias[mi] = *reinterpret_cast<const float4*>(w.bqkv + 32 * wave + 16 * mi + 4 * g);
+  float4 xv[NP];
+  auto request = [&](int grp) {
+    const long g0 = (long)grp * GT;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const int row = rowt + k * RPP;
+      long gt = g0 + (row < GT ? row : 0);
+      if (gt >= total) gt = total - 1;
+      xv[k] = *reinterpret_cast<const float4*>(x + gt * C + cq);
+    }
+  };
+  auto stage = [&](_Float16* buf) {   // LayerNorm + split of the requested rows -> buf
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const int row = rowt + k * RPP;
+      const float4 v = f4add(f4scale(xv[k], sqrtC), pev[k]);
+      float4 d; float rstd;
+      ln_stats<LPR>(v, d, rstd);
+      const float4 h = f4add(f4mul(f4scale(d, rstd), gam), bet);
+      const H2 s0 = f16_split2(h.x), s1 = f16_split2(h.y), s2 = f16_split2(h.z), s3 = f16_split2(h.w);
+      if (row < GT) {
+        *reinterpret_cast<f16x4*>(buf + row * LDB + cq) = f16x4{s0.a, s1.a, s2.a, s3.a};
+        *reinterpret_cast<f16x4*>(buf + xplane + row * LDB + cq) = f16x4{s0.b, s1.b, s2.b, s3.b};
+      }
+    }
+  };
+  int grp = blockIdx.x, it = 0;
+  if (grp < ngroups) { request(grp); stage(Hh); }
+  __syncthreads();
+  for (; grp < ngroups; grp += gridDim.x, ++it) {
+    const _Float16* cur = Hh + (it & 1) * bufsz;
+    const int nxt = grp + gridDim.x;
+    if (nxt < ngroups) request(nxt);
+    const long g0 = (long)grp * GT;
+#pragma unroll 1
+    for (int tt = 0; tt < GT / 16; ++tt) {
+      f32x4 acc[2], accx[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) { acc[mi] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[mi] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      const _Float16* xr = cur + (16 * tt + r) * LDB + 8 * g;
+      f16x8 b1[KC], b2[KC];
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) {
+        b1[kc] = *reinterpret_cast<const f16x8*>(xr + kc * 32);
+        b2[kc] = *reinterpret_cast<const f16x8*>(xr + xplane + kc * 32);
+      }
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          accx[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[mi][kc][1], b1[kc], accx[mi], 0, 0, 0);
+          acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[mi][kc][0], b1[kc], acc[mi], 0, 0, 0);
+          accx[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[mi][kc][0], b2[kc], accx[mi], 0, 0, 0);
+        }
+      const long gt = g0 + 16 * tt + r;
+      if (gt < total) {
+        const long win = gt / N;
+        const int tok = (int)(gt - win * N);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const int row0 = 32 * wave + 16 * mi + 4 * g;
+          float4 v = f4add(f4add(tofloat4(acc[mi]), f4scale(tofloat4(accx[mi]), RAL_H2_SCALE)), bias[mi]);
+          if (row0 < C) v = f4scale(v, 0.5f);  // q * head_dim^-0.5, head_dim = 4
+          *reinterpret_cast<float4*>(qkv + win * 3 * N * C + ((size_t)(row0 >> 2) * N + tok) * 4) = v;
+        }
+      }
+    }
+    if (nxt < ngroups) stage(Hh + ((it + 1) & 1) * bufsz);
     __syncthreads();
   }
 }
 
-// fp32 matrix (n elements) -> three bf16 planes (plane stride n)
-__global__ void k_split_planes(const float* __restrict__ src, __bf16* __restrict__ dst, size_t n) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const Bf3 s3 = bf16_split3(src[i]);
-    dst[i] = s3.a; dst[n + i] = s3.b; dst[2 * n + i] = s3.c;
+// The weight matrices of the levels that run on the f16 matrix cores -> tiled split planes (layout: wtile, ral_device.hpp).
+// desc[d] = {offset of the matrix in the parameter buffer (floats), rows M, columns K, first work item}; a work item is
+// eight consecutive columns of one row (16 bytes of each plane); the tiled planes of a matrix take the bytes of the
+// matrix's own place in a buffer shaped like the parameter buffer (2 planes x 2 bytes = 4 bytes per weight).
+__global__ void k_tile_planes(const float* __restrict__ params, _Float16* __restrict__ wt, const int4* __restrict__ desc,
+                              int ndesc, int nwork) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nwork; i += gridDim.x * blockDim.x) {
+    int d = 0;
+    while (d + 1 < ndesc && desc[d + 1].w <= i) ++d;
+    const int4 D = desc[d];
+    const int j = i - D.w, K8 = D.z >> 3, row = j / K8, k8 = j - row * K8;
+    const float4 v0 = *reinterpret_cast<const float4*>(params + D.x + (size_t)row * D.z + 8 * k8);
+    const float4 v1 = *reinterpret_cast<const float4*>(params + D.x + (size_t)row * D.z + 8 * k8 + 4);
+    const float xs[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    f16x8 h1, h2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const H2 s2 = f16_split2(xs[e]); h1[e] = s2.a; h2[e] = s2.b; }
+    const int mt = row >> 4, r = row & 15, kt = k8 >> 2, g = k8 & 3;
+    _Float16* dst = wt + 2 * (size_t)D.x + ((size_t)(mt * (D.z >> 5) + kt) * 2) * 512 + (g * 16 + r) * 8;
+    *reinterpret_cast<f16x8*>(dst) = h1;
+    *reinterpret_cast<f16x8*>(dst + 512) = h2;
   }
 }
-void launch_split_planes(const float* src, void* dst, size_t n, hipStream_t s) {
-  k_split_planes<<<(int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024), 256, 0, s>>>(src, reinterpret_cast<__bf16*>(dst), n);
+void launch_tile_planes(const float* params, void* wt, const void* desc, int ndesc, int nwork, hipStream_t s) {
+  if (ndesc <= 0) return;
+  const int blocks = (nwork + 255) / 256;
+  k_tile_planes<<<blocks < 2048 ? blocks : 2048, 256, 0, s>>>(params, reinterpret_cast<_Float16*>(wt), reinterpret_cast<const int4*>(desc), ndesc, nwork);
 }
 
 // =================================================================================
@@ -554,6 +688,130 @@ __global__ __launch_bounds__(512) void k_mlp_fwd(const float* __restrict__ x, co
 }
 
 // =================================================================================
+// K3h (wide levels, C >= 64): K3 with its three Linear layers on the f16 matrix cores - every GEMM operand as two fp16
+// pieces, three products per term (gemm_phase_h2, ral_device.hpp).  The operand tiles of the products (attention output,
+// LayerNorm output, hidden chunk) live in LDS as two K-contiguous fp16 planes (the same 4 bytes per element as fp32), the
+// residual tile stays fp32.  wt: the tiled split planes of the weight matrices (k_tile_planes, once per forward), a matrix
+// at twice its float offset from `pbase`.
+// A work item is WPI consecutive windows (T = WPI * N tokens, T % 32 == 0): at these widths a window is 32 - 64 tokens
+// against 144 - 576 KB of weights, and what bounds the products is how often the weights are pulled through the L2 - once
+// per ITEM.  Only the 3-tap conv of the local enhancement sees window boundaries (per-window zero halos in A0).
+// =================================================================================
+template <int C, int NCH, int NTH>
+__global__ __launch_bounds__(NTH, 4) void k_mlp_fwd_h(const float* __restrict__ x, const float* __restrict__ o_hm,
+                                                   BlockP w, const float* __restrict__ pbase, const _Float16* __restrict__ wt,
+                                                   float* __restrict__ x1_out,
+                                                   float* __restrict__ upre_out, float* __restrict__ x2_out,
+                                                   int N, int B, int WPI) {
+  extern __shared__ float4 smem4[];
+  constexpr int LD = LDof<C>::v, HC = 4 * C / NCH, LDG = ldb_of(C), LDU = ldb_of(HC), LPR = C / 4, RPP = NTH / LPR;
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  const int T = WPI * N;
+  float* Xs = reinterpret_cast<float*>(smem4);                  // T x LD        : x -> x1 -> x2 (fp32)
+  _Float16* Gh = reinterpret_cast<_Float16*>(Xs + T * LD);      // 2 x T x LDG   : o, then LN2(x1)
+  const int gplane = T * LDG, uplane = T * LDU;
+  _Float16* Uh = Gh + 2 * gplane;                               // 2 x T x LDU   : hidden chunk
+  float* A0 = reinterpret_cast<float*>(Uh + 2 * uplane);        // WPI x (N + 2) : GELU(u[:,0]) with zero halos
+  const int cq = (threadIdx.x % LPR) * 4;
+  const bool le = w.le != nullptr;
+  float lw0 = 0.f, lw1 = 0.f, lw2 = 0.f;
+  if (le) { lw0 = w.le[0]; lw1 = w.le[1]; lw2 = w.le[2]; }
+  if ((int)threadIdx.x < 2 * WPI) A0[(threadIdx.x >> 1) * (N + 2) + (threadIdx.x & 1) * (N + 1)] = 0.f;
+  const _Float16* wph = wt + 2 * (w.wp - pbase);   // tiled split planes of the three weight matrices
+  const _Float16* w1h = wt + 2 * (w.w1 - pbase);
+  const _Float16* w2h = wt + 2 * (w.w2 - pbase);
+  auto put_split = [&](_Float16* base, int plane, int off, float4 v) {
+    const H2 s0 = f16_split2(v.x), s1 = f16_split2(v.y), s2 = f16_split2(v.z), s3 = f16_split2(v.w);
+    *reinterpret_cast<f16x4*>(base + off) = f16x4{s0.a, s1.a, s2.a, s3.a};
+    *reinterpret_cast<f16x4*>(base + plane + off) = f16x4{s0.b, s1.b, s2.b, s3.b};
+  };
+  RAL_STAMP_INIT();
+  for (int item = blockIdx.x; item * WPI < B; item += gridDim.x) {
+    RAL_STAMP_AT(0);
+    const size_t wo = (size_t)item * T * C;
+    {   // x -> padded fp32 rows; o (head-major quads per window) -> token-major split planes
+      const float4* gx = reinterpret_cast<const float4*>(x + wo);
+      const float4* go = reinterpret_cast<const float4*>(o_hm + wo);
+      constexpr int q = C / 4;
+      const int n4 = T * q, nq = N * q;
+      auto put = [&](int i, float4 xv, float4 ov) {
+        *reinterpret_cast<float4*>(Xs + (i / q) * LD + (i % q) * 4) = xv;
+        const int wl = i / nq, i2 = i - wl * nq, qd = i2 / N, t = i2 - qd * N;
+        put_split(Gh, gplane, (wl * N + t) * LDG + qd * 4, ov);
+      };
+      for (int i0 = 0; i0 < n4; i0 += 2 * NTH) {
+        const int i = i0 + threadIdx.x, j = i + NTH;
+        const int ic = i < n4 ? i : 0, jc = j < n4 ? j : 0;
+        const float4 x0 = gx[ic], x1 = gx[jc], o0 = go[ic], o1 = go[jc];
+        if (i < n4) put(i, x0, o0);
+        if (j < n4) put(j, x1, o1);
+      }
+    }
+    __syncthreads();
+    RAL_STAMP_AT(1);
+    // ---- attention output projection + residual ----
+    float* x1w = x1_out ? x1_out + wo : nullptr;
+    gemm_phase_h2<C>(wph, C / 32, 0, 0, C, w.bp, Gh, gplane, LDG, T >> 4, [&](int row0, int tok, f32x4 a) {
+      float4* px = reinterpret_cast<float4*>(Xs + tok * LD + row0);
+      const float4 v = f4add(*px, tofloat4(a));
+      *px = v;
+      if (x1w) *reinterpret_cast<float4*>(x1w + (size_t)tok * C + row0) = v;
+    });
+    __syncthreads();
+    RAL_STAMP_AT(2);
+    // ---- LN2 -> split planes ----
+    {
+      const float4 gam = *reinterpret_cast<const float4*>(w.ln2w + cq);
+      const float4 bet = *reinterpret_cast<const float4*>(w.ln2b + cq);
+      for (int row = threadIdx.x / LPR; row < T; row += RPP) {
+        const float4 v = *reinterpret_cast<const float4*>(Xs + row * LD + cq);
+        float4 d; float rstd;
+        ln_stats<LPR>(v, d, rstd);
+        put_split(Gh, gplane, row * LDG + cq, f4add(f4mul(f4scale(d, rstd), gam), bet));
+      }
+    }
+    __syncthreads();
+    RAL_STAMP_AT(3);
+    float* upw = upre_out ? upre_out + wo * 4 : nullptr;
+    float* x2w = x2_out + wo;
+#pragma unroll 1
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int j0 = ch * HC;
+      gemm_phase_h2<C>(w1h, C / 32, j0 / 16, 0, HC, w.b1 + j0, Gh, gplane, LDG, T >> 4, [&](int row0, int tok, f32x4 a) {
+        const float4 u = tofloat4(a);
+        if (upw) *reinterpret_cast<float4*>(upw + (size_t)tok * 4 * C + j0 + row0) = u;
+        float4 h = make_float4(gelu_f(u.x), gelu_f(u.y), gelu_f(u.z), gelu_f(u.w));
+        if (le) {
+          if (ch == 0 && row0 == 0) A0[tok + 1 + 2 * (tok / N)] = h.x;   // conv input; hidden channel 0 is filled below
+          h = make_float4(gelu_f(h.x), gelu_f(h.y), gelu_f(h.z), gelu_f(h.w));
+        }
+        put_split(Uh, uplane, tok * LDU + row0, h);
+      });
+      __syncthreads();
+      RAL_STAMP_AT(4);
+      if (le && ch == 0) {
+        for (int n = threadIdx.x; n < T; n += NTH) {
+          const int a = n + 1 + 2 * (n / N);
+          const H2 s = f16_split2(gelu_f(lw0 * A0[a - 1] + lw1 * A0[a] + lw2 * A0[a + 1]));
+          Uh[n * LDU] = s.a; Uh[uplane + n * LDU] = s.b;
+        }
+        __syncthreads();
+      }
+      RAL_STAMP_AT(5);
+      gemm_phase_h2<HC>(w2h, 4 * C / 32, 0, j0 / 32, C, ch == 0 ? w.b2 : nullptr, Uh, uplane, LDU, T >> 4, [&](int row0, int tok, f32x4 a) {
+        float4* px = reinterpret_cast<float4*>(Xs + tok * LD + row0);
+        const float4 v = f4add(*px, tofloat4(a));
+        if (ch == NCH - 1) *reinterpret_cast<float4*>(x2w + (size_t)tok * C + row0) = v;   // block output
+        else *px = v;
+      });
+      __syncthreads();
+      RAL_STAMP_AT(6);
+    }
+  }
+}
+
+
+// =================================================================================
 // PatchMerging  : (N, C) viewed as (N/2, 2C) -> LN(2C) -> Linear(2C, 2C, no bias)
 // PatchSeparate : rows [x[:, :C/2] ; x[:, C/2:]] (2N, C/2) -> LN -> Linear (+ skip)
 // D = feature width of the LayerNorm / Linear; T = output tokens per window.
@@ -605,22 +863,35 @@ static inline int grid_for(int items) {
   return items < gmax ? items : gmax;
 }
 
-// widths whose projection has a bf16 x 3 kernel (the caller passes the weight planes to choose it)
-bool qkv_fwd_uses_bf16(int C) { return C == 64 || C == 128; }
+// widths whose projection has a split-operand kernel (the caller passes the tiled weight planes to choose it)
+bool qkv_fwd_uses_f16(int C) { return C == 64 || C == 128; }
 
-void launch_qkv_fwd(int C, const float* x, const float* pe, const BlockP& w, const void* wb, float* qkv, int N, int B, hipStream_t s) {
-  if (wb && qkv_fwd_uses_bf16(C) && N % 16 == 0) {
-    const size_t wplane = (size_t)3 * C * C;
-    const __bf16* wbp = reinterpret_cast<const __bf16*>(wb);
+void launch_qkv_fwd(int C, const float* x, const float* pe, const BlockP& w, const void* wt, float* qkv, int N, int B, hipStream_t s) {
+  if (wt && qkv_fwd_uses_f16(C) && N % 16 == 0) {
+    const _Float16* wtp = reinterpret_cast<const _Float16*>(wt);
     auto go = [&](auto kern, int GT) {
-      const size_t ldsb = (size_t)3 * GT * ldb_of(C) * 2;
+      const size_t ldsb = (size_t)2 * GT * ldb_of(C) * 2;
       RAL_SET_LDS(kern, ldsb);
       const long ngroups = ((long)B * N + GT - 1) / GT;
-      const int wgs = (int)(160 * 1024 / (ldsb + 1024)) * 256;   // what fits the CUs at once
-      kern<<<(int)(ngroups < wgs ? ngroups : wgs), 256, ldsb, s>>>(x, pe, w, wbp, wplane, qkv, N, B);
+      const int wgs = 512;
+      kern<<<(int)(ngroups < wgs ? ngroups : wgs), 256, ldsb, s>>>(x, pe, w, wtp, qkv, N, B);
     };
-    if (C == 64 && (N % 64 == 0 || 64 % N == 0)) { go(k_qkv_fwd_b<64, 64>, 64); return; }
-    if (C == 128 && (N % 64 == 0 || 64 % N == 0)) { go(k_qkv_fwd_b<128, 64>, 64); return; }
+    // weight-stationary kernel: one workgroup per CU (C = 128) / two (C = 64), token groups of 64 = whole windows
+    static const bool ws = !(getenv("RAL_QKV_WS") && atoi(getenv("RAL_QKV_WS")) == 0);
+    auto gows = [&](auto kern, int C_, int per_cu) {
+      const size_t ldsb = (size_t)2 * 2 * 64 * ldb_of(C_) * 2;
+      RAL_SET_LDS(kern, ldsb);
+      const long ngroups = ((long)B * N + 63) / 64;
+      static const int gq = getenv("RAL_GRID_QKVW") ? atoi(getenv("RAL_GRID_QKVW")) : 0;
+      const int wgs = gq > 0 ? gq : 256 * per_cu;
+      kern<<<(int)(ngroups < wgs ? ngroups : wgs), 6 * C_, ldsb, s>>>(x, pe, w, wtp, qkv, N, B);
+    };
+    if (ws && 64 % N == 0) {
+      if (C == 64) { gows(k_qkv_fwd_ws<64, 64>, 64, 2); return; }
+      if (C == 128) { gows(k_qkv_fwd_ws<128, 64>, 128, 1); return; }
+    }
+    if (C == 64 && (N % 64 == 0 || 64 % N == 0)) { go(k_qkv_fwd_h<64, 64>, 64); return; }
+    if (C == 128 && (N % 64 == 0 || 64 % N == 0)) { go(k_qkv_fwd_h<128, 64>, 64); return; }
   }
   const size_t lds = (size_t)N * ld_of(C) * sizeof(float);
   switch (C) {
@@ -696,8 +967,47 @@ static void launch_mlp_fwd_c(int nch, const float* x, const float* o, const Bloc
   else { RAL_SET_LDS((k_mlp_fwd<C, 4>), lds); k_mlp_fwd<C, 4><<<grid_for(B), 512, lds, s>>>(x, o, w, x1, upre, x2, N, B); }
 }
 
-void launch_mlp_fwd(int C, int nch, const float* x, const float* o, const BlockP& w, float* x1, float* upre,
-                    float* x2, int N, int B, hipStream_t s) {
+// wide levels on split fp16 operands (RAL_MLP_F16=0: the fp32-MFMA kernel everywhere)
+bool mlp_fwd_uses_f16(int C, int N) {
+  static const bool on = !(getenv("RAL_MLP_F16") && atoi(getenv("RAL_MLP_F16")) == 0);
+  return on && (C == 64 || C == 128) && N % 32 == 0;
+}
+size_t mlp_fwd_h_lds(int C, int T, int nch) {   // T = tokens of a work item
+  return (size_t)T * ld_of(C) * 4 + (size_t)2 * T * ldb_of(C) * 2 + (size_t)2 * T * ldb_of(4 * C / nch) * 2 + (T / 16 * 2 + T + 4) * 4;
+}
+// windows per work item and hidden chunks of the split-operand kernel: the most tokens (up to RAL_MLP_TOK, a power-of-two
+// number of windows dividing the batch) whose tiles fit RAL_MLP_HLDS bytes with at most four hidden chunks
+static void mlp_fwd_h_plan(int C, int N, int B, int* wpi_out, int* nch_out) {
+  static const int tokmax = getenv("RAL_MLP_TOK") ? atoi(getenv("RAL_MLP_TOK")) : 0;   // default: one window per item (64 / 128 tokens measured slower: mlp_fwd 1.87 / 1.93 against 1.76 ms per step - one workgroup per CU)
+  static const size_t budget = getenv("RAL_MLP_HLDS") ? (size_t)atoll(getenv("RAL_MLP_HLDS")) : 150 * 1024;
+  int wpi = 1;
+  while (wpi * 2 * N <= tokmax && B % (wpi * 2) == 0 && mlp_fwd_h_lds(C, wpi * 2 * N, 4) <= budget) wpi *= 2;
+  int nch = 1;
+  const size_t b1 = wpi == 1 ? 78000 : budget;
+  while (nch < 4 && mlp_fwd_h_lds(C, wpi * N, nch) > b1) nch *= 2;
+  *wpi_out = wpi; *nch_out = nch;
+}
+template <int C, int NTH>
+static void launch_mlp_fwd_hc(const float* x, const float* o, const BlockP& w, const float* pbase, const void* wh,
+                              float* x1, float* upre, float* x2, int N, int B, hipStream_t s) {
+  int wpi, nch;
+  mlp_fwd_h_plan(C, N, B, &wpi, &nch);
+  const size_t lds = mlp_fwd_h_lds(C, wpi * N, nch);
+  const _Float16* whp = reinterpret_cast<const _Float16*>(wh);
+  const int grid = grid_for(B / wpi);
+  if (nch == 1) { RAL_SET_LDS((k_mlp_fwd_h<C, 1, NTH>), lds); k_mlp_fwd_h<C, 1, NTH><<<grid, NTH, lds, s>>>(x, o, w, pbase, whp, x1, upre, x2, N, B, wpi); }
+  else if (nch == 2) { RAL_SET_LDS((k_mlp_fwd_h<C, 2, NTH>), lds); k_mlp_fwd_h<C, 2, NTH><<<grid, NTH, lds, s>>>(x, o, w, pbase, whp, x1, upre, x2, N, B, wpi); }
+  else { RAL_SET_LDS((k_mlp_fwd_h<C, 4, NTH>), lds); k_mlp_fwd_h<C, 4, NTH><<<grid, NTH, lds, s>>>(x, o, w, pbase, whp, x1, upre, x2, N, B, wpi); }
+}
+
+void launch_mlp_fwd(int C, int nch, const float* x, const float* o, const BlockP& w, const float* pbase, const void* wh,
+                    float* x1, float* upre, float* x2, int N, int B, hipStream_t s) {
+  if (wh && mlp_fwd_uses_f16(C, N)) {
+    static const int nth = getenv("RAL_MLP_HTHREADS") ? atoi(getenv("RAL_MLP_HTHREADS")) : 512;
+    if (C == 64) { if (nth == 1024) launch_mlp_fwd_hc<64, 1024>(x, o, w, pbase, wh, x1, upre, x2, N, B, s); else launch_mlp_fwd_hc<64, 512>(x, o, w, pbase, wh, x1, upre, x2, N, B, s); }
+    else { if (nth == 1024) launch_mlp_fwd_hc<128, 1024>(x, o, w, pbase, wh, x1, upre, x2, N, B, s); else launch_mlp_fwd_hc<128, 512>(x, o, w, pbase, wh, x1, upre, x2, N, B, s); }
+    return;
+  }
   switch (C) {
 #define CASE(c) case c: launch_mlp_fwd_c<c>(nch, x, o, w, x1, upre, x2, N, B, s); break;
     CASE(8) CASE(16) CASE(32) CASE(64) CASE(128)

@@ -16,16 +16,22 @@
   } while (0)
 
 // ---- forward (ral_fwd.hip)
-// wb: three bf16 planes of Wqkv (launch_split_planes) for the levels where qkv_fwd_uses_bf16(C), else ignored / null
-bool qkv_fwd_uses_bf16(int C);
-void launch_split_planes(const float* src, void* dst, size_t n, hipStream_t s);
-void launch_qkv_fwd(int C, const float* x, const float* pe, const BlockP& w, const void* wb, float* qkv, int N, int B, hipStream_t s);
+// Linear layers of the wide levels on the f16 matrix cores (two fp16 pieces per operand, three products per term): the
+// weight matrices are re-written once per forward as tiled split planes (launch_tile_planes: desc = int4 {float offset, rows,
+// columns, first work item} per matrix, nwork = sum of rows * columns / 8; a matrix's planes sit at twice its float offset
+// in `wt`).  wt == nullptr selects the fp32-MFMA kernels.
+bool qkv_fwd_uses_f16(int C);
+void launch_tile_planes(const float* params, void* wt, const void* desc, int ndesc, int nwork, hipStream_t s);
+void launch_qkv_fwd(int C, const float* x, const float* pe, const BlockP& w, const void* wt /* of Wqkv */, float* qkv, int N, int B, hipStream_t s);
 size_t attn_fwd_lds(int N, int HG, int Len);
 void launch_attn_fwd(const float* qkv, float* o_hm, float* lse, const float* table, int N, int H, int HG, int Len,
                      int B, hipStream_t s);
 size_t mlp_fwd_lds(int C, int N, int nch);
-void launch_mlp_fwd(int C, int nch, const float* x, const float* o, const BlockP& w, float* x1, float* upre,
-                    float* x2, int N, int B, hipStream_t s);
+// pbase / wt: the parameter buffer and the tiled-plane buffer; the levels where mlp_fwd_uses_f16(C, N) run their Linear
+// layers on the planes (wt == nullptr: fp32 MFMA everywhere)
+bool mlp_fwd_uses_f16(int C, int N);
+void launch_mlp_fwd(int C, int nch, const float* x, const float* o, const BlockP& w, const float* pbase, const void* wt,
+                    float* x1, float* upre, float* x2, int N, int B, hipStream_t s);
 void launch_resample_fwd(int D, bool sep, const float* x, const float* wred, const float* lnw, const float* lnb,
                          const float* skip, float* y, int T, int B, hipStream_t s);
 void launch_add(const float* a, const float* b, float* y, size_t n, hipStream_t s);
