@@ -260,6 +260,9 @@ struct RalModel {
                                             // offset), re-written every forward from the descriptors below
   int* wdesc = nullptr;                     // device: int4 {offset, rows, columns, first work item} per matrix
   int ndesc = 0, nwork = 0;
+  unsigned short* whT = nullptr;            // the same for the transposed matrices of the backward (from paramsT), training only
+  int* wdescT = nullptr;
+  int ndescT = 0, nworkT = 0;
   void* tdesc = nullptr; int tn = 0, ttotal = 0;
   const float* last_x = nullptr;
   int last_B = 0;
@@ -355,6 +358,8 @@ static size_t plan_workspace(const ral_config& c, RalModel* m /* may be null: si
     M.dz0 = take("dz0", E);
     Layout L_; build_layout(c, L_);
     M.paramsT = take("paramsT", (size_t)L_.nparam);
+    M.whT = reinterpret_cast<unsigned short*>(take("whT", (size_t)L_.nparam));
+    M.wdescT = reinterpret_cast<int*>(take("wdescT", 4 * 64));
     M.tdesc = take("tdesc", 4 * 128);
   }
   return cur;
@@ -590,7 +595,7 @@ static void run_block_bwd(RalModel* m, int bi, const float* dy, const float* ext
   const float *x1 = woff(a.x1, w0, E1), *upre = woff(a.upre, w0, 4 * E1), *qkv = woff(a.qkv, w0, 3 * E1),
               *o = woff(a.o, w0, E1), *lse = woff(a.lse, w0, E1 / 4), *xin = woff(a.in, w0, E1);
   bool fused_mlp_dw;
-  { ProfScope p(m, K_MLP_BWD, s); fused_mlp_dw = launch_mlp_bwd(C, m->nch_b[l], dyw, x1, upre, w, wt, g, dupre, dx1, dohm, a2c0, N, B, m->want_dw, s); }
+  { ProfScope p(m, K_MLP_BWD, s); fused_mlp_dw = launch_mlp_bwd(C, m->nch_b[l], dyw, x1, upre, w, wt, m->paramsT, (m->f16_split > 0 && C >= m->f16_split) ? m->whT : nullptr, g, dupre, dx1, dohm, a2c0, N, B, m->want_dw, s); }
   { ProfScope p(m, K_ATTN_BWD, s);
     // (each lane's scratch: its share of the stat2 region followed by its share of the partials region)
     float* scratch = m->astat[k] + (size_t)w0 * (E1 / 2 + 2048);
@@ -642,6 +647,7 @@ static int bwd_begin(RalModel* m, const float* dy, int B, hipStream_t s) {
   HIP_OK(hipMemsetAsync(m->grads, 0, (size_t)Y.nparam * sizeof(float), s));
   HIP_OK(hipMemsetAsync(m->bn_sums + 32, 0, 32 * sizeof(double), s));
   launch_transpose_mats(m->params, m->paramsT, m->tdesc, m->tn, m->ttotal, s);
+  if (m->f16_split > 0) launch_tile_planes(m->paramsT, m->whT, m->wdescT, m->ndescT, m->nworkT, s);
   float** gy = m->gy; float** gin = m->gin;
   const int nl = plan_lanes(m, B, s);
   LaneSet* LS = lanes_of(m);
@@ -924,6 +930,22 @@ int ral_create(const ral_config* cfg, ral_handle** out) {
       add(o.wqkv, 3 * C, C); add(o.wp, C, C); add(o.w1, 4 * C, C); add(o.w2, C, 4 * C);
     }
     m->ndesc = (int)d.size() / 4; m->nwork = run;
+    if (cfg->train) {   // transposed matrices of the backward's data-gradient products (rows x columns as they sit in paramsT)
+      std::vector<int> dt;
+      int runT = 0;
+      auto addT = [&](int64_t off, int rows, int cols) { dt.push_back((int)off); dt.push_back(rows); dt.push_back(cols); dt.push_back(runT); runT += rows * cols / 8; };
+      for (int b = 0; b < 18; ++b) {
+        const int C = CH[STAGES[b / 2].level];
+        if (!qkv_fwd_uses_f16(C)) continue;
+        const BlockOff& o = m->lay.blk[b];
+        addT(o.wp, C, C); addT(o.w1, C, 4 * C); addT(o.w2, 4 * C, C);
+      }
+      m->ndescT = (int)dt.size() / 4; m->nworkT = runT;
+      if (m->ndescT) {
+        e = hipMemcpy(m->wdescT, dt.data(), dt.size() * sizeof(int), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { fail("hipMemcpy(wdescT) failed: %s", hipGetErrorString(e)); destroy_model(m); delete h; return -1; }
+      }
+    }
     if (m->ndesc > 64) { fail("too many split-plane descriptors"); destroy_model(m); delete h; return -1; }
     if (m->ndesc) {
       e = hipMemcpy(m->wdesc, d.data(), d.size() * sizeof(int), hipMemcpyHostToDevice);

@@ -174,6 +174,215 @@ __global__ __launch_bounds__(512) void k_mlp_bwd(const float* __restrict__ dx2, 
 }
 
 // =================================================================================
+// B3h (wide levels, C >= 64): B3 with its three data-gradient products on the f16 matrix cores, every operand as two
+// fp16 pieces (gemm_wx_h2, ral_device.hpp).  wtt: tiled split planes of the TRANSPOSED weight matrices (a matrix at twice
+// its float offset from `ptbase`).  The gradient rows that feed a product (dx2, du, dx1) are scaled by a power of two
+// per TOKEN first (h2_row_scale: they are ~1e-6, fp16 starts at 6e-5) and the product is unscaled in its epilogue - the
+// contraction runs over a token's channels, so the scale factors out exactly.  For du the row maximum is only known
+// once every wave has its part of the row: the fc2^T phase keeps its (one) unit's du values in registers, raises the
+// token's maximum with an LDS atomic, and splits after a barrier - into the LDS bytes of the u_pre chunk, which nobody
+// reads any more.  That is why the kernel takes (N, HC) with exactly one 32 x 32 unit per wave: (HC / 32) (N / 32) == 8.
+// dx2 is not kept in fp32: the LayerNorm backward reads it again from global memory (L2).
+// =================================================================================
+template <int C, int NCH>
+__global__ __launch_bounds__(512, 4) void k_mlp_bwd_h(const float* __restrict__ dx2, const float* __restrict__ x1,
+                                                      const float* __restrict__ upre, BlockP w, BlockP wt, const float* __restrict__ ptbase,
+                                                      const _Float16* __restrict__ wtt, BlockP gr,
+                                                      float* __restrict__ dupre, float* __restrict__ dx1,
+                                                      float* __restrict__ do_hm, float* __restrict__ a2c0, int N, int B) {
+  extern __shared__ float4 smem4[];
+  constexpr int LD = LDof<C>::v, HC = 4 * C / NCH, LDUF = LDof<HC>::v, LDG = ldb_of(C), LDU = ldb_of(HC), LPR = C / 4, RPP = 512 / LPR;
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  _Float16* Dh = reinterpret_cast<_Float16*>(smem4);            // 2 x N x LDG : dx2, later dx1 (scaled, split)
+  const int dplane = N * LDG, uplane = N * LDU;
+  float* Gs = reinterpret_cast<float*>(Dh + 2 * dplane);        // N x LD      : dg accumulator (fp32)
+  float* Us = Gs + N * LD;                                      // N x LDUF    : u_pre chunk (fp32) ...
+  _Float16* Uh = reinterpret_cast<_Float16*>(Us);               // 2 x N x LDU : ... then du (scaled, split); N (HC + 8) floats
+  float* A0 = Us + N * (HC + 8);                                // N + 2  : gelu(u[:,0]), zero halo
+  float* DC0 = A0 + N + 2;                                      // N + 2  : d c0, zero halo
+  float* U0 = DC0 + N + 2;                                      // N      : u_pre[:,0]
+  float* C0 = U0 + N;                                           // N      : conv output c0
+  float* DU0 = C0 + N;                                          // N      : du of hidden channel 0 (local enhancement)
+  unsigned* smD = reinterpret_cast<unsigned*>(DU0 + N);         // N      : bits of max |dx2 row| / |dx1 row|
+  unsigned* smU = smD + N;                                      // N      : bits of max |du row| of the chunk
+  float* red = reinterpret_cast<float*>(smU + N);               // 2C + 4 : ln2 grads + le taps (block reduction)
+  const int cq = (threadIdx.x % LPR) * 4;
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
+  const bool le = w.le != nullptr;
+  float lw0 = 0.f, lw1 = 0.f, lw2 = 0.f;
+  if (le) { lw0 = w.le[0]; lw1 = w.le[1]; lw2 = w.le[2]; }
+  const float4 gam2 = *reinterpret_cast<const float4*>(w.ln2w + cq);
+  const _Float16* w2t = wtt + 2 * (wt.w2 - ptbase);   // (4C x C)
+  const _Float16* w1t = wtt + 2 * (wt.w1 - ptbase);   // (C x 4C)
+  const _Float16* wpt = wtt + 2 * (wt.wp - ptbase);   // (C x C)
+  float gle0 = 0.f, gle1 = 0.f, gle2 = 0.f;
+  float4 dgam = make_float4(0.f, 0.f, 0.f, 0.f), dbet = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto put_split = [&](_Float16* base, int plane, int off, float4 v) {
+    const H2 s0 = f16_split2(v.x), s1 = f16_split2(v.y), s2 = f16_split2(v.z), s3 = f16_split2(v.w);
+    *reinterpret_cast<f16x4*>(base + off) = f16x4{s0.a, s1.a, s2.a, s3.a};
+    *reinterpret_cast<f16x4*>(base + plane + off) = f16x4{s0.b, s1.b, s2.b, s3.b};
+  };
+  auto put_row = [&](int row, float4 v) {   // a gradient row held by LPR lanes -> scaled split planes of Dh + its maximum
+    const float mx = group_max<LPR>(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    const unsigned mb = __float_as_uint(mx);
+    put_split(Dh, dplane, row * LDG + cq, f4scale(v, h2_row_scale(mb)));
+    if (cq == 0) smD[row] = mb;
+  };
+  const int mb_ = HC / 32, um = wave % mb_, ut = wave / mb_;   // the wave's unit of the fc2^T phase
+  for (int win = blockIdx.x; win < B; win += gridDim.x) {
+    const size_t wo = (size_t)win * N * C;
+    for (int row0 = threadIdx.x / LPR; row0 < N; row0 += 2 * RPP) {
+      const int rowb = row0 + RPP < N ? row0 + RPP : row0;
+      const float4 va = *reinterpret_cast<const float4*>(dx2 + wo + (size_t)row0 * C + cq);
+      const float4 vb = *reinterpret_cast<const float4*>(dx2 + wo + (size_t)rowb * C + cq);
+      put_row(row0, va);
+      if (row0 + RPP < N) put_row(rowb, vb);
+    }
+    if ((int)threadIdx.x < N) smU[threadIdx.x] = 0u;
+#pragma unroll 1
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int j0 = ch * HC;
+      copy_in(Us, LDUF, upre + (size_t)win * N * 4 * C + j0, 4 * C, N, HC);
+      __syncthreads();
+      if (le && ch == 0) {
+        for (int i = threadIdx.x; i < N + 2; i += blockDim.x) {
+          const bool halo = (i == 0 || i == N + 1);
+          const float u = halo ? 0.f : Us[(i - 1) * LDUF];
+          A0[i] = halo ? 0.f : gelu_f(u);
+          DC0[i] = 0.f;
+          if (!halo) U0[i - 1] = u;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < N; i += blockDim.x) {
+          const float c0 = lw0 * A0[i] + lw1 * A0[i + 1] + lw2 * A0[i + 2];
+          C0[i] = c0;
+          if (a2c0) a2c0[(size_t)win * N + i] = gelu_f(c0);   // fc2 input of the LE channel, for the fc2 weight-gradient kernel
+        }
+        __syncthreads();
+      }
+      // ---- d a2 = dx2 W2[:, chunk] -> du: the wave's 32 hidden x 32 token unit, values kept in registers ----
+      float outv[2][2][4];
+      {
+        f32x4 acc[2][2], accx[2][2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) { acc[mi][tt] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[mi][tt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        gemm_wx_h2<C, 2, 2>(w2t, C / 32, j0 / 16 + um * 2, 0, Dh, dplane, LDG, ut * 32, acc, accx);
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          const int tok = ut * 32 + tt * 16 + r;
+          const float sd = h2_row_unscale(smD[tok]);
+          float mx = 0.f;
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) {
+            const int row0 = (um * 2 + mi) * 16 + 4 * g;
+            const f32x4 a = (acc[mi][tt] + accx[mi][tt] * RAL_H2_SCALE) * sd;
+            const float4 u = *reinterpret_cast<const float4*>(Us + tok * LDUF + row0);
+            const float uu[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float o;
+              if (!le) {
+                o = a[e] * gelu_grad_f(uu[e]);
+              } else if (ch == 0 && row0 + e == 0) {
+                DC0[tok + 1] = a[e] * gelu_grad_f(C0[tok]);
+                o = 0.f;  // filled by the channel-0 pass below
+              } else {
+                float a1, d1;
+                gelu_pair(uu[e], a1, d1);
+                o = a[e] * gelu_grad_f(a1) * d1;
+              }
+              outv[mi][tt][e] = o;
+              mx = fmaxf(mx, fabsf(o));
+            }
+          }
+          mx = rows_max(mx);
+          if (g == 0) atomicMax(smU + tok, __float_as_uint(mx));
+        }
+      }
+      __syncthreads();
+      if (le && ch == 0) {
+        for (int n = threadIdx.x; n < N; n += blockDim.x) {
+          const float da1 = lw0 * DC0[n + 2] + lw1 * DC0[n + 1] + lw2 * DC0[n];
+          const float v = da1 * gelu_grad_f(U0[n]);
+          DU0[n] = v;
+          atomicMax(smU + n, __float_as_uint(fabsf(v)));
+          const float dc = DC0[n + 1];
+          gle0 += dc * A0[n]; gle1 += dc * A0[n + 1]; gle2 += dc * A0[n + 2];
+        }
+        __syncthreads();
+      }
+      // every reader of the u_pre chunk is past a barrier: du goes to global memory (fp32) and, scaled and split, over it
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const int tok = ut * 32 + tt * 16 + r;
+        const float su = h2_row_scale(smU[tok]);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const int row0 = (um * 2 + mi) * 16 + 4 * g;
+          float4 v = make_float4(outv[mi][tt][0], outv[mi][tt][1], outv[mi][tt][2], outv[mi][tt][3]);
+          if (le && ch == 0 && row0 == 0) v.x = DU0[tok];
+          if (dupre) *reinterpret_cast<float4*>(dupre + ((size_t)win * N + tok) * 4 * C + j0 + row0) = v;   // (only the fc1 weight-gradient kernel reads it)
+          put_split(Uh, uplane, tok * LDU + row0, f4scale(v, su));
+        }
+      }
+      __syncthreads();
+      // ---- dg (+)= du W1[chunk, :] ----
+      gemm_phase_h2<HC>(w1t, 4 * C / 32, 0, j0 / 32, C, nullptr, Uh, uplane, LDU, N >> 4, [&](int row0, int tok, f32x4 a) {
+        const float si = h2_row_unscale(smU[tok]);
+        float4* pg = reinterpret_cast<float4*>(Gs + tok * LD + row0);
+        const float4 v = f4scale(tofloat4(a), si);
+        *pg = (ch == 0) ? v : f4add(*pg, v);
+      });
+      __syncthreads();
+      if ((int)threadIdx.x < N) smU[threadIdx.x] = 0u;
+    }
+    // ---- LN2 backward, dx1 = dx2 + dLN: to global memory and, scaled and split, into Dh ----
+    for (int row = threadIdx.x / LPR; row < N; row += RPP) {
+      const float4 v = *reinterpret_cast<const float4*>(x1 + wo + (size_t)row * C + cq);
+      const float4 d2 = *reinterpret_cast<const float4*>(dx2 + wo + (size_t)row * C + cq);
+      float4 d; float rstd;
+      ln_stats<LPR>(v, d, rstd);
+      const float4 xh = f4scale(d, rstd);
+      const float4 dg = *reinterpret_cast<const float4*>(Gs + row * LD + cq);
+      const float4 dyh = f4mul(dg, gam2);
+      constexpr float invC = 1.0f / C;
+      const float m1 = group_sum<LPR>(f4hsum(dyh)) * invC;
+      const float m2 = group_sum<LPR>(f4dot(dyh, xh)) * invC;
+      const float4 dx = f4add(d2, make_float4(rstd * (dyh.x - m1 - xh.x * m2), rstd * (dyh.y - m1 - xh.y * m2),
+                                              rstd * (dyh.z - m1 - xh.z * m2), rstd * (dyh.w - m1 - xh.w * m2)));
+      *reinterpret_cast<float4*>(dx1 + wo + (size_t)row * C + cq) = dx;
+      put_row(row, dx);
+      dgam = f4add(dgam, f4mul(dg, xh));
+      dbet = f4add(dbet, dg);
+    }
+    __syncthreads();
+    // ---- do = dx1 Wp (head-major) ----
+    float* dow = do_hm + wo;
+    gemm_phase_h2<C>(wpt, C / 32, 0, 0, C, nullptr, Dh, dplane, LDG, N >> 4, [&](int row0, int tok, f32x4 a) {
+      *reinterpret_cast<float4*>(dow + ((size_t)(row0 >> 2) * N + tok) * 4) = f4scale(tofloat4(a), h2_row_unscale(smD[tok]));
+    });
+    __syncthreads();
+  }
+  // ---- flush the small gradients ----
+  for (int i = threadIdx.x; i < 2 * C + 4; i += blockDim.x) red[i] = 0.f;
+  __syncthreads();
+  lds_add4(red, cq, dgam);
+  lds_add4(red, C + cq, dbet);
+  if (le) {
+    const float s0 = group_sum<64>(gle0), s1 = group_sum<64>(gle1), s2 = group_sum<64>(gle2);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(red + 2 * C, s0); atomicAdd(red + 2 * C + 1, s1); atomicAdd(red + 2 * C + 2, s2); }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < C) {
+    atomicAdd(gr.ln2w + threadIdx.x, red[threadIdx.x]);
+    atomicAdd(gr.ln2b + threadIdx.x, red[C + threadIdx.x]);
+  }
+  if (le && threadIdx.x < 3) atomicAdd(gr.le + threadIdx.x, red[2 * C + threadIdx.x]);
+}
+
+// =================================================================================
 // B3s: the same backward for the narrow levels (C <= 32) with the fc1 / fc2 WEIGHT gradients fused in.
 // At these widths dW1 (4C x C) and dW2 (C x 4C) fit in a few accumulator registers per wave, and both of
 // their operands (du | LN2(x1) and dx2 | a2) are already in LDS here, so the two token-contraction kernels
@@ -1370,6 +1579,32 @@ static bool launch_mlp_bwd_s(const float* dx2, const float* x1, const BlockP& w,
 #undef GO
 }
 
+// wide levels on split fp16 operands (RAL_MLP_F16=0: the fp32-MFMA kernel everywhere): the hidden-chunk count that gives
+// the fc2^T phase exactly one 32 x 32 unit per wave and fits the LDS budget, or 0
+size_t mlp_bwd_h_lds(int C, int N, int nch) {
+  const int HC = 4 * C / nch;
+  return (size_t)2 * N * ldb_of(C) * 2 + (size_t)N * ld_of(C) * 4 + (size_t)N * (HC + 8) * 4 + ((size_t)2 * (N + 2) + 5 * N + 2 * C + 4) * 4;
+}
+int mlp_bwd_h_nch(int C, int N) {
+  static const bool on = !(getenv("RAL_MLP_F16") && atoi(getenv("RAL_MLP_F16")) == 0);
+  if (!on || (C != 64 && C != 128) || N % 32 != 0) return 0;
+  for (int nch = 1; nch <= 4; nch *= 2)
+    if ((4 * C / nch / 32) * (N / 32) == 8 && mlp_bwd_h_lds(C, N, nch) <= 78000) return nch;
+  return 0;
+}
+template <int C>
+static void launch_mlp_bwd_hc(int nch, const float* dx2, const float* x1, const float* upre, const BlockP& w, const BlockP& wt,
+                              const float* ptbase, const void* wtt, const BlockP& gr, float* dupre, float* dx1, float* do_hm,
+                              float* a2c0, int N, int B, hipStream_t s) {
+  const size_t lds = mlp_bwd_h_lds(C, N, nch);
+  static const int gm = env_grid("RAL_GRID_MLPB", 512);
+  const int grid = cap(B, gm);
+  const _Float16* wp = reinterpret_cast<const _Float16*>(wtt);
+  if (nch == 1) { RAL_SET_LDS((k_mlp_bwd_h<C, 1>), lds); k_mlp_bwd_h<C, 1><<<grid, 512, lds, s>>>(dx2, x1, upre, w, wt, ptbase, wp, gr, dupre, dx1, do_hm, a2c0, N, B); }
+  else if (nch == 2) { RAL_SET_LDS((k_mlp_bwd_h<C, 2>), lds); k_mlp_bwd_h<C, 2><<<grid, 512, lds, s>>>(dx2, x1, upre, w, wt, ptbase, wp, gr, dupre, dx1, do_hm, a2c0, N, B); }
+  else { RAL_SET_LDS((k_mlp_bwd_h<C, 4>), lds); k_mlp_bwd_h<C, 4><<<grid, 512, lds, s>>>(dx2, x1, upre, w, wt, ptbase, wp, gr, dupre, dx1, do_hm, a2c0, N, B); }
+}
+
 template <int C>
 static bool launch_mlp_bwd_c(int nch, const float* dx2, const float* x1, const float* upre, const BlockP& w,
                              const BlockP& wt, const BlockP& gr, float* dupre, float* dx1, float* do_hm, float* a2c0, int N, int B,
@@ -1389,9 +1624,14 @@ static bool launch_mlp_bwd_c(int nch, const float* dx2, const float* x1, const f
 // returns true when the fc1 / fc2 weight (and bias) gradients were produced here (narrow levels): the caller then
 // skips those two products in launch_block_dw
 bool launch_mlp_bwd(int C, int nch, const float* dx2, const float* x1, const float* upre, const BlockP& w,
-                    const BlockP& wt, const BlockP& gr, float* dupre, float* dx1, float* do_hm, float* a2c0, int N, int B,
-                    bool want_dw, hipStream_t s) {
+                    const BlockP& wt, const float* ptbase, const void* wtt, const BlockP& gr, float* dupre, float* dx1, float* do_hm,
+                    float* a2c0, int N, int B, bool want_dw, hipStream_t s) {
   if (!want_dw) { dupre = nullptr; a2c0 = nullptr; }   // consumed by the weight-gradient kernels only
+  if (wtt) {
+    const int nh = mlp_bwd_h_nch(C, N);
+    if (nh && C == 64) { launch_mlp_bwd_hc<64>(nh, dx2, x1, upre, w, wt, ptbase, wtt, gr, dupre, dx1, do_hm, a2c0, N, B, s); return false; }
+    if (nh && C == 128) { launch_mlp_bwd_hc<128>(nh, dx2, x1, upre, w, wt, ptbase, wtt, gr, dupre, dx1, do_hm, a2c0, N, B, s); return false; }
+  }
   switch (C) {
 #define CASE(c) case c: return launch_mlp_bwd_c<c>(nch, dx2, x1, upre, w, wt, gr, dupre, dx1, do_hm, a2c0, N, B, want_dw, s);
     CASE(8) CASE(16) CASE(32) CASE(64) CASE(128)

@@ -14,6 +14,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -59,7 +60,11 @@ RAL_DEV void gemm_wx(const float* __restrict__ W, int ldw, int m0, int M, const 
       float4 wv[KB];
 #pragma unroll
       for (int c = 0; c < KB; ++c) {
+#ifdef RAL_GW_NOW   // diagnostic: the weight fragment of chunk 0 every time (same instructions, L1-hot)
+        const int k0 = 0;
+#else
         const int k0 = (kb + c) * 16;
+#endif
         if constexpr (!WT) {
           wv[c] = *reinterpret_cast<const float4*>(W + (size_t)mrow * ldw + k0 + 4 * g);
         } else {
@@ -157,6 +162,18 @@ RAL_DEV H2 f16_split2(float x) {
   return r;
 }
 #define RAL_H2_SCALE (1.0f / 2048.f)
+// Gradient rows are far below fp16's normal range (a mean-squared-error gradient is ~1e-6), so a row that feeds such a
+// product is multiplied by a power of two first: the scale that puts the row's largest magnitude (bits of |max| as an
+// unsigned) into [2^13, 2^14), capped at 2^60; the product is multiplied by the inverse afterwards (exact).  Entries far
+// below the row's maximum lose relative precision exactly where they no longer matter for the row's dot products.
+RAL_DEV float h2_row_scale(unsigned maxbits) {
+  const int f = 267 - (int)(maxbits >> 23);
+  return maxbits == 0u ? 1.0f : __uint_as_float((unsigned)(f < 187 ? f : 187) << 23);
+}
+RAL_DEV float h2_row_unscale(unsigned maxbits) {
+  const int f = 267 - (int)(maxbits >> 23);
+  return maxbits == 0u ? 1.0f : __uint_as_float((unsigned)(254 - (f < 187 ? f : 187)) << 23);
+}
 
 // Weight matrices reach these products as TILED split planes (k_tile_planes): tile (mt, kt) = rows 16 mt .., columns
 // 32 kt .. of W, both planes, is 2 KB of contiguous memory - plane p at + 512 p elements, the 16 bytes of lane (r, g) =
@@ -332,6 +349,29 @@ RAL_DEV float swap32_add(float v) {   // v[lane] + v[lane ^ 32]
   return __uint_as_float(p[0]) + __uint_as_float(p[1]);
 }
 RAL_DEV float rows_sum(float v) { return swap32_add(swap16_add(v)); }
+RAL_DEV float rows_max(float v) {   // max over the four rows of 16 lanes (same column)
+  auto p = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(p[0]), __uint_as_float(p[1]));
+  p = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(p[0]), __uint_as_float(p[1]));
+}
+template <int W> RAL_DEV float group_max(float v) {   // max over W consecutive lanes, result in every lane
+#define RAL_DPP_MAX(CTRL) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false)))
+  if constexpr (W >= 2) RAL_DPP_MAX(0xB1);
+  if constexpr (W >= 4) RAL_DPP_MAX(0x4E);
+  if constexpr (W >= 8) RAL_DPP_MAX(0x141);
+  if constexpr (W >= 16) RAL_DPP_MAX(0x140);
+#undef RAL_DPP_MAX
+  if constexpr (W >= 32) {
+    const auto p = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(p[0]), __uint_as_float(p[1]));
+  }
+  if constexpr (W >= 64) {
+    const auto p = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(p[0]), __uint_as_float(p[1]));
+  }
+  return v;
+}
 // 4 x 4 transpose between registers and the four 16-lane rows of a wave: in, register j of lane (r, g) holds E(j, g);
 // out, register j of lane (r, g) holds E(g, j).  (v_permlane32_swap a, b: a = [a.lanes 0-31, b.lanes 0-31], b =
 // [a.lanes 32-63, b.lanes 32-63]; v_permlane16_swap likewise inside each half.)

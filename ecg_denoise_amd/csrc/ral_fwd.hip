@@ -477,23 +477,6 @@ __global__ __launch_bounds__(512, (QT >= 4 ? 3 : 4)) void k_attn_fwd(const float
 // no more than the MFMA did, and the tile bookkeeping of the MFMA form disappears.
 // The softmax shift is the same Cauchy-Schwarz bound as above (exact running-max redo if a row underflows).
 // =================================================================================
-template <int W> RAL_DEV float group_max(float v) {   // max over W consecutive lanes, result in every lane
-#define RAL_DPP_MAX(CTRL) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false)))
-  if constexpr (W >= 2) RAL_DPP_MAX(0xB1);
-  if constexpr (W >= 4) RAL_DPP_MAX(0x4E);
-  if constexpr (W >= 8) RAL_DPP_MAX(0x141);
-  if constexpr (W >= 16) RAL_DPP_MAX(0x140);
-#undef RAL_DPP_MAX
-  if constexpr (W >= 32) {
-    const auto p = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = fmaxf(__uint_as_float(p[0]), __uint_as_float(p[1]));
-  }
-  if constexpr (W >= 64) {
-    const auto p = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = fmaxf(__uint_as_float(p[0]), __uint_as_float(p[1]));
-  }
-  return v;
-}
 
 template <bool BIAS>
 __global__ __launch_bounds__(256) void k_attn_fwd_v(const float* __restrict__ qkv, float* __restrict__ o_hm,

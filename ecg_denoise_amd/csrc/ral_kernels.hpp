@@ -66,9 +66,12 @@ void launch_transpose_mats(const float* src, float* dst, const void* desc, int n
 // ---- backward (ral_bwd.hip)
 size_t mlp_bwd_lds(int C, int N, int nch);
 bool mlp_bwd_is_fused(int C, int N);   // narrow levels: fused weight gradients, u_pre re-computed (not stored by the forward)
+// ptbase / wtt: the transposed-parameter buffer and the tiled split planes of its weight matrices (launch_tile_planes over
+// it); the (C, N) for which mlp_bwd_h_nch is non-zero run their data-gradient products on them (wtt == nullptr: fp32 MFMA)
+int mlp_bwd_h_nch(int C, int N);
 bool launch_mlp_bwd(int C, int nch, const float* dx2, const float* x1, const float* upre, const BlockP& w,
-                    const BlockP& wt, const BlockP& gr, float* dupre, float* dx1, float* do_hm, float* a2c0, int N, int B,
-                    bool want_dw, hipStream_t s);
+                    const BlockP& wt, const float* ptbase, const void* wtt, const BlockP& gr, float* dupre, float* dx1, float* do_hm,
+                    float* a2c0, int N, int B, bool want_dw, hipStream_t s);
 size_t attn_bwd_lds(int N, int HG, int Len);
 bool attn_bwd_uses_stat2(int N, int Len, bool table);   // does launch_attn_bwd need its (B, H, N, 2) scratch for this shape?
 void launch_attn_bwd(const float* qkv, const float* o_hm, const float* do_hm, const float* lse, const float* table,
