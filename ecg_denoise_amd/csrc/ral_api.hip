@@ -601,7 +601,7 @@ static void run_block_bwd(RalModel* m, int bi, const float* dy, const float* ext
     float* scratch = m->astat[k] + (size_t)w0 * (E1 / 2 + 2048);
     launch_attn_bwd(qkv, o, dohm, lse, table, gtable, dqkv, scratch, N, H, m->hg_b[l], Len, B, s); }
   { ProfScope p(m, K_QKV_BWD, s);
-    launch_qkv_bwd(C, dqkv, xin, m->pe[l], dx1, woff(extra, w0, E1), w, wt, g, woff(dx, w0, E1), N, B, s); }
+    launch_qkv_bwd(C, dqkv, xin, m->pe[l], dx1, woff(extra, w0, E1), w, wt, m->paramsT, (m->f16_split > 0 && C >= m->f16_split) ? m->whT : nullptr, g, woff(dx, w0, E1), N, B, s); }
   if (!m->want_dw) return;
   if (side) {
     EV(hipEventRecord(ln.ev_ready[k], s));
@@ -938,7 +938,7 @@ int ral_create(const ral_config* cfg, ral_handle** out) {
         const int C = CH[STAGES[b / 2].level];
         if (!qkv_fwd_uses_f16(C)) continue;
         const BlockOff& o = m->lay.blk[b];
-        addT(o.wp, C, C); addT(o.w1, C, 4 * C); addT(o.w2, 4 * C, C);
+        addT(o.wqkv, C, 3 * C); addT(o.wp, C, C); addT(o.w1, C, 4 * C); addT(o.w2, 4 * C, C);
       }
       m->ndescT = (int)dt.size() / 4; m->nworkT = runT;
       if (m->ndescT) {

@@ -685,6 +685,9 @@ __global__ __launch_bounds__(512, RAL_ATTNB_WPE) void k_attn_bwd(const float* __
   const int off = (N - Len) >> 1;
   const int kb0 = table ? (off & ~15) : N, kb1 = table ? ((off + Len + 15) & ~15) : N;
   for (int i = threadIdx.x; i < ntab; i += blockDim.x) dtab[i] = 0.f;
+#ifdef RAL_STAMP
+  constexpr int C = -1;   // (stamp conditions name the channel width)
+#endif
   RAL_STAMP_INIT();
   for (int item = blockIdx.x; item < B * ngrp; item += gridDim.x) {
     RAL_STAMP_AT(20);
@@ -1233,6 +1236,163 @@ __global__ __launch_bounds__(512, RAL_QKVB_MINB) void k_qkv_bwd(const float* dqk
 }
 
 // =================================================================================
+// B1h (wide levels, C >= 64, N C <= 4096): B1 with dh = dqkv Wqkv on the f16 matrix cores (two fp16 pieces per operand,
+// gemm_phase_h2).  The dqkv window sits in LDS as token-major split planes, every token row scaled by a power of two
+// (h2_row_scale; a row's 3C values arrive spread over the workgroup - head-major quads -, so its maximum is raised with LDS
+// atomics from the prefetch registers and the split happens one barrier later); the product is unscaled into Dh.
+// wtt: tiled split planes of the transposed weights (Wqkv^T: C x 3C).  Everything else as B1.
+// =================================================================================
+template <int C>
+__global__ __launch_bounds__(512, RAL_QKVB_MINB) void k_qkv_bwd_h(const float* dqkv, const float* x,
+                                                 const float* __restrict__ pe, const float* dx1,
+                                                 const float* extra, BlockP w, BlockP wt, const float* __restrict__ ptbase,
+                                                 const _Float16* __restrict__ wtt, BlockP gr,
+                                                 float* __restrict__ dx, int N, int B) {
+  extern __shared__ float4 smem4[];
+  constexpr int LD = LDof<C>::v, LPR = C / 4, LDQ = ldb_of(3 * C);
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  _Float16* Qh = reinterpret_cast<_Float16*>(smem4);   // 2 x N x LDQ : dqkv, token-major, scaled, split
+  const int qplane = N * LDQ;
+  float* Dh = reinterpret_cast<float*>(Qh + 2 * qplane);   // N x LD
+  float* red = Dh + N * LD;                     // 2C
+  unsigned* smQ = reinterpret_cast<unsigned*>(red + 2 * C);   // 2 x N : bits of max |dqkv row|, by window parity
+  const int RPP = blockDim.x / LPR;
+  const int cq = (threadIdx.x % LPR) * 4;
+  const float sqrtC = sqrtf((float)C);
+  const float4 gam1 = *reinterpret_cast<const float4*>(w.ln1w + cq);
+  float4 dgam = make_float4(0.f, 0.f, 0.f, 0.f), dbet = make_float4(0.f, 0.f, 0.f, 0.f);
+  const _Float16* wq = wtt + 2 * (wt.wqkv - ptbase);
+  constexpr int NQ = 6, NR = 2;
+  const int n4 = N * 3 * C / 4;   // <= NQ * 512 (launcher)
+  const int rbase = threadIdx.x / LPR;
+  const float* const ex = extra ? extra : dx1;
+  auto row_off = [&](int win, int u) -> size_t {
+    return (size_t)win * N * C + (size_t)min(rbase + u * RPP, N - 1) * C + cq;
+  };
+  auto ld4 = [&](const float* base, size_t o) -> float4 { return *reinterpret_cast<const float4*>(base + o); };
+  auto ld_dq = [&](int win, int u) -> float4 {
+    return reinterpret_cast<const float4*>(dqkv + (size_t)win * N * 3 * C)[min((int)threadIdx.x + u * (int)blockDim.x, n4 - 1)];
+  };
+  auto max_dq = [&](unsigned* sm, int u, float4 v) {   // flat float4 i = (channel quad, token)
+    const int i = threadIdx.x + u * blockDim.x;
+    if (i < n4) atomicMax(sm + i % N, __float_as_uint(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)))));
+  };
+  auto st_dq = [&](const unsigned* sm, int u, float4 v) {
+    const int i = threadIdx.x + u * blockDim.x;
+    if (i < n4) {
+      const int qd = i / N, t = i - qd * N;
+      v = f4scale(v, h2_row_scale(sm[t]));
+      const H2 s0 = f16_split2(v.x), s1 = f16_split2(v.y), s2 = f16_split2(v.z), s3 = f16_split2(v.w);
+      *reinterpret_cast<f16x4*>(Qh + t * LDQ + qd * 4) = f16x4{s0.a, s1.a, s2.a, s3.a};
+      *reinterpret_cast<f16x4*>(Qh + qplane + t * LDQ + qd * 4) = f16x4{s0.b, s1.b, s2.b, s3.b};
+    }
+  };
+  float4 pe4[NR];
+#pragma unroll
+  for (int u = 0; u < NR; ++u) pe4[u] = *reinterpret_cast<const float4*>(pe + min(rbase + u * RPP, N - 1) * C + cq);
+  auto ln_row = [&](size_t wo, int row, float4 v, float4 p, float4 d1, float4 e) {
+    v = f4add(f4scale(v, sqrtC), p);
+    float4 d; float rstd;
+    ln_stats<LPR>(v, d, rstd);
+    const float4 xh = f4scale(d, rstd);
+    const float4 dh = *reinterpret_cast<const float4*>(Dh + row * LD + cq);
+    const float4 dyh = f4mul(dh, gam1);
+    constexpr float invC = 1.0f / C;
+    const float m1 = group_sum<LPR>(f4hsum(dyh)) * invC;
+    const float m2 = group_sum<LPR>(f4dot(dyh, xh)) * invC;
+    const float k = rstd * sqrtC;
+    float4 out = make_float4(k * (dyh.x - m1 - xh.x * m2), k * (dyh.y - m1 - xh.y * m2),
+                             k * (dyh.z - m1 - xh.z * m2), k * (dyh.w - m1 - xh.w * m2));
+    out = f4add(out, d1);
+    if (extra) out = f4add(out, e);
+    *reinterpret_cast<float4*>(dx + wo + (size_t)row * C + cq) = out;
+    dgam = f4add(dgam, f4mul(dh, xh));
+    dbet = f4add(dbet, dh);
+  };
+
+  float4 rx[NR], rd[NR], re[NR];
+#pragma unroll
+  for (int u = 0; u < NR; ++u) rx[u] = rd[u] = re[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = threadIdx.x; i < 2 * N; i += blockDim.x) smQ[i] = 0u;
+  __syncthreads();
+  {
+    const int win0 = blockIdx.x;
+    if (win0 < B) {
+#pragma unroll
+      for (int u = 0; u < NR; ++u) {
+        const size_t o = row_off(win0, u);
+        rx[u] = ld4(x, o); rd[u] = ld4(dx1, o); re[u] = ld4(ex, o);
+      }
+      float4 q[NQ];
+#pragma unroll
+      for (int u = 0; u < NQ; ++u) q[u] = ld_dq(win0, u);
+#pragma unroll
+      for (int u = 0; u < NQ; ++u) max_dq(smQ, u, q[u]);
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < NQ; ++u) st_dq(smQ, u, q[u]);
+    }
+    __syncthreads();
+  }
+  int par = 0;
+  for (int win = blockIdx.x; win < B; win += gridDim.x, par ^= 1) {
+    const size_t wo = (size_t)win * N * C;
+    const unsigned* smc = smQ + par * N;
+    unsigned* smn = smQ + (par ^ 1) * N;
+    if ((int)threadIdx.x < N) smn[threadIdx.x] = 0u;   // (last read by the previous window's product)
+    // dh[t][c] = sum_m dqkv[t][m] Wqkv[m][c]
+    gemm_phase_h2<3 * C>(wq, 3 * C / 32, 0, 0, C, nullptr, Qh, qplane, LDQ, N >> 4, [&](int row0, int tok, f32x4 a) {
+      *reinterpret_cast<float4*>(Dh + tok * LD + row0) = f4scale(tofloat4(a), h2_row_unscale(smc[tok]));
+    });
+    __syncthreads();   // Dh complete, Qh free
+    const int nxt = win + gridDim.x;
+    const bool more = nxt < B;
+    const int pw = more ? nxt : win;   // (past the end: a harmless re-read, no branch around the loads)
+    float4 q[NQ], nx[NR], nd[NR], ne[NR];
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) q[u] = ld_dq(pw, u);
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+      const size_t o = row_off(pw, u);
+      nx[u] = ld4(x, o); nd[u] = ld4(dx1, o); ne[u] = ld4(ex, o);
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+      const int row = rbase + u * RPP;
+      if (row < N) ln_row(wo, row, rx[u], pe4[u], rd[u], re[u]);
+    }
+    for (int row = rbase + NR * RPP; row < N; row += RPP) {
+      const size_t o = wo + (size_t)row * C + cq;
+      ln_row(wo, row, *reinterpret_cast<const float4*>(x + o), *reinterpret_cast<const float4*>(pe + row * C + cq),
+             *reinterpret_cast<const float4*>(dx1 + o), *reinterpret_cast<const float4*>(ex + o));
+    }
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < NQ; ++u) max_dq(smn, u, q[u]);
+    }
+    __syncthreads();
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < NQ; ++u) st_dq(smn, u, q[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < NR; ++u) { rx[u] = nx[u]; rd[u] = nd[u]; re[u] = ne[u]; }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) red[i] = 0.f;
+  __syncthreads();
+  lds_add4(red, cq, dgam);
+  lds_add4(red, C + cq, dbet);
+  __syncthreads();
+  if ((int)threadIdx.x < C) {
+    atomicAdd(gr.ln1w + threadIdx.x, red[threadIdx.x]);
+    atomicAdd(gr.ln1b + threadIdx.x, red[C + threadIdx.x]);
+  }
+}
+
+// =================================================================================
 // PatchMerging / PatchSeparate backward: dh = dy W;  dx = LNbwd(dh) scattered back to
 // the input layout;  grads: LN w/b.  (dW of the reduction is a ral_dw.hip product.)
 // =================================================================================
@@ -1712,11 +1872,23 @@ void launch_attn_bwd(const float* qkv, const float* o_hm, const float* do_hm, co
 
 size_t qkv_bwd_lds(int C, int N) { return ((size_t)N * 3 * C + (size_t)N * ld_of(C) + 5 * C + 8) * sizeof(float); }
 
+bool qkv_bwd_uses_f16(int C, int N) {
+  static const bool on = !(getenv("RAL_QKVB_F16") && atoi(getenv("RAL_QKVB_F16")) == 0);
+  return on && (C == 64 || C == 128) && N % 32 == 0 && N * 3 * C / 4 <= 6 * 512;
+}
 void launch_qkv_bwd(int C, const float* dqkv, const float* x, const float* pe, const float* dx1, const float* extra,
-                    const BlockP& w, const BlockP& wt, const BlockP& gr, float* dx, int N, int B, hipStream_t s) {
-  const size_t lds = qkv_bwd_lds(C, N);
+                    const BlockP& w, const BlockP& wt, const float* ptbase, const void* wtt, const BlockP& gr, float* dx, int N, int B,
+                    hipStream_t s) {
   static const int gq = env_grid("RAL_GRID_QKVB", 192);
   const int grid = cap(B, gq);
+  if (wtt && qkv_bwd_uses_f16(C, N)) {
+    const size_t ldsh = (size_t)2 * N * ldb_of(3 * C) * 2 + ((size_t)N * ld_of(C) + 2 * C + 2 * N) * 4;
+    const _Float16* wp = reinterpret_cast<const _Float16*>(wtt);
+    if (C == 64) { RAL_SET_LDS((k_qkv_bwd_h<64>), ldsh); k_qkv_bwd_h<64><<<grid, 512, ldsh, s>>>(dqkv, x, pe, dx1, extra, w, wt, ptbase, wp, gr, dx, N, B); }
+    else { RAL_SET_LDS((k_qkv_bwd_h<128>), ldsh); k_qkv_bwd_h<128><<<grid, 512, ldsh, s>>>(dqkv, x, pe, dx1, extra, w, wt, ptbase, wp, gr, dx, N, B); }
+    return;
+  }
+  const size_t lds = qkv_bwd_lds(C, N);
   switch (C) {
 #define CASE(c) case c: RAL_SET_LDS((k_qkv_bwd<c>), lds); \
     k_qkv_bwd<c><<<grid, 512, lds, s>>>(dqkv, x, pe, dx1, extra, w, wt, gr, dx, N, B); break;

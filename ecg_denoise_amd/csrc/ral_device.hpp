@@ -182,7 +182,9 @@ RAL_DEV float h2_row_unscale(unsigned maxbits) {
 // through the vector L1, not for the matrix cores: with chunk 0's fragments re-used for every chunk fc2 at C = 128 ran
 // 4.2 x faster, without the MFMAs it did not change.)  KT = k-tiles per tile row of the matrix.
 RAL_DEV const _Float16* wtile(const _Float16* Wt, int KT, int mt, int kt, int p) {
-  return Wt + ((size_t)(mt * KT + kt) * 2 + p) * 512 + (threadIdx.x & 63) * 8;
+  // the tile is the same for the whole wave: saying so keeps its address in scalar registers (one shared lane offset)
+  const int tile = __builtin_amdgcn_readfirstlane((mt * KT + kt) * 2 + p);
+  return Wt + (size_t)tile * 512 + (threadIdx.x & 63) * 8;
 }
 // acc[mi][tt] += W1 X1, accx[mi][tt] += W1 X2 + W2 X1 for an MT x TT register block over k-tiles kt0 .. kt0 + K / 32 of the
 // tiled matrix Wt, m-tiles mt0 ..; Xh[p]: LDS rows of ldx elements, plane stride xplane.
@@ -206,15 +208,24 @@ RAL_DEV void h2_mma(const f16x8 (&a)[MT][2], const _Float16* xr, int xplane, int
       accx[mi][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mi][0], b2[tt], accx[mi][tt], 0, 0, 0);
     }
 }
-template <int K, int MT, int TT>
+struct NoHook { RAL_DEV void operator()() const {} };
+constexpr int h2_group(int kc, int gmax) {   // largest divisor of kc that is <= gmax
+  int g = kc < gmax ? kc : gmax;
+  while (kc % g) --g;
+  return g;
+}
+// hook(): called once, after the first weight fragments of the unit are requested and before anything waits for them -
+// the place to request global data of a LATER phase (loads return in order: requested earlier, they would be waited for
+// together with the fragments)
+template <int K, int MT, int TT, class Hook = NoHook, int GMAX_ = 0>
 RAL_DEV void gemm_wx_h2(const _Float16* __restrict__ Wt, int KT, int mt0, int kt0, const _Float16* Xh, int xplane, int ldx,
-                        int t0, f32x4 (&acc)[MT][TT], f32x4 (&accx)[MT][TT]) {
+                        int t0, f32x4 (&acc)[MT][TT], f32x4 (&accx)[MT][TT], Hook hook = Hook()) {
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
   constexpr int KC = K / 32;
   const _Float16* xr = Xh + (t0 + r) * ldx + 8 * g;
   if constexpr (MT == 1) {
-    constexpr int GS = KC < 8 ? KC : 8;
-    static_assert(KC % GS == 0, "chunk groups");
+    // (with a hook the caller keeps prefetched data in registers meanwhile: four chunks at a time then)
+    constexpr int GMAX = GMAX_ ? GMAX_ : (std::is_same<Hook, NoHook>::value ? 8 : 4), GS = h2_group(KC, GMAX);
 #pragma unroll 1
     for (int k0 = 0; k0 < KC; k0 += GS) {
       f16x8 a[GS][1][2];
@@ -228,6 +239,7 @@ RAL_DEV void gemm_wx_h2(const _Float16* __restrict__ Wt, int KT, int mt0, int kt
           a[j][0][p] = *reinterpret_cast<const f16x8*>(wtile(Wt, KT, mt0, kt0 + k0 + j, p));
 #endif
         }
+      if (k0 == 0) hook();
 #pragma unroll
       for (int j = 0; j < GS; ++j) h2_mma<1, TT>(a[j], xr + (k0 + j) * 32, xplane, ldx, acc, accx);
     }
@@ -237,6 +249,7 @@ RAL_DEV void gemm_wx_h2(const _Float16* __restrict__ Wt, int KT, int mt0, int kt
     for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
       for (int p = 0; p < 2; ++p) an[mi][p] = *reinterpret_cast<const f16x8*>(wtile(Wt, KT, mt0 + mi, kt0, p));
+    hook();
 #pragma unroll 1
     for (int kc = 0; kc < KC; ++kc) {
 #pragma unroll
@@ -260,9 +273,9 @@ RAL_DEV void gemm_wx_h2(const _Float16* __restrict__ Wt, int KT, int mt0, int kt
 // One GEMM phase of a workgroup on split operands: out(M rows x ntiles * 16 tokens) = W x X^T (+ bias; row 0 of the output
 // = row 16 mt0 of W, bias[0] its bias), work units of MT x 2 tiles dealt round-robin to the waves; M % (16 MT) == 0, ntiles even.  The bias rows of a unit are requested
 // before its products.  epi(row0, tok, v) as in gemm_phase.
-template <int K, int MT, class Epi>
+template <int K, int MT, int GMAX, class Epi, class Hook>
 RAL_DEV void gemm_phase_h2_t(const _Float16* __restrict__ Wt, int KT, int mt0, int kt0, int M, const float* __restrict__ bias,
-                             const _Float16* Xh, int xplane, int ldx, int ntiles, Epi& epi) {
+                             const _Float16* Xh, int xplane, int ldx, int ntiles, Epi& epi, Hook& hook) {
   constexpr int TT = 2;
   const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
@@ -278,7 +291,11 @@ RAL_DEV void gemm_phase_h2_t(const _Float16* __restrict__ Wt, int KT, int mt0, i
     for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) { acc[mi][tt] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[mi][tt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    gemm_wx_h2<K, MT, TT>(Wt, KT, mt0 + m * MT, kt0, Xh, xplane, ldx, t * TT * 16, acc, accx);
+    if constexpr (std::is_same<Hook, NoHook>::value) gemm_wx_h2<K, MT, TT, NoHook, GMAX>(Wt, KT, mt0 + m * MT, kt0, Xh, xplane, ldx, t * TT * 16, acc, accx);
+    else {
+      auto h1 = [&]() { if (u == wave) hook(); };
+      gemm_wx_h2<K, MT, TT, decltype(h1), GMAX>(Wt, KT, mt0 + m * MT, kt0, Xh, xplane, ldx, t * TT * 16, acc, accx, h1);
+    }
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
@@ -288,15 +305,18 @@ RAL_DEV void gemm_phase_h2_t(const _Float16* __restrict__ Wt, int KT, int mt0, i
         epi((m * MT + mi) * 16 + 4 * g, (t * TT + tt) * 16 + r, v);
       }
   }
+  if (wave >= mb * tb) hook();   // a wave without a unit still issues its share
 }
 // the larger block when it still gives every wave a unit
 // (Wt, KT): tiled planes of the matrix; the product uses its rows 16 mt0 .. + M and columns 32 kt0 .. + K
-template <int K, class Epi>
+// hook: see gemm_wx_h2; runs exactly once in every wave (inside its first unit)
+// GMAX: chunks of weight fragments requested together by a one-row-tile unit (0: eight, four with a hook)
+template <int K, int GMAX = 0, class Epi, class Hook = NoHook>
 RAL_DEV void gemm_phase_h2(const _Float16* __restrict__ Wt, int KT, int mt0, int kt0, int M, const float* __restrict__ bias,
-                           const _Float16* Xh, int xplane, int ldx, int ntiles, Epi epi) {
+                           const _Float16* Xh, int xplane, int ldx, int ntiles, Epi epi, Hook hook = Hook()) {
   const int nw = blockDim.x >> 6;
-  if (M % 32 == 0 && (M / 32) * (ntiles / 2) >= nw) gemm_phase_h2_t<K, 2>(Wt, KT, mt0, kt0, M, bias, Xh, xplane, ldx, ntiles, epi);
-  else gemm_phase_h2_t<K, 1>(Wt, KT, mt0, kt0, M, bias, Xh, xplane, ldx, ntiles, epi);
+  if (M % 32 == 0 && (M / 32) * (ntiles / 2) >= nw) gemm_phase_h2_t<K, 2, GMAX>(Wt, KT, mt0, kt0, M, bias, Xh, xplane, ldx, ntiles, epi, hook);
+  else gemm_phase_h2_t<K, 1, GMAX>(Wt, KT, mt0, kt0, M, bias, Xh, xplane, ldx, ntiles, epi, hook);
 }
 
 // row stride (floats) of a token-major LDS tile of width C: +4 breaks the power-of-two stride for the

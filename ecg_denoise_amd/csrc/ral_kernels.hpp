@@ -78,7 +78,8 @@ void launch_attn_bwd(const float* qkv, const float* o_hm, const float* do_hm, co
                      float* gtable, float* dqkv, float* stat2, int N, int H, int HG, int Len, int B, hipStream_t s);
 size_t qkv_bwd_lds(int C, int N);
 void launch_qkv_bwd(int C, const float* dqkv, const float* x, const float* pe, const float* dx1, const float* extra,
-                    const BlockP& w, const BlockP& wt, const BlockP& gr, float* dx, int N, int B, hipStream_t s);
+                    const BlockP& w, const BlockP& wt, const float* ptbase, const void* wtt /* as launch_mlp_bwd */, const BlockP& gr,
+                    float* dx, int N, int B, hipStream_t s);
 void launch_resample_bwd(int D, bool sep, const float* dy, const float* x, const float* wred, const float* lnw,
                          float* g_lnw, float* g_lnb, float* dx, int T, int B, hipStream_t s);
 void launch_final_bwd(int leads, const float* dy, const float* u0, const float* x0, const float* w, float* gw,
