@@ -42,8 +42,8 @@ python3 tools/diag/unet_timeline.py $O/unet_train_ks 20 > $O/unet_train_timeline
 # early gradient bucket's reduction start before the backward pass has ended?
 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $O/dp2_trace -- python3 bench.py --gpus 2 --steps 4 --warmup 2 --batch 1024 --no-cpu --no-infer --test-backend gloo --test-share-gpu > $O/dp2_trace.log 2>&1
 python3 tools/diag/dp_overlap.py $O/dp2_trace > $O/dp2_overlap.txt 2>&1
-# the CPU baseline at the bench batch (SURVEY 8d ii)
-python3 tools/cpu_baseline_big.py 2048 8 32 64 > $O/cpu_baseline_b2048.json 2> $O/cpu_baseline_b2048.err
+# the CPU baseline at the bench batch (SURVEY 8d ii; ~6 minutes of host time: SKIP_CPU_BIG=1 leaves it out of a re-collection)
+[ -z "$SKIP_CPU_BIG" ] && python3 tools/cpu_baseline_big.py 2048 8 32 64 > $O/cpu_baseline_b2048.json 2> $O/cpu_baseline_b2048.err
 # keep only the csv summaries (the merged directory is capped at 64 MiB)
 find $O -name "*agent_info.csv" -delete
 du -sh $O
