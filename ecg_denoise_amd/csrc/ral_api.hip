@@ -260,6 +260,7 @@ struct RalModel {
                                             // offset), re-written every forward from the descriptors below
   int* wdesc = nullptr;                     // device: int4 {offset, rows, columns, first work item} per matrix
   int ndesc = 0, nwork = 0;
+  unsigned* gmax = nullptr;                 // (18 blocks x 4 lanes x 4) largest-magnitude bits of dx2 / du / dx1 / dqkv per block and lane: scales of the split weight-gradient products; zeroed per backward
   unsigned short* whT = nullptr;            // the same for the transposed matrices of the backward (from paramsT), training only
   int* wdescT = nullptr;
   int ndescT = 0, nworkT = 0;
@@ -360,6 +361,7 @@ static size_t plan_workspace(const ral_config& c, RalModel* m /* may be null: si
     M.paramsT = take("paramsT", (size_t)L_.nparam);
     M.whT = reinterpret_cast<unsigned short*>(take("whT", (size_t)L_.nparam));
     M.wdescT = reinterpret_cast<int*>(take("wdescT", 4 * 64));
+    M.gmax = reinterpret_cast<unsigned*>(take("gmax", 18 * 4 * 4));
     M.tdesc = take("tdesc", 4 * 128);
   }
   return cur;
@@ -595,20 +597,26 @@ static void run_block_bwd(RalModel* m, int bi, const float* dy, const float* ext
   const float *x1 = woff(a.x1, w0, E1), *upre = woff(a.upre, w0, 4 * E1), *qkv = woff(a.qkv, w0, 3 * E1),
               *o = woff(a.o, w0, E1), *lse = woff(a.lse, w0, E1 / 4), *xin = woff(a.in, w0, E1);
   bool fused_mlp_dw;
-  { ProfScope p(m, K_MLP_BWD, s); fused_mlp_dw = launch_mlp_bwd(C, m->nch_b[l], dyw, x1, upre, w, wt, m->paramsT, (m->f16_split > 0 && C >= m->f16_split) ? m->whT : nullptr, g, dupre, dx1, dohm, a2c0, N, B, m->want_dw, s); }
+  const bool splitb = m->f16_split > 0 && C >= m->f16_split;
+  // maxima of this block's gradient tensors (this lane's windows), for the split weight-gradient products: only when both
+  // split data-gradient kernels take the shape (they publish them)
+  unsigned* gmax = (splitb && m->want_dw && mlp_bwd_h_nch(C, N) && qkv_bwd_uses_f16(C, N)) ? m->gmax + ((size_t)bi * 4 + (&ln - lanes_of(m)->l)) * 4 : nullptr;
+  { ProfScope p(m, K_MLP_BWD, s); fused_mlp_dw = launch_mlp_bwd(C, m->nch_b[l], dyw, x1, upre, w, wt, m->paramsT, splitb ? m->whT : nullptr, gmax, g, dupre, dx1, dohm, a2c0, N, B, m->want_dw, s); }
   { ProfScope p(m, K_ATTN_BWD, s);
     // (each lane's scratch: its share of the stat2 region followed by its share of the partials region)
     float* scratch = m->astat[k] + (size_t)w0 * (E1 / 2 + 2048);
     launch_attn_bwd(qkv, o, dohm, lse, table, gtable, dqkv, scratch, N, H, m->hg_b[l], Len, B, s); }
   { ProfScope p(m, K_QKV_BWD, s);
-    launch_qkv_bwd(C, dqkv, xin, m->pe[l], dx1, woff(extra, w0, E1), w, wt, m->paramsT, (m->f16_split > 0 && C >= m->f16_split) ? m->whT : nullptr, g, woff(dx, w0, E1), N, B, s); }
+    launch_qkv_bwd(C, dqkv, xin, m->pe[l], dx1, woff(extra, w0, E1), w, wt, m->paramsT, splitb ? m->whT : nullptr, gmax, g, woff(dx, w0, E1), N, B, s); }
   if (!m->want_dw) return;
   if (side) {
     EV(hipEventRecord(ln.ev_ready[k], s));
     EV(hipStreamWaitEvent(sd, ln.ev_ready[k], 0));
   }
   { ProfScope p(m, K_DW, sd);
-    launch_block_dw(C, dyw, upre, w.le ? a2c0 : nullptr, dupre, x1, dx1, o, dqkv, xin, m->pe[l], w, g, N, B, m->dw_ksplit[l], fused_mlp_dw, sd); }
+    static const int skipw = getenv("RAL_DIAG_SKIP_WIDE_DW") ? atoi(getenv("RAL_DIAG_SKIP_WIDE_DW")) : 0;   // diagnostic (wrong gradients): what the wide levels' weight-gradient kernels cost the step
+    if (!(skipw && C >= skipw))
+    launch_block_dw(C, dyw, upre, w.le ? a2c0 : nullptr, dupre, x1, dx1, o, dqkv, xin, m->pe[l], w, g, N, B, m->dw_ksplit[l], fused_mlp_dw, gmax, sd); }
   if (side) { EV(hipEventRecord(ln.ev_done[k], sd)); ln.dw_pending[k] = true; }
 }
 
@@ -648,6 +656,7 @@ static int bwd_begin(RalModel* m, const float* dy, int B, hipStream_t s) {
   HIP_OK(hipMemsetAsync(m->bn_sums + 32, 0, 32 * sizeof(double), s));
   launch_transpose_mats(m->params, m->paramsT, m->tdesc, m->tn, m->ttotal, s);
   if (m->f16_split > 0) launch_tile_planes(m->paramsT, m->whT, m->wdescT, m->ndescT, m->nworkT, s);
+  HIP_OK(hipMemsetAsync(m->gmax, 0, 18 * 4 * 4 * sizeof(unsigned), s));
   float** gy = m->gy; float** gin = m->gin;
   const int nl = plan_lanes(m, B, s);
   LaneSet* LS = lanes_of(m);

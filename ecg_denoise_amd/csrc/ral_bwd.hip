@@ -189,7 +189,8 @@ __global__ __launch_bounds__(512, 4) void k_mlp_bwd_h(const float* __restrict__ 
                                                       const float* __restrict__ upre, BlockP w, BlockP wt, const float* __restrict__ ptbase,
                                                       const _Float16* __restrict__ wtt, BlockP gr,
                                                       float* __restrict__ dupre, float* __restrict__ dx1,
-                                                      float* __restrict__ do_hm, float* __restrict__ a2c0, int N, int B) {
+                                                      float* __restrict__ do_hm, float* __restrict__ a2c0,
+                                                      unsigned* __restrict__ gmax, int N, int B) {
   extern __shared__ float4 smem4[];
   constexpr int LD = LDof<C>::v, HC = 4 * C / NCH, LDUF = LDof<HC>::v, LDG = ldb_of(C), LDU = ldb_of(HC), LPR = C / 4, RPP = 512 / LPR;
   typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -222,11 +223,15 @@ __global__ __launch_bounds__(512, 4) void k_mlp_bwd_h(const float* __restrict__ 
     *reinterpret_cast<f16x4*>(base + off) = f16x4{s0.a, s1.a, s2.a, s3.a};
     *reinterpret_cast<f16x4*>(base + plane + off) = f16x4{s0.b, s1.b, s2.b, s3.b};
   };
-  auto put_row = [&](int row, float4 v) {   // a gradient row held by LPR lanes -> scaled split planes of Dh + its maximum
+  // largest magnitudes this thread has seen of dx2, du and dx1: the weight-gradient kernels scale those operands by ONE
+  // power of two per launch (their contraction runs over tokens) and read it from gmax[0..2]
+  float tmx2 = 0.f, tmxu = 0.f, tmx1 = 0.f;
+  auto put_row = [&](int row, float4 v, float& tmx) {   // a gradient row held by LPR lanes -> scaled split planes of Dh + its maximum
     const float mx = group_max<LPR>(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
     const unsigned mb = __float_as_uint(mx);
     put_split(Dh, dplane, row * LDG + cq, f4scale(v, h2_row_scale(mb)));
     if (cq == 0) smD[row] = mb;
+    tmx = fmaxf(tmx, mx);
   };
   const int mb_ = HC / 32, um = wave % mb_, ut = wave / mb_;   // the wave's unit of the fc2^T phase
   for (int win = blockIdx.x; win < B; win += gridDim.x) {
@@ -235,8 +240,8 @@ __global__ __launch_bounds__(512, 4) void k_mlp_bwd_h(const float* __restrict__ 
       const int rowb = row0 + RPP < N ? row0 + RPP : row0;
       const float4 va = *reinterpret_cast<const float4*>(dx2 + wo + (size_t)row0 * C + cq);
       const float4 vb = *reinterpret_cast<const float4*>(dx2 + wo + (size_t)rowb * C + cq);
-      put_row(row0, va);
-      if (row0 + RPP < N) put_row(rowb, vb);
+      put_row(row0, va, tmx2);
+      if (row0 + RPP < N) put_row(rowb, vb, tmx2);
     }
     if ((int)threadIdx.x < N) smU[threadIdx.x] = 0u;
 #pragma unroll 1
@@ -298,6 +303,7 @@ __global__ __launch_bounds__(512, 4) void k_mlp_bwd_h(const float* __restrict__ 
             }
           }
           mx = rows_max(mx);
+          tmxu = fmaxf(tmxu, mx);
           if (g == 0) atomicMax(smU + tok, __float_as_uint(mx));
         }
       }
@@ -307,6 +313,7 @@ __global__ __launch_bounds__(512, 4) void k_mlp_bwd_h(const float* __restrict__ 
           const float da1 = lw0 * DC0[n + 2] + lw1 * DC0[n + 1] + lw2 * DC0[n];
           const float v = da1 * gelu_grad_f(U0[n]);
           DU0[n] = v;
+          tmxu = fmaxf(tmxu, fabsf(v));
           atomicMax(smU + n, __float_as_uint(fabsf(v)));
           const float dc = DC0[n + 1];
           gle0 += dc * A0[n]; gle1 += dc * A0[n + 1]; gle2 += dc * A0[n + 2];
@@ -353,7 +360,7 @@ __global__ __launch_bounds__(512, 4) void k_mlp_bwd_h(const float* __restrict__ 
       const float4 dx = f4add(d2, make_float4(rstd * (dyh.x - m1 - xh.x * m2), rstd * (dyh.y - m1 - xh.y * m2),
                                               rstd * (dyh.z - m1 - xh.z * m2), rstd * (dyh.w - m1 - xh.w * m2)));
       *reinterpret_cast<float4*>(dx1 + wo + (size_t)row * C + cq) = dx;
-      put_row(row, dx);
+      put_row(row, dx, tmx1);
       dgam = f4add(dgam, f4mul(dg, xh));
       dbet = f4add(dbet, dg);
     }
@@ -380,6 +387,15 @@ __global__ __launch_bounds__(512, 4) void k_mlp_bwd_h(const float* __restrict__ 
     atomicAdd(gr.ln2b + threadIdx.x, red[C + threadIdx.x]);
   }
   if (le && threadIdx.x < 3) atomicAdd(gr.le + threadIdx.x, red[2 * C + threadIdx.x]);
+  if (gmax) {   // one atomic per workgroup and tensor
+    __syncthreads();
+    if (threadIdx.x < 3) smD[threadIdx.x] = 0u;
+    __syncthreads();
+    const float m2 = group_max<64>(tmx2), mu = group_max<64>(tmxu), m1 = group_max<64>(tmx1);
+    if ((threadIdx.x & 63) == 0) { atomicMax(smD, __float_as_uint(m2)); atomicMax(smD + 1, __float_as_uint(mu)); atomicMax(smD + 2, __float_as_uint(m1)); }
+    __syncthreads();
+    if (threadIdx.x < 3) atomicMax(gmax + threadIdx.x, smD[threadIdx.x]);
+  }
 }
 
 // =================================================================================
@@ -1247,7 +1263,7 @@ __global__ __launch_bounds__(512, RAL_QKVB_MINB) void k_qkv_bwd_h(const float* d
                                                  const float* __restrict__ pe, const float* dx1,
                                                  const float* extra, BlockP w, BlockP wt, const float* __restrict__ ptbase,
                                                  const _Float16* __restrict__ wtt, BlockP gr,
-                                                 float* __restrict__ dx, int N, int B) {
+                                                 float* __restrict__ dx, unsigned* __restrict__ gmax, int N, int B) {
   extern __shared__ float4 smem4[];
   constexpr int LD = LDof<C>::v, LPR = C / 4, LDQ = ldb_of(3 * C);
   typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -1273,9 +1289,14 @@ __global__ __launch_bounds__(512, RAL_QKVB_MINB) void k_qkv_bwd_h(const float* d
   auto ld_dq = [&](int win, int u) -> float4 {
     return reinterpret_cast<const float4*>(dqkv + (size_t)win * N * 3 * C)[min((int)threadIdx.x + u * (int)blockDim.x, n4 - 1)];
   };
+  float tmxq = 0.f;   // largest |dqkv| this thread has seen: gmax[3], for the weight-gradient kernel (see k_mlp_bwd_h)
   auto max_dq = [&](unsigned* sm, int u, float4 v) {   // flat float4 i = (channel quad, token)
     const int i = threadIdx.x + u * blockDim.x;
-    if (i < n4) atomicMax(sm + i % N, __float_as_uint(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)))));
+    if (i < n4) {
+      const float mx = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+      tmxq = fmaxf(tmxq, mx);
+      atomicMax(sm + i % N, __float_as_uint(mx));
+    }
   };
   auto st_dq = [&](const unsigned* sm, int u, float4 v) {
     const int i = threadIdx.x + u * blockDim.x;
@@ -1389,6 +1410,15 @@ __global__ __launch_bounds__(512, RAL_QKVB_MINB) void k_qkv_bwd_h(const float* d
   if ((int)threadIdx.x < C) {
     atomicAdd(gr.ln1w + threadIdx.x, red[threadIdx.x]);
     atomicAdd(gr.ln1b + threadIdx.x, red[C + threadIdx.x]);
+  }
+  if (gmax) {
+    __syncthreads();
+    if (threadIdx.x == 0) smQ[0] = 0u;
+    __syncthreads();
+    const float mq = group_max<64>(tmxq);
+    if ((threadIdx.x & 63) == 0) atomicMax(smQ, __float_as_uint(mq));
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(gmax + 3, smQ[0]);
   }
 }
 
@@ -1755,14 +1785,14 @@ int mlp_bwd_h_nch(int C, int N) {
 template <int C>
 static void launch_mlp_bwd_hc(int nch, const float* dx2, const float* x1, const float* upre, const BlockP& w, const BlockP& wt,
                               const float* ptbase, const void* wtt, const BlockP& gr, float* dupre, float* dx1, float* do_hm,
-                              float* a2c0, int N, int B, hipStream_t s) {
+                              float* a2c0, unsigned* gmax, int N, int B, hipStream_t s) {
   const size_t lds = mlp_bwd_h_lds(C, N, nch);
   static const int gm = env_grid("RAL_GRID_MLPB", 512);
   const int grid = cap(B, gm);
   const _Float16* wp = reinterpret_cast<const _Float16*>(wtt);
-  if (nch == 1) { RAL_SET_LDS((k_mlp_bwd_h<C, 1>), lds); k_mlp_bwd_h<C, 1><<<grid, 512, lds, s>>>(dx2, x1, upre, w, wt, ptbase, wp, gr, dupre, dx1, do_hm, a2c0, N, B); }
-  else if (nch == 2) { RAL_SET_LDS((k_mlp_bwd_h<C, 2>), lds); k_mlp_bwd_h<C, 2><<<grid, 512, lds, s>>>(dx2, x1, upre, w, wt, ptbase, wp, gr, dupre, dx1, do_hm, a2c0, N, B); }
-  else { RAL_SET_LDS((k_mlp_bwd_h<C, 4>), lds); k_mlp_bwd_h<C, 4><<<grid, 512, lds, s>>>(dx2, x1, upre, w, wt, ptbase, wp, gr, dupre, dx1, do_hm, a2c0, N, B); }
+  if (nch == 1) { RAL_SET_LDS((k_mlp_bwd_h<C, 1>), lds); k_mlp_bwd_h<C, 1><<<grid, 512, lds, s>>>(dx2, x1, upre, w, wt, ptbase, wp, gr, dupre, dx1, do_hm, a2c0, gmax, N, B); }
+  else if (nch == 2) { RAL_SET_LDS((k_mlp_bwd_h<C, 2>), lds); k_mlp_bwd_h<C, 2><<<grid, 512, lds, s>>>(dx2, x1, upre, w, wt, ptbase, wp, gr, dupre, dx1, do_hm, a2c0, gmax, N, B); }
+  else { RAL_SET_LDS((k_mlp_bwd_h<C, 4>), lds); k_mlp_bwd_h<C, 4><<<grid, 512, lds, s>>>(dx2, x1, upre, w, wt, ptbase, wp, gr, dupre, dx1, do_hm, a2c0, gmax, N, B); }
 }
 
 template <int C>
@@ -1784,13 +1814,13 @@ static bool launch_mlp_bwd_c(int nch, const float* dx2, const float* x1, const f
 // returns true when the fc1 / fc2 weight (and bias) gradients were produced here (narrow levels): the caller then
 // skips those two products in launch_block_dw
 bool launch_mlp_bwd(int C, int nch, const float* dx2, const float* x1, const float* upre, const BlockP& w,
-                    const BlockP& wt, const float* ptbase, const void* wtt, const BlockP& gr, float* dupre, float* dx1, float* do_hm,
+                    const BlockP& wt, const float* ptbase, const void* wtt, unsigned* gmax, const BlockP& gr, float* dupre, float* dx1, float* do_hm,
                     float* a2c0, int N, int B, bool want_dw, hipStream_t s) {
   if (!want_dw) { dupre = nullptr; a2c0 = nullptr; }   // consumed by the weight-gradient kernels only
   if (wtt) {
     const int nh = mlp_bwd_h_nch(C, N);
-    if (nh && C == 64) { launch_mlp_bwd_hc<64>(nh, dx2, x1, upre, w, wt, ptbase, wtt, gr, dupre, dx1, do_hm, a2c0, N, B, s); return false; }
-    if (nh && C == 128) { launch_mlp_bwd_hc<128>(nh, dx2, x1, upre, w, wt, ptbase, wtt, gr, dupre, dx1, do_hm, a2c0, N, B, s); return false; }
+    if (nh && C == 64) { launch_mlp_bwd_hc<64>(nh, dx2, x1, upre, w, wt, ptbase, wtt, gr, dupre, dx1, do_hm, a2c0, want_dw ? gmax : nullptr, N, B, s); return false; }
+    if (nh && C == 128) { launch_mlp_bwd_hc<128>(nh, dx2, x1, upre, w, wt, ptbase, wtt, gr, dupre, dx1, do_hm, a2c0, want_dw ? gmax : nullptr, N, B, s); return false; }
   }
   switch (C) {
 #define CASE(c) case c: return launch_mlp_bwd_c<c>(nch, dx2, x1, upre, w, wt, gr, dupre, dx1, do_hm, a2c0, N, B, want_dw, s);
@@ -1877,15 +1907,15 @@ bool qkv_bwd_uses_f16(int C, int N) {
   return on && (C == 64 || C == 128) && N % 32 == 0 && N * 3 * C / 4 <= 6 * 512;
 }
 void launch_qkv_bwd(int C, const float* dqkv, const float* x, const float* pe, const float* dx1, const float* extra,
-                    const BlockP& w, const BlockP& wt, const float* ptbase, const void* wtt, const BlockP& gr, float* dx, int N, int B,
+                    const BlockP& w, const BlockP& wt, const float* ptbase, const void* wtt, unsigned* gmax, const BlockP& gr, float* dx, int N, int B,
                     hipStream_t s) {
   static const int gq = env_grid("RAL_GRID_QKVB", 192);
   const int grid = cap(B, gq);
   if (wtt && qkv_bwd_uses_f16(C, N)) {
     const size_t ldsh = (size_t)2 * N * ldb_of(3 * C) * 2 + ((size_t)N * ld_of(C) + 2 * C + 2 * N) * 4;
     const _Float16* wp = reinterpret_cast<const _Float16*>(wtt);
-    if (C == 64) { RAL_SET_LDS((k_qkv_bwd_h<64>), ldsh); k_qkv_bwd_h<64><<<grid, 512, ldsh, s>>>(dqkv, x, pe, dx1, extra, w, wt, ptbase, wp, gr, dx, N, B); }
-    else { RAL_SET_LDS((k_qkv_bwd_h<128>), ldsh); k_qkv_bwd_h<128><<<grid, 512, ldsh, s>>>(dqkv, x, pe, dx1, extra, w, wt, ptbase, wp, gr, dx, N, B); }
+    if (C == 64) { RAL_SET_LDS((k_qkv_bwd_h<64>), ldsh); k_qkv_bwd_h<64><<<grid, 512, ldsh, s>>>(dqkv, x, pe, dx1, extra, w, wt, ptbase, wp, gr, dx, gmax, N, B); }
+    else { RAL_SET_LDS((k_qkv_bwd_h<128>), ldsh); k_qkv_bwd_h<128><<<grid, 512, ldsh, s>>>(dqkv, x, pe, dx1, extra, w, wt, ptbase, wp, gr, dx, gmax, N, B); }
     return;
   }
   const size_t lds = qkv_bwd_lds(C, N);

@@ -162,6 +162,17 @@ RAL_DEV H2 f16_split2(float x) {
   return r;
 }
 #define RAL_H2_SCALE (1.0f / 2048.f)
+// The same split with the residual left as it is (h2 = fp16(x - h1)): for operands that were SCALED into fp16's upper
+// range first (|x| up to ~2^14).  The residual of a large element is a normal number, that of a small one a subnormal
+// with an absolute error of 2^-25 - which v_mfma_f32_16x16x32_f16 multiplies exactly (tools/diag/f16_denorm_probe.hip) -,
+// so x = h1 + h2 to 2^-25 of the operand's scale and all three products go into ONE accumulator.
+RAL_DEV H2 f16_split2u(float x) {
+  x = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
+  H2 r;
+  r.a = (_Float16)x;
+  r.b = (_Float16)(x - (float)r.a);
+  return r;
+}
 // Gradient rows are far below fp16's normal range (a mean-squared-error gradient is ~1e-6), so a row that feeds such a
 // product is multiplied by a power of two first: the scale that puts the row's largest magnitude (bits of |max| as an
 // unsigned) into [2^13, 2^14), capped at 2^60; the product is multiplied by the inverse afterwards (exact).  Entries far

@@ -72,7 +72,13 @@ RAL_DEV void issue_then_store(LD ld, ST st, IN inner) {
   }
 }
 
-template <int M, int NC, int MS, int NS, int LAYY, int XF>
+// H (wide levels, behind the split data-gradient kernels): both operands staged as fp16-pair planes - Y (a gradient) times
+// the power of two that puts the launch's largest |Y| (ymax, published by k_mlp_bwd_h / k_qkv_bwd_h) into [2^13, 2^14), X
+// (LayerNorm / GELU / attention outputs) times 2^8, residuals unscaled (f16_split2u) -, token-major rows; the consumers
+// fetch their fragments with the transposing LDS read (ds_read_b64_tr_b16: per 16 lanes a block of 4 tokens x 16 channels,
+// delivered channel-major - the contraction index of these products is the token) and issue three
+// v_mfma_f32_16x16x32_f16 per 32 tokens and tile into the one accumulator, which is unscaled once, at the flush.
+template <int M, int NC, int MS, int NS, int LAYY, int XF, bool H = false>
 // (Y, X, pe and a2c0 are deliberately NOT __restrict__: loads the compiler can prove invariant are sunk across the
 // compiler barrier of the staging code, next to their stores, which costs one HBM round trip per load)
 #ifndef RAL_DW_WPE
@@ -80,9 +86,14 @@ template <int M, int NC, int MS, int NS, int LAYY, int XF>
 #endif
 __global__ __launch_bounds__(512, RAL_DW_WPE) void k_dw(const float* Y, const float* X, const float* pe,
                                                const float* __restrict__ lnw, const float* __restrict__ lnb,
-                                               const float* a2c0, float* dW, float* dB, int N, int TC, int B) {
+                                               const float* a2c0, float* dW, float* dB, const unsigned* __restrict__ ymax,
+                                               int N, int TC, int B) {
   extern __shared__ float4 smem4[];
   constexpr bool YHM = LAYY == LAY_HM, XHM = XF == XF_HM;
+  constexpr int LDYH = MS + 8, LDXH = NS + 8;   // H: row strides of the token-major planes (2-byte elements)
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  const float ysc = H ? h2_row_scale(ymax[0]) : 1.0f;
+  constexpr float XSC = 256.0f;
   constexpr int TM = (MS + 15) / 16, TN = (NS + 15) / 16;
   constexpr int WM = WaveGrid4<TM, TN>::WM, WN = WaveGrid4<TM, TN>::WN, MI = TM / WM, NI = TN / WN;
   constexpr int NWB = WM * WN, KW = 4 / NWB;      // spare consumer waves split the chunk's tokens (folded at the end)
@@ -93,7 +104,8 @@ __global__ __launch_bounds__(512, RAL_DW_WPE) void k_dw(const float* Y, const fl
   static_assert(TM % WM == 0 && TN % WN == 0 && NWB <= 4, "consumer wave grid must tile the slice");
   static_assert(XHM || XF == XF_A2 || NS == NC, "LayerNorm operand must keep whole rows");
   static_assert(MS % 4 == 0 && NS % 4 == 0, "float4 staging");
-  const int ysz = YHM ? (MS / 4) * (TC + 1) * 4 : TC * LDY, xsz = XHM ? (NS / 4) * (TC + 1) * 4 : TC * LDX;
+  // (H: a tile is two planes of TC x LD 2-byte elements = TC x LD floats)
+  const int ysz = H ? TC * LDYH : (YHM ? (MS / 4) * (TC + 1) * 4 : TC * LDY), xsz = H ? TC * LDXH : (XHM ? (NS / 4) * (TC + 1) * 4 : TC * LDX);
   float* const buf0 = reinterpret_cast<float*>(smem4);
   float* const buf1 = buf0 + ysz + xsz;
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
@@ -140,7 +152,15 @@ __global__ __launch_bounds__(512, RAL_DW_WPE) void k_dw(const float* Y, const fl
     };
     auto store_y = [&](int u, float4 v) {
       const int j = min(tid + u * NPROD, n4y - 1);
-      if constexpr (YHM) {
+      if constexpr (H) {
+        int row, c;
+        if constexpr (YHM) { const int q = j / TC; row = j - q * TC; c = q * 4; }
+        else { row = j / (MS / 4); c = (j - row * (MS / 4)) * 4; }
+        const H2 s0 = f16_split2u(v.x * ysc), s1 = f16_split2u(v.y * ysc), s2 = f16_split2u(v.z * ysc), s3 = f16_split2u(v.w * ysc);
+        _Float16* Yh = reinterpret_cast<_Float16*>(Ys);
+        *reinterpret_cast<f16x4*>(Yh + row * LDYH + c) = f16x4{s0.a, s1.a, s2.a, s3.a};
+        *reinterpret_cast<f16x4*>(Yh + TC * LDYH + row * LDYH + c) = f16x4{s0.b, s1.b, s2.b, s3.b};
+      } else if constexpr (YHM) {
         const int q = j / TC, t = j - q * TC;
         *reinterpret_cast<float4*>(Ys + (q * (TC + 1) + t) * 4) = v;
       } else {
@@ -170,11 +190,18 @@ __global__ __launch_bounds__(512, RAL_DW_WPE) void k_dw(const float* Y, const fl
       }
       return o;
     };
+    auto put_xh = [&](int row, int c, float4 a) {
+      const H2 s0 = f16_split2u(a.x * XSC), s1 = f16_split2u(a.y * XSC), s2 = f16_split2u(a.z * XSC), s3 = f16_split2u(a.w * XSC);
+      _Float16* Xh = reinterpret_cast<_Float16*>(Xs);
+      *reinterpret_cast<f16x4*>(Xh + row * LDXH + c) = f16x4{s0.a, s1.a, s2.a, s3.a};
+      *reinterpret_cast<f16x4*>(Xh + TC * LDXH + row * LDXH + c) = f16x4{s0.b, s1.b, s2.b, s3.b};
+    };
     auto store_x = [&](int u, XLoad o) {
       const int j = (tid + u * NPROD) & (n4x - 1);
       if constexpr (XHM) {
         const int q = j / TC, t = j - q * TC;
-        *reinterpret_cast<float4*>(Xs + (q * (TC + 1) + t) * 4) = o.v;
+        if constexpr (H) put_xh(t, q * 4, o.v);
+        else *reinterpret_cast<float4*>(Xs + (q * (TC + 1) + t) * 4) = o.v;
       } else {
         const int row = j / (NS / 4), c = (j - row * (NS / 4)) * 4;
         float4 a = o.v;
@@ -198,7 +225,8 @@ __global__ __launch_bounds__(512, RAL_DW_WPE) void k_dw(const float* Y, const fl
           ln_stats<LPR>(a, d, rstd);
           a = f4add(f4mul(f4scale(d, rstd), gam), bet);   // (column c is the same for every u: 256 % (NS/4) == 0)
         }
-        *reinterpret_cast<float4*>(Xs + row * LDX + c) = a;
+        if constexpr (H) put_xh(row, c, a);
+        else *reinterpret_cast<float4*>(Xs + row * LDX + c) = a;
       }
     };
     fn(load_y, store_y, load_x, store_x);
@@ -292,6 +320,48 @@ __global__ __launch_bounds__(512, RAL_DW_WPE) void k_dw(const float* Y, const fl
   for (int ci = 0; ci < nci; ++ci) {
     const float* Ys = (ci & 1) ? buf1 : buf0;
     const float* Xs = Ys + ysz;
+    if constexpr (H) {
+      if (kw < KW) {
+        const _Float16* Yh = reinterpret_cast<const _Float16*>(Ys);
+        const _Float16* Xh = reinterpret_cast<const _Float16*>(Xs);
+        const int l16 = lane & 15, tq = l16 >> 2, tp = l16 & 3;   // transposing read: lane 4 q + p of a 16-lane group addresses row q, columns 4 p ..
+        typedef short s16x4 __attribute__((ext_vector_type(4)));
+        typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+        auto frag = [&](const _Float16* base, int ld, int t0, int c0) -> f16x8 {   // tokens t0 + 8 g .. + 7 of channel c0 + (lane & 15)
+          const _Float16* a = base + (t0 + 8 * g + tq) * ld + c0 + 4 * tp;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a + 4 * ld));
+          union { s16x4 s[2]; f16x8 h; } u;
+          u.s[0] = lo; u.s[1] = hi;
+          return u.h;
+        };
+        for (int tb = kw * 32; tb < TC; tb += 32 * KW) {
+          f16x8 a1[MI], a2[MI];
+#pragma unroll
+          for (int i = 0; i < MI; ++i) { a1[i] = frag(Yh, LDYH, tb, m0 + 16 * i); a2[i] = frag(Yh + TC * LDYH, LDYH, tb, m0 + 16 * i); }
+          if (bias) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+              float sm = 0.f;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) sm += (float)a1[i][e] + (float)a2[i][e];
+              bsum[i] += sm;
+            }
+          }
+          // (the X fragments one column tile at a time: all of them at once would cost the second workgroup per CU)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) {
+            const f16x8 b1 = frag(Xh, LDXH, tb, n0 + 16 * j), b2 = frag(Xh + TC * LDXH, LDXH, tb, n0 + 16 * j);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[i], b1, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[i], b2, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[i], b1, acc[i][j], 0, 0, 0);
+            }
+          }
+        }
+      }
+    } else
     if (kw < KW) {
       for (int tb = kw * 16; tb < TC; tb += 16 * KW) {
 #pragma unroll
@@ -327,6 +397,15 @@ __global__ __launch_bounds__(512, RAL_DW_WPE) void k_dw(const float* Y, const fl
 
 #pragma unroll
   for (int i = 0; i < MI; ++i) bsum[i] = rows_sum(bsum[i]);   // over the 4 k-groups: every lane (r, *) holds column r
+  if constexpr (H) {   // out of the operand scales
+    const float uy = h2_row_unscale(ymax[0]), ua = uy * (1.0f / XSC);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      bsum[i] *= uy;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] *= ua;
+    }
+  }
   if constexpr (KW > 1) {   // fold the K-split partials: wave (wb, kw > 0) -> LDS -> wave (wb, 0)
     float* red = buf0;      // staging buffers are free now (last barrier of the loop)
     float* redb = red + (KW - 1) * NWB * MI * NI * 256;
@@ -398,47 +477,65 @@ void set_dw_lds_budget(size_t bytes) { g_dw_budget = bytes < (size_t)RAL_DW_LDS_
 
 template <int M, int NC, int MS, int NS, int LAYY, int XF>
 static void launch_dw_t(const float* Y, const float* X, const float* pe, const float* lnw, const float* lnb,
-                        const float* a2c0, float* dW, float* dB, int N, int B, int ksplit, hipStream_t s) {
+                        const float* a2c0, float* dW, float* dB, int N, int B, int ksplit, hipStream_t s,
+                        const unsigned* ymax = nullptr) {
   static_assert(M % MS == 0 && NC % NS == 0, "slices must tile dW");
   constexpr bool yhm = LAYY == LAY_HM, xhm = XF == XF_HM;
   constexpr int TM = (MS + 15) / 16, TN = (NS + 15) / 16;
   constexpr int KW = 4 / (WaveGrid4<TM, TN>::WM * WaveGrid4<TM, TN>::WN);
-  // largest power-of-two token chunk dividing N within the compile-time staging bound and the LDS budget
-  int TC = dw_tcmax(MS, NS, yhm, xhm, XF == XF_LNPE);
-  auto bytes = [&](int tc) { return (size_t)2 * (dw_tile_floats(MS, yhm, tc) + dw_tile_floats(NS, xhm, tc)) * sizeof(float); };
-  while (TC > 16 && (N % TC != 0 || bytes(TC) > g_dw_budget)) TC /= 2;
-  const size_t fold = (size_t)(KW - 1) * (TM * TN * 256 + TM * 16) * sizeof(float);   // K-split partials of the spare waves
-  const size_t lds = bytes(TC) > fold ? bytes(TC) : fold;
-  RAL_SET_LDS((k_dw<M, NC, MS, NS, LAYY, XF>), lds);
   // ksplit is the split-K count of a fully sliced product; products with fewer slices get proportionally more
   // split-K workgroups so that every launch still fills the chip (at least ~256 workgroups)
   constexpr int nsl = (M / MS) * (NC / NS);
   int ks = ksplit;
   if (ks * nsl < RAL_DW_MINWG) ks = (RAL_DW_MINWG + nsl - 1) / nsl;
   dim3 grid(B < ks ? B : ks, nsl);
-  k_dw<M, NC, MS, NS, LAYY, XF><<<grid, 512, lds, s>>>(Y, X, pe, lnw, lnb, a2c0, dW, dB, N, TC, B);
+  const size_t fold = (size_t)(KW - 1) * (TM * TN * 256 + TM * 16) * sizeof(float);   // K-split partials of the spare waves
+  if constexpr (MS % 16 == 0 && NS % 16 == 0 && MS >= 64 && NS >= 64) {
+    if (ymax) {   // split operands (token chunks of at least one 32-token MFMA step)
+      int TC = dw_tcmax(MS, NS, yhm, xhm, XF == XF_LNPE);
+      auto bytesh = [&](int tc) { return (size_t)2 * tc * (MS + 8 + NS + 8) * sizeof(float); };
+      while (TC > 32 && (N % TC != 0 || bytesh(TC) > g_dw_budget)) TC /= 2;
+      if (TC >= 32 && N % TC == 0 && bytesh(TC) <= g_dw_budget + 4096) {
+        const size_t lds = bytesh(TC) > fold ? bytesh(TC) : fold;
+        RAL_SET_LDS((k_dw<M, NC, MS, NS, LAYY, XF, true>), lds);
+        k_dw<M, NC, MS, NS, LAYY, XF, true><<<grid, 512, lds, s>>>(Y, X, pe, lnw, lnb, a2c0, dW, dB, ymax, N, TC, B);
+        return;
+      }
+    }
+  }
+  // largest power-of-two token chunk dividing N within the compile-time staging bound and the LDS budget
+  int TC = dw_tcmax(MS, NS, yhm, xhm, XF == XF_LNPE);
+  auto bytes = [&](int tc) { return (size_t)2 * (dw_tile_floats(MS, yhm, tc) + dw_tile_floats(NS, xhm, tc)) * sizeof(float); };
+  while (TC > 16 && (N % TC != 0 || bytes(TC) > g_dw_budget)) TC /= 2;
+  const size_t lds = bytes(TC) > fold ? bytes(TC) : fold;
+  RAL_SET_LDS((k_dw<M, NC, MS, NS, LAYY, XF>), lds);
+  k_dw<M, NC, MS, NS, LAYY, XF><<<grid, 512, lds, s>>>(Y, X, pe, lnw, lnb, a2c0, dW, dB, nullptr, N, TC, B);
 }
 
 // slice widths: at most RAL_DW_SLICE rows/columns of the wide operand per workgroup
 template <int W> struct SliceOf { static constexpr int v = W > RAL_DW_SLICE ? ((W % RAL_DW_SLICE == 0) ? RAL_DW_SLICE : W / 2) : W; };
 
+// gmax (or nullptr): bits of the largest |dx2|, |du|, |dx1|, |dqkv| of this launch's windows (published by the split
+// data-gradient kernels): the four products then run on split operands (k_dw<..., true>)
 template <int C>
 static void launch_block_dw_c(const float* dx2, const float* upre, const float* a2c0, const float* dupre, const float* x1,
                               const float* dx1, const float* o_hm, const float* dqkv, const float* x, const float* pe,
-                              const BlockP& w, const BlockP& gr, int N, int B, int ks, bool skip_mlp, hipStream_t s) {
+                              const BlockP& w, const BlockP& gr, int N, int B, int ks, bool skip_mlp, const unsigned* gmax, hipStream_t s) {
+  static const bool h_on = !(getenv("RAL_DW_F16") && atoi(getenv("RAL_DW_F16")) == 0);
+  const unsigned* gm = (h_on && C >= 64) ? gmax : nullptr;
   if (!skip_mlp) {
-  launch_dw_t<C, 4 * C, C, SliceOf<4 * C>::v, LAY_TOK, XF_A2>(dx2, upre, nullptr, nullptr, nullptr, a2c0, gr.w2, gr.b2, N, B, ks, s);
-  launch_dw_t<4 * C, C, SliceOf<4 * C>::v, C, LAY_TOK, XF_LN>(dupre, x1, nullptr, w.ln2w, w.ln2b, nullptr, gr.w1, gr.b1, N, B, ks, s);
+  launch_dw_t<C, 4 * C, C, SliceOf<4 * C>::v, LAY_TOK, XF_A2>(dx2, upre, nullptr, nullptr, nullptr, a2c0, gr.w2, gr.b2, N, B, ks, s, gm ? gm + 0 : nullptr);
+  launch_dw_t<4 * C, C, SliceOf<4 * C>::v, C, LAY_TOK, XF_LN>(dupre, x1, nullptr, w.ln2w, w.ln2b, nullptr, gr.w1, gr.b1, N, B, ks, s, gm ? gm + 1 : nullptr);
   }
-  launch_dw_t<C, C, SliceOf<C>::v, C, LAY_TOK, XF_HM>(dx1, o_hm, nullptr, nullptr, nullptr, nullptr, gr.wp, gr.bp, N, B, ks, s);
-  launch_dw_t<3 * C, C, SliceOf<3 * C>::v, C, LAY_HM, XF_LNPE>(dqkv, x, pe, w.ln1w, w.ln1b, nullptr, gr.wqkv, gr.bqkv, N, B, ks, s);
+  launch_dw_t<C, C, SliceOf<C>::v, C, LAY_TOK, XF_HM>(dx1, o_hm, nullptr, nullptr, nullptr, nullptr, gr.wp, gr.bp, N, B, ks, s, gm ? gm + 2 : nullptr);
+  launch_dw_t<3 * C, C, SliceOf<3 * C>::v, C, LAY_HM, XF_LNPE>(dqkv, x, pe, w.ln1w, w.ln1b, nullptr, gr.wqkv, gr.bqkv, N, B, ks, s, gm ? gm + 3 : nullptr);
 }
 
 void launch_block_dw(int C, const float* dx2, const float* upre, const float* a2c0, const float* dupre, const float* x1,
                      const float* dx1, const float* o_hm, const float* dqkv, const float* x, const float* pe,
-                     const BlockP& w, const BlockP& gr, int N, int B, int ksplit, bool skip_mlp, hipStream_t s) {
+                     const BlockP& w, const BlockP& gr, int N, int B, int ksplit, bool skip_mlp, const unsigned* gmax, hipStream_t s) {
   switch (C) {
-#define CASE(c) case c: launch_block_dw_c<c>(dx2, upre, a2c0, dupre, x1, dx1, o_hm, dqkv, x, pe, w, gr, N, B, ksplit, skip_mlp, s); break;
+#define CASE(c) case c: launch_block_dw_c<c>(dx2, upre, a2c0, dupre, x1, dx1, o_hm, dqkv, x, pe, w, gr, N, B, ksplit, skip_mlp, gmax, s); break;
     CASE(8) CASE(16) CASE(32) CASE(64) CASE(128)
 #undef CASE
   }

@@ -69,8 +69,11 @@ bool mlp_bwd_is_fused(int C, int N);   // narrow levels: fused weight gradients,
 // ptbase / wtt: the transposed-parameter buffer and the tiled split planes of its weight matrices (launch_tile_planes over
 // it); the (C, N) for which mlp_bwd_h_nch is non-zero run their data-gradient products on them (wtt == nullptr: fp32 MFMA)
 int mlp_bwd_h_nch(int C, int N);
+bool qkv_bwd_uses_f16(int C, int N);
+// gmax (4 unsigned, zeroed by the caller): the split kernels raise it to the bits of the largest |dx2|, |du|, |dx1| (mlp) and
+// |dqkv| (qkv) of the launch - the scales of the split weight-gradient products (launch_block_dw)
 bool launch_mlp_bwd(int C, int nch, const float* dx2, const float* x1, const float* upre, const BlockP& w,
-                    const BlockP& wt, const float* ptbase, const void* wtt, const BlockP& gr, float* dupre, float* dx1, float* do_hm,
+                    const BlockP& wt, const float* ptbase, const void* wtt, unsigned* gmax, const BlockP& gr, float* dupre, float* dx1, float* do_hm,
                     float* a2c0, int N, int B, bool want_dw, hipStream_t s);
 size_t attn_bwd_lds(int N, int HG, int Len);
 bool attn_bwd_uses_stat2(int N, int Len, bool table);   // does launch_attn_bwd need its (B, H, N, 2) scratch for this shape?
@@ -78,8 +81,8 @@ void launch_attn_bwd(const float* qkv, const float* o_hm, const float* do_hm, co
                      float* gtable, float* dqkv, float* stat2, int N, int H, int HG, int Len, int B, hipStream_t s);
 size_t qkv_bwd_lds(int C, int N);
 void launch_qkv_bwd(int C, const float* dqkv, const float* x, const float* pe, const float* dx1, const float* extra,
-                    const BlockP& w, const BlockP& wt, const float* ptbase, const void* wtt /* as launch_mlp_bwd */, const BlockP& gr,
-                    float* dx, int N, int B, hipStream_t s);
+                    const BlockP& w, const BlockP& wt, const float* ptbase, const void* wtt /* as launch_mlp_bwd */, unsigned* gmax,
+                    const BlockP& gr, float* dx, int N, int B, hipStream_t s);
 void launch_resample_bwd(int D, bool sep, const float* dy, const float* x, const float* wred, const float* lnw,
                          float* g_lnw, float* g_lnb, float* dx, int T, int B, hipStream_t s);
 void launch_final_bwd(int leads, const float* dy, const float* u0, const float* x0, const float* w, float* gw,
@@ -93,7 +96,7 @@ void launch_conv1_bwd_dx(int leads, const float* dz, const float* w, float* dx, 
 // ---- weight gradients (ral_dw.hip)
 void launch_block_dw(int C, const float* dx2, const float* upre, const float* a2c0, const float* dupre, const float* x1,
                      const float* dx1, const float* o_hm, const float* dqkv, const float* x, const float* pe,
-                     const BlockP& w, const BlockP& gr, int N, int B, int ksplit, bool skip_mlp, hipStream_t s);
+                     const BlockP& w, const BlockP& gr, int N, int B, int ksplit, bool skip_mlp, const unsigned* gmax /* 4 maxima of the split data-gradient kernels, or nullptr */, hipStream_t s);
 void set_dw_lds_budget(size_t bytes);
 void launch_resample_dw(int D, bool sep, const float* dy, const float* x, const float* lnw, const float* lnb,
                         float* dW, int T, int B, int ksplit, hipStream_t s);
