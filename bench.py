@@ -457,10 +457,11 @@ def main():
             "median_ms_per_step_hipevent": round(median_ms, 3) if median_ms else None,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "arithmetic": "fp32 tensors and accumulators; the forward and data-gradient Linear layers of the two wide levels "
-                          "(C = 64, 128) are error-compensated fp16-pair products on the f16 matrix cores (x = h1 + 2^-11 h2, three "
-                          "products per term, ~2^-21 relative; gradient rows scaled by a power of two per token); everything "
-                          "else on the fp32 MFMA / vector ALU.  ral_set_option f16_split=0: every product on the fp32 MFMA",
+            "arithmetic": "fp32 tensors and accumulators; the Linear layers of the two wide levels (C = 64, 128: forward, "
+                          "data-gradient and weight-gradient products) are error-compensated fp16-pair products on the f16 matrix "
+                          "cores (x = h1 + h2, three products per term, ~2^-21 relative; gradient operands scaled by a power of two "
+                          "per token / per launch); everything else on the fp32 MFMA / vector ALU.  ral_set_option f16_split=0: "
+                          "every product on the fp32 MFMA",
             "config": {"workload": W["text"], "global_batch": B * world, "parallelism": f"dp{world}", "sync_bn": True},
             "final_loss": round(loss, 6),
         }

@@ -1777,9 +1777,9 @@ size_t mlp_bwd_h_lds(int C, int N, int nch) {
 }
 int mlp_bwd_h_nch(int C, int N) {
   static const bool on = !(getenv("RAL_MLP_F16") && atoi(getenv("RAL_MLP_F16")) == 0);
-  if (!on || (C != 64 && C != 128) || N % 32 != 0) return 0;
+  if (!on || (C != 32 && C != 64 && C != 128) || N % 32 != 0) return 0;
   for (int nch = 1; nch <= 4; nch *= 2)
-    if ((4 * C / nch / 32) * (N / 32) == 8 && mlp_bwd_h_lds(C, N, nch) <= 78000) return nch;
+    if ((4 * C / nch / 32) * (N / 32) == 8 && mlp_bwd_h_lds(C, N, nch) <= 79872) return nch;
   return 0;
 }
 template <int C>
@@ -1817,8 +1817,9 @@ bool launch_mlp_bwd(int C, int nch, const float* dx2, const float* x1, const flo
                     const BlockP& wt, const float* ptbase, const void* wtt, unsigned* gmax, const BlockP& gr, float* dupre, float* dx1, float* do_hm,
                     float* a2c0, int N, int B, bool want_dw, hipStream_t s) {
   if (!want_dw) { dupre = nullptr; a2c0 = nullptr; }   // consumed by the weight-gradient kernels only
-  if (wtt) {
+  if (wtt && upre) {   // (upre == nullptr: a level whose forward does not store u_pre - the fused narrow-level kernel re-computes it)
     const int nh = mlp_bwd_h_nch(C, N);
+    if (nh && C == 32) { launch_mlp_bwd_hc<32>(nh, dx2, x1, upre, w, wt, ptbase, wtt, gr, dupre, dx1, do_hm, a2c0, want_dw ? gmax : nullptr, N, B, s); return false; }
     if (nh && C == 64) { launch_mlp_bwd_hc<64>(nh, dx2, x1, upre, w, wt, ptbase, wtt, gr, dupre, dx1, do_hm, a2c0, want_dw ? gmax : nullptr, N, B, s); return false; }
     if (nh && C == 128) { launch_mlp_bwd_hc<128>(nh, dx2, x1, upre, w, wt, ptbase, wtt, gr, dupre, dx1, do_hm, a2c0, want_dw ? gmax : nullptr, N, B, s); return false; }
   }
@@ -1904,7 +1905,7 @@ size_t qkv_bwd_lds(int C, int N) { return ((size_t)N * 3 * C + (size_t)N * ld_of
 
 bool qkv_bwd_uses_f16(int C, int N) {
   static const bool on = !(getenv("RAL_QKVB_F16") && atoi(getenv("RAL_QKVB_F16")) == 0);
-  return on && (C == 64 || C == 128) && N % 32 == 0 && N * 3 * C / 4 <= 6 * 512;
+  return on && (C == 32 || C == 64 || C == 128) && N % 32 == 0 && N * 3 * C / 4 <= 6 * 512;
 }
 void launch_qkv_bwd(int C, const float* dqkv, const float* x, const float* pe, const float* dx1, const float* extra,
                     const BlockP& w, const BlockP& wt, const float* ptbase, const void* wtt, unsigned* gmax, const BlockP& gr, float* dx, int N, int B,
@@ -1914,7 +1915,8 @@ void launch_qkv_bwd(int C, const float* dqkv, const float* x, const float* pe, c
   if (wtt && qkv_bwd_uses_f16(C, N)) {
     const size_t ldsh = (size_t)2 * N * ldb_of(3 * C) * 2 + ((size_t)N * ld_of(C) + 2 * C + 2 * N) * 4;
     const _Float16* wp = reinterpret_cast<const _Float16*>(wtt);
-    if (C == 64) { RAL_SET_LDS((k_qkv_bwd_h<64>), ldsh); k_qkv_bwd_h<64><<<grid, 512, ldsh, s>>>(dqkv, x, pe, dx1, extra, w, wt, ptbase, wp, gr, dx, gmax, N, B); }
+    if (C == 32) { RAL_SET_LDS((k_qkv_bwd_h<32>), ldsh); k_qkv_bwd_h<32><<<grid, 512, ldsh, s>>>(dqkv, x, pe, dx1, extra, w, wt, ptbase, wp, gr, dx, gmax, N, B); }
+    else if (C == 64) { RAL_SET_LDS((k_qkv_bwd_h<64>), ldsh); k_qkv_bwd_h<64><<<grid, 512, ldsh, s>>>(dqkv, x, pe, dx1, extra, w, wt, ptbase, wp, gr, dx, gmax, N, B); }
     else { RAL_SET_LDS((k_qkv_bwd_h<128>), ldsh); k_qkv_bwd_h<128><<<grid, 512, ldsh, s>>>(dqkv, x, pe, dx1, extra, w, wt, ptbase, wp, gr, dx, gmax, N, B); }
     return;
   }

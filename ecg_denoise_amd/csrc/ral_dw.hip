@@ -490,7 +490,7 @@ static void launch_dw_t(const float* Y, const float* X, const float* pe, const f
   if (ks * nsl < RAL_DW_MINWG) ks = (RAL_DW_MINWG + nsl - 1) / nsl;
   dim3 grid(B < ks ? B : ks, nsl);
   const size_t fold = (size_t)(KW - 1) * (TM * TN * 256 + TM * 16) * sizeof(float);   // K-split partials of the spare waves
-  if constexpr (MS % 16 == 0 && NS % 16 == 0 && MS >= 64 && NS >= 64) {
+  if constexpr (MS % 16 == 0 && NS % 16 == 0 && MS >= 32 && NS >= 32) {
     if (ymax) {   // split operands (token chunks of at least one 32-token MFMA step)
       int TC = dw_tcmax(MS, NS, yhm, xhm, XF == XF_LNPE);
       auto bytesh = [&](int tc) { return (size_t)2 * tc * (MS + 8 + NS + 8) * sizeof(float); };
@@ -522,7 +522,7 @@ static void launch_block_dw_c(const float* dx2, const float* upre, const float* 
                               const float* dx1, const float* o_hm, const float* dqkv, const float* x, const float* pe,
                               const BlockP& w, const BlockP& gr, int N, int B, int ks, bool skip_mlp, const unsigned* gmax, hipStream_t s) {
   static const bool h_on = !(getenv("RAL_DW_F16") && atoi(getenv("RAL_DW_F16")) == 0);
-  const unsigned* gm = (h_on && C >= 64) ? gmax : nullptr;
+  const unsigned* gm = (h_on && C >= 32) ? gmax : nullptr;
   if (!skip_mlp) {
   launch_dw_t<C, 4 * C, C, SliceOf<4 * C>::v, LAY_TOK, XF_A2>(dx2, upre, nullptr, nullptr, nullptr, a2c0, gr.w2, gr.b2, N, B, ks, s, gm ? gm + 0 : nullptr);
   launch_dw_t<4 * C, C, SliceOf<4 * C>::v, C, LAY_TOK, XF_LN>(dupre, x1, nullptr, w.ln2w, w.ln2b, nullptr, gr.w1, gr.b1, N, B, ks, s, gm ? gm + 1 : nullptr);

@@ -847,7 +847,7 @@ static inline int grid_for(int items) {
 }
 
 // widths whose projection has a split-operand kernel (the caller passes the tiled weight planes to choose it)
-bool qkv_fwd_uses_f16(int C) { return C == 64 || C == 128; }
+bool qkv_fwd_uses_f16(int C) { return C == 32 || C == 64 || C == 128; }
 
 void launch_qkv_fwd(int C, const float* x, const float* pe, const BlockP& w, const void* wt, float* qkv, int N, int B, hipStream_t s) {
   if (wt && qkv_fwd_uses_f16(C) && N % 16 == 0) {
@@ -873,6 +873,7 @@ void launch_qkv_fwd(int C, const float* x, const float* pe, const BlockP& w, con
       if (C == 64) { gows(k_qkv_fwd_ws<64, 64>, 64, 2); return; }
       if (C == 128) { gows(k_qkv_fwd_ws<128, 64>, 128, 1); return; }
     }
+    if (C == 32 && (N % 64 == 0 || 64 % N == 0)) { go(k_qkv_fwd_h<32, 64>, 64); return; }
     if (C == 64 && (N % 64 == 0 || 64 % N == 0)) { go(k_qkv_fwd_h<64, 64>, 64); return; }
     if (C == 128 && (N % 64 == 0 || 64 % N == 0)) { go(k_qkv_fwd_h<128, 64>, 64); return; }
   }
@@ -953,7 +954,7 @@ static void launch_mlp_fwd_c(int nch, const float* x, const float* o, const Bloc
 // wide levels on split fp16 operands (RAL_MLP_F16=0: the fp32-MFMA kernel everywhere)
 bool mlp_fwd_uses_f16(int C, int N) {
   static const bool on = !(getenv("RAL_MLP_F16") && atoi(getenv("RAL_MLP_F16")) == 0);
-  return on && (C == 64 || C == 128) && N % 32 == 0;
+  return on && (C == 32 || C == 64 || C == 128) && N % 32 == 0;
 }
 size_t mlp_fwd_h_lds(int C, int T, int nch) {   // T = tokens of a work item
   return (size_t)T * ld_of(C) * 4 + (size_t)2 * T * ldb_of(C) * 2 + (size_t)2 * T * ldb_of(4 * C / nch) * 2 + (T / 16 * 2 + T + 4) * 4;
@@ -987,7 +988,8 @@ void launch_mlp_fwd(int C, int nch, const float* x, const float* o, const BlockP
                     float* x1, float* upre, float* x2, int N, int B, hipStream_t s) {
   if (wh && mlp_fwd_uses_f16(C, N)) {
     static const int nth = getenv("RAL_MLP_HTHREADS") ? atoi(getenv("RAL_MLP_HTHREADS")) : 512;
-    if (C == 64) { if (nth == 1024) launch_mlp_fwd_hc<64, 1024>(x, o, w, pbase, wh, x1, upre, x2, N, B, s); else launch_mlp_fwd_hc<64, 512>(x, o, w, pbase, wh, x1, upre, x2, N, B, s); }
+    if (C == 32) launch_mlp_fwd_hc<32, 512>(x, o, w, pbase, wh, x1, upre, x2, N, B, s);
+    else if (C == 64) { if (nth == 1024) launch_mlp_fwd_hc<64, 1024>(x, o, w, pbase, wh, x1, upre, x2, N, B, s); else launch_mlp_fwd_hc<64, 512>(x, o, w, pbase, wh, x1, upre, x2, N, B, s); }
     else { if (nth == 1024) launch_mlp_fwd_hc<128, 1024>(x, o, w, pbase, wh, x1, upre, x2, N, B, s); else launch_mlp_fwd_hc<128, 512>(x, o, w, pbase, wh, x1, upre, x2, N, B, s); }
     return;
   }
