@@ -354,6 +354,10 @@ __global__ __launch_bounds__(512, RAL_DW_WPE) void k_dw(const float* Y, const fl
             const f16x8 b1 = frag(Xh, LDXH, tb, n0 + 16 * j), b2 = frag(Xh + TC * LDXH, LDXH, tb, n0 + 16 * j);
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
+#if defined(RAL_DW_NOMFMA)   // diagnostic: without the matrix work (fragments still read)
+              acc[i][j][0] += (float)a1[i][0] + (float)a2[i][1] + (float)b1[2] + (float)b2[3];
+              continue;
+#endif
               acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[i], b1, acc[i][j], 0, 0, 0);
               acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[i], b2, acc[i][j], 0, 0, 0);
               acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[i], b1, acc[i][j], 0, 0, 0);
