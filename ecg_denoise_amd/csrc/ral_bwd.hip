@@ -1427,7 +1427,9 @@ __global__ __launch_bounds__(512, RAL_QKVB_MINB) void k_qkv_bwd_h(const float* d
 // the input layout;  grads: LN w/b.  (dW of the reduction is a ral_dw.hip product.)
 // =================================================================================
 template <int D, bool SEP>
-__global__ __launch_bounds__(256) void k_resample_bwd(const float* __restrict__ dy, const float* __restrict__ x,
+// (dy and x are deliberately NOT __restrict__: see k_dw - loads the compiler can prove invariant are sunk across the compiler
+// barrier of the prefetch, next to their uses)
+__global__ __launch_bounds__(256) void k_resample_bwd(const float* dy, const float* x,
                                                       const float* __restrict__ wred, const float* __restrict__ lnw,
                                                       float* __restrict__ g_lnw, float* __restrict__ g_lnb,
                                                       float* __restrict__ dx, int T, int B) {
@@ -1439,6 +1441,68 @@ __global__ __launch_bounds__(256) void k_resample_bwd(const float* __restrict__ 
   const int cq = (threadIdx.x % LPR) * 4;
   const float4 gam = *reinterpret_cast<const float4*>(lnw + cq);
   float4 dgam = make_float4(0.f, 0.f, 0.f, 0.f), dbet = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto src_of = [&](size_t wo, int row) -> size_t {
+    return SEP ? wo + (size_t)(row % (T / 2)) * 2 * D + (row / (T / 2)) * D : wo + (size_t)row * D;
+  };
+  auto ln_row = [&](int row, size_t src, float4 v) {   // LayerNorm backward of one row (all LPR lanes of the row take part)
+    float4 d; float rstd;
+    ln_stats<LPR>(v, d, rstd);
+    if (row < T) {
+      const float4 xh = f4scale(d, rstd);
+      const float4 dh = *reinterpret_cast<const float4*>(Dh + row * LD + cq);
+      const float4 dyh = f4mul(dh, gam);
+      constexpr float invD = 1.0f / D;
+      const float m1 = group_sum<LPR>(f4hsum(dyh)) * invD;
+      const float m2 = group_sum<LPR>(f4dot(dyh, xh)) * invD;
+      *reinterpret_cast<float4*>(dx + src + cq) =
+          make_float4(rstd * (dyh.x - m1 - xh.x * m2), rstd * (dyh.y - m1 - xh.y * m2),
+                      rstd * (dyh.z - m1 - xh.z * m2), rstd * (dyh.w - m1 - xh.w * m2));
+      dgam = f4add(dgam, f4mul(dh, xh));
+      dbet = f4add(dbet, dh);
+    }
+  };
+  if (T == 4 * RPP) {
+    // 512-sample windows (T D = 4096: four float4 of dy and four rows of x per thread).  One workgroup per CU runs next to
+    // the weight-gradient kernels, so nothing else hides this kernel's HBM round trips: the x rows of the LayerNorm
+    // phase are requested before the product, the next window's dy under the LayerNorm phase - one barrier-free round
+    // trip per window instead of two exposed ones (the eight launches of a step: 0.38 -> 0.32 ms).
+    constexpr int q = D / 4;
+    float4 dv[4], xv[4];
+    // (filled in place, not through a lambda: an array handed to a lambda by reference ends up in scratch memory)
+#define RAL_REQ_DY(win_) do { const float4* s4_ = reinterpret_cast<const float4*>(dy + (size_t)(win_) * T * D); \
+      _Pragma("unroll") for (int k = 0; k < 4; ++k) dv[k] = s4_[threadIdx.x + k * 256]; } while (0)
+    if ((int)blockIdx.x < B) RAL_REQ_DY(blockIdx.x);
+    else { dv[0] = dv[1] = dv[2] = dv[3] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    for (int win = blockIdx.x; win < B; win += gridDim.x) {
+      const size_t wo = (size_t)win * T * D;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = threadIdx.x + k * 256;
+        *reinterpret_cast<float4*>(Ys + (i / q) * LD + (i % q) * 4) = dv[k];
+      }
+      __syncthreads();
+      size_t src4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        src4[u] = src_of(wo, threadIdx.x / LPR + u * RPP);
+        xv[u] = *reinterpret_cast<const float4*>(x + src4[u] + cq);
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      gemm_phase<D, TTBof<D>::v, false, LAY_TOK>(wred /* W^T */, D, D, Ys, LD, T >> 4, [&](int row0, int tok, f32x4 a) {
+        *reinterpret_cast<float4*>(Dh + tok * LD + row0) = tofloat4(a);
+      });
+      __syncthreads();
+      const int nxt = win + gridDim.x;
+      RAL_REQ_DY(nxt < B ? nxt : win);   // (past the end: a harmless re-read, no branch around the loads)
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) ln_row(threadIdx.x / LPR + u * RPP, src4[u], xv[u]);
+    }
+#undef RAL_REQ_DY
+    __syncthreads();
+  } else {
   for (int win = blockIdx.x; win < B; win += gridDim.x) {
     const size_t wo = (size_t)win * T * D;
     copy_in(Ys, LD, dy + wo, D, T, D);
@@ -1452,31 +1516,14 @@ __global__ __launch_bounds__(256) void k_resample_bwd(const float* __restrict__ 
       float4 v4[4]; size_t src4[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int row = min(row0 + u * RPP, T - 1);
-        src4[u] = SEP ? wo + (size_t)(row % (T / 2)) * 2 * D + (row / (T / 2)) * D : wo + (size_t)row * D;
+        src4[u] = src_of(wo, min(row0 + u * RPP, T - 1));
         v4[u] = *reinterpret_cast<const float4*>(x + src4[u] + cq);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int row = row0 + u * RPP;
-        float4 d; float rstd;
-        ln_stats<LPR>(v4[u], d, rstd);
-        if (row < T) {
-          const float4 xh = f4scale(d, rstd);
-          const float4 dh = *reinterpret_cast<const float4*>(Dh + row * LD + cq);
-          const float4 dyh = f4mul(dh, gam);
-          constexpr float invD = 1.0f / D;
-          const float m1 = group_sum<LPR>(f4hsum(dyh)) * invD;
-          const float m2 = group_sum<LPR>(f4dot(dyh, xh)) * invD;
-          *reinterpret_cast<float4*>(dx + src4[u] + cq) =
-              make_float4(rstd * (dyh.x - m1 - xh.x * m2), rstd * (dyh.y - m1 - xh.y * m2),
-                          rstd * (dyh.z - m1 - xh.z * m2), rstd * (dyh.w - m1 - xh.w * m2));
-          dgam = f4add(dgam, f4mul(dh, xh));
-          dbet = f4add(dbet, dh);
-        }
-      }
+      for (int u = 0; u < 4; ++u) ln_row(row0 + u * RPP, src4[u], v4[u]);
     }
     __syncthreads();
+  }
   }
   for (int i = threadIdx.x; i < 2 * D; i += blockDim.x) red[i] = 0.f;
   __syncthreads();
