@@ -270,7 +270,9 @@ static inline int ew_grid(size_t n, int per = 256) {
 void launch_conv1_fwd(int leads, int mode, const float* x, const float* w, const float* b, float* out, double* stats,
                       const float* bnw, const float* bnb, const float* rmean, const float* rvar, int L, int B,
                       hipStream_t s) {
-  const int grid = ew_grid((size_t)B * L);
+  // training: every workgroup ends with 16 double atomics on the same 16 addresses (~15 ns per link of a same-address
+  // chain): 4096 workgroups were a 56 us kernel for 38 MB of traffic, 512 are an 18 us one
+  const int grid = ew_grid((size_t)B * L, mode == 0 ? 2048 : 256);
 #define CASE(ld)                                                                                             \
   case ld:                                                                                                   \
     if (mode == 0) k_conv1_fwd<ld, 0><<<grid, 256, 0, s>>>(x, w, b, out, stats, bnw, bnb, rmean, rvar, L, B); \

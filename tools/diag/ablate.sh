@@ -19,6 +19,6 @@ def load(f):
     return {re.sub(r"\(.*", "", r["Name"]).replace("void ", ""): (float(r["AverageNs"]) / 1e3, int(r["Calls"])) for r in csv.DictReader(open(f))}
 tabs = [load(f) for f in sys.argv[1:]]
 rows = sorted(tabs[0].items(), key=lambda kv: -kv[1][0] * kv[1][1])
-for k, (us, n) in rows[:45]:
+for k, (us, n) in rows[:int(__import__("os").environ.get("ABL_ROWS", "45"))]:
     print(f"{k[:44]:44s} x{n:4d} {us:8.1f} | " + " | ".join(f"{t[k][0]:8.1f}" if k in t else "       -" for t in tabs[1:]))
 PY
