@@ -614,8 +614,10 @@ static void run_block_bwd(RalModel* m, int bi, const float* dy, const float* ext
     EV(hipStreamWaitEvent(sd, ln.ev_ready[k], 0));
   }
   { ProfScope p(m, K_DW, sd);
-    static const int skipw = getenv("RAL_DIAG_SKIP_WIDE_DW") ? atoi(getenv("RAL_DIAG_SKIP_WIDE_DW")) : 0;   // diagnostic (wrong gradients): what the wide levels' weight-gradient kernels cost the step
+#ifdef RAL_DIAG   // diagnostic builds only (make VARIANT=diag EXTRA=-DRAL_DIAG; WRONG gradients): what the weight-gradient kernels of the levels C >= RAL_DIAG_SKIP_WIDE_DW cost the step
+    static const int skipw = getenv("RAL_DIAG_SKIP_WIDE_DW") ? atoi(getenv("RAL_DIAG_SKIP_WIDE_DW")) : 0;
     if (!(skipw && C >= skipw))
+#endif
     launch_block_dw(C, dyw, upre, w.le ? a2c0 : nullptr, dupre, x1, dx1, o, dqkv, xin, m->pe[l], w, g, N, B, m->dw_ksplit[l], fused_mlp_dw, gmax, sd); }
   if (side) { EV(hipEventRecord(ln.ev_done[k], sd)); ln.dw_pending[k] = true; }
 }
