@@ -214,9 +214,15 @@ RAL_DEV void h2_mma(const f16x8 (&a)[MT][2], const _Float16* xr, int xplane, int
   for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) {
+#ifdef RAL_H2_ONEACC   // diagnostic (wrong scaling of the cross terms): what ONE accumulator per tile would be worth in registers / time
+      acc[mi][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mi][1], b1[tt], acc[mi][tt], 0, 0, 0);
+      acc[mi][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mi][0], b1[tt], acc[mi][tt], 0, 0, 0);
+      acc[mi][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mi][0], b2[tt], acc[mi][tt], 0, 0, 0);
+#else
       accx[mi][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mi][1], b1[tt], accx[mi][tt], 0, 0, 0);
       acc[mi][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mi][0], b1[tt], acc[mi][tt], 0, 0, 0);
       accx[mi][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mi][0], b2[tt], accx[mi][tt], 0, 0, 0);
+#endif
     }
 }
 struct NoHook { RAL_DEV void operator()() const {} };
