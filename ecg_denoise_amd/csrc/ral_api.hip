@@ -533,7 +533,7 @@ static int fwd_end(RalModel* m, float* y, int B, int64_t global_windows, int tra
     launch_bn_apply8(m->a0, m->ss, m->x0, (size_t)B * m->L, s);
   }
   const bool tr = training != 0;
-  if (m->f16_split > 0) launch_tile_planes(m->params, m->wh, m->wdesc, m->ndesc, m->nwork, s);   // split planes of the wide levels' weights
+  if (m->f16_split > 0) launch_tile_planes(m->params, m->wh, m->wdesc, m->ndesc, m->nwork, 1.0f, 0, s);   // split planes of the wide levels' weights
   const int nl = plan_lanes(m, B, s);
   fork_lanes(m, s);
   LaneSet* LS = lanes_of(m);
@@ -657,7 +657,7 @@ static int bwd_begin(RalModel* m, const float* dy, int B, hipStream_t s) {
   HIP_OK(hipMemsetAsync(m->grads, 0, (size_t)Y.nparam * sizeof(float), s));
   HIP_OK(hipMemsetAsync(m->bn_sums + 32, 0, 32 * sizeof(double), s));
   launch_transpose_mats(m->params, m->paramsT, m->tdesc, m->tn, m->ttotal, s);
-  if (m->f16_split > 0) launch_tile_planes(m->paramsT, m->whT, m->wdescT, m->ndescT, m->nworkT, s);
+  if (m->f16_split > 0) launch_tile_planes(m->paramsT, m->whT, m->wdescT, m->ndescT, m->nworkT, RAL_WT_SCALE, 1, s);
   HIP_OK(hipMemsetAsync(m->gmax, 0, 18 * 4 * 4 * sizeof(unsigned), s));
   float** gy = m->gy; float** gin = m->gin;
   const int nl = plan_lanes(m, B, s);

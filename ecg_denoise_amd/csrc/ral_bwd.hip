@@ -219,7 +219,7 @@ __global__ __launch_bounds__(512, 4) void k_mlp_bwd_h(const float* __restrict__ 
   float gle0 = 0.f, gle1 = 0.f, gle2 = 0.f;
   float4 dgam = make_float4(0.f, 0.f, 0.f, 0.f), dbet = make_float4(0.f, 0.f, 0.f, 0.f);
   auto put_split = [&](_Float16* base, int plane, int off, float4 v) {
-    const H2 s0 = f16_split2(v.x), s1 = f16_split2(v.y), s2 = f16_split2(v.z), s3 = f16_split2(v.w);
+    const H2 s0 = f16_split2u(v.x), s1 = f16_split2u(v.y), s2 = f16_split2u(v.z), s3 = f16_split2u(v.w);   // (rows arrive scaled)
     *reinterpret_cast<f16x4*>(base + off) = f16x4{s0.a, s1.a, s2.a, s3.a};
     *reinterpret_cast<f16x4*>(base + plane + off) = f16x4{s0.b, s1.b, s2.b, s3.b};
   };
@@ -273,16 +273,16 @@ __global__ __launch_bounds__(512, 4) void k_mlp_bwd_h(const float* __restrict__ 
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
           for (int tt = 0; tt < 2; ++tt) { acc[mi][tt] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[mi][tt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        gemm_wx_h2<C, 2, 2>(w2t, C / 32, j0 / 16 + um * 2, 0, Dh, dplane, LDG, ut * 32, acc, accx);
+        gemm_wx_h2<C, 2, 2, NoHook, 0, 1>(w2t, C / 32, j0 / 16 + um * 2, 0, Dh, dplane, LDG, ut * 32, acc, accx);
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
           const int tok = ut * 32 + tt * 16 + r;
-          const float sd = h2_row_unscale(smD[tok]);
+          const float sd = h2_row_unscale(smD[tok]) * (1.0f / RAL_WT_SCALE);
           float mx = 0.f;
 #pragma unroll
           for (int mi = 0; mi < 2; ++mi) {
             const int row0 = (um * 2 + mi) * 16 + 4 * g;
-            const f32x4 a = (acc[mi][tt] + accx[mi][tt] * RAL_H2_SCALE) * sd;
+            const f32x4 a = acc[mi][tt] * sd;
             const float4 u = *reinterpret_cast<const float4*>(Us + tok * LDUF + row0);
             const float uu[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
@@ -336,8 +336,8 @@ __global__ __launch_bounds__(512, 4) void k_mlp_bwd_h(const float* __restrict__ 
       }
       __syncthreads();
       // ---- dg (+)= du W1[chunk, :] ----
-      gemm_phase_h2<HC>(w1t, 4 * C / 32, 0, j0 / 32, C, nullptr, Uh, uplane, LDU, N >> 4, [&](int row0, int tok, f32x4 a) {
-        const float si = h2_row_unscale(smU[tok]);
+      gemm_phase_h2<HC, 0, 1>(w1t, 4 * C / 32, 0, j0 / 32, C, nullptr, Uh, uplane, LDU, N >> 4, [&](int row0, int tok, f32x4 a) {
+        const float si = h2_row_unscale(smU[tok]) * (1.0f / RAL_WT_SCALE);
         float4* pg = reinterpret_cast<float4*>(Gs + tok * LD + row0);
         const float4 v = f4scale(tofloat4(a), si);
         *pg = (ch == 0) ? v : f4add(*pg, v);
@@ -367,8 +367,8 @@ __global__ __launch_bounds__(512, 4) void k_mlp_bwd_h(const float* __restrict__ 
     __syncthreads();
     // ---- do = dx1 Wp (head-major) ----
     float* dow = do_hm + wo;
-    gemm_phase_h2<C>(wpt, C / 32, 0, 0, C, nullptr, Dh, dplane, LDG, N >> 4, [&](int row0, int tok, f32x4 a) {
-      *reinterpret_cast<float4*>(dow + ((size_t)(row0 >> 2) * N + tok) * 4) = f4scale(tofloat4(a), h2_row_unscale(smD[tok]));
+    gemm_phase_h2<C, 0, 1>(wpt, C / 32, 0, 0, C, nullptr, Dh, dplane, LDG, N >> 4, [&](int row0, int tok, f32x4 a) {
+      *reinterpret_cast<float4*>(dow + ((size_t)(row0 >> 2) * N + tok) * 4) = f4scale(tofloat4(a), h2_row_unscale(smD[tok]) * (1.0f / RAL_WT_SCALE));
     });
     __syncthreads();
   }
@@ -1303,7 +1303,7 @@ __global__ __launch_bounds__(512, RAL_QKVB_MINB) void k_qkv_bwd_h(const float* d
     if (i < n4) {
       const int qd = i / N, t = i - qd * N;
       v = f4scale(v, h2_row_scale(sm[t]));
-      const H2 s0 = f16_split2(v.x), s1 = f16_split2(v.y), s2 = f16_split2(v.z), s3 = f16_split2(v.w);
+      const H2 s0 = f16_split2u(v.x), s1 = f16_split2u(v.y), s2 = f16_split2u(v.z), s3 = f16_split2u(v.w);
       *reinterpret_cast<f16x4*>(Qh + t * LDQ + qd * 4) = f16x4{s0.a, s1.a, s2.a, s3.a};
       *reinterpret_cast<f16x4*>(Qh + qplane + t * LDQ + qd * 4) = f16x4{s0.b, s1.b, s2.b, s3.b};
     }
@@ -1362,8 +1362,8 @@ __global__ __launch_bounds__(512, RAL_QKVB_MINB) void k_qkv_bwd_h(const float* d
     unsigned* smn = smQ + (par ^ 1) * N;
     if ((int)threadIdx.x < N) smn[threadIdx.x] = 0u;   // (last read by the previous window's product)
     // dh[t][c] = sum_m dqkv[t][m] Wqkv[m][c]
-    gemm_phase_h2<3 * C>(wq, 3 * C / 32, 0, 0, C, nullptr, Qh, qplane, LDQ, N >> 4, [&](int row0, int tok, f32x4 a) {
-      *reinterpret_cast<float4*>(Dh + tok * LD + row0) = f4scale(tofloat4(a), h2_row_unscale(smc[tok]));
+    gemm_phase_h2<3 * C, 0, 2>(wq, 3 * C / 32, 0, 0, C, nullptr, Qh, qplane, LDQ, N >> 4, [&](int row0, int tok, f32x4 a) {
+      *reinterpret_cast<float4*>(Dh + tok * LD + row0) = f4scale(tofloat4(a), h2_row_unscale(smc[tok]) * (1.0f / RAL_WT_SCALE));
     });
     __syncthreads();   // Dh complete, Qh free
     const int nxt = win + gridDim.x;

@@ -203,27 +203,42 @@ RAL_DEV const _Float16* wtile(const _Float16* Wt, int KT, int mt, int kt, int p)
 // unit is what the product costs: one-row-tile units (MT = 1) request the fragments of up to eight chunks together (64
 // registers), two-row-tile units (the fc1 phase, whose GELU epilogue gives the other waves work meanwhile) keep one chunk
 // in flight under the MFMAs of the current one.
-template <int MT, int TT>
+// MODE 0: residual pieces scaled by 2^11 (f16_split2): result = acc + 2^-11 accx.  MODE 1 / 2: both operands were scaled
+// into fp16's upper range and carry UNSCALED residuals (f16_split2u): 1 = the three products go into acc alone (blocks of
+// at least four tiles: with fewer, consecutive MFMAs into one tile wait for each other), 2 = cross terms still in accx,
+// result = acc + accx
+template <int MT, int TT, int ONE = 0>
 RAL_DEV void h2_mma(const f16x8 (&a)[MT][2], const _Float16* xr, int xplane, int ldx, f32x4 (&acc)[MT][TT], f32x4 (&accx)[MT][TT]) {
   f16x8 b1[TT], b2[TT];
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) {
     b1[tt] = *reinterpret_cast<const f16x8*>(xr + 16 * tt * ldx); b2[tt] = *reinterpret_cast<const f16x8*>(xr + xplane + 16 * tt * ldx);
   }
-#pragma unroll
-  for (int tt = 0; tt < TT; ++tt)
-#pragma unroll
-    for (int mi = 0; mi < MT; ++mi) {
 #ifdef RAL_H2_ONEACC   // diagnostic (wrong scaling of the cross terms): what ONE accumulator per tile would be worth in registers / time
-      acc[mi][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mi][1], b1[tt], acc[mi][tt], 0, 0, 0);
-      acc[mi][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mi][0], b1[tt], acc[mi][tt], 0, 0, 0);
-      acc[mi][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mi][0], b2[tt], acc[mi][tt], 0, 0, 0);
+  constexpr bool one = true;
 #else
-      accx[mi][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mi][1], b1[tt], accx[mi][tt], 0, 0, 0);
-      acc[mi][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mi][0], b1[tt], acc[mi][tt], 0, 0, 0);
-      accx[mi][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mi][0], b2[tt], accx[mi][tt], 0, 0, 0);
+  constexpr bool one = ONE == 1;
 #endif
-    }
+  if constexpr (one) {
+    // product by product over all tiles of the block: consecutive MFMAs never write the same accumulator
+    // (three back-to-back into one tile would each wait for the one before)
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+          acc[mi][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mi][p == 0 ? 1 : 0], p == 1 ? b2[tt] : b1[tt], acc[mi][tt], 0, 0, 0);
+  } else {
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) {
+        accx[mi][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mi][1], b1[tt], accx[mi][tt], 0, 0, 0);
+        acc[mi][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mi][0], b1[tt], acc[mi][tt], 0, 0, 0);
+        accx[mi][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mi][0], b2[tt], accx[mi][tt], 0, 0, 0);
+      }
+  }
 }
 struct NoHook { RAL_DEV void operator()() const {} };
 constexpr int h2_group(int kc, int gmax) {   // largest divisor of kc that is <= gmax
@@ -234,7 +249,7 @@ constexpr int h2_group(int kc, int gmax) {   // largest divisor of kc that is <=
 // hook(): called once, after the first weight fragments of the unit are requested and before anything waits for them -
 // the place to request global data of a LATER phase (loads return in order: requested earlier, they would be waited for
 // together with the fragments)
-template <int K, int MT, int TT, class Hook = NoHook, int GMAX_ = 0>
+template <int K, int MT, int TT, class Hook = NoHook, int GMAX_ = 0, int ONE = 0>
 RAL_DEV void gemm_wx_h2(const _Float16* __restrict__ Wt, int KT, int mt0, int kt0, const _Float16* Xh, int xplane, int ldx,
                         int t0, f32x4 (&acc)[MT][TT], f32x4 (&accx)[MT][TT], Hook hook = Hook()) {
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
@@ -258,7 +273,7 @@ RAL_DEV void gemm_wx_h2(const _Float16* __restrict__ Wt, int KT, int mt0, int kt
         }
       if (k0 == 0) hook();
 #pragma unroll
-      for (int j = 0; j < GS; ++j) h2_mma<1, TT>(a[j], xr + (k0 + j) * 32, xplane, ldx, acc, accx);
+      for (int j = 0; j < GS; ++j) h2_mma<1, TT, ONE>(a[j], xr + (k0 + j) * 32, xplane, ldx, acc, accx);
     }
   } else {
     f16x8 a[MT][2], an[MT][2];
@@ -282,7 +297,7 @@ RAL_DEV void gemm_wx_h2(const _Float16* __restrict__ Wt, int KT, int mt0, int kt
       for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
         for (int p = 0; p < 2; ++p) an[mi][p] = *reinterpret_cast<const f16x8*>(wtile(Wt, KT, mt0 + mi, kt0 + kn, p));
-      h2_mma<MT, TT>(a, xr + kc * 32, xplane, ldx, acc, accx);
+      h2_mma<MT, TT, ONE>(a, xr + kc * 32, xplane, ldx, acc, accx);
     }
   }
 }
@@ -290,7 +305,7 @@ RAL_DEV void gemm_wx_h2(const _Float16* __restrict__ Wt, int KT, int mt0, int kt
 // One GEMM phase of a workgroup on split operands: out(M rows x ntiles * 16 tokens) = W x X^T (+ bias; row 0 of the output
 // = row 16 mt0 of W, bias[0] its bias), work units of MT x 2 tiles dealt round-robin to the waves; M % (16 MT) == 0, ntiles even.  The bias rows of a unit are requested
 // before its products.  epi(row0, tok, v) as in gemm_phase.
-template <int K, int MT, int GMAX, class Epi, class Hook>
+template <int K, int MT, int GMAX, int ONE, class Epi, class Hook>
 RAL_DEV void gemm_phase_h2_t(const _Float16* __restrict__ Wt, int KT, int mt0, int kt0, int M, const float* __restrict__ bias,
                              const _Float16* Xh, int xplane, int ldx, int ntiles, Epi& epi, Hook& hook) {
   constexpr int TT = 2;
@@ -308,16 +323,16 @@ RAL_DEV void gemm_phase_h2_t(const _Float16* __restrict__ Wt, int KT, int mt0, i
     for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) { acc[mi][tt] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[mi][tt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    if constexpr (std::is_same<Hook, NoHook>::value) gemm_wx_h2<K, MT, TT, NoHook, GMAX>(Wt, KT, mt0 + m * MT, kt0, Xh, xplane, ldx, t * TT * 16, acc, accx);
+    if constexpr (std::is_same<Hook, NoHook>::value) gemm_wx_h2<K, MT, TT, NoHook, GMAX, ONE>(Wt, KT, mt0 + m * MT, kt0, Xh, xplane, ldx, t * TT * 16, acc, accx);
     else {
       auto h1 = [&]() { if (u == wave) hook(); };
-      gemm_wx_h2<K, MT, TT, decltype(h1), GMAX>(Wt, KT, mt0 + m * MT, kt0, Xh, xplane, ldx, t * TT * 16, acc, accx, h1);
+      gemm_wx_h2<K, MT, TT, decltype(h1), GMAX, ONE>(Wt, KT, mt0 + m * MT, kt0, Xh, xplane, ldx, t * TT * 16, acc, accx, h1);
     }
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) {
-        f32x4 v = acc[mi][tt] + accx[mi][tt] * RAL_H2_SCALE;
+        f32x4 v = ONE == 1 ? acc[mi][tt] : (ONE == 2 ? acc[mi][tt] + accx[mi][tt] : acc[mi][tt] + accx[mi][tt] * RAL_H2_SCALE);
         v[0] += bv[mi].x; v[1] += bv[mi].y; v[2] += bv[mi].z; v[3] += bv[mi].w;
         epi((m * MT + mi) * 16 + 4 * g, (t * TT + tt) * 16 + r, v);
       }
@@ -328,12 +343,12 @@ RAL_DEV void gemm_phase_h2_t(const _Float16* __restrict__ Wt, int KT, int mt0, i
 // (Wt, KT): tiled planes of the matrix; the product uses its rows 16 mt0 .. + M and columns 32 kt0 .. + K
 // hook: see gemm_wx_h2; runs exactly once in every wave (inside its first unit)
 // GMAX: chunks of weight fragments requested together by a one-row-tile unit (0: eight, four with a hook)
-template <int K, int GMAX = 0, class Epi, class Hook = NoHook>
+template <int K, int GMAX = 0, int ONE = 0, class Epi, class Hook = NoHook>
 RAL_DEV void gemm_phase_h2(const _Float16* __restrict__ Wt, int KT, int mt0, int kt0, int M, const float* __restrict__ bias,
                            const _Float16* Xh, int xplane, int ldx, int ntiles, Epi epi, Hook hook = Hook()) {
   const int nw = blockDim.x >> 6;
-  if (M % 32 == 0 && (M / 32) * (ntiles / 2) >= nw) gemm_phase_h2_t<K, 2, GMAX>(Wt, KT, mt0, kt0, M, bias, Xh, xplane, ldx, ntiles, epi, hook);
-  else gemm_phase_h2_t<K, 1, GMAX>(Wt, KT, mt0, kt0, M, bias, Xh, xplane, ldx, ntiles, epi, hook);
+  if (M % 32 == 0 && (M / 32) * (ntiles / 2) >= nw) gemm_phase_h2_t<K, 2, GMAX, ONE>(Wt, KT, mt0, kt0, M, bias, Xh, xplane, ldx, ntiles, epi, hook);
+  else gemm_phase_h2_t<K, 1, GMAX, ONE>(Wt, KT, mt0, kt0, M, bias, Xh, xplane, ldx, ntiles, epi, hook);
 }
 
 // row stride (floats) of a token-major LDS tile of width C: +4 breaks the power-of-two stride for the

@@ -240,8 +240,10 @@ __global__ __launch_bounds__(6 * C) void k_qkv_fwd_ws(const float* __restrict__ 
 // desc[d] = {offset of the matrix in the parameter buffer (floats), rows M, columns K, first work item}; a work item is
 // eight consecutive columns of one row (16 bytes of each plane); the tiled planes of a matrix take the bytes of the
 // matrix's own place in a buffer shaped like the parameter buffer (2 planes x 2 bytes = 4 bytes per weight).
+// scale / unscaled: the backward's planes hold 2^8 W with unscaled residuals (products with operands that are scaled
+// themselves go into one accumulator, ral_device.hpp), the forward's W with the 2^11-scaled residual
 __global__ void k_tile_planes(const float* __restrict__ params, _Float16* __restrict__ wt, const int4* __restrict__ desc,
-                              int ndesc, int nwork) {
+                              int ndesc, int nwork, float scale, int unscaled) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nwork; i += gridDim.x * blockDim.x) {
     int d = 0;
     while (d + 1 < ndesc && desc[d + 1].w <= i) ++d;
@@ -252,17 +254,17 @@ __global__ void k_tile_planes(const float* __restrict__ params, _Float16* __rest
     const float xs[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
     f16x8 h1, h2;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { const H2 s2 = f16_split2(xs[e]); h1[e] = s2.a; h2[e] = s2.b; }
+    for (int e = 0; e < 8; ++e) { const H2 s2 = unscaled ? f16_split2u(xs[e] * scale) : f16_split2(xs[e] * scale); h1[e] = s2.a; h2[e] = s2.b; }
     const int mt = row >> 4, r = row & 15, kt = k8 >> 2, g = k8 & 3;
     _Float16* dst = wt + 2 * (size_t)D.x + ((size_t)(mt * (D.z >> 5) + kt) * 2) * 512 + (g * 16 + r) * 8;
     *reinterpret_cast<f16x8*>(dst) = h1;
     *reinterpret_cast<f16x8*>(dst + 512) = h2;
   }
 }
-void launch_tile_planes(const float* params, void* wt, const void* desc, int ndesc, int nwork, hipStream_t s) {
+void launch_tile_planes(const float* params, void* wt, const void* desc, int ndesc, int nwork, float scale, int unscaled, hipStream_t s) {
   if (ndesc <= 0) return;
   const int blocks = (nwork + 255) / 256;
-  k_tile_planes<<<blocks < 2048 ? blocks : 2048, 256, 0, s>>>(params, reinterpret_cast<_Float16*>(wt), reinterpret_cast<const int4*>(desc), ndesc, nwork);
+  k_tile_planes<<<blocks < 2048 ? blocks : 2048, 256, 0, s>>>(params, reinterpret_cast<_Float16*>(wt), reinterpret_cast<const int4*>(desc), ndesc, nwork, scale, unscaled);
 }
 
 // =================================================================================

@@ -21,7 +21,8 @@
 // columns, first work item} per matrix, nwork = sum of rows * columns / 8; a matrix's planes sit at twice its float offset
 // in `wt`).  wt == nullptr selects the fp32-MFMA kernels.
 bool qkv_fwd_uses_f16(int C);
-void launch_tile_planes(const float* params, void* wt, const void* desc, int ndesc, int nwork, hipStream_t s);
+void launch_tile_planes(const float* params, void* wt, const void* desc, int ndesc, int nwork, float scale, int unscaled_residual, hipStream_t s);
+#define RAL_WT_SCALE 256.0f   // the backward's (transposed) planes hold RAL_WT_SCALE * W with unscaled residuals
 void launch_qkv_fwd(int C, const float* x, const float* pe, const BlockP& w, const void* wt /* of Wqkv */, float* qkv, int N, int B, hipStream_t s);
 size_t attn_fwd_lds(int N, int HG, int Len);
 void launch_attn_fwd(const float* qkv, float* o_hm, float* lse, const float* table, int N, int H, int HG, int Len,
