@@ -605,7 +605,8 @@ static void run_block_bwd(RalModel* m, int bi, const float* dy, const float* ext
   { ProfScope p(m, K_ATTN_BWD, s);
     // (each lane's scratch: its share of the stat2 region followed by its share of the partials region)
     float* scratch = m->astat[k] + (size_t)w0 * (E1 / 2 + 2048);
-    launch_attn_bwd(qkv, o, dohm, lse, table, gtable, dqkv, scratch, N, H, m->hg_b[l], Len, B, s); }
+    launch_attn_bwd(qkv, o, dohm, lse, table, gtable, dqkv, scratch, (size_t)B * (E1 / 2 + 2048), N, H, m->hg_b[l], Len, B,
+                    (m->f16_split > 0 && attn_f16_default()) ? 1 : 0, s); }
   { ProfScope p(m, K_QKV_BWD, s);
     launch_qkv_bwd(C, dqkv, xin, m->pe[l], dx1, woff(extra, w0, E1), w, wt, m->paramsT, splitb ? m->whT : nullptr, gmax, g, woff(dx, w0, E1), N, B, s); }
   if (!m->want_dw) return;
@@ -1273,8 +1274,7 @@ int ral_attention_forward(const float* qkv, float* o, float* lse, const float* t
 
 int64_t ral_attention_backward_scratch_floats(int N, int H, int Len, int has_table, int B) {
   if (check_attn_args(N, H, has_table ? Len : 0, B)) return -1;
-  if (!attn_bwd_uses_stat2(N, has_table ? Len : 0, has_table != 0)) return 0;
-  return (int64_t)B * H * N * 2 + (int64_t)B * 2 * H * 64;
+  return (int64_t)attn_bwd_scratch_floats(N, H, has_table ? Len : 0, has_table != 0, B);
 }
 
 int ral_attention_backward(const float* qkv, const float* o, const float* d_o, const float* lse, const float* table,
@@ -1288,8 +1288,8 @@ int ral_attention_backward(const float* qkv, const float* o, const float* d_o, c
   if (need > 0 && (!scratch || scratch_floats < need))
     return fail("attention backward: this shape needs %lld floats of scratch (ral_attention_backward_scratch_floats), got %lld",
                 (long long)need, (long long)(scratch ? scratch_floats : 0));
-  launch_attn_bwd(qkv, o, d_o, lse, table, gtable, dqkv, need > 0 ? scratch : nullptr, N, H,
-                  attn_head_group(N, H, table ? Len : 0, true), table ? Len : 0, B, (hipStream_t)s);
+  launch_attn_bwd(qkv, o, d_o, lse, table, gtable, dqkv, need > 0 ? scratch : nullptr, need > 0 ? (size_t)scratch_floats : 0, N, H,
+                  attn_head_group(N, H, table ? Len : 0, true), table ? Len : 0, B, attn_f16_default(), (hipStream_t)s);
   HIP_OK(hipGetLastError());
   return 0;
 }

@@ -1,0 +1,721 @@
+// Attention backward of the SHORT windows (N = 32, 64, 128): wave-autonomous form.
+//
+// Reference op: MSAttention.forward's backward (model/raletransformer.py:291-322, model/transformer.py:289-323, R-wave bias
+// model/transformer.py:508-558) - the same arithmetic as k_attn_bwd (ral_bwd.hip): P is recomputed from q, k and the saved
+// log-sum-exp, S and dP are exact fp32 MFMA tiles with -lse / -delta as their C operands, sweep A accumulates dQ with a
+// query block on the lanes, sweep B dK / dV with a key block on the lanes.
+//
+// What is different is who owns a head.  k_attn_bwd gives a (window, head group) item to a 256 / 512-thread workgroup:
+// stage -> barrier -> sweeps -> barrier.  At N <= 128 an item's sweeps are as short as its staging pass (N = 64: 4.7 us of
+// tiles behind a 43 KB load), the waves of a workgroup sit in the same phase, and with two workgroups per CU half the
+// waves of a SIMD wait while the other half computes: 380 cycles per tile visit at N = 64 against 229 at N = 512 (r03).
+// Here ONE WAVE owns a head (two heads at N = 32) from its global loads to its stores:
+//   * its operands live in a private slice of the LDS (72 B per token: q log2 e, k, v, dO as 16-byte quads, -lse log2 e,
+//     -delta), written and read by that wave only - no workgroup barrier anywhere in the task loop;
+//   * the NEXT head's operands (q, k, v, dO, O, lse: 21 registers per token and lane) are requested before the current
+//     head's sweeps and land under them; delta = rowsum(dO O) and the scalings are applied on the way into the LDS;
+//   * the waves of a SIMD are at unrelated points of their tasks, so one wave's loads, LDS traffic and epilogue hide under
+//     the others' tiles without any scheduling on our side;
+//   * the R-wave table gradient is accumulated in an LDS copy for the whole life of the (persistent) workgroup and leaves
+//     as ONE row of partials per workgroup (plain stores; k_attn_tpart_reduce adds the rows): the per-item flush of
+//     k_attn_bwd was a 2048-link chain of same-address global atomics per table entry;
+//   * a tile takes the biased path only when ITS 16 queries and ITS 16 keys meet the window (k_attn_bwd decides per
+//     32-query block: at N = 64 half of all tile visits ran the table code for 16 of 4096 scores);
+//   * the sums over the four lane groups at the end of a block are a 4 x 4 register / row transpose plus three adds (7
+//     instructions per quad instead of 16) and every lane stores one float (256 contiguous bytes per wave-instruction).
+#include "ral_device.hpp"
+#include "ral_kernels.hpp"
+#include <stdio.h>
+#include <stdlib.h>
+#include <type_traits>
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+RAL_DEV f32x2 pk_fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+#define RAL_LOG2E 1.4426950408889634f
+#define RAL_LN2 0.6931471805599453f
+
+#ifndef RAL_ATTNW_UNROLL
+#define RAL_ATTNW_UNROLL 1   // key / query tiles per trip of the sweep loops
+#endif
+#ifndef RAL_ATTNW_WPE
+#define RAL_ATTNW_WPE 3   // waves per SIMD the register budget is sized for (168 registers)
+#endif
+
+// sum of a per-lane quad over the four 16-lane rows of the wave: lane (r, g) ends with component g of the total
+RAL_DEV float quad_rows_sum(float x, float y, float z, float w) {
+  float v[4] = {x, y, z, w};
+  rows_transpose4(v);
+  return (v[0] + v[1]) + (v[2] + v[3]);
+}
+
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+struct H2x4 { h16x4 a, b; };   // x = a + b to ~2^-23 relative (2^-25 absolute for small x), element-wise
+RAL_DEV H2x4 split4(float4 x) {
+  H2x4 r;
+  const H2 s0 = f16_split2u(x.x), s1 = f16_split2u(x.y), s2 = f16_split2u(x.z), s3 = f16_split2u(x.w);
+  r.a = h16x4{s0.a, s1.a, s2.a, s3.a}; r.b = h16x4{s0.b, s1.b, s2.b, s3.b};
+  return r;
+}
+RAL_DEV float f4absmax(float4 v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
+
+// F16: the S and dP tiles on the f16 matrix cores.  A 16 x 16 tile of q k^T at head_dim 4 is a K = 4 product; with both
+// operands as fp16 PAIRS (x = h1 + h2, unscaled residual) the four piece products of the four dims are exactly one
+// v_mfma_f32_16x16x16_f16: lane group g' carries piece pair (g' >> 1, g' & 1) over the four dims, i.e. the A operand of a
+// lane is plane (g >> 1) of its row's token and the B operand plane (g & 1) of its column's token - one 8-byte LDS read
+// each, no packing instruction.  Beside the tile's vector work such an MFMA costs 10.6 cycles per SIMD slot against 41.7
+// for v_mfma_f32_16x16x4_f32 (tools/diag/valu_probe.hip, kinds 23-26: 164.5 -> 102.2 cycles per sweep-A tile).
+// Range: dO and v are multiplied by one power of two per task first (largest magnitude into [2^13, 2^14): dP is linear in
+// both, the factor leaves with the results), q and k are not (S goes through the exponential); their pieces carry an
+// ABSOLUTE error of 2^-25 below |x| = 2^-2, which is what matters for a score, and 2^-23 relative above.
+template <int NT, bool TAB, bool F16, int QT>
+__global__ __launch_bounds__(256, RAL_ATTNW_WPE) void k_attn_bwd_w(const float* qkv, const float* o_hm, const float* do_hm,
+                                                                   const float* lse, const float* __restrict__ table,
+                                                                   float* __restrict__ tpart, float* dqkv, int H, int Len_rt,
+                                                                   int ntask) {
+  constexpr int HW = NT >= 64 ? 1 : 64 / NT;   // heads per task
+  constexpr int T = HW * NT, TPL = T / 64;     // tokens per task, tokens per lane
+  constexpr int WSZ = T * (F16 ? 30 : 18);     // floats of LDS per wave
+  constexpr int NB = NT / (16 * QT);           // query (key) blocks per head
+  static_assert(NT % (16 * QT) == 0 && T % 64 == 0, "window length");
+  constexpr int NBU = NB <= 2 ? NB : 1;        // unrolled blocks (a static store count for the wait, see the task loop)
+  // Tiles are ROTATED by SH tokens when there is an R-wave table: tile x covers tokens (x + SH .. x + SH + 15) mod NT.  The
+  // window is centred (off + Len / 2 = NT / 2, a multiple of 16), so unrotated it always straddles a tile boundary and
+  // meets 2 x 2 tiles per head; rotated by 8 a window of up to 16 tokens sits inside ONE tile.  Attention sums over all
+  // keys in any order, so the rotation only changes index arithmetic.
+  constexpr int SH = TAB ? 8 : 0, MSK = NT - 1;
+  extern __shared__ float4 smem4[];
+  float* sm = reinterpret_cast<float*>(smem4);
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // fp32 tiles (quads per token): Q32 = q log2 e, K32, D32 = dO (and V32 without F16); pair planes (F16): Qp, Kp, Vp, Dp,
+  // plane p of a tile at + p * 2 T floats, the four halves of token t at float index 2 t
+  float* Q32 = sm + wave * WSZ;
+  float* K32 = Q32 + 4 * T;
+  float* D32 = K32 + 4 * T;
+  float* V32 = D32 + 4 * T;              // !F16 only
+  float* Qp = D32 + 4 * T;               // F16 only (same place as V32)
+  float* Kp = Qp + 4 * T;
+  float* Vp = Kp + 4 * T;
+  float* Dp = Vp + 4 * T;
+  float* Ls = F16 ? Dp + 4 * T : V32 + 4 * T;   // -lse * log2(e)   (negated: C operands of the S / dP tiles)
+  float* Dl = Ls + T;                           // -rowsum(dO * O) (F16: times the task's scale)
+  const int Len = TAB ? Len_rt : 0;
+  const int ntab = TAB ? (2 * Len - 1) * H : 0;
+  float* tab = sm + 4 * WSZ;     // bias * log2(e), (2 Len - 1, H)
+  float* dtab = tab + ntab;
+  const int off = (NT - Len) >> 1;
+  if constexpr (TAB) {
+    for (int i = threadIdx.x; i < ntab; i += blockDim.x) { tab[i] = table[i] * RAL_LOG2E; dtab[i] = 0.f; }
+    __syncthreads();
+  }
+  // does the rotated range [x0, x0 + w) meet the window?  (wave-uniform; a window that reaches into the first SH tokens
+  // wraps in rotated coordinates: every tile takes the table path then, the per-element test stays exact)
+  auto meets = [&](int x0, int w) -> bool {
+    return TAB && (off < SH || (x0 < off + Len - SH && x0 + w > off - SH));
+  };
+  const int xe0 = !TAB ? NT : (off < SH ? 0 : ((off - SH) & ~15));
+  const int xe1 = !TAB ? NT : (off < SH ? NT : ((off + Len - SH + 15) & ~15));
+  const int stride = gridDim.x * 4;
+  int task = blockIdx.x * 4 + wave;
+  float inv = 1.f;               // F16: 1 / (scale of dO x scale of v) of the task in the LDS
+
+  // operands of one task in flight (PREF: one token per lane): q, k, v, dO, O quads and lse
+  float4 pq, pk, pv, pd, po;
+  float pl;
+  auto task_ptrs = [&](int tk, const float4*& gq, const float4*& gk, const float4*& gv, const float4*& gd, const float4*& go,
+                       const float*& gl) {
+    const int hh = tk * HW, win = hh / H, h0 = hh - win * H;
+    gq = reinterpret_cast<const float4*>(qkv) + ((size_t)win * 3 * H + h0) * NT;
+    gk = gq + (size_t)H * NT;
+    gv = gk + (size_t)H * NT;
+    const size_t hq = ((size_t)win * H + h0) * NT;
+    gd = reinterpret_cast<const float4*>(do_hm) + hq;
+    go = reinterpret_cast<const float4*>(o_hm) + hq;
+    gl = lse + hq;
+  };
+  auto put = [&](int t, float4 q, float4 k, float4 v, float4 d, float4 o, float l, float cd, float cv) {
+    const float4 ql = f4scale(q, RAL_LOG2E);
+    reinterpret_cast<float4*>(Q32)[t] = ql;
+    reinterpret_cast<float4*>(K32)[t] = k;
+    reinterpret_cast<float4*>(D32)[t] = d;
+    Ls[t] = -l * RAL_LOG2E;
+    if constexpr (F16) {
+      auto planes = [&](float* X, float4 x) {
+        const H2x4 s2 = split4(x);
+        *reinterpret_cast<h16x4*>(X + 2 * t) = s2.a;
+        *reinterpret_cast<h16x4*>(X + 2 * T + 2 * t) = s2.b;
+      };
+      planes(Qp, ql); planes(Kp, k); planes(Vp, f4scale(v, cv)); planes(Dp, f4scale(d, cd));
+      Dl[t] = -f4dot(d, o) * (cd * cv);
+    } else {
+      reinterpret_cast<float4*>(V32)[t] = v;
+      Dl[t] = -f4dot(d, o);
+    }
+  };
+  // the task's powers of two for dO and v (largest magnitude into [2^13, 2^14)); returns 1 / their product
+  auto scales = [&](float md, float mv, float& cd, float& cv) -> float {
+    const unsigned bd = __float_as_uint(group_max<64>(md)), bv = __float_as_uint(group_max<64>(mv));
+    cd = h2_row_scale(bd); cv = h2_row_scale(bv);
+    return h2_row_unscale(bd) * h2_row_unscale(bv);
+  };
+  auto request = [&](int tk) {
+    const float4 *gq, *gk, *gv, *gd, *go; const float* gl;
+    task_ptrs(tk, gq, gk, gv, gd, go, gl);
+    pq = gq[lane]; pk = gk[lane]; pv = gv[lane]; pd = gd[lane]; po = go[lane]; pl = gl[lane];
+  };
+  auto deposit = [&]() {
+    float cd = 1.f, cv = 1.f;
+    if constexpr (F16) inv = scales(f4absmax(pd), f4absmax(pv), cd, cv);
+    put(lane, pq, pk, pv, pd, po, pl, cd, cv);
+  };
+  auto stage = [&](int tk) {   // request + deposit in one go (all loads of the task in flight together)
+    const float4 *gq, *gk, *gv, *gd, *go; const float* gl;
+    task_ptrs(tk, gq, gk, gv, gd, go, gl);
+    float4 q[TPL], k[TPL], v[TPL], d[TPL], o[TPL]; float l[TPL];
+#pragma unroll
+    for (int u = 0; u < TPL; ++u) {
+      const int t = lane + 64 * u;
+      q[u] = gq[t]; k[u] = gk[t]; v[u] = gv[t]; d[u] = gd[t]; o[u] = go[t]; l[u] = gl[t];
+    }
+    float cd = 1.f, cv = 1.f;
+    if constexpr (F16) {
+      float md = 0.f, mv = 0.f;
+#pragma unroll
+      for (int u = 0; u < TPL; ++u) { md = fmaxf(md, f4absmax(d[u])); mv = fmaxf(mv, f4absmax(v[u])); }
+      inv = scales(md, mv, cd, cv);
+    }
+#pragma unroll
+    for (int u = 0; u < TPL; ++u) put(lane + 64 * u, q[u], k[u], v[u], d[u], o[u], l[u], cd, cv);
+  };
+  // MFMA operands of the token on this lane's row (A) / column (B) of a tile
+  auto opA = [&](const float* X, int tok) -> h16x4 { return *reinterpret_cast<const h16x4*>(X + (g >> 1) * 2 * T + 2 * tok); };
+  auto opB = [&](const float* X, int tok) -> h16x4 { return *reinterpret_cast<const h16x4*>(X + (g & 1) * 2 * T + 2 * tok); };
+  auto mm = [&](h16x4 a, h16x4 b, f32x4 c) -> f32x4 { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); };
+  // Order inside a trip: request the next task's operands, sweep (and store) the current one, THEN wait for the request
+  // and move it into the LDS.  With the wait at the top of the next trip (across the back edge) the compiler could not
+  // count the stores issued since and waited for them too - a store round trip exposed per task; here the loads, the
+  // (statically counted) stores and the wait are straight-line code and the wait is s_waitcnt vmcnt(<stores after>).
+  // Two tokens per lane (N = 128) would be 42 registers in flight, which the register allocator answers by waiting for
+  // the loads at once and parking them in scratch; there a task is ~13 us of tiles behind a ~2 us load and the other
+  // waves of the SIMD cover it: no prefetch, the operands are requested and deposited at the top of the trip.
+  constexpr bool PREF = TPL == 1;
+  if constexpr (PREF) { if (task < ntask) { request(task); deposit(); } }
+  while (task < ntask) {
+    const int next = task + stride;
+    if constexpr (PREF) { request(next < ntask ? next : task); asm volatile("" ::: "memory"); }   // (the last task re-requests its own operands: no branch around the loads)
+    else stage(task);
+    const int hh = task * HW, win = hh / H, h0 = hh - win * H;
+    float* dbase = dqkv + (size_t)win * 3 * H * NT * 4;
+    const float oscale = F16 ? inv : 1.f;
+#pragma unroll
+    for (int hl = 0; hl < HW; ++hl) {
+      const int head = h0 + hl, tb = hl * NT;   // tb: first token of the head in the task's tiles
+      const float* Lh = Ls + tb; const float* Eh = Dl + tb;
+      // ---------------- sweep A: dQ (query block on the lanes, loop over key tiles) ----------------
+#pragma unroll NBU
+      for (int qb = 0; qb < NB; ++qb) {
+        const int q0 = qb * 16 * QT;
+        const float4* K4 = reinterpret_cast<const float4*>(K32) + tb;
+        float qf[QT], df[QT];
+        h16x4 qh[QT], dh[QT];
+        f32x4 lq[QT], dl[QT];
+        f32x2 dq01[QT], dq23[QT];
+        bool qin[QT];
+        int qtok[QT];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+          const int q = (q0 + 16 * qt + SH + r) & MSK;
+          qtok[qt] = q;
+          if constexpr (F16) { qh[qt] = opB(Qp, tb + q); dh[qt] = opB(Dp, tb + q); }
+          else { qf[qt] = Q32[(tb + q) * 4 + g]; df[qt] = D32[(tb + q) * 4 + g]; }
+          const float l = Lh[q], d = Eh[q];
+          lq[qt] = f32x4{l, l, l, l}; dl[qt] = f32x4{d, d, d, d};
+          dq01[qt] = f32x2{0.f, 0.f}; dq23[qt] = f32x2{0.f, 0.f};
+          qin[qt] = meets(q0 + 16 * qt, 16);
+        }
+        auto tileA = [&](int kt, auto biased) {
+          const int kr = tb + ((kt + SH + r) & MSK), k4i = (kt + SH + 4 * g) & MSK;
+          float kf, vf; h16x4 kh, vh;
+          if constexpr (F16) { kh = opA(Kp, kr); vh = opA(Vp, kr); }
+          else { kf = K32[kr * 4 + g]; vf = V32[kr * 4 + g]; }
+          float4 k4[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) k4[j] = K4[k4i + j];
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt) {
+            f32x4 s, dp;
+            if constexpr (F16) { s = mm(kh, qh[qt], lq[qt]); dp = mm(vh, dh[qt], dl[qt]); }
+            else { s = mfma4(kf, qf[qt], lq[qt]); dp = mfma4(vf, df[qt], dl[qt]); }   // s - lse, dP - delta   [key 4g+j][query r]
+            float ds[4];
+            if (decltype(biased)::value && qin[qt]) {
+              // (the four table reads are unconditional - clamped index - and issued together: one LDS round trip per tile)
+              const int qi = qtok[qt] - off;
+              const bool qok = (unsigned)qi < (unsigned)Len;
+              const int rel0 = qi - (k4i - off) + Len - 1;
+              int e[4]; bool in[4]; float b[4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                in[j] = qok && (unsigned)(k4i + j - off) < (unsigned)Len;
+                e[j] = min(max(rel0 - j, 0), 2 * Len - 2) * H + head;
+              }
+#pragma unroll
+              for (int j = 0; j < 4; ++j) b[j] = tab[e[j]];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) ds[j] = __builtin_amdgcn_exp2f(s[j] + (in[j] ? b[j] : 0.f)) * dp[j];
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                if (in[j]) atomicAdd(dtab + e[j], ds[j] * oscale);
+            } else {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) ds[j] = __builtin_amdgcn_exp2f(s[j]) * dp[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              dq01[qt] = pk_fma2(f32x2{ds[j], ds[j]}, f32x2{k4[j].x, k4[j].y}, dq01[qt]);
+              dq23[qt] = pk_fma2(f32x2{ds[j], ds[j]}, f32x2{k4[j].z, k4[j].w}, dq23[qt]);
+            }
+          }
+        };
+        // key tiles that meet the R-wave window run the table code (only for the query tiles that meet it too); the
+        // others stay in branch-free loops
+        const bool anyq = meets(q0, 16 * QT);
+        const int e0 = anyq ? xe0 : NT, e1 = anyq ? xe1 : NT;
+#pragma unroll RAL_ATTNW_UNROLL
+        for (int kt = 0; kt < e0; kt += 16) tileA(kt, std::false_type{});
+        if constexpr (TAB) {
+#pragma unroll 1
+          for (int kt = e0; kt < e1; kt += 16) tileA(kt, std::true_type{});
+#pragma unroll RAL_ATTNW_UNROLL
+          for (int kt = e1; kt < NT; kt += 16) tileA(kt, std::false_type{});
+        }
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+          const float v = quad_rows_sum(dq01[qt][0], dq01[qt][1], dq23[qt][0], dq23[qt][1]);
+          dbase[((size_t)head * NT + qtok[qt]) * 4 + g] = (0.5f * oscale) * v;   // q = 0.5 (h Wq^T + b)
+        }
+      }
+      // ---------------- sweep B: dK, dV (key block on the lanes, loop over query tiles) ----------------
+#pragma unroll NBU
+      for (int kb = 0; kb < NB; ++kb) {
+        const int k0 = kb * 16 * QT;
+        const float4* Q4 = reinterpret_cast<const float4*>(Q32) + tb;
+        const float4* D4 = reinterpret_cast<const float4*>(D32) + tb;
+        float kf[QT], vf[QT];
+        h16x4 kh[QT], vh[QT];
+        f32x2 dk01[QT], dk23[QT], dv01[QT], dv23[QT];
+        bool kin[QT];
+        int ktok[QT];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+          const int k = (k0 + 16 * t + SH + r) & MSK;
+          ktok[t] = k;
+          if constexpr (F16) { kh[t] = opB(Kp, tb + k); vh[t] = opB(Vp, tb + k); }
+          else { kf[t] = K32[(tb + k) * 4 + g]; vf[t] = V32[(tb + k) * 4 + g]; }
+          dk01[t] = f32x2{0.f, 0.f}; dk23[t] = f32x2{0.f, 0.f}; dv01[t] = f32x2{0.f, 0.f}; dv23[t] = f32x2{0.f, 0.f};
+          kin[t] = meets(k0 + 16 * t, 16);
+        }
+        auto tileB = [&](int qt, auto biased) {
+          const int qr = tb + ((qt + SH + r) & MSK), q4i = (qt + SH + 4 * g) & MSK;
+          float qa, da; h16x4 qah, dah;
+          if constexpr (F16) { qah = opA(Qp, qr); dah = opA(Dp, qr); }
+          else { qa = Q32[qr * 4 + g]; da = D32[qr * 4 + g]; }
+          const float4 l4 = *reinterpret_cast<const float4*>(Lh + q4i);
+          const float4 d4 = *reinterpret_cast<const float4*>(Eh + q4i);
+          float4 q4[4], o4[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { q4[j] = Q4[q4i + j]; o4[j] = D4[q4i + j]; }
+#pragma unroll
+          for (int t = 0; t < QT; ++t) {
+            f32x4 s, dp;
+            if constexpr (F16) { s = mm(qah, kh[t], f32x4{l4.x, l4.y, l4.z, l4.w}); dp = mm(dah, vh[t], f32x4{d4.x, d4.y, d4.z, d4.w}); }
+            else { s = mfma4(qa, kf[t], f32x4{l4.x, l4.y, l4.z, l4.w}); dp = mfma4(da, vf[t], f32x4{d4.x, d4.y, d4.z, d4.w}); }   // [query 4g+j][key r]
+            if (decltype(biased)::value && kin[t]) {
+              const int ki = ktok[t] - off;
+              const bool kok = (unsigned)ki < (unsigned)Len;
+              const int rel0 = (q4i - off) - ki + Len - 1;
+              float b[4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) b[j] = tab[min(max(rel0 + j, 0), 2 * Len - 2) * H + head];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) s[j] += (kok && (unsigned)(q4i + j - off) < (unsigned)Len) ? b[j] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float p = __builtin_amdgcn_exp2f(s[j]);
+              const float ds = p * dp[j];
+              dv01[t] = pk_fma2(f32x2{p, p}, f32x2{o4[j].x, o4[j].y}, dv01[t]);
+              dv23[t] = pk_fma2(f32x2{p, p}, f32x2{o4[j].z, o4[j].w}, dv23[t]);
+              dk01[t] = pk_fma2(f32x2{ds, ds}, f32x2{q4[j].x, q4[j].y}, dk01[t]);
+              dk23[t] = pk_fma2(f32x2{ds, ds}, f32x2{q4[j].z, q4[j].w}, dk23[t]);
+            }
+          }
+        };
+        const bool anyk = meets(k0, 16 * QT);
+        const int e0 = anyk ? xe0 : NT, e1 = anyk ? xe1 : NT;
+#pragma unroll RAL_ATTNW_UNROLL
+        for (int qt = 0; qt < e0; qt += 16) tileB(qt, std::false_type{});
+        if constexpr (TAB) {
+#pragma unroll 1
+          for (int qt = e0; qt < e1; qt += 16) tileB(qt, std::true_type{});
+#pragma unroll RAL_ATTNW_UNROLL
+          for (int qt = e1; qt < NT; qt += 16) tileB(qt, std::false_type{});
+        }
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+          const float vk = quad_rows_sum(dk01[t][0], dk01[t][1], dk23[t][0], dk23[t][1]);
+          const float vv = quad_rows_sum(dv01[t][0], dv01[t][1], dv23[t][0], dv23[t][1]);
+          const size_t kk = ((size_t)head * NT + ktok[t]) * 4 + g;
+          dbase[(size_t)H * NT * 4 + kk] = vk * (RAL_LN2 * oscale);      // Q32 carried log2(e)
+          dbase[(size_t)2 * H * NT * 4 + kk] = vv;
+        }
+      }
+    }
+    if constexpr (PREF) deposit();
+    task = next;
+  }
+  if constexpr (TAB) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < ntab; i += blockDim.x) tpart[(size_t)blockIdx.x * ntab + i] = dtab[i];
+  }
+}
+
+// =====================================================================================================================
+// Long windows (N >= 256): the workgroup form of k_attn_bwd (ral_bwd.hip) - an item = (window, head group), staged once
+// into the LDS, sweep A / sweep B tasks dealt to the waves - with the S and dP tiles on the f16 matrix cores as above.
+// LDS per token: fp32 quads q log2 e, k, dO (the vector-ALU operands of the dq / dk / dv products) + pair planes of q, k,
+// v, dO (token-interleaved: [h1 x 4 | h2 x 4] = 16 bytes, so that v and dO are converted IN PLACE once the head's scale
+// is known) + -lse, -delta: 120 bytes, 512 threads, two workgroups per CU.
+// The staging pass is cut in two by one more barrier: pass 1 writes everything that needs no scale and raises the head's
+// max |v|, max |dO| (wave maximum, one LDS atomic per wave and tensor); pass 2 scales and splits v and dO.
+// The R-wave table gradient stays in the LDS for the life of the workgroup (all H heads) and leaves as one row of
+// partials per workgroup (k_attn_tpart_reduce).
+// =====================================================================================================================
+template <int QT, bool TAB>
+__global__ __launch_bounds__(512, 4) void k_attn_bwd_h(const float* __restrict__ qkv, const float* __restrict__ o_hm,
+                                                       const float* __restrict__ do_hm, const float* __restrict__ lse,
+                                                       const float* __restrict__ table, float* __restrict__ tpart,
+                                                       float* __restrict__ dqkv, int N, int H, int HG, int Len_rt, int B) {
+  extern __shared__ float4 smem4[];
+  float* sm = reinterpret_cast<float*>(smem4);
+  const int T = HG * N;
+  float* Q32 = sm;                 // q * log2(e)
+  float* K32 = Q32 + 4 * T;
+  float* D32 = K32 + 4 * T;
+  float* Qp = D32 + 4 * T;         // pair planes, token-interleaved
+  float* Kp = Qp + 4 * T;
+  float* Vp = Kp + 4 * T;
+  float* Dp = Vp + 4 * T;
+  float* Ls = Dp + 4 * T;          // -lse * log2(e)
+  float* Dl = Ls + T;              // -rowsum(dO * O) * scale
+  unsigned* mx = reinterpret_cast<unsigned*>(Dl + T);   // [HG][2]: bits of max |dO|, max |v| of the item's heads
+  const int Len = TAB ? Len_rt : 0;
+  const int ntab = TAB ? (2 * Len - 1) * H : 0;
+  float* tab = reinterpret_cast<float*>(mx + 2 * HG);   // bias * log2(e), (2 Len - 1, H)
+  float* dtab = tab + ntab;
+  const int ngrp = H / HG;
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+  const int off = (N - Len) >> 1;
+  const int kb0 = TAB ? (off & ~15) : N, kb1 = TAB ? ((off + Len + 15) & ~15) : N;
+  for (int i = threadIdx.x; i < ntab; i += blockDim.x) { tab[i] = table[i] * RAL_LOG2E; dtab[i] = 0.f; }
+  auto opA = [&](const float* X, int tok) -> h16x4 { return *reinterpret_cast<const h16x4*>(X + 4 * tok + 2 * (g >> 1)); };
+  auto opB = [&](const float* X, int tok) -> h16x4 { return *reinterpret_cast<const h16x4*>(X + 4 * tok + 2 * (g & 1)); };
+  auto mm = [&](h16x4 a, h16x4 b, f32x4 c) -> f32x4 { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); };
+  auto put_planes = [&](float* X, int t, float4 x) {
+    const H2x4 s2 = split4(x);
+    *reinterpret_cast<h16x4*>(X + 4 * t) = s2.a;
+    *reinterpret_cast<h16x4*>(X + 4 * t + 2) = s2.b;
+  };
+  for (int item = blockIdx.x; item < B * ngrp; item += gridDim.x) {
+    const int win = item / ngrp, h0 = (item - win * ngrp) * HG;
+    const float* base = qkv + (size_t)win * 3 * H * N * 4;
+    float* dbase = dqkv + (size_t)win * 3 * H * N * 4;
+    const size_t hq0 = ((size_t)win * H + h0) * N;
+    __syncthreads();   // every wave is done with the previous item's tiles and scales
+    if (threadIdx.x < 2 * HG) mx[threadIdx.x] = 0u;
+    __syncthreads();
+    // ---- staging pass 1: the six loads of an index are issued together; everything that needs no scale is written
+    {
+      const float4* gq = reinterpret_cast<const float4*>(base + (size_t)h0 * N * 4);
+      const float4* gk = reinterpret_cast<const float4*>(base + (size_t)(H + h0) * N * 4);
+      const float4* gv = reinterpret_cast<const float4*>(base + (size_t)(2 * H + h0) * N * 4);
+      const float4* gd = reinterpret_cast<const float4*>(do_hm) + hq0;
+      const float4* go = reinterpret_cast<const float4*>(o_hm) + hq0;
+      const int bd = blockDim.x;
+      for (int i0 = 0; i0 < T; i0 += 2 * bd) {      // (T is a multiple of 256: whole waves fall on one side of it)
+        const int ia = i0 + threadIdx.x, ib = ia + bd;
+        const bool hb = ib < T;
+        const int ic = hb ? ib : ia;
+        const float4 q0 = gq[ia], q1 = gq[ic], k0 = gk[ia], k1 = gk[ic], v0 = gv[ia], v1 = gv[ic];
+        const float4 d0 = gd[ia], d1 = gd[ic], o0 = go[ia], o1 = go[ic];
+        const float l0 = lse[hq0 + ia], l1 = lse[hq0 + ic];
+        auto one = [&](int t, float4 q, float4 k, float4 v, float4 d, float4 o, float l) {
+          const float4 ql = f4scale(q, RAL_LOG2E);
+          reinterpret_cast<float4*>(Q32)[t] = ql;
+          reinterpret_cast<float4*>(K32)[t] = k;
+          reinterpret_cast<float4*>(D32)[t] = d;
+          reinterpret_cast<float4*>(Vp)[t] = v;            // fp32 for now: split in place by pass 2
+          put_planes(Qp, t, ql); put_planes(Kp, t, k);
+          Ls[t] = -l * RAL_LOG2E; Dl[t] = -f4dot(d, o);
+          const float md = group_max<64>(f4absmax(d)), mv = group_max<64>(f4absmax(v));
+          if (lane == 0) { const int hl = t / N; atomicMax(mx + 2 * hl, __float_as_uint(md)); atomicMax(mx + 2 * hl + 1, __float_as_uint(mv)); }
+        };
+        if (ia < T) one(ia, q0, k0, v0, d0, o0, l0);
+        if (hb) one(ib, q1, k1, v1, d1, o1, l1);
+      }
+    }
+    __syncthreads();
+    // ---- staging pass 2: v and dO times their head's power of two, split in place; delta times both
+    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+      const int hl = t / N;
+      const float cd = h2_row_scale(mx[2 * hl]), cv = h2_row_scale(mx[2 * hl + 1]);
+      const float4 v = reinterpret_cast<const float4*>(Vp)[t], d = reinterpret_cast<const float4*>(D32)[t];
+      put_planes(Vp, t, f4scale(v, cv)); put_planes(Dp, t, f4scale(d, cd));
+      Dl[t] *= cd * cv;
+    }
+    __syncthreads();
+    const int nblk = N / (16 * QT);
+    // ---------------- sweep A: dQ (query block on the lanes, loop over key tiles) ----------------
+    for (int task = wave; task < HG * nblk; task += nw) {
+      const int hl = task / nblk, q0 = (task - hl * nblk) * 16 * QT, tb = hl * N, head = h0 + hl;
+      const float oscale = h2_row_unscale(mx[2 * hl]) * h2_row_unscale(mx[2 * hl + 1]);
+      const float4* K4 = reinterpret_cast<const float4*>(K32) + tb;
+      h16x4 qh[QT], dh[QT];
+      f32x4 lq[QT], dl[QT];
+      f32x2 dq01[QT], dq23[QT];
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        const int q = tb + q0 + 16 * qt + r;
+        qh[qt] = opB(Qp, q); dh[qt] = opB(Dp, q);
+        const float l = Ls[q], d = Dl[q];
+        lq[qt] = f32x4{l, l, l, l}; dl[qt] = f32x4{d, d, d, d};
+        dq01[qt] = f32x2{0.f, 0.f}; dq23[qt] = f32x2{0.f, 0.f};
+      }
+      auto tileA = [&](int kt, auto biased) {
+        const h16x4 kh = opA(Kp, tb + kt + r), vh = opA(Vp, tb + kt + r);
+        float4 k4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) k4[j] = K4[kt + 4 * g + j];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+          f32x4 s = mm(kh, qh[qt], lq[qt]);               // s - lse      [key 4g+j][query r]
+          const f32x4 dp = mm(vh, dh[qt], dl[qt]);        // (dP - delta) * scale
+          float ds[4];
+          if constexpr (decltype(biased)::value) {
+            const int qi = q0 + 16 * qt + r - off;
+            const bool qok = (unsigned)qi < (unsigned)Len;
+            const int rel0 = qi - (kt + 4 * g - off) + Len - 1;
+            int e[4]; bool in[4]; float b[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              in[j] = qok && (unsigned)(kt + 4 * g + j - off) < (unsigned)Len;
+              e[j] = min(max(rel0 - j, 0), 2 * Len - 2) * H + head;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = tab[e[j]];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ds[j] = __builtin_amdgcn_exp2f(s[j] + (in[j] ? b[j] : 0.f)) * dp[j];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (in[j]) atomicAdd(dtab + e[j], ds[j] * oscale);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ds[j] = __builtin_amdgcn_exp2f(s[j]) * dp[j];
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            dq01[qt] = pk_fma2(f32x2{ds[j], ds[j]}, f32x2{k4[j].x, k4[j].y}, dq01[qt]);
+            dq23[qt] = pk_fma2(f32x2{ds[j], ds[j]}, f32x2{k4[j].z, k4[j].w}, dq23[qt]);
+          }
+        }
+      };
+      const bool qbias = TAB && (q0 < off + Len) && (q0 + 16 * QT > off);
+      const int e0 = qbias ? kb0 : N, e1 = qbias ? kb1 : N;
+      for (int kt = 0; kt < e0; kt += 16) tileA(kt, std::false_type{});
+      if constexpr (TAB) {
+        for (int kt = e0; kt < e1; kt += 16) tileA(kt, std::true_type{});
+        for (int kt = e1; kt < N; kt += 16) tileA(kt, std::false_type{});
+      }
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        const float v = quad_rows_sum(dq01[qt][0], dq01[qt][1], dq23[qt][0], dq23[qt][1]);
+        dbase[((size_t)head * N + q0 + 16 * qt + r) * 4 + g] = (0.5f * oscale) * v;   // q = 0.5 (h Wq^T + b)
+      }
+    }
+    // ---------------- sweep B: dK, dV (key block on the lanes, loop over query tiles) ----------------
+    for (int task = wave; task < HG * nblk; task += nw) {
+      const int hl = task / nblk, k0 = (task - hl * nblk) * 16 * QT, tb = hl * N, head = h0 + hl;
+      const float oscale = h2_row_unscale(mx[2 * hl]) * h2_row_unscale(mx[2 * hl + 1]);
+      const float4* Q4 = reinterpret_cast<const float4*>(Q32) + tb;
+      const float4* D4 = reinterpret_cast<const float4*>(D32) + tb;
+      h16x4 kh[QT], vh[QT];
+      f32x2 dk01[QT], dk23[QT], dv01[QT], dv23[QT];
+#pragma unroll
+      for (int t = 0; t < QT; ++t) {
+        const int k = tb + k0 + 16 * t + r;
+        kh[t] = opB(Kp, k); vh[t] = opB(Vp, k);
+        dk01[t] = f32x2{0.f, 0.f}; dk23[t] = f32x2{0.f, 0.f}; dv01[t] = f32x2{0.f, 0.f}; dv23[t] = f32x2{0.f, 0.f};
+      }
+      auto tileB = [&](int qt, auto biased) {
+        const h16x4 qah = opA(Qp, tb + qt + r), dah = opA(Dp, tb + qt + r);
+        const float4 l4 = *reinterpret_cast<const float4*>(Ls + tb + qt + 4 * g);
+        const float4 d4 = *reinterpret_cast<const float4*>(Dl + tb + qt + 4 * g);
+        float4 q4[4], o4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { q4[j] = Q4[qt + 4 * g + j]; o4[j] = D4[qt + 4 * g + j]; }
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+          f32x4 s = mm(qah, kh[t], f32x4{l4.x, l4.y, l4.z, l4.w});        // S[query 4g+j][key r] - lse
+          const f32x4 dp = mm(dah, vh[t], f32x4{d4.x, d4.y, d4.z, d4.w});  // (dP[query][key] - delta) * scale
+          if constexpr (decltype(biased)::value) {
+            const int ki = k0 + 16 * t + r - off;
+            const bool kok = (unsigned)ki < (unsigned)Len;
+            const int rel0 = (qt + 4 * g - off) - ki + Len - 1;
+            float b[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = tab[min(max(rel0 + j, 0), 2 * Len - 2) * H + head];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[j] += (kok && (unsigned)(qt + 4 * g + j - off) < (unsigned)Len) ? b[j] : 0.f;
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float p = __builtin_amdgcn_exp2f(s[j]);
+            const float ds = p * dp[j];
+            dv01[t] = pk_fma2(f32x2{p, p}, f32x2{o4[j].x, o4[j].y}, dv01[t]);
+            dv23[t] = pk_fma2(f32x2{p, p}, f32x2{o4[j].z, o4[j].w}, dv23[t]);
+            dk01[t] = pk_fma2(f32x2{ds, ds}, f32x2{q4[j].x, q4[j].y}, dk01[t]);
+            dk23[t] = pk_fma2(f32x2{ds, ds}, f32x2{q4[j].z, q4[j].w}, dk23[t]);
+          }
+        }
+      };
+      const bool kbias = TAB && (k0 < off + Len) && (k0 + 16 * QT > off);
+      const int e0 = kbias ? kb0 : N, e1 = kbias ? kb1 : N;
+      for (int qt = 0; qt < e0; qt += 16) tileB(qt, std::false_type{});
+      if constexpr (TAB) {
+        for (int qt = e0; qt < e1; qt += 16) tileB(qt, std::true_type{});
+        for (int qt = e1; qt < N; qt += 16) tileB(qt, std::false_type{});
+      }
+#pragma unroll
+      for (int t = 0; t < QT; ++t) {
+        const float vk = quad_rows_sum(dk01[t][0], dk01[t][1], dk23[t][0], dk23[t][1]);
+        const float vv = quad_rows_sum(dv01[t][0], dv01[t][1], dv23[t][0], dv23[t][1]);
+        const size_t kk = ((size_t)head * N + k0 + 16 * t + r) * 4 + g;
+        dbase[(size_t)H * N * 4 + kk] = vk * (RAL_LN2 * oscale);      // Q32 carried log2(e)
+        dbase[(size_t)2 * H * N * 4 + kk] = vv;
+      }
+    }
+  }
+  if constexpr (TAB) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < ntab; i += blockDim.x) tpart[(size_t)blockIdx.x * ntab + i] = dtab[i];
+  }
+}
+
+// gtable[i] += sum over the workgroups' rows of partials: one WAVE per table entry (lane l adds rows l, l + 64, ...: every
+// load of the launch is independent; a thread per entry walking the rows was a 200-link chain of memory round trips,
+// + 50 us behind a 120 us kernel)
+__global__ __launch_bounds__(256) void k_attn_tpart_reduce(const float* __restrict__ tpart, float* __restrict__ gtable, int ntab, int nrow) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= ntab) return;
+  float a0 = 0.f, a1 = 0.f;
+  int b = lane;
+  for (; b + 64 < nrow; b += 128) { a0 += tpart[(size_t)b * ntab + i]; a1 += tpart[(size_t)(b + 64) * ntab + i]; }
+  if (b < nrow) a0 += tpart[(size_t)b * ntab + i];
+  const float t = group_sum<64>(a0 + a1);
+  if (lane == 0) atomicAdd(gtable + i, t);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+int attn_f16_default() {
+  static const int m = [] { const char* v = getenv("RAL_ATTN_F16"); return v ? atoi(v) : 1; }();
+  return m;
+}
+static int attnw_mode() {   // RAL_ATTN_BWD_W=0: never (the workgroup kernels of ral_bwd.hip take every shape)
+  static const int m = [] { const char* v = getenv("RAL_ATTN_BWD_W"); return v ? atoi(v) : 1; }();
+  return m;
+}
+// upper bound of the grid (what the scratch is sized for): one workgroup per four tasks, at most 1024
+static int attnw_grid_max(int N, int H, int B) {
+  const int hw = N >= 64 ? 1 : 64 / N;
+  const int ntask = B * H / hw, g = (ntask + 3) / 4;
+  return g < 1024 ? g : 1024;
+}
+// the grid of a launch: a whole number of resident rounds (workgroups per CU x 256 CUs) - 1024 workgroups on 768 slots
+// would run a second round one third full (RAL_GRID_ATTNW overrides)
+template <class K>
+static int attnw_grid(K kernel, size_t lds, int N, int H, int B) {
+  static const int genv = [] { const char* v = getenv("RAL_GRID_ATTNW"); return v ? atoi(v) : 0; }();
+  const int gmax = attnw_grid_max(N, H, B);
+  if (genv > 0) return genv < gmax ? genv : gmax;
+  int occ = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, lds) != hipSuccess || occ < 1) occ = 3;
+  const int slots = 256 * (occ > 4 ? 4 : occ);
+  return slots < gmax ? slots : gmax;
+}
+bool attn_bwd_w_takes(int N, int H, int Len, bool table) {
+  if (!attnw_mode()) return false;
+  if (N != 32 && N != 64 && N != 128) return false;
+  if (N == 32 && (H & 1)) return false;
+  if (table && (2 * Len - 1) * H > 2048) return false;
+  return true;
+}
+size_t attn_bwd_w_scratch_floats(int N, int H, int Len, bool table, int B) {
+  if (!table || !attn_bwd_w_takes(N, H, Len, table)) return 0;
+  return (size_t)attnw_grid_max(N, H, B) * (size_t)((2 * Len - 1) * H);
+}
+// ---- long windows on the f16 matrix cores
+static int attnh_hg(int N, int H, int Len) {
+  int hg = H;
+  while (hg > 1 && attn_bwd_h_lds(N, H, hg, Len) > 64 * 1024) hg /= 2;
+  return hg;
+}
+size_t attn_bwd_h_lds(int N, int H, int hg, int Len) {
+  return ((size_t)30 * hg * N + 2 * hg + (Len > 0 ? (size_t)2 * (2 * Len - 1) * H : 0) + 4) * sizeof(float);
+}
+bool attn_bwd_h_takes(int N, int H, int Len, bool table) {
+  static const int on = [] { const char* v = getenv("RAL_ATTN_BWD_H"); return v ? atoi(v) : 1; }();
+  if (!on || N < 256 || N % 32 != 0) return false;
+  if (table && (2 * Len - 1) * H > 2048) return false;
+  return attn_bwd_h_lds(N, H, attnh_hg(N, H, Len), Len) <= 150 * 1024;
+}
+static int attnh_grid(int N, int H, int Len, int B) {
+  static const int gmax = [] { const char* v = getenv("RAL_GRID_ATTNH"); return v ? atoi(v) : 1024; }();
+  const int items = B * (H / attnh_hg(N, H, Len));
+  return items < gmax ? items : gmax;
+}
+size_t attn_bwd_h_scratch_floats(int N, int H, int Len, bool table, int B) {
+  if (!table || !attn_bwd_h_takes(N, H, Len, table)) return 0;
+  const int items = B * (H / attnh_hg(N, H, Len));
+  return (size_t)(items < 1024 ? items : 1024) * (size_t)((2 * Len - 1) * H);
+}
+void launch_attn_bwd_h(const float* qkv, const float* o_hm, const float* do_hm, const float* lse, const float* table,
+                       float* gtable, float* dqkv, float* tpart, int N, int H, int Len, int B, hipStream_t s) {
+  const int hg = attnh_hg(N, H, Len), grid = attnh_grid(N, H, Len, B);
+  const size_t lds = attn_bwd_h_lds(N, H, hg, Len);
+  const int ntab = table ? (2 * Len - 1) * H : 0;
+  if (table) { RAL_SET_LDS((k_attn_bwd_h<2, true>), lds); k_attn_bwd_h<2, true><<<grid, 512, lds, s>>>(qkv, o_hm, do_hm, lse, table, tpart, dqkv, N, H, hg, Len, B); }
+  else { RAL_SET_LDS((k_attn_bwd_h<2, false>), lds); k_attn_bwd_h<2, false><<<grid, 512, lds, s>>>(qkv, o_hm, do_hm, lse, nullptr, nullptr, dqkv, N, H, hg, 0, B); }
+  if (table) k_attn_tpart_reduce<<<(ntab + 3) / 4, 256, 0, s>>>(tpart, gtable, ntab, grid);
+}
+
+void launch_attn_bwd_w(const float* qkv, const float* o_hm, const float* do_hm, const float* lse, const float* table,
+                       float* gtable, float* dqkv, float* tpart, int N, int H, int Len, int B, int f16, hipStream_t s) {
+  const int hw = N >= 64 ? 1 : 64 / N, T = hw * N;
+  const int ntask = B * H / hw;
+  const int ntab = table ? (2 * Len - 1) * H : 0;
+  const size_t lds = ((size_t)4 * T * (f16 ? 30 : 18) + 2 * ntab) * sizeof(float);
+  int grid = 0;
+#define GO(n, tab, h, qt) { RAL_SET_LDS((k_attn_bwd_w<n, tab, h, qt>), lds); grid = attnw_grid(k_attn_bwd_w<n, tab, h, qt>, lds, N, H, B); \
+    k_attn_bwd_w<n, tab, h, qt><<<grid, 256, lds, s>>>(qkv, o_hm, do_hm, lse, table, tpart, dqkv, H, Len, ntask); }
+#define GOH(n, tab) { if (f16) GO(n, tab, true, 2) else GO(n, tab, false, 2) }
+  if (N == 32) { if (table) GOH(32, true) else GOH(32, false) }
+  else if (N == 64) {
+    static const int qt64 = [] { const char* v = getenv("RAL_ATTNW_QT64"); return v ? atoi(v) : 2; }();
+    if (qt64 == 4) { if (table) { if (f16) GO(64, true, true, 4) else GO(64, true, false, 4) } else { if (f16) GO(64, false, true, 4) else GO(64, false, false, 4) } }
+    else if (table) GOH(64, true) else GOH(64, false)
+  }
+  else { if (table) GOH(128, true) else GOH(128, false) }
+#undef GOH
+#undef GO
+  if (table) k_attn_tpart_reduce<<<(ntab + 3) / 4, 256, 0, s>>>(tpart, gtable, ntab, grid);
+}

@@ -1896,8 +1896,28 @@ bool attn_bwd_uses_stat2(int N, int Len, bool table) {
   return !table && N <= 128;
 }
 
+size_t attn_bwd_scratch_floats(int N, int H, int Len, bool table, int B) {
+  if (attn_bwd_w_takes(N, H, Len, table)) return attn_bwd_w_scratch_floats(N, H, Len, table, B);
+  if (attn_bwd_h_takes(N, H, Len, table)) return attn_bwd_h_scratch_floats(N, H, Len, table, B);   // (what its f16 form needs)
+  if (!attn_bwd_uses_stat2(N, Len, table)) return 0;
+  return (size_t)B * H * N * 2 + (size_t)B * 2 * H * 64;
+}
+
 void launch_attn_bwd(const float* qkv, const float* o_hm, const float* do_hm, const float* lse, const float* table,
-                     float* gtable, float* dqkv, float* stat2, int N, int H, int HG, int Len, int B, hipStream_t s) {
+                     float* gtable, float* dqkv, float* stat2, size_t scratch_floats, int N, int H, int HG, int Len, int B,
+                     int f16, hipStream_t s) {
+  // short windows: one wave per head, no workgroup barriers (ral_attn.hip)
+  if (attn_bwd_w_takes(N, H, Len, table != nullptr) &&
+      (stat2 ? scratch_floats : 0) >= attn_bwd_w_scratch_floats(N, H, Len, table != nullptr, B)) {
+    launch_attn_bwd_w(qkv, o_hm, do_hm, lse, table, gtable, dqkv, stat2, N, H, Len, B, f16, s);
+    return;
+  }
+  if (f16 && attn_bwd_h_takes(N, H, Len, table != nullptr) &&
+      (stat2 ? scratch_floats : 0) >= attn_bwd_h_scratch_floats(N, H, Len, table != nullptr, B)) {
+    launch_attn_bwd_h(qkv, o_hm, do_hm, lse, table, gtable, dqkv, stat2, N, H, Len, B, s);
+    return;
+  }
+  if (stat2 && scratch_floats < (size_t)B * H * N * 2 + (size_t)B * 2 * H * 64) stat2 = nullptr;
   // the two scalar-path sweeps; stat2 is scratch: (B, H, N, 2) floats handed from the query sweep to the key / value
   // sweep, followed by (B, 2, H, 64) floats of R-wave table-gradient partials
   if (stat2 && attn_bwd_uses_stat2(N, Len, table != nullptr)) {

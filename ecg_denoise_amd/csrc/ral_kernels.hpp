@@ -78,8 +78,25 @@ bool launch_mlp_bwd(int C, int nch, const float* dx2, const float* x1, const flo
                     float* a2c0, int N, int B, bool want_dw, hipStream_t s);
 size_t attn_bwd_lds(int N, int HG, int Len);
 bool attn_bwd_uses_stat2(int N, int Len, bool table);   // does launch_attn_bwd need its (B, H, N, 2) scratch for this shape?
+// scratch / scratch_floats: caller-owned; attn_bwd_scratch_floats() says how much the kernels chosen for a shape need
+size_t attn_bwd_scratch_floats(int N, int H, int Len, bool table, int B);
 void launch_attn_bwd(const float* qkv, const float* o_hm, const float* do_hm, const float* lse, const float* table,
-                     float* gtable, float* dqkv, float* stat2, int N, int H, int HG, int Len, int B, hipStream_t s);
+                     float* gtable, float* dqkv, float* scratch, size_t scratch_floats, int N, int H, int HG, int Len, int B,
+                     int f16, hipStream_t s);
+// f16: S and dP tiles as fp16-pair products on the f16 matrix cores (0: exact fp32 MFMA).  attn_f16_default(): 1 unless
+// RAL_ATTN_F16=0 (what the handle-free operator entry points use; a model handle follows its f16_split option)
+int attn_f16_default();
+// long windows with the S / dP tiles on the f16 matrix cores (ral_attn.hip; only with f16 != 0)
+size_t attn_bwd_h_lds(int N, int H, int hg, int Len);
+bool attn_bwd_h_takes(int N, int H, int Len, bool table);
+size_t attn_bwd_h_scratch_floats(int N, int H, int Len, bool table, int B);
+void launch_attn_bwd_h(const float* qkv, const float* o_hm, const float* do_hm, const float* lse, const float* table,
+                       float* gtable, float* dqkv, float* tpart, int N, int H, int Len, int B, hipStream_t s);
+// wave-autonomous kernels of the short windows (ral_attn.hip)
+bool attn_bwd_w_takes(int N, int H, int Len, bool table);
+size_t attn_bwd_w_scratch_floats(int N, int H, int Len, bool table, int B);
+void launch_attn_bwd_w(const float* qkv, const float* o_hm, const float* do_hm, const float* lse, const float* table,
+                       float* gtable, float* dqkv, float* tpart, int N, int H, int Len, int B, int f16, hipStream_t s);
 size_t qkv_bwd_lds(int C, int N);
 void launch_qkv_bwd(int C, const float* dqkv, const float* x, const float* pe, const float* dx1, const float* extra,
                     const BlockP& w, const BlockP& wt, const float* ptbase, const void* wtt /* as launch_mlp_bwd */, unsigned* gmax,

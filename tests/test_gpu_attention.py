@@ -91,16 +91,18 @@ def test_attention_operator_many_windows(N, H, Len):
 
 
 def test_attention_backward_rejects_missing_scratch():
-    """a shape that runs as two launches needs caller scratch; without it the call fails instead of allocating"""
+    """a shape whose kernels hand partial results from one launch to the next (here the per-workgroup R-wave table
+    gradient rows of the short-window kernel) needs caller scratch; without it the call fails instead of allocating"""
     L = _lib.lib()
-    N, H, B = 64, 16, 4
-    ns = L.ral_attention_backward_scratch_floats(N, H, 0, 0, B)
+    N, H, Len, B = 64, 16, 4, 4
+    ns = L.ral_attention_backward_scratch_floats(N, H, Len, 1, B)
     assert ns > 0
     qkv = torch.randn(B, 3 * H, N, 4, device=DEV)
+    table = torch.zeros(2 * Len - 1, H, device=DEV); gt = torch.zeros_like(table)
     o = torch.empty(B, H, N, 4, device=DEV); lse = torch.empty(B, H, N, device=DEV); dqkv = torch.empty_like(qkv)
-    _lib.check(L.ral_attention_forward(_vp(qkv), _vp(o), _vp(lse), None, N, H, 0, B, _stream()))
-    rc = L.ral_attention_backward(_vp(qkv), _vp(o), _vp(o), _vp(lse), None, None, _vp(dqkv), None, 0, N, H, 0, B, _stream())
+    _lib.check(L.ral_attention_forward(_vp(qkv), _vp(o), _vp(lse), _vp(table), N, H, Len, B, _stream()))
+    rc = L.ral_attention_backward(_vp(qkv), _vp(o), _vp(o), _vp(lse), _vp(table), _vp(gt), _vp(dqkv), None, 0, N, H, Len, B, _stream())
     assert rc != 0 and b"scratch" in L.ral_last_error()
     small = torch.empty(ns - 1, device=DEV)
-    rc = L.ral_attention_backward(_vp(qkv), _vp(o), _vp(o), _vp(lse), None, None, _vp(dqkv), _vp(small), ns - 1, N, H, 0, B, _stream())
+    rc = L.ral_attention_backward(_vp(qkv), _vp(o), _vp(o), _vp(lse), _vp(table), _vp(gt), _vp(dqkv), _vp(small), ns - 1, N, H, Len, B, _stream())
     assert rc != 0

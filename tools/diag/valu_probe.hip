@@ -3,6 +3,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -o valu_probe tools/diag/valu_probe.hip && ./valu_probe
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <vector>
 
 #define REP 64     // instructions of the measured kind per loop iteration
@@ -173,6 +174,41 @@ __global__ void k_probe(float* out, long long* cyc, float seed, int iters) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %1, %0" : "+v"(ac[i]) : "v"(ab));
       acc = ac[0] + ac[1] + ac[2] + ac[3];
+    } else if (KIND == 21 || KIND == 22) {   // 16 bare f16 MFMAs: 21 = 16x16x16 (K = 16: two operand registers), 22 = 16x16x32
+      typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+      typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+      h4 a4; h8 a8;
+      for (int i = 0; i < 4; ++i) a4[i] = (_Float16)a[i];
+      for (int i = 0; i < 8; ++i) a8[i] = (_Float16)a[i];
+      f32x4 ac[4] = {acc, acc, acc, acc};
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (KIND == 21) asm volatile("v_mfma_f32_16x16x16_f16 %0, %1, %1, %0" : "+v"(ac[i]) : "v"(a4));
+          else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %1, %0" : "+v"(ac[i]) : "v"(a8));
+        }
+      acc = ac[0] + ac[1] + ac[2] + ac[3];
+    } else if (KIND >= 23 && KIND <= 26) {   // backward sweep-A tile (2 MFMAs, 4 exp, 4 mul, 8 pk_fma): 23 = fp32 MFMAs, 24 = 16x16x16 f16, 25 = 16x16x32 f16, 26 = none
+      typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+      typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+      h4 a4; h8 a8;
+      for (int i = 0; i < 4; ++i) a4[i] = (_Float16)a[i];
+      for (int i = 0; i < 8; ++i) a8[i] = (_Float16)a[i];
+      f32x4 ac2 = acc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (KIND == 23) { acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], a[1], acc, 0, 0, 0); ac2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], a[3], ac2, 0, 0, 0); }
+        if (KIND == 24) { asm volatile("v_mfma_f32_16x16x16_f16 %0, %1, %1, %0" : "+v"(acc) : "v"(a4)); asm volatile("v_mfma_f32_16x16x16_f16 %0, %1, %1, %0" : "+v"(ac2) : "v"(a4)); }
+        if (KIND == 25) { asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %1, %0" : "+v"(acc) : "v"(a8)); asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %1, %0" : "+v"(ac2) : "v"(a8)); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("v_exp_f32 %0, %0" : "+v"(a[4 + i]));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[8 + i]) : "v"(m));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p[2 + (i & 3)]) : "v"(m2), "v"(c2));
+      }
+      acc += ac2;
     } else if (KIND == 8) {   // 16 bare mfma 16x16x4 f32 (4 accumulators)
       f32x4 ac[4] = {acc, acc, acc, acc};
 #pragma unroll
@@ -230,6 +266,13 @@ int main() {
   run<8>("v_mfma_f32_16x16x4_f32 (per mfma)", 16);
   run<12>("v_mfma_f32_16x16x32_bf16 (per mfma)", 16);
   run<20>("v_mfma_f32_16x16x32_bf16, asm-forced (per mfma)", 16);
+  run<21>("v_mfma_f32_16x16x16_f16 (per mfma)", 16);
+  run<22>("v_mfma_f32_16x16x32_f16 (per mfma)", 16);
+  run<26>("bwd tile A, no mfma (4exp 4mul 8pkfma)", 4);
+  run<23>("bwd tile A + 2 fp32 mfma 16x16x4", 4);
+  run<24>("bwd tile A + 2 f16 mfma 16x16x16", 4);
+  run<25>("bwd tile A + 2 f16 mfma 16x16x32", 4);
+  if (getenv("PROBE_SHORT")) return 0;
   run<13>("v_fma_f32 with an SGPR operand", REP);
   run<14>("v_pk_fma_f32 with an SGPR-pair operand", REP);
   run<15>("v_pk_fma_f32 op_sel broadcast", REP);
