@@ -423,6 +423,29 @@ def main():
     dt = tmax.item()
     loss = out["loss"].item()
 
+    # strict-fp32 leg: the same step with every product on the fp32 MFMA (f16_split = 0: no fp16-pair operand anywhere),
+    # timed right after the headline region on the same box, so that the line carries both arithmetics
+    fp32_leg = None
+    if inner is not None:
+        h = inner.eng.h
+        _lib.check(lib.ral_set_option(h, b"f16_split", 0))
+        n32 = max(5, min(10, a.steps))
+        for _ in range(2):
+            step()
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(n32):
+            step()
+        sync()
+        t32 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t32, op=dist.ReduceOp.MAX)
+        fp32_leg = {"ms_per_step": round(t32.item() / n32 * 1e3, 3), "value": round(B * world * n32 / t32.item(), 1),
+                    "unit": "windows/s", "steps": n32,
+                    "what": "the same step with ral_set_option f16_split=0: every contraction on v_mfma_f32_16x16x4_f32 / the vector ALU"}
+        _lib.check(lib.ral_set_option(h, b"f16_split", int(os.environ.get("RAL_F16_SPLIT", "64"))))
+        step(); sync()
+
     infer = infer_graph = None
     if not a.no_infer and a.config != "newrale":
         # BASELINE config 5's kernel path: eval-mode forward (BatchNorm running statistics), eager and hipGraph-captured
@@ -458,10 +481,11 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "arithmetic": "fp32 tensors and accumulators; the Linear layers of the two wide levels (C = 64, 128: forward, "
-                          "data-gradient and weight-gradient products) are error-compensated fp16-pair products on the f16 matrix "
-                          "cores (x = h1 + h2, three products per term, ~2^-21 relative; gradient operands scaled by a power of two "
-                          "per token / per launch); everything else on the fp32 MFMA / vector ALU.  ral_set_option f16_split=0: "
-                          "every product on the fp32 MFMA",
+                          "data-gradient and weight-gradient products) and the attention score tiles (S = q k^T, dP = dO v^T; "
+                          "head_dim 4) are error-compensated fp16-pair products on the f16 matrix cores (x = h1 + h2, ~2^-22 "
+                          "relative; operands brought into range by powers of two per token / head / launch, none clamped in "
+                          "the attention tiles); everything else on the fp32 MFMA / vector ALU.  fp32_mfma: the same step with "
+                          "ral_set_option f16_split=0 (every product on the fp32 MFMA)",
             "config": {"workload": W["text"], "global_batch": B * world, "parallelism": f"dp{world}", "sync_bn": True},
             "final_loss": round(loss, 6),
         }
@@ -489,6 +513,8 @@ def main():
             res["roofline"] = {"bound": "hbm", "kernel": "whole U-Net train step (all conv stages)", "achieved": round(ach, 1),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                                "measured": "stage-granular algorithmic bytes per window (SURVEY 8d) x windows / step time, per GPU"}
+        if fp32_leg is not None:
+            res["fp32_mfma"] = fp32_leg
         if infer is not None:
             res["infer_windows_per_s"] = round(infer, 1)
             res["infer_hipgraph_windows_per_s"] = round(infer_graph, 1)

@@ -13,6 +13,21 @@ import os as _os
 # half-way through it (measured, tools/diag/bucket_overlap.py: 100 % vs 51 % of the backward pass).  The variable is read
 # when the HIP runtime initialises, i.e. it must be set before the first GPU call of the process: importing this package
 # first does that; a caller that initialises the GPU earlier sets it itself.
+_HWQ_SET_LATE = False
+if "GPU_MAX_HW_QUEUES" not in _os.environ:
+    try:
+        import torch as _torch
+        _HWQ_SET_LATE = bool(_torch.cuda.is_initialized())   # the runtime is up already: the variable can no longer take effect
+    except Exception:                                       # pragma: no cover
+        pass
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+
+def hw_queues_set_too_late():
+    """True when this package was imported AFTER the process had initialised the GPU with GPU_MAX_HW_QUEUES unset: the
+    data-parallel trainer's early gradient bucket then shares a hardware queue with a compute chain and its all-reduce
+    runs after the backward pass instead of under it (dp.HipEngineAdapter warns once)."""
+    return _HWQ_SET_LATE
+
 
 from .model import ACDAE, DANet, NewRALE, RALENet, UNet, ralenet  # noqa: F401

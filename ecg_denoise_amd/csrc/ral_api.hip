@@ -41,6 +41,9 @@ static thread_local const char* g_sched_what = "";
     hipError_t e_ = (expr);                                                                  \
     if (e_ != hipSuccess && g_sched_err == hipSuccess) { g_sched_err = e_; g_sched_what = #expr; } \
   } while (0)
+// every entry point that records events / stream waits starts from a clean slate (an error remembered by a call that left
+// through another failure must not surface in a later, unrelated one) and ends with sched_check()
+static void sched_reset() { g_sched_err = hipSuccess; g_sched_what = ""; }
 static int sched_check() {
   if (g_sched_err == hipSuccess) return 0;
   const hipError_t e = g_sched_err;
@@ -249,6 +252,7 @@ struct RalModel {
   void* lanes = nullptr;   // LaneSet
   int n_lanes = 2;
   bool side_stream = true;
+  bool attn_f16 = true;      // attention score tiles (S, dP) as fp16-pair products - only while f16_split > 0 (option "attn_f16"; RAL_ATTN_F16=0)
   int f16_split = 64;         // narrowest width whose Linear layers (q/k/v projection, proj, fc1, fc2 of the forward) run as
                               // two-piece fp16 products on the f16 matrix cores (0 = none: fp32 MFMA everywhere)
   bool want_dw = true;      // false inside ral_backward_input: frozen weights, data gradients only
@@ -456,7 +460,8 @@ static void run_block_fwd(RalModel* m, int bi, const float* in, bool training, c
   float* o = woff(a.o, w0, E1);
   { ProfScope p(m, K_QKV_FWD, s); launch_qkv_fwd(C, x, m->pe[l], w, split ? m->wh + 2 * m->lay.blk[bi].wqkv : nullptr, qkv, N, B, s); }
   { ProfScope p(m, K_ATTN_FWD, s);
-    launch_attn_fwd(qkv, o, training ? woff(a.lse, w0, E1 / 4) : nullptr, table, N, H, m->hg_f[l], Len, B, s); }
+    launch_attn_fwd(qkv, o, training ? woff(a.lse, w0, E1 / 4) : nullptr, table, N, H, m->hg_f[l], Len, B,
+                    (m->f16_split > 0 && m->attn_f16) ? 1 : 0, s); }
   { ProfScope p(m, K_MLP_FWD, s);
     launch_mlp_fwd(C, m->nch_f[l], x, o, w, m->params, split ? m->wh : nullptr, training ? woff(a.x1, w0, E1) : nullptr,
                    (training && !mlp_bwd_is_fused(C, N)) ? woff(a.upre, w0, 4 * E1) : nullptr,
@@ -508,6 +513,7 @@ static void join_lanes(RalModel* m, hipStream_t s) {     // s continues after ev
 }
 
 static int fwd_begin(RalModel* m, const float* x, int B, int training, hipStream_t s) {
+  sched_reset();
   if (!m->params || !m->state) return fail("ral_bind was not called");
   if (B <= 0 || B > m->cfg.max_batch) return fail("batch %d outside (0, max_batch=%d]", B, m->cfg.max_batch);
   if (training && !m->cfg.train) return fail("handle was created with train=0");
@@ -526,6 +532,7 @@ static int fwd_begin(RalModel* m, const float* x, int B, int training, hipStream
 }
 
 static int fwd_end(RalModel* m, float* y, int B, int64_t global_windows, int training, hipStream_t s) {
+  sched_reset();
   const Layout& Y = m->lay;
   if (training) {
     launch_bn_finalize(m->bn_sums, (double)global_windows * m->L, m->params + Y.bn_w, m->params + Y.bn_b, m->ss,
@@ -533,7 +540,7 @@ static int fwd_end(RalModel* m, float* y, int B, int64_t global_windows, int tra
     launch_bn_apply8(m->a0, m->ss, m->x0, (size_t)B * m->L, s);
   }
   const bool tr = training != 0;
-  if (m->f16_split > 0) launch_tile_planes(m->params, m->wh, m->wdesc, m->ndesc, m->nwork, 1.0f, 0, s);   // split planes of the wide levels' weights
+  if (m->f16_split > 0) launch_tile_planes(m->params, m->wh, m->wdesc, m->ndesc, m->nwork, 0, s);   // split planes of the wide levels' weights
   const int nl = plan_lanes(m, B, s);
   fork_lanes(m, s);
   LaneSet* LS = lanes_of(m);
@@ -606,7 +613,7 @@ static void run_block_bwd(RalModel* m, int bi, const float* dy, const float* ext
     // (each lane's scratch: its share of the stat2 region followed by its share of the partials region)
     float* scratch = m->astat[k] + (size_t)w0 * (E1 / 2 + 2048);
     launch_attn_bwd(qkv, o, dohm, lse, table, gtable, dqkv, scratch, (size_t)B * (E1 / 2 + 2048), N, H, m->hg_b[l], Len, B,
-                    (m->f16_split > 0 && attn_f16_default()) ? 1 : 0, s); }
+                    (m->f16_split > 0 && m->attn_f16) ? 1 : 0, s); }
   { ProfScope p(m, K_QKV_BWD, s);
     launch_qkv_bwd(C, dqkv, xin, m->pe[l], dx1, woff(extra, w0, E1), w, wt, m->paramsT, splitb ? m->whT : nullptr, gmax, g, woff(dx, w0, E1), N, B, s); }
   if (!m->want_dw) return;
@@ -651,6 +658,7 @@ static void run_res_bwd(RalModel* m, int ri, const float* dy, const float* in, f
 }
 
 static int bwd_begin(RalModel* m, const float* dy, int B, hipStream_t s) {
+  sched_reset();
   if (!m->cfg.train) return fail("handle was created with train=0");
   if (!m->grads || !m->bn_sums) return fail("ral_bind: grads / bn_sums not bound");
   if (B != m->last_B) return fail("backward batch %d != forward batch %d", B, m->last_B);
@@ -658,7 +666,7 @@ static int bwd_begin(RalModel* m, const float* dy, int B, hipStream_t s) {
   HIP_OK(hipMemsetAsync(m->grads, 0, (size_t)Y.nparam * sizeof(float), s));
   HIP_OK(hipMemsetAsync(m->bn_sums + 32, 0, 32 * sizeof(double), s));
   launch_transpose_mats(m->params, m->paramsT, m->tdesc, m->tn, m->ttotal, s);
-  if (m->f16_split > 0) launch_tile_planes(m->paramsT, m->whT, m->wdescT, m->ndescT, m->nworkT, RAL_WT_SCALE, 1, s);
+  if (m->f16_split > 0) launch_tile_planes(m->paramsT, m->whT, m->wdescT, m->ndescT, m->nworkT, 1, s);
   HIP_OK(hipMemsetAsync(m->gmax, 0, 18 * 4 * 4 * sizeof(unsigned), s));
   float** gy = m->gy; float** gin = m->gin;
   const int nl = plan_lanes(m, B, s);
@@ -710,6 +718,7 @@ static int bwd_begin(RalModel* m, const float* dy, int B, hipStream_t s) {
 }
 
 static int bwd_end(RalModel* m, float* dx, int B, int64_t global_windows, hipStream_t s) {
+  sched_reset();
   const Layout& Y = m->lay;
   launch_conv1_bwd(m->cfg.leads, m->gin[0], m->a0, m->last_x, m->ss, m->params + Y.bn_w, m->bn_sums + 32,
                    (double)global_windows * m->L, m->grads + Y.conv1_w, m->grads + Y.conv1_b, dx ? m->dz0 : nullptr,
@@ -719,7 +728,7 @@ static int bwd_end(RalModel* m, float* dx, int B, int64_t global_windows, hipStr
   HIP_OK(hipEventRecord(m->ev_bwd_done, s));
   m->bwd_recorded = true;
   HIP_OK(hipGetLastError());
-  return 0;
+  return sched_check();
 }
 
 // ---------------------------------------------------------------------------------
@@ -916,6 +925,7 @@ int ral_create(const ral_config* cfg, ral_handle** out) {
     }
   }
   if (const char* v = getenv("RAL_F16_SPLIT")) m->f16_split = atoi(v);
+  m->attn_f16 = attn_f16_default() != 0;
   if (cfg->train) {
     m->side_stream = getenv("RAL_NO_SIDE_STREAM") == nullptr;
     std::vector<int> d;
@@ -1085,7 +1095,11 @@ int ral_grad_bucket_wait(ral_handle* h, int k, ral_stream s) {
   if (k == 1) {
     if (m->dec_lanes <= 0) return fail("bucket 1 is available after ral_backward_begin");
     LaneSet* LS = lanes_of(m);
-    static const int dbg = getenv("RAL_BUCKET_WAIT") ? atoi(getenv("RAL_BUCKET_WAIT")) : 3;   // diagnostic: 1 chains only, 2 side streams only, 0 none
+#ifdef RAL_DIAG   // diagnostic builds only (dropping a wait is a data race): 1 chains only, 2 side streams only, 0 none
+    static const int dbg = getenv("RAL_BUCKET_WAIT") ? atoi(getenv("RAL_BUCKET_WAIT")) : 3;
+#else
+    constexpr int dbg = 3;
+#endif
     for (int i = 0; i < m->dec_lanes; ++i) {
       if (dbg & 1) HIP_OK(hipStreamWaitEvent((hipStream_t)s, LS->l[i].ev_dec_main, 0));
       if (m->dec_side && (dbg & 2)) HIP_OK(hipStreamWaitEvent((hipStream_t)s, LS->l[i].ev_dec_side, 0));
@@ -1165,6 +1179,7 @@ int ral_set_option(ral_handle* h, const char* key, int value) {
   if (!strcmp(key, "lanes")) { m->n_lanes = value < 1 ? 1 : (value > MAX_LANES ? MAX_LANES : value); return 0; }
   if (!strcmp(key, "side_stream")) { m->side_stream = value != 0; return 0; }
   if (!strcmp(key, "f16_split")) { m->f16_split = value; return 0; }
+  if (!strcmp(key, "attn_f16")) { m->attn_f16 = value != 0; return 0; }
   return fail("unknown option %s", key);
 }
 
@@ -1267,7 +1282,7 @@ int ral_attention_forward(const float* qkv, float* o, float* lse, const float* t
                           ral_stream s) {
   if (!qkv || !o) return fail("attention: null pointer");
   if (check_attn_args(N, H, table ? Len : 0, B)) return -1;
-  launch_attn_fwd(qkv, o, lse, table, N, H, attn_head_group(N, H, table ? Len : 0, false), table ? Len : 0, B, (hipStream_t)s);
+  launch_attn_fwd(qkv, o, lse, table, N, H, attn_head_group(N, H, table ? Len : 0, false), table ? Len : 0, B, attn_f16_default(), (hipStream_t)s);
   HIP_OK(hipGetLastError());
   return 0;
 }

@@ -52,7 +52,7 @@ typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 struct H2x4 { h16x4 a, b; };   // x = a + b to ~2^-23 relative (2^-25 absolute for small x), element-wise
 RAL_DEV H2x4 split4(float4 x) {
   H2x4 r;
-  const H2 s0 = f16_split2u(x.x), s1 = f16_split2u(x.y), s2 = f16_split2u(x.z), s3 = f16_split2u(x.w);
+  const H2 s0 = f16_split2n(x.x), s1 = f16_split2n(x.y), s2 = f16_split2n(x.z), s3 = f16_split2n(x.w);
   r.a = h16x4{s0.a, s1.a, s2.a, s3.a}; r.b = h16x4{s0.b, s1.b, s2.b, s3.b};
   return r;
 }
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256, RAL_ATTNW_WPE) void k_attn_bwd_w(const float* 
     go = reinterpret_cast<const float4*>(o_hm) + hq;
     gl = lse + hq;
   };
-  auto put = [&](int t, float4 q, float4 k, float4 v, float4 d, float4 o, float l, float cd, float cv) {
+  auto put = [&](int t, float4 q, float4 k, float4 v, float4 d, float4 o, float l, float cd, float cv, float cq, float ck) {
     const float4 ql = f4scale(q, RAL_LOG2E);
     reinterpret_cast<float4*>(Q32)[t] = ql;
     reinterpret_cast<float4*>(K32)[t] = k;
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256, RAL_ATTNW_WPE) void k_attn_bwd_w(const float* 
         *reinterpret_cast<h16x4*>(X + 2 * t) = s2.a;
         *reinterpret_cast<h16x4*>(X + 2 * T + 2 * t) = s2.b;
       };
-      planes(Qp, ql); planes(Kp, k); planes(Vp, f4scale(v, cv)); planes(Dp, f4scale(d, cd));
+      planes(Qp, f4scale(ql, cq)); planes(Kp, f4scale(k, ck)); planes(Vp, f4scale(v, cv)); planes(Dp, f4scale(d, cd));
       Dl[t] = -f4dot(d, o) * (cd * cv);
     } else {
       reinterpret_cast<float4*>(V32)[t] = v;
@@ -164,9 +164,12 @@ __global__ __launch_bounds__(256, RAL_ATTNW_WPE) void k_attn_bwd_w(const float* 
     pq = gq[lane]; pk = gk[lane]; pv = gv[lane]; pd = gd[lane]; po = go[lane]; pl = gl[lane];
   };
   auto deposit = [&]() {
-    float cd = 1.f, cv = 1.f;
-    if constexpr (F16) inv = scales(f4absmax(pd), f4absmax(pv), cd, cv);
-    put(lane, pq, pk, pv, pd, po, pl, cd, cv);
+    float cd = 1.f, cv = 1.f, cq = 1.f, ck = 1.f;
+    if constexpr (F16) {
+      inv = scales(f4absmax(pd), f4absmax(pv), cd, cv);
+      pair_balance(group_max<64>(f4absmax(pq)) * RAL_LOG2E, group_max<64>(f4absmax(pk)), cq, ck);
+    }
+    put(lane, pq, pk, pv, pd, po, pl, cd, cv, cq, ck);
   };
   auto stage = [&](int tk) {   // request + deposit in one go (all loads of the task in flight together)
     const float4 *gq, *gk, *gv, *gd, *go; const float* gl;
@@ -177,15 +180,18 @@ __global__ __launch_bounds__(256, RAL_ATTNW_WPE) void k_attn_bwd_w(const float* 
       const int t = lane + 64 * u;
       q[u] = gq[t]; k[u] = gk[t]; v[u] = gv[t]; d[u] = gd[t]; o[u] = go[t]; l[u] = gl[t];
     }
-    float cd = 1.f, cv = 1.f;
+    float cd = 1.f, cv = 1.f, cq = 1.f, ck = 1.f;
     if constexpr (F16) {
-      float md = 0.f, mv = 0.f;
+      float md = 0.f, mv = 0.f, mq = 0.f, mk = 0.f;
 #pragma unroll
-      for (int u = 0; u < TPL; ++u) { md = fmaxf(md, f4absmax(d[u])); mv = fmaxf(mv, f4absmax(v[u])); }
+      for (int u = 0; u < TPL; ++u) {
+        md = fmaxf(md, f4absmax(d[u])); mv = fmaxf(mv, f4absmax(v[u])); mq = fmaxf(mq, f4absmax(q[u])); mk = fmaxf(mk, f4absmax(k[u]));
+      }
       inv = scales(md, mv, cd, cv);
+      pair_balance(group_max<64>(mq) * RAL_LOG2E, group_max<64>(mk), cq, ck);
     }
 #pragma unroll
-    for (int u = 0; u < TPL; ++u) put(lane + 64 * u, q[u], k[u], v[u], d[u], o[u], l[u], cd, cv);
+    for (int u = 0; u < TPL; ++u) put(lane + 64 * u, q[u], k[u], v[u], d[u], o[u], l[u], cd, cv, cq, ck);
   };
   // MFMA operands of the token on this lane's row (A) / column (B) of a tile
   auto opA = [&](const float* X, int tok) -> h16x4 { return *reinterpret_cast<const h16x4*>(X + (g >> 1) * 2 * T + 2 * tok); };
@@ -407,10 +413,10 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd_h(const float* __restrict__
   float* Dp = Vp + 4 * T;
   float* Ls = Dp + 4 * T;          // -lse * log2(e)
   float* Dl = Ls + T;              // -rowsum(dO * O) * scale
-  unsigned* mx = reinterpret_cast<unsigned*>(Dl + T);   // [HG][2]: bits of max |dO|, max |v| of the item's heads
+  unsigned* mx = reinterpret_cast<unsigned*>(Dl + T);   // [HG][4]: bits of max |dO|, |v|, |q log2 e|, |k| of the item's heads
   const int Len = TAB ? Len_rt : 0;
   const int ntab = TAB ? (2 * Len - 1) * H : 0;
-  float* tab = reinterpret_cast<float*>(mx + 2 * HG);   // bias * log2(e), (2 Len - 1, H)
+  float* tab = reinterpret_cast<float*>(mx + 4 * HG);   // bias * log2(e), (2 Len - 1, H)
   float* dtab = tab + ntab;
   const int ngrp = H / HG;
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
@@ -432,7 +438,7 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd_h(const float* __restrict__
     float* dbase = dqkv + (size_t)win * 3 * H * N * 4;
     const size_t hq0 = ((size_t)win * H + h0) * N;
     __syncthreads();   // every wave is done with the previous item's tiles and scales
-    if (threadIdx.x < 2 * HG) mx[threadIdx.x] = 0u;
+    if (threadIdx.x < 4 * HG) mx[threadIdx.x] = 0u;
     __syncthreads();
     // ---- staging pass 1: the six loads of an index are issued together; everything that needs no scale is written
     {
@@ -455,22 +461,30 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd_h(const float* __restrict__
           reinterpret_cast<float4*>(K32)[t] = k;
           reinterpret_cast<float4*>(D32)[t] = d;
           reinterpret_cast<float4*>(Vp)[t] = v;            // fp32 for now: split in place by pass 2
-          put_planes(Qp, t, ql); put_planes(Kp, t, k);
           Ls[t] = -l * RAL_LOG2E; Dl[t] = -f4dot(d, o);
           const float md = group_max<64>(f4absmax(d)), mv = group_max<64>(f4absmax(v));
-          if (lane == 0) { const int hl = t / N; atomicMax(mx + 2 * hl, __float_as_uint(md)); atomicMax(mx + 2 * hl + 1, __float_as_uint(mv)); }
+          const float mq = group_max<64>(f4absmax(ql)), mk = group_max<64>(f4absmax(k));
+          if (lane == 0) {
+            unsigned* m4 = mx + 4 * (t / N);
+            atomicMax(m4, __float_as_uint(md)); atomicMax(m4 + 1, __float_as_uint(mv));
+            atomicMax(m4 + 2, __float_as_uint(mq)); atomicMax(m4 + 3, __float_as_uint(mk));
+          }
         };
         if (ia < T) one(ia, q0, k0, v0, d0, o0, l0);
         if (hb) one(ib, q1, k1, v1, d1, o1, l1);
       }
     }
     __syncthreads();
-    // ---- staging pass 2: v and dO times their head's power of two, split in place; delta times both
+    // ---- staging pass 2: v and dO times their head's power of two, split in place; delta times both; q and k balanced
     for (int t = threadIdx.x; t < T; t += blockDim.x) {
-      const int hl = t / N;
-      const float cd = h2_row_scale(mx[2 * hl]), cv = h2_row_scale(mx[2 * hl + 1]);
+      const unsigned* m4 = mx + 4 * (t / N);
+      const float cd = h2_row_scale(m4[0]), cv = h2_row_scale(m4[1]);
+      float cq, ck;
+      pair_balance(__uint_as_float(m4[2]), __uint_as_float(m4[3]), cq, ck);
       const float4 v = reinterpret_cast<const float4*>(Vp)[t], d = reinterpret_cast<const float4*>(D32)[t];
       put_planes(Vp, t, f4scale(v, cv)); put_planes(Dp, t, f4scale(d, cd));
+      put_planes(Qp, t, f4scale(reinterpret_cast<const float4*>(Q32)[t], cq));
+      put_planes(Kp, t, f4scale(reinterpret_cast<const float4*>(K32)[t], ck));
       Dl[t] *= cd * cv;
     }
     __syncthreads();
@@ -478,7 +492,7 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd_h(const float* __restrict__
     // ---------------- sweep A: dQ (query block on the lanes, loop over key tiles) ----------------
     for (int task = wave; task < HG * nblk; task += nw) {
       const int hl = task / nblk, q0 = (task - hl * nblk) * 16 * QT, tb = hl * N, head = h0 + hl;
-      const float oscale = h2_row_unscale(mx[2 * hl]) * h2_row_unscale(mx[2 * hl + 1]);
+      const float oscale = h2_row_unscale(mx[4 * hl]) * h2_row_unscale(mx[4 * hl + 1]);
       const float4* K4 = reinterpret_cast<const float4*>(K32) + tb;
       h16x4 qh[QT], dh[QT];
       f32x4 lq[QT], dl[QT];
@@ -491,6 +505,8 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd_h(const float* __restrict__
         lq[qt] = f32x4{l, l, l, l}; dl[qt] = f32x4{d, d, d, d};
         dq01[qt] = f32x2{0.f, 0.f}; dq23[qt] = f32x2{0.f, 0.f};
       }
+      // (requesting the MFMA operands of the NEXT key tile ahead of the current tile's products was measured: 715 against
+      // 698 us at N = 512 - four waves per SIMD already cover the LDS round trip, the extra registers spill)
       auto tileA = [&](int kt, auto biased) {
         const h16x4 kh = opA(Kp, tb + kt + r), vh = opA(Vp, tb + kt + r);
         float4 k4[4];
@@ -545,7 +561,7 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd_h(const float* __restrict__
     // ---------------- sweep B: dK, dV (key block on the lanes, loop over query tiles) ----------------
     for (int task = wave; task < HG * nblk; task += nw) {
       const int hl = task / nblk, k0 = (task - hl * nblk) * 16 * QT, tb = hl * N, head = h0 + hl;
-      const float oscale = h2_row_unscale(mx[2 * hl]) * h2_row_unscale(mx[2 * hl + 1]);
+      const float oscale = h2_row_unscale(mx[4 * hl]) * h2_row_unscale(mx[4 * hl + 1]);
       const float4* Q4 = reinterpret_cast<const float4*>(Q32) + tb;
       const float4* D4 = reinterpret_cast<const float4*>(D32) + tb;
       h16x4 kh[QT], vh[QT];
@@ -663,6 +679,239 @@ size_t attn_bwd_w_scratch_floats(int N, int H, int Len, bool table, int B) {
   if (!table || !attn_bwd_w_takes(N, H, Len, table)) return 0;
   return (size_t)attnw_grid_max(N, H, B) * (size_t)((2 * Len - 1) * H);
 }
+// =====================================================================================================================
+// Attention FORWARD (softmax(q k^T + bias) v, raletransformer.py:299-316 / transformer.py:302-310) in the same two forms:
+// k_attn_fwd_w (N = 32, 64, 128: one wave per head, operands requested one task ahead) and k_attn_fwd_h (N >= 256: a
+// workgroup per (window, head group)), with the S tile on the f16 matrix cores when F16.  The softmax shift is the
+// Cauchy-Schwarz bound of k_attn_fwd (ral_fwd.hip): m[q] = |q| max|k| + max(bias, 0) enters the MFMA as its C operand;
+// a row whose sum underflows is redone with the exact running maximum.
+// =====================================================================================================================
+// exact recurrence for one query tile (lane = query r, keys 4g .. 4g + 3 of every tile; merged over the lane groups)
+template <bool F16, class SF, class BF, class VF>
+RAL_DEV void attn_fwd_exact(int NTK, SF score, BF bias, VF vrow, float4& o, float& mg, float& l) {
+  float mx = -INFINITY; l = 0.f; o = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int kt = 0; kt < NTK; kt += 16) {
+    f32x4 s = score(kt);
+    bias(kt, s);
+    const float mn = fmaxf(fmaxf(mx, fmaxf(s[0], s[1])), fmaxf(s[2], s[3]));
+    const float corr = __builtin_amdgcn_exp2f(mx - mn);
+    mx = mn; l *= corr; o = f4scale(o, corr);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float p = __builtin_amdgcn_exp2f(s[j] - mn);
+      const float4 v = vrow(kt, j);
+      l += p;
+      o.x = fmaf(p, v.x, o.x); o.y = fmaf(p, v.y, o.y); o.z = fmaf(p, v.z, o.z); o.w = fmaf(p, v.w, o.w);
+    }
+  }
+  mg = rows_max(mx);
+  const float sc = __builtin_amdgcn_exp2f(mx - mg);
+  l = rows_sum(l * sc);
+  o = make_float4(rows_sum(o.x * sc), rows_sum(o.y * sc), rows_sum(o.z * sc), rows_sum(o.w * sc));
+}
+
+template <int NT, bool TAB, bool F16>
+__global__ __launch_bounds__(256, (NT == 64 ? 3 : 4)) void k_attn_fwd_w(const float* qkv, float* o_hm, float* lse, const float* __restrict__ table,
+                                                       int H, int Len_rt, int ntask) {
+  constexpr int QT = 2;
+  constexpr int HW = NT >= 64 ? 1 : 64 / NT;
+  constexpr int T = HW * NT, TPL = T / 64;
+  constexpr int WSZ = T * 13;                  // floats of LDS per wave: q, k operand tiles + v quads + |q|
+  constexpr int NB = NT / (16 * QT);
+  constexpr int SH = TAB ? 8 : 0, MSK = NT - 1;   // rotated tiles (see k_attn_bwd_w)
+  constexpr int NBU = NB <= 2 ? NB : 1;
+  extern __shared__ float4 smem4[];
+  float* sm = reinterpret_cast<float*>(smem4);
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* Qx = sm + wave * WSZ;   // q log2 e: fp32 quads, or (F16) token-interleaved pair planes - 16 bytes per token either way
+  float* Kx = Qx + 4 * T;
+  float* V32 = Kx + 4 * T;
+  float* Mq = V32 + 4 * T;       // |q| (log2 units)
+  const int Len = TAB ? Len_rt : 0;
+  const int ntab = TAB ? (2 * Len - 1) * H : 0;
+  float* tab = sm + 4 * WSZ;     // bias * log2(e), (2 Len - 1, H)
+  float* bmax = tab + ntab;      // H: max(bias, 0) per head
+  const int off = (NT - Len) >> 1;
+  if constexpr (TAB) {
+    for (int i = threadIdx.x; i < ntab; i += blockDim.x) tab[i] = table[i] * RAL_LOG2E;
+    for (int h = threadIdx.x; h < H; h += blockDim.x) {
+      float m = 0.f;
+      for (int e = 0; e < 2 * Len - 1; ++e) m = fmaxf(m, table[e * H + h] * RAL_LOG2E);
+      bmax[h] = m;
+    }
+    __syncthreads();
+  }
+  auto meets = [&](int x0, int w) -> bool { return TAB && (off < SH || (x0 < off + Len - SH && x0 + w > off - SH)); };
+  const int xe0 = !TAB ? NT : (off < SH ? 0 : ((off - SH) & ~15));
+  const int xe1 = !TAB ? NT : (off < SH ? NT : ((off + Len - SH + 15) & ~15));
+  const int stride = gridDim.x * 4;
+  int task = blockIdx.x * 4 + wave;
+  float kmx = 0.f;               // max |k| of the task in the LDS (a bound for every head of the task)
+  float4 pq, pk, pv;
+  auto task_ptrs = [&](int tk, const float4*& gq, const float4*& gk, const float4*& gv) {
+    const int hh = tk * HW, win = hh / H, h0 = hh - win * H;
+    gq = reinterpret_cast<const float4*>(qkv) + ((size_t)win * 3 * H + h0) * NT;
+    gk = gq + (size_t)H * NT;
+    gv = gk + (size_t)H * NT;
+  };
+  auto put = [&](int t, float4 q, float4 k, float4 v, float cq, float ck) {
+    const float4 ql = f4scale(q, RAL_LOG2E);
+    if constexpr (F16) {
+      const H2x4 a = split4(f4scale(ql, cq)), b = split4(f4scale(k, ck));
+      *reinterpret_cast<h16x4*>(Qx + 4 * t) = a.a; *reinterpret_cast<h16x4*>(Qx + 4 * t + 2) = a.b;
+      *reinterpret_cast<h16x4*>(Kx + 4 * t) = b.a; *reinterpret_cast<h16x4*>(Kx + 4 * t + 2) = b.b;
+    } else {
+      reinterpret_cast<float4*>(Qx)[t] = ql; reinterpret_cast<float4*>(Kx)[t] = k;
+    }
+    reinterpret_cast<float4*>(V32)[t] = v;
+    Mq[t] = sqrtf(f4dot(ql, ql));
+  };
+  auto request = [&](int tk) {
+    const float4 *gq, *gk, *gv; task_ptrs(tk, gq, gk, gv);
+    pq = gq[lane]; pk = gk[lane]; pv = gv[lane];
+  };
+  auto deposit = [&]() {
+    kmx = sqrtf(group_max<64>(f4dot(pk, pk))) * 1.0000002f;
+    float cq = 1.f, ck = 1.f;
+    if constexpr (F16) pair_balance(group_max<64>(f4absmax(pq)) * RAL_LOG2E, group_max<64>(f4absmax(pk)), cq, ck);
+    put(lane, pq, pk, pv, cq, ck);
+  };
+  auto stage = [&](int tk) {
+    const float4 *gq, *gk, *gv; task_ptrs(tk, gq, gk, gv);
+    float4 q[TPL], k[TPL], v[TPL];
+#pragma unroll
+    for (int u = 0; u < TPL; ++u) { const int t = lane + 64 * u; q[u] = gq[t]; k[u] = gk[t]; v[u] = gv[t]; }
+    float m = 0.f, mq = 0.f, mk = 0.f;
+#pragma unroll
+    for (int u = 0; u < TPL; ++u) { m = fmaxf(m, f4dot(k[u], k[u])); mq = fmaxf(mq, f4absmax(q[u])); mk = fmaxf(mk, f4absmax(k[u])); }
+    kmx = sqrtf(group_max<64>(m)) * 1.0000002f;
+    float cq = 1.f, ck = 1.f;
+    if constexpr (F16) pair_balance(group_max<64>(mq) * RAL_LOG2E, group_max<64>(mk), cq, ck);
+#pragma unroll
+    for (int u = 0; u < TPL; ++u) put(lane + 64 * u, q[u], k[u], v[u], cq, ck);
+  };
+  auto opA = [&](const float* X, int tok) -> h16x4 { return *reinterpret_cast<const h16x4*>(X + 4 * tok + 2 * (g >> 1)); };
+  auto opB = [&](const float* X, int tok) -> h16x4 { return *reinterpret_cast<const h16x4*>(X + 4 * tok + 2 * (g & 1)); };
+  constexpr bool PREF = TPL == 1;
+  if constexpr (PREF) { if (task < ntask) { request(task); deposit(); } }
+  while (task < ntask) {
+    const int next = task + stride;
+    if constexpr (PREF) { request(next < ntask ? next : task); asm volatile("" ::: "memory"); }
+    else stage(task);
+    const int hh = task * HW, win = hh / H, h0 = hh - win * H;
+#pragma unroll
+    for (int hl = 0; hl < HW; ++hl) {
+      const int head = h0 + hl, tb = hl * NT;
+      const size_t hq0 = ((size_t)win * H + head) * NT;
+      const float4* V4 = reinterpret_cast<const float4*>(V32) + tb;
+      const float badd = TAB ? bmax[head] : 0.f;
+#pragma unroll NBU
+      for (int qb = 0; qb < NB; ++qb) {
+        const int q0 = qb * 16 * QT;
+        float qf[QT]; h16x4 qh[QT];
+        float mq[QT];
+        f32x4 nm[QT];
+        f32x2 l2[QT], o01[QT], o23[QT];
+        bool qin[QT];
+        int qtok[QT];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+          const int q = (q0 + 16 * qt + SH + r) & MSK;
+          qtok[qt] = q;
+          if constexpr (F16) qh[qt] = opB(Qx, tb + q); else qf[qt] = Qx[(tb + q) * 4 + g];
+          mq[qt] = Mq[tb + q] * kmx + badd;
+          nm[qt] = f32x4{-mq[qt], -mq[qt], -mq[qt], -mq[qt]};
+          l2[qt] = f32x2{0.f, 0.f}; o01[qt] = f32x2{0.f, 0.f}; o23[qt] = f32x2{0.f, 0.f};
+          qin[qt] = meets(q0 + 16 * qt, 16);
+        }
+        auto addbias = [&](int kt, int qtk, f32x4& s) {
+          const int k4i = (kt + SH + 4 * g) & MSK;
+          const int qi = qtk - off;
+          const bool qok = (unsigned)qi < (unsigned)Len;
+          const int rel0 = qi - (k4i - off) + Len - 1;
+          float b[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) b[j] = tab[min(max(rel0 - j, 0), 2 * Len - 2) * H + head];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) s[j] += (qok && (unsigned)(k4i + j - off) < (unsigned)Len) ? b[j] : 0.f;
+        };
+        auto tile = [&](int kt, auto biased) {
+          const int kr = tb + ((kt + SH + r) & MSK), k4i = (kt + SH + 4 * g) & MSK;
+          float kf; h16x4 kh;
+          if constexpr (F16) kh = opA(Kx, kr); else kf = Kx[kr * 4 + g];
+          float4 v4[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v4[j] = V4[k4i + j];
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt) {
+            f32x4 s;
+            if constexpr (F16) s = __builtin_amdgcn_mfma_f32_16x16x16f16(kh, qh[qt], nm[qt], 0, 0, 0);
+            else s = mfma4(kf, qf[qt], nm[qt]);                      // s - m, log2 units   [key 4g+j][query r]
+            if (decltype(biased)::value && qin[qt]) addbias(kt, qtok[qt], s);
+            const f32x2 p01 = f32x2{__builtin_amdgcn_exp2f(s[0]), __builtin_amdgcn_exp2f(s[1])};
+            const f32x2 p23 = f32x2{__builtin_amdgcn_exp2f(s[2]), __builtin_amdgcn_exp2f(s[3])};
+            l2[qt] += p01;
+            l2[qt] += p23;
+            o01[qt] = pk_fma2(f32x2{p01[0], p01[0]}, f32x2{v4[0].x, v4[0].y}, o01[qt]);
+            o23[qt] = pk_fma2(f32x2{p01[0], p01[0]}, f32x2{v4[0].z, v4[0].w}, o23[qt]);
+            o01[qt] = pk_fma2(f32x2{p01[1], p01[1]}, f32x2{v4[1].x, v4[1].y}, o01[qt]);
+            o23[qt] = pk_fma2(f32x2{p01[1], p01[1]}, f32x2{v4[1].z, v4[1].w}, o23[qt]);
+            o01[qt] = pk_fma2(f32x2{p23[0], p23[0]}, f32x2{v4[2].x, v4[2].y}, o01[qt]);
+            o23[qt] = pk_fma2(f32x2{p23[0], p23[0]}, f32x2{v4[2].z, v4[2].w}, o23[qt]);
+            o01[qt] = pk_fma2(f32x2{p23[1], p23[1]}, f32x2{v4[3].x, v4[3].y}, o01[qt]);
+            o23[qt] = pk_fma2(f32x2{p23[1], p23[1]}, f32x2{v4[3].z, v4[3].w}, o23[qt]);
+          }
+        };
+        const bool anyq = meets(q0, 16 * QT);
+        const int e0 = anyq ? xe0 : NT, e1 = anyq ? xe1 : NT;
+#pragma unroll 1
+        for (int kt = 0; kt < e0; kt += 16) tile(kt, std::false_type{});
+        if constexpr (TAB) {
+#pragma unroll 1
+          for (int kt = e0; kt < e1; kt += 16) tile(kt, std::true_type{});
+#pragma unroll 1
+          for (int kt = e1; kt < NT; kt += 16) tile(kt, std::false_type{});
+        }
+        bool redo = false;
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+          const float lv = rows_sum(l2[qt][0] + l2[qt][1]);
+          const float ov = quad_rows_sum(o01[qt][0], o01[qt][1], o23[qt][0], o23[qt][1]);
+          redo = redo || !(lv > 1e-30f);
+          o_hm[(hq0 + qtok[qt]) * 4 + g] = ov * (1.0f / lv);
+          if (lse && g == 0) lse[hq0 + qtok[qt]] = (mq[qt] + __builtin_amdgcn_logf(lv)) * RAL_LN2;   // natural-log units
+        }
+        if (__any(redo)) {   // (rolled, with the tile's values picked by static index: a run-time index would park the arrays in scratch)
+          static_assert(QT == 2, "two query tiles");
+#pragma unroll 1
+          for (int qt = 0; qt < QT; ++qt) {
+            const h16x4 qhv = qt ? qh[1] : qh[0];
+            const float qfv = qt ? qf[1] : qf[0];
+            const int qtk = qt ? qtok[1] : qtok[0];
+            const bool qinv = qt ? qin[1] : qin[0];
+            float4 o; float mg, l;
+            attn_fwd_exact<F16>(NT,
+                                [&](int kt) {
+                                  const int kr = tb + ((kt + SH + r) & MSK);
+                                  if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x16f16(opA(Kx, kr), qhv, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                                  else return mfma4(Kx[kr * 4 + g], qfv, f32x4{0.f, 0.f, 0.f, 0.f});
+                                },
+                                [&](int kt, f32x4& sv) { if (TAB && qinv && meets(kt, 16)) addbias(kt, qtk, sv); },
+                                [&](int kt, int j) { return V4[((kt + SH + 4 * g) & MSK) + j]; }, o, mg, l);
+            const float inv = 1.0f / l;
+            const float og = g == 0 ? o.x : (g == 1 ? o.y : (g == 2 ? o.z : o.w));
+            o_hm[(hq0 + qtk) * 4 + g] = og * inv;
+            if (lse && g == 0) lse[hq0 + qtk] = (mg + __builtin_amdgcn_logf(l)) * RAL_LN2;
+          }
+        }
+      }
+    }
+    if constexpr (PREF) deposit();
+    task = next;
+  }
+}
+
 // ---- long windows on the f16 matrix cores
 static int attnh_hg(int N, int H, int Len) {
   int hg = H;
@@ -670,7 +919,7 @@ static int attnh_hg(int N, int H, int Len) {
   return hg;
 }
 size_t attn_bwd_h_lds(int N, int H, int hg, int Len) {
-  return ((size_t)30 * hg * N + 2 * hg + (Len > 0 ? (size_t)2 * (2 * Len - 1) * H : 0) + 4) * sizeof(float);
+  return ((size_t)30 * hg * N + 4 * hg + (Len > 0 ? (size_t)2 * (2 * Len - 1) * H : 0) + 4) * sizeof(float);
 }
 bool attn_bwd_h_takes(int N, int H, int Len, bool table) {
   static const int on = [] { const char* v = getenv("RAL_ATTN_BWD_H"); return v ? atoi(v) : 1; }();
@@ -696,6 +945,32 @@ void launch_attn_bwd_h(const float* qkv, const float* o_hm, const float* do_hm, 
   if (table) { RAL_SET_LDS((k_attn_bwd_h<2, true>), lds); k_attn_bwd_h<2, true><<<grid, 512, lds, s>>>(qkv, o_hm, do_hm, lse, table, tpart, dqkv, N, H, hg, Len, B); }
   else { RAL_SET_LDS((k_attn_bwd_h<2, false>), lds); k_attn_bwd_h<2, false><<<grid, 512, lds, s>>>(qkv, o_hm, do_hm, lse, nullptr, nullptr, dqkv, N, H, hg, 0, B); }
   if (table) k_attn_tpart_reduce<<<(ntab + 3) / 4, 256, 0, s>>>(tpart, gtable, ntab, grid);
+}
+
+bool attn_fwd_w_takes(int N, int H, int Len, bool table) {
+  static const int on = [] { const char* v = getenv("RAL_ATTN_FWD_W"); return v ? atoi(v) : 1; }();
+  // measured at batch 2048 (us per launch, this kernel with f16 tiles / the kernels of ral_fwd.hip): N = 32: 39 / 45,
+  // 64 (table): 64 / 54, 128 (table): 90 / 91 - the scalar-path forward keeps N = 64 and 128 (RAL_ATTN_FWD_W=2: all three)
+  if (!on || (N != 32 && N != 64 && N != 128) || (on < 2 && N != 32)) return false;
+  if (N == 32 && (H & 1)) return false;
+  if (table && (2 * Len - 1) * H > 2048) return false;
+  return true;
+}
+void launch_attn_fwd_w(const float* qkv, float* o_hm, float* lse, const float* table, int N, int H, int Len, int B, int f16,
+                       hipStream_t s) {
+  const int hw = N >= 64 ? 1 : 64 / N, T = hw * N;
+  const int ntask = B * H / hw;
+  const int ntab = table ? (2 * Len - 1) * H : 0;
+  const size_t lds = ((size_t)4 * T * 13 + ntab + (table ? H : 0)) * sizeof(float);
+  int grid = 0;
+#define GO(n, tab, h) { RAL_SET_LDS((k_attn_fwd_w<n, tab, h>), lds); grid = attnw_grid(k_attn_fwd_w<n, tab, h>, lds, N, H, B); \
+    k_attn_fwd_w<n, tab, h><<<grid, 256, lds, s>>>(qkv, o_hm, lse, table, H, Len, ntask); }
+#define GOH(n, tab) { if (f16) GO(n, tab, true) else GO(n, tab, false) }
+  if (N == 32) { if (table) GOH(32, true) else GOH(32, false) }
+  else if (N == 64) { if (table) GOH(64, true) else GOH(64, false) }
+  else { if (table) GOH(128, true) else GOH(128, false) }
+#undef GOH
+#undef GO
 }
 
 void launch_attn_bwd_w(const float* qkv, const float* o_hm, const float* do_hm, const float* lse, const float* table,

@@ -216,6 +216,7 @@ __global__ __launch_bounds__(512, 4) void k_mlp_bwd_h(const float* __restrict__ 
   const _Float16* w2t = wtt + 2 * (wt.w2 - ptbase);   // (4C x C)
   const _Float16* w1t = wtt + 2 * (wt.w1 - ptbase);   // (C x 4C)
   const _Float16* wpt = wtt + 2 * (wt.wp - ptbase);   // (C x C)
+  const float wun2 = wplane_unscale(w2t, 4 * C, C), wun1 = wplane_unscale(w1t, C, 4 * C), wunp = wplane_unscale(wpt, C, C);   // (the planes' powers of two)
   float gle0 = 0.f, gle1 = 0.f, gle2 = 0.f;
   float4 dgam = make_float4(0.f, 0.f, 0.f, 0.f), dbet = make_float4(0.f, 0.f, 0.f, 0.f);
   auto put_split = [&](_Float16* base, int plane, int off, float4 v) {
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(512, 4) void k_mlp_bwd_h(const float* __restrict__ 
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
           const int tok = ut * 32 + tt * 16 + r;
-          const float sd = h2_row_unscale(smD[tok]) * (1.0f / RAL_WT_SCALE);
+          const float sd = h2_row_unscale(smD[tok]) * wun2;
           float mx = 0.f;
 #pragma unroll
           for (int mi = 0; mi < 2; ++mi) {
@@ -336,8 +337,8 @@ __global__ __launch_bounds__(512, 4) void k_mlp_bwd_h(const float* __restrict__ 
       }
       __syncthreads();
       // ---- dg (+)= du W1[chunk, :] ----
-      gemm_phase_h2<HC, 0, 1>(w1t, 4 * C / 32, 0, j0 / 32, C, nullptr, Uh, uplane, LDU, N >> 4, [&](int row0, int tok, f32x4 a) {
-        const float si = h2_row_unscale(smU[tok]) * (1.0f / RAL_WT_SCALE);
+      gemm_phase_h2<HC, 0, 1>(w1t, 4 * C / 32, 0, j0 / 32, C, nullptr, 1.0f, Uh, uplane, LDU, N >> 4, [&](int row0, int tok, f32x4 a) {
+        const float si = h2_row_unscale(smU[tok]) * wun1;
         float4* pg = reinterpret_cast<float4*>(Gs + tok * LD + row0);
         const float4 v = f4scale(tofloat4(a), si);
         *pg = (ch == 0) ? v : f4add(*pg, v);
@@ -367,8 +368,8 @@ __global__ __launch_bounds__(512, 4) void k_mlp_bwd_h(const float* __restrict__ 
     __syncthreads();
     // ---- do = dx1 Wp (head-major) ----
     float* dow = do_hm + wo;
-    gemm_phase_h2<C, 0, 1>(wpt, C / 32, 0, 0, C, nullptr, Dh, dplane, LDG, N >> 4, [&](int row0, int tok, f32x4 a) {
-      *reinterpret_cast<float4*>(dow + ((size_t)(row0 >> 2) * N + tok) * 4) = f4scale(tofloat4(a), h2_row_unscale(smD[tok]) * (1.0f / RAL_WT_SCALE));
+    gemm_phase_h2<C, 0, 1>(wpt, C / 32, 0, 0, C, nullptr, 1.0f, Dh, dplane, LDG, N >> 4, [&](int row0, int tok, f32x4 a) {
+      *reinterpret_cast<float4*>(dow + ((size_t)(row0 >> 2) * N + tok) * 4) = f4scale(tofloat4(a), h2_row_unscale(smD[tok]) * wunp);
     });
     __syncthreads();
   }
@@ -1278,6 +1279,7 @@ __global__ __launch_bounds__(512, RAL_QKVB_MINB) void k_qkv_bwd_h(const float* d
   const float4 gam1 = *reinterpret_cast<const float4*>(w.ln1w + cq);
   float4 dgam = make_float4(0.f, 0.f, 0.f, 0.f), dbet = make_float4(0.f, 0.f, 0.f, 0.f);
   const _Float16* wq = wtt + 2 * (wt.wqkv - ptbase);
+  const float wunq = wplane_unscale(wq, C, 3 * C);
   constexpr int NQ = 6, NR = 2;
   const int n4 = N * 3 * C / 4;   // <= NQ * 512 (launcher)
   const int rbase = threadIdx.x / LPR;
@@ -1362,8 +1364,8 @@ __global__ __launch_bounds__(512, RAL_QKVB_MINB) void k_qkv_bwd_h(const float* d
     unsigned* smn = smQ + (par ^ 1) * N;
     if ((int)threadIdx.x < N) smn[threadIdx.x] = 0u;   // (last read by the previous window's product)
     // dh[t][c] = sum_m dqkv[t][m] Wqkv[m][c]
-    gemm_phase_h2<3 * C, 0, 2>(wq, 3 * C / 32, 0, 0, C, nullptr, Qh, qplane, LDQ, N >> 4, [&](int row0, int tok, f32x4 a) {
-      *reinterpret_cast<float4*>(Dh + tok * LD + row0) = f4scale(tofloat4(a), h2_row_unscale(smc[tok]) * (1.0f / RAL_WT_SCALE));
+    gemm_phase_h2<3 * C, 0, 2>(wq, 3 * C / 32, 0, 0, C, nullptr, 1.0f, Qh, qplane, LDQ, N >> 4, [&](int row0, int tok, f32x4 a) {
+      *reinterpret_cast<float4*>(Dh + tok * LD + row0) = f4scale(tofloat4(a), h2_row_unscale(smc[tok]) * wunq);
     });
     __syncthreads();   // Dh complete, Qh free
     const int nxt = win + gridDim.x;

@@ -150,12 +150,14 @@ constexpr int ldb_of(int K) { return K + 8; }
 // three products h1 h1, h1 h2, h2 h1 reproduce the fp32 product to ~2^-21 relative (the dropped h2 h2 term is 2^-22).  The
 // cross terms are summed in their own accumulator and enter the result as acc + 2^-11 accx.  3 x 16 matrix-core cycles
 // per 16 x 16 x 32 against 6 x 16 for the bf16 triple split and 8 x 34.5 for the fp32 MFMA; operands are 4 bytes per
-// element, as in fp32.  |x| is clamped to fp16's largest finite value (65504) - LayerNorm / GELU / attention outputs and
-// weights are orders of magnitude below it; gradient tensors are NOT (they underflow fp16): those stay on bf16 x 3 / fp32.
+// element, as in fp32.  Nothing is clamped: an operand beyond fp16's largest finite value (65504 - LayerNorm / GELU /
+// attention outputs and weights are orders of magnitude below it) becomes h1 = Inf, h2 = -Inf and the product NaN, a NaN
+// stays a NaN: the result is non-finite and visible (loss = NaN), never a silently saturated number.  `f16_split = 0`
+// is the path for a model that needs that range.  Gradient tensors are far BELOW fp16's range: they are multiplied by a
+// power of two first (h2_row_scale below, per token; one per launch in the weight-gradient kernels).
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 struct H2 { _Float16 a, b; };
 RAL_DEV H2 f16_split2(float x) {
-  x = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
   H2 r;
   r.a = (_Float16)x;
   r.b = (_Float16)((x - (float)r.a) * 2048.f);
@@ -167,11 +169,29 @@ RAL_DEV H2 f16_split2(float x) {
 // with an absolute error of 2^-25 - which v_mfma_f32_16x16x32_f16 multiplies exactly (tools/diag/f16_denorm_probe.hip) -,
 // so x = h1 + h2 to 2^-25 of the operand's scale and all three products go into ONE accumulator.
 RAL_DEV H2 f16_split2u(float x) {
-  x = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
   H2 r;
   r.a = (_Float16)x;
   r.b = (_Float16)(x - (float)r.a);
   return r;
+}
+// The same without the clamp, for operands that were brought into range by a power of two first (attention tiles,
+// ral_attn.hip): a non-finite element stays non-finite (h1 = Inf / NaN, h2 = NaN) and reaches the result, as in fp32.
+RAL_DEV H2 f16_split2n(float x) {
+  H2 r;
+  r.a = (_Float16)x;
+  r.b = (_Float16)(x - (float)r.a);
+  return r;
+}
+// q . k on fp16 pairs: the two operands of a score are BALANCED by one power of two, q' = 2^-a q, k' = 2^a k with a = half the
+// difference of their largest exponents, so that the product is unchanged (no unscaling in front of the exponential) and
+// both sides sit at the geometric mean of their magnitudes: finite while max|q| max|k| < 2^31, and the absolute error of
+// the pieces (2^-25 below 2^-2) is as small relative to the score as it can be.
+RAL_DEV void pair_balance(float mq, float mk, float& cq, float& ck) {
+  const int eq = (int)(__float_as_uint(mq) >> 23), ek = (int)(__float_as_uint(mk) >> 23);
+  int a = (mq > 0.f && mk > 0.f) ? (eq - ek) / 2 : 0;
+  a = a < -100 ? -100 : (a > 100 ? 100 : a);
+  cq = __uint_as_float((unsigned)(127 - a) << 23);
+  ck = __uint_as_float((unsigned)(127 + a) << 23);
 }
 // Gradient rows are far below fp16's normal range (a mean-squared-error gradient is ~1e-6), so a row that feeds such a
 // product is multiplied by a power of two first: the scale that puts the row's largest magnitude (bits of |max| as an
@@ -192,6 +212,11 @@ RAL_DEV float h2_row_unscale(unsigned maxbits) {
 // (Row-major planes made it sixteen half-used lines per load; at these widths the products wait for the weight stream
 // through the vector L1, not for the matrix cores: with chunk 0's fragments re-used for every chunk fc2 at C = 128 ran
 // 4.2 x faster, without the MFMAs it did not change.)  KT = k-tiles per tile row of the matrix.
+// the inverse of the power of two the planes of an (M x K) matrix were multiplied by (k_weight_scales, ral_fwd.hip): the
+// first float of the slot behind the matrix's planes
+RAL_DEV float wplane_unscale(const _Float16* Wt, int M, int K) {
+  return __builtin_nontemporal_load(reinterpret_cast<const float*>(Wt + 2 * (size_t)M * K));
+}
 RAL_DEV const _Float16* wtile(const _Float16* Wt, int KT, int mt, int kt, int p) {
   // the tile is the same for the whole wave: saying so keeps its address in scalar registers (one shared lane offset)
   const int tile = __builtin_amdgcn_readfirstlane((mt * KT + kt) * 2 + p);
@@ -305,8 +330,9 @@ RAL_DEV void gemm_wx_h2(const _Float16* __restrict__ Wt, int KT, int mt0, int kt
 // One GEMM phase of a workgroup on split operands: out(M rows x ntiles * 16 tokens) = W x X^T (+ bias; row 0 of the output
 // = row 16 mt0 of W, bias[0] its bias), work units of MT x 2 tiles dealt round-robin to the waves; M % (16 MT) == 0, ntiles even.  The bias rows of a unit are requested
 // before its products.  epi(row0, tok, v) as in gemm_phase.
+// wun: the inverse of the matrix's power-of-two scale (wplane_unscale), applied to the accumulators before the bias
 template <int K, int MT, int GMAX, int ONE, class Epi, class Hook>
-RAL_DEV void gemm_phase_h2_t(const _Float16* __restrict__ Wt, int KT, int mt0, int kt0, int M, const float* __restrict__ bias,
+RAL_DEV void gemm_phase_h2_t(const _Float16* __restrict__ Wt, int KT, int mt0, int kt0, int M, const float* __restrict__ bias, float wun,
                              const _Float16* Xh, int xplane, int ldx, int ntiles, Epi& epi, Hook& hook) {
   constexpr int TT = 2;
   const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -333,6 +359,7 @@ RAL_DEV void gemm_phase_h2_t(const _Float16* __restrict__ Wt, int KT, int mt0, i
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) {
         f32x4 v = ONE == 1 ? acc[mi][tt] : (ONE == 2 ? acc[mi][tt] + accx[mi][tt] : acc[mi][tt] + accx[mi][tt] * RAL_H2_SCALE);
+        v *= wun;
         v[0] += bv[mi].x; v[1] += bv[mi].y; v[2] += bv[mi].z; v[3] += bv[mi].w;
         epi((m * MT + mi) * 16 + 4 * g, (t * TT + tt) * 16 + r, v);
       }
@@ -344,11 +371,11 @@ RAL_DEV void gemm_phase_h2_t(const _Float16* __restrict__ Wt, int KT, int mt0, i
 // hook: see gemm_wx_h2; runs exactly once in every wave (inside its first unit)
 // GMAX: chunks of weight fragments requested together by a one-row-tile unit (0: eight, four with a hook)
 template <int K, int GMAX = 0, int ONE = 0, class Epi, class Hook = NoHook>
-RAL_DEV void gemm_phase_h2(const _Float16* __restrict__ Wt, int KT, int mt0, int kt0, int M, const float* __restrict__ bias,
+RAL_DEV void gemm_phase_h2(const _Float16* __restrict__ Wt, int KT, int mt0, int kt0, int M, const float* __restrict__ bias, float wun,
                            const _Float16* Xh, int xplane, int ldx, int ntiles, Epi epi, Hook hook = Hook()) {
   const int nw = blockDim.x >> 6;
-  if (M % 32 == 0 && (M / 32) * (ntiles / 2) >= nw) gemm_phase_h2_t<K, 2, GMAX, ONE>(Wt, KT, mt0, kt0, M, bias, Xh, xplane, ldx, ntiles, epi, hook);
-  else gemm_phase_h2_t<K, 1, GMAX, ONE>(Wt, KT, mt0, kt0, M, bias, Xh, xplane, ldx, ntiles, epi, hook);
+  if (M % 32 == 0 && (M / 32) * (ntiles / 2) >= nw) gemm_phase_h2_t<K, 2, GMAX, ONE>(Wt, KT, mt0, kt0, M, bias, wun, Xh, xplane, ldx, ntiles, epi, hook);
+  else gemm_phase_h2_t<K, 1, GMAX, ONE>(Wt, KT, mt0, kt0, M, bias, wun, Xh, xplane, ldx, ntiles, epi, hook);
 }
 
 // row stride (floats) of a token-major LDS tile of width C: +4 breaks the power-of-two stride for the

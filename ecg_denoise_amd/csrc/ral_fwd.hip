@@ -71,6 +71,7 @@ __global__ __launch_bounds__(256) void k_qkv_fwd_h(const float* __restrict__ x, 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
   const long total = (long)B * N;
   const int ngroups = (int)((total + GT - 1) / GT);
+  const float wun = wplane_unscale(wt, 3 * C, C);
   RAL_STAMP_INIT();
   for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     RAL_STAMP_AT(8);
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void k_qkv_fwd_h(const float* __restrict__ x, 
           if (gt < total) {
             const long win = gt / N;
             const int tok = (int)(gt - win * N);
-            float4 v = f4add(f4add(tofloat4(acc[mi][tt]), f4scale(tofloat4(accx[mi][tt]), RAL_H2_SCALE)), bias);
+            float4 v = f4add(f4scale(f4add(tofloat4(acc[mi][tt]), f4scale(tofloat4(accx[mi][tt]), RAL_H2_SCALE)), wun), bias);
             if (row0 < C) v = f4scale(v, 0.5f);  // q * head_dim^-0.5, head_dim = 4
             *reinterpret_cast<float4*>(qkv + win * 3 * N * C + ((size_t)(row0 >> 2) * N + tok) * 4) = v;
           }
@@ -153,6 +154,7 @@ __global__ __launch_bounds__(6 * C) void k_qkv_fwd_ws(const float* __restrict__ 
     for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
       for (int p = 0; p < 2; ++p) wf[mi][kc][p] = *reinterpret_cast<const f16x8*>(wtile(wt, KC, 2 * wave + mi, kc, p));
+  const float wun = wplane_unscale(wt, 3 * C, C);
   const float4 gam = *reinterpret_cast<const float4*>(w.ln1w + cq);
   const float4 bet = *reinterpret_cast<const float4*>(w.ln1b + cq);
   float4 pev[NP];
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(6 * C) void k_qkv_fwd_ws(const float* __restrict__ 
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
           const int row0 = 32 * wave + 16 * mi + 4 * g;
-          float4 v = f4add(f4add(tofloat4(acc[mi]), f4scale(tofloat4(accx[mi]), RAL_H2_SCALE)), bias[mi]);
+          float4 v = f4add(f4scale(f4add(tofloat4(acc[mi]), f4scale(tofloat4(accx[mi]), RAL_H2_SCALE)), wun), bias[mi]);
           if (row0 < C) v = f4scale(v, 0.5f);  // q * head_dim^-0.5, head_dim = 4
           *reinterpret_cast<float4*>(qkv + win * 3 * N * C + ((size_t)(row0 >> 2) * N + tok) * 4) = v;
         }
@@ -240,14 +242,40 @@ __global__ __launch_bounds__(6 * C) void k_qkv_fwd_ws(const float* __restrict__ 
 // desc[d] = {offset of the matrix in the parameter buffer (floats), rows M, columns K, first work item}; a work item is
 // eight consecutive columns of one row (16 bytes of each plane); the tiled planes of a matrix take the bytes of the
 // matrix's own place in a buffer shaped like the parameter buffer (2 planes x 2 bytes = 4 bytes per weight).
-// scale / unscaled: the backward's planes hold 2^8 W with unscaled residuals (products with operands that are scaled
-// themselves go into one accumulator, ral_device.hpp), the forward's W with the 2^11-scaled residual
+// Every matrix is multiplied by ITS OWN power of two first (k_weight_scales: largest |w| into [2^13, 2^14)), so that the
+// pieces carry 22 bits relative to the matrix's scale whatever that scale is (weights of 1e-7 were 11-bit numbers with a
+// fixed factor: fp16 has nothing below 6e-8) and nothing can reach fp16's upper end.  The inverse sits in the first bytes
+// of the slot BEHIND the matrix's planes (the place of the bias that follows every weight matrix in the parameter buffer;
+// wplane_unscale, ral_device.hpp) and the consumers multiply their accumulators by it.
+// unscaled: the backward's planes carry unscaled residuals (products with operands that are scaled themselves go into one
+// accumulator, ral_device.hpp), the forward's the 2^11-scaled residual
+__global__ __launch_bounds__(256) void k_weight_scales(const float* __restrict__ params, _Float16* __restrict__ wt, const int4* __restrict__ desc) {
+  const int4 D = desc[blockIdx.x];
+  const int n4 = (D.y * D.z) >> 2;
+  const float4* w4 = reinterpret_cast<const float4*>(params + D.x);
+  float m = 0.f;
+  for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+    const float4 v = w4[i];
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+  }
+  __shared__ float red[4];
+  m = group_max<64>(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned bits = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+    float* slot = reinterpret_cast<float*>(wt + 2 * ((size_t)D.x + (size_t)D.y * D.z));
+    slot[0] = h2_row_unscale(bits);
+    slot[1] = h2_row_scale(bits);
+  }
+}
 __global__ void k_tile_planes(const float* __restrict__ params, _Float16* __restrict__ wt, const int4* __restrict__ desc,
-                              int ndesc, int nwork, float scale, int unscaled) {
+                              int ndesc, int nwork, int unscaled) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nwork; i += gridDim.x * blockDim.x) {
     int d = 0;
     while (d + 1 < ndesc && desc[d + 1].w <= i) ++d;
     const int4 D = desc[d];
+    const float scale = reinterpret_cast<const float*>(wt + 2 * ((size_t)D.x + (size_t)D.y * D.z))[1];
     const int j = i - D.w, K8 = D.z >> 3, row = j / K8, k8 = j - row * K8;
     const float4 v0 = *reinterpret_cast<const float4*>(params + D.x + (size_t)row * D.z + 8 * k8);
     const float4 v1 = *reinterpret_cast<const float4*>(params + D.x + (size_t)row * D.z + 8 * k8 + 4);
@@ -261,10 +289,11 @@ __global__ void k_tile_planes(const float* __restrict__ params, _Float16* __rest
     *reinterpret_cast<f16x8*>(dst + 512) = h2;
   }
 }
-void launch_tile_planes(const float* params, void* wt, const void* desc, int ndesc, int nwork, float scale, int unscaled, hipStream_t s) {
+void launch_tile_planes(const float* params, void* wt, const void* desc, int ndesc, int nwork, int unscaled, hipStream_t s) {
   if (ndesc <= 0) return;
+  k_weight_scales<<<ndesc, 256, 0, s>>>(params, reinterpret_cast<_Float16*>(wt), reinterpret_cast<const int4*>(desc));
   const int blocks = (nwork + 255) / 256;
-  k_tile_planes<<<blocks < 2048 ? blocks : 2048, 256, 0, s>>>(params, reinterpret_cast<_Float16*>(wt), reinterpret_cast<const int4*>(desc), ndesc, nwork, scale, unscaled);
+  k_tile_planes<<<blocks < 2048 ? blocks : 2048, 256, 0, s>>>(params, reinterpret_cast<_Float16*>(wt), reinterpret_cast<const int4*>(desc), ndesc, nwork, unscaled);
 }
 
 // =================================================================================
@@ -291,7 +320,17 @@ RAL_STAMPS_DEFINE(ral_debug_stamps_fwd)
 // running-max recurrence (never seen on real data; forced by tests/test_gpu_configs.py::test_attention_forward_exact_fallback).
 // NT > 0: window length as a compile-time constant, TAB = false: no R-wave table (short windows: a task is 2-4 tiles, its
 // set-up and loop control weigh as much as the tiles - see k_attn_bwd)
-template <int QT, int NT = 0, bool TAB = true>
+// F16: the S tile on the f16 matrix cores - q log2 e and k staged as token-interleaved fp16-pair planes ([h1 x 4 | h2 x 4],
+// 16 bytes per token as the fp32 quad they replace), one v_mfma_f32_16x16x16_f16 per tile (lane group g' = piece pair
+// (g' >> 1, g' & 1) over the four dims; see k_attn_bwd_w in ral_attn.hip), 10.6 instead of 41.7 cycles beside the tile's
+// vector work (tools/diag/valu_probe.hip)
+typedef _Float16 fh16x4 __attribute__((ext_vector_type(4)));
+RAL_DEV void put_pair_planes(float* X, int t, float4 x) {
+  const H2 s0 = f16_split2n(x.x), s1 = f16_split2n(x.y), s2 = f16_split2n(x.z), s3 = f16_split2n(x.w);
+  *reinterpret_cast<fh16x4*>(X + 4 * t) = fh16x4{s0.a, s1.a, s2.a, s3.a};
+  *reinterpret_cast<fh16x4*>(X + 4 * t + 2) = fh16x4{s0.b, s1.b, s2.b, s3.b};
+}
+template <int QT, int NT = 0, bool TAB = true, bool F16 = false>
 __global__ __launch_bounds__(512, (QT >= 4 ? 3 : 4)) void k_attn_fwd(const float* __restrict__ qkv, float* __restrict__ o_hm,
                                                   float* __restrict__ lse, const float* __restrict__ table,
                                                   int N_rt, int H, int HG, int Len, int B) {
@@ -305,6 +344,7 @@ __global__ __launch_bounds__(512, (QT >= 4 ? 3 : 4)) void k_attn_fwd(const float
   int* Kmax = reinterpret_cast<int*>(Mq + HG * N);  // HG : max |k|^2 as float bits
   float* tab = reinterpret_cast<float*>(Kmax + HG + 4);  // (2Len-1) x HG, times log2(e)
   float* Bmax = tab + (table ? (2 * Len - 1) * HG : 0);   // HG : max(bias, 0)
+  int* Qmax = reinterpret_cast<int*>(Bmax + HG);          // HG : max |q|^2 as float bits (F16: balances the pair planes)
   const int ngrp = H / HG;
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
   const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -313,7 +353,7 @@ __global__ __launch_bounds__(512, (QT >= 4 ? 3 : 4)) void k_attn_fwd(const float
   for (int item = blockIdx.x; item < B * ngrp; item += gridDim.x) {
     const int win = item / ngrp, h0 = (item - win * ngrp) * HG;
     const float* base = qkv + (size_t)win * 3 * H * N * 4;
-    if ((int)threadIdx.x < HG) { Kmax[threadIdx.x] = 0; if (table) Bmax[threadIdx.x] = 0.f; }
+    if ((int)threadIdx.x < HG) { Kmax[threadIdx.x] = 0; Qmax[threadIdx.x] = 0; if (table) Bmax[threadIdx.x] = 0.f; }
     __syncthreads();
     {   // one staging pass with the q, k and v loads of two indices in flight together
       const float4* gq = reinterpret_cast<const float4*>(base + (size_t)h0 * N * 4);
@@ -327,6 +367,7 @@ __global__ __launch_bounds__(512, (QT >= 4 ? 3 : 4)) void k_attn_fwd(const float
         q0 = f4scale(q0, RAL_LOG2E); q1 = f4scale(q1, RAL_LOG2E);
         reinterpret_cast<float4*>(Qs)[i] = q0; reinterpret_cast<float4*>(Qs)[i + bd] = q1;
         reinterpret_cast<float4*>(Ks)[i] = k0; reinterpret_cast<float4*>(Ks)[i + bd] = k1;
+        if constexpr (F16) { atomicMax(Qmax + i / N, __float_as_int(f4dot(q0, q0))); atomicMax(Qmax + (i + bd) / N, __float_as_int(f4dot(q1, q1))); }
         reinterpret_cast<float4*>(Vs)[i] = v0; reinterpret_cast<float4*>(Vs)[i + bd] = v1;
         Mq[i] = sqrtf(f4dot(q0, q0)); Mq[i + bd] = sqrtf(f4dot(q1, q1));
         atomicMax(Kmax + i / N, __float_as_int(f4dot(k0, k0)));   // non-negative floats order like ints
@@ -335,6 +376,7 @@ __global__ __launch_bounds__(512, (QT >= 4 ? 3 : 4)) void k_attn_fwd(const float
       for (; i < n4; i += bd) {
         const float4 q0 = f4scale(gq[i], RAL_LOG2E), k0 = gk[i], v0 = gv[i];
         reinterpret_cast<float4*>(Qs)[i] = q0; reinterpret_cast<float4*>(Ks)[i] = k0; reinterpret_cast<float4*>(Vs)[i] = v0;
+        if constexpr (F16) atomicMax(Qmax + i / N, __float_as_int(f4dot(q0, q0)));
         Mq[i] = sqrtf(f4dot(q0, q0));
         atomicMax(Kmax + i / N, __float_as_int(f4dot(k0, k0)));
       }
@@ -346,6 +388,15 @@ __global__ __launch_bounds__(512, (QT >= 4 ? 3 : 4)) void k_attn_fwd(const float
         if (t > 0.f) atomicMax(reinterpret_cast<int*>(Bmax) + i % HG, __float_as_int(t));
       }
     __syncthreads();
+    if constexpr (F16) {   // second pass: q and k of a head balanced by one power of two (pair_balance) and split IN PLACE
+      for (int i = threadIdx.x; i < HG * N; i += blockDim.x) {
+        float cq, ck;
+        pair_balance(sqrtf(__int_as_float(Qmax[i / N])), sqrtf(__int_as_float(Kmax[i / N])), cq, ck);
+        const float4 q = reinterpret_cast<const float4*>(Qs)[i], k = reinterpret_cast<const float4*>(Ks)[i];
+        put_pair_planes(Qs, i, f4scale(q, cq)); put_pair_planes(Ks, i, f4scale(k, ck));
+      }
+      __syncthreads();
+    }
     const int qblocks = N / (16 * QT);
     for (int task = wave; task < HG * qblocks; task += nw) {
       const int hl = task / qblocks, q0 = (task - hl * qblocks) * 16 * QT;
@@ -354,23 +405,29 @@ __global__ __launch_bounds__(512, (QT >= 4 ? 3 : 4)) void k_attn_fwd(const float
       const float4* Vh = reinterpret_cast<const float4*>(Vs + hl * N * 4);
       const float kmx = sqrtf(__int_as_float(Kmax[hl])) * 1.0000002f;
       float qf[QT], mq[QT];
+      fh16x4 qh[QT];
       f32x2 l2[QT], o01[QT], o23[QT];
+      // MFMA operands of a token: fp32 element g of its quad, or (F16) plane g >> 1 (A, row token) / g & 1 (B, column token)
+      auto sc_tile = [&](int kt, int qt, f32x4 c) -> f32x4 {
+        if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x16f16(*reinterpret_cast<const fh16x4*>(Kh + 4 * (kt + r) + 2 * (g >> 1)), qh[qt], c, 0, 0, 0);
+        else return mfma4(Kh[(kt + r) * 4 + g], qf[qt], c);
+      };
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {
         const int q = q0 + 16 * qt + r;
-        qf[qt] = Qh[q * 4 + g];
+        if constexpr (F16) qh[qt] = *reinterpret_cast<const fh16x4*>(Qh + 4 * q + 2 * (g & 1));
+        else qf[qt] = Qh[q * 4 + g];
         mq[qt] = Mq[hl * N + q] * kmx + (table ? Bmax[hl] : 0.f);
         l2[qt] = f32x2{0.f, 0.f}; o01[qt] = f32x2{0.f, 0.f}; o23[qt] = f32x2{0.f, 0.f};
       }
       auto tile = [&](int kt, auto biased) {
-        const float kf = Kh[(kt + r) * 4 + g];
         float4 v4[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) v4[j] = Vh[kt + 4 * g + j];
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
           const float nm = -mq[qt];
-          f32x4 s = mfma4(kf, qf[qt], f32x4{nm, nm, nm, nm});   // s - m, log2 units
+          f32x4 s = sc_tile(kt, qt, f32x4{nm, nm, nm, nm});   // s - m, log2 units
           if constexpr (decltype(biased)::value) {
             const int qi = q0 + 16 * qt + r - off;
 #pragma unroll
@@ -422,7 +479,7 @@ __global__ __launch_bounds__(512, (QT >= 4 ? 3 : 4)) void k_attn_fwd(const float
           float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
           const int qi = q0 + 16 * qt + r - off;
           for (int kt = 0; kt < N; kt += 16) {
-            f32x4 s = mfma4(Kh[(kt + r) * 4 + g], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});
+            f32x4 s = sc_tile(kt, qt, f32x4{0.f, 0.f, 0.f, 0.f});
             if (table) {
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
@@ -705,6 +762,7 @@ __global__ __launch_bounds__(NTH, 4) void k_mlp_fwd_h(const float* __restrict__ 
   const _Float16* wph = wt + 2 * (w.wp - pbase);   // tiled split planes of the three weight matrices
   const _Float16* w1h = wt + 2 * (w.w1 - pbase);
   const _Float16* w2h = wt + 2 * (w.w2 - pbase);
+  const float wunp = wplane_unscale(wph, C, C), wun1 = wplane_unscale(w1h, 4 * C, C), wun2 = wplane_unscale(w2h, C, 4 * C);
   auto put_split = [&](_Float16* base, int plane, int off, float4 v) {
     const H2 s0 = f16_split2(v.x), s1 = f16_split2(v.y), s2 = f16_split2(v.z), s3 = f16_split2(v.w);
     *reinterpret_cast<f16x4*>(base + off) = f16x4{s0.a, s1.a, s2.a, s3.a};
@@ -736,7 +794,7 @@ __global__ __launch_bounds__(NTH, 4) void k_mlp_fwd_h(const float* __restrict__ 
     RAL_STAMP_AT(1);
     // ---- attention output projection + residual ----
     float* x1w = x1_out ? x1_out + wo : nullptr;
-    gemm_phase_h2<C>(wph, C / 32, 0, 0, C, w.bp, Gh, gplane, LDG, T >> 4, [&](int row0, int tok, f32x4 a) {
+    gemm_phase_h2<C>(wph, C / 32, 0, 0, C, w.bp, wunp, Gh, gplane, LDG, T >> 4, [&](int row0, int tok, f32x4 a) {
       float4* px = reinterpret_cast<float4*>(Xs + tok * LD + row0);
       const float4 v = f4add(*px, tofloat4(a));
       *px = v;
@@ -762,7 +820,7 @@ __global__ __launch_bounds__(NTH, 4) void k_mlp_fwd_h(const float* __restrict__ 
 #pragma unroll 1
     for (int ch = 0; ch < NCH; ++ch) {
       const int j0 = ch * HC;
-      gemm_phase_h2<C>(w1h, C / 32, j0 / 16, 0, HC, w.b1 + j0, Gh, gplane, LDG, T >> 4, [&](int row0, int tok, f32x4 a) {
+      gemm_phase_h2<C>(w1h, C / 32, j0 / 16, 0, HC, w.b1 + j0, wun1, Gh, gplane, LDG, T >> 4, [&](int row0, int tok, f32x4 a) {
         const float4 u = tofloat4(a);
         if (upw) *reinterpret_cast<float4*>(upw + (size_t)tok * 4 * C + j0 + row0) = u;
         float4 h = make_float4(gelu_f(u.x), gelu_f(u.y), gelu_f(u.z), gelu_f(u.w));
@@ -783,7 +841,7 @@ __global__ __launch_bounds__(NTH, 4) void k_mlp_fwd_h(const float* __restrict__ 
         __syncthreads();
       }
       RAL_STAMP_AT(5);
-      gemm_phase_h2<HC>(w2h, 4 * C / 32, 0, j0 / 32, C, ch == 0 ? w.b2 : nullptr, Uh, uplane, LDU, T >> 4, [&](int row0, int tok, f32x4 a) {
+      gemm_phase_h2<HC>(w2h, 4 * C / 32, 0, j0 / 32, C, ch == 0 ? w.b2 : nullptr, wun2, Uh, uplane, LDU, T >> 4, [&](int row0, int tok, f32x4 a) {
         float4* px = reinterpret_cast<float4*>(Xs + tok * LD + row0);
         const float4 v = f4add(*px, tofloat4(a));
         if (ch == NCH - 1) *reinterpret_cast<float4*>(x2w + (size_t)tok * C + row0) = v;   // block output
@@ -888,18 +946,23 @@ void launch_qkv_fwd(int C, const float* x, const float* pe, const BlockP& w, con
 }
 
 size_t attn_fwd_lds(int N, int HG, int Len) {
-  return ((size_t)3 * HG * N * 4 + (size_t)HG * N + 2 * HG + 8 + (Len > 0 ? (size_t)(2 * Len - 1) * HG : 0)) * sizeof(float);
+  return ((size_t)3 * HG * N * 4 + (size_t)HG * N + 3 * HG + 8 + (Len > 0 ? (size_t)(2 * Len - 1) * HG : 0)) * sizeof(float);
 }
 
 void launch_attn_fwd(const float* qkv, float* o_hm, float* lse, const float* table, int N, int H, int HG, int Len,
-                     int B, hipStream_t s) {
+                     int B, int f16, hipStream_t s) {
+  if (attn_fwd_w_takes(N, H, Len, table != nullptr)) { launch_attn_fwd_w(qkv, o_hm, lse, table, N, H, Len, B, f16, s); return; }
   // Window lengths [lo, hi] that take the query-per-lane kernel on the scalar path.  Measured at batch 2048
   // (tools/attn_bench.py, us per launch, MFMA-tile kernel vs scalar path): N = 512: 322 / 333, 256: 184 / 172,
   // 128: 122 / 90, 64: 91 / 51.  RAL_ATTN_FWD_V="lo:hi" overrides (0:0 = never).
   static int vlo = 64, vhi = 256;
   static const bool vinit = [] { if (const char* v = getenv("RAL_ATTN_FWD_V")) sscanf(v, "%d:%d", &vlo, &vhi); return true; }();
   (void)vinit;
-  if (N >= vlo && N <= vhi && N >= 64 && N % 4 == 0 && (!table || 2 * Len - 1 <= 64)) {
+  // with the S tile on the f16 matrix cores the tile kernel takes the long windows from the scalar path again
+  // (RAL_ATTN_FWD_H = smallest such N, 0 = never)
+  static const int hlo = [] { const char* v = getenv("RAL_ATTN_FWD_H"); return v ? atoi(v) : 256; }();
+  const bool tile16 = f16 && hlo > 0 && N >= hlo && N % 32 == 0;
+  if (!tile16 && N >= vlo && N <= vhi && N >= 64 && N % 4 == 0 && (!table || 2 * Len - 1 <= 64)) {
     const int ntask = B * H * ((N + 63) / 64);
     if (table) k_attn_fwd_v<true><<<(ntask + 3) / 4, 256, 0, s>>>(qkv, o_hm, lse, table, N, H, Len, ntask);
     else k_attn_fwd_v<false><<<(ntask + 3) / 4, 256, 0, s>>>(qkv, o_hm, lse, table, N, H, 0, ntask);
@@ -918,6 +981,11 @@ void launch_attn_fwd(const float* qkv, float* o_hm, float* lse, const float* tab
     if (N == 32 && !table && !nt_off) {
       RAL_SET_LDS((k_attn_fwd<2, 32, false>), l2);
       k_attn_fwd<2, 32, false><<<grid_for(B * (H / hg)), 512 / split, l2, s>>>(qkv, o_hm, lse, table, N, H, hg, Len, B);
+      return;
+    }
+    if (tile16) {
+      RAL_SET_LDS((k_attn_fwd<2, 0, true, true>), l2);
+      k_attn_fwd<2, 0, true, true><<<grid_for(B * (H / hg)), 512 / split, l2, s>>>(qkv, o_hm, lse, table, N, H, hg, Len, B);
       return;
     }
     RAL_SET_LDS((k_attn_fwd<2>), l2);

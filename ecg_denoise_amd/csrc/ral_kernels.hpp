@@ -21,12 +21,11 @@
 // columns, first work item} per matrix, nwork = sum of rows * columns / 8; a matrix's planes sit at twice its float offset
 // in `wt`).  wt == nullptr selects the fp32-MFMA kernels.
 bool qkv_fwd_uses_f16(int C);
-void launch_tile_planes(const float* params, void* wt, const void* desc, int ndesc, int nwork, float scale, int unscaled_residual, hipStream_t s);
-#define RAL_WT_SCALE 256.0f   // the backward's (transposed) planes hold RAL_WT_SCALE * W with unscaled residuals
+void launch_tile_planes(const float* params, void* wt, const void* desc, int ndesc, int nwork, int unscaled_residual, hipStream_t s);
 void launch_qkv_fwd(int C, const float* x, const float* pe, const BlockP& w, const void* wt /* of Wqkv */, float* qkv, int N, int B, hipStream_t s);
 size_t attn_fwd_lds(int N, int HG, int Len);
 void launch_attn_fwd(const float* qkv, float* o_hm, float* lse, const float* table, int N, int H, int HG, int Len,
-                     int B, hipStream_t s);
+                     int B, int f16, hipStream_t s);
 size_t mlp_fwd_lds(int C, int N, int nch);
 // pbase / wt: the parameter buffer and the tiled-plane buffer; the levels where mlp_fwd_uses_f16(C, N) run their Linear
 // layers on the planes (wt == nullptr: fp32 MFMA everywhere)
@@ -93,6 +92,9 @@ size_t attn_bwd_h_scratch_floats(int N, int H, int Len, bool table, int B);
 void launch_attn_bwd_h(const float* qkv, const float* o_hm, const float* do_hm, const float* lse, const float* table,
                        float* gtable, float* dqkv, float* tpart, int N, int H, int Len, int B, hipStream_t s);
 // wave-autonomous kernels of the short windows (ral_attn.hip)
+bool attn_fwd_w_takes(int N, int H, int Len, bool table);
+void launch_attn_fwd_w(const float* qkv, float* o_hm, float* lse, const float* table, int N, int H, int Len, int B, int f16,
+                       hipStream_t s);
 bool attn_bwd_w_takes(int N, int H, int Len, bool table);
 size_t attn_bwd_w_scratch_floats(int N, int H, int Len, bool table, int B);
 void launch_attn_bwd_w(const float* qkv, const float* o_hm, const float* do_hm, const float* lse, const float* table,

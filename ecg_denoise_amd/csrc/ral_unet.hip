@@ -1700,13 +1700,22 @@ static Stage make_stage(UNetModel* m, int si, const float* x, bool training, boo
 // residual operand r of the specialised kernel is always lrelu(BN(z)) (bottleneck.6 + x); main operand act is a runtime flag
 template <int CIN, int COUT, int KS, int MODE>
 static void launch_fwd_t(const Stage& st, int B, int grid, hipStream_t s) {
-  // windows per workgroup pass: all of a workgroup's windows at once (up to 4), so the grid is B / WP workgroups
+  // windows per workgroup pass: all of a workgroup's windows at once (up to 4), so the grid is B / WP workgroups - fewer
+  // while the tiles of a pass would not leave room for two workgroups per CU (long windows: at L = 2048 the 32-channel
+  // stages take 64 KB at WP = 2 already); dynamic LDS above 64 KB is opted into per instantiation
+  auto lds_of = [&](int WP) {
+    return ((size_t)WP * CIN * (st.lin + 8) + (st.r.z ? (size_t)WP * COUT * st.lout : 0) + (size_t)CIN * COUT * KS + MAXC +
+            12 * MAXC + 2 * MAXC + 8) * sizeof(float);
+  };
   int WP = (B + grid - 1) / grid;
   if (WP > 4) WP = 4;
   if (WP < 1) WP = 1;
-  const int g2 = (B + WP - 1) / WP < grid ? (B + WP - 1) / WP : grid;
-  const size_t lds = ((size_t)WP * CIN * (st.lin + 8) + (st.r.z ? (size_t)WP * COUT * st.lout : 0) + (size_t)CIN * COUT * KS + MAXC +
-                      12 * MAXC + 2 * MAXC + 8) * sizeof(float);
+  while (WP > 1 && lds_of(WP) > 80 * 1024) --WP;
+  const int nwg = (B + WP - 1) / WP;
+  const int g2 = nwg < grid ? nwg : grid;         // (the kernel loops over passes)
+  const size_t lds = lds_of(WP);
+  static size_t cur = 0;                          // (one per instantiation)
+  if (lds > cur) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_unet_fwd_t<CIN, COUT, KS, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); cur = lds; }
   k_unet_fwd_t<CIN, COUT, KS, MODE><<<g2, UNET_FWD_THREADS, lds, s>>>(st, B, WP);
 }
 

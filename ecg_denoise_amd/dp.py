@@ -7,12 +7,19 @@ Collectives per step (torch.distributed; backend "nccl" is RCCL over xGMI on ROC
   3. flat gradient buffer     (4.35 MB fp32) in two buckets: the decoder half (utransformer4 .. transconv) is
      final about half-way through the backward pass and is all-reduced on a side stream WHILE the bottleneck and
      encoder backward kernels run (`ral_grad_bucket` / `ral_grad_bucket_wait`); the other half follows the stem
-  4. the scalar loss (reporting only)
-No collective touches activations; inference needs none (replicas).
+  4. metrics (loss, SNR, RMSE: three doubles) once per LOGGING INTERVAL (`log_every` steps), on the communication
+     stream: the compute stream never waits for it (`DataParallelTrainer.metrics()` reads the result)
+That is 4 collectives per step with sync-BN (2 with `sync_bn=False`: per-rank statistics, the PyTorch-DDP default), plus
+one per logging interval.  No collective touches activations; inference needs none (replicas).
 `NewRALEEngineAdapter` runs the 12-lead transfer-learning model the same way: the frozen inner RA-LENet is cut at the same
 two reduction points (its BatchNorm still uses batch statistics), only the 8.8 KB adapter gradient is all-reduced.
-U-Net (a BatchNorm after every conv): `UNetEngineAdapter` cuts the step at every layer, 10 + 10 reductions of 64
-doubles per step, for exact global-batch statistics.
+U-Net (a BatchNorm after every conv): with `sync_bn=True` `UNetEngineAdapter` cuts the step at every layer, 10 + 10
+reductions of 64 doubles per step, for exact global-batch statistics.  They cannot be packed: layer l + 1 normalises with
+the COMPLETE statistics of layer l, and the backward sums of layer l are formed from the gradient that left layer l + 1 -
+each reduction is a true dependency of the next stage, so a 0.5 ms step pays ~20 latency-bound collectives.  With
+`sync_bn=False` every rank normalises with its own shard's statistics (what `torch.nn.parallel.DistributedDataParallel`
+does without SyncBatchNorm) and the step is the fused single-GPU forward / backward plus ONE gradient all-reduce;
+tests/test_dp_gloo.py measures how far that is from the global-batch step (1e-3 class at 64 windows per rank).
 
 The trainer only sequences engine calls and collectives, so it is testable on CPU with
 `gloo` and any engine exposing the same methods (tests/test_dp_gloo.py).
@@ -75,6 +82,12 @@ class HipEngineAdapter:
     def bucket_stream(self):
         if getattr(self, "_comm", None) is None:
             self._comm = torch.cuda.Stream(device=self.m.eng.device)
+            from . import hw_queues_set_too_late
+            if hw_queues_set_too_late():
+                import warnings
+                warnings.warn("ecg_denoise_amd was imported after the GPU was initialised and GPU_MAX_HW_QUEUES is not set: "
+                              "the early gradient bucket's all-reduce will run AFTER the backward pass, not under it. "
+                              "Export GPU_MAX_HW_QUEUES=8 (or import ecg_denoise_amd before the first GPU call).", RuntimeWarning)
         return self._comm
 
     def bucket_wait(self, k, stream):
@@ -125,6 +138,14 @@ class UNetEngineAdapter:
                 yield self.bn_sums[128 * bn + 64:128 * bn + 128]
             self._lib.check(L.ral_unet_backward_stage(h, B, si, global_windows, self._stream()))
         self._lib.check(L.ral_unet_backward_finish(h, B, global_windows, self._stream()))
+
+    # ---- per-rank BatchNorm statistics: the fused single-GPU entry points, no reduction point inside the step
+    def forward_local(self, x):
+        self.pred = self.m.forward(x)
+        return self.pred
+
+    def backward_local(self):
+        self.m.backward()
 
     def adam(self, lr):
         self.m.step(lr)
@@ -220,11 +241,19 @@ class DataParallelTrainer:
     parameters, BatchNorm running statistics, Adam moments, the step count and `num_batches_tracked` are broadcast
     (the model constructors draw their weights from OS entropy unless given a seed, and only gradients are ever
     all-reduced, so replicas that start apart stay apart).  Call `sync_state()` again after loading a checkpoint on
-    one rank."""
+    one rank.
 
-    def __init__(self, engine, group=None, sync_bn=True, sync_state=True):
-        self.e, self.group, self.sync_bn = engine, group, sync_bn
+    `sync_bn`: True = BatchNorm statistics of the global batch (the N-rank step IS the single-process step on the
+    concatenated batch); False = every rank's own statistics (no BatchNorm collective).
+    `log_every`: the loss / SNR / RMSE means of the last `log_every` steps are all-reduced once per interval on the
+    communication stream; `metrics()` returns them.  With `log_every == 1` (default) `train_step` also waits for the
+    reduction and returns the global loss, as the reference loop prints it every step (denoise_train.py:54-64); with a
+    longer interval `train_step` returns this rank's own mean (`loss_is_global` False) and never waits."""
+
+    def __init__(self, engine, group=None, sync_bn=True, sync_state=True, log_every=1):
+        self.e, self.group, self.sync_bn, self.log_every = engine, group, sync_bn, max(1, int(log_every))
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._hist, self._pending, self._last = [], None, None
         if sync_state:
             self.sync_state()
 
@@ -244,23 +273,68 @@ class DataParallelTrainer:
         if self.world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
+    def _comm_stream(self):
+        return self.e.bucket_stream() if hasattr(self.e, "bucket_stream") else None
+
+    # ---- metrics: one reduction per logging interval, off the compute stream -------------------------------------
+    def _log(self, loss, snr, rmse, G):
+        """loss: this rank's share of the global mean ((sse / n) / G); snr, rmse: per local window"""
+        self._hist.append((loss, snr, rmse))
+        if len(self._hist) < self.log_every:
+            return None
+        k = len(self._hist)
+        buf = torch.stack([torch.stack([l.reshape(()).double() for l, _, _ in self._hist]).sum(),
+                           torch.stack([s.double().sum() for _, s, _ in self._hist]).sum() / G,
+                           torch.stack([r.double().sum() for _, _, r in self._hist]).sum() / G]) / k
+        self._hist = []
+        work = None
+        if self.world > 1:
+            comm = self._comm_stream()
+            if comm is not None:
+                comm.wait_stream(torch.cuda.current_stream(buf.device))
+                with torch.cuda.stream(comm):
+                    work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            else:
+                work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._pending = (buf, work, k)
+        return self._pending
+
+    def metrics(self):
+        """global means over the last completed logging interval: {"loss", "snr", "rmse", "steps"} (None before the first)"""
+        if self._pending is not None:
+            buf, work, k = self._pending
+            if work is not None:
+                work.wait()
+            self._last = {"loss": buf[0], "snr": buf[1], "rmse": buf[2], "steps": k}
+            self._pending = None
+        return self._last
+
+    def _finish(self, loss, snr, rmse, pred, G):
+        logged = self._log(loss, snr, rmse, G)
+        if self.log_every == 1 and logged is not None:
+            return {"loss": self.metrics()["loss"].reshape(1), "loss_is_global": True, "snr": snr, "rmse": rmse, "pred": pred}
+        return {"loss": loss * self.world, "loss_is_global": self.world == 1, "snr": snr, "rmse": rmse, "pred": pred}
+
     def train_step(self, x_local, target_local, lr=1e-3):
-        """x_local: this rank's shard (equal shard sizes).  Returns loss (global mean), snr, rmse (local)."""
+        """x_local: this rank's shard (equal shard sizes).  Returns loss (see `log_every`), snr, rmse (local)."""
         B = x_local.shape[0]
         G = B * self.world
         e = self.e
-        if hasattr(e, "forward_iter"):     # an engine with one reduction point per layer (U-Net sync-BatchNorm)
-            for t in e.forward_iter(x_local, G):
-                self._allreduce(t)
-            pred = e.pred
-            loss, snr, rmse = e.loss(pred, target_local, G)
-            for t in e.backward_iter(G):
-                self._allreduce(t)
-            self._allreduce(e.grads)
+        if hasattr(e, "forward_iter"):     # an engine with one reduction point per layer (U-Net)
+            if self.sync_bn:
+                for t in e.forward_iter(x_local, G):
+                    self._allreduce(t)
+                pred = e.pred
+                loss, snr, rmse = e.loss(pred, target_local, G)
+                for t in e.backward_iter(G):
+                    self._allreduce(t)
+            else:                          # per-rank statistics: the fused step, no reduction point inside it
+                pred = e.forward_local(x_local)
+                loss, snr, rmse = e.loss(pred, target_local, G)
+                e.backward_local()
+            self._allreduce(e.grads)       # dy carries 1 / G: the sum of the local gradients is the global-mean gradient
             e.adam(lr)
-            loss = loss.clone()
-            self._allreduce(loss)
-            return {"loss": loss, "snr": snr, "rmse": rmse, "pred": pred}
+            return self._finish(loss, snr, rmse, pred, G)
         e.forward_begin(x_local)
         if self.sync_bn:
             self._allreduce(e.bn_sums[:32])
@@ -288,6 +362,4 @@ class DataParallelTrainer:
         else:
             self._allreduce(e.grads)      # dy already carries 1/G: the sum IS the global-mean gradient
         e.adam(lr)
-        loss = loss.clone()
-        self._allreduce(loss)             # sum of local (sse/n)/G -> global mean
-        return {"loss": loss, "snr": snr, "rmse": rmse, "pred": pred}
+        return self._finish(loss, snr, rmse, pred, G)

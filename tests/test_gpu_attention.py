@@ -35,12 +35,14 @@ def _bias_full(table, Len, N):
     return b
 
 
-def _case(N, H, Len, B, seed):
+def _case(N, H, Len, B, seed, scales=(1.0, 1.0, 1.0, 1.0)):
     g = torch.Generator().manual_seed(seed)
     qkv = torch.randn(B, 3 * H, N, 4, generator=g)
-    qkv[:, :H] *= 0.5
+    qkv[:, :H] *= 0.5 * scales[0]
+    qkv[:, H:2 * H] *= scales[1]
+    qkv[:, 2 * H:] *= scales[2]
     table = 0.5 * torch.randn(2 * Len - 1, H, generator=g) if Len else None
-    do = torch.randn(B, H, N, 4, generator=g)
+    do = torch.randn(B, H, N, 4, generator=g) * scales[3]
     q, k, v = (t.double().requires_grad_(True) for t in (qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]))
     tb = table.double().requires_grad_(True) if Len else None
     s = q @ k.transpose(-1, -2)
@@ -80,6 +82,46 @@ def _case(N, H, Len, B, seed):
 def test_attention_operator_against_fp64(N, H, Len, B):
     errs = _case(N, H, Len, B, seed=N + Len)
     assert all(e == e and e < 2e-5 for e in errs.values()), errs    # fp32 tolerance; NaN = an element left unwritten
+
+
+@pytest.mark.parametrize("N,H,Len", [(512, 2, 32), (64, 16, 4), (32, 32, 0)])
+@pytest.mark.parametrize("scales", [
+    (1e4, 1e-4, 1.0, 1.0), (1e-4, 1e4, 1.0, 1.0),      # q and k twenty-six binades apart (scores still O(1))
+    (1e-3, 1e-3, 1.0, 1.0),                            # scores ~1e-6: a uniform softmax
+    (1.0, 1.0, 1e-6, 1.0), (1.0, 1.0, 1e6, 1.0),       # v far below / above fp16's range
+    (1.0, 1.0, 1.0, 1e-12), (1.0, 1.0, 1.0, 1e8),      # dO: a converged loss, an exploding one
+    (30.0, 1.0, 3e-5, 1e-9),
+])
+def test_attention_operator_operand_ranges(N, H, Len, scales):
+    """The S and dP tiles multiply fp16 PAIRS.  Every operand reaches them through a power of two chosen per head (dO, v:
+    largest magnitude into [2^13, 2^14); q, k: balanced against each other so that q.k is unchanged), so magnitudes far
+    outside fp16's range - where a plain conversion would flush to zero or saturate at 65504 - keep the fp32 tolerance."""
+    errs = _case(N, H, Len, 3, seed=11, scales=scales)
+    assert all(e == e and e < 2e-5 for e in errs.values()), (scales, errs)
+
+
+def test_attention_operator_propagates_non_finite_values():
+    """no clamp anywhere: a NaN in q / an Inf in dO reaches the outputs of its head (as in the fp32 reference) instead of
+    being replaced by a finite number"""
+    L = _lib.lib()
+    for N, H, Len in ((64, 16, 4), (512, 2, 32)):
+        B = 2
+        qkv = torch.randn(B, 3 * H, N, 4, device=DEV)
+        do = torch.randn(B, H, N, 4, device=DEV)
+        qkv[1, 0, 5, 2] = float("nan")
+        do[0, 1, 7, 1] = float("inf")
+        table = torch.zeros(2 * Len - 1, H, device=DEV); gt = torch.zeros_like(table)
+        o = torch.empty(B, H, N, 4, device=DEV); lse = torch.empty(B, H, N, device=DEV); dqkv = torch.zeros_like(qkv)
+        _lib.check(L.ral_attention_forward(_vp(qkv), _vp(o), _vp(lse), _vp(table), N, H, Len, B, _stream()))
+        ns = L.ral_attention_backward_scratch_floats(N, H, Len, 1, B)
+        sc = torch.empty(max(ns, 1), device=DEV)
+        _lib.check(L.ral_attention_backward(_vp(qkv), _vp(o), _vp(do), _vp(lse), _vp(table), _vp(gt), _vp(dqkv), _vp(sc), ns,
+                                            N, H, Len, B, _stream()))
+        torch.cuda.synchronize()
+        assert not torch.isfinite(o[1, 0, 5]).all()                  # the NaN query's own output row
+        assert not torch.isfinite(dqkv[1, 0]).all()                  # ... and the gradients of its head
+        assert not torch.isfinite(dqkv[0, H + 1]).all()              # the Inf output gradient reaches dk of its head
+        assert torch.isfinite(dqkv[0, 0]).all() and torch.isfinite(o[0]).all()   # other heads are untouched
 
 
 @pytest.mark.parametrize("N,H,Len", [(64, 16, 4), (32, 32, 0)])

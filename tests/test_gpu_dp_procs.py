@@ -74,6 +74,12 @@ def test_two_processes_equal_one_process(kind, tmp_path):
                         # (and the running mean behind it follows); nothing else depends on it
         if v.dtype.is_floating_point and kind == "unet" and not k.endswith("running_var"):
             assert np.abs(r0["state"][k].numpy() - v.cpu().numpy()).max() < 1e-4, k     # a tenth of the step (lr = 1e-3)
+        elif v.dtype.is_floating_point and k.endswith("to_kv.bias"):
+            # the KEY half of this bias has an identically zero gradient (softmax is shift invariant: tests/parity_util.py
+            # bounds it by rounding noise), so Adam steps it along the SIGN of that noise - a different 1e-3 walk in every
+            # run, two runs of the same process included; only the value half is a statement about the arithmetic
+            C2 = v.numel() // 2
+            assert rel(r0["state"][k].numpy()[C2:], v.cpu().numpy()[C2:]) < 5e-5, k
         elif v.dtype.is_floating_point:
             assert rel(r0["state"][k].numpy(), v.cpu().numpy()) < 5e-5, k
         else:
