@@ -86,6 +86,7 @@ _SIGS = {
     "ral_wavelet_denoise": (C.c_int, [_VP, _VP, C.c_int64, C.c_int, C.c_float, _VP]),
     "ral_profile_select": (C.c_int, [_VP, C.c_char_p]),
     "ral_profile_read": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "ral_profile_timeline": (C.c_int, [_VP, C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_int64)]),
     "ral_pe_table": (C.c_int, [C.POINTER(RalConfig), C.c_int, _VP, C.c_int64]),
 }
 EXPORTS = tuple(_SIGS)

@@ -275,8 +275,9 @@ struct RalModel {
   int dw_ksplit[5] = {256, 256, 256, 256, 256};
   // optional in-library kernel timing (bench.py roofline leg): hipEvent pairs around the
   // launches of ONE selected kernel kind, on the stream the kernels run on
-  int prof_kind = -1;
+  int prof_kind = -1;                       // a kernel kind, -1 = off, K_ALL = every kind (ral_profile_timeline)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
+  std::vector<std::pair<int, hipStream_t>> prof_meta;   // (kind, stream) of each recorded pair
   size_t prof_used = 0;
 };
 
@@ -284,9 +285,10 @@ enum { K_QKV_FWD = 0, K_ATTN_FWD, K_MLP_FWD, K_MLP_BWD, K_ATTN_BWD, K_QKV_BWD, K
 static const char* KIND_NAMES[K_NKINDS] = {"qkv_fwd", "attn_fwd", "mlp_fwd", "mlp_bwd", "attn_bwd", "qkv_bwd",
                                            "dw", "resample_fwd", "resample_bwd", "stem"};
 
+enum { K_ALL = 1000 };
 struct ProfScope {
   RalModel* m; hipStream_t s; bool on;
-  ProfScope(RalModel* m_, int kind, hipStream_t s_) : m(m_), s(s_), on(m_->prof_kind == kind) {
+  ProfScope(RalModel* m_, int kind, hipStream_t s_) : m(m_), s(s_), on(m_->prof_kind == kind || m_->prof_kind == K_ALL) {
     if (!on) return;
     if (m->prof_used == m->prof_ev.size()) {
       hipEvent_t a = nullptr, b = nullptr;
@@ -296,7 +298,9 @@ struct ProfScope {
         return;
       }
       m->prof_ev.push_back({a, b});
+      m->prof_meta.push_back({kind, s});
     }
+    m->prof_meta[m->prof_used] = {kind, s};
     EV(hipEventRecord(m->prof_ev[m->prof_used].first, s));
   }
   ~ProfScope() {
@@ -1189,6 +1193,7 @@ int ral_profile_select(ral_handle* h, const char* kind) {
   m->prof_used = 0;
   m->prof_kind = -1;
   if (!kind || !*kind) return 0;
+  if (!strcmp(kind, "*")) { m->prof_kind = K_ALL; return 0; }
   for (int k = 0; k < K_NKINDS; ++k)
     if (!strcmp(kind, KIND_NAMES[k])) { m->prof_kind = k; return 0; }
   return fail("unknown kernel kind %s", kind);
@@ -1206,6 +1211,26 @@ int ral_profile_read(ral_handle* h, double* total_ms, int64_t* launches) {
   }
   *total_ms = tot;
   *launches = (int64_t)m->prof_used;
+  m->prof_used = 0;
+  return 0;
+}
+
+int ral_profile_timeline(ral_handle* h, double* rows, int64_t cap_rows, int64_t* nrows) {
+  if (!h || h->kind != 0) return fail("profiling is available for RA-LENet handles only");
+  RalModel* m = h->m;
+  *nrows = (int64_t)m->prof_used;
+  if ((int64_t)m->prof_used > cap_rows) return fail("timeline: %zu rows, room for %lld", m->prof_used, (long long)cap_rows);
+  std::vector<hipStream_t> streams;
+  for (size_t i = 0; i < m->prof_used; ++i) {
+    HIP_OK(hipEventSynchronize(m->prof_ev[i].second));
+    float t0 = 0.f, t1 = 0.f;
+    HIP_OK(hipEventElapsedTime(&t0, m->prof_ev[0].first, m->prof_ev[i].first));
+    HIP_OK(hipEventElapsedTime(&t1, m->prof_ev[0].first, m->prof_ev[i].second));
+    size_t si = 0;
+    while (si < streams.size() && streams[si] != m->prof_meta[i].second) ++si;
+    if (si == streams.size()) streams.push_back(m->prof_meta[i].second);
+    rows[4 * i] = m->prof_meta[i].first; rows[4 * i + 1] = (double)si; rows[4 * i + 2] = t0; rows[4 * i + 3] = t1;
+  }
   m->prof_used = 0;
   return 0;
 }

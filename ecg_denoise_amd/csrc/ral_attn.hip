@@ -913,9 +913,13 @@ __global__ __launch_bounds__(256, (NT == 64 ? 3 : 4)) void k_attn_fwd_w(const fl
 }
 
 // ---- long windows on the f16 matrix cores
+static int attnh_lds_budget() {   // bytes of LDS an item may take (RAL_ATTNH_LDS)
+  static const int b = [] { const char* v = getenv("RAL_ATTNH_LDS"); return v ? atoi(v) : 64 * 1024; }();
+  return b;
+}
 static int attnh_hg(int N, int H, int Len) {
   int hg = H;
-  while (hg > 1 && attn_bwd_h_lds(N, H, hg, Len) > 64 * 1024) hg /= 2;
+  while (hg > 1 && attn_bwd_h_lds(N, H, hg, Len) > (size_t)attnh_lds_budget()) hg /= 2;
   return hg;
 }
 size_t attn_bwd_h_lds(int N, int H, int hg, int Len) {
@@ -942,8 +946,12 @@ void launch_attn_bwd_h(const float* qkv, const float* o_hm, const float* do_hm, 
   const int hg = attnh_hg(N, H, Len), grid = attnh_grid(N, H, Len, B);
   const size_t lds = attn_bwd_h_lds(N, H, hg, Len);
   const int ntab = table ? (2 * Len - 1) * H : 0;
-  if (table) { RAL_SET_LDS((k_attn_bwd_h<2, true>), lds); k_attn_bwd_h<2, true><<<grid, 512, lds, s>>>(qkv, o_hm, do_hm, lse, table, tpart, dqkv, N, H, hg, Len, B); }
-  else { RAL_SET_LDS((k_attn_bwd_h<2, false>), lds); k_attn_bwd_h<2, false><<<grid, 512, lds, s>>>(qkv, o_hm, do_hm, lse, nullptr, nullptr, dqkv, N, H, hg, 0, B); }
+  static const int thr_env = [] { const char* v = getenv("RAL_ATTNH_THREADS"); return v ? atoi(v) : 0; }();
+  // a wave per sweep task where the item has fewer than sixteen (one head of a 256-token window: 8 tasks)
+  const int ntask = hg * (N / 32);
+  const int threads = thr_env ? thr_env : (ntask >= 16 ? 512 : (ntask >= 8 ? 256 : 128));
+  if (table) { RAL_SET_LDS((k_attn_bwd_h<2, true>), lds); k_attn_bwd_h<2, true><<<grid, threads, lds, s>>>(qkv, o_hm, do_hm, lse, table, tpart, dqkv, N, H, hg, Len, B); }
+  else { RAL_SET_LDS((k_attn_bwd_h<2, false>), lds); k_attn_bwd_h<2, false><<<grid, threads, lds, s>>>(qkv, o_hm, do_hm, lse, nullptr, nullptr, dqkv, N, H, hg, 0, B); }
   if (table) k_attn_tpart_reduce<<<(ntab + 3) / 4, 256, 0, s>>>(tpart, gtable, ntab, grid);
 }
 

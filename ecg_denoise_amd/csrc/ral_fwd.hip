@@ -1063,6 +1063,7 @@ void launch_mlp_fwd(int C, int nch, const float* x, const float* o, const BlockP
     else { if (nth == 1024) launch_mlp_fwd_hc<128, 1024>(x, o, w, pbase, wh, x1, upre, x2, N, B, s); else launch_mlp_fwd_hc<128, 512>(x, o, w, pbase, wh, x1, upre, x2, N, B, s); }
     return;
   }
+  if (mlp_fwd_w_takes(C, N, upre != nullptr)) { launch_mlp_fwd_w(C, x, o, w, x1, x2, N, B, s); return; }   // narrow levels: ral_mlpw.hip
   switch (C) {
 #define CASE(c) case c: launch_mlp_fwd_c<c>(nch, x, o, w, x1, upre, x2, N, B, s); break;
     CASE(8) CASE(16) CASE(32) CASE(64) CASE(128)

@@ -32,6 +32,9 @@ size_t mlp_fwd_lds(int C, int N, int nch);
 bool mlp_fwd_uses_f16(int C, int N);
 void launch_mlp_fwd(int C, int nch, const float* x, const float* o, const BlockP& w, const float* pbase, const void* wt,
                     float* x1, float* upre, float* x2, int N, int B, hipStream_t s);
+// narrow levels (C <= 32), wave-autonomous (ral_mlpw.hip)
+bool mlp_fwd_w_takes(int C, int N, bool want_upre);
+void launch_mlp_fwd_w(int C, const float* x, const float* o, const BlockP& w, float* x1, float* x2, int N, int B, hipStream_t s);
 void launch_resample_fwd(int D, bool sep, const float* x, const float* wred, const float* lnw, const float* lnb,
                          const float* skip, float* y, int T, int B, hipStream_t s);
 void launch_add(const float* a, const float* b, float* y, size_t n, hipStream_t s);
