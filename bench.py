@@ -65,7 +65,7 @@ def _profile_json(name):
 
 def measured_traffic(kind):
     """HBM bytes per launch of this kernel kind from the committed PMC run (newest profiles/rNN_hbm_traffic.json)."""
-    for name in ("r03_hbm_traffic.json", "r02_hbm_traffic.json"):
+    for name in ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json"):
         d = _profile_json(name)
         if d and kind in d.get("per_launch_bytes", {}):
             return d["per_launch_bytes"][kind]["total"]
@@ -74,7 +74,7 @@ def measured_traffic(kind):
 
 def unet_fused_traffic():
     """(bytes per launch of the fused U-Net inference kernel at batch 2048 from the committed PMC run, file name)"""
-    for name in ("r03_unet_hbm_traffic.json", "r02_unet_hbm_traffic.json"):
+    for name in ("r04_unet_hbm_traffic.json", "r03_unet_hbm_traffic.json", "r02_unet_hbm_traffic.json"):
         d = _profile_json(name)
         if d:
             f = d.get("fused", {})
@@ -190,7 +190,7 @@ def cpu_baseline(leads, L, variant, big_batch=256):
             res["large_batch"] = {"error": str(exc)[:200]}
     # the figure at the bench batch itself, measured once per round by tools/cpu_baseline_big.py on the GPU box's host
     # (40 s per step and ~50 GB of autograd state: not re-measured inside the default run) and committed under profiles/
-    for name in ("r03_cpu_baseline_b2048.json",):
+    for name in ("r04_cpu_baseline_b2048.json", "r03_cpu_baseline_b2048.json"):
         d = _profile_json(name)
         if d and "value" in d and leads == 1 and L == 512:
             res["bench_batch"] = {"value": d["value"], "batch": 2048, "cores": d.get("cores"), "source": "profiles/" + name,
@@ -316,6 +316,7 @@ def main():
     ap.add_argument("--kind", default="attn_bwd", help="kernel kind timed for the roofline object")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline and the other N = 1 extras")
     ap.add_argument("--no-infer", action="store_true", help="skip the inference-forward leg")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the strict-fp32 leg (profile collection: one arithmetic per trace)")
     ap.add_argument("--kinds", action="store_true", help="print a per-kernel-kind time table to stderr (3 steps each)")
     ap.add_argument("--dry-run-launcher", action="store_true", help="CPU/gloo rendezvous only: tests the process launcher")
     # test hooks (tests/test_gpu_dp_procs.py, tests/test_bench_cpu.py): never part of a measurement
@@ -426,7 +427,7 @@ def main():
     # strict-fp32 leg: the same step with every product on the fp32 MFMA (f16_split = 0: no fp16-pair operand anywhere),
     # timed right after the headline region on the same box, so that the line carries both arithmetics
     fp32_leg = None
-    if inner is not None:
+    if inner is not None and not a.no_fp32:
         h = inner.eng.h
         _lib.check(lib.ral_set_option(h, b"f16_split", 0))
         n32 = max(5, min(10, a.steps))

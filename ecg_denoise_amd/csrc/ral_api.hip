@@ -1038,6 +1038,16 @@ int ral_loss(ral_handle* h, const float* pred, const float* target, int B, int64
   return 0;
 }
 
+int ral_loss_mean(const float* pred, const float* target, int n, int B, int64_t global_windows, float* dy, float* snr,
+                  float* rmse, double* loss_mean, double* scratch2, ral_stream s) {
+  if (!pred || !target || !loss_mean || !scratch2) return fail("ral_loss_mean: null pointer");
+  if (n <= 0 || B <= 0 || global_windows <= 0) return fail("ral_loss_mean: n, B and global_windows must be positive");
+  launch_loss(pred, target, dy, snr, rmse, scratch2, n, B, (float)(2.0 / ((double)global_windows * n)), (hipStream_t)s, loss_mean,
+              1.0 / (double)global_windows);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
 int ral_loss_flat(const float* pred, const float* target, int n, int B, int64_t global_windows, float* dy, float* snr,
                   float* rmse, double* loss_sum, ral_stream s) {
   if (!pred || !target) return fail("ral_loss_flat: null pointer");

@@ -166,10 +166,27 @@ __global__ __launch_bounds__(256) void k_final_fwd(const float* __restrict__ u0,
 //   snr = 10 log10(sy2/sse), rmse = sqrt(sse/n), dy = 2 (p-t) / (global_B * n)
 //   loss_sum += sse / n   (caller divides by the global batch)
 // ---------------------------------------------------------------------------------
+// One thread per workgroup adds the workgroup's share.  With `fin` (ral_loss_mean) the LAST workgroup to arrive also
+// finishes the job on the device: fin[0] = total * fin_scale (the mean over the global batch), and the accumulator and
+// the arrival counter go back to zero for the next call - no fill kernel before the launch, no division kernel after it
+// (they were two torch kernels per training step).  scratch: {double sum, unsigned long long arrivals}, zero on entry.
+RAL_DEV void loss_commit(double* sum, double mine, double* fin, double fin_scale) {
+  atomicAdd(sum, mine);
+  if (!fin) return;
+  unsigned long long* cnt = reinterpret_cast<unsigned long long*>(sum + 1);
+  __threadfence();
+  if (atomicAdd(cnt, 1ull) == (unsigned long long)gridDim.x - 1ull) {
+    __threadfence();
+    const double tot = atomicAdd(sum, 0.0);
+    fin[0] = tot * fin_scale;
+    atomicExch(reinterpret_cast<unsigned long long*>(sum), 0ull);
+    atomicExch(cnt, 0ull);
+  }
+}
 __global__ __launch_bounds__(256) void k_loss(const float* __restrict__ pred, const float* __restrict__ target,
                                               float* __restrict__ dy, float* __restrict__ snr,
                                               float* __restrict__ rmse, double* __restrict__ loss_sum, int n,
-                                              float gscale) {
+                                              float gscale, double* __restrict__ fin, double fin_scale) {
   __shared__ double red[2 * 4];
   const size_t base = (size_t)blockIdx.x * n;
   float v[2] = {0.f, 0.f};
@@ -189,7 +206,7 @@ __global__ __launch_bounds__(256) void k_loss(const float* __restrict__ pred, co
     const float mse = (float)(sse / n), my2 = (float)(sy2 / n);
     if (snr) snr[blockIdx.x] = 10.0f * log10f(my2 / mse);
     if (rmse) rmse[blockIdx.x] = sqrtf(mse);
-    if (loss_sum) atomicAdd(loss_sum, sse / n);
+    if (loss_sum) loss_commit(loss_sum, sse / n, fin, fin_scale);
   }
 }
 
@@ -200,7 +217,7 @@ __global__ __launch_bounds__(256) void k_loss(const float* __restrict__ pred, co
 __global__ __launch_bounds__(256) void k_loss_w(const float* __restrict__ pred, const float* __restrict__ target,
                                                 float* __restrict__ dy, float* __restrict__ snr,
                                                 float* __restrict__ rmse, double* __restrict__ loss_sum, int n, int B,
-                                                float gscale) {
+                                                float gscale, double* __restrict__ fin, double fin_scale) {
   __shared__ double red[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n4 = n >> 2;
   double mine = 0.0;                      // (lane 0: sum over this wave's windows of sse / n)
@@ -236,7 +253,7 @@ __global__ __launch_bounds__(256) void k_loss_w(const float* __restrict__ pred, 
   }
   if (lane == 0) red[wave] = mine;
   __syncthreads();
-  if (threadIdx.x == 0 && loss_sum) atomicAdd(loss_sum, (red[0] + red[1]) + (red[2] + red[3]));
+  if (threadIdx.x == 0 && loss_sum) loss_commit(loss_sum, (red[0] + red[1]) + (red[2] + red[3]), fin, fin_scale);
 }
 
 // ---------------------------------------------------------------------------------
@@ -299,12 +316,12 @@ void launch_final_fwd(int leads, const float* u0, const float* x0, const float* 
 }
 
 void launch_loss(const float* pred, const float* target, float* dy, float* snr, float* rmse, double* loss_sum,
-                 int n, int B, float gscale, hipStream_t s) {
+                 int n, int B, float gscale, hipStream_t s, double* fin, double fin_scale) {
   if (n % 4 == 0) {
     const int g = (B + 3) / 4;
-    k_loss_w<<<g < 512 ? g : 512, 256, 0, s>>>(pred, target, dy, snr, rmse, loss_sum, n, B, gscale);
+    k_loss_w<<<g < 512 ? g : 512, 256, 0, s>>>(pred, target, dy, snr, rmse, loss_sum, n, B, gscale, fin, fin_scale);
   } else {
-    k_loss<<<B, 256, 0, s>>>(pred, target, dy, snr, rmse, loss_sum, n, gscale);
+    k_loss<<<B, 256, 0, s>>>(pred, target, dy, snr, rmse, loss_sum, n, gscale, fin, fin_scale);
   }
 }
 

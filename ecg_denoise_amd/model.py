@@ -216,12 +216,15 @@ class _ModuleBase:
         target = target.contiguous()
         snr = torch.empty(B, dtype=torch.float32, device=pred.device)
         rmse = torch.empty_like(snr)
-        loss_sum = torch.zeros(1, dtype=torch.float64, device=pred.device)
+        loss = torch.empty(1, dtype=torch.float64, device=pred.device)
         dy = torch.empty_like(pred) if want_grad else None
-        _lib.check(_lib.lib().ral_loss(self.eng.h, _ptr(pred), _ptr(target), B, gw, _ptr(dy), _ptr(snr), _ptr(rmse),
-                                       _ptr(loss_sum), _stream()))
+        # (the mean is finished on the device, ral_loss_mean: no fill kernel before the launch, no division after it)
+        if getattr(self, "_loss_scratch", None) is None:
+            self._loss_scratch = torch.zeros(2, dtype=torch.float64, device=pred.device)
+        _lib.check(_lib.lib().ral_loss_mean(_ptr(pred), _ptr(target), pred[0].numel(), B, gw, _ptr(dy), _ptr(snr), _ptr(rmse),
+                                            _ptr(loss), _ptr(self._loss_scratch), _stream()))
         self._dy = dy
-        return loss_sum / gw, snr, rmse
+        return loss, snr, rmse
 
     def backward(self, dy=None, want_dx=False):
         dy = self._dy if dy is None else dy.contiguous()
@@ -438,12 +441,14 @@ class NewRALE:
         pred, target = pred.contiguous(), target.contiguous()
         snr = torch.empty(B, dtype=torch.float32, device=pred.device)
         rmse = torch.empty_like(snr)
-        loss_sum = torch.zeros(1, dtype=torch.float64, device=pred.device)
+        loss = torch.empty(1, dtype=torch.float64, device=pred.device)
         dy = torch.empty_like(pred) if want_grad else None
-        _lib.check(_lib.lib().ral_loss_flat(_ptr(pred), _ptr(target), n, B, gw, _ptr(dy), _ptr(snr), _ptr(rmse),
-                                            _ptr(loss_sum), _stream()))
+        if getattr(self, "_loss_scratch", None) is None:
+            self._loss_scratch = torch.zeros(2, dtype=torch.float64, device=pred.device)
+        _lib.check(_lib.lib().ral_loss_mean(_ptr(pred), _ptr(target), n, B, gw, _ptr(dy), _ptr(snr), _ptr(rmse),
+                                            _ptr(loss), _ptr(self._loss_scratch), _stream()))
         self._dy = dy
-        return loss_sum / gw, snr, rmse
+        return loss, snr, rmse
 
     def _conv_bwd(self, name, x, y, dy, lrelu, want_dx):
         dx = torch.empty_like(x) if want_dx else None

@@ -1,10 +1,13 @@
 """The attention operator on its own (ral_attention_forward / ral_attention_backward through the C-ABI) against an fp64
 torch autograd restatement of `softmax(q k^T + R-wave bias) v` (raletransformer.py:299-316; bias table :534-558), one case
-per kernel variant the launcher can pick:
-  * N = 512 / 256 / 128 with a table: the generic MFMA-tile kernels (k_attn_fwd<2> / k_attn_fwd_v, k_attn_bwd<2, 0, true>)
-  * N = 64 with a table and N = 32 without: the compile-time-window-length instantiations
-  * N = 128 / 64 without a table: the scalar-path backward sweeps (k_attn_bwd_vq / _vkv)
-  * N = 48 (L = 768 windows): QT = 1, no workgroup split
+per kernel the launchers can pick (default switches; `test_every_kernel_choice_of_the_launchers` re-runs the file with the
+others):
+  * N = 512 / 256, with and without a table: k_attn_bwd_h (workgroup per head group, S / dP tiles as fp16-pair products),
+    forward k_attn_fwd<2, 0, true, true> (f16 S tile)
+  * N = 128 / 64 / 32, with and without a table: k_attn_bwd_w (one wave per head, rotated tiles with a table), forward
+    k_attn_fwd_v (N = 64, 128) and k_attn_fwd_w (N = 32)
+  * N = 48 (L = 768 windows) and N = 1024: the generic kernels of ral_bwd.hip / ral_fwd.hip (QT = 1; one head per item)
+  * a table as wide as the window (N = 32, Len = 8 ... N = 64, Len = 32): every tile takes the table path
 Batches that are not a multiple of anything (5, 3) and B = 700 (persistent workgroups take several items)."""
 import ctypes as C
 
@@ -78,6 +81,7 @@ def _case(N, H, Len, B, seed, scales=(1.0, 1.0, 1.0, 1.0)):
     (512, 2, 32, 3), (256, 4, 16, 5), (128, 8, 8, 5), (64, 16, 4, 5), (32, 32, 0, 5),   # the five levels of a 512-sample window
     (128, 8, 0, 3), (64, 16, 0, 5),                                                      # the same lengths without a table
     (48, 8, 8, 3), (1024, 2, 64, 1),                                                     # L = 768 and L = 1024 top levels
+    (256, 4, 0, 3), (512, 2, 0, 2), (32, 8, 8, 5), (64, 2, 32, 3), (32, 2, 24, 3),                       # long windows without a table; a table as wide as the short window's tiles
 ])
 def test_attention_operator_against_fp64(N, H, Len, B):
     errs = _case(N, H, Len, B, seed=N + Len)
@@ -148,3 +152,22 @@ def test_attention_backward_rejects_missing_scratch():
     small = torch.empty(ns - 1, device=DEV)
     rc = L.ral_attention_backward(_vp(qkv), _vp(o), _vp(o), _vp(lse), _vp(table), _vp(gt), _vp(dqkv), _vp(small), ns - 1, N, H, Len, B, _stream())
     assert rc != 0
+
+
+@pytest.mark.parametrize("env", [
+    {"RAL_ATTN_F16": "0"},                                                        # fp32-MFMA tiles in the new kernels (strict mode)
+    {"RAL_ATTN_BWD_W": "0", "RAL_ATTN_BWD_H": "0", "RAL_ATTN_FWD_W": "0", "RAL_ATTN_FWD_H": "0"},   # the workgroup / scalar-path kernels of ral_fwd.hip, ral_bwd.hip
+    {"RAL_ATTN_FWD_W": "2"},                                                      # wave-autonomous forward at N = 64 and 128 too
+    {"RAL_ATTN_FWD_W": "2", "RAL_ATTN_F16": "0"},
+])
+def test_every_kernel_choice_of_the_launchers(env):
+    """The launchers pick kernels by shape and by process-wide switches (read once): each alternative choice runs the
+    fp64 comparison of this file in a process of its own."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
+                        "against_fp64 or many_windows or operand_ranges or non_finite"],
+                       env=dict(os.environ, **env), cwd=root, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]

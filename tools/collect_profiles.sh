@@ -4,16 +4,16 @@
 # --kernel-trace only), the same for the U-Net forward, plus the attention and VALU micro-benchmarks.
 #   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r03'
 # Everything lands under gpurun_out/<round>/; tools/summarise_profiles.py turns it into profiles/<round>_*.
-R=${1:-r03}
+R=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$R
 rm -rf "$O"; mkdir -p "$O"
-BENCH="python3 bench.py --steps 5 --warmup 2 --no-cpu --no-infer"
+BENCH="python3 bench.py --steps 5 --warmup 2 --no-cpu --no-infer --no-fp32"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_default -- $BENCH > $O/ks_default.log 2>&1
 export RAL_LANES=1 RAL_NO_SIDE_STREAM=1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_serial -- $BENCH > $O/ks_serial.log 2>&1
-B1="python3 bench.py --steps 1 --warmup 1 --no-cpu --no-infer"
+B1="python3 bench.py --steps 1 --warmup 1 --no-cpu --no-infer --no-fp32"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- $B1 > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- $B1 > $O/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq -- $B1 > $O/pmc_sq.log 2>&1
@@ -29,6 +29,9 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/unet_staged_
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/unet_staged_write -- $U > $O/unet_staged_write.log 2>&1
 unset RAL_UNET_FUSED
 python3 tools/attn_bench.py > $O/attn_bench.log 2>&1
+RAL_ATTN_F16=0 python3 tools/attn_bench.py > $O/attn_bench_fp32.log 2>&1
+python3 tools/diag/step_timeline_events.py $O/step_timeline_events.txt > /dev/null 2>&1
+RAL_LANES=1 RAL_NO_SIDE_STREAM=1 python3 tools/diag/step_timeline_events.py $O/step_timeline_events_serial.txt > /dev/null 2>&1
 [ -x tools/diag/valu_probe ] && ./tools/diag/valu_probe > $O/valu_probe.log 2>&1
 python3 bench.py --steps 50 --warmup 5 --kinds > $O/bench.json 2> $O/bench_kinds.log
 python3 bench.py --config newrale --no-cpu > $O/bench_newrale.json 2> $O/bench_newrale.err

@@ -29,7 +29,9 @@ for src, name in (("attn_bench.log", "attn_bench.jsonl"), ("valu_probe.log", "va
                   ("bench_kinds.log", "bench_kinds.txt"), ("config_bench.log", "config_bench.jsonl"),
                   ("baselines_bench.log", "baselines_bench.jsonl"), ("bench_newrale.json", "bench_newrale.json"),
                   ("bench_unet.json", "bench_unet.json"), ("unet_train_timeline.txt", "unet_train_timeline.txt"),
-                  ("dp2_overlap.txt", "dp2_overlap.txt"), ("cpu_baseline_b2048.json", "cpu_baseline_b2048.json")):
+                  ("dp2_overlap.txt", "dp2_overlap.txt"), ("cpu_baseline_b2048.json", "cpu_baseline_b2048.json"),
+                  ("attn_bench_fp32.log", "attn_bench_fp32.jsonl"), ("step_timeline_events.txt", "step_timeline_events.txt"),
+                  ("step_timeline_events_serial.txt", "step_timeline_events_serial.txt")):
     if os.path.exists(os.path.join(SRC, src)):
         lines = [l for l in open(os.path.join(SRC, src)) if "amdgpu.ids" not in l]
         open(os.path.join(DST, f"{R}_{name}"), "w").writelines(lines)
