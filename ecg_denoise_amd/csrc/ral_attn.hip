@@ -101,7 +101,8 @@ __global__ __launch_bounds__(256, RAL_ATTNW_WPE) void k_attn_bwd_w(const float* 
   float* Dl = Ls + T;                           // -rowsum(dO * O) (F16: times the task's scale)
   const int Len = TAB ? Len_rt : 0;
   const int ntab = TAB ? (2 * Len - 1) * H : 0;
-  float* tab = sm + 4 * WSZ;     // bias * log2(e), (2 Len - 1, H)
+  const int nwv = blockDim.x >> 6;   // waves per workgroup (the launcher sizes it so that the wave slices fill the LDS)
+  float* tab = sm + nwv * WSZ;   // bias * log2(e), (2 Len - 1, H)
   float* dtab = tab + ntab;
   const int off = (NT - Len) >> 1;
   if constexpr (TAB) {
@@ -115,8 +116,8 @@ __global__ __launch_bounds__(256, RAL_ATTNW_WPE) void k_attn_bwd_w(const float* 
   };
   const int xe0 = !TAB ? NT : (off < SH ? 0 : ((off - SH) & ~15));
   const int xe1 = !TAB ? NT : (off < SH ? NT : ((off + Len - SH + 15) & ~15));
-  const int stride = gridDim.x * 4;
-  int task = blockIdx.x * 4 + wave;
+  const int stride = gridDim.x * nwv;
+  int task = blockIdx.x * nwv + wave;
   float inv = 1.f;               // F16: 1 / (scale of dO x scale of v) of the task in the LDS
 
   // operands of one task in flight (PREF: one token per lane): q, k, v, dO, O quads and lse
@@ -986,10 +987,26 @@ void launch_attn_bwd_w(const float* qkv, const float* o_hm, const float* do_hm, 
   const int hw = N >= 64 ? 1 : 64 / N, T = hw * N;
   const int ntask = B * H / hw;
   const int ntab = table ? (2 * Len - 1) * H : 0;
-  const size_t lds = ((size_t)4 * T * (f16 ? 30 : 18) + 2 * ntab) * sizeof(float);
+  // waves per workgroup (RAL_ATTNW_WAVES).  Measured at batch 2048, us per launch with 4 / 3 / 2 / 1 waves: N = 128: 236 / 274 /
+  // 245 / 283 (four-wave workgroups of 61 KB leave a CU two of them, five two-wave ones fit - and are no faster), N = 64:
+  // 131 / 135 / 142 / 173, N = 32: 82 / 80 / 83 / 99
+  static const int wv_env = [] { const char* v = getenv("RAL_ATTNW_WAVES"); return v ? atoi(v) : 0; }();
+  const int nwv = wv_env ? wv_env : 4;
+  const size_t lds = ((size_t)nwv * T * (f16 ? 30 : 18) + 2 * ntab) * sizeof(float);
   int grid = 0;
-#define GO(n, tab, h, qt) { RAL_SET_LDS((k_attn_bwd_w<n, tab, h, qt>), lds); grid = attnw_grid(k_attn_bwd_w<n, tab, h, qt>, lds, N, H, B); \
-    k_attn_bwd_w<n, tab, h, qt><<<grid, 256, lds, s>>>(qkv, o_hm, do_hm, lse, table, tpart, dqkv, H, Len, ntask); }
+  auto grid_of = [&](auto kern) {
+    static const int genv = [] { const char* v = getenv("RAL_GRID_ATTNW"); return v ? atoi(v) : 0; }();
+    const int gmax = attnw_grid_max(N, H, B);          // (the scratch is sized for one workgroup per four tasks)
+    if (genv > 0) return genv < gmax ? genv : gmax;
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64 * nwv, lds) != hipSuccess || occ < 1) occ = 3;
+    const int slots = 256 * (occ > 8 ? 8 : occ);
+    const int need = (ntask + nwv - 1) / nwv;
+    int g = slots < need ? slots : need;
+    return g < gmax ? g : gmax;
+  };
+#define GO(n, tab, h, qt) { RAL_SET_LDS((k_attn_bwd_w<n, tab, h, qt>), lds); grid = grid_of(k_attn_bwd_w<n, tab, h, qt>); \
+    k_attn_bwd_w<n, tab, h, qt><<<grid, 64 * nwv, lds, s>>>(qkv, o_hm, do_hm, lse, table, tpart, dqkv, H, Len, ntask); }
 #define GOH(n, tab) { if (f16) GO(n, tab, true, 2) else GO(n, tab, false, 2) }
   if (N == 32) { if (table) GOH(32, true) else GOH(32, false) }
   else if (N == 64) {
