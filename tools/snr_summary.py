@@ -3,8 +3,10 @@ epochs of the main.py protocol, three intra-op thread counts = three summation o
 made by oracle/gen_ref_train_curve.py in the build container) next to the HIP path's own repeats from the same initial
 weights (gpurun_out/snr_experiment_full_seed777_*.json, tools/snr_experiment.py on one MI355X; fp32 atomics make them
 differ) and the round-1 runs (same init and three other seeds)."""
-import glob, json, os
+import glob, json, os, sys
 import numpy as np
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r02"      # output profiles/<round>_snr_experiment.json
+TAG = sys.argv[2] if len(sys.argv) > 2 else ""            # only the HIP runs whose file name carries this tag (e.g. _r4)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ref = []
 for tag, th in (("", 6), ("_t2", 2), ("_t3", 3), ("_t1", 1), ("_t4", 4)):
@@ -15,12 +17,12 @@ for tag, th in (("", 6), ("_t2", 2), ("_t3", 3), ("_t1", 1), ("_t4", 4)):
     ref.append({"threads": th, "final_test_snr_db": round(c[-1], 4), "mean_last10_db": round(c[-10:].mean(), 4),
                 "first5_db": [round(v, 4) for v in c[:5]], "seconds_cpu": round(float(g["seconds"])), "test_snr_curve": [round(v, 4) for v in c]})
 hip = []
-for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "snr_experiment_full_seed777_*.json"))):
+for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"snr_experiment_full_seed777{TAG}*.json"))):
     d = json.load(open(f))
     hip.append({"run": os.path.basename(f)[-6:-5], "init_seed": 777, "final_test_snr_db": round(d["final_test_snr_db"], 4),
                 "mean_last10_db": round(d["mean_last10_db"], 4), "first5_db": [round(v, 4) for v in d["test_snr_curve"][:5]],
                 "seconds_gpu": d["seconds"], "test_snr_curve": [round(v, 4) for v in d["test_snr_curve"]]})
-r01 = json.load(open(os.path.join(ROOT, "profiles", "r01_snr_experiment.json")))["runs"]
+r01 = json.load(open(os.path.join(ROOT, "profiles", "r01_snr_experiment.json")))["runs"] if not TAG else []
 for d in r01:
     hip.append({"run": "r01", "init_seed": d["init_seed"], "final_test_snr_db": d["final_test_snr_db"], "mean_last10_db": d.get("mean_last10_db"),
                 "seconds_gpu": d.get("seconds")})
@@ -43,5 +45,5 @@ out = {"note": __doc__.replace("\n", " "),
                    "hip_minus_reference_mean_last10_db": round(float(np.mean(hl) - np.mean(rl)), 3),
                    "epochs_1_2_max_difference_db": round(agree, 5), "reading": reading},
        "reference_runs": ref, "hip_runs": hip}
-json.dump(out, open(os.path.join(ROOT, "profiles", "r02_snr_experiment.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "profiles", f"{ROUND}_snr_experiment.json"), "w"), indent=1)
 print(json.dumps(out["summary"], indent=1))
