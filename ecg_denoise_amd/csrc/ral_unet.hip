@@ -55,6 +55,13 @@ struct Stage {
 };
 
 RAL_DEV float lrelu01(float v) { return v > 0.f ? v : 0.01f * v; }
+// x / d (x >= 0) for a divisor that is nearly always a power of two here (window lengths, tensor sizes, tile counts):
+// sh = log2(d) or -1.  A run-time integer division is ~25 vector instructions; the stage kernels are bound by those.
+// Row stride (floats) of a weight matrix kept in LDS as a B operand of the MFMA tiles: lane (r, g) of a k-step reads row r,
+// column 4 ks + g - conflict-free when the stride is 4 x an odd number (the row lengths 32, 64, 96 put 16 rows in 2 banks).
+constexpr int wrow_ld(int row) { return (row % 8 == 4) ? row : row + 4; }
+RAL_DEV int pow2_shift(int d) { return (d > 0 && (d & (d - 1)) == 0) ? __builtin_ctz((unsigned)d) : -1; }
+RAL_DEV int qdiv(int x, int d, int sh) { return sh >= 0 ? (x >> sh) : x / d; }
 
 // One BatchNorm record (S1[MAXC], S2[MAXC] doubles) that may be spread over `nrep` replicas of 64 doubles -> out64 (LDS).
 // All 256 threads of the workgroup take part (thread t: entry t & 63 of the replicas (t >> 6) + 4 j), the four partial rows
@@ -233,6 +240,20 @@ RAL_DEV void seg_atomic(float* addr, float v, int w) {
 // thread produces 4 consecutive positions of one output channel from registers (inputs of a channel are
 // read once from the zero-haloed LDS row and reused by the 4 outputs), per-channel statistics go to LDS
 // with two atomics per thread.  MODE 0: Conv1d(k3, s2, p1); 1: Conv1d(k1 | k3, s1, same); 2: ConvTranspose1d(k4, s2, p1)
+// phase stamps of ONE instantiation (diagnostic builds: make STAMP=1 STAMPTU=UNET STAMPSEL='CIN==4&&COUT==2&&MODE==2';
+// tools/diag/stamp_unet_bwd.py): slots 16.. = prologue, load phase, input gradient, weight gradient, flush of the backward stage;
+// slots 8.. = prologue, load phase, compute, flush of the forward stage
+#ifndef UNET_STAMP_WG
+#define UNET_STAMP_WG 0
+#endif
+#if defined(RAL_STAMP) && defined(RAL_STAMP_HERE) && defined(UNET_STAMP_SEL)
+#define UB_STAMP(i) do { if ((UNET_STAMP_SEL) && blockIdx.x == UNET_STAMP_WG && threadIdx.x == 0) { const long long t_ = clock64(); \
+    atomicAdd(&g_ral_stamps[i], (unsigned long long)(t_ - ub_prev_)); ub_prev_ = t_; } } while (0)
+#define UB_STAMP_INIT() long long ub_prev_ = clock64()
+#else
+#define UB_STAMP(i) do {} while (0)
+#define UB_STAMP_INIT() do {} while (0)
+#endif
 // ---------------------------------------------------------------------------------
 #ifndef UNET_FWD_THREADS
 #define UNET_FWD_THREADS 512
@@ -248,10 +269,16 @@ __global__ __launch_bounds__(UNET_FWD_THREADS) void k_unet_fwd_t(Stage st, int B
   const int lin = st.lin, lout = st.lout, LP = lin + 2 * HALO;
   float* in = reinterpret_cast<float*>(smem4);  // WP x CIN x LP
   float* rt = in + WP * CIN * LP;               // residual operand (already lrelu(BN(z))): WP x COUT x lout, when st.r.z
+  // weights: [co][ci][k] (Conv1d) / [ci][co][k] (ConvTranspose1d) as in global memory; the MFMA path of the Conv1d layers reads
+  // rows of one output channel per lane and keeps them at a padded stride (wrow_ld)
+  constexpr bool FMFMA = CIN >= 4 && (CIN * KS) % 4 == 0 && (MODE != 2 || COUT >= 16);   // (narrow ConvTranspose1d layers: 16-channel tiles
+                                                                                          //  would be mostly padding; measured slower)
+  constexpr int FKTOT = CIN * KS, WLD = (FMFMA && MODE != 2) ? wrow_ld(FKTOT) : FKTOT, WSZ = (MODE == 2) ? nw : COUT * WLD;
   float* ws = rt + (st.r.z ? WP * COUT * lout : 0);
-  float* bs = ws + nw;
+  float* bs = ws + WSZ;
   float* ca = bs + MAXC; float* cb = ca + 4 * MAXC; float* cr = cb + 4 * MAXC;
   float* red = cr + 4 * MAXC;
+  UB_STAMP_INIT();
   // every global load of the prologue is requested before the first is waited for: the BatchNorm records of the
   // operands, the weights (at most 3 float4 per thread) and the bias
   const SrcReq la = src_request(st.a, CIN, st.w), lb = src_request(st.b.z ? st.b : st.a, CIN, st.w),
@@ -270,7 +297,7 @@ __global__ __launch_bounds__(UNET_FWD_THREADS) void k_unet_fwd_t(Stage st, int B
 #pragma unroll
   for (int k = 0; k < NWVF; ++k) {
     const int i = threadIdx.x + k * NTF;
-    if (i < nw / 4) reinterpret_cast<float4*>(ws)[i] = wv[k];
+    if (i < nw / 4) *reinterpret_cast<float4*>(ws + (WLD == FKTOT ? 4 * i : (4 * i / FKTOT) * WLD + (4 * i) % FKTOT)) = wv[k];
   }
   if ((int)threadIdx.x < COUT) bs[threadIdx.x] = bv;
   for (int i = threadIdx.x; i < 2 * MAXC; i += blockDim.x) red[i] = 0.f;
@@ -285,17 +312,42 @@ __global__ __launch_bounds__(UNET_FWD_THREADS) void k_unet_fwd_t(Stage st, int B
   if (st.r.z) src_coeffs_slot(st.r, COUT, st.count_r, cr, lr, 2, 2);
   __syncthreads();
   const int nin = CIN * lin, nout = COUT * lout, q = lout >> 2, nslots = COUT * q, nin4 = nin >> 2, nout4 = nout >> 2;
+  const int sh_lin = pow2_shift(lin), sh_lout = pow2_shift(lout), sh_nin4 = pow2_shift(nin4), sh_nout4 = pow2_shift(nout4),
+            sh_q = pow2_shift(q), sh_nslots = pow2_shift(nslots);
   const bool a_lrelu = st.a.act == ACT_LRELU;
+  // Layers with at least four input channels run on the matrix pipe (the vector loop below it is bound by its LDS reads: 5 of
+  // the 11.5 us of the 32 -> 32 k3 stage): tiles of 16 output positions x 16 output channels, K = (ci, k) pairs in the order
+  // kk = ci KS + k = 4 ks + (lane >> 4), both operands gathered from the LDS tiles by index - per-lane bases that repeat with
+  // period FW_P in the k-step plus compile-time multiples of a uniform step (as in the backward kernel's input gradient).
+  // A wave keeps one channel tile; a lane ends with 4 consecutive positions of one output channel.
+  constexpr int FCT = (COUT + 15) / 16, FKST = FKTOT / 4, FNWAVE = UNET_FWD_THREADS / 64;
+  constexpr int FW_P = (KS == 3) ? 3 : 1, FW_CSTEP = 4 * FW_P / KS;
+  constexpr int FW_KCH = FKST < 12 ? (FKST < 1 ? 1 : FKST) : 12;
+  static_assert(FNWAVE % FCT == 0, "a wave keeps its channel tile");
+  const int lane = threadIdx.x & 63, r = lane & 15, g4 = lane >> 4, wave = threadIdx.x >> 6;
+  const int cow = ((wave % FCT) << 4) + r, coc = cow < COUT ? cow : COUT - 1;
+  int fabase[FW_P], fbbase[FW_P];
+  bool fazero[FW_P];
+#pragma unroll
+  for (int j = 0; j < FW_P; ++j) {
+    const int kk0 = 4 * j + g4, ci0 = kk0 / KS, k = kk0 - ci0 * KS, t0 = r + 1 - k;   // (MODE 2: output n0 + r meets input (pos + 1 - k) / 2)
+    fabase[j] = ci0 * LP + HALO + (MODE == 1 ? k - (KS - 1) / 2 : (MODE == 0 ? k - 1 : (t0 >> 1)));
+    fazero[j] = MODE == 2 && (t0 & 1);
+    fbbase[j] = (MODE == 2) ? (ci0 * COUT + coc) * KS + k : coc * WLD + kk0;
+  }
+  constexpr int FW_BSTEP = (MODE == 2) ? FW_CSTEP * COUT * KS : 4 * FW_P;   // floats of the weight tensor per period of k-steps
+  const float fbias = bs[coc];
   // lanes of a wave that hold the same output channel in the compute loop (q consecutive slots, when q is a power of two
   // and every wave of the loop is full): their sums are combined before the LDS atomic - same-address LDS atomics of a
   // wave execute one after the other
   const int segw = ((q & (q - 1)) == 0 && q >= 8 && nslots % 64 == 0) ? (q < 64 ? q : 64) : 1;
+  UB_STAMP(8);
   for (int w0 = blockIdx.x * WP; w0 < B; w0 += gridDim.x * WP) {
     const int nwin = (B - w0) < WP ? (B - w0) : WP;
     const float4* za = reinterpret_cast<const float4*>(st.a.z + (size_t)w0 * nin);
     const float4* zb = st.b.z ? reinterpret_cast<const float4*>(st.b.z + (size_t)w0 * nin) : nullptr;
     auto put = [&](int i, float4 v, float4 u) {
-      const int wi = i / nin4, e = (i - wi * nin4) << 2, c = e / lin, p = e - c * lin;
+      const int wi = qdiv(i, nin4, sh_nin4), e = (i - wi * nin4) << 2, c = qdiv(e, lin, sh_lin), p = e - c * lin;
       const float sa = ca[c], ha = ca[CIN + c];
       v = make_float4(v.x * sa + ha, v.y * sa + ha, v.z * sa + ha, v.w * sa + ha);
       if (a_lrelu) v = make_float4(lrelu01(v.x), lrelu01(v.y), lrelu01(v.z), lrelu01(v.w));
@@ -324,7 +376,7 @@ __global__ __launch_bounds__(UNET_FWD_THREADS) void k_unet_fwd_t(Stage st, int B
           const int i = i0 + k * bd + (int)threadIdx.x;
           if (i < na) put(i, v[k], u[k]);
           if (i < nr) {
-            const int e = (i % nout4) << 2, c = e / lout;
+            const int e = (i - qdiv(i, nout4, sh_nout4) * nout4) << 2, c = qdiv(e, lout, sh_lout);
             const float sr = cr[c], hr = cr[COUT + c];
             const float4 z4 = rr[k];
             reinterpret_cast<float4*>(rt)[i] = make_float4(lrelu01(z4.x * sr + hr), lrelu01(z4.y * sr + hr), lrelu01(z4.z * sr + hr), lrelu01(z4.w * sr + hr));
@@ -333,8 +385,59 @@ __global__ __launch_bounds__(UNET_FWD_THREADS) void k_unet_fwd_t(Stage st, int B
       }
     }
     __syncthreads();
+    UB_STAMP(9);
+    if constexpr (FMFMA) {
+      const int ptiles = (lout + 15) >> 4, sh_pt = pow2_shift(ptiles);
+      for (int tile = wave; tile < nwin * ptiles * FCT; tile += FNWAVE) {
+        const int tp = tile / FCT, wi = qdiv(tp, ptiles, sh_pt), n0 = (tp - wi * ptiles) << 4;
+        const int pos = n0 + r, posc = pos < lout ? pos : lout - 1;   // (rows past the end: clamped address, dropped below)
+        const float* xa = in + wi * CIN * LP + (MODE == 1 ? posc : (MODE == 0 ? 2 * posc : (n0 >> 1)));
+        f32x4 acc0 = {fbias, fbias, fbias, fbias}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < FKST; kc += FW_KCH) {
+          float av[FW_KCH], bv[FW_KCH];
+#pragma unroll
+          for (int u = 0; u < FW_KCH; ++u) {
+            const int ks = kc + u, j = ks % FW_P, i = ks / FW_P;
+            if (ks < FKST) {
+              av[u] = xa[fabase[j] + i * FW_CSTEP * LP];
+              if (MODE == 2 && fazero[j]) av[u] = 0.f;
+              bv[u] = ws[fbbase[j] + i * FW_BSTEP];
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < FW_KCH; ++u) {
+            if (kc + u < FKST) {
+              if (u & 1) acc1 = mfma4(av[u], bv[u], acc1); else acc0 = mfma4(av[u], bv[u], acc0);
+            }
+          }
+        }
+        f32x4 accv = acc0 + acc1;
+        const int p0 = n0 + 4 * g4;
+        const bool valid = cow < COUT && p0 < lout;
+        float s1 = 0.f, s2 = 0.f;
+        if (valid) {
+          float acc[4] = {accv[0], accv[1], accv[2], accv[3]};
+          if (st.post_lrelu) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = lrelu01(acc[j]);
+          }
+          if (st.r.z) {
+            const float4 rr = *reinterpret_cast<const float4*>(rt + (size_t)wi * nout + (size_t)cow * lout + p0);
+            acc[0] += rr.x; acc[1] += rr.y; acc[2] += rr.z; acc[3] += rr.w;
+          }
+          *reinterpret_cast<float4*>(st.out + (size_t)(w0 + wi) * nout + (size_t)cow * lout + p0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+          s1 = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+          s2 = (acc[0] * acc[0] + acc[1] * acc[1]) + (acc[2] * acc[2] + acc[3] * acc[3]);
+        }
+        if (st.sums_out) {   // the four position groups of a channel meet in one lane: one LDS atomic per channel, tile and sum
+          s1 = rows_sum(s1); s2 = rows_sum(s2);
+          if (g4 == 0 && cow < COUT) { atomicAdd(red + cow, s1); atomicAdd(red + MAXC + cow, s2); }
+        }
+      }
+    } else
     for (int slot = threadIdx.x; slot < nwin * nslots; slot += blockDim.x) {
-      const int wi = slot / nslots, sl = slot - wi * nslots, co = sl / q, l0 = (sl - co * q) << 2;
+      const int wi = qdiv(slot, nslots, sh_nslots), sl = slot - wi * nslots, co = qdiv(sl, q, sh_q), l0 = (sl - co * q) << 2;
       float acc[4] = {bs[co], bs[co], bs[co], bs[co]};
 #pragma unroll 4
       for (int ci = 0; ci < CIN; ++ci) {
@@ -384,13 +487,16 @@ __global__ __launch_bounds__(UNET_FWD_THREADS) void k_unet_fwd_t(Stage st, int B
         seg_atomic(red + MAXC + co, (acc[0] * acc[0] + acc[1] * acc[1]) + (acc[2] * acc[2] + acc[3] * acc[3]), segw);
       }
     }
+    UB_STAMP(10);
     __syncthreads();
+    UB_STAMP(11);
   }
   if (st.sums_out && (int)threadIdx.x < COUT) {
     double* rec = st.sums_out + (size_t)(blockIdx.x % st.nrep) * 64;
     atomicAdd(rec + threadIdx.x, (double)red[threadIdx.x]);
     atomicAdd(rec + MAXC + threadIdx.x, (double)red[MAXC + threadIdx.x]);
   }
+  UB_STAMP(12);
 }
 
 // `sums` is the record the statistics come from, in nrep replicas; `final` (the caller-visible bn_sums record) receives the
@@ -666,16 +772,6 @@ __global__ __launch_bounds__(256) void k_unet_bwd(Stage st, int B) {
 // (st.part: workgroups x parameters), folded by k_unet_fold after the last stage - no global atomics except the 2 x C
 // BatchNorm-backward sums the NEXT stage needs.  (st.part == nullptr: atomics straight into the gradient buffer.)
 // ---------------------------------------------------------------------------------
-// phase stamps of ONE instantiation (diagnostic builds: make STAMP=1 STAMPTU=UNET STAMPSEL='CIN==4&&COUT==2&&MODE==2';
-// tools/diag/stamp_unet_bwd.py): slots 16.. = prologue, load phase, input gradient, weight gradient, flush
-#if defined(RAL_STAMP) && defined(RAL_STAMP_HERE) && defined(UNET_STAMP_SEL)
-#define UB_STAMP(i) do { if ((UNET_STAMP_SEL) && blockIdx.x == 0 && threadIdx.x == 0) { const long long t_ = clock64(); \
-    atomicAdd(&g_ral_stamps[i], (unsigned long long)(t_ - ub_prev_)); ub_prev_ = t_; } } while (0)
-#define UB_STAMP_INIT() long long ub_prev_ = clock64()
-#else
-#define UB_STAMP(i) do {} while (0)
-#define UB_STAMP_INIT() do {} while (0)
-#endif
 #define UNET_BWD_THREADS 512
 template <int CIN, int COUT, int KS, int MODE>
 __global__ __launch_bounds__(UNET_BWD_THREADS, 2) void k_unet_bwd_t(Stage st, int B, int WP) {
@@ -689,8 +785,11 @@ __global__ __launch_bounds__(UNET_BWD_THREADS, 2) void k_unet_bwd_t(Stage st, in
   float* zra = in + WP * CIN * LP;                                    // WP x CIN x LP   raw z of operand a (want_din)
   float* aux = zra + (want_din ? WP * CIN * LP : 0);                  // WP x CIN x LP   raw z of operand b | old G_a
   float* dc = aux + ((has_b || acc_a) ? WP * CIN * LP : 0);           // WP x COUT x LPO gradient at the conv output
+  // weights as in global memory ([co][ci][k] / ConvTranspose1d: [ci][co][k]); the ConvTranspose1d layers read one row per
+  // lane in the input gradient and keep the rows at a padded stride (wrow_ld)
+  constexpr int BWROW = COUT * KS, BWLD = (MODE == 2) ? wrow_ld(BWROW) : BWROW, BWSZ = (MODE == 2) ? CIN * BWLD : nw;
   float* ws = dc + WP * COUT * LPO;              // weights
-  float* gws = ws + nw;                          // weight-gradient partial of the workgroup
+  float* gws = ws + BWSZ;                        // weight-gradient partial of the workgroup
   float* ca = gws + nw; float* cb = ca + 4 * MAXC; float* cr = cb + 4 * MAXC; float* co_ = cr + 4 * MAXC;
   float* sa = co_ + 5 * MAXC; float* sb = sa + 2 * MAXC; float* sr = sb + 2 * MAXC;
   float* gbs = sr + 2 * MAXC;                    // MAXC bias grads + 4*MAXC scratch
@@ -712,7 +811,7 @@ __global__ __launch_bounds__(UNET_BWD_THREADS, 2) void k_unet_bwd_t(Stage st, in
 #pragma unroll
   for (int k = 0; k < NWV; ++k) {
     const int i = threadIdx.x + k * NT;
-    if (i < nw / 4) reinterpret_cast<float4*>(ws)[i] = wv[k];
+    if (i < nw / 4) *reinterpret_cast<float4*>(ws + (BWLD == BWROW ? 4 * i : (4 * i / BWROW) * BWLD + (4 * i) % BWROW)) = wv[k];
   }
   for (int i = threadIdx.x; i < nw; i += NT) gws[i] = 0.f;
   for (int i = threadIdx.x; i < 7 * MAXC; i += NT) sa[i] = 0.f;   // sa, sb, sr, gbs[0:MAXC]
@@ -747,6 +846,7 @@ __global__ __launch_bounds__(UNET_BWD_THREADS, 2) void k_unet_bwd_t(Stage st, in
   }
   __syncthreads();
   const int nin = CIN * lin, nout = COUT * lout, nin4 = nin >> 2, nout4 = nout >> 2;
+  const int sh_lin = pow2_shift(lin), sh_lout = pow2_shift(lout), sh_nin4 = pow2_shift(nin4), sh_nout4 = pow2_shift(nout4);
   const bool a_lrelu = st.a.act == ACT_LRELU;
   // lanes of a wave that hold the same output channel in the staging loop below (lout / 4 consecutive threads, when
   // that is a power of two and every wave of the loop is full): their sums are combined before the LDS atomic
@@ -763,6 +863,28 @@ __global__ __launch_bounds__(UNET_BWD_THREADS, 2) void k_unet_bwd_t(Stage st, in
   for (int ti = 0; ti < DW_TPW; ++ti) dwacc[ti] = f32x4{0.f, 0.f, 0.f, 0.f};
   const bool has_r = st.r.z && st.r.G;
   const bool has_z = st.type != TY_PLAIN;
+  // input-gradient tiles: 16 positions x 16 input channels, K = (co, k) pairs in the order kk = 4 ks + (lane >> 4).  A wave
+  // keeps ONE channel tile (tile index = wave + i NWAVE, channel tile = tile % CT), so everything that depends on the lane's
+  // channel and k-pairs is a per-lane constant: the LDS offsets of both operands repeat with period DIN_P in the k-step
+  // (k3: kk + 12 is the same tap four channels on) and the epilogue's BatchNorm coefficients are read once.
+  constexpr int KTOT = COUT * KS, CT = (CIN + 15) / 16, KST = KTOT / 4;
+  constexpr int DIN_P = (KS == 3) ? 3 : 1, DIN_CSTEP = 4 * DIN_P / KS, DIN_BSTEP = (MODE == 2) ? DIN_CSTEP * KS : DIN_CSTEP * CIN * KS;
+  constexpr int DIN_KCH = KST < 12 ? (KST < 1 ? 1 : KST) : 12;
+  static_assert(KTOT % 4 == 0 || CIN <= 2, "k-steps of the input-gradient tiles are whole");
+  static_assert(NWAVE % CT == 0, "a wave keeps its channel tile");
+  const int cibw = ((wave % CT) << 4) + r, cibc = cibw < CIN ? cibw : CIN - 1;
+  const bool cokw = cibw < CIN;
+  int abase[DIN_P], bbase[DIN_P];
+  bool azero[DIN_P];
+#pragma unroll
+  for (int j = 0; j < DIN_P; ++j) {
+    const int kk0 = 4 * j + g4, co0 = kk0 / KS, k = kk0 - co0 * KS, t0 = r + 1 - k;   // (MODE 0: position n0 + r meets output (pos + 1 - k) / 2)
+    abase[j] = co0 * LPO + HALO + (MODE == 1 ? (KS - 1) / 2 - k : (MODE == 2 ? k - 1 : (t0 >> 1)));
+    azero[j] = MODE == 0 && (t0 & 1);
+    bbase[j] = (MODE == 2) ? cibc * BWLD + kk0 : (co0 * CIN + cibc) * KS + k;
+  }
+  const float4 eca = make_float4(ca[cibc], ca[CIN + cibc], ca[2 * CIN + cibc], ca[3 * CIN + cibc]);
+  const float4 ecb = has_b ? make_float4(cb[cibc], cb[CIN + cibc], cb[2 * CIN + cibc], cb[3 * CIN + cibc]) : eca;
   UB_STAMP(16);
   for (int w0 = blockIdx.x * WP; w0 < B; w0 += gridDim.x * WP) {
     const int nwin = (B - w0) < WP ? (B - w0) : WP;
@@ -775,7 +897,7 @@ __global__ __launch_bounds__(UNET_BWD_THREADS, 2) void k_unet_bwd_t(Stage st, in
     const float4* R4 = has_r ? reinterpret_cast<const float4*>(st.r.z + (size_t)w0 * nout) : nullptr;
     float4* RG4 = has_r ? reinterpret_cast<float4*>(st.r.G + (size_t)w0 * nout) : nullptr;
     auto put = [&](int i, float4 v, float4 u) {
-      const int wi = i / nin4, e = (i - wi * nin4) << 2, c = e / lin, p = e - c * lin;
+      const int wi = qdiv(i, nin4, sh_nin4), e = (i - wi * nin4) << 2, c = qdiv(e, lin, sh_lin), p = e - c * lin;
       const int oo = (wi * CIN + c) * LP + HALO + p;
       if (want_din) *reinterpret_cast<float4*>(zra + oo) = v;
       if (zx) *reinterpret_cast<float4*>(aux + oo) = u;
@@ -789,7 +911,7 @@ __global__ __launch_bounds__(UNET_BWD_THREADS, 2) void k_unet_bwd_t(Stage st, in
       *reinterpret_cast<float4*>(in + oo) = v;
     };
     auto putg = [&](int i, float4 g4v, float4 z4, float4 zr) {
-      const int wi = i / nout4, e = (i - wi * nout4) << 2, c = e / lout, p = e - c * lout;
+      const int wi = qdiv(i, nout4, sh_nout4), e = (i - wi * nout4) << 2, c = qdiv(e, lout, sh_lout), p = e - c * lout;
       float g[4] = {g4v.x, g4v.y, g4v.z, g4v.w};
       if (has_z) {
         const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
@@ -848,51 +970,50 @@ __global__ __launch_bounds__(UNET_BWD_THREADS, 2) void k_unet_bwd_t(Stage st, in
     UB_STAMP(17);
     // ---- input gradient ----
     if (want_din) {
-      constexpr int KTOT = COUT * KS, CT = (CIN + 15) / 16, KST = (KTOT + 3) / 4;
-      const int ptiles = (lin + 15) >> 4;
+      const int ptiles = (lin + 15) >> 4, sh_pt = pow2_shift(ptiles);
       for (int tile = wave; tile < nwin * ptiles * CT; tile += NWAVE) {
-        const int wi = tile / (ptiles * CT), t2 = tile - wi * ptiles * CT, pt = t2 / CT, n0 = pt << 4, m0 = (t2 - pt * CT) << 4;
-        const int pos = n0 + r, cib = m0 + r;
-        const bool pok = pos < lin, cok = cib < CIN;
-        const float* dcw = dc + wi * COUT * LPO;
-        f32x4 accv = {0.f, 0.f, 0.f, 0.f};
-        // operands of four k-steps are fetched together, then their MFMAs issue back to back (one LDS latency per four)
-#pragma unroll 1
-        for (int ks0 = 0; ks0 < KST; ks0 += 4) {
-          float av[4], bv[4];
+        const int tp = tile / CT, wi = qdiv(tp, ptiles, sh_pt), n0 = (tp - wi * ptiles) << 4;   // (channel tile: tile % CT == wave % CT)
+        const int pos = n0 + r, posc = pos < lin ? pos : lin - 1;   // (rows past the end are computed on a clamped address and dropped)
+        const float* da = dc + wi * COUT * LPO + (MODE == 1 ? posc : (MODE == 2 ? 2 * posc : (n0 >> 1)));
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        // operands of up to twelve k-steps are fetched together (addresses: a per-lane base + a compile-time multiple of a
+        // uniform step), then their MFMAs issue back to back on two accumulators
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int kk = (ks0 + u) * 4 + g4, co = kk / KS, k = kk - co * KS;
-            const bool kok = kk < KTOT;
-            av[u] = 0.f; bv[u] = 0.f;
-            if (pok && kok) {
-              if constexpr (MODE == 1) av[u] = dcw[co * LPO + HALO + pos + (KS - 1) / 2 - k];
-              else if constexpr (MODE == 0) { const int t = pos + 1 - k; av[u] = (t & 1) ? 0.f : dcw[co * LPO + HALO + (t >> 1)]; }
-              else av[u] = dcw[co * LPO + HALO + 2 * pos - 1 + k];
+        for (int kc = 0; kc < KST; kc += DIN_KCH) {
+          float av[DIN_KCH], bv[DIN_KCH];
+#pragma unroll
+          for (int u = 0; u < DIN_KCH; ++u) {
+            const int ks = kc + u, j = ks % DIN_P, i = ks / DIN_P;
+            if (ks < KST) {
+              av[u] = da[abase[j] + i * DIN_CSTEP * LPO];
+              if (MODE == 0 && azero[j]) av[u] = 0.f;
+              bv[u] = ws[bbase[j] + i * DIN_BSTEP];
             }
-            if (cok && kok) bv[u] = (MODE == 2) ? ws[(cib * COUT + co) * KS + k] : ws[(co * CIN + cib) * KS + k];
           }
 #pragma unroll
-          for (int u = 0; u < 4; ++u)
-            if (ks0 + u < KST) accv = mfma4(av[u], bv[u], accv);
+          for (int u = 0; u < DIN_KCH; ++u) {
+            if (kc + u < KST) {
+              if (u & 1) acc1 = mfma4(av[u], bv[u], acc1); else acc0 = mfma4(av[u], bv[u], acc0);
+            }
+          }
         }
-        // epilogue of the lane's (input channel cib, positions p0 .. p0 + 3): activation derivative, store (to one or two
+        const f32x4 accv = acc0 + acc1;
+        // epilogue of the lane's (input channel cibw, positions p0 .. p0 + 3): activation derivative, store (to one or two
         // producers), contributions to their BatchNorm-backward sums - all operands from the LDS
         const int p0 = n0 + 4 * g4;
-        const bool valid = cok && p0 < lin;
+        const bool valid = cokw && p0 < lin;
         float s1a = 0.f, s2a = 0.f, s1b = 0.f, s2b = 0.f;
         if (valid) {
-          const int oo = (wi * CIN + cib) * LP + HALO + p0;
-          const size_t og = (size_t)(w0 + wi) * nin + (size_t)cib * lin + p0;
+          const int oo = (wi * CIN + cibw) * LP + HALO + p0;
+          const size_t og = (size_t)(w0 + wi) * nin + (size_t)cibw * lin + p0;
           const float acc[4] = {accv[0], accv[1], accv[2], accv[3]};
           const float4 z4 = *reinterpret_cast<const float4*>(zra + oo);
           const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
-          const float s_ = ca[cib], h = ca[CIN + cib], mu = ca[2 * CIN + cib], rs = ca[3 * CIN + cib];
           float ga[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            ga[j] = (a_lrelu && zz[j] * s_ + h <= 0.f) ? 0.01f * acc[j] : acc[j];
-            s1a += ga[j]; s2a += ga[j] * (zz[j] - mu) * rs;
+            ga[j] = (a_lrelu && zz[j] * eca.x + eca.y <= 0.f) ? 0.01f * acc[j] : acc[j];
+            s1a += ga[j]; s2a += ga[j] * (zz[j] - eca.z) * eca.w;
           }
           float4 outv = make_float4(ga[0], ga[1], ga[2], ga[3]);
           if (acc_a) outv = f4add(outv, *reinterpret_cast<const float4*>(aux + oo));
@@ -900,12 +1021,11 @@ __global__ __launch_bounds__(UNET_BWD_THREADS, 2) void k_unet_bwd_t(Stage st, in
           if (has_b && st.b.G) {
             const float4 y4 = *reinterpret_cast<const float4*>(aux + oo);
             const float yy[4] = {y4.x, y4.y, y4.z, y4.w};
-            const float sB = cb[cib], hB = cb[CIN + cib], muB = cb[2 * CIN + cib], rsB = cb[3 * CIN + cib];
             float gb4[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              gb4[j] = (yy[j] * sB + hB <= 0.f) ? 0.01f * acc[j] : acc[j];
-              s1b += gb4[j]; s2b += gb4[j] * (yy[j] - muB) * rsB;
+              gb4[j] = (yy[j] * ecb.x + ecb.y <= 0.f) ? 0.01f * acc[j] : acc[j];
+              s1b += gb4[j]; s2b += gb4[j] * (yy[j] - ecb.z) * ecb.w;
             }
             float4 ob = make_float4(gb4[0], gb4[1], gb4[2], gb4[3]);
             if (st.b.accumulate) ob = f4add(ob, *reinterpret_cast<const float4*>(st.b.G + og));
@@ -915,49 +1035,60 @@ __global__ __launch_bounds__(UNET_BWD_THREADS, 2) void k_unet_bwd_t(Stage st, in
         // the sums of a channel are added up across the four position groups of the tile (lanes r, r + 16, r + 32,
         // r + 48) before ONE LDS atomic per channel and tile: same-address LDS atomics of a wave run one after the other
         s1a = rows_sum(s1a); s2a = rows_sum(s2a);
-        if (g4 == 0 && cok && st.a.bsums) { atomicAdd(sa + cib, s1a); atomicAdd(sa + MAXC + cib, s2a); }
+        if (g4 == 0 && cokw && st.a.bsums) { atomicAdd(sa + cibw, s1a); atomicAdd(sa + MAXC + cibw, s2a); }
         if (has_b && st.b.G) {
           s1b = rows_sum(s1b); s2b = rows_sum(s2b);
-          if (g4 == 0 && cok) { atomicAdd(sb + cib, s1b); atomicAdd(sb + MAXC + cib, s2b); }
+          if (g4 == 0 && cokw) { atomicAdd(sb + cibw, s1b); atomicAdd(sb + MAXC + cibw, s2b); }
         }
       }
     }
     UB_STAMP(18);
     // ---- weight gradient ----
+    // D rows / columns of padding lanes (co >= COUT, (ci, k) pair >= CIN KS) are dropped at the flush, so those lanes read a
+    // clamped (valid, finite) address instead of being masked; the address of every read is a per-lane base + a
+    // compile-time offset, advanced by a uniform step per 16 positions
 #pragma unroll
     for (int ti = 0; ti < DW_TPW; ++ti) {
       const int unit = wave + ti * NWAVE;
       if (unit >= DW_UNITS) continue;
       const int tile = unit / KSPLIT, ks = unit - tile * KSPLIT;
       const int m0 = (tile / DW_NT) << 4, n0 = (tile % DW_NT) << 4;
-      const int co = m0 + r, nn = n0 + r, ci = nn / KS, k = nn - ci * KS;
+      const int co = m0 + r, nn = n0 + r;
       const bool cook = co < COUT, nok = nn < CIN * KS;
+      const int coc = cook ? co : 0, nnc = nok ? nn : 0, ci = nnc / KS, k = nnc - ci * KS;
       const int q_lo = ks * kchunk, q_hi = (q_lo + kchunk) < lout ? (q_lo + kchunk) : lout;
-      f32x4 accw = dwacc[ti];
+      const float* dr = dc + coc * LPO + HALO + g4;
+      const int t0 = g4 + 1 - k;                       // (MODE 2: output position pp = q0 + 4 u + g4 meets input (pp + 1 - k) / 2)
+      const bool bz = MODE == 2 && (t0 & 1);
+      const float* ir = in + ci * LP + HALO + (MODE == 1 ? g4 - (KS - 1) / 2 + k : (MODE == 0 ? 2 * g4 - 1 + k : (t0 >> 1)));
+      constexpr int BQ = MODE == 1 ? 4 : (MODE == 0 ? 8 : 2);     // floats of the B row per 4 output positions
+      f32x4 accw = dwacc[ti], accx = {0.f, 0.f, 0.f, 0.f};
       for (int wi = 0; wi < nwin; ++wi) {
-        const float* dr = dc + (wi * COUT + (cook ? co : 0)) * LPO + HALO;
-        const float* ir = in + (wi * CIN + (nok ? ci : 0)) * LP + HALO;
-        // 16 output positions per iteration: the eight operand reads first, then four MFMAs back to back
-#pragma unroll 1
-        for (int q0 = q_lo; q0 < q_hi; q0 += 16) {
+        const float* d2 = dr + wi * COUT * LPO;
+        const float* i2 = ir + wi * CIN * LP;
+        int q0 = q_lo;
+        for (; q0 + 16 <= q_hi; q0 += 16) {
           float av[4], bv[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            const int pp = q0 + 4 * u + g4;
-            const bool pk = pp < q_hi;
-            av[u] = (cook && pk) ? dr[pp] : 0.f;
-            bv[u] = 0.f;
-            if (nok && pk) {
-              if constexpr (MODE == 1) bv[u] = ir[pp - (KS - 1) / 2 + k];
-              else if constexpr (MODE == 0) bv[u] = ir[2 * pp - 1 + k];
-              else { const int t = pp + 1 - k; bv[u] = (t & 1) ? 0.f : ir[t >> 1]; }
-            }
+            av[u] = d2[q0 + 4 * u];
+            bv[u] = i2[(q0 >> 2) * BQ + u * BQ];
+            if (bz) bv[u] = 0.f;
           }
+          accw = mfma4(av[0], bv[0], accw); accx = mfma4(av[1], bv[1], accx);
+          accw = mfma4(av[2], bv[2], accw); accx = mfma4(av[3], bv[3], accx);
+        }
+        if (q0 < q_hi) {   // ragged end (lout not a multiple of 16)
 #pragma unroll
-          for (int u = 0; u < 4; ++u) accw = mfma4(av[u], bv[u], accw);
+          for (int u = 0; u < 4; ++u) {
+            const bool pk = q0 + 4 * u + g4 < q_hi;
+            const float a_ = pk ? d2[q0 + 4 * u] : 0.f;
+            const float b_ = (pk && !bz) ? i2[(q0 >> 2) * BQ + u * BQ] : 0.f;
+            accw = mfma4(a_, b_, accw);
+          }
         }
       }
-      dwacc[ti] = accw;
+      dwacc[ti] = accw + accx;
     }
     UB_STAMP(19);
     __syncthreads();
@@ -1704,8 +1835,8 @@ static void launch_fwd_t(const Stage& st, int B, int grid, hipStream_t s) {
   // while the tiles of a pass would not leave room for two workgroups per CU (long windows: at L = 2048 the 32-channel
   // stages take 64 KB at WP = 2 already); dynamic LDS above 64 KB is opted into per instantiation
   auto lds_of = [&](int WP) {
-    return ((size_t)WP * CIN * (st.lin + 8) + (st.r.z ? (size_t)WP * COUT * st.lout : 0) + (size_t)CIN * COUT * KS + MAXC +
-            12 * MAXC + 2 * MAXC + 8) * sizeof(float);
+    return ((size_t)WP * CIN * (st.lin + 8) + (st.r.z ? (size_t)WP * COUT * st.lout : 0) + (size_t)COUT * (CIN * KS + 4) + MAXC +
+            12 * MAXC + 2 * MAXC + 8) * sizeof(float);   // (weights: rows padded by up to 4 floats)
   };
   int WP = (B + grid - 1) / grid;
   if (WP > 4) WP = 4;
@@ -1854,7 +1985,7 @@ static void launch_bwd_t(const Stage& st, int B, int grid, int wp_req, hipStream
   const bool want_din = st.a.G != nullptr, third = st.b.z != nullptr || (want_din && st.a.accumulate);
   auto lds_of = [&](int WP) {
     return ((size_t)WP * CIN * (st.lin + 8) * (1 + (want_din ? 1 : 0) + (third ? 1 : 0)) + (size_t)WP * COUT * (st.lout + 8) +
-            (size_t)2 * CIN * COUT * KS + 28 * MAXC + 8) * sizeof(float);
+            (size_t)2 * CIN * COUT * KS + 4 * CIN + 28 * MAXC + 8) * sizeof(float);   // (weights: rows padded by up to 4 floats)
   };
   int WP = (B + grid - 1) / grid;                 // windows per workgroup
   if (WP > wp_req) WP = wp_req;

@@ -23,6 +23,11 @@ m.train_step(x, t); torch.cuda.synchronize()
 fn(buf, 0)
 names = {16: "prologue", 17: "load phase", 18: "input gradient", 19: "weight gradient", 20: "barrier", 21: "flush"}
 tot = sum(buf[i] for i in range(16, 22))
-print("cycles of workgroup 0 (100 MHz clock64 ticks x ...):", tot)
+print("backward stage, cycles of the stamped workgroup:", tot)
 for i in range(16, 22):
+    print(f"  {names[i]:16s} {buf[i]:10d}  {100.0 * buf[i] / max(tot, 1):5.1f}%")
+names = {8: "prologue", 9: "load phase", 10: "compute", 11: "barrier", 12: "flush"}
+tot = sum(buf[i] for i in range(8, 13))
+print("forward stage, cycles of the stamped workgroup:", tot)
+for i in range(8, 13):
     print(f"  {names[i]:16s} {buf[i]:10d}  {100.0 * buf[i] / max(tot, 1):5.1f}%")
