@@ -214,14 +214,15 @@ __global__ __launch_bounds__(256) void k_loss(const float* __restrict__ pred, co
 // persistent workgroups (at most 512) that add their share of the loss with ONE atomic each - a workgroup per window
 // was 2048 same-address double atomics in a row (~12 ns per link: most of the kernel's 30 us at batch 2048) on top of one
 // memory round trip per 4-byte element.
-__global__ __launch_bounds__(256) void k_loss_w(const float* __restrict__ pred, const float* __restrict__ target,
+#define LOSS_W_WAVES 8
+__global__ __launch_bounds__(64 * LOSS_W_WAVES) void k_loss_w(const float* __restrict__ pred, const float* __restrict__ target,
                                                 float* __restrict__ dy, float* __restrict__ snr,
                                                 float* __restrict__ rmse, double* __restrict__ loss_sum, int n, int B,
                                                 float gscale, double* __restrict__ fin, double fin_scale) {
-  __shared__ double red[4];
+  __shared__ double red[LOSS_W_WAVES];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n4 = n >> 2;
   double mine = 0.0;                      // (lane 0: sum over this wave's windows of sse / n)
-  for (int w = blockIdx.x * 4 + wave; w < B; w += gridDim.x * 4) {
+  for (int w = blockIdx.x * LOSS_W_WAVES + wave; w < B; w += gridDim.x * LOSS_W_WAVES) {
     const float4* p4 = reinterpret_cast<const float4*>(pred + (size_t)w * n);
     const float4* t4 = reinterpret_cast<const float4*>(target + (size_t)w * n);
     float4* d4 = dy ? reinterpret_cast<float4*>(dy + (size_t)w * n) : nullptr;
@@ -253,7 +254,8 @@ __global__ __launch_bounds__(256) void k_loss_w(const float* __restrict__ pred, 
   }
   if (lane == 0) red[wave] = mine;
   __syncthreads();
-  if (threadIdx.x == 0 && loss_sum) loss_commit(loss_sum, (red[0] + red[1]) + (red[2] + red[3]), fin, fin_scale);
+  if (threadIdx.x == 0 && loss_sum)
+    loss_commit(loss_sum, ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7])), fin, fin_scale);
 }
 
 // ---------------------------------------------------------------------------------
@@ -318,8 +320,11 @@ void launch_final_fwd(int leads, const float* u0, const float* x0, const float* 
 void launch_loss(const float* pred, const float* target, float* dy, float* snr, float* rmse, double* loss_sum,
                  int n, int B, float gscale, hipStream_t s, double* fin, double fin_scale) {
   if (n % 4 == 0) {
-    const int g = (B + 3) / 4;
-    k_loss_w<<<g < 512 ? g : 512, 256, 0, s>>>(pred, target, dy, snr, rmse, loss_sum, n, B, gscale, fin, fin_scale);
+    // (a workgroup ends with two same-address atomics - its share of the sum and its arrival: 512 four-wave workgroups were
+    // 19 us at batch 2048 x 1024 floats, 256 eight-wave ones with one window per wave are LOSS_US_256)
+    static const int gmax = getenv("RAL_LOSS_GRID") ? atoi(getenv("RAL_LOSS_GRID")) : 256;
+    const int g = (B + LOSS_W_WAVES - 1) / LOSS_W_WAVES;
+    k_loss_w<<<g < gmax ? g : gmax, 64 * LOSS_W_WAVES, 0, s>>>(pred, target, dy, snr, rmse, loss_sum, n, B, gscale, fin, fin_scale);
   } else {
     k_loss<<<B, 256, 0, s>>>(pred, target, dy, snr, rmse, loss_sum, n, gscale, fin, fin_scale);
   }

@@ -58,8 +58,13 @@ RAL_DEV float lrelu01(float v) { return v > 0.f ? v : 0.01f * v; }
 // x / d (x >= 0) for a divisor that is nearly always a power of two here (window lengths, tensor sizes, tile counts):
 // sh = log2(d) or -1.  A run-time integer division is ~25 vector instructions; the stage kernels are bound by those.
 // Row stride (floats) of a weight matrix kept in LDS as a B operand of the MFMA tiles: lane (r, g) of a k-step reads row r,
-// column 4 ks + g - conflict-free when the stride is 4 x an odd number (the row lengths 32, 64, 96 put 16 rows in 2 banks).
-constexpr int wrow_ld(int row) { return (row % 8 == 4) ? row : row + 4; }
+// column 4 ks + g.  A 4-byte LDS read serves lanes 0-31 together (16 rows x 2 columns) from 32 banks: conflict-free when the
+// stride is 2 x an odd number (the row lengths 32, 64, 96 put the 16 rows in ONE bank pair; rows are staged as 8-byte pieces).
+constexpr int wrow_ld(int row) { return (row % 4 == 2) ? row : row + 2; }
+RAL_DEV void st_f4_as_f2(float* dst, float4 v) {   // 16 bytes to an 8-byte aligned LDS address
+  *reinterpret_cast<float2*>(dst) = make_float2(v.x, v.y);
+  *reinterpret_cast<float2*>(dst + 2) = make_float2(v.z, v.w);
+}
 RAL_DEV int pow2_shift(int d) { return (d > 0 && (d & (d - 1)) == 0) ? __builtin_ctz((unsigned)d) : -1; }
 RAL_DEV int qdiv(int x, int d, int sh) { return sh >= 0 ? (x >> sh) : x / d; }
 
@@ -273,7 +278,7 @@ __global__ __launch_bounds__(UNET_FWD_THREADS) void k_unet_fwd_t(Stage st, int B
   // rows of one output channel per lane and keeps them at a padded stride (wrow_ld)
   constexpr bool FMFMA = CIN >= 4 && (CIN * KS) % 4 == 0 && (MODE != 2 || COUT >= 16);   // (narrow ConvTranspose1d layers: 16-channel tiles
                                                                                           //  would be mostly padding; measured slower)
-  constexpr int FKTOT = CIN * KS, WLD = (FMFMA && MODE != 2) ? wrow_ld(FKTOT) : FKTOT, WSZ = (MODE == 2) ? nw : COUT * WLD;
+  constexpr int FKTOT = CIN * KS, WLD = (FMFMA && MODE != 2) ? wrow_ld(FKTOT) : FKTOT, WSZ = (MODE == 2) ? nw : ((COUT * WLD + 3) & ~3);
   float* ws = rt + (st.r.z ? WP * COUT * lout : 0);
   float* bs = ws + WSZ;
   float* ca = bs + MAXC; float* cb = ca + 4 * MAXC; float* cr = cb + 4 * MAXC;
@@ -297,7 +302,7 @@ __global__ __launch_bounds__(UNET_FWD_THREADS) void k_unet_fwd_t(Stage st, int B
 #pragma unroll
   for (int k = 0; k < NWVF; ++k) {
     const int i = threadIdx.x + k * NTF;
-    if (i < nw / 4) *reinterpret_cast<float4*>(ws + (WLD == FKTOT ? 4 * i : (4 * i / FKTOT) * WLD + (4 * i) % FKTOT)) = wv[k];
+    if (i < nw / 4) st_f4_as_f2(ws + (WLD == FKTOT ? 4 * i : (4 * i / FKTOT) * WLD + (4 * i) % FKTOT), wv[k]);
   }
   if ((int)threadIdx.x < COUT) bs[threadIdx.x] = bv;
   for (int i = threadIdx.x; i < 2 * MAXC; i += blockDim.x) red[i] = 0.f;
@@ -778,7 +783,10 @@ __global__ __launch_bounds__(UNET_BWD_THREADS, 2) void k_unet_bwd_t(Stage st, in
   extern __shared__ float4 smem4[];
   UB_STAMP_INIT();
   constexpr int HALO = 4, nw = CIN * COUT * KS, NT = UNET_BWD_THREADS, NWAVE = NT / 64;
-  const int lin = st.lin, lout = st.lout, LP = lin + 2 * HALO, LPO = lout + 2 * HALO;
+  // rows of the gradient tile: halo 4 | lout | halo 6.  The weight-gradient tiles read 16 ROWS per 4-byte access (lanes 0-31:
+  // 16 output channels x 2 positions, 32 banks): a stride of 2 x an odd number keeps them in different banks (lout + 8 put
+  // four rows in each bank); rows are therefore 8-byte aligned and written as 8-byte pieces
+  const int lin = st.lin, lout = st.lout, LP = lin + 2 * HALO, LPO = lout + 2 * HALO + 2;
   const bool has_b = st.b.z != nullptr, want_din = st.a.G != nullptr;
   const bool acc_a = want_din && st.a.accumulate != 0;
   float* in = reinterpret_cast<float*>(smem4);                        // WP x CIN x LP   conv operand
@@ -787,8 +795,8 @@ __global__ __launch_bounds__(UNET_BWD_THREADS, 2) void k_unet_bwd_t(Stage st, in
   float* dc = aux + ((has_b || acc_a) ? WP * CIN * LP : 0);           // WP x COUT x LPO gradient at the conv output
   // weights as in global memory ([co][ci][k] / ConvTranspose1d: [ci][co][k]); the ConvTranspose1d layers read one row per
   // lane in the input gradient and keep the rows at a padded stride (wrow_ld)
-  constexpr int BWROW = COUT * KS, BWLD = (MODE == 2) ? wrow_ld(BWROW) : BWROW, BWSZ = (MODE == 2) ? CIN * BWLD : nw;
-  float* ws = dc + WP * COUT * LPO;              // weights
+  constexpr int BWROW = COUT * KS, BWLD = (MODE == 2) ? wrow_ld(BWROW) : BWROW, BWSZ = (MODE == 2) ? ((CIN * BWLD + 3) & ~3) : nw;
+  float* ws = dc + ((WP * COUT * LPO + 3) & ~3);  // weights (16-byte aligned)
   float* gws = ws + BWSZ;                        // weight-gradient partial of the workgroup
   float* ca = gws + nw; float* cb = ca + 4 * MAXC; float* cr = cb + 4 * MAXC; float* co_ = cr + 4 * MAXC;
   float* sa = co_ + 5 * MAXC; float* sb = sa + 2 * MAXC; float* sr = sb + 2 * MAXC;
@@ -811,7 +819,7 @@ __global__ __launch_bounds__(UNET_BWD_THREADS, 2) void k_unet_bwd_t(Stage st, in
 #pragma unroll
   for (int k = 0; k < NWV; ++k) {
     const int i = threadIdx.x + k * NT;
-    if (i < nw / 4) *reinterpret_cast<float4*>(ws + (BWLD == BWROW ? 4 * i : (4 * i / BWROW) * BWLD + (4 * i) % BWROW)) = wv[k];
+    if (i < nw / 4) st_f4_as_f2(ws + (BWLD == BWROW ? 4 * i : (4 * i / BWROW) * BWLD + (4 * i) % BWROW), wv[k]);
   }
   for (int i = threadIdx.x; i < nw; i += NT) gws[i] = 0.f;
   for (int i = threadIdx.x; i < 7 * MAXC; i += NT) sa[i] = 0.f;   // sa, sb, sr, gbs[0:MAXC]
@@ -819,9 +827,9 @@ __global__ __launch_bounds__(UNET_BWD_THREADS, 2) void k_unet_bwd_t(Stage st, in
     const int c = i / (2 * HALO), h = i % (2 * HALO);
     in[c * LP + (h < HALO ? h : lin + h)] = 0.f;
   }
-  for (int i = threadIdx.x; i < WP * COUT * 2 * HALO; i += NT) {
-    const int c = i / (2 * HALO), h = i % (2 * HALO);
-    dc[c * LPO + (h < HALO ? h : lout + h)] = 0.f;
+  for (int i = threadIdx.x; i < WP * COUT * 16; i += NT) {
+    const int c = i >> 4, h = i & 15;
+    if (h < 2 * HALO + 2) dc[c * LPO + (h < HALO ? h : lout + h)] = 0.f;
   }
   if ((threadIdx.x >> 6) < UNET_FOLD_SLOTS) fold_store(fl, fp.nrep, threadIdx.x >> 6);
   __syncthreads();
@@ -924,7 +932,7 @@ __global__ __launch_bounds__(UNET_BWD_THREADS, 2) void k_unet_bwd_t(Stage st, in
           g[j] = v;
         }
       }
-      *reinterpret_cast<float4*>(dc + (wi * COUT + c) * LPO + HALO + p) = make_float4(g[0], g[1], g[2], g[3]);
+      st_f4_as_f2(dc + (wi * COUT + c) * LPO + HALO + p, make_float4(g[0], g[1], g[2], g[3]));
       seg_atomic(gbs + c, (g[0] + g[1]) + (g[2] + g[3]), segw);
       if (has_r) {   // residual operand lrelu(BN(z_r)) was added to the output: its gradient is Gout * lrelu'
         const float zrr[4] = {zr.x, zr.y, zr.z, zr.w}, gg[4] = {g4v.x, g4v.y, g4v.z, g4v.w};
@@ -1159,19 +1167,27 @@ RAL_DEV void bn_affine_grads(const BnGrad& b, int c, double share) {
   if (b.final_ != b.bsums) { b.final_[c] = s1; b.final_[MAXC + c] = s2; }
   b.gb[c] = (float)(s1 * share); b.gw[c] = (float)(s2 * share);
 }
-__global__ __launch_bounds__(256) void k_unet_fold(const float* __restrict__ part, int64_t stride, int rows, const int* __restrict__ cols,
-                                                   int ncols, float* __restrict__ grads, BnGradAll u, double share) {
+#define UNET_FOLD_WAVES 16
+__global__ __launch_bounds__(64 * UNET_FOLD_WAVES) void k_unet_fold(const float* __restrict__ part, int64_t stride, int rows, const int* __restrict__ cols,
+                                                   int ncols, float* __restrict__ grads, BnGradAll u, double share,
+                                                   double* __restrict__ zero, int nzero) {
   if (blockIdx.x == gridDim.x - 1) {
     for (int t = threadIdx.x; t < 10 * MAXC; t += blockDim.x) bn_affine_grads(u.l[t / MAXC], t % MAXC, share);
+    // the replica records of both directions are no longer needed (the forward ones were folded by k_unet_out, the backward
+    // ones right here): zeroed for the next step, which then needs no fill kernel
+    __syncthreads();
+    for (int i = threadIdx.x; i < nzero; i += blockDim.x) zero[i] = 0.0;
     return;
   }
-  __shared__ float red[4][64];
+  // sixteen waves share the rows of 64 columns (eight 256-byte row pieces in flight per wave: four round trips at 512 rows;
+  // with four waves it was sixteen and the kernel 13 us for 29 MB)
+  __shared__ float red[UNET_FOLD_WAVES][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = blockIdx.x * 64 + lane;
   const int col = j < ncols ? cols[j] : -1;
   float acc = 0.f;
   if (col >= 0) {
-    const int r0 = (int)((int64_t)rows * wave / 4), r1 = (int)((int64_t)rows * (wave + 1) / 4);
+    const int r0 = (int)((int64_t)rows * wave / UNET_FOLD_WAVES), r1 = (int)((int64_t)rows * (wave + 1) / UNET_FOLD_WAVES);
     int rr = r0;
     for (; rr + 8 <= r1; rr += 8) {
       float v[8];
@@ -1184,7 +1200,12 @@ __global__ __launch_bounds__(256) void k_unet_fold(const float* __restrict__ par
   }
   red[wave][lane] = acc;
   __syncthreads();
-  if (wave == 0 && col >= 0) grads[col] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  if (wave == 0 && col >= 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < UNET_FOLD_WAVES; ++k) t += red[k][lane];
+    grads[col] = t;
+  }
 }
 
 // BatchNorm affine gradients of all layers from the backward sums: g_gamma = S2, g_beta = S1 (the path without the fold)
@@ -1648,6 +1669,7 @@ struct UNetModel {
   double* rep = nullptr;
   int nrep_f = 1, nrep_b = 1;     // replicas the current forward / backward pass adds to (1: straight into bn_sums)
   bool rep_bwd_clean = false;     // the backward half of `rep` was zeroed by the forward pass's fill and not used since
+  bool rep_all_clean = false;     // both halves were zeroed by the last backward pass's fold kernel and not used since
 };
 
 int unet_check_cfg(const ral_config* c, char* err, size_t cap) {
@@ -1879,7 +1901,10 @@ int unet_forward_stage(UNetModel* m, const float* x, int B, int training, int si
     m->last_x = x; m->last_B = B;
     if (training) {
       // (one fill for both halves of the replica records: the backward pass of this step finds its half zeroed)
-      if (m->nrep_f > 1) { (void)hipMemsetAsync(unet_rep(m, 0, 0), 0, (size_t)2 * 10 * UNET_MAXREP * 64 * sizeof(double), s); m->rep_bwd_clean = true; }
+      if (m->nrep_f > 1) {
+        if (!m->rep_all_clean) (void)hipMemsetAsync(unet_rep(m, 0, 0), 0, (size_t)2 * 10 * UNET_MAXREP * 64 * sizeof(double), s);
+        m->rep_all_clean = false; m->rep_bwd_clean = true;
+      }
       else (void)hipMemsetAsync(P.bn_sums, 0, 1280 * sizeof(double), s);
     }
   } else if (x != m->last_x || B != m->last_B) { snprintf(err, cap, "U-Net stages must follow stage 0 of the same batch"); return -1; }
@@ -1984,12 +2009,12 @@ template <int CIN, int COUT, int KS, int MODE>
 static void launch_bwd_t(const Stage& st, int B, int grid, int wp_req, hipStream_t s) {
   const bool want_din = st.a.G != nullptr, third = st.b.z != nullptr || (want_din && st.a.accumulate);
   auto lds_of = [&](int WP) {
-    return ((size_t)WP * CIN * (st.lin + 8) * (1 + (want_din ? 1 : 0) + (third ? 1 : 0)) + (size_t)WP * COUT * (st.lout + 8) +
-            (size_t)2 * CIN * COUT * KS + 4 * CIN + 28 * MAXC + 8) * sizeof(float);   // (weights: rows padded by up to 4 floats)
+    return ((size_t)WP * CIN * (st.lin + 8) * (1 + (want_din ? 1 : 0) + (third ? 1 : 0)) + (size_t)WP * COUT * (st.lout + 10) +
+            (size_t)2 * CIN * COUT * KS + 4 * CIN + 28 * MAXC + 12) * sizeof(float);   // (weights: rows padded by up to 4 floats)
   };
   int WP = (B + grid - 1) / grid;                 // windows per workgroup
   if (WP > wp_req) WP = wp_req;
-  while (WP > 1 && lds_of(WP) > 80 * 1024) --WP;  // two workgroups per CU
+  while (WP > 1 && lds_of(WP) > 80 * 1024) WP = WP > 2 ? 2 : 1;  // two workgroups per CU; passes of equal size (4, 2 or 1 windows)
   const size_t lds = lds_of(WP);
   static size_t cur = 0;                          // (one per instantiation)
   if (lds > cur) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_unet_bwd_t<CIN, COUT, KS, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); cur = lds; }
@@ -2025,7 +2050,7 @@ int unet_backward_start(UNetModel* m, const float* dy, int B, int64_t gwin, hipS
   // the ten backward halves [64, 128) of the 128-double BatchNorm records, one strided fill
   if (m->nrep_b > 1) {
     if (!m->rep_bwd_clean) (void)hipMemsetAsync(unet_rep(m, 1, 0), 0, (size_t)10 * UNET_MAXREP * 64 * sizeof(double), s);
-    m->rep_bwd_clean = false;
+    m->rep_bwd_clean = false; m->rep_all_clean = false;
   } else (void)hipMemset2DAsync(P.bn_sums + 64, 128 * sizeof(double), 0, 64 * sizeof(double), 10, s);
   m->last_dy = dy;
   m->bwd_rows = 0;
@@ -2071,8 +2096,11 @@ int unet_backward_finish(UNetModel* m, int B, int64_t gwin, hipStream_t s, char*
                      P.grads + m->lay.bnw[bi], P.grads + m->lay.bnb[bi], m->lay.bnC[bi], m->nrep_b};
   if (m->fold) {
     if (m->bwd_rows <= 0) { snprintf(err, cap, "U-Net backward finish without its stages"); return -1; }
-    k_unet_fold<<<(m->ncols + 63) / 64 + 1, 256, 0, s>>>(m->part, m->part_stride, m->bwd_rows, m->cols, m->ncols, P.grads, u,
-                                                        (double)B / (double)gwin);
+    const bool reps = m->nrep_b > 1;
+    k_unet_fold<<<(m->ncols + 63) / 64 + 1, 64 * UNET_FOLD_WAVES, 0, s>>>(m->part, m->part_stride, m->bwd_rows, m->cols, m->ncols, P.grads, u,
+                                                        (double)B / (double)gwin, reps ? unet_rep(m, 0, 0) : nullptr,
+                                                        reps ? 2 * 10 * UNET_MAXREP * 64 : 0);
+    if (reps) m->rep_all_clean = true;
   } else {
     k_unet_bn_grads<<<10, MAXC, 0, s>>>(u, (double)B / (double)gwin);
   }
