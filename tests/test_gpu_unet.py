@@ -90,14 +90,27 @@ def test_unet_against_reference_golden(golden_dir):
     np.testing.assert_allclose(losses, g["adam_losses"], rtol=5e-4)
 
 
-def test_unet_bench_batch_matches_fp64_oracle():
+# (1024, 2048) and (2048, 1100): long windows at a full grid - the launchers cut the windows per pass to what two workgroups
+# per CU leave of the LDS (32-channel stages at L = 2048: 64 KB for two windows), so a workgroup loops over several passes,
+# the last one ragged at 1100 windows; the dynamic LDS above 64 KB is opted into per instantiation
+@pytest.mark.parametrize("L,B", [(512, 2048), (1024, 2048), (2048, 1100)])
+def test_unet_bench_batch_matches_fp64_oracle(L, B):
     """BASELINE batch (2048 x 2 x 512): every stage kernel runs its multi-window loop (512 workgroups), the wide layers'
     MFMA gradient products accumulate over four windows per workgroup, and the BatchNorm statistics are sums over 2048
-    windows.  Output, loss and running statistics at the usual 1e-5; gradients at 1e-3 (LeakyReLU has a kink at 0: with
-    ~50 M activations a few sit within fp32 rounding of it and take the other slope in fp64)."""
-    m, y, loss, p, bn, yo, lo, grads, x, tgt = _run(2, 512, 2048, seed=4321)
+    windows.  Output, loss and running statistics at the usual 1e-5; gradients at 1e-3 or 2.5 x what an fp32 evaluation of
+    the oracle itself deviates by (LeakyReLU has a kink at 0: with 50-100 M activations a few sit within fp32 rounding of
+    it and take the other slope in fp64)."""
+    m, y, loss, p, bn, yo, lo, grads, x, tgt = _run(2, L, B, seed=4321)
     assert rel(y.cpu().numpy(), yo.detach().numpy()) < 1e-5
     assert abs(loss.item() - lo.item()) < 1e-5 * abs(lo.item())
+    # what fp32 arithmetic itself costs at this size: the oracle evaluated in fp32 on the CPU against its fp64 evaluation
+    # (2048 x 2 x 1024: 1.4e-3 .. 2.0e-3 on the encoder's gradients - twice the activations, twice the slope flips; the HIP
+    # path measured 1.6e-3 .. 3.1e-3 there, tools/diag/r4_unet_kink.py)
+    p32 = OrderedDict((k, v.detach().float().requires_grad_(True)) for k, v in p.items())
+    y32 = O.unet_forward(p32, x.float(), True, O.unet_bn_state(p32, torch.float32))
+    g32 = torch.autograd.grad(O.mse(y32, tgt.float()), list(p32.values()))
+    e32 = max(rel(gf.numpy(), gr.numpy()) for gf, gr in zip(g32, grads) if gr.norm().item() >= 1e-9)
+    bound = max(1e-3, 2.5 * e32)
     ng = m.named_grads()
     bad = {}
     for (k, _), gr in zip(p.items(), grads):
@@ -106,9 +119,9 @@ def test_unet_bench_batch_matches_fp64_oracle():
                 bad[k] = "nonzero"
             continue
         e = rel(ng[k].cpu().numpy(), gr.numpy())
-        if e > 1e-3:
+        if e > bound:
             bad[k] = e
-    assert not bad, bad
+    assert not bad, (bad, bound)
     sd = m.state_dict()
     for k in O.UNET_BN:
         np.testing.assert_allclose(sd[k + ".running_mean"].cpu().numpy(), bn[k]["running_mean"].numpy(), rtol=1e-5, atol=1e-6)
