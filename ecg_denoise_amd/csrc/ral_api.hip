@@ -253,6 +253,7 @@ struct RalModel {
   int n_lanes = 2;
   bool side_stream = true;
   bool attn_f16 = true;      // attention score tiles (S, dP) as fp16-pair products - only while f16_split > 0 (option "attn_f16"; RAL_ATTN_F16=0)
+  bool narrow_f16 = true;    // the strip kernel of the narrow levels' MLP forward on fp16-pair products - only while f16_split > 0 (option "narrow_f16")
   int f16_split = 64;         // narrowest width whose Linear layers (q/k/v projection, proj, fc1, fc2 of the forward) run as
                               // two-piece fp16 products on the f16 matrix cores (0 = none: fp32 MFMA everywhere)
   bool want_dw = true;      // false inside ral_backward_input: frozen weights, data gradients only
@@ -469,7 +470,7 @@ static void run_block_fwd(RalModel* m, int bi, const float* in, bool training, c
   { ProfScope p(m, K_MLP_FWD, s);
     launch_mlp_fwd(C, m->nch_f[l], x, o, w, m->params, split ? m->wh : nullptr, training ? woff(a.x1, w0, E1) : nullptr,
                    (training && !mlp_bwd_is_fused(C, N)) ? woff(a.upre, w0, 4 * E1) : nullptr,
-                   woff(a.out, w0, E1), N, B, s); }
+                   woff(a.out, w0, E1), N, B, (m->f16_split > 0 && m->narrow_f16) ? 1 : 0, s); }
 }
 
 static const float* run_stage_fwd(RalModel* m, int si, const float* in, bool training, const Lane& ln) {
@@ -1194,6 +1195,7 @@ int ral_set_option(ral_handle* h, const char* key, int value) {
   if (!strcmp(key, "side_stream")) { m->side_stream = value != 0; return 0; }
   if (!strcmp(key, "f16_split")) { m->f16_split = value; return 0; }
   if (!strcmp(key, "attn_f16")) { m->attn_f16 = value != 0; return 0; }
+  if (!strcmp(key, "narrow_f16")) { m->narrow_f16 = value != 0; return 0; }
   return fail("unknown option %s", key);
 }
 

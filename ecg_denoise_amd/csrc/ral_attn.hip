@@ -48,14 +48,6 @@ RAL_DEV float quad_rows_sum(float x, float y, float z, float w) {
   return (v[0] + v[1]) + (v[2] + v[3]);
 }
 
-typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
-struct H2x4 { h16x4 a, b; };   // x = a + b to ~2^-23 relative (2^-25 absolute for small x), element-wise
-RAL_DEV H2x4 split4(float4 x) {
-  H2x4 r;
-  const H2 s0 = f16_split2n(x.x), s1 = f16_split2n(x.y), s2 = f16_split2n(x.z), s3 = f16_split2n(x.w);
-  r.a = h16x4{s0.a, s1.a, s2.a, s3.a}; r.b = h16x4{s0.b, s1.b, s2.b, s3.b};
-  return r;
-}
 RAL_DEV float f4absmax(float4 v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
 
 // F16: the S and dP tiles on the f16 matrix cores.  A 16 x 16 tile of q k^T at head_dim 4 is a K = 4 product; with both

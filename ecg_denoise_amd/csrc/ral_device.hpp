@@ -182,6 +182,14 @@ RAL_DEV H2 f16_split2n(float x) {
   r.b = (_Float16)(x - (float)r.a);
   return r;
 }
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+struct H2x4 { h16x4 a, b; };   // x = a + b to ~2^-23 relative (2^-25 absolute for small x), element-wise
+RAL_DEV H2x4 split4(float4 x) {
+  H2x4 r;
+  const H2 s0 = f16_split2n(x.x), s1 = f16_split2n(x.y), s2 = f16_split2n(x.z), s3 = f16_split2n(x.w);
+  r.a = h16x4{s0.a, s1.a, s2.a, s3.a}; r.b = h16x4{s0.b, s1.b, s2.b, s3.b};
+  return r;
+}
 // q . k on fp16 pairs: the two operands of a score are BALANCED by one power of two, q' = 2^-a q, k' = 2^a k with a = half the
 // difference of their largest exponents, so that the product is unchanged (no unscaling in front of the exponential) and
 // both sides sit at the geometric mean of their magnitudes: finite while max|q| max|k| < 2^31, and the absolute error of
@@ -410,7 +418,27 @@ RAL_DEV void gelu_pair(float x, float& g, float& dg) {
   g = x * cdf;
   dg = fmaf(x, 0.39894228040143267794f * e, cdf);
 }
-RAL_DEV float gelu_f(float x) { float g, d; gelu_pair(x, g, d); return g; }
+// The forward alone needs no derivative, and then no reciprocal either: 0.5 erfc(a) = 2^-(1 + a P(a)) with a = |x| / sqrt2 and
+// P a degree-7 polynomial (least-squares fit of -log2 erfc(a) / a on [0, 5.5] weighted by erfc(a), i.e. uniform in the
+// error of Phi: 8e-9, below the 1.5e-7 of the formula above; beyond the fitted range a P(a) keeps growing and the term
+// underflows to 0), so GELU(x) = max(x, 0) - |x| * 2^-(1 + a P(a)): 8 FMAs that the compiler packs in pairs + ONE
+// quarter-rate instruction - 12 issue slots per element against 16 for the pair formula without its derivative.
+// (tools/diag/gelu_fit.py re-derives the coefficients and checks the fp32 evaluation against scipy's erfc.)
+RAL_DEV float gelu_f(float x) {
+#ifdef RAL_NOGELU
+  return x;
+#endif
+  const float ax = fabsf(x), a = ax * 0.70710678118654752440f;
+  float p = fmaf(4.527986043e-05f, a, -4.451398044e-04f);
+  p = fmaf(p, a, 1.489045845e-03f);
+  p = fmaf(p, a, 7.741376838e-04f);
+  p = fmaf(p, a, -2.825238065e-02f);
+  p = fmaf(p, a, 1.484806716e-01f);
+  p = fmaf(p, a, 9.184166615e-01f);
+  p = fmaf(p, a, 1.627908569e+00f);
+  const float h = __builtin_amdgcn_exp2f(fmaf(-a, p, -1.0f));   // 0.5 erfc(|x| / sqrt2) = Phi(-|x|)
+  return fmaf(-ax, h, fmaxf(x, 0.f));
+}
 RAL_DEV float gelu_grad_f(float x) { float g, d; gelu_pair(x, g, d); return d; }
 
 // Cross-lane sums without the LDS crossbar (__shfl_xor compiles to ds_bpermute_b32, ~100 cycles of latency per

@@ -1055,7 +1055,7 @@ static void launch_mlp_fwd_hc(const float* x, const float* o, const BlockP& w, c
 }
 
 void launch_mlp_fwd(int C, int nch, const float* x, const float* o, const BlockP& w, const float* pbase, const void* wh,
-                    float* x1, float* upre, float* x2, int N, int B, hipStream_t s) {
+                    float* x1, float* upre, float* x2, int N, int B, int f16_narrow, hipStream_t s) {
   if (wh && mlp_fwd_uses_f16(C, N)) {
     static const int nth = getenv("RAL_MLP_HTHREADS") ? atoi(getenv("RAL_MLP_HTHREADS")) : 512;
     if (C == 32) launch_mlp_fwd_hc<32, 512>(x, o, w, pbase, wh, x1, upre, x2, N, B, s);
@@ -1063,7 +1063,7 @@ void launch_mlp_fwd(int C, int nch, const float* x, const float* o, const BlockP
     else { if (nth == 1024) launch_mlp_fwd_hc<128, 1024>(x, o, w, pbase, wh, x1, upre, x2, N, B, s); else launch_mlp_fwd_hc<128, 512>(x, o, w, pbase, wh, x1, upre, x2, N, B, s); }
     return;
   }
-  if (mlp_fwd_w_takes(C, N, upre != nullptr)) { launch_mlp_fwd_w(C, x, o, w, x1, x2, N, B, s); return; }   // narrow levels: ral_mlpw.hip
+  if (const int kind = mlp_fwd_w_kind(C, N, upre != nullptr, f16_narrow != 0)) { launch_mlp_fwd_w(C, kind, x, o, w, x1, x2, N, B, s); return; }   // narrow levels: ral_mlpw.hip
   switch (C) {
 #define CASE(c) case c: launch_mlp_fwd_c<c>(nch, x, o, w, x1, upre, x2, N, B, s); break;
     CASE(8) CASE(16) CASE(32) CASE(64) CASE(128)

@@ -30,11 +30,13 @@ size_t mlp_fwd_lds(int C, int N, int nch);
 // pbase / wt: the parameter buffer and the tiled-plane buffer; the levels where mlp_fwd_uses_f16(C, N) run their Linear
 // layers on the planes (wt == nullptr: fp32 MFMA everywhere)
 bool mlp_fwd_uses_f16(int C, int N);
+// f16_narrow: the model allows fp16-pair products (f16_split > 0): the narrow levels may take their f16 strip kernel
 void launch_mlp_fwd(int C, int nch, const float* x, const float* o, const BlockP& w, const float* pbase, const void* wt,
-                    float* x1, float* upre, float* x2, int N, int B, hipStream_t s);
-// narrow levels (C <= 32), wave-autonomous (ral_mlpw.hip)
+                    float* x1, float* upre, float* x2, int N, int B, int f16_narrow, hipStream_t s);
+// narrow levels (C <= 32), wave-autonomous (ral_mlpw.hip): kind 0 = not taken, 1 = fp32-MFMA strips, 2 = f16 strips
+int mlp_fwd_w_kind(int C, int N, bool want_upre, bool f16_ok);
 bool mlp_fwd_w_takes(int C, int N, bool want_upre);
-void launch_mlp_fwd_w(int C, const float* x, const float* o, const BlockP& w, float* x1, float* x2, int N, int B, hipStream_t s);
+void launch_mlp_fwd_w(int C, int kind, const float* x, const float* o, const BlockP& w, float* x1, float* x2, int N, int B, hipStream_t s);
 void launch_resample_fwd(int D, bool sep, const float* x, const float* wred, const float* lnw, const float* lnb,
                          const float* skip, float* y, int T, int B, hipStream_t s);
 void launch_add(const float* a, const float* b, float* y, size_t n, hipStream_t s);

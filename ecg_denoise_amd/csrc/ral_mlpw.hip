@@ -198,17 +198,240 @@ __global__ __launch_bounds__(256, RAL_MLPW_WPE) void k_mlp_fwd_w(const float* __
   }
 }
 
+// ---------------------------------------------------------------------------------
+// The same strip kernel with every product on the f16 matrix cores (fp16-pair operands, ral_device.hpp): the fp32 MFMA is
+// what the narrow levels pay for (41.7 cycles per v_mfma_f32_16x16x4_f32 beside vector work, and it blocks the vector ALU;
+// v_mfma_f32_16x16x16_f16: 10.6, overlapping).  An accumulator tile D[channel 4g+q][token r] is the B operand of
+// v_mfma_f32_16x16x16_f16 as it stands (lane (r, g) holds K = 4g .. 4g+3 of column r): it is split into its two fp16 pieces
+// in registers - ONCE per tile, for all the output tiles it feeds - and a 16-channel block of a product is three MFMAs
+// (h1 h1 into acc; h2 h1 and h1 h2, residuals scaled by 2^11, into accx; result acc + 2^-11 accx) instead of four fp32 ones.
+//   * weights: split when the (persistent) workgroup stages them - every matrix multiplied by its own power of two first
+//     (largest magnitude into [2^13, 2^14)), the inverse applied to the accumulators - as planes of K-contiguous rows at a
+//     stride of K + 8 halves (the 8-byte fragment reads of lanes 0-31 then cover all 64 banks);
+//   * activations (attention output, LayerNorm output, GELU outputs) are not scaled: 22 bits for magnitudes in
+//     [6e-5, 65504], an absolute 3e-8 below, non-finite beyond (nothing clamped, as in the wide-level kernels);
+//   * the local-enhancement edge tokens stay on the vector ALU in fp32 (fp32 copies of Wp and of row 0 of W1 for them).
+template <int C>
+struct MlpwhShape {
+  static constexpr int KP = C < 16 ? 16 : C, MT = KP / 16, HID = 4 * C, HT = HID / 16, S = C >= 32 ? 2 : 4;
+  static constexpr int LDC = KP + 4;                           // fp32 Wp rows (edge tokens)
+  static constexpr int LDA = KP + 8, LDB = HID + 8;            // halves: rows of K = C matrices / of W2 (K = 4C)
+  // floats: Wp fp32 [KP][LDC] | w10 [KP] | bp, g2, be2, b2 [KP each] | b1 [HID] | unscale[4] | max bits[4] | scratch 4 x 64
+  static constexpr int W10O = KP * LDC, VO = W10O + KP, B1O = VO + 4 * KP, UNO = B1O + HID, SCR = UNO + 8, FTOT = SCR + 4 * 64;
+  // halves behind the floats: Wp planes [2][KP][LDA] | W1 planes [2][HID][LDA] | W2 planes [2][KP][LDB]
+  static constexpr int HWP = 0, HW1 = HWP + 2 * KP * LDA, HW2 = HW1 + 2 * HID * LDA, HTOT = HW2 + 2 * KP * LDB;
+  static constexpr size_t BYTES = (size_t)FTOT * 4 + (size_t)HTOT * 2;
+};
+RAL_DEV H2x4 split4s(f32x4 x) {   // pieces with the residual scaled by 2^11 (f16_split2)
+  H2x4 r;
+  const H2 s0 = f16_split2(x[0]), s1 = f16_split2(x[1]), s2 = f16_split2(x[2]), s3 = f16_split2(x[3]);
+  r.a = h16x4{s0.a, s1.a, s2.a, s3.a}; r.b = h16x4{s0.b, s1.b, s2.b, s3.b};
+  return r;
+}
+// fp32 matrix (rows x cols, row stride src_ld... dense) -> two planes of rows x ld halves, scaled by `scale`
+RAL_DEV void stage_planes(const float* __restrict__ W, int rows, int cols, float scale, _Float16* dst, int ld, int plane) {
+  for (int i = threadIdx.x; i < rows * cols; i += blockDim.x) {
+    const int m = i / cols, k = i - m * cols;
+    const H2 h = f16_split2(W[i] * scale);
+    dst[m * ld + k] = h.a; dst[plane + m * ld + k] = h.b;
+  }
+}
+
+template <int C>
+__global__ __launch_bounds__(256, RAL_MLPW_WPE) void k_mlp_fwd_wh(const float* __restrict__ x, const float* __restrict__ o_hm,
+                                                                  BlockP w, float* __restrict__ x1_out, float* __restrict__ x2_out,
+                                                                  int N, int B) {
+  using SH = MlpwhShape<C>;
+  constexpr int KP = SH::KP, MT = SH::MT, HID = SH::HID, HT = SH::HT, LDC = SH::LDC, LDA = SH::LDA, LDB = SH::LDB, S = SH::S;
+  extern __shared__ float4 smem4[];
+  float* sm = reinterpret_cast<float*>(smem4);
+  float* Wp = sm; float* w10 = sm + SH::W10O;
+  float* bp = sm + SH::VO; float* g2 = bp + KP; float* be2 = g2 + KP; float* b2 = be2 + KP; float* b1 = sm + SH::B1O;
+  float* uns = sm + SH::UNO; unsigned* mxb = reinterpret_cast<unsigned*>(uns + 4);
+  _Float16* hb = reinterpret_cast<_Float16*>(sm + SH::FTOT);
+  _Float16* WpH = hb + SH::HWP; _Float16* W1H = hb + SH::HW1; _Float16* W2H = hb + SH::HW2;
+  constexpr int PWP = KP * LDA, PW1 = HID * LDA, PW2 = KP * LDB;   // plane strides
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* scr = sm + SH::SCR + wave * 64;
+  // ---- the block's weights -> LDS (once per workgroup): zero everything, matrix maxima, planes
+  for (int i = threadIdx.x; i < (int)(SH::BYTES / 4); i += blockDim.x) sm[i] = 0.f;
+  __syncthreads();
+  {
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+    for (int i = threadIdx.x; i < C * C; i += blockDim.x) m0 = fmaxf(m0, fabsf(w.wp[i]));
+    for (int i = threadIdx.x; i < HID * C; i += blockDim.x) { m1 = fmaxf(m1, fabsf(w.w1[i])); m2 = fmaxf(m2, fabsf(w.w2[i])); }
+    m0 = group_max<64>(m0); m1 = group_max<64>(m1); m2 = group_max<64>(m2);
+    if (lane == 0) { atomicMax(mxb, __float_as_uint(m0)); atomicMax(mxb + 1, __float_as_uint(m1)); atomicMax(mxb + 2, __float_as_uint(m2)); }
+  }
+  __syncthreads();
+  const float sp = h2_row_scale(mxb[0]), s1 = h2_row_scale(mxb[1]), s2 = h2_row_scale(mxb[2]);
+  const float unp = h2_row_unscale(mxb[0]), un1 = h2_row_unscale(mxb[1]), un2 = h2_row_unscale(mxb[2]);
+  stage_planes(w.wp, C, C, sp, WpH, LDA, PWP);
+  stage_planes(w.w1, HID, C, s1, W1H, LDA, PW1);
+  stage_planes(w.w2, C, HID, s2, W2H, LDB, PW2);
+  for (int i = threadIdx.x; i < C * C; i += blockDim.x) Wp[(i / C) * LDC + i % C] = w.wp[i];
+  for (int i = threadIdx.x; i < C; i += blockDim.x) { w10[i] = w.w1[i]; bp[i] = w.bp[i]; g2[i] = w.ln2w[i]; be2[i] = w.ln2b[i]; b2[i] = w.b2[i]; }
+  for (int i = threadIdx.x; i < HID; i += blockDim.x) b1[i] = w.b1[i];
+  const bool le = w.le != nullptr;
+  float lw0 = 0.f, lw1 = 0.f, lw2 = 0.f;
+  if (le) { lw0 = w.le[0]; lw1 = w.le[1]; lw2 = w.le[2]; }
+  __syncthreads();
+  const bool cv = (C >= 16) || (4 * g < C);
+  const int spw = N / (16 * S), nstrip = B * spw;
+  constexpr float invC = 1.0f / C;
+  // (acc, accx)[mo] += W[16 mo + r][K block kb] x the split tile `bt`
+  auto mma_h = [&](const _Float16* Wh, int plane, int ld, int mo, int kb, const H2x4& bt, f32x4& acc, f32x4& accx) {
+    const _Float16* p = Wh + (16 * mo + r) * ld + 16 * kb + 4 * g;
+    const h16x4 a1 = *reinterpret_cast<const h16x4*>(p), a2 = *reinterpret_cast<const h16x4*>(p + plane);
+    acc = __builtin_amdgcn_mfma_f32_16x16x16f16(a1, bt.a, acc, 0, 0, 0);
+    accx = __builtin_amdgcn_mfma_f32_16x16x16f16(a2, bt.a, accx, 0, 0, 0);
+    accx = __builtin_amdgcn_mfma_f32_16x16x16f16(a1, bt.b, accx, 0, 0, 0);
+  };
+  auto vec4 = [&](const float* v, int tile) -> f32x4 {
+    const float4 t = *reinterpret_cast<const float4*>(v + 16 * tile + 4 * g);
+    return f32x4{t.x, t.y, t.z, t.w};
+  };
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  for (int strip = blockIdx.x * 4 + wave; strip < nstrip; strip += gridDim.x * 4) {
+    const int win = strip / spw, t0 = (strip - win * spw) * 16 * S;
+    const size_t wo = (size_t)win * N * C;
+    const float* xw = x + wo; const float* ow = o_hm + wo;
+    float hl = 0.f, hr = 0.f;
+    if (le) {   // the two edge tokens of the neighbouring strips, fp32 on the vector ALU (see k_mlp_fwd_w)
+      const int c = lane & 31, side = lane >> 5;
+      const int th = side ? t0 + 16 * S : t0 - 1;
+      const bool tin = th >= 0 && th < N, lv = c < C;
+      const int thc = tin ? th : 0;
+      scr[lane] = lv ? ow[((size_t)(c >> 2) * N + thc) * 4 + (c & 3)] : 0.f;
+      float a = lv ? xw[(size_t)thc * C + c] + bp[c] : 0.f;
+      const float* wr = Wp + (lv ? c : 0) * LDC;
+#pragma unroll
+      for (int k = 0; k < KP; k += 4) {
+        const float4 ov = *reinterpret_cast<const float4*>(scr + side * 32 + k);
+        const float4 wv = *reinterpret_cast<const float4*>(wr + k);
+        a = fmaf(wv.x, ov.x, a); a = fmaf(wv.y, ov.y, a); a = fmaf(wv.z, ov.z, a); a = fmaf(wv.w, ov.w, a);
+      }
+      a = lv ? a : 0.f;
+      const float mean = group_sum<32>(a) * invC;
+      const float d = lv ? a - mean : 0.f;
+      const float rstd = 1.0f / sqrtf(group_sum<32>(d * d) * invC + 1e-5f);
+      const float gg = lv ? (d * rstd * g2[c] + be2[c]) * w10[c] : 0.f;
+      const float u0 = group_sum<32>(gg) + b1[0];
+      const float a0 = tin ? gelu_f(u0) : 0.f;
+      hl = lane_value(a0, 0); hr = lane_value(a0, 32);
+    }
+    // ---- pass 1: per tile  x1 = x + o Wp^T + bp,  g = LN2(x1) (kept as its two pieces),  a0 = GELU(u[:, 0])
+    f32x4 x1t[S][MT];
+    H2x4 gth[S][MT];
+    float a0r[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const int tok = t0 + 16 * s + r;
+      H2x4 ob[MT];
+      f32x4 xin[MT], acc[MT], accx[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const float4 ov = cv ? *reinterpret_cast<const float4*>(ow + ((size_t)(4 * m + g) * N + tok) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 xv = cv ? *reinterpret_cast<const float4*>(xw + (size_t)tok * C + 16 * m + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+        ob[m] = split4s(f32x4{ov.x, ov.y, ov.z, ov.w});
+        xin[m] = f32x4{xv.x, xv.y, xv.z, xv.w} + vec4(bp, m);
+        acc[m] = zero4; accx[m] = zero4;
+      }
+#pragma unroll
+      for (int mo = 0; mo < MT; ++mo)
+#pragma unroll
+        for (int kb = 0; kb < MT; ++kb) mma_h(WpH, PWP, LDA, mo, kb, ob[kb], acc[mo], accx[mo]);
+      float sum = 0.f;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        acc[m] = xin[m] + (acc[m] + accx[m] * RAL_H2_SCALE) * unp;
+        x1t[s][m] = acc[m];
+        if (x1_out && cv) *reinterpret_cast<float4*>(x1_out + wo + (size_t)tok * C + 16 * m + 4 * g) = tofloat4(acc[m]);
+        sum += (acc[m][0] + acc[m][1]) + (acc[m][2] + acc[m][3]);
+      }
+      const float mean = rows_sum(sum) * invC;
+      float var = 0.f;
+      f32x4 d[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        d[m] = cv ? acc[m] - mean : zero4;
+        var += (d[m][0] * d[m][0] + d[m][1] * d[m][1]) + (d[m][2] * d[m][2] + d[m][3] * d[m][3]);
+      }
+      const float rstd = 1.0f / sqrtf(rows_sum(var) * invC + 1e-5f);
+      float u0 = 0.f;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const f32x4 gv = d[m] * rstd * vec4(g2, m) + vec4(be2, m);
+        const f32x4 wr0 = vec4(w10, m);                  // row 0 of W1 (padded columns are zero)
+        u0 += (gv[0] * wr0[0] + gv[1] * wr0[1]) + (gv[2] * wr0[2] + gv[3] * wr0[3]);
+        gth[s][m] = split4s(gv);
+      }
+      a0r[s] = le ? gelu_f(rows_sum(u0) + b1[0]) : 0.f;
+    }
+    // ---- pass 2: per tile  hidden = GELU chain(g W1^T + b1),  x2 = x1 + hidden W2^T + b2
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const int tok = t0 + 16 * s + r;
+      f32x4 out[MT], outx[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) { out[m] = zero4; outx[m] = zero4; }
+      float c0 = 0.f;
+      if (le) {
+        const float left = s == 0 ? hl : lane_value(a0r[s > 0 ? s - 1 : 0], 15);
+        const float right = s == S - 1 ? hr : lane_value(a0r[s < S - 1 ? s + 1 : S - 1], 0);
+        const float sm1 = dpp_shift<0x111>(a0r[s]), sp1 = dpp_shift<0x101>(a0r[s]);   // row_shr:1 / row_shl:1
+        const float am = r == 0 ? left : sm1;
+        const float ap = r == 15 ? right : sp1;
+        c0 = gelu_f(lw0 * am + lw1 * a0r[s] + lw2 * ap);
+      }
+#pragma unroll
+      for (int ht = 0; ht < HT; ++ht) {
+        f32x4 h = zero4, hx = zero4;
+#pragma unroll
+        for (int kb = 0; kb < MT; ++kb) mma_h(W1H, PW1, LDA, ht, kb, gth[s][kb], h, hx);
+        h = (h + hx * RAL_H2_SCALE) * un1 + vec4(b1, ht);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float a = gelu_f(h[q]);
+          if (le) a = (ht == 0 && q == 0 && g == 0) ? c0 : gelu_f(a);
+          h[q] = a;
+        }
+        const H2x4 hh = split4s(h);
+#pragma unroll
+        for (int mo = 0; mo < MT; ++mo) mma_h(W2H, PW2, LDB, mo, ht, hh, out[mo], outx[mo]);
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+        if (cv) *reinterpret_cast<float4*>(x2_out + wo + (size_t)tok * C + 16 * m + 4 * g) =
+            tofloat4(x1t[s][m] + vec4(b2, m) + (out[m] + outx[m] * RAL_H2_SCALE) * un2);
+    }
+  }
+}
+
 // Measured at batch 2048 (rocprofv3, serialised step, us per launch: this kernel / k_mlp_fwd): C = 16 (N = 256): 67.6 / 78.7;
 // C = 8 (N = 512): 73.9 / 65.5 - half of every padded MFMA tile is zeros there, k_mlp_fwd has a K = 8 path; C = 32
 // (N = 128): 107 / 92 - two tiles of state per strip already spill (284 bytes per lane at 168 registers).  Both forms sit
 // at about half their issue bound (C = 16: 36 fp32 MFMAs + 32 GELU evaluations per lane and tile = ~2 400 cycles, measured
 // 4 200 / 4 900): what the narrow levels pay for is the fp32 MFMA itself, not the barriers.  Default: C = 16 only
 // (RAL_MLP_FWD_W=2: all three widths, 0: never).
-bool mlp_fwd_w_takes(int C, int N, bool want_upre) {
-  static const int on = [] { const char* v = getenv("RAL_MLP_FWD_W"); return v ? atoi(v) : 1; }();
-  if (!on || want_upre || N % 64 != 0) return false;   // (64: a whole number of strips at every width)
-  return on >= 2 ? (C == 8 || C == 16 || C == 32) : C == 16;
+// which narrow-level forward: 0 = k_mlp_fwd (ral_fwd.hip), 1 = k_mlp_fwd_w (fp32 MFMA), 2 = k_mlp_fwd_wh (f16 matrix cores;
+// only when the model allows fp16-pair products, f16_split > 0).  RAL_MLP_FWD_W: 0 never a strip kernel, 1 fp32 strips
+// at C = 16 only, 2 fp32 strips at every width, 3 (default) C = 16 only, f16 strips where allowed (else fp32 strips),
+// 4 f16 strips at every width.
+// Measured at batch 2048 (rocprofv3, serialised step, us per launch; k_mlp_fwd / fp32 strips / f16 strips): C = 16: 78.7 / 68.5 /
+// 62.1; C = 8: 66.0 / 73.9 / 71.4; C = 32: 93.4 / 107 / 137 (two tiles of state per strip spill at 168 registers).  The f16
+// form removes the matrix share (36 fp32 MFMAs = 1 500 of ~4 200 cycles per tile -> 27 f16 ones that overlap) and shows
+// what is left: the 32 GELU evaluations per lane and tile.
+int mlp_fwd_w_kind(int C, int N, bool want_upre, bool f16_ok) {
+  static const int on = [] { const char* v = getenv("RAL_MLP_FWD_W"); return v ? atoi(v) : 3; }();
+  if (!on || want_upre || N % 64 != 0 || !(C == 8 || C == 16 || C == 32)) return 0;   // (64: a whole number of strips at every width)
+  if (on == 4) return f16_ok ? 2 : 1;
+  if (on == 2) return 1;
+  if (C != 16) return 0;
+  return (on == 3 && f16_ok) ? 2 : 1;
 }
+bool mlp_fwd_w_takes(int C, int N, bool want_upre) { return mlp_fwd_w_kind(C, N, want_upre, false) != 0; }
 
 template <int C>
 static void go_mlp_fwd_w(const float* x, const float* o, const BlockP& w, float* x1, float* x2, int N, int B, hipStream_t s) {
@@ -222,7 +445,25 @@ static void go_mlp_fwd_w(const float* x, const float* o, const BlockP& w, float*
   if (grid > nwg) grid = nwg;
   k_mlp_fwd_w<C><<<grid, 256, lds, s>>>(x, o, w, x1, x2, N, B);
 }
-void launch_mlp_fwd_w(int C, const float* x, const float* o, const BlockP& w, float* x1, float* x2, int N, int B, hipStream_t s) {
+template <int C>
+static void go_mlp_fwd_wh(const float* x, const float* o, const BlockP& w, float* x1, float* x2, int N, int B, hipStream_t s) {
+  const size_t lds = MlpwhShape<C>::BYTES;
+  RAL_SET_LDS((k_mlp_fwd_wh<C>), lds);
+  static const int genv = [] { const char* v = getenv("RAL_GRID_MLPW"); return v ? atoi(v) : 0; }();
+  static int occ = 0;
+  if (!occ && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_mlp_fwd_wh<C>, 256, lds) != hipSuccess || occ < 1)) occ = 3;
+  const int nwg = (B * (N / (16 * MlpwhShape<C>::S)) + 3) / 4;
+  int grid = genv > 0 ? genv : 256 * (occ > 4 ? 4 : occ);
+  if (grid > nwg) grid = nwg;
+  k_mlp_fwd_wh<C><<<grid, 256, lds, s>>>(x, o, w, x1, x2, N, B);
+}
+void launch_mlp_fwd_w(int C, int kind, const float* x, const float* o, const BlockP& w, float* x1, float* x2, int N, int B, hipStream_t s) {
+  if (kind == 2) {
+    if (C == 8) go_mlp_fwd_wh<8>(x, o, w, x1, x2, N, B, s);
+    else if (C == 16) go_mlp_fwd_wh<16>(x, o, w, x1, x2, N, B, s);
+    else go_mlp_fwd_wh<32>(x, o, w, x1, x2, N, B, s);
+    return;
+  }
   if (C == 8) go_mlp_fwd_w<8>(x, o, w, x1, x2, N, B, s);
   else if (C == 16) go_mlp_fwd_w<16>(x, o, w, x1, x2, N, B, s);
   else go_mlp_fwd_w<32>(x, o, w, x1, x2, N, B, s);
