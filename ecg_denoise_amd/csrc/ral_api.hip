@@ -1049,6 +1049,16 @@ int ral_loss_mean(const float* pred, const float* target, int n, int B, int64_t 
   return 0;
 }
 
+int ral_loss_means(const float* pred, const float* target, int n, int B, int64_t global_windows, float* dy, float* snr,
+                   float* rmse, double* means3, double* scratch4, ral_stream s) {
+  if (!pred || !target || !means3 || !scratch4) return fail("ral_loss_means: null pointer");
+  if (n <= 0 || B <= 0 || global_windows <= 0) return fail("ral_loss_means: n, B and global_windows must be positive");
+  launch_loss(pred, target, dy, snr, rmse, scratch4, n, B, (float)(2.0 / ((double)global_windows * n)), (hipStream_t)s, means3,
+              1.0 / (double)global_windows, 1);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
 int ral_loss_flat(const float* pred, const float* target, int n, int B, int64_t global_windows, float* dy, float* snr,
                   float* rmse, double* loss_sum, ral_stream s) {
   if (!pred || !target) return fail("ral_loss_flat: null pointer");

@@ -249,21 +249,29 @@ __global__ __launch_bounds__(6 * C) void k_qkv_fwd_ws(const float* __restrict__ 
 // wplane_unscale, ral_device.hpp) and the consumers multiply their accumulators by it.
 // unscaled: the backward's planes carry unscaled residuals (products with operands that are scaled themselves go into one
 // accumulator, ral_device.hpp), the forward's the 2^11-scaled residual
-__global__ __launch_bounds__(256) void k_weight_scales(const float* __restrict__ params, _Float16* __restrict__ wt, const int4* __restrict__ desc) {
+// (one workgroup per matrix, 1024 threads with four 16-byte loads in flight each: the largest matrix, 64 K floats, is four
+// round trips - with 256 threads and one load per iteration it was 64 and the kernel 23 us, twice per step)
+__global__ __launch_bounds__(1024) void k_weight_scales(const float* __restrict__ params, _Float16* __restrict__ wt, const int4* __restrict__ desc) {
   const int4 D = desc[blockIdx.x];
   const int n4 = (D.y * D.z) >> 2;
   const float4* w4 = reinterpret_cast<const float4*>(params + D.x);
   float m = 0.f;
-  for (int i = threadIdx.x; i < n4; i += blockDim.x) {
-    const float4 v = w4[i];
-    m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+  for (int i0 = 0; i0 < n4; i0 += 4 * 1024) {
+    float4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int i = i0 + k * 1024 + (int)threadIdx.x; v[k] = w4[i < n4 ? i : 0]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) m = fmaxf(m, fmaxf(fmaxf(fabsf(v[k].x), fabsf(v[k].y)), fmaxf(fabsf(v[k].z), fabsf(v[k].w))));
   }
-  __shared__ float red[4];
+  __shared__ float red[16];
   m = group_max<64>(m);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned bits = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+    float mm = red[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) mm = fmaxf(mm, red[k]);
+    const unsigned bits = __float_as_uint(mm);
     float* slot = reinterpret_cast<float*>(wt + 2 * ((size_t)D.x + (size_t)D.y * D.z));
     slot[0] = h2_row_unscale(bits);
     slot[1] = h2_row_scale(bits);
@@ -291,7 +299,7 @@ __global__ void k_tile_planes(const float* __restrict__ params, _Float16* __rest
 }
 void launch_tile_planes(const float* params, void* wt, const void* desc, int ndesc, int nwork, int unscaled, hipStream_t s) {
   if (ndesc <= 0) return;
-  k_weight_scales<<<ndesc, 256, 0, s>>>(params, reinterpret_cast<_Float16*>(wt), reinterpret_cast<const int4*>(desc));
+  k_weight_scales<<<ndesc, 1024, 0, s>>>(params, reinterpret_cast<_Float16*>(wt), reinterpret_cast<const int4*>(desc));
   const int blocks = (nwork + 255) / 256;
   k_tile_planes<<<blocks < 2048 ? blocks : 2048, 256, 0, s>>>(params, reinterpret_cast<_Float16*>(wt), reinterpret_cast<const int4*>(desc), ndesc, nwork, unscaled);
 }

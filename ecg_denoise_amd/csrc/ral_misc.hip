@@ -170,9 +170,12 @@ __global__ __launch_bounds__(256) void k_final_fwd(const float* __restrict__ u0,
 // finishes the job on the device: fin[0] = total * fin_scale (the mean over the global batch), and the accumulator and
 // the arrival counter go back to zero for the next call - no fill kernel before the launch, no division kernel after it
 // (they were two torch kernels per training step).  scratch: {double sum, unsigned long long arrivals}, zero on entry.
-RAL_DEV void loss_commit(double* sum, double mine, double* fin, double fin_scale) {
+// fin3 (ral_loss_means): the sums of the windows' SNR and RMSE ride along (scratch[2], scratch[3]; fin[1], fin[2] = their
+// means over the global batch) - the trainer's per-step metrics then cost no kernel of their own.
+RAL_DEV void loss_commit(double* sum, double mine, double* fin, double fin_scale, int fin3 = 0, double msnr = 0.0, double mrmse = 0.0) {
   atomicAdd(sum, mine);
   if (!fin) return;
+  if (fin3) { atomicAdd(sum + 2, msnr); atomicAdd(sum + 3, mrmse); }
   unsigned long long* cnt = reinterpret_cast<unsigned long long*>(sum + 1);
   __threadfence();
   if (atomicAdd(cnt, 1ull) == (unsigned long long)gridDim.x - 1ull) {
@@ -180,13 +183,19 @@ RAL_DEV void loss_commit(double* sum, double mine, double* fin, double fin_scale
     const double tot = atomicAdd(sum, 0.0);
     fin[0] = tot * fin_scale;
     atomicExch(reinterpret_cast<unsigned long long*>(sum), 0ull);
+    if (fin3) {
+      fin[1] = atomicAdd(sum + 2, 0.0) * fin_scale;
+      fin[2] = atomicAdd(sum + 3, 0.0) * fin_scale;
+      atomicExch(reinterpret_cast<unsigned long long*>(sum + 2), 0ull);
+      atomicExch(reinterpret_cast<unsigned long long*>(sum + 3), 0ull);
+    }
     atomicExch(cnt, 0ull);
   }
 }
 __global__ __launch_bounds__(256) void k_loss(const float* __restrict__ pred, const float* __restrict__ target,
                                               float* __restrict__ dy, float* __restrict__ snr,
                                               float* __restrict__ rmse, double* __restrict__ loss_sum, int n,
-                                              float gscale, double* __restrict__ fin, double fin_scale) {
+                                              float gscale, double* __restrict__ fin, double fin_scale, int fin3) {
   __shared__ double red[2 * 4];
   const size_t base = (size_t)blockIdx.x * n;
   float v[2] = {0.f, 0.f};
@@ -204,9 +213,10 @@ __global__ __launch_bounds__(256) void k_loss(const float* __restrict__ pred, co
     double sse = 0, sy2 = 0;
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { sse += red[w * 2]; sy2 += red[w * 2 + 1]; }
     const float mse = (float)(sse / n), my2 = (float)(sy2 / n);
-    if (snr) snr[blockIdx.x] = 10.0f * log10f(my2 / mse);
-    if (rmse) rmse[blockIdx.x] = sqrtf(mse);
-    if (loss_sum) loss_commit(loss_sum, sse / n, fin, fin_scale);
+    const float sn = 10.0f * log10f(my2 / mse), rm = sqrtf(mse);
+    if (snr) snr[blockIdx.x] = sn;
+    if (rmse) rmse[blockIdx.x] = rm;
+    if (loss_sum) loss_commit(loss_sum, sse / n, fin, fin_scale, fin3, (double)sn, (double)rm);
   }
 }
 
@@ -218,10 +228,10 @@ __global__ __launch_bounds__(256) void k_loss(const float* __restrict__ pred, co
 __global__ __launch_bounds__(64 * LOSS_W_WAVES) void k_loss_w(const float* __restrict__ pred, const float* __restrict__ target,
                                                 float* __restrict__ dy, float* __restrict__ snr,
                                                 float* __restrict__ rmse, double* __restrict__ loss_sum, int n, int B,
-                                                float gscale, double* __restrict__ fin, double fin_scale) {
-  __shared__ double red[LOSS_W_WAVES];
+                                                float gscale, double* __restrict__ fin, double fin_scale, int fin3) {
+  __shared__ double red[3][LOSS_W_WAVES];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n4 = n >> 2;
-  double mine = 0.0;                      // (lane 0: sum over this wave's windows of sse / n)
+  double mine = 0.0, msnr = 0.0, mrmse = 0.0;   // (lane 0: sums over this wave's windows of sse / n, SNR, RMSE)
   for (int w = blockIdx.x * LOSS_W_WAVES + wave; w < B; w += gridDim.x * LOSS_W_WAVES) {
     const float4* p4 = reinterpret_cast<const float4*>(pred + (size_t)w * n);
     const float4* t4 = reinterpret_cast<const float4*>(target + (size_t)w * n);
@@ -247,15 +257,20 @@ __global__ __launch_bounds__(64 * LOSS_W_WAVES) void k_loss_w(const float* __res
     if (lane == 0) {
       const double sse = (double)s0;
       const float mse = (float)(sse / n), my2 = (float)((double)s1 / n);
-      if (snr) snr[w] = 10.0f * log10f(my2 / mse);
-      if (rmse) rmse[w] = sqrtf(mse);
-      mine += sse / n;
+      const float sn = 10.0f * log10f(my2 / mse), rm = sqrtf(mse);
+      if (snr) snr[w] = sn;
+      if (rmse) rmse[w] = rm;
+      mine += sse / n; msnr += (double)sn; mrmse += (double)rm;
     }
   }
-  if (lane == 0) red[wave] = mine;
+  if (lane == 0) { red[0][wave] = mine; red[1][wave] = msnr; red[2][wave] = mrmse; }
   __syncthreads();
-  if (threadIdx.x == 0 && loss_sum)
-    loss_commit(loss_sum, ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7])), fin, fin_scale);
+  if (threadIdx.x == 0 && loss_sum) {
+    double t[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) t[k] = ((red[k][0] + red[k][1]) + (red[k][2] + red[k][3])) + ((red[k][4] + red[k][5]) + (red[k][6] + red[k][7]));
+    loss_commit(loss_sum, t[0], fin, fin_scale, fin3, t[1], t[2]);
+  }
 }
 
 // ---------------------------------------------------------------------------------
@@ -318,15 +333,15 @@ void launch_final_fwd(int leads, const float* u0, const float* x0, const float* 
 }
 
 void launch_loss(const float* pred, const float* target, float* dy, float* snr, float* rmse, double* loss_sum,
-                 int n, int B, float gscale, hipStream_t s, double* fin, double fin_scale) {
+                 int n, int B, float gscale, hipStream_t s, double* fin, double fin_scale, int fin3) {
   if (n % 4 == 0) {
     // (a workgroup ends with two same-address atomics - its share of the sum and its arrival: 512 four-wave workgroups were
     // 19 us at batch 2048 x 1024 floats, 256 eight-wave ones with one window per wave are LOSS_US_256)
     static const int gmax = getenv("RAL_LOSS_GRID") ? atoi(getenv("RAL_LOSS_GRID")) : 256;
     const int g = (B + LOSS_W_WAVES - 1) / LOSS_W_WAVES;
-    k_loss_w<<<g < gmax ? g : gmax, 64 * LOSS_W_WAVES, 0, s>>>(pred, target, dy, snr, rmse, loss_sum, n, B, gscale, fin, fin_scale);
+    k_loss_w<<<g < gmax ? g : gmax, 64 * LOSS_W_WAVES, 0, s>>>(pred, target, dy, snr, rmse, loss_sum, n, B, gscale, fin, fin_scale, fin3);
   } else {
-    k_loss<<<B, 256, 0, s>>>(pred, target, dy, snr, rmse, loss_sum, n, gscale, fin, fin_scale);
+    k_loss<<<B, 256, 0, s>>>(pred, target, dy, snr, rmse, loss_sum, n, gscale, fin, fin_scale, fin3);
   }
 }
 

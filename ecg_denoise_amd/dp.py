@@ -279,13 +279,27 @@ class DataParallelTrainer:
     # ---- metrics: one reduction per logging interval, off the compute stream -------------------------------------
     def _log(self, loss, snr, rmse, G):
         """loss: this rank's share of the global mean ((sse / n) / G); snr, rmse: per local window"""
-        self._hist.append((loss, snr, rmse))
-        if len(self._hist) < self.log_every:
-            return None
-        k = len(self._hist)
-        buf = torch.stack([torch.stack([l.reshape(()).double() for l, _, _ in self._hist]).sum(),
-                           torch.stack([s.double().sum() for _, s, _ in self._hist]).sum() / G,
-                           torch.stack([r.double().sum() for _, _, r in self._hist]).sum() / G]) / k
+        # the HIP engines' loss kernel leaves {loss share, sum SNR / G, sum RMSE / G} in one three-double tensor
+        # (ral_loss_means; `loss` is a view of its first entry): nothing is reduced here then, and with log_every == 1 the
+        # step has no metric kernel at all
+        means = getattr(getattr(self.e, "m", None), "_means", None)
+        if means is not None and means.data_ptr() == loss.data_ptr():
+            self._hist.append(means)
+            if len(self._hist) < self.log_every:
+                return None
+            k = len(self._hist)
+            if k > 1:
+                buf = torch.stack(self._hist).sum(0) / k
+            else:     # (a copy where the all-reduce below would otherwise overwrite the tensor `loss` is a view of)
+                buf = self._hist[0].clone() if self.world > 1 else self._hist[0]
+        else:
+            self._hist.append((loss, snr, rmse))
+            if len(self._hist) < self.log_every:
+                return None
+            k = len(self._hist)
+            buf = torch.stack([torch.stack([l.reshape(()).double() for l, _, _ in self._hist]).sum(),
+                               torch.stack([s.double().sum() for _, s, _ in self._hist]).sum() / G,
+                               torch.stack([r.double().sum() for _, _, r in self._hist]).sum() / G]) / k
         self._hist = []
         work = None
         if self.world > 1:

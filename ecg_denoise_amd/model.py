@@ -216,13 +216,16 @@ class _ModuleBase:
         target = target.contiguous()
         snr = torch.empty(B, dtype=torch.float32, device=pred.device)
         rmse = torch.empty_like(snr)
-        loss = torch.empty(1, dtype=torch.float64, device=pred.device)
+        means = torch.empty(3, dtype=torch.float64, device=pred.device)   # loss share, sum SNR / gw, sum RMSE / gw
+        loss = means[:1]
         dy = torch.empty_like(pred) if want_grad else None
-        # (the mean is finished on the device, ral_loss_mean: no fill kernel before the launch, no division after it)
+        # (the means are finished on the device, ral_loss_means: no fill kernel before the launch, no division or metric
+        # reduction after it)
         if getattr(self, "_loss_scratch", None) is None:
-            self._loss_scratch = torch.zeros(2, dtype=torch.float64, device=pred.device)
-        _lib.check(_lib.lib().ral_loss_mean(_ptr(pred), _ptr(target), pred[0].numel(), B, gw, _ptr(dy), _ptr(snr), _ptr(rmse),
-                                            _ptr(loss), _ptr(self._loss_scratch), _stream()))
+            self._loss_scratch = torch.zeros(4, dtype=torch.float64, device=pred.device)
+        _lib.check(_lib.lib().ral_loss_means(_ptr(pred), _ptr(target), pred[0].numel(), B, gw, _ptr(dy), _ptr(snr), _ptr(rmse),
+                                             _ptr(means), _ptr(self._loss_scratch), _stream()))
+        self._means = means
         self._dy = dy
         return loss, snr, rmse
 
@@ -441,12 +444,14 @@ class NewRALE:
         pred, target = pred.contiguous(), target.contiguous()
         snr = torch.empty(B, dtype=torch.float32, device=pred.device)
         rmse = torch.empty_like(snr)
-        loss = torch.empty(1, dtype=torch.float64, device=pred.device)
+        means = torch.empty(3, dtype=torch.float64, device=pred.device)   # loss share, sum SNR / gw, sum RMSE / gw
+        loss = means[:1]
         dy = torch.empty_like(pred) if want_grad else None
         if getattr(self, "_loss_scratch", None) is None:
-            self._loss_scratch = torch.zeros(2, dtype=torch.float64, device=pred.device)
-        _lib.check(_lib.lib().ral_loss_mean(_ptr(pred), _ptr(target), n, B, gw, _ptr(dy), _ptr(snr), _ptr(rmse),
-                                            _ptr(loss), _ptr(self._loss_scratch), _stream()))
+            self._loss_scratch = torch.zeros(4, dtype=torch.float64, device=pred.device)
+        _lib.check(_lib.lib().ral_loss_means(_ptr(pred), _ptr(target), n, B, gw, _ptr(dy), _ptr(snr), _ptr(rmse),
+                                             _ptr(means), _ptr(self._loss_scratch), _stream()))
+        self._means = means
         self._dy = dy
         return loss, snr, rmse
 
