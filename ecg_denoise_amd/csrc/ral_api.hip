@@ -436,8 +436,10 @@ struct Lane {
   bool dw_pending[MAX_SETS] = {};
   int bwd_count = 0;
 };
+#ifndef MAX_LANES
 #define MAX_LANES 4
-struct LaneSet { Lane l[MAX_LANES]; int n = 1; hipStream_t own[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr}; };
+#endif
+struct LaneSet { Lane l[MAX_LANES]; int n = 1; hipStream_t own[MAX_LANES] = {}; };
 static LaneSet* lanes_of(RalModel* m);
 
 template <class T> static inline T* woff(T* p, int w0, size_t per_window) { return p ? p + (size_t)w0 * per_window : p; }
@@ -1050,10 +1052,10 @@ int ral_loss_mean(const float* pred, const float* target, int n, int B, int64_t 
 }
 
 int ral_loss_means(const float* pred, const float* target, int n, int B, int64_t global_windows, float* dy, float* snr,
-                   float* rmse, double* means3, double* scratch4, ral_stream s) {
-  if (!pred || !target || !means3 || !scratch4) return fail("ral_loss_means: null pointer");
+                   float* rmse, double* means3, double* scratch64, ral_stream s) {
+  if (!pred || !target || !means3 || !scratch64) return fail("ral_loss_means: null pointer");
   if (n <= 0 || B <= 0 || global_windows <= 0) return fail("ral_loss_means: n, B and global_windows must be positive");
-  launch_loss(pred, target, dy, snr, rmse, scratch4, n, B, (float)(2.0 / ((double)global_windows * n)), (hipStream_t)s, means3,
+  launch_loss(pred, target, dy, snr, rmse, scratch64, n, B, (float)(2.0 / ((double)global_windows * n)), (hipStream_t)s, means3,
               1.0 / (double)global_windows, 1);
   HIP_OK(hipGetLastError());
   return 0;

@@ -51,7 +51,7 @@ void launch_bn_apply8(const float* a0, const float* ss, float* x0, size_t ntok, 
 void launch_final_fwd(int leads, const float* u0, const float* x0, const float* w, const float* b, float* y, int L,
                       int B, hipStream_t s);
 // fin != nullptr: loss_sum is a {double, counter} scratch that is zero on entry and left zero; fin[0] = sum * fin_scale
-// fin3: the scratch has four doubles {sum, counter, SNR sum, RMSE sum}; fin[1], fin[2] = the sums of the windows' SNR / RMSE * fin_scale
+// fin3: the scratch has 64 doubles (sum [0], counter [16], SNR sum [32], RMSE sum [48]: a cache line each); fin[1], fin[2] = the sums of the windows' SNR / RMSE * fin_scale
 void launch_loss(const float* pred, const float* target, float* dy, float* snr, float* rmse, double* loss_sum,
                  int n, int B, float gscale, hipStream_t s, double* fin = nullptr, double fin_scale = 1.0, int fin3 = 0);
 void launch_adam(float* p, const float* g, float* m, float* v, size_t n, double lr, double b1, double b2, double eps,

@@ -170,13 +170,15 @@ __global__ __launch_bounds__(256) void k_final_fwd(const float* __restrict__ u0,
 // finishes the job on the device: fin[0] = total * fin_scale (the mean over the global batch), and the accumulator and
 // the arrival counter go back to zero for the next call - no fill kernel before the launch, no division kernel after it
 // (they were two torch kernels per training step).  scratch: {double sum, unsigned long long arrivals}, zero on entry.
-// fin3 (ral_loss_means): the sums of the windows' SNR and RMSE ride along (scratch[2], scratch[3]; fin[1], fin[2] = their
-// means over the global batch) - the trainer's per-step metrics then cost no kernel of their own.
+// fin3 (ral_loss_means): the sums of the windows' SNR and RMSE ride along and their means over the global batch leave as
+// fin[1], fin[2] - the trainer's per-step metrics then cost no kernel of their own.  The four words then sit in FOUR cache
+// lines (scratch of 64 doubles: sum [0], arrivals [16], SNR [32], RMSE [48]): same-line atomics are served one after the other,
+// ~12 ns each (256 workgroups: 12.8 us with two words in one line, 18.8 with four), different lines side by side.
 RAL_DEV void loss_commit(double* sum, double mine, double* fin, double fin_scale, int fin3 = 0, double msnr = 0.0, double mrmse = 0.0) {
   atomicAdd(sum, mine);
   if (!fin) return;
-  if (fin3) { atomicAdd(sum + 2, msnr); atomicAdd(sum + 3, mrmse); }
-  unsigned long long* cnt = reinterpret_cast<unsigned long long*>(sum + 1);
+  if (fin3) { atomicAdd(sum + 32, msnr); atomicAdd(sum + 48, mrmse); }
+  unsigned long long* cnt = reinterpret_cast<unsigned long long*>(sum + (fin3 ? 16 : 1));
   __threadfence();
   if (atomicAdd(cnt, 1ull) == (unsigned long long)gridDim.x - 1ull) {
     __threadfence();
@@ -184,10 +186,10 @@ RAL_DEV void loss_commit(double* sum, double mine, double* fin, double fin_scale
     fin[0] = tot * fin_scale;
     atomicExch(reinterpret_cast<unsigned long long*>(sum), 0ull);
     if (fin3) {
-      fin[1] = atomicAdd(sum + 2, 0.0) * fin_scale;
-      fin[2] = atomicAdd(sum + 3, 0.0) * fin_scale;
-      atomicExch(reinterpret_cast<unsigned long long*>(sum + 2), 0ull);
-      atomicExch(reinterpret_cast<unsigned long long*>(sum + 3), 0ull);
+      fin[1] = atomicAdd(sum + 32, 0.0) * fin_scale;
+      fin[2] = atomicAdd(sum + 48, 0.0) * fin_scale;
+      atomicExch(reinterpret_cast<unsigned long long*>(sum + 32), 0ull);
+      atomicExch(reinterpret_cast<unsigned long long*>(sum + 48), 0ull);
     }
     atomicExch(cnt, 0ull);
   }
@@ -232,35 +234,54 @@ __global__ __launch_bounds__(64 * LOSS_W_WAVES) void k_loss_w(const float* __res
   __shared__ double red[3][LOSS_W_WAVES];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n4 = n >> 2;
   double mine = 0.0, msnr = 0.0, mrmse = 0.0;   // (lane 0: sums over this wave's windows of sse / n, SNR, RMSE)
-  for (int w = blockIdx.x * LOSS_W_WAVES + wave; w < B; w += gridDim.x * LOSS_W_WAVES) {
-    const float4* p4 = reinterpret_cast<const float4*>(pred + (size_t)w * n);
-    const float4* t4 = reinterpret_cast<const float4*>(target + (size_t)w * n);
-    float4* d4 = dy ? reinterpret_cast<float4*>(dy + (size_t)w * n) : nullptr;
-    float v0 = 0.f, v1 = 0.f;
-    auto take = [&](int i, float4 p, float4 t) {
-      const float4 d = f4sub(p, t);
-      v0 += f4dot(d, d); v1 += f4dot(t, t);
-      if (d4) d4[i] = f4scale(d, gscale);
-    };
-    int i = lane;
-    for (; i + 3 * 64 < n4; i += 4 * 64) {
-      float4 pv[4], tv[4];
+  // a wave takes its windows two at a time: both windows' loads (up to 4 x 16 bytes per lane and operand, indices past the
+  // end clamped) are requested before either is reduced - one memory round trip per pair
+  const int stride = gridDim.x * LOSS_W_WAVES;
+  for (int w = blockIdx.x * LOSS_W_WAVES + wave; w < B; w += 2 * stride) {
+    const bool two = w + stride < B;
+    const int wb = two ? w + stride : w;
+    const float4* pa = reinterpret_cast<const float4*>(pred + (size_t)w * n);
+    const float4* ta = reinterpret_cast<const float4*>(target + (size_t)w * n);
+    const float4* pb = reinterpret_cast<const float4*>(pred + (size_t)wb * n);
+    const float4* tb = reinterpret_cast<const float4*>(target + (size_t)wb * n);
+    float4* da = dy ? reinterpret_cast<float4*>(dy + (size_t)w * n) : nullptr;
+    float4* db = dy ? reinterpret_cast<float4*>(dy + (size_t)wb * n) : nullptr;
+    float va0 = 0.f, va1 = 0.f, vb0 = 0.f, vb1 = 0.f;
+    for (int i0 = 0; i0 < n4; i0 += 4 * 64) {
+      float4 pav[4], tav[4], pbv[4], tbv[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) pv[k] = p4[i + k * 64];
+      for (int k = 0; k < 4; ++k) {
+        const int i = i0 + k * 64 + lane, j = i < n4 ? i : 0;
+        pav[k] = pa[j]; tav[k] = ta[j]; pbv[k] = pb[j]; tbv[k] = tb[j];
+      }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) tv[k] = t4[i + k * 64];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) take(i + k * 64, pv[k], tv[k]);
+      for (int k = 0; k < 4; ++k) {
+        const int i = i0 + k * 64 + lane;
+        if (i < n4) {
+          const float4 d = f4sub(pav[k], tav[k]);
+          va0 += f4dot(d, d); va1 += f4dot(tav[k], tav[k]);
+          if (da) da[i] = f4scale(d, gscale);
+          if (two) {
+            const float4 e = f4sub(pbv[k], tbv[k]);
+            vb0 += f4dot(e, e); vb1 += f4dot(tbv[k], tbv[k]);
+            if (db) db[i] = f4scale(e, gscale);
+          }
+        }
+      }
     }
-    for (; i < n4; i += 64) take(i, p4[i], t4[i]);
-    const float s0 = group_sum<64>(v0), s1 = group_sum<64>(v1);
+    const float sa0 = group_sum<64>(va0), sa1 = group_sum<64>(va1), sb0 = group_sum<64>(vb0), sb1 = group_sum<64>(vb1);
     if (lane == 0) {
-      const double sse = (double)s0;
-      const float mse = (float)(sse / n), my2 = (float)((double)s1 / n);
-      const float sn = 10.0f * log10f(my2 / mse), rm = sqrtf(mse);
-      if (snr) snr[w] = sn;
-      if (rmse) rmse[w] = rm;
-      mine += sse / n; msnr += (double)sn; mrmse += (double)rm;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (h == 1 && !two) break;
+        const double sse = (double)(h ? sb0 : sa0);
+        const float mse = (float)(sse / n), my2 = (float)((double)(h ? sb1 : sa1) / n);
+        const float sn = 10.0f * log10f(my2 / mse), rm = sqrtf(mse);
+        const int ww = h ? wb : w;
+        if (snr) snr[ww] = sn;
+        if (rmse) rmse[ww] = rm;
+        mine += sse / n; msnr += (double)sn; mrmse += (double)rm;
+      }
     }
   }
   if (lane == 0) { red[0][wave] = mine; red[1][wave] = msnr; red[2][wave] = mrmse; }
@@ -335,8 +356,9 @@ void launch_final_fwd(int leads, const float* u0, const float* x0, const float* 
 void launch_loss(const float* pred, const float* target, float* dy, float* snr, float* rmse, double* loss_sum,
                  int n, int B, float gscale, hipStream_t s, double* fin, double fin_scale, int fin3) {
   if (n % 4 == 0) {
-    // (a workgroup ends with two same-address atomics - its share of the sum and its arrival: 512 four-wave workgroups were
-    // 19 us at batch 2048 x 1024 floats, 256 eight-wave ones with one window per wave are LOSS_US_256)
+    // (a workgroup ends with atomics on the same words - its share of the sum(s) and its arrival: at batch 2048 x 1024 floats
+    // 512 four-wave workgroups were 19 us, 256 eight-wave ones 12.8 with two words in one cache line and 18.8 with four;
+    // 128 / 64 workgroups: 13.8 / 13.1 - fewer links but half the CUs pulling the 24 MB.  256 and one line per word)
     static const int gmax = getenv("RAL_LOSS_GRID") ? atoi(getenv("RAL_LOSS_GRID")) : 256;
     const int g = (B + LOSS_W_WAVES - 1) / LOSS_W_WAVES;
     k_loss_w<<<g < gmax ? g : gmax, 64 * LOSS_W_WAVES, 0, s>>>(pred, target, dy, snr, rmse, loss_sum, n, B, gscale, fin, fin_scale, fin3);

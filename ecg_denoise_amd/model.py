@@ -222,7 +222,7 @@ class _ModuleBase:
         # (the means are finished on the device, ral_loss_means: no fill kernel before the launch, no division or metric
         # reduction after it)
         if getattr(self, "_loss_scratch", None) is None:
-            self._loss_scratch = torch.zeros(4, dtype=torch.float64, device=pred.device)
+            self._loss_scratch = torch.zeros(64, dtype=torch.float64, device=pred.device)
         _lib.check(_lib.lib().ral_loss_means(_ptr(pred), _ptr(target), pred[0].numel(), B, gw, _ptr(dy), _ptr(snr), _ptr(rmse),
                                              _ptr(means), _ptr(self._loss_scratch), _stream()))
         self._means = means
@@ -448,7 +448,7 @@ class NewRALE:
         loss = means[:1]
         dy = torch.empty_like(pred) if want_grad else None
         if getattr(self, "_loss_scratch", None) is None:
-            self._loss_scratch = torch.zeros(4, dtype=torch.float64, device=pred.device)
+            self._loss_scratch = torch.zeros(64, dtype=torch.float64, device=pred.device)
         _lib.check(_lib.lib().ral_loss_means(_ptr(pred), _ptr(target), n, B, gw, _ptr(dy), _ptr(snr), _ptr(rmse),
                                              _ptr(means), _ptr(self._loss_scratch), _stream()))
         self._means = means

@@ -43,7 +43,7 @@ def test_loss_means_carry_the_metric_means(B, n, gw):
     with the loss - sums of the per-window fp32 values in double, divided by the global window count."""
     g = torch.Generator().manual_seed(3 * B + n)
     pred = torch.randn(B, n, generator=g).to(DEV); tgt = torch.randn(B, n, generator=g).to(DEV)
-    scratch = torch.zeros(4, dtype=torch.float64, device=DEV)
+    scratch = torch.zeros(64, dtype=torch.float64, device=DEV)
     L = _lib.lib()
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     ref_mse = ((pred.double() - tgt.double()) ** 2).mean(1)
