@@ -863,9 +863,16 @@ __global__ __launch_bounds__(UNET_BWD_THREADS, 2) void k_unet_bwd_t(Stage st, in
   const int lane = threadIdx.x & 63, r = lane & 15, g4 = lane >> 4, wave = threadIdx.x >> 6;
   // weight-gradient work units of the workgroup: (tile, position range); layers with fewer tiles than waves split the
   // output positions KSPLIT ways so that every wave has one
-  constexpr int DW_MT = (COUT + 15) / 16, DW_NT = (CIN * KS + 15) / 16, DW_NU = DW_MT * DW_NT;
+  // Conv1d layers: rows = output channels, columns = (ci, k) pairs, contraction over OUTPUT positions.  ConvTranspose1d layers
+  // (TDW): rows = (co, k) pairs, columns = input channels, contraction over INPUT positions i - gw[ci][co][k] = sum_i
+  // in[ci][i] D[co][2 i - 1 + k] - half as many terms as over output positions, where every second one is a zero (the
+  // decoder's weight gradients were 128 MFMAs per window and layer: 4-5 us of a stage at the fp32 MFMA's rate)
+  constexpr bool TDW = MODE == 2;
+  constexpr int DW_M = TDW ? COUT * KS : COUT, DW_N = TDW ? CIN : CIN * KS;
+  constexpr int DW_MT = (DW_M + 15) / 16, DW_NT = (DW_N + 15) / 16, DW_NU = DW_MT * DW_NT;
   constexpr int KSPLIT = DW_NU >= NWAVE ? 1 : (NWAVE + DW_NU - 1) / DW_NU, DW_UNITS = DW_NU * KSPLIT, DW_TPW = (DW_UNITS + NWAVE - 1) / NWAVE;
-  const int kchunk = (((lout + 15) >> 4) + KSPLIT - 1) / KSPLIT * 16;   // output positions per split (multiple of 16)
+  const int dw_klen = TDW ? lin : lout;
+  const int kchunk = (((dw_klen + 15) >> 4) + KSPLIT - 1) / KSPLIT * 16;   // contraction positions per split (multiple of 16)
   f32x4 dwacc[DW_TPW];
 #pragma unroll
   for (int ti = 0; ti < DW_TPW; ++ti) dwacc[ti] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1061,15 +1068,16 @@ __global__ __launch_bounds__(UNET_BWD_THREADS, 2) void k_unet_bwd_t(Stage st, in
       if (unit >= DW_UNITS) continue;
       const int tile = unit / KSPLIT, ks = unit - tile * KSPLIT;
       const int m0 = (tile / DW_NT) << 4, n0 = (tile % DW_NT) << 4;
-      const int co = m0 + r, nn = n0 + r;
-      const bool cook = co < COUT, nok = nn < CIN * KS;
-      const int coc = cook ? co : 0, nnc = nok ? nn : 0, ci = nnc / KS, k = nnc - ci * KS;
-      const int q_lo = ks * kchunk, q_hi = (q_lo + kchunk) < lout ? (q_lo + kchunk) : lout;
-      const float* dr = dc + coc * LPO + HALO + g4;
-      const int t0 = g4 + 1 - k;                       // (MODE 2: output position pp = q0 + 4 u + g4 meets input (pp + 1 - k) / 2)
-      const bool bz = MODE == 2 && (t0 & 1);
-      const float* ir = in + ci * LP + HALO + (MODE == 1 ? g4 - (KS - 1) / 2 + k : (MODE == 0 ? 2 * g4 - 1 + k : (t0 >> 1)));
-      constexpr int BQ = MODE == 1 ? 4 : (MODE == 0 ? 8 : 2);     // floats of the B row per 4 output positions
+      const int mm = m0 + r, nn = n0 + r;
+      const int mc = mm < DW_M ? mm : 0, nc = nn < DW_N ? nn : 0;          // (padding lanes: clamped, dropped at the flush)
+      const int q_lo = ks * kchunk, q_hi = (q_lo + kchunk) < dw_klen ? (q_lo + kchunk) : dw_klen;
+      // A row: TDW: (co, k) = (mc / KS, mc % KS), element i = D[co][2 i - 1 + k]; else co = mc, element pp = D[co][pp]
+      // B row: TDW: ci = nc, element i = in[ci][i]; else (ci, k) = (nc / KS, nc % KS), element pp = in[ci][f(pp, k)]
+      const int ci = TDW ? nc : nc / KS, k = TDW ? mc % KS : nc - (nc / KS) * KS, co = TDW ? mc / KS : mc;
+      const float* dr = dc + co * LPO + HALO + (TDW ? 2 * g4 - 1 + k : g4);
+      const float* ir = in + ci * LP + HALO + (TDW ? g4 : (MODE == 1 ? g4 - (KS - 1) / 2 + k : 2 * g4 - 1 + k));
+      constexpr int AQ = TDW ? 8 : 4;                                // floats of the A row per 4 contraction positions
+      constexpr int BQ = TDW ? 4 : (MODE == 1 ? 4 : 8);              // floats of the B row per 4 contraction positions
       f32x4 accw = dwacc[ti], accx = {0.f, 0.f, 0.f, 0.f};
       for (int wi = 0; wi < nwin; ++wi) {
         const float* d2 = dr + wi * COUT * LPO;
@@ -1079,19 +1087,18 @@ __global__ __launch_bounds__(UNET_BWD_THREADS, 2) void k_unet_bwd_t(Stage st, in
           float av[4], bv[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            av[u] = d2[q0 + 4 * u];
+            av[u] = d2[(q0 >> 2) * AQ + u * AQ];
             bv[u] = i2[(q0 >> 2) * BQ + u * BQ];
-            if (bz) bv[u] = 0.f;
           }
           accw = mfma4(av[0], bv[0], accw); accx = mfma4(av[1], bv[1], accx);
           accw = mfma4(av[2], bv[2], accw); accx = mfma4(av[3], bv[3], accx);
         }
-        if (q0 < q_hi) {   // ragged end (lout not a multiple of 16)
+        if (q0 < q_hi) {   // ragged end (length not a multiple of 16)
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const bool pk = q0 + 4 * u + g4 < q_hi;
-            const float a_ = pk ? d2[q0 + 4 * u] : 0.f;
-            const float b_ = (pk && !bz) ? i2[(q0 >> 2) * BQ + u * BQ] : 0.f;
+            const float a_ = pk ? d2[(q0 >> 2) * AQ + u * AQ] : 0.f;
+            const float b_ = pk ? i2[(q0 >> 2) * BQ + u * BQ] : 0.f;
             accw = mfma4(a_, b_, accw);
           }
         }
@@ -1103,21 +1110,21 @@ __global__ __launch_bounds__(UNET_BWD_THREADS, 2) void k_unet_bwd_t(Stage st, in
     UB_STAMP(20);
   }
   // ---- the workgroup's partial sums leave ----
-  // weight-gradient tiles: lane (r, g) holds rows co = m0 + 4 g + v of column nn = n0 + r; position splits of one tile meet
-  // in the LDS copy of the weight tensor
+  // weight-gradient tiles: lane (r, g) holds rows m0 + 4 g + v of column n0 + r; position splits of one tile meet in the LDS
+  // copy of the weight tensor
 #pragma unroll
   for (int ti = 0; ti < DW_TPW; ++ti) {
     const int unit = wave + ti * NWAVE;
     if (unit >= DW_UNITS) continue;
     const int tile = unit / KSPLIT;
     const int m0 = (tile / DW_NT) << 4, n0 = (tile % DW_NT) << 4, nn = n0 + r;
-    if (nn >= CIN * KS) continue;
-    const int ci = nn / KS, k = nn - ci * KS;
+    if (nn >= DW_N) continue;
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      const int co = m0 + 4 * g4 + v;
-      if (co < COUT) {
-        float* dst = gws + ((MODE == 2) ? (ci * COUT + co) * KS + k : co * CIN * KS + nn);
+      const int mm = m0 + 4 * g4 + v;
+      if (mm < DW_M) {
+        // [co][ci][k] (Conv1d): row co, column (ci, k); [ci][co][k] (ConvTranspose1d): row (co, k), column ci
+        float* dst = gws + (TDW ? nn * (COUT * KS) + mm : mm * CIN * KS + nn);
         if (KSPLIT == 1) *dst = dwacc[ti][v]; else atomicAdd(dst, dwacc[ti][v]);
       }
     }
