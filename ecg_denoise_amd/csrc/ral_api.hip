@@ -615,7 +615,8 @@ static void run_block_bwd(RalModel* m, int bi, const float* dy, const float* ext
   // maxima of this block's gradient tensors (this lane's windows), for the split weight-gradient products: only when both
   // split data-gradient kernels take the shape (they publish them)
   unsigned* gmax = (splitb && m->want_dw && !mlp_bwd_is_fused(C, N) && mlp_bwd_h_nch(C, N) && qkv_bwd_uses_f16(C, N)) ? m->gmax + ((size_t)bi * 4 + (&ln - lanes_of(m)->l)) * 4 : nullptr;
-  { ProfScope p(m, K_MLP_BWD, s); fused_mlp_dw = launch_mlp_bwd(C, m->nch_b[l], dyw, x1, upre, w, wt, m->paramsT, splitb ? m->whT : nullptr, gmax, g, dupre, dx1, dohm, a2c0, N, B, m->want_dw, s); }
+  { ProfScope p(m, K_MLP_BWD, s); fused_mlp_dw = launch_mlp_bwd(C, m->nch_b[l], dyw, x1, upre, w, wt, m->paramsT, splitb ? m->whT : nullptr, gmax, g, dupre, dx1, dohm, a2c0, N, B, m->want_dw, s,
+                                                                  (m->f16_split > 0 && m->narrow_f16) ? 1 : 0); }
   { ProfScope p(m, K_ATTN_BWD, s);
     // (each lane's scratch: its share of the stat2 region followed by its share of the partials region)
     float* scratch = m->astat[k] + (size_t)w0 * (E1 / 2 + 2048);

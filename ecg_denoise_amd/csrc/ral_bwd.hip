@@ -1864,13 +1864,19 @@ static bool launch_mlp_bwd_c(int nch, const float* dx2, const float* x1, const f
 // skips those two products in launch_block_dw
 bool launch_mlp_bwd(int C, int nch, const float* dx2, const float* x1, const float* upre, const BlockP& w,
                     const BlockP& wt, const float* ptbase, const void* wtt, unsigned* gmax, const BlockP& gr, float* dupre, float* dx1, float* do_hm,
-                    float* a2c0, int N, int B, bool want_dw, hipStream_t s) {
+                    float* a2c0, int N, int B, bool want_dw, hipStream_t s, int f16_narrow) {
   if (!want_dw) { dupre = nullptr; a2c0 = nullptr; }   // consumed by the weight-gradient kernels only
   if (wtt && upre) {   // (upre == nullptr: a level whose forward does not store u_pre - the fused narrow-level kernel re-computes it)
     const int nh = mlp_bwd_h_nch(C, N);
     if (nh && C == 32) { launch_mlp_bwd_hc<32>(nh, dx2, x1, upre, w, wt, ptbase, wtt, gr, dupre, dx1, do_hm, a2c0, want_dw ? gmax : nullptr, N, B, s); return false; }
     if (nh && C == 64) { launch_mlp_bwd_hc<64>(nh, dx2, x1, upre, w, wt, ptbase, wtt, gr, dupre, dx1, do_hm, a2c0, want_dw ? gmax : nullptr, N, B, s); return false; }
     if (nh && C == 128) { launch_mlp_bwd_hc<128>(nh, dx2, x1, upre, w, wt, ptbase, wtt, gr, dupre, dx1, do_hm, a2c0, want_dw ? gmax : nullptr, N, B, s); return false; }
+  }
+  if (!upre && mlp_bwd_is_fused(C, N)) {   // strip kernels (ral_mlpw.hip), fc1 / fc2 weight gradients fused
+    if (const int kind = mlp_bwd_w_kind(C, N, f16_narrow != 0)) {
+      launch_mlp_bwd_w(C, kind, dx2, x1, w, gr, dx1, do_hm, N, B, want_dw, s);
+      return true;
+    }
   }
   switch (C) {
 #define CASE(c) case c: return launch_mlp_bwd_c<c>(nch, dx2, x1, upre, w, wt, gr, dupre, dx1, do_hm, a2c0, N, B, want_dw, s);

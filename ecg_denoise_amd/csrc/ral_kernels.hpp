@@ -37,6 +37,11 @@ void launch_mlp_fwd(int C, int nch, const float* x, const float* o, const BlockP
 int mlp_fwd_w_kind(int C, int N, bool want_upre, bool f16_ok);
 bool mlp_fwd_w_takes(int C, int N, bool want_upre);
 void launch_mlp_fwd_w(int C, int kind, const float* x, const float* o, const BlockP& w, float* x1, float* x2, int N, int B, hipStream_t s);
+// narrow levels, backward as a strip kernel (ral_mlpw.hip; fc1 / fc2 weight gradients fused like k_mlp_bwd_s)
+// kind: 0 = not taken, 1 = fp32-MFMA strips, 2 = f16 strips (f16_ok: the model allows fp16-pair products)
+int mlp_bwd_w_kind(int C, int N, bool f16_ok);
+void launch_mlp_bwd_w(int C, int kind, const float* dx2, const float* x1, const BlockP& w, const BlockP& gr, float* dx1, float* do_hm, int N, int B,
+                      bool want_dw, hipStream_t s);
 void launch_resample_fwd(int D, bool sep, const float* x, const float* wred, const float* lnw, const float* lnb,
                          const float* skip, float* y, int T, int B, hipStream_t s);
 void launch_add(const float* a, const float* b, float* y, size_t n, hipStream_t s);
@@ -81,7 +86,7 @@ bool qkv_bwd_uses_f16(int C, int N);
 // |dqkv| (qkv) of the launch - the scales of the split weight-gradient products (launch_block_dw)
 bool launch_mlp_bwd(int C, int nch, const float* dx2, const float* x1, const float* upre, const BlockP& w,
                     const BlockP& wt, const float* ptbase, const void* wtt, unsigned* gmax, const BlockP& gr, float* dupre, float* dx1, float* do_hm,
-                    float* a2c0, int N, int B, bool want_dw, hipStream_t s);
+                    float* a2c0, int N, int B, bool want_dw, hipStream_t s, int f16_narrow = 0);
 size_t attn_bwd_lds(int N, int HG, int Len);
 bool attn_bwd_uses_stat2(int N, int Len, bool table);   // does launch_attn_bwd need its (B, H, N, 2) scratch for this shape?
 // scratch / scratch_floats: caller-owned; attn_bwd_scratch_floats() says how much the kernels chosen for a shape need

