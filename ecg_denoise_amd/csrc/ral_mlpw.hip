@@ -553,26 +553,47 @@ __global__ __launch_bounds__(256, RAL_MLPW_WPE) void k_mlp_bwd_w(const float* __
   for (int m = 0; m < MT; ++m) { sb2[m] = zero4; sgam[m] = zero4; sbet[m] = zero4; }
   float gle0 = 0.f, gle1 = 0.f, gle2 = 0.f;
   const int tpw = N >> 4, ntile = B * tpw;
+  // The operands of a tile - 16 tokens of x1 and dx2 and, for the local enhancement, one channel of each of the four halo
+  // tokens per lane - are REQUESTED one tile ahead: a wave has nothing else in flight while it waits, and with three waves
+  // per SIMD a round trip per 16 tokens was most of what the tile cost.
+  float4 pxa[MT], pda[MT];
+  float pxh = 0.f, pdh = 0.f;
+  auto request = [&](int tl, float4 (&xa)[MT], float4 (&da)[MT], float& hx, float& hd) {
+    const int tlc = tl < ntile ? tl : ntile - 1;                      // (past the end: a valid address, never used)
+    const int win_ = tlc / tpw, t0_ = (tlc - win_ * tpw) << 4;
+    const float* xw_ = x1 + (size_t)win_ * N * C; const float* dw_ = dx2 + (size_t)win_ * N * C;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int off = (t0_ + r) * C + (cv ? 16 * m + 4 * g : 0);
+      xa[m] = *reinterpret_cast<const float4*>(xw_ + off);
+      da[m] = *reinterpret_cast<const float4*>(dw_ + off);
+    }
+    if (le) {
+      const int th = g < 2 ? t0_ - 2 + g : t0_ + 14 + g;
+      const int thc = (th >= 0 && th < N) ? th : 0, rc = r < C ? r : 0;
+      hx = xw_[(size_t)thc * C + rc]; hd = dw_[(size_t)thc * C + rc];
+    }
+  };
+  request(blockIdx.x * 4 + wave, pxa, pda, pxh, pdh);
   for (int tile = blockIdx.x * 4 + wave; tile < ntile; tile += gridDim.x * 4) {
     const int win = tile / tpw, t0 = (tile - win * tpw) << 4, tok = t0 + r;
     const size_t wo = (size_t)win * N * C;
-    const float* xw = x1 + wo; const float* dw = dx2 + wo;
-    // ---- loads: the tile and (local enhancement) the four halo tokens t0-2, t0-1, t0+16, t0+17 (lane group g = slot, lane r = channel)
     f32x4 xv[MT], dv[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-      const float4 a = cv ? *reinterpret_cast<const float4*>(xw + (size_t)tok * C + 16 * m + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
-      const float4 d = cv ? *reinterpret_cast<const float4*>(dw + (size_t)tok * C + 16 * m + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
-      xv[m] = f32x4{a.x, a.y, a.z, a.w}; dv[m] = f32x4{d.x, d.y, d.z, d.w};
+      xv[m] = cv ? f32x4{pxa[m].x, pxa[m].y, pxa[m].z, pxa[m].w} : zero4;
+      dv[m] = cv ? f32x4{pda[m].x, pda[m].y, pda[m].z, pda[m].w} : zero4;
     }
+    const float cxh = pxh, cdh = pdh;
+    request(tile + gridDim.x * 4, pxa, pda, pxh, pdh);                 // the next tile's operands
     float hA0[4] = {0.f, 0.f, 0.f, 0.f}, hD[2] = {0.f, 0.f};   // GELU(u[:, 0]) of the halo tokens; da2[:, 0] of t0-1 and t0+16
-    if (le) {
+    if (le) {   // halo tokens t0-2, t0-1, t0+16, t0+17: lane group g = slot, lane r = channel
       static_assert(C <= 16, "one halo channel per lane");
       const int th = g < 2 ? t0 - 2 + g : t0 + 14 + g;
       const bool tin = th >= 0 && th < N, lv = r < C;
-      const int thc = tin ? th : 0, rc = lv ? r : 0;
-      const float xh_ = lv ? xw[(size_t)thc * C + rc] : 0.f;
-      const float dh_ = lv ? dw[(size_t)thc * C + rc] : 0.f;
+      const int rc = lv ? r : 0;
+      const float xh_ = lv ? cxh : 0.f;
+      const float dh_ = lv ? cdh : 0.f;
       const float mean = group_sum<16>(xh_) * invC;
       const float d = lv ? xh_ - mean : 0.f;
       const float rstd = 1.0f / sqrtf(group_sum<16>(d * d) * invC + 1e-5f);
@@ -647,19 +668,19 @@ __global__ __launch_bounds__(256, RAL_MLPW_WPE) void k_mlp_bwd_w(const float* __
       f32x4 u = vec4(b1, ht), da2 = zero4;
 #pragma unroll
       for (int kb = 0; kb < MT; ++kb) { u = mma_block(W1, LDC, ht, kb, gx[kb], u); da2 = mma_block(W2T, LDC, ht, kb, dv[kb], da2); }
-      f32x4 du, a2;
+      // (straight-line over the four elements, the uniform `le` test outside: hipcc then packs the polynomials of two
+      // elements into v_pk_* instructions - with the test inside the element loop every evaluation was scalar code
+      // behind a branch, 16 branches per tile)
+      f32x4 du, a2, a1v, d1v;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float a1, d1;
-        gelu_pair(u[q], a1, d1);
-        if (!le) { du[q] = da2[q] * d1; a2[q] = a1; }
-        else {
-          float g2_, d2;
-          gelu_pair(a1, g2_, d2);
-          du[q] = da2[q] * d2 * d1; a2[q] = g2_;
-        }
-      }
-      if (le && ht == 0 && g == 0) { du[0] = du_0; a2[0] = a2_0; }          // hidden channel 0: through the conv
+      for (int q = 0; q < 4; ++q) { float a_, d_; gelu_pair(u[q], a_, d_); a1v[q] = a_; d1v[q] = d_; }
+      if (le) {
+        f32x4 g2v, d2v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { float a_, d_; gelu_pair(a1v[q], a_, d_); g2v[q] = a_; d2v[q] = d_; }
+        du = da2 * d2v * d1v; a2 = g2v;
+        if (ht == 0 && g == 0) { du[0] = du_0; a2[0] = a2_0; }              // hidden channel 0: through the conv
+      } else { du = da2 * d1v; a2 = a1v; }
 #pragma unroll
       for (int mo = 0; mo < MT; ++mo) dg[mo] = mma_block(W1T, LDH, mo, ht, du, dg[mo]);
       if (want_dw) {
