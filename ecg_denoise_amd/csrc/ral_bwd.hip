@@ -83,17 +83,21 @@ __global__ __launch_bounds__(512) void k_mlp_bwd(const float* __restrict__ dx2, 
         float4* pu = reinterpret_cast<float4*>(Us + tok * LDU + row0);
         const float4 u = *pu;
         float uu[4] = {u.x, u.y, u.z, u.w}, out[4];
+        // (the uniform `le` test OUTSIDE the element loop and the channel-0 exception patched afterwards: straight-line code
+        // over the four elements is what hipcc packs two at a time; behind per-element branches every GELU was scalar)
+        if (!le) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (!le) {
-            out[e] = a[e] * gelu_grad_f(uu[e]);
-          } else if (ch == 0 && row0 + e == 0) {
-            DC0[tok + 1] = a[e] * gelu_grad_f(C0[tok]);
-            out[e] = 0.f;  // filled by the channel-0 pass below
-          } else {
+          for (int e = 0; e < 4; ++e) out[e] = a[e] * gelu_grad_f(uu[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
             float a1, d1;
             gelu_pair(uu[e], a1, d1);
             out[e] = a[e] * gelu_grad_f(a1) * d1;
+          }
+          if (ch == 0 && row0 == 0) {
+            DC0[tok + 1] = a[0] * gelu_grad_f(C0[tok]);
+            out[0] = 0.f;  // filled by the channel-0 pass below
           }
         }
         *pu = make_float4(out[0], out[1], out[2], out[3]);
@@ -286,22 +290,24 @@ __global__ __launch_bounds__(512, 4) void k_mlp_bwd_h(const float* __restrict__ 
             const f32x4 a = acc[mi][tt] * sd;
             const float4 u = *reinterpret_cast<const float4*>(Us + tok * LDUF + row0);
             const float uu[4] = {u.x, u.y, u.z, u.w};
+            float o4[4];
+            if (!le) {     // (the `le` test outside the element loop: see k_mlp_bwd)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              float o;
-              if (!le) {
-                o = a[e] * gelu_grad_f(uu[e]);
-              } else if (ch == 0 && row0 + e == 0) {
-                DC0[tok + 1] = a[e] * gelu_grad_f(C0[tok]);
-                o = 0.f;  // filled by the channel-0 pass below
-              } else {
+              for (int e = 0; e < 4; ++e) o4[e] = a[e] * gelu_grad_f(uu[e]);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
                 float a1, d1;
                 gelu_pair(uu[e], a1, d1);
-                o = a[e] * gelu_grad_f(a1) * d1;
+                o4[e] = a[e] * gelu_grad_f(a1) * d1;
               }
-              outv[mi][tt][e] = o;
-              mx = fmaxf(mx, fabsf(o));
+              if (ch == 0 && row0 == 0) {
+                DC0[tok + 1] = a[0] * gelu_grad_f(C0[tok]);
+                o4[0] = 0.f;  // filled by the channel-0 pass below
+              }
             }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { outv[mi][tt][e] = o4[e]; mx = fmaxf(mx, fabsf(o4[e])); }
           }
           mx = rows_max(mx);
           tmxu = fmaxf(tmxu, mx);
@@ -497,20 +503,22 @@ __global__ __launch_bounds__(512, 4) void k_mlp_bwd_s(const float* __restrict__ 
                                                 [&](int row0, int tok, f32x4 a) {
         float4* pu = reinterpret_cast<float4*>(Us + tok * LD + row0);
         const float4 u = *pu;
-        float uu[4] = {u.x, u.y, u.z, u.w}, out[4], a2[4];
+        float uu[4] = {u.x, u.y, u.z, u.w}, out[4], a2[4], a1v[4], d1v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float a1, d1;
-          gelu_pair(uu[e], a1, d1);
-          if (!le) {
-            out[e] = a[e] * d1; a2[e] = a1;
-          } else if (ch == 0 && row0 + e == 0) {
-            DC0[tok + 1] = a[e] * gelu_grad_f(C0[tok]);
-            out[e] = 0.f; a2[e] = 0.f;  // both filled by the channel-0 pass below
-          } else {
+        for (int e = 0; e < 4; ++e) gelu_pair(uu[e], a1v[e], d1v[e]);
+        if (!le) {     // (the `le` test outside the element loop: see k_mlp_bwd)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { out[e] = a[e] * d1v[e]; a2[e] = a1v[e]; }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
             float g2, d2;
-            gelu_pair(a1, g2, d2);
-            out[e] = a[e] * d2 * d1; a2[e] = g2;
+            gelu_pair(a1v[e], g2, d2);
+            out[e] = a[e] * d2 * d1v[e]; a2[e] = g2;
+          }
+          if (ch == 0 && row0 == 0) {
+            DC0[tok + 1] = a[0] * gelu_grad_f(C0[tok]);
+            out[0] = 0.f; a2[0] = 0.f;  // both filled by the channel-0 pass below
           }
         }
         *pu = make_float4(out[0], out[1], out[2], out[3]);
