@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256, RAL_MLPW_WPE) void k_mlp_fwd_w(const float* __
 //   * the local-enhancement edge tokens stay on the vector ALU in fp32 (fp32 copies of Wp and of row 0 of W1 for them).
 template <int C>
 struct MlpwhShape {
-  static constexpr int KP = C < 16 ? 16 : C, MT = KP / 16, HID = 4 * C, HT = HID / 16, S = C >= 32 ? 2 : 4;
+  static constexpr int KP = C < 16 ? 16 : C, MT = KP / 16, HID = 4 * C, HT = HID / 16, S = C >= 32 ? 1 : 4;   // (C = 32: two tiles of state spilled)
   static constexpr int LDC = KP + 4;                           // fp32 Wp rows (edge tokens)
   static constexpr int LDA = KP + 8, LDB = HID + 8;            // halves: rows of K = C matrices / of W2 (K = 4C)
   // floats: Wp fp32 [KP][LDC] | w10 [KP] | bp, g2, be2, b2 [KP each] | b1 [HID] | unscale[4] | max bits[4] | scratch 4 x 64
