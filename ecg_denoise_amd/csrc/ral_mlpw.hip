@@ -417,19 +417,20 @@ __global__ __launch_bounds__(256, RAL_MLPW_WPE) void k_mlp_fwd_wh(const float* _
 // (RAL_MLP_FWD_W=2: all three widths, 0: never).
 // which narrow-level forward: 0 = k_mlp_fwd (ral_fwd.hip), 1 = k_mlp_fwd_w (fp32 MFMA), 2 = k_mlp_fwd_wh (f16 matrix cores;
 // only when the model allows fp16-pair products, f16_split > 0).  RAL_MLP_FWD_W: 0 never a strip kernel, 1 fp32 strips
-// at C = 16 only, 2 fp32 strips at every width, 3 (default) C = 16 only, f16 strips where allowed (else fp32 strips),
-// 4 f16 strips at every width.
-// Measured at batch 2048 (rocprofv3, serialised step, us per launch; k_mlp_fwd / fp32 strips / f16 strips): C = 16: 78.7 / 68.5 /
-// 62.1; C = 8: 66.0 / 73.9 / 71.4; C = 32: 93.4 / 107 / 137 (two tiles of state per strip spill at 168 registers).  The f16
-// form removes the matrix share (36 fp32 MFMAs = 1 500 of ~4 200 cycles per tile -> 27 f16 ones that overlap) and shows
-// what is left: the 32 GELU evaluations per lane and tile.
+// at C = 16 only, 2 fp32 strips at every width, 3 (default) f16 strips at every width where allowed, else fp32 strips at
+// C = 16.
+// Measured at batch 2048 (rocprofv3, serialised step, us per launch; k_mlp_fwd / fp32 strips / f16 strips), first with the
+// two-transcendental GELU: C = 16: 78.7 / 68.5 / 62.1; C = 8: 66.0 / 73.9 / 71.4; C = 32: 93.4 / 107 / 137 (two tiles of state
+// per strip spilled at 168 registers); then with the one-exponential forward GELU and one-tile strips at C = 32 (104
+// registers): C = 16: - / - / 51.3; C = 8: 64.1 / - / 62.1; C = 32: 86.5 / - / 71.2.  The f16 form removes the matrix share
+// (36 fp32 MFMAs = 1 500 of ~4 200 cycles per tile at C = 16 -> 27 f16 ones that overlap); what is left is the 32 GELU
+// evaluations per lane and tile.
 int mlp_fwd_w_kind(int C, int N, bool want_upre, bool f16_ok) {
   static const int on = [] { const char* v = getenv("RAL_MLP_FWD_W"); return v ? atoi(v) : 3; }();
   if (!on || want_upre || N % 64 != 0 || !(C == 8 || C == 16 || C == 32)) return 0;   // (64: a whole number of strips at every width)
-  if (on == 4) return f16_ok ? 2 : 1;
+  if (on >= 3 && f16_ok) return 2;
   if (on == 2) return 1;
-  if (C != 16) return 0;
-  return (on == 3 && f16_ok) ? 2 : 1;
+  return C == 16 ? 1 : 0;
 }
 bool mlp_fwd_w_takes(int C, int N, bool want_upre) { return mlp_fwd_w_kind(C, N, want_upre, false) != 0; }
 
