@@ -195,6 +195,7 @@ def cpu_baseline(leads, L, variant, big_batch=256):
         if d and "value" in d and leads == 1 and L == 512:
             res["bench_batch"] = {"value": d["value"], "batch": 2048, "cores": d.get("cores"), "source": "profiles/" + name,
                                   "s_per_step": min(r["s_per_step"] for r in d.get("runs", [{"s_per_step": None}]))}
+            break                                   # (the newest round's file)
     return res
 
 
