@@ -105,7 +105,7 @@ def test_unet_bench_batch_matches_fp64_oracle(L, B):
     assert abs(loss.item() - lo.item()) < 1e-5 * abs(lo.item())
     # what fp32 arithmetic itself costs at this size: the oracle evaluated in fp32 on the CPU against its fp64 evaluation
     # (2048 x 2 x 1024: 1.4e-3 .. 2.0e-3 on the encoder's gradients - twice the activations, twice the slope flips; the HIP
-    # path measured 1.6e-3 .. 3.1e-3 there, tools/diag/r4_unet_kink.py)
+    # path measured 1.6e-3 .. 3.1e-3 there, tools/diag/unet_kink.py)
     p32 = OrderedDict((k, v.detach().float().requires_grad_(True)) for k, v in p.items())
     y32 = O.unet_forward(p32, x.float(), True, O.unet_bn_state(p32, torch.float32))
     g32 = torch.autograd.grad(O.mse(y32, tgt.float()), list(p32.values()))
