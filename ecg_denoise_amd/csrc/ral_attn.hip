@@ -634,6 +634,10 @@ __global__ __launch_bounds__(256) void k_attn_tpart_reduce(const float* __restri
   if (lane == 0) atomicAdd(gtable + i, t);
 }
 
+void launch_attn_tpart_reduce(const float* tpart, float* gtable, int ntab, int nrow, hipStream_t s) {
+  k_attn_tpart_reduce<<<(ntab + 3) / 4, 256, 0, s>>>(tpart, gtable, ntab, nrow);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 int attn_f16_default() {
   static const int m = [] { const char* v = getenv("RAL_ATTN_F16"); return v ? atoi(v) : 1; }();
@@ -644,7 +648,7 @@ static int attnw_mode() {   // RAL_ATTN_BWD_W=0: never (the workgroup kernels of
   return m;
 }
 // upper bound of the grid (what the scratch is sized for): one workgroup per four tasks, at most 1024
-static int attnw_grid_max(int N, int H, int B) {
+int attnw_grid_max(int N, int H, int B) {
   const int hw = N >= 64 ? 1 : 64 / N;
   const int ntask = B * H / hw, g = (ntask + 3) / 4;
   return g < 1024 ? g : 1024;

@@ -1913,6 +1913,7 @@ bool attn_bwd_uses_stat2(int N, int Len, bool table) {
 }
 
 size_t attn_bwd_scratch_floats(int N, int H, int Len, bool table, int B) {
+  if (attn_bwd_m_takes(N, H, Len, table)) return attn_bwd_m_scratch_floats(N, H, Len, table, B);
   if (attn_bwd_w_takes(N, H, Len, table)) return attn_bwd_w_scratch_floats(N, H, Len, table, B);
   if (attn_bwd_h_takes(N, H, Len, table)) return attn_bwd_h_scratch_floats(N, H, Len, table, B);   // (what its f16 form needs)
   if (!attn_bwd_uses_stat2(N, Len, table)) return 0;
@@ -1922,6 +1923,12 @@ size_t attn_bwd_scratch_floats(int N, int H, int Len, bool table, int B) {
 void launch_attn_bwd(const float* qkv, const float* o_hm, const float* do_hm, const float* lse, const float* table,
                      float* gtable, float* dqkv, float* stat2, size_t scratch_floats, int N, int H, int HG, int Len, int B,
                      int f16, hipStream_t s) {
+  // one sweep with every contraction on the f16 matrix cores (ral_attnm.hip)
+  if (f16 && attn_bwd_m_takes(N, H, Len, table != nullptr) &&
+      (stat2 ? scratch_floats : 0) >= attn_bwd_m_scratch_floats(N, H, Len, table != nullptr, B)) {
+    launch_attn_bwd_m(qkv, o_hm, do_hm, lse, table, gtable, dqkv, stat2, N, H, Len, B, s);
+    return;
+  }
   // short windows: one wave per head, no workgroup barriers (ral_attn.hip)
   if (attn_bwd_w_takes(N, H, Len, table != nullptr) &&
       (stat2 ? scratch_floats : 0) >= attn_bwd_w_scratch_floats(N, H, Len, table != nullptr, B)) {

@@ -111,6 +111,13 @@ bool attn_bwd_w_takes(int N, int H, int Len, bool table);
 size_t attn_bwd_w_scratch_floats(int N, int H, int Len, bool table, int B);
 void launch_attn_bwd_w(const float* qkv, const float* o_hm, const float* do_hm, const float* lse, const float* table,
                        float* gtable, float* dqkv, float* tpart, int N, int H, int Len, int B, int f16, hipStream_t s);
+int attnw_grid_max(int N, int H, int B);   // upper bound of the wave-autonomous kernels' grids (what their scratch is sized for)
+void launch_attn_tpart_reduce(const float* tpart, float* gtable, int ntab, int nrow, hipStream_t s);
+// one sweep, every contraction on the f16 matrix cores (ral_attnm.hip; only with f16 != 0)
+bool attn_bwd_m_takes(int N, int H, int Len, bool table);
+size_t attn_bwd_m_scratch_floats(int N, int H, int Len, bool table, int B);
+void launch_attn_bwd_m(const float* qkv, const float* o_hm, const float* do_hm, const float* lse, const float* table,
+                       float* gtable, float* dqkv, float* tpart, int N, int H, int Len, int B, hipStream_t s);
 size_t qkv_bwd_lds(int C, int N);
 void launch_qkv_bwd(int C, const float* dqkv, const float* x, const float* pe, const float* dx1, const float* extra,
                     const BlockP& w, const BlockP& wt, const float* ptbase, const void* wtt /* as launch_mlp_bwd */, unsigned* gmax,
