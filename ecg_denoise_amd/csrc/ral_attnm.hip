@@ -94,6 +94,14 @@ RAL_DEV float pow2_inv(float p) { return __uint_as_float((254u << 23) - __float_
 
 RAL_DEV float f4amax(float4 v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
 
+#ifndef RAL_ATTNM_FENCE
+#define RAL_ATTNM_FENCE 1
+#endif
+#if RAL_ATTNM_FENCE
+#define RAL_XB_FENCE() asm volatile("" ::: "memory")
+#else
+#define RAL_XB_FENCE() do {} while (0)
+#endif
 #ifndef RAL_ATTNM_WPE
 #define RAL_ATTNM_WPE 4
 #endif
@@ -283,7 +291,7 @@ __global__ __launch_bounds__(256, RAL_ATTNM_WPE) void k_attn_bwd_m(const float* 
           float* bw = Xb + (kt & 1) * 2 * BUF + r * 10 + 2 * g;
           *reinterpret_cast<u32x2*>(bw) = u32x2{sh1[0], sh1[1]};
           *reinterpret_cast<u32x2*>(bw + BUF) = u32x2{sh2[0], sh2[1]};
-          asm volatile("" ::: "memory");
+          RAL_XB_FENCE();
           if (kt > 0) dq_step(kt - 1);
         }
 // (fence + keep-alive below: without them hipcc interleaves the reads of this last step with the last tile and re-uses the
@@ -322,6 +330,234 @@ __global__ __launch_bounds__(256, RAL_ATTNM_WPE) void k_attn_bwd_m(const float* 
   }
 }
 
+// =====================================================================================================================
+// Long windows (N >= 256; any N = 16 KT W with W waves per head dividing 8): a 512-thread workgroup per (window, head group),
+// as k_attn_bwd_h stages it - all operands of the item as plane images in the LDS, scales per head from LDS maxima - but with
+// the one-sweep tiles above.  A wave owns KT key tiles of one head for the whole item: their K / V operands and k^T planes
+// stay in registers, dV^T / dK^T in KT accumulators; it walks over ALL query tiles of the head, and the dQ^T tile of a query
+// tile (summed over the wave's keys in registers) is added to an fp32 image of dQ in the LDS with ONE ds_add_f32 per lane
+// (a 4 x 4 register / row transpose puts (query r, dim g) on lane (r, g)); the image leaves after a barrier, scaled.
+// LDS per token: 64 bytes of planes + -lse, -delta + 32 bytes of dQ = 104; N = 512: 53 KB + 8 x 2.5 KB of dS tiles per
+// workgroup, two workgroups per CU.
+// =====================================================================================================================
+template <int KT, bool TAB>
+__global__ __launch_bounds__(512, 4) void k_attn_bwd_mh(const float* __restrict__ qkv, const float* __restrict__ o_hm,
+                                                        const float* __restrict__ do_hm, const float* __restrict__ lse,
+                                                        const float* __restrict__ table, float* __restrict__ tpart,
+                                                        float* __restrict__ dqkv, int N, int H, int HG, int Len_rt, int B) {
+  constexpr int BUF = 160;
+  extern __shared__ float4 smem4[];
+  float* sm = reinterpret_cast<float*>(smem4);
+  const int T = HG * N;
+  float* Qp = sm;
+  float* Kp = Qp + 4 * T;
+  float* Vp = Kp + 4 * T;
+  float* Dp = Vp + 4 * T;
+  float* Ls = Dp + 4 * T;
+  float* Dl = Ls + T;
+  // dQ image, (T, 4) DOUBLES in units of 1 / sc_dq: on gfx950 ds_add_f64 takes 8 LDS cycles per wave-instruction, ds_add_f32
+  // 192 (three per lane; tools/diag/lds_cost_probe.hip) - with fp32 adds this image was 48 of the 74 LDS cycles of a tile
+  double* dQb = reinterpret_cast<double*>(Dl + T);
+  unsigned* mx = reinterpret_cast<unsigned*>(dQb + 4 * T);   // [HG][4]: bits of max |dO|, |v|, |q log2 e|, |k|
+  float* Xw = reinterpret_cast<float*>(mx + 4 * HG);      // dS piece tiles, 4 BUF per wave
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+  float* Xb = Xw + wave * 4 * BUF;
+  const int Len = TAB ? Len_rt : 0;
+  const int ntab = TAB ? (2 * Len - 1) * H : 0;
+  float* tab = Xw + nw * 4 * BUF;
+  float* dtab = tab + ntab;
+  const int off = (N - Len) >> 1;
+  for (int i = threadIdx.x; i < ntab; i += blockDim.x) { tab[i] = table[i] * RAL_LOG2E; dtab[i] = 0.f; }
+  const int ngrp = H / HG;
+  const int wph = N / (16 * KT);                          // waves per head
+  const int hl = wave / wph, ks = (wave - hl * wph) * KT * 16;   // this wave's head of the group and first key
+  const int tb = hl * N;
+  const int tq = r >> 2, tp = r & 3;
+  const bool lowrows = r < 8;
+  auto meets = [&](int x0, int w) -> bool { return TAB && x0 < off + Len && x0 + w > off; };
+  for (int item = blockIdx.x; item < B * ngrp; item += gridDim.x) {
+    const int win = item / ngrp, h0 = (item - win * ngrp) * HG;
+    const float* base = qkv + (size_t)win * 3 * H * N * 4;
+    float* dbase = dqkv + (size_t)win * 3 * H * N * 4;
+    const size_t hq0 = ((size_t)win * H + h0) * N;
+    __syncthreads();   // every wave is done with the previous item
+    if (threadIdx.x < 4 * HG) mx[threadIdx.x] = 0u;
+    __syncthreads();
+    // ---- staging pass 1: fp32 quads into the plane slots, -lse, -delta (unscaled), the heads' maxima
+    {
+      const float4* gq = reinterpret_cast<const float4*>(base + (size_t)h0 * N * 4);
+      const float4* gk = reinterpret_cast<const float4*>(base + (size_t)(H + h0) * N * 4);
+      const float4* gv = reinterpret_cast<const float4*>(base + (size_t)(2 * H + h0) * N * 4);
+      const float4* gd = reinterpret_cast<const float4*>(do_hm) + hq0;
+      const float4* go = reinterpret_cast<const float4*>(o_hm) + hq0;
+      const int bd = blockDim.x;
+      for (int i0 = 0; i0 < T; i0 += 2 * bd) {      // (T is a multiple of 256: whole waves fall on one side of it)
+        const int ia = i0 + threadIdx.x, ib = ia + bd;
+        const bool hb = ib < T;
+        const int ic = hb ? ib : ia;
+        const float4 q0 = gq[ia], q1 = gq[ic], k0 = gk[ia], k1 = gk[ic], v0 = gv[ia], v1 = gv[ic];
+        const float4 d0 = gd[ia], d1 = gd[ic], o0 = go[ia], o1 = go[ic];
+        const float l0 = lse[hq0 + ia], l1 = lse[hq0 + ic];
+        auto one = [&](int t, float4 q, float4 k, float4 v, float4 d, float4 o, float l) {
+          reinterpret_cast<float4*>(Qp)[t] = q;
+          reinterpret_cast<float4*>(Kp)[t] = k;
+          reinterpret_cast<float4*>(Vp)[t] = v;
+          reinterpret_cast<float4*>(Dp)[t] = d;
+          reinterpret_cast<double4*>(dQb)[t] = make_double4(0., 0., 0., 0.);
+          Ls[t] = fmaf(-l, RAL_LOG2E, RAL_PSH); Dl[t] = -f4dot(d, o);
+          const float md = group_max<64>(f4amax(d)), mv = group_max<64>(f4amax(v));
+          const float mq = group_max<64>(f4amax(q)), mk = group_max<64>(f4amax(k));
+          if (lane == 0) {
+            unsigned* m4 = mx + 4 * (t / N);
+            atomicMax(m4, __float_as_uint(md)); atomicMax(m4 + 1, __float_as_uint(mv));
+            atomicMax(m4 + 2, __float_as_uint(mq * RAL_LOG2E)); atomicMax(m4 + 3, __float_as_uint(mk));
+          }
+        };
+        if (ia < T) one(ia, q0, k0, v0, d0, o0, l0);
+        if (hb) one(ib, q1, k1, v1, d1, o1, l1);
+      }
+    }
+    __syncthreads();
+    // ---- staging pass 2: every tensor times its head's power of two, split in place
+    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+      const unsigned* m4 = mx + 4 * (t / N);
+      const float cd = pow2_to(m4[0], 2), cv = pow2_to(m4[1], 0);
+      float cq, ck;
+      pair_balance(__uint_as_float(m4[2]), __uint_as_float(m4[3]), cq, ck);
+      const float4 q = reinterpret_cast<const float4*>(Qp)[t], k = reinterpret_cast<const float4*>(Kp)[t];
+      const float4 v = reinterpret_cast<const float4*>(Vp)[t], d = reinterpret_cast<const float4*>(Dp)[t];
+      reinterpret_cast<uint4*>(Qp)[t] = pair_quad(q, RAL_LOG2E * cq);
+      reinterpret_cast<uint4*>(Kp)[t] = pair_quad(k, ck);
+      reinterpret_cast<uint4*>(Vp)[t] = pair_quad(v, cv);
+      reinterpret_cast<uint4*>(Dp)[t] = pair_quad(d, cd);
+      Dl[t] *= cd * cv;
+    }
+    __syncthreads();
+    // the head's output factors
+    float sc_dq, sc_dk, sc_dv, sc_tab;
+    {
+      const unsigned* m4 = mx + 4 * hl;
+      const float cd = pow2_to(m4[0], 2), cv = pow2_to(m4[1], 0);
+      float cq, ck;
+      pair_balance(__uint_as_float(m4[2]), __uint_as_float(m4[3]), cq, ck);
+      sc_tab = RAL_PSH_INV * pow2_inv(cd) * pow2_inv(cv);
+      sc_dq = 0.5f * sc_tab * cq;
+      sc_dk = RAL_LN2 * sc_tab * ck;
+      sc_dv = RAL_PSH_INV * pow2_inv(cd);
+    }
+    if (hl < HG) {
+      const int head = h0 + hl;
+      const float* Qh = Qp + 4 * tb; const float* Kh = Kp + 4 * tb; const float* Vh = Vp + 4 * tb; const float* Dh = Dp + 4 * tb;
+      // this wave's keys: S / dP column operands and k^T planes, for the whole sweep
+      u32x2 Bk[KT], Bv[KT], kx[KT];
+      f32x4 acc[KT];
+      bool kin[KT];
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        const int k0 = ks + 16 * kt;
+        Bk[kt] = *reinterpret_cast<const u32x2*>(Kh + 4 * (k0 + r) + 2 * (g & 1));
+        Bv[kt] = *reinterpret_cast<const u32x2*>(Vh + 4 * (k0 + r) + 2 * (g & 1));
+        kx[kt] = tr_read((tp < 2 ? Kh : Vh) + 4 * (k0 + 4 * g + tq) + 2 * (tp & 1));
+        acc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        kin[kt] = meets(k0, 16);
+      }
+#pragma unroll 1
+      for (int q0 = 0; q0 < N; q0 += 16) {
+        const int qr = q0 + r, q4 = q0 + 4 * g;
+        const u32x2 Aq = *reinterpret_cast<const u32x2*>(Qh + 4 * qr + 2 * (g >> 1));
+        const u32x2 Ad = *reinterpret_cast<const u32x2*>(Dh + 4 * qr + 2 * (g >> 1));
+        const float4 l4 = *reinterpret_cast<const float4*>(Ls + tb + q4);
+        const float4 d4 = *reinterpret_cast<const float4*>(Dl + tb + q4);
+        const f32x4 cl = {l4.x, l4.y, l4.z, l4.w}, cdl = {d4.x, d4.y, d4.z, d4.w};
+        const u32x2 xt = tr_read((tp < 2 ? Dh : Qh) + 4 * (q4 + tq) + 2 * (tp & 1));
+        const u32x4 a8 = lowrows ? u32x4{xt[0], xt[1], 0u, 0u} : u32x4{0u, 0u, xt[0], xt[1]};
+        const bool qin = meets(q0, 16);
+        f32x4 dq = {0.f, 0.f, 0.f, 0.f};
+        auto dq_step = [&](int kp) {
+          const float* bp = Xb + (kp & 1) * 2 * BUF + (4 * g + tq) * 10 + 2 * tp;
+          const u32x2 b1 = tr_read(bp), b2 = tr_read(bp + BUF);
+          dq = mm32(u32x4{kx[kp][0], kx[kp][1], kx[kp][0], kx[kp][1]}, u32x4{b1[0], b1[1], b2[0], b2[1]}, dq);
+        };
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          const int k0 = ks + 16 * kt;
+          f32x4 s = mm16(Aq, Bk[kt], cl);
+          const f32x4 dp = mm16(Ad, Bv[kt], cdl);
+          float p[4];
+          unsigned ph1[2], ph2[2], sh1[2], sh2[2];
+          if (TAB && qin && kin[kt]) {
+            const int ki = k0 + r - off;
+            const bool kok = (unsigned)ki < (unsigned)Len;
+            const int rel0 = (q4 - off) - ki + Len - 1;
+            int e[4]; bool in[4]; float b[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              in[j] = kok && (unsigned)(q4 + j - off) < (unsigned)Len;
+              e[j] = min(max(rel0 + j, 0), 2 * Len - 2) * H + head;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = tab[e[j]];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) p[j] = __builtin_amdgcn_exp2f(s[j] + (in[j] ? b[j] : 0.f));
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (in[j]) atomicAdd(dtab + e[j], p[j] * dp[j] * sc_tab);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) p[j] = __builtin_amdgcn_exp2f(s[j]);
+          }
+          pair_of2(p[0], p[1], ph1[0], ph2[0]); pair_of2(p[2], p[3], ph1[1], ph2[1]);
+          pair_prod2(p[0], dp[0], p[1], dp[1], sh1[0], sh2[0]); pair_prod2(p[2], dp[2], p[3], dp[3], sh1[1], sh2[1]);
+          pair_settle(ph2[0], ph2[1], sh2[0], sh2[1]);
+          acc[kt] = mm32(a8, u32x4{ph1[0], ph1[1], sh1[0], sh1[1]}, acc[kt]);
+          acc[kt] = mm32(a8, u32x4{ph2[0], ph2[1], sh2[0], sh2[1]}, acc[kt]);
+          RAL_XB_FENCE();
+          float* bw = Xb + (kt & 1) * 2 * BUF + r * 10 + 2 * g;
+          *reinterpret_cast<u32x2*>(bw) = u32x2{sh1[0], sh1[1]};
+          *reinterpret_cast<u32x2*>(bw + BUF) = u32x2{sh2[0], sh2[1]};
+          RAL_XB_FENCE();
+          if (kt > 0) dq_step(kt - 1);
+        }
+        asm volatile("" ::: "memory");   // (see k_attn_bwd_m)
+        dq_step(KT - 1);
+        // lane (r, g) <- dQ^T rows g (h1 planes of k) and 4 + g (h2 planes) of query r; one add into the image
+        {
+          float v[4] = {dq[0], dq[1], dq[2], dq[3]};
+          rows_transpose4(v);
+          atomicAdd(dQb + 4 * (tb + q0 + r) + g, (double)(v[0] + v[1]));
+        }
+        asm volatile("" :: "v"(a8));
+      }
+      // dV (lane groups 0, 1) and dK (lane groups 2, 3) of the wave's key tiles
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        const int kr = ks + 16 * kt + r;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = swap16_add(acc[kt][j]);
+        const float sc = g < 2 ? sc_dv : sc_dk;
+        float* dst = dbase + (size_t)(g < 2 ? 2 : 1) * H * N * 4 + ((size_t)head * N + kr) * 4;
+        if ((g & 1) == 0) *reinterpret_cast<float4*>(dst) = make_float4(v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc);
+      }
+    }
+    __syncthreads();
+    // dQ leaves, scaled per head
+    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+      const unsigned* m4 = mx + 4 * (t / N);
+      float cq, ck;
+      pair_balance(__uint_as_float(m4[2]), __uint_as_float(m4[3]), cq, ck);
+      const float sc = 0.5f * RAL_PSH_INV * pow2_inv(pow2_to(m4[0], 2)) * pow2_inv(pow2_to(m4[1], 0)) * cq;
+      const double4 v = reinterpret_cast<const double4*>(dQb)[t];
+      reinterpret_cast<float4*>(dbase + (size_t)h0 * N * 4)[t] = make_float4((float)v.x * sc, (float)v.y * sc, (float)v.z * sc, (float)v.w * sc);
+    }
+  }
+  if constexpr (TAB) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < ntab; i += blockDim.x) tpart[(size_t)blockIdx.x * ntab + i] = dtab[i];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 static int attnm_mode() {   // RAL_ATTN_BWD_M=0: never
   static const int m = [] { const char* v = getenv("RAL_ATTN_BWD_M"); return v ? atoi(v) : 1; }();
@@ -338,6 +574,46 @@ size_t attn_bwd_m_scratch_floats(int N, int H, int Len, bool table, int B) {
   if (!table || !attn_bwd_m_takes(N, H, Len, table)) return 0;
   return (size_t)attnw_grid_max(N, H, B) * (size_t)((2 * Len - 1) * H);
 }
+// ---- long windows
+static int attnmh_kt(int N) { return N >= 1024 ? 8 : 4; }
+size_t attn_bwd_mh_lds(int N, int H, int hg, int Len) {
+  return ((size_t)26 * hg * N + 4 * hg + 8 * 4 * 160 + (Len > 0 ? (size_t)2 * (2 * Len - 1) * H : 0) + 4) * sizeof(float);
+}
+static int attnmh_hg(int N, int H) {   // heads per item: eight waves of KT key tiles each
+  const int wph = N / (16 * attnmh_kt(N));
+  return wph >= 8 ? 1 : 8 / wph;
+}
+bool attn_bwd_mh_takes(int N, int H, int Len, bool table) {
+  static const int on = [] { const char* v = getenv("RAL_ATTN_BWD_MH"); return v ? atoi(v) : 1; }();
+  if (!on || N < 256) return false;
+  const int kt = attnmh_kt(N), wph = N / (16 * kt);
+  if (N % (16 * kt) != 0 || (wph != 1 && wph != 2 && wph != 4 && wph != 8)) return false;
+  const int hg = attnmh_hg(N, H);
+  if (H % hg != 0) return false;
+  if (table && (2 * Len - 1) * H > 2048) return false;
+  return attn_bwd_mh_lds(N, H, hg, Len) <= 150 * 1024;
+}
+static int attnmh_grid(int N, int H, int B) {
+  const int items = B * (H / attnmh_hg(N, H));
+  return items < 1024 ? items : 1024;
+}
+size_t attn_bwd_mh_scratch_floats(int N, int H, int Len, bool table, int B) {
+  if (!table || !attn_bwd_mh_takes(N, H, Len, table)) return 0;
+  return (size_t)attnmh_grid(N, H, B) * (size_t)((2 * Len - 1) * H);
+}
+void launch_attn_bwd_mh(const float* qkv, const float* o_hm, const float* do_hm, const float* lse, const float* table,
+                        float* gtable, float* dqkv, float* tpart, int N, int H, int Len, int B, hipStream_t s) {
+  const int hg = attnmh_hg(N, H), grid = attnmh_grid(N, H, B), kt = attnmh_kt(N);
+  const size_t lds = attn_bwd_mh_lds(N, H, hg, Len);
+  const int ntab = table ? (2 * Len - 1) * H : 0;
+#define GO(k, tab) { RAL_SET_LDS((k_attn_bwd_mh<k, tab>), lds); \
+    k_attn_bwd_mh<k, tab><<<grid, 512, lds, s>>>(qkv, o_hm, do_hm, lse, table, tpart, dqkv, N, H, hg, table ? Len : 0, B); }
+  if (kt == 4) { if (table) GO(4, true) else GO(4, false) }
+  else { if (table) GO(8, true) else GO(8, false) }
+#undef GO
+  if (table) launch_attn_tpart_reduce(tpart, gtable, ntab, grid, s);
+}
+
 void launch_attn_bwd_m(const float* qkv, const float* o_hm, const float* do_hm, const float* lse, const float* table,
                        float* gtable, float* dqkv, float* tpart, int N, int H, int Len, int B, hipStream_t s) {
   const int hw = N >= 64 ? 1 : 64 / N, T = hw * N;

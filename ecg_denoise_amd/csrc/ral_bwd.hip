@@ -1914,6 +1914,10 @@ bool attn_bwd_uses_stat2(int N, int Len, bool table) {
 
 size_t attn_bwd_scratch_floats(int N, int H, int Len, bool table, int B) {
   if (attn_bwd_m_takes(N, H, Len, table)) return attn_bwd_m_scratch_floats(N, H, Len, table, B);
+  if (attn_bwd_mh_takes(N, H, Len, table)) {   // (the larger of its own and the fallback's: the f16 switch is per call)
+    const size_t a = attn_bwd_mh_scratch_floats(N, H, Len, table, B), b = attn_bwd_h_takes(N, H, Len, table) ? attn_bwd_h_scratch_floats(N, H, Len, table, B) : 0;
+    return a > b ? a : b;
+  }
   if (attn_bwd_w_takes(N, H, Len, table)) return attn_bwd_w_scratch_floats(N, H, Len, table, B);
   if (attn_bwd_h_takes(N, H, Len, table)) return attn_bwd_h_scratch_floats(N, H, Len, table, B);   // (what its f16 form needs)
   if (!attn_bwd_uses_stat2(N, Len, table)) return 0;
@@ -1927,6 +1931,11 @@ void launch_attn_bwd(const float* qkv, const float* o_hm, const float* do_hm, co
   if (f16 && attn_bwd_m_takes(N, H, Len, table != nullptr) &&
       (stat2 ? scratch_floats : 0) >= attn_bwd_m_scratch_floats(N, H, Len, table != nullptr, B)) {
     launch_attn_bwd_m(qkv, o_hm, do_hm, lse, table, gtable, dqkv, stat2, N, H, Len, B, s);
+    return;
+  }
+  if (f16 && attn_bwd_mh_takes(N, H, Len, table != nullptr) &&
+      (stat2 ? scratch_floats : 0) >= attn_bwd_mh_scratch_floats(N, H, Len, table != nullptr, B)) {
+    launch_attn_bwd_mh(qkv, o_hm, do_hm, lse, table, gtable, dqkv, stat2, N, H, Len, B, s);
     return;
   }
   // short windows: one wave per head, no workgroup barriers (ral_attn.hip)

@@ -118,6 +118,10 @@ bool attn_bwd_m_takes(int N, int H, int Len, bool table);
 size_t attn_bwd_m_scratch_floats(int N, int H, int Len, bool table, int B);
 void launch_attn_bwd_m(const float* qkv, const float* o_hm, const float* do_hm, const float* lse, const float* table,
                        float* gtable, float* dqkv, float* tpart, int N, int H, int Len, int B, hipStream_t s);
+bool attn_bwd_mh_takes(int N, int H, int Len, bool table);   // its workgroup form for N >= 256
+size_t attn_bwd_mh_scratch_floats(int N, int H, int Len, bool table, int B);
+void launch_attn_bwd_mh(const float* qkv, const float* o_hm, const float* do_hm, const float* lse, const float* table,
+                        float* gtable, float* dqkv, float* tpart, int N, int H, int Len, int B, hipStream_t s);
 size_t qkv_bwd_lds(int C, int N);
 void launch_qkv_bwd(int C, const float* dqkv, const float* x, const float* pe, const float* dx1, const float* extra,
                     const BlockP& w, const BlockP& wt, const float* ptbase, const void* wtt /* as launch_mlp_bwd */, unsigned* gmax,
