@@ -136,10 +136,10 @@ __global__ __launch_bounds__(256, RAL_ATTNM_WPE) void k_attn_bwd_m(const float* 
   const int ntab = TAB ? (2 * Len - 1) * H : 0;
   const int nwv = blockDim.x >> 6;
   float* tab = sm + nwv * WSZ;     // bias * log2(e), (2 Len - 1, H)
-  float* dtab = tab + ntab;
+  double* dtab = reinterpret_cast<double*>(tab + ((ntab + 1) & ~1));   // table gradient in DOUBLES (ds_add_f64: 8 LDS cycles; ds_add_f32: 192)
   const int off = (NT - Len) >> 1;
   if constexpr (TAB) {
-    for (int i = threadIdx.x; i < ntab; i += blockDim.x) { tab[i] = table[i] * RAL_LOG2E; dtab[i] = 0.f; }
+    for (int i = threadIdx.x; i < ntab; i += blockDim.x) { tab[i] = table[i] * RAL_LOG2E; dtab[i] = 0.; }
     __syncthreads();
   }
   auto meets = [&](int x0, int w) -> bool {
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256, RAL_ATTNM_WPE) void k_attn_bwd_m(const float* 
             for (int j = 0; j < 4; ++j) p[j] = __builtin_amdgcn_exp2f(s[j] + (in[j] ? b[j] : 0.f));
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-              if (in[j]) atomicAdd(dtab + e[j], p[j] * dp[j] * sc_tab);
+              if (in[j]) atomicAdd(dtab + e[j], (double)(p[j] * dp[j] * sc_tab));
           } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) p[j] = __builtin_amdgcn_exp2f(s[j]);
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256, RAL_ATTNM_WPE) void k_attn_bwd_m(const float* 
   }
   if constexpr (TAB) {
     __syncthreads();
-    for (int i = threadIdx.x; i < ntab; i += blockDim.x) tpart[(size_t)blockIdx.x * ntab + i] = dtab[i];
+    for (int i = threadIdx.x; i < ntab; i += blockDim.x) tpart[(size_t)blockIdx.x * ntab + i] = (float)dtab[i];
   }
 }
 
@@ -366,9 +366,9 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd_mh(const float* __restrict_
   const int Len = TAB ? Len_rt : 0;
   const int ntab = TAB ? (2 * Len - 1) * H : 0;
   float* tab = Xw + nw * 4 * BUF;
-  float* dtab = tab + ntab;
+  double* dtab = reinterpret_cast<double*>(tab + ((ntab + 1) & ~1));
   const int off = (N - Len) >> 1;
-  for (int i = threadIdx.x; i < ntab; i += blockDim.x) { tab[i] = table[i] * RAL_LOG2E; dtab[i] = 0.f; }
+  for (int i = threadIdx.x; i < ntab; i += blockDim.x) { tab[i] = table[i] * RAL_LOG2E; dtab[i] = 0.; }
   const int ngrp = H / HG;
   const int wph = N / (16 * KT);                          // waves per head
   const int hl = wave / wph, ks = (wave - hl * wph) * KT * 16;   // this wave's head of the group and first key
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd_mh(const float* __restrict_
             for (int j = 0; j < 4; ++j) p[j] = __builtin_amdgcn_exp2f(s[j] + (in[j] ? b[j] : 0.f));
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-              if (in[j]) atomicAdd(dtab + e[j], p[j] * dp[j] * sc_tab);
+              if (in[j]) atomicAdd(dtab + e[j], (double)(p[j] * dp[j] * sc_tab));
           } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) p[j] = __builtin_amdgcn_exp2f(s[j]);
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd_mh(const float* __restrict_
   }
   if constexpr (TAB) {
     __syncthreads();
-    for (int i = threadIdx.x; i < ntab; i += blockDim.x) tpart[(size_t)blockIdx.x * ntab + i] = dtab[i];
+    for (int i = threadIdx.x; i < ntab; i += blockDim.x) tpart[(size_t)blockIdx.x * ntab + i] = (float)dtab[i];
   }
 }
 
@@ -577,7 +577,7 @@ size_t attn_bwd_m_scratch_floats(int N, int H, int Len, bool table, int B) {
 // ---- long windows
 static int attnmh_kt(int N) { return N >= 1024 ? 8 : 4; }
 size_t attn_bwd_mh_lds(int N, int H, int hg, int Len) {
-  return ((size_t)26 * hg * N + 4 * hg + 8 * 4 * 160 + (Len > 0 ? (size_t)2 * (2 * Len - 1) * H : 0) + 4) * sizeof(float);
+  return ((size_t)26 * hg * N + 4 * hg + 8 * 4 * 160 + (Len > 0 ? (size_t)3 * (2 * Len - 1) * H + 2 : 0) + 4) * sizeof(float);
 }
 static int attnmh_hg(int N, int H) {   // heads per item: eight waves of KT key tiles each
   const int wph = N / (16 * attnmh_kt(N));
@@ -620,7 +620,7 @@ void launch_attn_bwd_m(const float* qkv, const float* o_hm, const float* do_hm, 
   const int ntask = B * H / hw;
   const int ntab = table ? (2 * Len - 1) * H : 0;
   const int nwv = 4;
-  const size_t lds = ((size_t)nwv * (T * 18 + 4 * 160) + 2 * ntab) * sizeof(float);
+  const size_t lds = ((size_t)nwv * (T * 18 + 4 * 160) + 3 * ntab + 2) * sizeof(float);
   int grid = 0;
   auto grid_of = [&](auto kern) {
     const int gmax = attnw_grid_max(N, H, B);          // (the scratch is sized for one workgroup per four tasks)
