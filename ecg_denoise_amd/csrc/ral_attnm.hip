@@ -21,8 +21,13 @@
 //     cycles): the two pipes are balanced, where the two-sweep form left the matrix pipe idle.
 // Range.  p is evaluated as 2^8 p (the shift sits in the C operand of the S tile, next to -lse) so that probabilities down to
 // 2^-22 keep 22 bits in their pair; dO and v are multiplied by one power of two per task (largest magnitudes into [4, 8) and
-// [1, 2)) so that |2^8 p (dP - delta)| < 2^15 for ANY inputs; q and k are balanced against each other (pair_balance).  All
-// factors are powers of two and leave with the results.  Non-finite inputs give non-finite outputs of their head.
+// [1, 2)) so that |2^8 p (dP - delta)| < 2^15 for ANY inputs.  q log2 e and k each get THEIR OWN power of two (largest magnitude
+// into [8, 16)): their planes are also the operands of the dK / dQ products, where a pair of a small number (second piece
+// subnormal in fp16) would carry 14 bits - with q and k merely balanced against each other (as the two-sweep kernels do,
+// which contract with fp32 quads) dq / dk of a head with |scores| ~ 1e-6 were off by 2.5e-5.  The score tile therefore comes
+// out as (cq ck) (s - lse + 8) - its C operand carries the same factor - and is multiplied by 1 / (cq ck) on the way to the
+// exponential (four v_mul_f32 per tile).  All factors are powers of two and leave with the results.  Non-finite inputs give
+// non-finite outputs of their head.
 #include "ral_device.hpp"
 #include "ral_kernels.hpp"
 #include <stdio.h>
@@ -86,10 +91,13 @@ RAL_DEV u32x2 tr_read(const float* a) {
   return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a)));
 }
 // power of two that puts a magnitude with the bits `maxbits` into [2^e, 2^(e+1)) (capped at 2^60), and its inverse
-RAL_DEV float pow2_to(unsigned maxbits, int e) {
+RAL_DEV float pow2_to(unsigned maxbits, int e, int cap = 60) {
   const int f = 254 + e - (int)(maxbits >> 23);
-  return maxbits == 0u ? 1.0f : __uint_as_float((unsigned)(f < 187 ? (f > 1 ? f : 1) : 187) << 23);
+  return maxbits == 0u ? 1.0f : __uint_as_float((unsigned)(f < 127 + cap ? (f > 1 ? f : 1) : 127 + cap) << 23);
 }
+// the powers of two of q log2 e and k (bits of their largest magnitudes): planes in [8, 16), capped at 2^50 each so that the
+// C operand of the score tile, (cq ck) (8 - lse log2 e), stays finite
+RAL_DEV void qk_scales(unsigned mqbits, unsigned mkbits, float& cq, float& ck) { cq = pow2_to(mqbits, 3, 50); ck = pow2_to(mkbits, 3, 50); }
 RAL_DEV float pow2_inv(float p) { return __uint_as_float((254u << 23) - __float_as_uint(p)); }
 
 RAL_DEV float f4amax(float4 v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
@@ -147,8 +155,8 @@ __global__ __launch_bounds__(256, RAL_ATTNM_WPE) void k_attn_bwd_m(const float* 
   };
   const int stride = gridDim.x * nwv;
   int task = blockIdx.x * nwv + wave;
-  // per-task factors (wave-uniform): results x these
-  float sc_dq = 1.f, sc_dk = 1.f, sc_dv = 1.f, sc_tab = 1.f;
+  // per-task factors (wave-uniform): results x these; su = 1 / (cq ck) brings the score tile back to log2 units
+  float sc_dq = 1.f, sc_dk = 1.f, sc_dv = 1.f, sc_tab = 1.f, su = 1.f;
 
   float4 pq, pk, pv, pd, po;
   float pl;
@@ -168,18 +176,19 @@ __global__ __launch_bounds__(256, RAL_ATTNM_WPE) void k_attn_bwd_m(const float* 
     reinterpret_cast<uint4*>(Kp)[t] = pair_quad(k, ck);
     reinterpret_cast<uint4*>(Vp)[t] = pair_quad(v, cv);
     reinterpret_cast<uint4*>(Dp)[t] = pair_quad(d, cd);
-    Ls[t] = fmaf(-l, RAL_LOG2E, RAL_PSH);
+    Ls[t] = fmaf(-l, RAL_LOG2E, RAL_PSH) * (cq * ck);
     Dl[t] = -f4dot(d, o) * (cd * cv);
   };
   // the task's powers of two; sets the output factors
   auto scales = [&](float mq, float mk, float mv, float md, float& cq, float& ck, float& cv, float& cd) {
-    pair_balance(group_max<64>(mq) * RAL_LOG2E, group_max<64>(mk), cq, ck);
+    qk_scales(__float_as_uint(group_max<64>(mq) * RAL_LOG2E), __float_as_uint(group_max<64>(mk)), cq, ck);
     cv = pow2_to(__float_as_uint(group_max<64>(mv)), 0);
     cd = pow2_to(__float_as_uint(group_max<64>(md)), 2);
     const float icd = pow2_inv(cd), icv = pow2_inv(cv);
+    su = pow2_inv(cq) * pow2_inv(ck);
     sc_tab = RAL_PSH_INV * icd * icv;        // dS = sc_tab dS'
-    sc_dq = 0.5f * sc_tab * cq;              // q = 0.5 (h Wq^T + b); the k planes carried ck = 1 / cq
-    sc_dk = RAL_LN2 * sc_tab * ck;           // the q planes carried log2(e) cq
+    sc_dq = 0.5f * sc_tab * pow2_inv(ck);    // q = 0.5 (h Wq^T + b); the k planes carried ck
+    sc_dk = RAL_LN2 * sc_tab * pow2_inv(cq); // the q planes carried log2(e) cq
     sc_dv = RAL_PSH_INV * icd;
   };
   auto request = [&](int tk) {
@@ -257,8 +266,10 @@ __global__ __launch_bounds__(256, RAL_ATTNM_WPE) void k_attn_bwd_m(const float* 
           const int kr = (k0 + SH + r) & MSK;        // this lane's key: the column of the S tile
           const u32x2 Bk = *reinterpret_cast<const u32x2*>(Kh + 4 * kr + 2 * (g & 1));
           const u32x2 Bv = *reinterpret_cast<const u32x2*>(Vh + 4 * kr + 2 * (g & 1));
-          f32x4 s = mm16(Aq, Bk, cl);                // S - lse + 8 (log2 units)   [query 4g+j][key r]
+          f32x4 s = mm16(Aq, Bk, cl);                // (cq ck) (S - lse + 8), log2 units   [query 4g+j][key r]
           const f32x4 dp = mm16(Ad, Bv, cdl);        // (dP - delta) cd cv
+#pragma unroll
+          for (int j = 0; j < 4; ++j) s[j] *= su;
           float p[4];
           unsigned ph1[2], ph2[2], sh1[2], sh2[2];
           if (TAB && qin && meets(k0, 16)) {
@@ -405,7 +416,7 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd_mh(const float* __restrict_
           reinterpret_cast<float4*>(Vp)[t] = v;
           reinterpret_cast<float4*>(Dp)[t] = d;
           reinterpret_cast<double4*>(dQb)[t] = make_double4(0., 0., 0., 0.);
-          Ls[t] = fmaf(-l, RAL_LOG2E, RAL_PSH); Dl[t] = -f4dot(d, o);
+          Ls[t] = fmaf(-l, RAL_LOG2E, RAL_PSH); Dl[t] = -f4dot(d, o);   // (both times their factors in pass 2)
           const float md = group_max<64>(f4amax(d)), mv = group_max<64>(f4amax(v));
           const float mq = group_max<64>(f4amax(q)), mk = group_max<64>(f4amax(k));
           if (lane == 0) {
@@ -424,7 +435,7 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd_mh(const float* __restrict_
       const unsigned* m4 = mx + 4 * (t / N);
       const float cd = pow2_to(m4[0], 2), cv = pow2_to(m4[1], 0);
       float cq, ck;
-      pair_balance(__uint_as_float(m4[2]), __uint_as_float(m4[3]), cq, ck);
+      qk_scales(m4[2], m4[3], cq, ck);
       const float4 q = reinterpret_cast<const float4*>(Qp)[t], k = reinterpret_cast<const float4*>(Kp)[t];
       const float4 v = reinterpret_cast<const float4*>(Vp)[t], d = reinterpret_cast<const float4*>(Dp)[t];
       reinterpret_cast<uint4*>(Qp)[t] = pair_quad(q, RAL_LOG2E * cq);
@@ -432,18 +443,19 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd_mh(const float* __restrict_
       reinterpret_cast<uint4*>(Vp)[t] = pair_quad(v, cv);
       reinterpret_cast<uint4*>(Dp)[t] = pair_quad(d, cd);
       Dl[t] *= cd * cv;
+      Ls[t] *= cq * ck;
     }
     __syncthreads();
     // the head's output factors
-    float sc_dq, sc_dk, sc_dv, sc_tab;
+    float sc_dk, sc_dv, sc_tab, su;
     {
-      const unsigned* m4 = mx + 4 * hl;
+      const unsigned* m4 = mx + 4 * (hl < HG ? hl : 0);
       const float cd = pow2_to(m4[0], 2), cv = pow2_to(m4[1], 0);
       float cq, ck;
-      pair_balance(__uint_as_float(m4[2]), __uint_as_float(m4[3]), cq, ck);
+      qk_scales(m4[2], m4[3], cq, ck);
+      su = pow2_inv(cq) * pow2_inv(ck);
       sc_tab = RAL_PSH_INV * pow2_inv(cd) * pow2_inv(cv);
-      sc_dq = 0.5f * sc_tab * cq;
-      sc_dk = RAL_LN2 * sc_tab * ck;
+      sc_dk = RAL_LN2 * sc_tab * pow2_inv(cq);
       sc_dv = RAL_PSH_INV * pow2_inv(cd);
     }
     if (hl < HG) {
@@ -484,6 +496,8 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd_mh(const float* __restrict_
           const int k0 = ks + 16 * kt;
           f32x4 s = mm16(Aq, Bk[kt], cl);
           const f32x4 dp = mm16(Ad, Bv[kt], cdl);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) s[j] *= su;
           float p[4];
           unsigned ph1[2], ph2[2], sh1[2], sh2[2];
           if (TAB && qin && kin[kt]) {
@@ -546,8 +560,8 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd_mh(const float* __restrict_
     for (int t = threadIdx.x; t < T; t += blockDim.x) {
       const unsigned* m4 = mx + 4 * (t / N);
       float cq, ck;
-      pair_balance(__uint_as_float(m4[2]), __uint_as_float(m4[3]), cq, ck);
-      const float sc = 0.5f * RAL_PSH_INV * pow2_inv(pow2_to(m4[0], 2)) * pow2_inv(pow2_to(m4[1], 0)) * cq;
+      qk_scales(m4[2], m4[3], cq, ck);
+      const float sc = 0.5f * RAL_PSH_INV * pow2_inv(pow2_to(m4[0], 2)) * pow2_inv(pow2_to(m4[1], 0)) * pow2_inv(ck);
       const double4 v = reinterpret_cast<const double4*>(dQb)[t];
       reinterpret_cast<float4*>(dbase + (size_t)h0 * N * 4)[t] = make_float4((float)v.x * sc, (float)v.y * sc, (float)v.z * sc, (float)v.w * sc);
     }
