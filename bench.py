@@ -267,11 +267,56 @@ def launcher_dry_run(a):
         sys.exit(3)
     if a.test_hang_rank == rank:          # a rank that never finishes: the launcher must end it when another one fails
         time.sleep(3600)
+    facts = collective_facts(dist, world, rank, int(os.environ.get("LOCAL_RANK", "0")), "gloo" if world > 1 else None, None)
     if rank == 0:
+        B, G = batch_plan(a, world)
         print(json.dumps({"dry_run": True, "n_gpus": world, "local_rank": int(os.environ.get("LOCAL_RANK", "0")),
-                          "rank_sum": t.item(), "steps": a.steps, "warmup": a.warmup}))
+                          "rank_sum": t.item(), "steps": a.steps, "warmup": a.warmup,
+                          "batch_per_gpu": B, "global_batch": G, "config3_leg": config3_batch(a, world), "collective": facts}))
     if world > 1:
         dist.destroy_process_group()
+
+
+def batch_plan(a, world):
+    """-> (windows per GPU, global batch).  `--global-batch G` fixes the job's batch (G / world per GPU: strong scaling);
+    otherwise `--batch` (per GPU) or the config's stated per-GPU batch (weak scaling: 2048 windows per GPU for RA-LENet and
+    U-Net, 256 for newrale)."""
+    default = 256 if a.config == "newrale" else 2048
+    if a.global_batch:
+        if a.global_batch % world:
+            raise SystemExit(f"--global-batch {a.global_batch} is not a multiple of the {world} ranks")
+        return a.global_batch // world, a.global_batch
+    B = a.batch or default
+    return B, B * world
+
+
+def config3_batch(a, world):
+    """BASELINE config 3 is RA-LENet at global batch 8192 on 8 GPUs (8 x 1024 windows; SURVEY 8d 'C2').  The headline line
+    keeps 2048 windows per GPU at every N (weak scaling, so that the driver's per-N values are comparable); at --gpus 8 the
+    same process ALSO times config 3's own shape and reports it as `config3` - per-GPU batch of that leg, or None."""
+    if a.config == "ralenet" and world == 8 and not a.batch and not a.global_batch and not a.leads and not a.L:
+        return 1024
+    return None
+
+
+def collective_facts(dist, world, rank, local, backend, trainer):
+    """What proves that N ranks on N devices took part: backend, RCCL version, the world size as torch.distributed sees it,
+    the device index of every rank (gathered) and the collectives one train step issues (counted on this rank)."""
+    if world <= 1:
+        return None
+    import torch
+    devs = [None] * world
+    dist.all_gather_object(devs, {"rank": rank, "local_rank": local, "host": socket.gethostname(),
+                                   "device": (torch.cuda.current_device() if torch.cuda.is_available() else None)})
+    ver = None
+    try:
+        if backend == "nccl":
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:
+        ver = None
+    return {"backend": dist.get_backend(), "rccl_version": ver, "world_size": dist.get_world_size(), "ranks": devs,
+            "collectives_per_step": getattr(trainer, "collectives_last_step", None) if trainer is not None else None,
+            "metric_collectives_per_step": getattr(trainer, "metric_collectives_last_step", None) if trainer is not None else None}
 
 
 def build_workload(a, dev, rank):
@@ -280,20 +325,22 @@ def build_workload(a, dev, rank):
     from ecg_denoise_amd import NewRALE, RALENet, UNet
     from ecg_denoise_amd.dp import DataParallelTrainer, HipEngineAdapter, NewRALEEngineAdapter, UNetEngineAdapter
     g = torch.Generator().manual_seed(2023 + rank)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    Bplan = a.batch_override or batch_plan(a, world)[0]
     if a.config == "newrale":
-        B, leads, L = a.batch or 256, 12, a.L or 1024
+        B, leads, L = Bplan, 12, a.L or 1024
         inner = RALENet(a.variant, leads=2, L=L, max_batch=B, train=True, device=dev, seed=2023)
         model = NewRALE(inner, seed=2024)
         eng = NewRALEEngineAdapter(model)
         text = (f"newrale (12-lead adapter around a frozen RA-LENet '{a.variant}', ralenet_12leads.py:680-709) train step, "
                 f"12-lead {L}-sample windows, batch {B}/GPU")
     elif a.config == "unet":
-        B, leads, L = a.batch or 2048, a.leads or 2, a.L or 512
+        B, leads, L = Bplan, a.leads or 2, a.L or 512
         model = inner_none = UNet(leads=leads, L=L, max_batch=B, train=True, device=dev, seed=2023)
         inner, eng = None, UNetEngineAdapter(model)
         text = f"U-Net (UNet.py:96-141) train step, {leads}-lead {L}-sample windows, batch {B}/GPU"
     else:
-        B, leads, L = a.batch or 2048, a.leads or 1, a.L or 512
+        B, leads, L = Bplan, a.leads or 1, a.L or 512
         model = inner = RALENet(a.variant, leads=leads, L=L, max_batch=B, train=True, device=dev, seed=2023)
         eng = HipEngineAdapter(model)
         text = f"RA-LENet '{a.variant}' train step, {leads}-lead {L}-sample windows, batch {B}/GPU"
@@ -311,6 +358,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="ralenet", choices=("ralenet", "unet", "newrale"))
     ap.add_argument("--batch", type=int, default=0, help="windows per GPU (default: the config's stated batch)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="windows of the whole job (G / N per GPU: strong scaling); default: the per-GPU batch at every N (weak)")
     ap.add_argument("--leads", type=int, default=0)
     ap.add_argument("--L", type=int, default=0)
     ap.add_argument("--variant", default="full")
@@ -323,9 +372,11 @@ def main():
     # test hooks (tests/test_gpu_dp_procs.py, tests/test_bench_cpu.py): never part of a measurement
     ap.add_argument("--test-share-gpu", action="store_true", help="every rank on device 0 (a box with one GPU)")
     ap.add_argument("--test-backend", default="nccl", help="collective backend; gloo when ranks share a device")
+    ap.add_argument("--test-config3-batch", type=int, default=0, help="run the config-3 leg at this per-GPU batch whatever N is")
     ap.add_argument("--test-fail-rank", type=int, default=-1)
     ap.add_argument("--test-hang-rank", type=int, default=-1)
     a = ap.parse_args()
+    a.batch_override = 0
 
     # N > 1 and nobody started the ranks for us: start them (before torch is imported or the GPU touched)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -474,13 +525,38 @@ def main():
         infer_graph = B * world * a.steps / tg.item()
         model.train()
 
+    # what proves N ranks on N devices took part (every rank: it gathers)
+    facts = collective_facts(dist, world, rank, local, a.test_backend if world > 1 else None, trainer)
+
+    # BASELINE config 3's own shape (global batch 8192 = 8 x 1024) next to the weak-scaling headline, in the same job
+    config3 = None
+    b3 = config3_batch(a, world) or (a.test_config3_batch if world > 1 else 0)
+    if b3:
+        a.batch_override = b3
+        W3 = build_workload(a, dev, rank)
+        for _ in range(max(2, a.warmup)):
+            W3["trainer"].train_step(W3["x"], W3["tgt"])
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            W3["trainer"].train_step(W3["x"], W3["tgt"])
+        sync()
+        t3 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t3, op=dist.ReduceOp.MAX)
+        config3 = {"workload": W3["text"] + f"; global batch {b3 * world} = {world} x {b3} (BASELINE configs[2])",
+                   "global_batch": b3 * world, "batch_per_gpu": b3, "value": round(b3 * world * a.steps / t3.item(), 1),
+                   "unit": "windows/s", "ms_per_step": round(t3.item() / a.steps * 1e3, 3), "steps": a.steps}
+        del W3
+        a.batch_override = 0
+
     if rank == 0:
         res = {
             "metric": f"ECG windows/sec ({L}-sample, bs{B}) train step; inference forward in infer_*_windows_per_s",
             "value": round(B * world * a.steps / dt, 1), "unit": "windows/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "median_ms_per_step_hipevent": round(median_ms, 3) if median_ms else None,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if a.global_batch else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "arithmetic": "fp32 tensors and accumulators; the Linear layers of the two wide levels (C = 64, 128: forward, "
                           "data-gradient and weight-gradient products), the MLP forward of the narrow levels (C = 8, 16, 32) and the attention "
@@ -488,9 +564,13 @@ def main():
                           "f16 matrix cores (x = h1 + h2, ~2^-22 relative; operands brought into range by powers of two per "
                           "weight matrix / token / head, nothing clamped); everything else on the fp32 MFMA / vector ALU.  "
                           "fp32_mfma: the same step with ral_set_option f16_split=0 (every product on the fp32 MFMA)",
-            "config": {"workload": W["text"], "global_batch": B * world, "parallelism": f"dp{world}", "sync_bn": True},
+            "config": {"workload": W["text"], "global_batch": B * world, "batch_per_gpu": B, "parallelism": f"dp{world}", "sync_bn": True},
             "final_loss": round(loss, 6),
         }
+        if facts is not None:
+            res["collective"] = facts
+        if config3 is not None:
+            res["config3"] = config3
         if inner is not None:
             ksec = ms.value * 1e-3
             ach = kind_work(a.kind, Lk, Bk) * rl_steps / ksec / 1e12 if ksec > 0 else 0.0

@@ -244,7 +244,10 @@ class DataParallelTrainer:
     one rank.
 
     `sync_bn`: True = BatchNorm statistics of the global batch (the N-rank step IS the single-process step on the
-    concatenated batch); False = every rank's own statistics (no BatchNorm collective).
+    concatenated batch); False = every rank's own statistics (no BatchNorm collective).  With False the BatchNorm RUNNING
+    statistics of the ranks drift apart (DistributedDataParallel would re-broadcast rank 0's buffers every forward; this
+    trainer does not): call `sync_state()` before evaluating or writing a checkpoint, otherwise both depend on the rank.
+    The gradient of a step then differs from the global-batch gradient by ~1e-2 of its norm (tests/test_dp_gloo.py).
     `log_every`: the loss / SNR / RMSE means of the last `log_every` steps are all-reduced once per interval on the
     communication stream; `metrics()` returns them.  With `log_every == 1` (default) `train_step` also waits for the
     reduction and returns the global loss, as the reference loop prints it every step (denoise_train.py:54-64); with a
@@ -254,6 +257,8 @@ class DataParallelTrainer:
         self.e, self.group, self.sync_bn, self.log_every = engine, group, sync_bn, max(1, int(log_every))
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._hist, self._pending, self._last = [], None, None
+        # collectives issued by the last train_step: data path (BatchNorm sums, gradient buckets) / metric reductions
+        self._ncoll, self._nmet, self.collectives_last_step, self.metric_collectives_last_step = 0, 0, None, None
         if sync_state:
             self.sync_state()
 
@@ -271,6 +276,7 @@ class DataParallelTrainer:
 
     def _allreduce(self, t):
         if self.world > 1:
+            self._ncoll += 1
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     def _comm_stream(self):
@@ -303,9 +309,14 @@ class DataParallelTrainer:
         self._hist = []
         work = None
         if self.world > 1:
+            self._nmet += 1
+            if self._pending is not None and self._pending[1] is not None:
+                self._pending[1].wait()          # a reduction nobody asked for (metrics() not called): finish it before its buffer goes
             comm = self._comm_stream()
             if comm is not None:
                 comm.wait_stream(torch.cuda.current_stream(buf.device))
+                if buf.is_cuda:
+                    buf.record_stream(comm)      # allocated on the compute stream, used on the communication stream
                 with torch.cuda.stream(comm):
                     work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             else:
@@ -325,6 +336,7 @@ class DataParallelTrainer:
 
     def _finish(self, loss, snr, rmse, pred, G):
         logged = self._log(loss, snr, rmse, G)
+        self.collectives_last_step, self.metric_collectives_last_step, self._ncoll, self._nmet = self._ncoll, self._nmet, 0, 0
         if self.log_every == 1 and logged is not None:
             return {"loss": self.metrics()["loss"].reshape(1), "loss_is_global": True, "snr": snr, "rmse": rmse, "pred": pred}
         return {"loss": loss * self.world, "loss_is_global": self.world == 1, "snr": snr, "rmse": rmse, "pred": pred}
@@ -362,6 +374,7 @@ class DataParallelTrainer:
             (o0, n0), (o1, n1) = e.grad_buckets()
             comm = e.bucket_stream()
             e.bucket_wait(1, comm)
+            self._ncoll += 1
             if comm is not None:
                 with torch.cuda.stream(comm):
                     early = dist.all_reduce(e.grads[o1:o1 + n1], op=dist.ReduceOp.SUM, group=self.group, async_op=True)

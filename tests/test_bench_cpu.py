@@ -23,7 +23,28 @@ def test_self_launch_two_ranks_relays_rank0_line():
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]        # (gloo prints its own connection notes)
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
-    assert d == {"dry_run": True, "n_gpus": 2, "local_rank": 0, "rank_sum": 3.0, "steps": 7, "warmup": 2}
+    col = d.pop("collective")
+    assert d == {"dry_run": True, "n_gpus": 2, "local_rank": 0, "rank_sum": 3.0, "steps": 7, "warmup": 2,
+                 "batch_per_gpu": 2048, "global_batch": 4096, "config3_leg": None}
+    # the collective facts a multi-GPU line carries: backend, world size as torch.distributed sees it, one entry per rank
+    assert col["backend"] == "gloo" and col["world_size"] == 2 and col["rccl_version"] is None
+    assert [(r["rank"], r["local_rank"]) for r in col["ranks"]] == [(0, 0), (1, 1)]
+
+
+def test_global_batch_is_split_over_the_ranks_and_config3_runs_at_eight():
+    """`--global-batch G`: G / N windows per GPU (strong scaling); BASELINE config 3 (8192 = 8 x 1024) is a second leg of the
+    default --gpus 8 run, next to the 2048-per-GPU weak-scaling headline"""
+    r = _run(["--gpus", "2", "--global-batch", "8192", "--dry-run-launcher"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert (d["batch_per_gpu"], d["global_batch"], d["config3_leg"]) == (4096, 8192, None)
+    r = _run(["--gpus", "2", "--global-batch", "8191", "--dry-run-launcher"])
+    assert r.returncode != 0
+    r = _run(["--gpus", "8", "--dry-run-launcher"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert (d["n_gpus"], d["batch_per_gpu"], d["global_batch"], d["config3_leg"]) == (8, 2048, 16384, 1024)
+    assert d["collective"]["world_size"] == 8 and len(d["collective"]["ranks"]) == 8
 
 
 def test_self_launch_fails_when_a_rank_fails():

@@ -89,11 +89,23 @@ def test_two_processes_equal_one_process(kind, tmp_path):
 def test_bench_two_ranks_on_one_gpu():
     """bench.py --gpus 2 end to end (self-launch, replica broadcast, timed region with barriers, MAX over ranks, the
     inference leg), the two ranks sharing this box's GPU over gloo: one JSON line with n_gpus = 2 and the job total"""
-    d = _bench(["--batch", "256"])
+    d = _bench(["--batch", "256", "--test-config3-batch", "64"])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 512 and d["scaling"] == "weak"
     assert d["value"] > 0 and abs(d["value"] - 512 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
     assert np.isfinite(d["final_loss"]) and d["infer_windows_per_s"] > 0
     assert d["roofline"]["kernel"] == "attn_bwd" and d["roofline"]["frac"] > 0
+    # the collective facts of a multi-rank line, and the second leg on another global batch (config 3's place at --gpus 8)
+    col = d["collective"]
+    assert col["backend"] == "gloo" and col["world_size"] == 2 and [r["device"] for r in col["ranks"]] == [0, 0]
+    assert col["collectives_per_step"] == 4 and col["metric_collectives_per_step"] == 1      # 2 BatchNorm sums + 2 gradient buckets
+    c3 = d["config3"]
+    assert c3["global_batch"] == 128 and c3["batch_per_gpu"] == 64 and c3["value"] > 0
+
+
+def test_bench_global_batch_two_ranks_on_one_gpu():
+    """`--global-batch G` splits G over the ranks (strong scaling)"""
+    d = _bench(["--global-batch", "256", "--no-infer"])
+    assert d["config"]["global_batch"] == 256 and d["config"]["batch_per_gpu"] == 128 and d["scaling"] == "strong"
 
 
 def _bench(extra):
