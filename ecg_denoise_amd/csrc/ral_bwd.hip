@@ -14,9 +14,12 @@
 
 RAL_STAMPS_DEFINE(ral_debug_stamps)
 
-// LDS float4 atomic accumulate of per-channel vectors: red[c..c+3] += v
-RAL_DEV void lds_add4(float* red, int c, float4 v) {
-  atomicAdd(red + c, v.x); atomicAdd(red + c + 1, v.y); atomicAdd(red + c + 2, v.z); atomicAdd(red + c + 3, v.w);
+// LDS atomic accumulate of per-channel vectors: red[c..c+3] += v.  The block reduction of the small gradients runs in DOUBLES:
+// a full-wave ds_add_f32 takes 192 LDS cycles on gfx950 (three per active lane), ds_add_f64 eight (tools/diag/lds_cost_probe.hip;
+// with fp32 this flush was 8 waves x 8 adds x 192 = 12 000 LDS cycles at the end of every workgroup, all workgroups of a CU
+// at once).  `redd` sits at the base of the dynamic LDS, whose tiles are dead by then.
+RAL_DEV void lds_add4(double* red, int c, float4 v) {
+  atomicAdd(red + c, (double)v.x); atomicAdd(red + c + 1, (double)v.y); atomicAdd(red + c + 2, (double)v.z); atomicAdd(red + c + 3, (double)v.w);
 }
 
 // =================================================================================
@@ -159,22 +162,23 @@ __global__ __launch_bounds__(512) void k_mlp_bwd(const float* __restrict__ dx2, 
     RAL_STAMP_AT(11);
   }
   // ---- flush the small gradients ----
-  for (int i = threadIdx.x; i < 2 * C + 4; i += blockDim.x) red[i] = 0.f;
+  double* redd = reinterpret_cast<double*>(smem4);
+  for (int i = threadIdx.x; i < 2 * C + 4; i += blockDim.x) redd[i] = 0.;
   __syncthreads();
-  lds_add4(red, cq, dgam);
-  lds_add4(red, C + cq, dbet);
+  lds_add4(redd, cq, dgam);
+  lds_add4(redd, C + cq, dbet);
   if (le) {
     const float s0 = group_sum<64>(gle0), s1 = group_sum<64>(gle1), s2 = group_sum<64>(gle2);
-    if ((threadIdx.x & 63) == 0) { atomicAdd(red + 2 * C, s0); atomicAdd(red + 2 * C + 1, s1); atomicAdd(red + 2 * C + 2, s2); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(redd + 2 * C, (double)s0); atomicAdd(redd + 2 * C + 1, (double)s1); atomicAdd(redd + 2 * C + 2, (double)s2); }
   }
   __syncthreads();
   if ((int)threadIdx.x < C) {
 #ifndef RAL_NOVECATOMICS   // (diagnostic build: what the same-address chains of the small-vector gradients cost)
-    atomicAdd(gr.ln2w + threadIdx.x, red[threadIdx.x]);
-    atomicAdd(gr.ln2b + threadIdx.x, red[C + threadIdx.x]);
+    atomicAdd(gr.ln2w + threadIdx.x, (float)redd[threadIdx.x]);
+    atomicAdd(gr.ln2b + threadIdx.x, (float)redd[C + threadIdx.x]);
 #endif
   }
-  if (le && threadIdx.x < 3) atomicAdd(gr.le + threadIdx.x, red[2 * C + threadIdx.x]);
+  if (le && threadIdx.x < 3) atomicAdd(gr.le + threadIdx.x, (float)redd[2 * C + threadIdx.x]);
 }
 
 // =================================================================================
@@ -380,20 +384,21 @@ __global__ __launch_bounds__(512, 4) void k_mlp_bwd_h(const float* __restrict__ 
     __syncthreads();
   }
   // ---- flush the small gradients ----
-  for (int i = threadIdx.x; i < 2 * C + 4; i += blockDim.x) red[i] = 0.f;
+  double* redd = reinterpret_cast<double*>(smem4);
+  for (int i = threadIdx.x; i < 2 * C + 4; i += blockDim.x) redd[i] = 0.;
   __syncthreads();
-  lds_add4(red, cq, dgam);
-  lds_add4(red, C + cq, dbet);
+  lds_add4(redd, cq, dgam);
+  lds_add4(redd, C + cq, dbet);
   if (le) {
     const float s0 = group_sum<64>(gle0), s1 = group_sum<64>(gle1), s2 = group_sum<64>(gle2);
-    if ((threadIdx.x & 63) == 0) { atomicAdd(red + 2 * C, s0); atomicAdd(red + 2 * C + 1, s1); atomicAdd(red + 2 * C + 2, s2); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(redd + 2 * C, (double)s0); atomicAdd(redd + 2 * C + 1, (double)s1); atomicAdd(redd + 2 * C + 2, (double)s2); }
   }
   __syncthreads();
   if ((int)threadIdx.x < C) {
-    atomicAdd(gr.ln2w + threadIdx.x, red[threadIdx.x]);
-    atomicAdd(gr.ln2b + threadIdx.x, red[C + threadIdx.x]);
+    atomicAdd(gr.ln2w + threadIdx.x, (float)redd[threadIdx.x]);
+    atomicAdd(gr.ln2b + threadIdx.x, (float)redd[C + threadIdx.x]);
   }
-  if (le && threadIdx.x < 3) atomicAdd(gr.le + threadIdx.x, red[2 * C + threadIdx.x]);
+  if (le && threadIdx.x < 3) atomicAdd(gr.le + threadIdx.x, (float)redd[2 * C + threadIdx.x]);
   if (gmax) {   // one atomic per workgroup and tensor
     __syncthreads();
     if (threadIdx.x < 3) smD[threadIdx.x] = 0u;
@@ -593,22 +598,23 @@ __global__ __launch_bounds__(512, 4) void k_mlp_bwd_s(const float* __restrict__ 
     __syncthreads();
   }
   // ---- flush the small gradients ----
-  for (int i = threadIdx.x; i < 2 * C + 4; i += blockDim.x) red[i] = 0.f;
+  double* redd = reinterpret_cast<double*>(smem4);
+  for (int i = threadIdx.x; i < 2 * C + 4; i += blockDim.x) redd[i] = 0.;
   __syncthreads();
-  lds_add4(red, cq, dgam);
-  lds_add4(red, C + cq, dbet);
+  lds_add4(redd, cq, dgam);
+  lds_add4(redd, C + cq, dbet);
   if (le) {
     const float s0 = group_sum<64>(gle0), s1 = group_sum<64>(gle1), s2 = group_sum<64>(gle2);
-    if ((threadIdx.x & 63) == 0) { atomicAdd(red + 2 * C, s0); atomicAdd(red + 2 * C + 1, s1); atomicAdd(red + 2 * C + 2, s2); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(redd + 2 * C, (double)s0); atomicAdd(redd + 2 * C + 1, (double)s1); atomicAdd(redd + 2 * C + 2, (double)s2); }
   }
   __syncthreads();
   if ((int)threadIdx.x < C) {
 #ifndef RAL_NOVECATOMICS   // (diagnostic build: what the same-address chains of the small-vector gradients cost)
-    atomicAdd(gr.ln2w + threadIdx.x, red[threadIdx.x]);
-    atomicAdd(gr.ln2b + threadIdx.x, red[C + threadIdx.x]);
+    atomicAdd(gr.ln2w + threadIdx.x, (float)redd[threadIdx.x]);
+    atomicAdd(gr.ln2b + threadIdx.x, (float)redd[C + threadIdx.x]);
 #endif
   }
-  if (le && threadIdx.x < 3) atomicAdd(gr.le + threadIdx.x, red[2 * C + threadIdx.x]);
+  if (le && threadIdx.x < 3) atomicAdd(gr.le + threadIdx.x, (float)redd[2 * C + threadIdx.x]);
   // ---- flush the weight gradients: fold the token-split partials through LDS, then one atomic per element ----
   if (!want_dw) return;
 #pragma unroll
@@ -1247,15 +1253,16 @@ __global__ __launch_bounds__(512, RAL_QKVB_MINB) void k_qkv_bwd(const float* dqk
     for (int u = 0; u < NR; ++u) { rx[u] = nx[u]; rd[u] = nd[u]; re[u] = ne[u]; }
     __syncthreads();
   }
-  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) red[i] = 0.f;
+  double* redd = reinterpret_cast<double*>(smem4);
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) redd[i] = 0.;
   __syncthreads();
-  lds_add4(red, cq, dgam);
-  lds_add4(red, C + cq, dbet);
+  lds_add4(redd, cq, dgam);
+  lds_add4(redd, C + cq, dbet);
   __syncthreads();
   if ((int)threadIdx.x < C) {
 #ifndef RAL_NOVECATOMICS
-    atomicAdd(gr.ln1w + threadIdx.x, red[threadIdx.x]);
-    atomicAdd(gr.ln1b + threadIdx.x, red[C + threadIdx.x]);
+    atomicAdd(gr.ln1w + threadIdx.x, (float)redd[threadIdx.x]);
+    atomicAdd(gr.ln1b + threadIdx.x, (float)redd[C + threadIdx.x]);
 #endif
   }
 }
@@ -1412,14 +1419,15 @@ __global__ __launch_bounds__(512, RAL_QKVB_MINB) void k_qkv_bwd_h(const float* d
     for (int u = 0; u < NR; ++u) { rx[u] = nx[u]; rd[u] = nd[u]; re[u] = ne[u]; }
     __syncthreads();
   }
-  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) red[i] = 0.f;
+  double* redd = reinterpret_cast<double*>(smem4);
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) redd[i] = 0.;
   __syncthreads();
-  lds_add4(red, cq, dgam);
-  lds_add4(red, C + cq, dbet);
+  lds_add4(redd, cq, dgam);
+  lds_add4(redd, C + cq, dbet);
   __syncthreads();
   if ((int)threadIdx.x < C) {
-    atomicAdd(gr.ln1w + threadIdx.x, red[threadIdx.x]);
-    atomicAdd(gr.ln1b + threadIdx.x, red[C + threadIdx.x]);
+    atomicAdd(gr.ln1w + threadIdx.x, (float)redd[threadIdx.x]);
+    atomicAdd(gr.ln1b + threadIdx.x, (float)redd[C + threadIdx.x]);
   }
   if (gmax) {
     __syncthreads();
@@ -1535,15 +1543,16 @@ __global__ __launch_bounds__(256) void k_resample_bwd(const float* dy, const flo
     __syncthreads();
   }
   }
-  for (int i = threadIdx.x; i < 2 * D; i += blockDim.x) red[i] = 0.f;
+  double* redd = reinterpret_cast<double*>(smem4);
+  for (int i = threadIdx.x; i < 2 * D; i += blockDim.x) redd[i] = 0.;
   __syncthreads();
-  lds_add4(red, cq, dgam);
-  lds_add4(red, D + cq, dbet);
+  lds_add4(redd, cq, dgam);
+  lds_add4(redd, D + cq, dbet);
   __syncthreads();
   if ((int)threadIdx.x < D) {
 #ifndef RAL_NOVECATOMICS
-    atomicAdd(g_lnw + threadIdx.x, red[threadIdx.x]);
-    atomicAdd(g_lnb + threadIdx.x, red[D + threadIdx.x]);
+    atomicAdd(g_lnw + threadIdx.x, (float)redd[threadIdx.x]);
+    atomicAdd(g_lnb + threadIdx.x, (float)redd[D + threadIdx.x]);
 #endif
   }
 }

@@ -498,7 +498,7 @@ struct MlpbwShape {
   //         per wave: NTT x 16 x LDT transpose tiles
   static constexpr int W2TO = HID * LDC, W1TO = W2TO + HID * LDC, WPTO = W1TO + KP * LDH, VO = WPTO + KP * LDC, B1O = VO + 4 * KP,
                        SCR = B1O + HID, WSCR = NTT * 16 * LDT, TOTAL = SCR + 4 * WSCR;
-  static_assert(VO >= 8 * C * C + 2 * HID + 4 * KP + 8, "the flush staging fits the weight region");
+  static_assert(TOTAL >= 16 * C * C + 2 * HID + 4 * KP + 8, "the flush staging (weight-gradient tiles in doubles) fits the kernel's LDS");
 };
 
 template <int C>
@@ -728,9 +728,13 @@ __global__ __launch_bounds__(256, RAL_MLPW_WPE) void k_mlp_bwd_w(const float* __
   }
   // ---- flush: small gradients (sums over the 16 token lanes of a row), then the weight-gradient tiles through the LDS
   __syncthreads();                                     // every wave is done with the weight copies
-  float* stg = sm;                                     // dW1 [HID][C] | dW2 [C][HID] | b1 [HID] | b2, gamma, beta [KP each] | le [4]
-  float* sB1 = stg + 8 * C * C; float* sB2 = sB1 + HID; float* sG = sB2 + KP; float* sBe = sG + KP; float* sLe = sBe + KP;
-  for (int i = threadIdx.x; i < 8 * C * C + HID + 3 * KP + 4; i += blockDim.x) stg[i] = 0.f;
+  // dW1 [HID][C] | dW2 [C][HID] as DOUBLES (a full-wave ds_add_f32 takes 192 LDS cycles on gfx950, ds_add_f64 8:
+  // tools/diag/lds_cost_probe.hip; with fp32 tiles this flush was ~6 000 LDS cycles per wave, all waves of a CU at once) |
+  // b1 [HID] | b2, gamma, beta [KP each] | le [4] as floats (sixteen or fewer lanes per add)
+  double* stg = reinterpret_cast<double*>(sm);
+  float* sB1 = sm + 16 * C * C; float* sB2 = sB1 + HID; float* sG = sB2 + KP; float* sBe = sG + KP; float* sLe = sBe + KP;
+  for (int i = threadIdx.x; i < 8 * C * C; i += blockDim.x) stg[i] = 0.;
+  for (int i = threadIdx.x; i < HID + 3 * KP + 4; i += blockDim.x) sB1[i] = 0.f;
   __syncthreads();
   if (want_dw) {
 #pragma unroll
@@ -742,9 +746,9 @@ __global__ __launch_bounds__(256, RAL_MLPW_WPE) void k_mlp_bwd_w(const float* __
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
           const int hid = 16 * h + 4 * g + q, c = 16 * m + r;                 // dW1 tile: row hidden, column channel
-          if (c < C) atomicAdd(stg + hid * C + c, dW1[h][m][q]);
+          if (c < C) atomicAdd(stg + hid * C + c, (double)dW1[h][m][q]);
           const int c2 = 16 * m + 4 * g + q, hid2 = 16 * h + r;               // dW2 tile: row channel, column hidden
-          if (c2 < C) atomicAdd(stg + 4 * C * C + c2 * HID + hid2, dW2[m][h][q]);
+          if (c2 < C) atomicAdd(stg + 4 * C * C + c2 * HID + hid2, (double)dW2[m][h][q]);
         }
       }
     }
@@ -769,7 +773,7 @@ __global__ __launch_bounds__(256, RAL_MLPW_WPE) void k_mlp_bwd_w(const float* __
   }
   __syncthreads();
   if (want_dw) {
-    for (int i = threadIdx.x; i < 4 * C * C; i += blockDim.x) { atomicAdd(gr.w1 + i, stg[i]); atomicAdd(gr.w2 + i, stg[4 * C * C + i]); }
+    for (int i = threadIdx.x; i < 4 * C * C; i += blockDim.x) { atomicAdd(gr.w1 + i, (float)stg[i]); atomicAdd(gr.w2 + i, (float)stg[4 * C * C + i]); }
     for (int i = threadIdx.x; i < HID; i += blockDim.x) atomicAdd(gr.b1 + i, sB1[i]);
     for (int i = threadIdx.x; i < C; i += blockDim.x) atomicAdd(gr.b2 + i, sB2[i]);
   }

@@ -25,7 +25,7 @@ __global__ void k(long long* cyc, float* sink, int iters) {
   if (KIND == 3) a = base + (tp < 2 ? 0 : 4096) + (4 * g + tq) * 16 + (tp & 1) * 8;
   if (KIND == 4) a = base + r * 16 + (g & 1) * 8;
   if (KIND == 5) a = base + g * 16;
-  if (KIND == 6 || KIND == 9 || KIND == 12 || KIND == 13 || KIND == 14 || KIND == 15) a = base + lane * 4;
+  if (KIND == 6 || (KIND >= 20 && KIND <= 25) || KIND == 9 || KIND == 12 || KIND == 13 || KIND == 14 || KIND == 15) a = base + lane * 4;
   if (KIND == 10 || KIND == 11) a = base + lane * 8;
   if (KIND == 7 || KIND == 8) a = base + lane * 8;
   float v0 = 1.f, v1 = 2.f, acc = 0.f;
@@ -39,6 +39,10 @@ __global__ void k(long long* cyc, float* sink, int iters) {
     if (KIND == 4 || KIND == 8) { double d; asm volatile(R8("ds_read_b64 %0, %1\n") "s_waitcnt lgkmcnt(0)" : "=v"(d) : "v"(a) : "memory"); acc += (float)d; }
     if (KIND == 5) { float4 d; asm volatile(R8("ds_read_b128 %0, %1\n") "s_waitcnt lgkmcnt(0)" : "=v"(d) : "v"(a) : "memory"); acc += d.x; }
     if (KIND == 6) asm volatile(R8("ds_add_f32 %0, %1\n") "s_waitcnt lgkmcnt(0)" :: "v"(a), "v"(v1) : "memory");
+    if (KIND >= 20 && KIND <= 23) { const int nl = KIND == 20 ? 1 : KIND == 21 ? 4 : KIND == 22 ? 16 : 32;
+      if (lane < nl) asm volatile(R8("ds_add_f32 %0, %1\n") "s_waitcnt lgkmcnt(0)" :: "v"(a), "v"(v1) : "memory"); }
+    if (KIND == 24) { if ((lane & 15) == 0) asm volatile(R8("ds_add_f32 %0, %1\n") "s_waitcnt lgkmcnt(0)" :: "v"(a), "v"(v1) : "memory"); }
+    if (KIND == 25) asm volatile(R8("ds_add_f32 %0, %1\n") "s_waitcnt lgkmcnt(0)" :: "v"(base + (lane & 3) * 4), "v"(v1) : "memory");
     if (KIND == 9) asm volatile(R8("ds_add_u32 %0, %1\n") "s_waitcnt lgkmcnt(0)" :: "v"(a), "v"(v1) : "memory");
     if (KIND == 10) asm volatile(R8("ds_add_u64 %0, %1\n") "s_waitcnt lgkmcnt(0)" :: "v"(a), "v"(*(double*)&v0) : "memory");
     if (KIND == 11) asm volatile(R8("ds_add_f64 %0, %1\n") "s_waitcnt lgkmcnt(0)" :: "v"(a), "v"(*(double*)&v0) : "memory");
@@ -76,6 +80,12 @@ int main() {
   run<5>("ds_read_b128 row constants");
   run<6>("ds_add_f32 consecutive");
   run<15>("ds_add_rtn_f32");
+  run<20>("ds_add_f32, 1 active lane");
+  run<21>("ds_add_f32, 4 active lanes");
+  run<22>("ds_add_f32, 16 active lanes");
+  run<23>("ds_add_f32, 32 active lanes");
+  run<24>("ds_add_f32, lanes 0,16,32,48");
+  run<25>("ds_add_f32, 64 lanes on 4 addresses");
   run<9>("ds_add_u32 consecutive");
   run<10>("ds_add_u64 consecutive");
   run<11>("ds_add_f64 consecutive");
