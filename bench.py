@@ -368,6 +368,7 @@ def main():
     ap.add_argument("--no-infer", action="store_true", help="skip the inference-forward leg")
     ap.add_argument("--no-fp32", action="store_true", help="skip the strict-fp32 leg (profile collection: one arithmetic per trace)")
     ap.add_argument("--kinds", action="store_true", help="print a per-kernel-kind time table to stderr (3 steps each)")
+    ap.add_argument("--opt", action="append", default=[], help="library switch key=value (ral_global_option; diagnostics only, repeatable)")
     ap.add_argument("--dry-run-launcher", action="store_true", help="CPU/gloo rendezvous only: tests the process launcher")
     # test hooks (tests/test_gpu_dp_procs.py, tests/test_bench_cpu.py): never part of a measurement
     ap.add_argument("--test-share-gpu", action="store_true", help="every rank on device 0 (a box with one GPU)")
@@ -391,6 +392,7 @@ def main():
     import torch.distributed as dist
     from ecg_denoise_amd import _lib
 
+    _lib.apply_options(",".join(a.opt))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

@@ -85,6 +85,7 @@ _SIGS = {
     "ral_attention_backward": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, C.c_int, C.c_int, C.c_int,
                                          C.c_int, _VP]),
     "ral_set_option": (C.c_int, [_VP, C.c_char_p, C.c_int]),
+    "ral_global_option": (C.c_int, [C.c_char_p, C.c_longlong]),
     "ral_wavelet_denoise": (C.c_int, [_VP, _VP, C.c_int64, C.c_int, C.c_float, _VP]),
     "ral_profile_select": (C.c_int, [_VP, C.c_char_p]),
     "ral_profile_read": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
@@ -108,6 +109,16 @@ def lib():
             fn.argtypes = args
         _lib = L
     return _lib
+
+
+def apply_options(spec):
+    """`"attn_f16=0,mlp_fwd_w=2"` -> ral_global_option for each pair.  Process-wide library switches (kernel choices, grid
+    caps); to be called before the library is first used.  Nothing calls this implicitly: the tests (tests/conftest.py,
+    RAL_TEST_OPTIONS) and the diagnostic tools (bench.py --opt, RAL_TOOL_OPTIONS in tools/) do, explicitly."""
+    for kv in (spec or "").split(","):
+        if kv.strip():
+            k, v = kv.split("=")
+            check(lib().ral_global_option(k.strip().encode(), int(v)))
 
 
 def check(rc):

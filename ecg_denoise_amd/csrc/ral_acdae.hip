@@ -674,7 +674,7 @@ int acdae_forward(AcdaeModel* m, const float* x, float* y, int B, hipStream_t st
   for (int i = 0; i < 4; ++i) {
     const int cin = ACH[i], cout = ACH[i + 1], lin = L >> i;
     const size_t lds = (size_t)cin * (lin + 16) * sizeof(float);
-    static const bool enc_mfma = getenv("RAL_ACDAE_ENC_MFMA") == nullptr || atoi(getenv("RAL_ACDAE_ENC_MFMA")) != 0;
+    static const bool enc_mfma = ral_knob("ACDAE_ENC_MFMA", 1) != 0;
     if (AKS[i] == 13) { ACD_LDS(k_acd_enc_fwd<13>, lds); k_acd_enc_fwd<13><<<grid, 256, lds, st>>>(in, P.params + Y.ew[i], P.params + Y.eb[i], m->e[i], m->am[i], cin, cout, lin, B); }
     else if (enc_mfma && cin >= 16 && cout % 32 == 0 && lin % 16 == 0) {
       const size_t l2 = lds + (size_t)32 * cin * 7 * sizeof(float);
@@ -705,7 +705,7 @@ static void launch_acd_dw(const float* Yg, const float* Xg, float* gw, float* gb
   int splits = 2048 / nblk;                      // ~2048 workgroups per launch
   if (splits < 1) splits = 1;
   if (splits > B) splits = B;
-  static const bool mfma_on = getenv("RAL_ACDAE_DW_MFMA") == nullptr || atoi(getenv("RAL_ACDAE_DW_MFMA")) != 0;
+  static const bool mfma_on = ral_knob("ACDAE_DW_MFMA", 1) != 0;
   if (mfma_on && CY >= 16) {
     const int NT = (CX * KS + 15) / 16, NG = (NT + 15) / 16, MT = (CY + 15) / 16;
     const int cxr = (16 * 16) / KS + 2 < CX ? (16 * 16) / KS + 2 : CX;          // input-channel rows a column group touches

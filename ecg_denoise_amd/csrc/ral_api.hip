@@ -6,7 +6,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <ctype.h>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -25,6 +27,61 @@ static int fail(const char* fmt, ...) {
   return -1;
 }
 extern "C" const char* ral_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Switches.  Every tuning / experiment switch of the library has a compile-time default and a name in the list below.  The
+// product build reads NO environment variable for them: the only way to change one is ral_global_option() (C ABI; process-
+// wide, to be called before the first use - most are read once), which the tests use to pick kernels.  The library reads
+// exactly two environment variables, both validated: RAL_LANES (1 .. 4 micro-batch chains) and RAL_NO_SIDE_STREAM (0 / 1).
+// A diagnostic build (-DRAL_DIAG) additionally takes RAL_<NAME> from the environment for every switch (tools/diag/*.sh).
+static const char* const KNOB_NAMES[] = {
+  "ACDAE_DW_MFMA", "ACDAE_ENC_MFMA", "ATTNB_NT0", "ATTNF_NT0", "ATTNW_WAVES",
+  "ATTN_BWD_LDS", "ATTN_BWD_M", "ATTN_BWD_MH", "ATTN_BWD_V_HI", "ATTN_BWD_V_LO", "ATTN_BWD_W", "ATTN_F16", "ATTN_FWD_H",
+  "ATTN_FWD_LDS", "ATTN_FWD_V_HI", "ATTN_FWD_V_LO", "ATTN_FWD_W", "ATTN_QT1", "ATTN_QT4", "ATTN_SPLIT", "BUCKET_WAIT", "DANET_GRID_A",
+  "DANET_GRID_B", "DANET_GRID_D", "DANET_GRID_F", "DANET_GRID_W", "DIAG_SKIP_WIDE_DW", "DW_F16", "DW_KSPLIT_128", "DW_KSPLIT_16",
+  "DW_KSPLIT_32", "DW_KSPLIT_64", "DW_KSPLIT_8", "DW_LDS", "DW_PRIO", "DW_SETS", "F16_SPLIT", "FUSE_DW", "GRID_ATTNB", 
+  "GRID_ATTNW", "GRID_FWD", "GRID_MLPB", "GRID_MLPBW", "GRID_MLPS", "GRID_MLPW", "GRID_QKVB", "GRID_QKVW", "GRID_RESB", "LOSS_GRID",
+  "MLP_BWD_W", "MLP_F16", "MLP_FWD_W", "MLP_HLDS", "MLP_HTHREADS", "MLP_LDS", "MLP_TOK", "QKVB_F16", "QKV_WS", "UNET_BWD_GRID",
+  "UNET_BWD_WP", "UNET_DEBUG", "UNET_EVAL_GRID", "UNET_FOLD", "UNET_FUSED", "UNET_FWD_GRID", "UNET_NREP", "UNET_WG_PER_CU"};
+static std::mutex g_knob_mu;
+static std::map<std::string, long long>& knob_table() { static std::map<std::string, long long> t; return t; }
+long long ral_knob(const char* name, long long dflt) {
+  {
+    std::lock_guard<std::mutex> lk(g_knob_mu);
+    auto it = knob_table().find(name);
+    if (it != knob_table().end()) return it->second;
+  }
+#ifdef RAL_DIAG
+  const std::string e = std::string("RAL_") + name;
+  if (const char* v = getenv(e.c_str())) return atoll(v);
+#endif
+  return dflt;
+}
+// a validated integer environment variable (the product build has two): out-of-range or non-numeric text keeps the default
+int ral_env_int(const char* name, int dflt, int lo, int hi) {
+  const char* v = getenv(name);
+  if (!v || !*v) return dflt;
+  char* end = nullptr;
+  const long x = strtol(v, &end, 10);
+  if (end == v || *end != 0 || x < lo || x > hi) {
+    fprintf(stderr, "libralenet: %s=\"%s\" ignored (an integer in [%d, %d] is expected)\n", name, v, lo, hi);
+    return dflt;
+  }
+  return (int)x;
+}
+extern "C" int ral_global_option(const char* key, long long value) {
+  if (!key) return fail("null key");
+  std::string k(key);
+  for (auto& c : k) c = (char)toupper((unsigned char)c);
+  if (k.rfind("RAL_", 0) == 0) k = k.substr(4);
+  bool known = false;
+  for (const char* n : KNOB_NAMES) known = known || k == n;
+  if (!known) return fail("unknown switch %s", key);
+  if (value < 0) return fail("switch %s: negative value %lld", key, value);
+  std::lock_guard<std::mutex> lk(g_knob_mu);
+  knob_table()[k] = value;
+  return 0;
+}
 
 #define HIP_OK(expr)                                                                         \
   do {                                                                                       \
@@ -221,8 +278,7 @@ struct BlockAct { float *in, *qkv, *o, *lse, *x1, *upre, *out; };
 #define MAX_SETS 8
 static int dw_sets() {
   static const int n = [] {
-    const char* v = getenv("RAL_DW_SETS");
-    int k = v ? atoi(v) : 6;
+    int k = (int)ral_knob("DW_SETS", 6);
     return k < 2 ? 2 : (k > MAX_SETS ? MAX_SETS : k);
   }();
   return n;
@@ -376,10 +432,7 @@ static size_t plan_workspace(const ral_config& c, RalModel* m /* may be null: si
   return cur;
 }
 
-static size_t env_size(const char* name, size_t dflt) {
-  const char* v = getenv(name);
-  return v && *v ? (size_t)atoll(v) : dflt;
-}
+static size_t env_size(const char* name, size_t dflt) { return (size_t)ral_knob(name + 4, (long long)dflt); }   // (name = "RAL_<KNOB>")
 
 // head-group size of the attention kernels: the largest power-of-two fraction of the heads whose tiles fit the LDS budget
 static int attn_head_group(int N, int H, int Len, bool bwd) {
@@ -397,7 +450,10 @@ static void choose_tiling(RalModel* m) {
   // fewer slices get more, up to RAL_DW_MINWG workgroups per launch - see ral_dw.hip for why that is 192)
   static const int KS_DEFAULT[5] = {128, 128, 128, 64, 32};
   for (int l = 0; l < 5; ++l) m->dw_ksplit[l] = KS_DEFAULT[l];
-  if (const char* v = getenv("RAL_DW_KSPLIT")) sscanf(v, "%d,%d,%d,%d,%d", &m->dw_ksplit[0], &m->dw_ksplit[1], &m->dw_ksplit[2], &m->dw_ksplit[3], &m->dw_ksplit[4]);
+  {   // DW_KSPLIT_<width>: split-K workgroups of one channel width
+    static const char* const KSN[5] = {"DW_KSPLIT_8", "DW_KSPLIT_16", "DW_KSPLIT_32", "DW_KSPLIT_64", "DW_KSPLIT_128"};
+    for (int l = 0; l < 5; ++l) { const int v = (int)ral_knob(KSN[l], m->dw_ksplit[l]); if (v > 0) m->dw_ksplit[l] = v; }
+  }
   set_dw_lds_budget(env_size("RAL_DW_LDS", 76 * 1024));
   for (int l = 0; l < 5; ++l) {
     const int C = CH[l], N = m->L >> l, H = C / 4;
@@ -631,7 +687,7 @@ static void run_block_bwd(RalModel* m, int bi, const float* dy, const float* ext
   }
   { ProfScope p(m, K_DW, sd);
 #ifdef RAL_DIAG   // diagnostic builds only (make VARIANT=diag EXTRA=-DRAL_DIAG; WRONG gradients): what the weight-gradient kernels of the levels C >= RAL_DIAG_SKIP_WIDE_DW cost the step
-    static const int skipw = getenv("RAL_DIAG_SKIP_WIDE_DW") ? atoi(getenv("RAL_DIAG_SKIP_WIDE_DW")) : 0;
+    static const int skipw = (int)ral_knob("DIAG_SKIP_WIDE_DW", 0);
     if (!(skipw && C >= skipw))
 #endif
     launch_block_dw(C, dyw, upre, w.le ? a2c0 : nullptr, dupre, x1, dx1, o, dqkv, xin, m->pe[l], w, g, N, B, m->dw_ksplit[l], fused_mlp_dw, gmax, sd); }
@@ -887,9 +943,7 @@ int ral_create(const ral_config* cfg, ral_handle** out) {
   {
     LaneSet* LS = new LaneSet();
     m->lanes = LS;
-    m->n_lanes = (int)env_size("RAL_LANES", 2);
-    if (m->n_lanes < 1) m->n_lanes = 1;
-    if (m->n_lanes > MAX_LANES) m->n_lanes = MAX_LANES;
+    m->n_lanes = ral_env_int("RAL_LANES", 2, 1, MAX_LANES);        // one of the TWO environment variables the library reads
     // the weight-gradient streams are off the critical path: lowest priority, so that their workgroups fill the
     // gaps the main chain leaves instead of competing with it (RAL_DW_PRIO=0 keeps the default priority)
     int prio_least = 0, prio_greatest = 0;
@@ -932,10 +986,10 @@ int ral_create(const ral_config* cfg, ral_handle** out) {
       return -1;
     }
   }
-  if (const char* v = getenv("RAL_F16_SPLIT")) m->f16_split = atoi(v);
+  m->f16_split = (int)ral_knob("F16_SPLIT", m->f16_split);   // (a process-wide default for tests: ral_global_option; never the environment)
   m->attn_f16 = attn_f16_default() != 0;
   if (cfg->train) {
-    m->side_stream = getenv("RAL_NO_SIDE_STREAM") == nullptr;
+    m->side_stream = ral_env_int("RAL_NO_SIDE_STREAM", 0, 0, 1) == 0;   // ... and the other
     std::vector<int> d;
     int run = 0;
     auto add = [&](int64_t off, int rows, int cols) { d.push_back((int)off); d.push_back(rows); d.push_back(cols); d.push_back(run); run += rows * cols; };
@@ -1124,7 +1178,7 @@ int ral_grad_bucket_wait(ral_handle* h, int k, ral_stream s) {
     if (m->dec_lanes <= 0) return fail("bucket 1 is available after ral_backward_begin");
     LaneSet* LS = lanes_of(m);
 #ifdef RAL_DIAG   // diagnostic builds only (dropping a wait is a data race): 1 chains only, 2 side streams only, 0 none
-    static const int dbg = getenv("RAL_BUCKET_WAIT") ? atoi(getenv("RAL_BUCKET_WAIT")) : 3;
+    static const int dbg = (int)ral_knob("BUCKET_WAIT", 3);
 #else
     constexpr int dbg = 3;
 #endif

@@ -378,248 +378,6 @@ __global__ __launch_bounds__(256, RAL_ATTNW_WPE) void k_attn_bwd_w(const float* 
   }
 }
 
-// =====================================================================================================================
-// Long windows (N >= 256): the workgroup form of k_attn_bwd (ral_bwd.hip) - an item = (window, head group), staged once
-// into the LDS, sweep A / sweep B tasks dealt to the waves - with the S and dP tiles on the f16 matrix cores as above.
-// LDS per token: fp32 quads q log2 e, k, dO (the vector-ALU operands of the dq / dk / dv products) + pair planes of q, k,
-// v, dO (token-interleaved: [h1 x 4 | h2 x 4] = 16 bytes, so that v and dO are converted IN PLACE once the head's scale
-// is known) + -lse, -delta: 120 bytes, 512 threads, two workgroups per CU.
-// The staging pass is cut in two by one more barrier: pass 1 writes everything that needs no scale and raises the head's
-// max |v|, max |dO| (wave maximum, one LDS atomic per wave and tensor); pass 2 scales and splits v and dO.
-// The R-wave table gradient stays in the LDS for the life of the workgroup (all H heads) and leaves as one row of
-// partials per workgroup (k_attn_tpart_reduce).
-// =====================================================================================================================
-template <int QT, bool TAB>
-__global__ __launch_bounds__(512, 4) void k_attn_bwd_h(const float* __restrict__ qkv, const float* __restrict__ o_hm,
-                                                       const float* __restrict__ do_hm, const float* __restrict__ lse,
-                                                       const float* __restrict__ table, float* __restrict__ tpart,
-                                                       float* __restrict__ dqkv, int N, int H, int HG, int Len_rt, int B) {
-  extern __shared__ float4 smem4[];
-  float* sm = reinterpret_cast<float*>(smem4);
-  const int T = HG * N;
-  float* Q32 = sm;                 // q * log2(e)
-  float* K32 = Q32 + 4 * T;
-  float* D32 = K32 + 4 * T;
-  float* Qp = D32 + 4 * T;         // pair planes, token-interleaved
-  float* Kp = Qp + 4 * T;
-  float* Vp = Kp + 4 * T;
-  float* Dp = Vp + 4 * T;
-  float* Ls = Dp + 4 * T;          // -lse * log2(e)
-  float* Dl = Ls + T;              // -rowsum(dO * O) * scale
-  unsigned* mx = reinterpret_cast<unsigned*>(Dl + T);   // [HG][4]: bits of max |dO|, |v|, |q log2 e|, |k| of the item's heads
-  const int Len = TAB ? Len_rt : 0;
-  const int ntab = TAB ? (2 * Len - 1) * H : 0;
-  float* tab = reinterpret_cast<float*>(mx + 4 * HG);   // bias * log2(e), (2 Len - 1, H)
-  float* dtab = tab + ntab;
-  const int ngrp = H / HG;
-  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
-  const int off = (N - Len) >> 1;
-  const int kb0 = TAB ? (off & ~15) : N, kb1 = TAB ? ((off + Len + 15) & ~15) : N;
-  for (int i = threadIdx.x; i < ntab; i += blockDim.x) { tab[i] = table[i] * RAL_LOG2E; dtab[i] = 0.f; }
-  auto opA = [&](const float* X, int tok) -> h16x4 { return *reinterpret_cast<const h16x4*>(X + 4 * tok + 2 * (g >> 1)); };
-  auto opB = [&](const float* X, int tok) -> h16x4 { return *reinterpret_cast<const h16x4*>(X + 4 * tok + 2 * (g & 1)); };
-  auto mm = [&](h16x4 a, h16x4 b, f32x4 c) -> f32x4 { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); };
-  auto put_planes = [&](float* X, int t, float4 x) {
-    const H2x4 s2 = split4(x);
-    *reinterpret_cast<h16x4*>(X + 4 * t) = s2.a;
-    *reinterpret_cast<h16x4*>(X + 4 * t + 2) = s2.b;
-  };
-  for (int item = blockIdx.x; item < B * ngrp; item += gridDim.x) {
-    const int win = item / ngrp, h0 = (item - win * ngrp) * HG;
-    const float* base = qkv + (size_t)win * 3 * H * N * 4;
-    float* dbase = dqkv + (size_t)win * 3 * H * N * 4;
-    const size_t hq0 = ((size_t)win * H + h0) * N;
-    __syncthreads();   // every wave is done with the previous item's tiles and scales
-    if (threadIdx.x < 4 * HG) mx[threadIdx.x] = 0u;
-    __syncthreads();
-    // ---- staging pass 1: the six loads of an index are issued together; everything that needs no scale is written
-    {
-      const float4* gq = reinterpret_cast<const float4*>(base + (size_t)h0 * N * 4);
-      const float4* gk = reinterpret_cast<const float4*>(base + (size_t)(H + h0) * N * 4);
-      const float4* gv = reinterpret_cast<const float4*>(base + (size_t)(2 * H + h0) * N * 4);
-      const float4* gd = reinterpret_cast<const float4*>(do_hm) + hq0;
-      const float4* go = reinterpret_cast<const float4*>(o_hm) + hq0;
-      const int bd = blockDim.x;
-      for (int i0 = 0; i0 < T; i0 += 2 * bd) {      // (T is a multiple of 256: whole waves fall on one side of it)
-        const int ia = i0 + threadIdx.x, ib = ia + bd;
-        const bool hb = ib < T;
-        const int ic = hb ? ib : ia;
-        const float4 q0 = gq[ia], q1 = gq[ic], k0 = gk[ia], k1 = gk[ic], v0 = gv[ia], v1 = gv[ic];
-        const float4 d0 = gd[ia], d1 = gd[ic], o0 = go[ia], o1 = go[ic];
-        const float l0 = lse[hq0 + ia], l1 = lse[hq0 + ic];
-        auto one = [&](int t, float4 q, float4 k, float4 v, float4 d, float4 o, float l) {
-          const float4 ql = f4scale(q, RAL_LOG2E);
-          reinterpret_cast<float4*>(Q32)[t] = ql;
-          reinterpret_cast<float4*>(K32)[t] = k;
-          reinterpret_cast<float4*>(D32)[t] = d;
-          reinterpret_cast<float4*>(Vp)[t] = v;            // fp32 for now: split in place by pass 2
-          Ls[t] = -l * RAL_LOG2E; Dl[t] = -f4dot(d, o);
-          const float md = group_max<64>(f4absmax(d)), mv = group_max<64>(f4absmax(v));
-          const float mq = group_max<64>(f4absmax(ql)), mk = group_max<64>(f4absmax(k));
-          if (lane == 0) {
-            unsigned* m4 = mx + 4 * (t / N);
-            atomicMax(m4, __float_as_uint(md)); atomicMax(m4 + 1, __float_as_uint(mv));
-            atomicMax(m4 + 2, __float_as_uint(mq)); atomicMax(m4 + 3, __float_as_uint(mk));
-          }
-        };
-        if (ia < T) one(ia, q0, k0, v0, d0, o0, l0);
-        if (hb) one(ib, q1, k1, v1, d1, o1, l1);
-      }
-    }
-    __syncthreads();
-    // ---- staging pass 2: v and dO times their head's power of two, split in place; delta times both; q and k balanced
-    for (int t = threadIdx.x; t < T; t += blockDim.x) {
-      const unsigned* m4 = mx + 4 * (t / N);
-      const float cd = h2_row_scale(m4[0]), cv = h2_row_scale(m4[1]);
-      float cq, ck;
-      pair_balance(__uint_as_float(m4[2]), __uint_as_float(m4[3]), cq, ck);
-      const float4 v = reinterpret_cast<const float4*>(Vp)[t], d = reinterpret_cast<const float4*>(D32)[t];
-      put_planes(Vp, t, f4scale(v, cv)); put_planes(Dp, t, f4scale(d, cd));
-      put_planes(Qp, t, f4scale(reinterpret_cast<const float4*>(Q32)[t], cq));
-      put_planes(Kp, t, f4scale(reinterpret_cast<const float4*>(K32)[t], ck));
-      Dl[t] *= cd * cv;
-    }
-    __syncthreads();
-    const int nblk = N / (16 * QT);
-    // ---------------- sweep A: dQ (query block on the lanes, loop over key tiles) ----------------
-    for (int task = wave; task < HG * nblk; task += nw) {
-      const int hl = task / nblk, q0 = (task - hl * nblk) * 16 * QT, tb = hl * N, head = h0 + hl;
-      const float oscale = h2_row_unscale(mx[4 * hl]) * h2_row_unscale(mx[4 * hl + 1]);
-      const float4* K4 = reinterpret_cast<const float4*>(K32) + tb;
-      h16x4 qh[QT], dh[QT];
-      f32x4 lq[QT], dl[QT];
-      f32x2 dq01[QT], dq23[QT];
-#pragma unroll
-      for (int qt = 0; qt < QT; ++qt) {
-        const int q = tb + q0 + 16 * qt + r;
-        qh[qt] = opB(Qp, q); dh[qt] = opB(Dp, q);
-        const float l = Ls[q], d = Dl[q];
-        lq[qt] = f32x4{l, l, l, l}; dl[qt] = f32x4{d, d, d, d};
-        dq01[qt] = f32x2{0.f, 0.f}; dq23[qt] = f32x2{0.f, 0.f};
-      }
-      // (requesting the MFMA operands of the NEXT key tile ahead of the current tile's products was measured: 715 against
-      // 698 us at N = 512 - four waves per SIMD already cover the LDS round trip, the extra registers spill)
-      auto tileA = [&](int kt, auto biased) {
-        const h16x4 kh = opA(Kp, tb + kt + r), vh = opA(Vp, tb + kt + r);
-        float4 k4[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) k4[j] = K4[kt + 4 * g + j];
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-          f32x4 s = mm(kh, qh[qt], lq[qt]);               // s - lse      [key 4g+j][query r]
-          const f32x4 dp = mm(vh, dh[qt], dl[qt]);        // (dP - delta) * scale
-          float ds[4];
-          if constexpr (decltype(biased)::value) {
-            const int qi = q0 + 16 * qt + r - off;
-            const bool qok = (unsigned)qi < (unsigned)Len;
-            const int rel0 = qi - (kt + 4 * g - off) + Len - 1;
-            int e[4]; bool in[4]; float b[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              in[j] = qok && (unsigned)(kt + 4 * g + j - off) < (unsigned)Len;
-              e[j] = min(max(rel0 - j, 0), 2 * Len - 2) * H + head;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = tab[e[j]];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) ds[j] = __builtin_amdgcn_exp2f(s[j] + (in[j] ? b[j] : 0.f)) * dp[j];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (in[j]) atomicAdd(dtab + e[j], ds[j] * oscale);
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) ds[j] = __builtin_amdgcn_exp2f(s[j]) * dp[j];
-          }
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            dq01[qt] = pk_fma2(f32x2{ds[j], ds[j]}, f32x2{k4[j].x, k4[j].y}, dq01[qt]);
-            dq23[qt] = pk_fma2(f32x2{ds[j], ds[j]}, f32x2{k4[j].z, k4[j].w}, dq23[qt]);
-          }
-        }
-      };
-      const bool qbias = TAB && (q0 < off + Len) && (q0 + 16 * QT > off);
-      const int e0 = qbias ? kb0 : N, e1 = qbias ? kb1 : N;
-      for (int kt = 0; kt < e0; kt += 16) tileA(kt, std::false_type{});
-      if constexpr (TAB) {
-        for (int kt = e0; kt < e1; kt += 16) tileA(kt, std::true_type{});
-        for (int kt = e1; kt < N; kt += 16) tileA(kt, std::false_type{});
-      }
-#pragma unroll
-      for (int qt = 0; qt < QT; ++qt) {
-        const float v = quad_rows_sum(dq01[qt][0], dq01[qt][1], dq23[qt][0], dq23[qt][1]);
-        dbase[((size_t)head * N + q0 + 16 * qt + r) * 4 + g] = (0.5f * oscale) * v;   // q = 0.5 (h Wq^T + b)
-      }
-    }
-    // ---------------- sweep B: dK, dV (key block on the lanes, loop over query tiles) ----------------
-    for (int task = wave; task < HG * nblk; task += nw) {
-      const int hl = task / nblk, k0 = (task - hl * nblk) * 16 * QT, tb = hl * N, head = h0 + hl;
-      const float oscale = h2_row_unscale(mx[4 * hl]) * h2_row_unscale(mx[4 * hl + 1]);
-      const float4* Q4 = reinterpret_cast<const float4*>(Q32) + tb;
-      const float4* D4 = reinterpret_cast<const float4*>(D32) + tb;
-      h16x4 kh[QT], vh[QT];
-      f32x2 dk01[QT], dk23[QT], dv01[QT], dv23[QT];
-#pragma unroll
-      for (int t = 0; t < QT; ++t) {
-        const int k = tb + k0 + 16 * t + r;
-        kh[t] = opB(Kp, k); vh[t] = opB(Vp, k);
-        dk01[t] = f32x2{0.f, 0.f}; dk23[t] = f32x2{0.f, 0.f}; dv01[t] = f32x2{0.f, 0.f}; dv23[t] = f32x2{0.f, 0.f};
-      }
-      auto tileB = [&](int qt, auto biased) {
-        const h16x4 qah = opA(Qp, tb + qt + r), dah = opA(Dp, tb + qt + r);
-        const float4 l4 = *reinterpret_cast<const float4*>(Ls + tb + qt + 4 * g);
-        const float4 d4 = *reinterpret_cast<const float4*>(Dl + tb + qt + 4 * g);
-        float4 q4[4], o4[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { q4[j] = Q4[qt + 4 * g + j]; o4[j] = D4[qt + 4 * g + j]; }
-#pragma unroll
-        for (int t = 0; t < QT; ++t) {
-          f32x4 s = mm(qah, kh[t], f32x4{l4.x, l4.y, l4.z, l4.w});        // S[query 4g+j][key r] - lse
-          const f32x4 dp = mm(dah, vh[t], f32x4{d4.x, d4.y, d4.z, d4.w});  // (dP[query][key] - delta) * scale
-          if constexpr (decltype(biased)::value) {
-            const int ki = k0 + 16 * t + r - off;
-            const bool kok = (unsigned)ki < (unsigned)Len;
-            const int rel0 = (qt + 4 * g - off) - ki + Len - 1;
-            float b[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = tab[min(max(rel0 + j, 0), 2 * Len - 2) * H + head];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) s[j] += (kok && (unsigned)(qt + 4 * g + j - off) < (unsigned)Len) ? b[j] : 0.f;
-          }
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float p = __builtin_amdgcn_exp2f(s[j]);
-            const float ds = p * dp[j];
-            dv01[t] = pk_fma2(f32x2{p, p}, f32x2{o4[j].x, o4[j].y}, dv01[t]);
-            dv23[t] = pk_fma2(f32x2{p, p}, f32x2{o4[j].z, o4[j].w}, dv23[t]);
-            dk01[t] = pk_fma2(f32x2{ds, ds}, f32x2{q4[j].x, q4[j].y}, dk01[t]);
-            dk23[t] = pk_fma2(f32x2{ds, ds}, f32x2{q4[j].z, q4[j].w}, dk23[t]);
-          }
-        }
-      };
-      const bool kbias = TAB && (k0 < off + Len) && (k0 + 16 * QT > off);
-      const int e0 = kbias ? kb0 : N, e1 = kbias ? kb1 : N;
-      for (int qt = 0; qt < e0; qt += 16) tileB(qt, std::false_type{});
-      if constexpr (TAB) {
-        for (int qt = e0; qt < e1; qt += 16) tileB(qt, std::true_type{});
-        for (int qt = e1; qt < N; qt += 16) tileB(qt, std::false_type{});
-      }
-#pragma unroll
-      for (int t = 0; t < QT; ++t) {
-        const float vk = quad_rows_sum(dk01[t][0], dk01[t][1], dk23[t][0], dk23[t][1]);
-        const float vv = quad_rows_sum(dv01[t][0], dv01[t][1], dv23[t][0], dv23[t][1]);
-        const size_t kk = ((size_t)head * N + k0 + 16 * t + r) * 4 + g;
-        dbase[(size_t)H * N * 4 + kk] = vk * (RAL_LN2 * oscale);      // Q32 carried log2(e)
-        dbase[(size_t)2 * H * N * 4 + kk] = vv;
-      }
-    }
-  }
-  if constexpr (TAB) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < ntab; i += blockDim.x) tpart[(size_t)blockIdx.x * ntab + i] = dtab[i];
-  }
-}
-
 // gtable[i] += sum over the workgroups' rows of partials: one WAVE per table entry (lane l adds rows l, l + 64, ...: every
 // load of the launch is independent; a thread per entry walking the rows was a 200-link chain of memory round trips,
 // + 50 us behind a 120 us kernel)
@@ -640,11 +398,11 @@ void launch_attn_tpart_reduce(const float* tpart, float* gtable, int ntab, int n
 
 // ---------------------------------------------------------------------------------------------------------------------
 int attn_f16_default() {
-  static const int m = [] { const char* v = getenv("RAL_ATTN_F16"); return v ? atoi(v) : 1; }();
+  static const int m = (int)ral_knob("ATTN_F16", 1);
   return m;
 }
 static int attnw_mode() {   // RAL_ATTN_BWD_W=0: never (the workgroup kernels of ral_bwd.hip take every shape)
-  static const int m = [] { const char* v = getenv("RAL_ATTN_BWD_W"); return v ? atoi(v) : 1; }();
+  static const int m = (int)ral_knob("ATTN_BWD_W", 1);
   return m;
 }
 // upper bound of the grid (what the scratch is sized for): one workgroup per four tasks, at most 1024
@@ -657,7 +415,7 @@ int attnw_grid_max(int N, int H, int B) {
 // would run a second round one third full (RAL_GRID_ATTNW overrides)
 template <class K>
 static int attnw_grid(K kernel, size_t lds, int N, int H, int B) {
-  static const int genv = [] { const char* v = getenv("RAL_GRID_ATTNW"); return v ? atoi(v) : 0; }();
+  static const int genv = (int)ral_knob("GRID_ATTNW", 0);
   const int gmax = attnw_grid_max(N, H, B);
   if (genv > 0) return genv < gmax ? genv : gmax;
   int occ = 0;
@@ -909,51 +667,8 @@ __global__ __launch_bounds__(256, (NT == 64 ? 3 : 4)) void k_attn_fwd_w(const fl
   }
 }
 
-// ---- long windows on the f16 matrix cores
-static int attnh_lds_budget() {   // bytes of LDS an item may take (RAL_ATTNH_LDS)
-  static const int b = [] { const char* v = getenv("RAL_ATTNH_LDS"); return v ? atoi(v) : 64 * 1024; }();
-  return b;
-}
-static int attnh_hg(int N, int H, int Len) {
-  int hg = H;
-  while (hg > 1 && attn_bwd_h_lds(N, H, hg, Len) > (size_t)attnh_lds_budget()) hg /= 2;
-  return hg;
-}
-size_t attn_bwd_h_lds(int N, int H, int hg, int Len) {
-  return ((size_t)30 * hg * N + 4 * hg + (Len > 0 ? (size_t)2 * (2 * Len - 1) * H : 0) + 4) * sizeof(float);
-}
-bool attn_bwd_h_takes(int N, int H, int Len, bool table) {
-  static const int on = [] { const char* v = getenv("RAL_ATTN_BWD_H"); return v ? atoi(v) : 1; }();
-  if (!on || N < 256 || N % 32 != 0) return false;
-  if (table && (2 * Len - 1) * H > 2048) return false;
-  return attn_bwd_h_lds(N, H, attnh_hg(N, H, Len), Len) <= 150 * 1024;
-}
-static int attnh_grid(int N, int H, int Len, int B) {
-  static const int gmax = [] { const char* v = getenv("RAL_GRID_ATTNH"); return v ? atoi(v) : 1024; }();
-  const int items = B * (H / attnh_hg(N, H, Len));
-  return items < gmax ? items : gmax;
-}
-size_t attn_bwd_h_scratch_floats(int N, int H, int Len, bool table, int B) {
-  if (!table || !attn_bwd_h_takes(N, H, Len, table)) return 0;
-  const int items = B * (H / attnh_hg(N, H, Len));
-  return (size_t)(items < 1024 ? items : 1024) * (size_t)((2 * Len - 1) * H);
-}
-void launch_attn_bwd_h(const float* qkv, const float* o_hm, const float* do_hm, const float* lse, const float* table,
-                       float* gtable, float* dqkv, float* tpart, int N, int H, int Len, int B, hipStream_t s) {
-  const int hg = attnh_hg(N, H, Len), grid = attnh_grid(N, H, Len, B);
-  const size_t lds = attn_bwd_h_lds(N, H, hg, Len);
-  const int ntab = table ? (2 * Len - 1) * H : 0;
-  static const int thr_env = [] { const char* v = getenv("RAL_ATTNH_THREADS"); return v ? atoi(v) : 0; }();
-  // a wave per sweep task where the item has fewer than sixteen (one head of a 256-token window: 8 tasks)
-  const int ntask = hg * (N / 32);
-  const int threads = thr_env ? thr_env : (ntask >= 16 ? 512 : (ntask >= 8 ? 256 : 128));
-  if (table) { RAL_SET_LDS((k_attn_bwd_h<2, true>), lds); k_attn_bwd_h<2, true><<<grid, threads, lds, s>>>(qkv, o_hm, do_hm, lse, table, tpart, dqkv, N, H, hg, Len, B); }
-  else { RAL_SET_LDS((k_attn_bwd_h<2, false>), lds); k_attn_bwd_h<2, false><<<grid, threads, lds, s>>>(qkv, o_hm, do_hm, lse, nullptr, nullptr, dqkv, N, H, hg, 0, B); }
-  if (table) k_attn_tpart_reduce<<<(ntab + 3) / 4, 256, 0, s>>>(tpart, gtable, ntab, grid);
-}
-
 bool attn_fwd_w_takes(int N, int H, int Len, bool table) {
-  static const int on = [] { const char* v = getenv("RAL_ATTN_FWD_W"); return v ? atoi(v) : 1; }();
+  static const int on = (int)ral_knob("ATTN_FWD_W", 1);
   // measured at batch 2048 (us per launch, this kernel with f16 tiles / the kernels of ral_fwd.hip): N = 32: 39 / 45,
   // 64 (table): 64 / 54, 128 (table): 90 / 91 - the scalar-path forward keeps N = 64 and 128 (RAL_ATTN_FWD_W=2: all three)
   if (!on || (N != 32 && N != 64 && N != 128) || (on < 2 && N != 32)) return false;
@@ -986,12 +701,13 @@ void launch_attn_bwd_w(const float* qkv, const float* o_hm, const float* do_hm, 
   // waves per workgroup (RAL_ATTNW_WAVES).  Measured at batch 2048, us per launch with 4 / 3 / 2 / 1 waves: N = 128: 236 / 274 /
   // 245 / 283 (four-wave workgroups of 61 KB leave a CU two of them, five two-wave ones fit - and are no faster), N = 64:
   // 131 / 135 / 142 / 173, N = 32: 82 / 80 / 83 / 99
-  static const int wv_env = [] { const char* v = getenv("RAL_ATTNW_WAVES"); return v ? atoi(v) : 0; }();
+  static const int wv_env = (int)ral_knob("ATTNW_WAVES", 0);
   const int nwv = wv_env ? wv_env : 4;
-  const size_t lds = ((size_t)nwv * T * (f16 ? 30 : 18) + 2 * ntab) * sizeof(float);
+  (void)f16;
+  const size_t lds = ((size_t)nwv * T * 18 + 2 * ntab) * sizeof(float);
   int grid = 0;
   auto grid_of = [&](auto kern) {
-    static const int genv = [] { const char* v = getenv("RAL_GRID_ATTNW"); return v ? atoi(v) : 0; }();
+    static const int genv = (int)ral_knob("GRID_ATTNW", 0);
     const int gmax = attnw_grid_max(N, H, B);          // (the scratch is sized for one workgroup per four tasks)
     if (genv > 0) return genv < gmax ? genv : gmax;
     int occ = 0;
@@ -1003,12 +719,10 @@ void launch_attn_bwd_w(const float* qkv, const float* o_hm, const float* do_hm, 
   };
 #define GO(n, tab, h, qt) { RAL_SET_LDS((k_attn_bwd_w<n, tab, h, qt>), lds); grid = grid_of(k_attn_bwd_w<n, tab, h, qt>); \
     k_attn_bwd_w<n, tab, h, qt><<<grid, 64 * nwv, lds, s>>>(qkv, o_hm, do_hm, lse, table, tpart, dqkv, H, Len, ntask); }
-#define GOH(n, tab) { if (f16) GO(n, tab, true, 2) else GO(n, tab, false, 2) }
+#define GOH(n, tab) { GO(n, tab, false, 2) }   // (the f16 tiles of this form went with round 5: k_attn_bwd_m, ral_attnm.hip)
   if (N == 32) { if (table) GOH(32, true) else GOH(32, false) }
   else if (N == 64) {
-    static const int qt64 = [] { const char* v = getenv("RAL_ATTNW_QT64"); return v ? atoi(v) : 2; }();
-    if (qt64 == 4) { if (table) { if (f16) GO(64, true, true, 4) else GO(64, true, false, 4) } else { if (f16) GO(64, false, true, 4) else GO(64, false, false, 4) } }
-    else if (table) GOH(64, true) else GOH(64, false)
+    if (table) GOH(64, true) else GOH(64, false)
   }
   else { if (table) GOH(128, true) else GOH(128, false) }
 #undef GOH

@@ -1,8 +1,8 @@
 // Attention backward with EVERY contraction on the f16 matrix cores, in ONE sweep (round 5).
 //
 // Reference op: the backward of MSAttention.forward (model/raletransformer.py:291-322, model/transformer.py:289-323, R-wave
-// bias model/transformer.py:508-558).  P is recomputed from q, k and the saved log-sum-exp, as in k_attn_bwd_w / k_attn_bwd_h
-// (ral_attn.hip), but those kernels evaluate every score tile TWICE (sweep A: dQ with the query on the lane, sweep B: dK, dV
+// bias model/transformer.py:508-558).  P is recomputed from q, k and the saved log-sum-exp, as in the two-sweep kernels of rounds 1-4
+// (k_attn_bwd_w in ral_attn.hip, k_attn_bwd in ral_bwd.hip: today the strict-fp32 path), but those kernels evaluate every score tile TWICE (sweep A: dQ with the query on the lane, sweep B: dK, dV
 // with the key on the lane) and contract dS / P with k, q, dO on the vector ALU: 8 exponentials, 8 multiplies and 24
 // packed FMAs per tile pair - 245 issue cycles at best, 341-520 measured - beside a matrix pipe that is 16 % busy.
 //
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256, RAL_ATTNM_WPE) void k_attn_bwd_m(const float* 
 
 // =====================================================================================================================
 // Long windows (N >= 256; any N = 16 KT W with W waves per head dividing 8): a 512-thread workgroup per (window, head group),
-// as k_attn_bwd_h stages it - all operands of the item as plane images in the LDS, scales per head from LDS maxima - but with
+// staged in two passes - all operands of the item as plane images in the LDS, scales per head from LDS maxima - but with
 // the one-sweep tiles above.  A wave owns KT key tiles of one head for the whole item: their K / V operands and k^T planes
 // stay in registers, dV^T / dK^T in KT accumulators; it walks over ALL query tiles of the head, and the dQ^T tile of a query
 // tile (summed over the wave's keys in registers) is added to an fp32 image of dQ in the LDS with ONE ds_add_f32 per lane
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd_mh(const float* __restrict_
 
 // ---------------------------------------------------------------------------------------------------------------------
 static int attnm_mode() {   // RAL_ATTN_BWD_M=0: never
-  static const int m = [] { const char* v = getenv("RAL_ATTN_BWD_M"); return v ? atoi(v) : 1; }();
+  static const int m = (int)ral_knob("ATTN_BWD_M", 1);
   return m;
 }
 bool attn_bwd_m_takes(int N, int H, int Len, bool table) {
@@ -598,7 +598,7 @@ static int attnmh_hg(int N, int H) {   // heads per item: eight waves of KT key 
   return wph >= 8 ? 1 : 8 / wph;
 }
 bool attn_bwd_mh_takes(int N, int H, int Len, bool table) {
-  static const int on = [] { const char* v = getenv("RAL_ATTN_BWD_MH"); return v ? atoi(v) : 1; }();
+  static const int on = (int)ral_knob("ATTN_BWD_MH", 1);
   if (!on || N < 256) return false;
   const int kt = attnmh_kt(N), wph = N / (16 * kt);
   if (N % (16 * kt) != 0 || (wph != 1 && wph != 2 && wph != 4 && wph != 8)) return false;

@@ -1781,7 +1781,7 @@ __global__ void k_conv1_bwd_dx(const float* __restrict__ dz, const float* __rest
 // a ragged last round), 256: 17.29 - the CUs it leaves free go to the weight-gradient kernels running beside it; then
 // k_mlp_bwd_s at 256: 17.11, 320: 17.08, 384: 16.99, 448: 17.02, 512: 17.04.
 // (RAL_GRID_QKVB / RESB / MLPB / MLPS / ATTNB override.)
-static inline int env_grid(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+static inline int env_grid(const char* name, int dflt) { return (int)ral_knob(name + 4, dflt); }   // (name = "RAL_<KNOB>")
 static inline int cap(int items, int gmax) { return items < gmax ? items : gmax; }
 static inline int ew_grid(size_t n, int per = 256) {
   size_t g = (n + per - 1) / per;
@@ -1797,7 +1797,7 @@ size_t mlp_bwd_lds(int C, int N, int nch) {
 // does the fused narrow-level kernel take (C, N)?  The forward asks too: it does not store u_pre for such blocks
 template <int C>
 static bool mlp_bwd_s_applies(int N, int* tw_out, size_t* lds_out) {
-  static const int maxc = getenv("RAL_FUSE_DW") ? atoi(getenv("RAL_FUSE_DW")) : 32;
+  static const int maxc = (int)ral_knob("FUSE_DW", 32);
   constexpr int MT = C >= 16 ? C / 16 : 1;
   if (C > maxc || (N * MT) % 128 != 0) return false;
   const int tw = N * MT / 128;
@@ -1842,7 +1842,7 @@ size_t mlp_bwd_h_lds(int C, int N, int nch) {
   return (size_t)2 * N * ldb_of(C) * 2 + (size_t)N * ld_of(C) * 4 + (size_t)N * (HC + 8) * 4 + ((size_t)2 * (N + 2) + 5 * N + 2 * C + 4) * 4;
 }
 int mlp_bwd_h_nch(int C, int N) {
-  static const bool on = !(getenv("RAL_MLP_F16") && atoi(getenv("RAL_MLP_F16")) == 0);
+  static const bool on = (ral_knob("MLP_F16", 1) != 0);
   if (!on || (C != 32 && C != 64 && C != 128) || N % 32 != 0) return 0;
   for (int nch = 1; nch <= 4; nch *= 2)
     if ((4 * C / nch / 32) * (N / 32) == 8 && mlp_bwd_h_lds(C, N, nch) <= 79872) return nch;
@@ -1911,10 +1911,10 @@ size_t attn_bwd_lds(int N, int HG, int Len) {
 // kernel vs scalar path).  Without an R-wave table: N = 512: 790 / 853, 256: 446 / 464, 128: 285 / 265, 64: 208 / 155;
 // with one (the in-window keys cost two lane gathers each, plus the partial-sum pass): 128: 285 / 293, 64: 208 / 192, and
 // inside the training step (bench.py --kinds) the N = 64 case with a table came out 2 % slower than the MFMA-tile kernel.
-// So: N <= 128 without a table, never with one.  RAL_ATTN_BWD_V="lo:hi" forces a range for both cases (0:0 = never).
+// So: N <= 128 without a table, never with one.  The switches ATTN_BWD_V_LO / _HI force a range for both cases (0 / 0 = never).
 bool attn_bwd_uses_stat2(int N, int Len, bool table) {
   static int lo = -1, hi = -1;
-  static const bool init = [] { if (const char* v = getenv("RAL_ATTN_BWD_V")) sscanf(v, "%d:%d", &lo, &hi); return true; }();
+  static const bool init = [] { lo = (int)ral_knob("ATTN_BWD_V_LO", -1); hi = (int)ral_knob("ATTN_BWD_V_HI", -1); return true; }();
   (void)init;
   if (N < 64 || N % 4 != 0 || (table && 2 * Len - 1 > 64)) return false;
   if (lo >= 0) return N >= lo && N <= hi;
@@ -1923,12 +1923,8 @@ bool attn_bwd_uses_stat2(int N, int Len, bool table) {
 
 size_t attn_bwd_scratch_floats(int N, int H, int Len, bool table, int B) {
   if (attn_bwd_m_takes(N, H, Len, table)) return attn_bwd_m_scratch_floats(N, H, Len, table, B);
-  if (attn_bwd_mh_takes(N, H, Len, table)) {   // (the larger of its own and the fallback's: the f16 switch is per call)
-    const size_t a = attn_bwd_mh_scratch_floats(N, H, Len, table, B), b = attn_bwd_h_takes(N, H, Len, table) ? attn_bwd_h_scratch_floats(N, H, Len, table, B) : 0;
-    return a > b ? a : b;
-  }
+  if (attn_bwd_mh_takes(N, H, Len, table)) return attn_bwd_mh_scratch_floats(N, H, Len, table, B);
   if (attn_bwd_w_takes(N, H, Len, table)) return attn_bwd_w_scratch_floats(N, H, Len, table, B);
-  if (attn_bwd_h_takes(N, H, Len, table)) return attn_bwd_h_scratch_floats(N, H, Len, table, B);   // (what its f16 form needs)
   if (!attn_bwd_uses_stat2(N, Len, table)) return 0;
   return (size_t)B * H * N * 2 + (size_t)B * 2 * H * 64;
 }
@@ -1950,12 +1946,7 @@ void launch_attn_bwd(const float* qkv, const float* o_hm, const float* do_hm, co
   // short windows: one wave per head, no workgroup barriers (ral_attn.hip)
   if (attn_bwd_w_takes(N, H, Len, table != nullptr) &&
       (stat2 ? scratch_floats : 0) >= attn_bwd_w_scratch_floats(N, H, Len, table != nullptr, B)) {
-    launch_attn_bwd_w(qkv, o_hm, do_hm, lse, table, gtable, dqkv, stat2, N, H, Len, B, f16, s);
-    return;
-  }
-  if (f16 && attn_bwd_h_takes(N, H, Len, table != nullptr) &&
-      (stat2 ? scratch_floats : 0) >= attn_bwd_h_scratch_floats(N, H, Len, table != nullptr, B)) {
-    launch_attn_bwd_h(qkv, o_hm, do_hm, lse, table, gtable, dqkv, stat2, N, H, Len, B, s);
+    launch_attn_bwd_w(qkv, o_hm, do_hm, lse, table, gtable, dqkv, stat2, N, H, Len, B, 0, s);   // (fp32 tiles: strict mode, or the one-sweep kernels switched off)
     return;
   }
   if (stat2 && scratch_floats < (size_t)B * H * N * 2 + (size_t)B * 2 * H * 64) stat2 = nullptr;
@@ -1976,14 +1967,14 @@ void launch_attn_bwd(const float* qkv, const float* o_hm, const float* do_hm, co
     }
     return;
   }
-  static const int split_env = getenv("RAL_ATTN_SPLIT") ? atoi(getenv("RAL_ATTN_SPLIT")) : 2;   // see launch_attn_fwd
+  static const int split_env = (int)ral_knob("ATTN_SPLIT", 2);   // see launch_attn_fwd
   int split = split_env;
   while (split > 1 && (HG % split != 0 || N % 32 != 0)) split /= 2;
   if (split > 1) {
     const int hg = HG / split;
     const size_t l2 = attn_bwd_lds(N, hg, Len);
     const int it2 = B * (H / hg);
-    static const bool nt_off = getenv("RAL_ATTNB_NT0") != nullptr;   // experiment knob: run-time window length everywhere
+    static const bool nt_off = (ral_knob("ATTNB_NT0", 0) != 0);   // experiment knob: run-time window length everywhere
     const int grid2 = cap(it2, env_grid("RAL_GRID_ATTNB", 8192));
 #define NTCASE(n, tab) { RAL_SET_LDS((k_attn_bwd<2, n, tab>), l2); \
       k_attn_bwd<2, n, tab><<<grid2, 512 / split, l2, s>>>(qkv, o_hm, do_hm, lse, table, gtable, dqkv, N, H, hg, Len, B); return; }
@@ -1999,7 +1990,7 @@ void launch_attn_bwd(const float* qkv, const float* o_hm, const float* do_hm, co
   const size_t lds = attn_bwd_lds(N, HG, Len);
   const int items = B * (H / HG);
   const int grid = items < 4096 ? items : 4096;
-  static const bool force1 = getenv("RAL_ATTN_QT1") != nullptr;   // experiment knob
+  static const bool force1 = (ral_knob("ATTN_QT1", 0) != 0);   // experiment knob
   if (N % 32 == 0 && !force1) {
     RAL_SET_LDS((k_attn_bwd<2>), lds);
     k_attn_bwd<2><<<grid, 512, lds, s>>>(qkv, o_hm, do_hm, lse, table, gtable, dqkv, N, H, HG, Len, B);
@@ -2012,7 +2003,7 @@ void launch_attn_bwd(const float* qkv, const float* o_hm, const float* do_hm, co
 size_t qkv_bwd_lds(int C, int N) { return ((size_t)N * 3 * C + (size_t)N * ld_of(C) + 5 * C + 8) * sizeof(float); }
 
 bool qkv_bwd_uses_f16(int C, int N) {
-  static const bool on = !(getenv("RAL_QKVB_F16") && atoi(getenv("RAL_QKVB_F16")) == 0);
+  static const bool on = (ral_knob("QKVB_F16", 1) != 0);
   return on && (C == 32 || C == 64 || C == 128) && N % 32 == 0 && N * 3 * C / 4 <= 6 * 512;
 }
 void launch_qkv_bwd(int C, const float* dqkv, const float* x, const float* pe, const float* dx1, const float* extra,

@@ -1077,11 +1077,11 @@ int danet_forward(DanetModel* m, const float* x, float* y, int B, int training, 
   if (!P.params || !P.state) { snprintf(err, cap, "ral_bind was not called"); return -1; }
   if (B <= 0 || B > P.cfg.max_batch) { snprintf(err, cap, "batch %d outside (0, %d]", B, P.cfg.max_batch); return -1; }
   if (training && B < 2) { snprintf(err, cap, "DANet: a training forward needs at least 2 windows (BatchNorm over the batch of descriptors)"); return -1; }
-  static const int gf = getenv("RAL_DANET_GRID_F") ? atoi(getenv("RAL_DANET_GRID_F")) : 1024;
+  static const int gf = (int)ral_knob("DANET_GRID_F", 1024);
   const int grid = B < gf ? B : gf;
-  static const int gdesc = getenv("RAL_DANET_GRID_D") ? atoi(getenv("RAL_DANET_GRID_D")) : 256;   // descriptor-level kernels: a wave per window,
+  static const int gdesc = (int)ral_knob("DANET_GRID_D", 256);   // descriptor-level kernels: a wave per window,
   const int gridd = (B + 15) / 16 < gdesc ? (B + 15) / 16 : gdesc;                                   // 16 windows per workgroup and pass
-  static const int gact = getenv("RAL_DANET_GRID_A") ? atoi(getenv("RAL_DANET_GRID_A")) : 256;    // elementwise kernels: EW = 4 windows per pass
+  static const int gact = (int)ral_knob("DANET_GRID_A", 256);    // elementwise kernels: EW = 4 windows per pass
   const int grida = (B + 3) / 4 < gact ? (B + 3) / 4 : gact;
   if (training) (void)hipMemsetAsync(m->sums, 0, sizeof(double) * 8 * S_CELL, st);
   m->last_x = x; m->last_B = B; m->last_training = training != 0;
@@ -1127,13 +1127,13 @@ int danet_backward(DanetModel* m, const float* dy, float* dx, int B, hipStream_t
   DanetPublic& P = m->pub;
   if (!P.cfg.train || !P.grads) { snprintf(err, cap, "DANet backward needs train=1 and a bound gradient buffer"); return -1; }
   if (B != m->last_B || !m->last_training) { snprintf(err, cap, "DANet backward needs a training forward of the same batch first"); return -1; }
-  static const int gb = getenv("RAL_DANET_GRID_B") ? atoi(getenv("RAL_DANET_GRID_B")) : 1024;   // (train step at batch 2048: 3.84 / 3.58 / 4.43 ms with 512 / 1024 / 2048)
+  static const int gb = (int)ral_knob("DANET_GRID_B", 1024);   // (train step at batch 2048: 3.84 / 3.58 / 4.43 ms with 512 / 1024 / 2048)
   const int grid = B < gb ? B : gb;
-  static const int gdesc = getenv("RAL_DANET_GRID_D") ? atoi(getenv("RAL_DANET_GRID_D")) : 256;   // descriptor-level kernels (see danet_forward)
+  static const int gdesc = (int)ral_knob("DANET_GRID_D", 256);   // descriptor-level kernels (see danet_forward)
   const int gridd = (B + 15) / 16 < gdesc ? (B + 15) / 16 : gdesc;
-  static const int gact = getenv("RAL_DANET_GRID_A") ? atoi(getenv("RAL_DANET_GRID_A")) : 256;    // elementwise kernels (see danet_forward)
+  static const int gact = (int)ral_knob("DANET_GRID_A", 256);    // elementwise kernels (see danet_forward)
   const int grida = (B + 3) / 4 < gact ? (B + 3) / 4 : gact;
-  static const int gwin = getenv("RAL_DANET_GRID_W") ? atoi(getenv("RAL_DANET_GRID_W")) : 512;   // window-at-a-time kernels with column-sum flushes (train step at batch 2048: 2.33 / 2.23 / 2.26 / 2.44 ms with 1024 / 512 / 256 / 128)
+  static const int gwin = (int)ral_knob("DANET_GRID_W", 512);   // window-at-a-time kernels with column-sum flushes (train step at batch 2048: 2.33 / 2.23 / 2.26 / 2.44 ms with 1024 / 512 / 256 / 128)
   const int gridw = B < gwin ? B : gwin;
   (void)hipMemsetAsync(P.grads, 0, (size_t)m->lay.nparam * sizeof(float), st);
   // the backward halves [T_D2, S_CELL) of the eight cells' sum records: one strided fill

@@ -18,6 +18,12 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Host side, every translation unit: switches (ral_api.hip): compile-time defaults, changed only through ral_global_option (a diagnostic build, -DRAL_DIAG,
+// also reads RAL_<NAME> from the environment); ral_env_int: the two validated environment variables of the product build
+long long ral_knob(const char* name, long long dflt);
+int ral_env_int(const char* name, int dflt, int lo, int hi);
+
+
 #define RAL_DEV __device__ __forceinline__
 
 RAL_DEV f32x4 mfma4(float a, float b, f32x4 c) {

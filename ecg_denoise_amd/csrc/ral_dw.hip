@@ -525,7 +525,7 @@ template <int C>
 static void launch_block_dw_c(const float* dx2, const float* upre, const float* a2c0, const float* dupre, const float* x1,
                               const float* dx1, const float* o_hm, const float* dqkv, const float* x, const float* pe,
                               const BlockP& w, const BlockP& gr, int N, int B, int ks, bool skip_mlp, const unsigned* gmax, hipStream_t s) {
-  static const bool h_on = !(getenv("RAL_DW_F16") && atoi(getenv("RAL_DW_F16")) == 0);
+  static const bool h_on = (ral_knob("DW_F16", 1) != 0);
   const unsigned* gm = (h_on && C >= 32) ? gmax : nullptr;
   if (!skip_mlp) {
   launch_dw_t<C, 4 * C, C, SliceOf<4 * C>::v, LAY_TOK, XF_A2>(dx2, upre, nullptr, nullptr, nullptr, a2c0, gr.w2, gr.b2, N, B, ks, s, gm ? gm + 0 : nullptr);

@@ -910,7 +910,7 @@ __global__ void k_add(const float* __restrict__ a, const float* __restrict__ b, 
 // host launchers
 // =================================================================================
 static inline int grid_for(int items) {
-  static const int gmax = getenv("RAL_GRID_FWD") ? atoi(getenv("RAL_GRID_FWD")) : 4096;
+  static const int gmax = (int)ral_knob("GRID_FWD", 4096);
   return items < gmax ? items : gmax;
 }
 
@@ -928,12 +928,12 @@ void launch_qkv_fwd(int C, const float* x, const float* pe, const BlockP& w, con
       kern<<<(int)(ngroups < wgs ? ngroups : wgs), 256, ldsb, s>>>(x, pe, w, wtp, qkv, N, B);
     };
     // weight-stationary kernel: one workgroup per CU (C = 128) / two (C = 64), token groups of 64 = whole windows
-    static const bool ws = !(getenv("RAL_QKV_WS") && atoi(getenv("RAL_QKV_WS")) == 0);
+    static const bool ws = (ral_knob("QKV_WS", 1) != 0);
     auto gows = [&](auto kern, int C_, int per_cu) {
       const size_t ldsb = (size_t)2 * 2 * 64 * ldb_of(C_) * 2;
       RAL_SET_LDS(kern, ldsb);
       const long ngroups = ((long)B * N + 63) / 64;
-      static const int gq = getenv("RAL_GRID_QKVW") ? atoi(getenv("RAL_GRID_QKVW")) : 0;
+      static const int gq = (int)ral_knob("GRID_QKVW", 0);
       const int wgs = gq > 0 ? gq : 256 * per_cu;
       kern<<<(int)(ngroups < wgs ? ngroups : wgs), 6 * C_, ldsb, s>>>(x, pe, w, wtp, qkv, N, B);
     };
@@ -962,13 +962,13 @@ void launch_attn_fwd(const float* qkv, float* o_hm, float* lse, const float* tab
   if (attn_fwd_w_takes(N, H, Len, table != nullptr)) { launch_attn_fwd_w(qkv, o_hm, lse, table, N, H, Len, B, f16, s); return; }
   // Window lengths [lo, hi] that take the query-per-lane kernel on the scalar path.  Measured at batch 2048
   // (tools/attn_bench.py, us per launch, MFMA-tile kernel vs scalar path): N = 512: 322 / 333, 256: 184 / 172,
-  // 128: 122 / 90, 64: 91 / 51.  RAL_ATTN_FWD_V="lo:hi" overrides (0:0 = never).
+  // 128: 122 / 90, 64: 91 / 51.  The switches ATTN_FWD_V_LO / _HI override (0 / 0 = never).
   static int vlo = 64, vhi = 256;
-  static const bool vinit = [] { if (const char* v = getenv("RAL_ATTN_FWD_V")) sscanf(v, "%d:%d", &vlo, &vhi); return true; }();
+  static const bool vinit = [] { vlo = (int)ral_knob("ATTN_FWD_V_LO", vlo); vhi = (int)ral_knob("ATTN_FWD_V_HI", vhi); return true; }();
   (void)vinit;
   // with the S tile on the f16 matrix cores the tile kernel takes the long windows from the scalar path again
   // (RAL_ATTN_FWD_H = smallest such N, 0 = never)
-  static const int hlo = [] { const char* v = getenv("RAL_ATTN_FWD_H"); return v ? atoi(v) : 256; }();
+  static const int hlo = (int)ral_knob("ATTN_FWD_H", 256);
   const bool tile16 = f16 && hlo > 0 && N >= hlo && N % 32 == 0;
   if (!tile16 && N >= vlo && N <= vhi && N >= 64 && N % 4 == 0 && (!table || 2 * Len - 1 <= 64)) {
     const int ntask = B * H * ((N + 63) / 64);
@@ -979,13 +979,13 @@ void launch_attn_fwd(const float* qkv, float* o_hm, float* lse, const float* tab
   // Workgroup split: 1 / SPLIT of the head group per item and 512 / SPLIT threads, so that 2 * SPLIT workgroups share
   // a CU and one's staging latency and barrier waits hide behind the others' tiles (same waves per CU, same LDS).
   // Measured at batch 2048 (fwd + bwd attention, ms per step): split 1: 7.76, split 2: 7.53 (RAL_ATTN_SPLIT).
-  static const int split_env = getenv("RAL_ATTN_SPLIT") ? atoi(getenv("RAL_ATTN_SPLIT")) : 2;
+  static const int split_env = (int)ral_knob("ATTN_SPLIT", 2);
   int split = split_env;
   while (split > 1 && (HG % split != 0 || N % 32 != 0)) split /= 2;
   if (split > 1) {
     const int hg = HG / split;
     const size_t l2 = attn_fwd_lds(N, hg, Len);
-    static const bool nt_off = getenv("RAL_ATTNF_NT0") != nullptr;   // experiment knob: run-time window length everywhere
+    static const bool nt_off = (ral_knob("ATTNF_NT0", 0) != 0);   // experiment knob: run-time window length everywhere
     if (N == 32 && !table && !nt_off) {
       RAL_SET_LDS((k_attn_fwd<2, 32, false>), l2);
       k_attn_fwd<2, 32, false><<<grid_for(B * (H / hg)), 512 / split, l2, s>>>(qkv, o_hm, lse, table, N, H, hg, Len, B);
@@ -1002,8 +1002,8 @@ void launch_attn_fwd(const float* qkv, float* o_hm, float* lse, const float* tab
   }
   const size_t lds = attn_fwd_lds(N, HG, Len);
   const int items = B * (H / HG);
-  static const bool force1 = getenv("RAL_ATTN_QT1") != nullptr;   // experiment knobs
-  static const bool force4 = getenv("RAL_ATTN_QT4") != nullptr;
+  static const bool force1 = (ral_knob("ATTN_QT1", 0) != 0);   // experiment knobs
+  static const bool force4 = (ral_knob("ATTN_QT4", 0) != 0);
   if (N % 64 == 0 && force4) {
     RAL_SET_LDS((k_attn_fwd<4>), lds);
     k_attn_fwd<4><<<grid_for(items), 512, lds, s>>>(qkv, o_hm, lse, table, N, H, HG, Len, B);
@@ -1031,7 +1031,7 @@ static void launch_mlp_fwd_c(int nch, const float* x, const float* o, const Bloc
 
 // wide levels on split fp16 operands (RAL_MLP_F16=0: the fp32-MFMA kernel everywhere)
 bool mlp_fwd_uses_f16(int C, int N) {
-  static const bool on = !(getenv("RAL_MLP_F16") && atoi(getenv("RAL_MLP_F16")) == 0);
+  static const bool on = (ral_knob("MLP_F16", 1) != 0);
   return on && (C == 32 || C == 64 || C == 128) && N % 32 == 0;
 }
 size_t mlp_fwd_h_lds(int C, int T, int nch) {   // T = tokens of a work item
@@ -1040,8 +1040,8 @@ size_t mlp_fwd_h_lds(int C, int T, int nch) {   // T = tokens of a work item
 // windows per work item and hidden chunks of the split-operand kernel: the most tokens (up to RAL_MLP_TOK, a power-of-two
 // number of windows dividing the batch) whose tiles fit RAL_MLP_HLDS bytes with at most four hidden chunks
 static void mlp_fwd_h_plan(int C, int N, int B, int* wpi_out, int* nch_out) {
-  static const int tokmax = getenv("RAL_MLP_TOK") ? atoi(getenv("RAL_MLP_TOK")) : 0;   // default: one window per item (64 / 128 tokens measured slower: mlp_fwd 1.87 / 1.93 against 1.76 ms per step - one workgroup per CU)
-  static const size_t budget = getenv("RAL_MLP_HLDS") ? (size_t)atoll(getenv("RAL_MLP_HLDS")) : 150 * 1024;
+  static const int tokmax = (int)ral_knob("MLP_TOK", 0);   // default: one window per item (64 / 128 tokens measured slower: mlp_fwd 1.87 / 1.93 against 1.76 ms per step - one workgroup per CU)
+  static const size_t budget = (size_t)ral_knob("MLP_HLDS", 150 * 1024);
   int wpi = 1;
   while (wpi * 2 * N <= tokmax && B % (wpi * 2) == 0 && mlp_fwd_h_lds(C, wpi * 2 * N, 4) <= budget) wpi *= 2;
   int nch = 1;
@@ -1065,7 +1065,7 @@ static void launch_mlp_fwd_hc(const float* x, const float* o, const BlockP& w, c
 void launch_mlp_fwd(int C, int nch, const float* x, const float* o, const BlockP& w, const float* pbase, const void* wh,
                     float* x1, float* upre, float* x2, int N, int B, int f16_narrow, hipStream_t s) {
   if (wh && mlp_fwd_uses_f16(C, N)) {
-    static const int nth = getenv("RAL_MLP_HTHREADS") ? atoi(getenv("RAL_MLP_HTHREADS")) : 512;
+    static const int nth = (int)ral_knob("MLP_HTHREADS", 512);
     if (C == 32) launch_mlp_fwd_hc<32, 512>(x, o, w, pbase, wh, x1, upre, x2, N, B, s);
     else if (C == 64) { if (nth == 1024) launch_mlp_fwd_hc<64, 1024>(x, o, w, pbase, wh, x1, upre, x2, N, B, s); else launch_mlp_fwd_hc<64, 512>(x, o, w, pbase, wh, x1, upre, x2, N, B, s); }
     else { if (nth == 1024) launch_mlp_fwd_hc<128, 1024>(x, o, w, pbase, wh, x1, upre, x2, N, B, s); else launch_mlp_fwd_hc<128, 512>(x, o, w, pbase, wh, x1, upre, x2, N, B, s); }

@@ -97,12 +97,6 @@ void launch_attn_bwd(const float* qkv, const float* o_hm, const float* do_hm, co
 // f16: S and dP tiles as fp16-pair products on the f16 matrix cores (0: exact fp32 MFMA).  attn_f16_default(): 1 unless
 // RAL_ATTN_F16=0 (what the handle-free operator entry points use; a model handle follows its f16_split option)
 int attn_f16_default();
-// long windows with the S / dP tiles on the f16 matrix cores (ral_attn.hip; only with f16 != 0)
-size_t attn_bwd_h_lds(int N, int H, int hg, int Len);
-bool attn_bwd_h_takes(int N, int H, int Len, bool table);
-size_t attn_bwd_h_scratch_floats(int N, int H, int Len, bool table, int B);
-void launch_attn_bwd_h(const float* qkv, const float* o_hm, const float* do_hm, const float* lse, const float* table,
-                       float* gtable, float* dqkv, float* tpart, int N, int H, int Len, int B, hipStream_t s);
 // wave-autonomous kernels of the short windows (ral_attn.hip)
 bool attn_fwd_w_takes(int N, int H, int Len, bool table);
 void launch_attn_fwd_w(const float* qkv, float* o_hm, float* lse, const float* table, int N, int H, int Len, int B, int f16,

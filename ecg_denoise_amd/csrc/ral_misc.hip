@@ -359,7 +359,7 @@ void launch_loss(const float* pred, const float* target, float* dy, float* snr, 
     // (a workgroup ends with atomics on the same words - its share of the sum(s) and its arrival: at batch 2048 x 1024 floats
     // 512 four-wave workgroups were 19 us, 256 eight-wave ones 12.8 with two words in one cache line and 18.8 with four;
     // 128 / 64 workgroups: 13.8 / 13.1 - fewer links but half the CUs pulling the 24 MB.  256 and one line per word)
-    static const int gmax = getenv("RAL_LOSS_GRID") ? atoi(getenv("RAL_LOSS_GRID")) : 256;
+    static const int gmax = [] { const int v = (int)ral_knob("LOSS_GRID", 256); return v < 1 ? 1 : v; }();
     const int g = (B + LOSS_W_WAVES - 1) / LOSS_W_WAVES;
     k_loss_w<<<g < gmax ? g : gmax, 64 * LOSS_W_WAVES, 0, s>>>(pred, target, dy, snr, rmse, loss_sum, n, B, gscale, fin, fin_scale, fin3);
   } else {

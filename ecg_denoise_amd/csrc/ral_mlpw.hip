@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256, RAL_MLPW_WPE) void k_mlp_fwd_wh(const float* _
 // (36 fp32 MFMAs = 1 500 of ~4 200 cycles per tile at C = 16 -> 27 f16 ones that overlap); what is left is the 32 GELU
 // evaluations per lane and tile.
 int mlp_fwd_w_kind(int C, int N, bool want_upre, bool f16_ok) {
-  static const int on = [] { const char* v = getenv("RAL_MLP_FWD_W"); return v ? atoi(v) : 3; }();
+  static const int on = (int)ral_knob("MLP_FWD_W", 3);
   if (!on || want_upre || N % 64 != 0 || !(C == 8 || C == 16 || C == 32)) return 0;   // (64: a whole number of strips at every width)
   if (on >= 3 && f16_ok) return 2;
   if (on == 2) return 1;
@@ -440,7 +440,7 @@ template <int C>
 static void go_mlp_fwd_w(const float* x, const float* o, const BlockP& w, float* x1, float* x2, int N, int B, hipStream_t s) {
   const size_t lds = (size_t)MlpwShape<C>::TOTAL * sizeof(float);
   RAL_SET_LDS((k_mlp_fwd_w<C>), lds);
-  static const int genv = [] { const char* v = getenv("RAL_GRID_MLPW"); return v ? atoi(v) : 0; }();
+  static const int genv = (int)ral_knob("GRID_MLPW", 0);
   static int occ = 0;
   if (!occ && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_mlp_fwd_w<C>, 256, lds) != hipSuccess || occ < 1)) occ = 3;
   const int nwg = (B * (N / (16 * MlpwShape<C>::S)) + 3) / 4;
@@ -452,7 +452,7 @@ template <int C>
 static void go_mlp_fwd_wh(const float* x, const float* o, const BlockP& w, float* x1, float* x2, int N, int B, hipStream_t s) {
   const size_t lds = MlpwhShape<C>::BYTES;
   RAL_SET_LDS((k_mlp_fwd_wh<C>), lds);
-  static const int genv = [] { const char* v = getenv("RAL_GRID_MLPW"); return v ? atoi(v) : 0; }();
+  static const int genv = (int)ral_knob("GRID_MLPW", 0);
   static int occ = 0;
   if (!occ && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_mlp_fwd_wh<C>, 256, lds) != hipSuccess || occ < 1)) occ = 3;
   const int nwg = (B * (N / (16 * MlpwhShape<C>::S)) + 3) / 4;
@@ -560,8 +560,11 @@ __global__ __launch_bounds__(256, RAL_MLPW_WPE) void k_mlp_bwd_w(const float* __
   // tokens per lane - are REQUESTED one tile ahead: a wave has nothing else in flight while it waits, and with three waves
   // per SIMD a round trip per 16 tokens was most of what the tile cost.
   float4 pxa[MT], pda[MT];
-  float pxh = 0.f, pdh = 0.f;
-  auto request = [&](int tl, float4 (&xa)[MT], float4 (&da)[MT], float& hx, float& hd) {
+  constexpr int CPL = C > 16 ? C / 16 : 1;          // halo channels per lane (a halo token is spread over the 16 lanes of a row)
+  float pxh[CPL], pdh[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) { pxh[c] = 0.f; pdh[c] = 0.f; }
+  auto request = [&](int tl, float4 (&xa)[MT], float4 (&da)[MT], float (&hx)[CPL], float (&hd)[CPL]) {
     const int tlc = tl < ntile ? tl : ntile - 1;                      // (past the end: a valid address, never used)
     const int win_ = tlc / tpw, t0_ = (tlc - win_ * tpw) << 4;
     const float* xw_ = x1 + (size_t)win_ * N * C; const float* dw_ = dx2 + (size_t)win_ * N * C;
@@ -573,8 +576,12 @@ __global__ __launch_bounds__(256, RAL_MLPW_WPE) void k_mlp_bwd_w(const float* __
     }
     if (le) {
       const int th = g < 2 ? t0_ - 2 + g : t0_ + 14 + g;
-      const int thc = (th >= 0 && th < N) ? th : 0, rc = r < C ? r : 0;
-      hx = xw_[(size_t)thc * C + rc]; hd = dw_[(size_t)thc * C + rc];
+      const int thc = (th >= 0 && th < N) ? th : 0;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const int rc = r + 16 * c < C ? r + 16 * c : 0;
+        hx[c] = xw_[(size_t)thc * C + rc]; hd[c] = dw_[(size_t)thc * C + rc];
+      }
     }
   };
   request(blockIdx.x * 4 + wave, pxa, pda, pxh, pdh);
@@ -587,23 +594,33 @@ __global__ __launch_bounds__(256, RAL_MLPW_WPE) void k_mlp_bwd_w(const float* __
       xv[m] = cv ? f32x4{pxa[m].x, pxa[m].y, pxa[m].z, pxa[m].w} : zero4;
       dv[m] = cv ? f32x4{pda[m].x, pda[m].y, pda[m].z, pda[m].w} : zero4;
     }
-    const float cxh = pxh, cdh = pdh;
+    float cxh[CPL], cdh[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) { cxh[c] = pxh[c]; cdh[c] = pdh[c]; }
     request(tile + gridDim.x * 4, pxa, pda, pxh, pdh);                 // the next tile's operands
     float hA0[4] = {0.f, 0.f, 0.f, 0.f}, hD[2] = {0.f, 0.f};   // GELU(u[:, 0]) of the halo tokens; da2[:, 0] of t0-1 and t0+16
     if (le) {   // halo tokens t0-2, t0-1, t0+16, t0+17: lane group g = slot, lane r = channel
-      static_assert(C <= 16, "one halo channel per lane");
       const int th = g < 2 ? t0 - 2 + g : t0 + 14 + g;
-      const bool tin = th >= 0 && th < N, lv = r < C;
-      const int rc = lv ? r : 0;
-      const float xh_ = lv ? cxh : 0.f;
-      const float dh_ = lv ? cdh : 0.f;
-      const float mean = group_sum<16>(xh_) * invC;
-      const float d = lv ? xh_ - mean : 0.f;
-      const float rstd = 1.0f / sqrtf(group_sum<16>(d * d) * invC + 1e-5f);
-      const float gg = lv ? (d * rstd * g2[rc] + be2[rc]) * w10[rc] : 0.f;
+      const bool tin = th >= 0 && th < N;
+      float xs = 0.f;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) xs += (r + 16 * c < C) ? cxh[c] : 0.f;
+      const float mean = group_sum<16>(xs) * invC;
+      float dd[CPL], vs = 0.f;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) { dd[c] = (r + 16 * c < C) ? cxh[c] - mean : 0.f; vs += dd[c] * dd[c]; }
+      const float rstd = 1.0f / sqrtf(group_sum<16>(vs) * invC + 1e-5f);
+      float gg = 0.f, dh = 0.f;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const bool lv = r + 16 * c < C;
+        const int rc = lv ? r + 16 * c : 0;
+        gg += lv ? (dd[c] * rstd * g2[rc] + be2[rc]) * w10[rc] : 0.f;
+        dh += lv ? cdh[c] * w2c0[rc] : 0.f;
+      }
       const float u0 = group_sum<16>(gg) + b1[0];
       const float a0 = tin ? gelu_f(u0) : 0.f;
-      const float d0 = tin ? group_sum<16>(dh_ * w2c0[rc]) : 0.f;
+      const float d0 = tin ? group_sum<16>(dh) : 0.f;
       hA0[0] = lane_value(a0, 0); hA0[1] = lane_value(a0, 16); hA0[2] = lane_value(a0, 32); hA0[3] = lane_value(a0, 48);
       hD[0] = lane_value(d0, 16); hD[1] = lane_value(d0, 32);
     }
@@ -787,14 +804,14 @@ __global__ __launch_bounds__(256, RAL_MLPW_WPE) void k_mlp_bwd_w(const float* __
 // RAL_MLP_BWD_W: 0 never, 1: C = 16 only, 2 (default): C = 8 and 16.
 int mlp_bwd_w_kind(int C, int N, bool f16_ok) {
   (void)f16_ok;
-  static const int on = [] { const char* v = getenv("RAL_MLP_BWD_W"); return v ? atoi(v) : 2; }();
+  static const int on = (int)ral_knob("MLP_BWD_W", 2);
   if (!on || N % 16 != 0 || !(C == 16 || (on >= 2 && C == 8))) return 0;
   return 1;
 }
 template <int C>
 static void go_mlp_bwd_w(const float* dx2, const float* x1, const BlockP& w, const BlockP& gr, float* dx1, float* do_hm, int N, int B,
                          bool want_dw, hipStream_t s) {
-  static const int genv = [] { const char* v = getenv("RAL_GRID_MLPBW"); return v ? atoi(v) : 0; }();
+  static const int genv = (int)ral_knob("GRID_MLPBW", 0);
   const int nwg = (B * (N / 16) + 3) / 4;
   const size_t lds = (size_t)MlpbwShape<C>::TOTAL * sizeof(float);
   RAL_SET_LDS((k_mlp_bwd_w<C>), lds);

@@ -1739,11 +1739,11 @@ UNetModel* unet_create(const ral_config* c, char* err, size_t cap) {
     return nullptr;
   }
   unet_plan(*c, m, m->slab);
-  m->fused = !(getenv("RAL_UNET_FUSED") && atoi(getenv("RAL_UNET_FUSED")) == 0);
+  m->fused = (ral_knob("UNET_FUSED", 1) != 0);
   if (c->train) {
     // the specialised backward kernels (all of them apply when every level's length is a multiple of 4) leave their
     // weight-gradient partials in scratch rows; otherwise some stage runs the generic kernel and everything stays atomic
-    m->fold = c->L % 64 == 0 && !(getenv("RAL_UNET_FOLD") && atoi(getenv("RAL_UNET_FOLD")) == 0);
+    m->fold = c->L % 64 == 0 && (ral_knob("UNET_FOLD", 1) != 0);
     std::vector<int> cols;
     const int ch[5] = {c->leads, 4, 8, 16, 32};
     const int Cs[11] = {4, 8, 16, 32, 32, 32, 32, 16, 8, 4, ch[0]};
@@ -1915,8 +1915,8 @@ int unet_forward_stage(UNetModel* m, const float* x, int B, int training, int si
       else (void)hipMemsetAsync(P.bn_sums, 0, 1280 * sizeof(double), s);
     }
   } else if (x != m->last_x || B != m->last_B) { snprintf(err, cap, "U-Net stages must follow stage 0 of the same batch"); return -1; }
-  static const int fgmax = getenv("RAL_UNET_FWD_GRID") ? atoi(getenv("RAL_UNET_FWD_GRID")) : 512;   // (train forward at batch 2048: 0.31 / 0.27 / 0.29 / 0.41 ms with 256 / 512 / 1024 / 2048 workgroups)
-  static const int egmax = getenv("RAL_UNET_EVAL_GRID") ? atoi(getenv("RAL_UNET_EVAL_GRID")) : 512;   // (stage-by-stage eval forward at batch 2048: 173 / 158 / 177 us with 256 / 512 / 1024 workgroups)
+  static const int fgmax = (int)ral_knob("UNET_FWD_GRID", 512);   // (train forward at batch 2048: 0.31 / 0.27 / 0.29 / 0.41 ms with 256 / 512 / 1024 / 2048 workgroups)
+  static const int egmax = (int)ral_knob("UNET_EVAL_GRID", 512);   // (stage-by-stage eval forward at batch 2048: 173 / 158 / 177 us with 256 / 512 / 1024 workgroups)
   const int gcap = training ? fgmax : egmax;
   const int grid = B < gcap ? B : gcap;
   Stage st = make_stage(m, si, x, training != 0, false, B, (double)gwin);
@@ -1983,8 +1983,8 @@ static int unet_forward_fused(UNetModel* m, const float* x, float* y, int B, hip
     const hipError_t e = P.cfg.leads == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_unet_infer<1>, 256, lds)
                                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_unet_infer<2>, 256, lds);
     if (e != hipSuccess || per_cu < 1) per_cu = 1;
-    if (getenv("RAL_UNET_DEBUG")) fprintf(stderr, "k_unet_infer: lds %zu B, occupancy query -> %d workgroups per CU (rc %d), %d CUs\n", lds, per_cu, (int)e, ncu);
-    if (const char* v = getenv("RAL_UNET_WG_PER_CU")) per_cu = atoi(v) > 0 ? atoi(v) : per_cu;
+    if (ral_knob("UNET_DEBUG", 0)) fprintf(stderr, "k_unet_infer: lds %zu B, occupancy query -> %d workgroups per CU (rc %d), %d CUs\n", lds, per_cu, (int)e, ncu);
+    { const int v = (int)ral_knob("UNET_WG_PER_CU", 0); if (v > 0) per_cu = v; }
     m->infer_grid = per_cu * ncu;
   }
   const int grid = B < m->infer_grid ? B : m->infer_grid;
@@ -1995,7 +1995,7 @@ static int unet_forward_fused(UNetModel* m, const float* x, float* y, int B, hip
 }
 
 static int unet_nrep() {
-  static const int n = [] { const char* v = getenv("RAL_UNET_NREP"); int k = v ? atoi(v) : UNET_MAXREP; return k < 1 ? 1 : (k > UNET_MAXREP ? UNET_MAXREP : k); }();
+  static const int n = [] { int k = (int)ral_knob("UNET_NREP", UNET_MAXREP); return k < 1 ? 1 : (k > UNET_MAXREP ? UNET_MAXREP : k); }();
   return n;
 }
 
@@ -2077,8 +2077,8 @@ int unet_backward_stage(UNetModel* m, int B, int si, int64_t gwin, hipStream_t s
   // every workgroup ends with ~2 000 global atomics (its share of dW, db and the BatchNorm-backward sums): the chip retires
   // ~75 of them per ns, so 1024 workgroups spend 30 us per launch on them alone.  Measured train step at batch 2048 with
   // 1024 / 512 / 384 workgroups: 1.23 / 1.08 / 1.12 ms (RAL_UNET_BWD_GRID)
-  static const int gmax0 = getenv("RAL_UNET_BWD_GRID") ? atoi(getenv("RAL_UNET_BWD_GRID")) : 512;
-  static const int wp = getenv("RAL_UNET_BWD_WP") ? atoi(getenv("RAL_UNET_BWD_WP")) : 2;
+  static const int gmax0 = (int)ral_knob("UNET_BWD_GRID", 512);
+  static const int wp = (int)ral_knob("UNET_BWD_WP", 2);
   const int gmax = (m->fold && gmax0 > m->part_rows_max) ? m->part_rows_max : gmax0;
   const int grid = B < gmax ? B : gmax;
   if (m->last_dy == nullptr) { snprintf(err, cap, "U-Net backward stages must follow ral_unet_backward_start"); return -1; }

@@ -26,3 +26,15 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_sessionstart(session):
+    """`RAL_TEST_OPTIONS="attn_f16=0,mlp_fwd_w=2"`: process-wide library switches for this test process, set through the C ABI
+    (ral_global_option) before the library is first used - the library itself reads no environment variable for them.
+    The tests that run every kernel choice start pytest subprocesses with this variable."""
+    import os
+    opts = os.environ.get("RAL_TEST_OPTIONS", "")
+    if not opts:
+        return
+    from ecg_denoise_amd import _lib
+    _lib.apply_options(opts)

@@ -2,9 +2,9 @@
 torch autograd restatement of `softmax(q k^T + R-wave bias) v` (raletransformer.py:299-316; bias table :534-558), one case
 per kernel the launchers can pick (default switches; `test_every_kernel_choice_of_the_launchers` re-runs the file with the
 others):
-  * N = 512 / 256, with and without a table: k_attn_bwd_h (workgroup per head group, S / dP tiles as fp16-pair products),
-    forward k_attn_fwd<2, 0, true, true> (f16 S tile)
-  * N = 128 / 64 / 32, with and without a table: k_attn_bwd_w (one wave per head, rotated tiles with a table), forward
+  * N = 512 / 256, with and without a table: k_attn_bwd_mh (workgroup per head group, ONE sweep, every contraction on the
+    f16 matrix cores), forward k_attn_fwd<2, 0, true, true> (f16 S tile)
+  * N = 128 / 64 / 32, with and without a table: k_attn_bwd_m (one wave per head, rotated tiles with a table), forward
     k_attn_fwd_v (N = 64, 128) and k_attn_fwd_w (N = 32)
   * N = 48 (L = 768 windows) and N = 1024: the generic kernels of ral_bwd.hip / ral_fwd.hip (QT = 1; one head per item)
   * a table as wide as the window (N = 32, Len = 8 ... N = 64, Len = 32): every tile takes the table path
@@ -154,20 +154,21 @@ def test_attention_backward_rejects_missing_scratch():
     assert rc != 0
 
 
-@pytest.mark.parametrize("env", [
-    {"RAL_ATTN_F16": "0"},                                                        # fp32-MFMA tiles in the new kernels (strict mode)
-    {"RAL_ATTN_BWD_W": "0", "RAL_ATTN_BWD_H": "0", "RAL_ATTN_FWD_W": "0", "RAL_ATTN_FWD_H": "0"},   # the workgroup / scalar-path kernels of ral_fwd.hip, ral_bwd.hip
-    {"RAL_ATTN_FWD_W": "2"},                                                      # wave-autonomous forward at N = 64 and 128 too
-    {"RAL_ATTN_FWD_W": "2", "RAL_ATTN_F16": "0"},
+@pytest.mark.parametrize("opts", [
+    "attn_f16=0",                                              # strict mode: the two-sweep kernels with fp32-MFMA tiles
+    "attn_bwd_m=0,attn_bwd_mh=0",                              # the one-sweep matrix-core backward switched off (two-sweep kernels take f16 callers too)
+    "attn_bwd_m=0,attn_bwd_mh=0,attn_bwd_w=0,attn_fwd_w=0,attn_fwd_h=0",   # the workgroup / scalar-path kernels of ral_fwd.hip, ral_bwd.hip
+    "attn_fwd_w=2",                                            # wave-autonomous forward at N = 64 and 128 too
+    "attn_fwd_w=2,attn_f16=0",
 ])
-def test_every_kernel_choice_of_the_launchers(env):
-    """The launchers pick kernels by shape and by process-wide switches (read once): each alternative choice runs the
-    fp64 comparison of this file in a process of its own."""
+def test_every_kernel_choice_of_the_launchers(opts):
+    """The launchers pick kernels by shape and by process-wide switches (ral_global_option, read once): each alternative
+    choice runs the fp64 comparison of this file in a process of its own (tests/conftest.py applies RAL_TEST_OPTIONS)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
                         "against_fp64 or many_windows or operand_ranges or non_finite"],
-                       env=dict(os.environ, **env), cwd=root, capture_output=True, text=True, timeout=900)
+                       env=dict(os.environ, RAL_TEST_OPTIONS=opts), cwd=root, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]

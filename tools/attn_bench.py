@@ -14,6 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from ecg_denoise_amd import _lib
+_lib.apply_options(os.environ.get("RAL_TOOL_OPTIONS", ""))   # library switches for this run (diagnostics), e.g. attn_f16=0
 
 DEV = "cuda:0"
 PEAK = 157.3

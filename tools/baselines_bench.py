@@ -1,3 +1,4 @@
+import os
 """Throughput of the comparison baselines (SURVEY 8 f4) on one MI355X at batch 2048 x 2 x 512: train step and inference
 forward of ACDAE and DANet, and the db8 wavelet-threshold denoiser.  One JSON line per model."""
 import json, os, sys, time

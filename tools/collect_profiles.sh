@@ -23,13 +23,13 @@ U="python3 tools/unet_bench.py"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/unet_ks -- $U > $O/unet_ks.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/unet_fetch -- $U > $O/unet_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/unet_write -- $U > $O/unet_write.log 2>&1
-export RAL_UNET_FUSED=0
+export RAL_TOOL_OPTIONS=unet_fused=0
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/unet_staged_ks -- $U > $O/unet_staged_ks.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/unet_staged_fetch -- $U > $O/unet_staged_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/unet_staged_write -- $U > $O/unet_staged_write.log 2>&1
-unset RAL_UNET_FUSED
+unset RAL_TOOL_OPTIONS
 python3 tools/attn_bench.py > $O/attn_bench.log 2>&1
-RAL_ATTN_F16=0 python3 tools/attn_bench.py > $O/attn_bench_fp32.log 2>&1
+RAL_TOOL_OPTIONS=attn_f16=0 python3 tools/attn_bench.py > $O/attn_bench_fp32.log 2>&1
 python3 tools/diag/step_timeline_events.py $O/step_timeline_events.txt > /dev/null 2>&1
 RAL_LANES=1 RAL_NO_SIDE_STREAM=1 python3 tools/diag/step_timeline_events.py $O/step_timeline_events_serial.txt > /dev/null 2>&1
 [ -x tools/diag/valu_probe ] && ./tools/diag/valu_probe > $O/valu_probe.log 2>&1

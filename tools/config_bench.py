@@ -1,3 +1,4 @@
+import os
 """Throughput of the BASELINE configurations that bench.py does not time (one MI355X each):
   C3  12-lead 1024-sample windows through newrale (inner RA-LENet 'full', 2 x 1024), batch 256 per GPU, train step
   C4  inference: 30-minute 2-lead records (650 000 samples) streamed in batches of 4096 512-sample windows,

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Per-kernel statistics of the bench step for kernels matching a pattern, optionally with extra environment settings:
-#   gpurun -- 'bash tools/diag/prof_kernel.sh "qkv_fwd|split" RAL_F16_SPLIT=0'
+#   gpurun -- 'bash tools/diag/prof_kernel.sh "qkv_fwd|split" --opt f16_split=0'
 PAT=$1; shift
 for kv in "$@"; do export "$kv"; done
 cd /tmp && export TMPDIR=/tmp

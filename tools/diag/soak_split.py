@@ -1,8 +1,10 @@
 """Soak of the split-operand kernels: 300 training steps on fresh random batches (batch 256 x 2 x 512), the loss trajectory of
-the default arithmetic next to the fp32-MFMA one (RAL_F16_SPLIT=0) from the same weights and data: finite everywhere, and the
+the default arithmetic next to the fp32-MFMA one (the switch f16_split = 0) from the same weights and data: finite everywhere, and the
 two stay within the run-to-run noise of the fp32 atomics for the first steps.   python tools/diag/soak_split.py"""
 import os, sys, subprocess, json
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ecg_denoise_amd import _lib
+_lib.apply_options(os.environ.get("RAL_TOOL_OPTIONS", ""))
 if len(sys.argv) > 1:
     sys.path.insert(0, ROOT)
     import torch
@@ -20,7 +22,7 @@ if len(sys.argv) > 1:
 else:
     res = {}
     for split in ("64", "0"):
-        env = dict(os.environ, RAL_F16_SPLIT=split)
+        env = dict(os.environ, RAL_TOOL_OPTIONS="f16_split=" + split)
         r = subprocess.run([sys.executable, __file__, "run"], env=env, capture_output=True, text=True)
         if r.returncode != 0 or not r.stdout.strip():
             sys.exit("run failed:\n" + r.stderr[-2000:])

@@ -4,7 +4,8 @@ import os, sys, time, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-from ecg_denoise_amd import UNet
+from ecg_denoise_amd import UNet, _lib
+_lib.apply_options(os.environ.get("RAL_TOOL_OPTIONS", ""))   # library switches for this run (diagnostics), e.g. unet_fused=0
 B, leads, L = int(os.environ.get("B", 2048)), 2, 512
 m = UNet(leads=leads, L=L, max_batch=B, device="cuda:0", seed=1)
 g = torch.Generator().manual_seed(2023)
