@@ -230,14 +230,17 @@ RAL_DEV int dw_tile(int s, int slots) { return (s + (int)blockIdx.x) % slots; }
 
 // LDS atomic add of the sum over groups of `w` consecutive lanes (w = 1: every lane adds its own value; w in {8, 16,
 // 32, 64}: the group's first lane adds the group sum - same-address LDS atomics of a wave execute one after the other)
-RAL_DEV void seg_atomic(float* addr, float v, int w) {
-  if (w == 1) { atomicAdd(addr, v); return; }
+// (the fast stage kernels keep these accumulators in DOUBLES: ds_add_f64 takes 8 LDS cycles per wave-instruction on gfx950,
+// ds_add_f32 three per active lane - 49 for the sixteen lanes of an MFMA tile's column sums; tools/diag/lds_cost_probe.hip)
+template <class T>
+RAL_DEV void seg_atomic(T* addr, float v, int w) {
+  if (w == 1) { atomicAdd(addr, (T)v); return; }
   const int lane = threadIdx.x & 63;
   if (w == 64) v = group_sum<64>(v);
   else if (w == 32) v = group_sum<32>(v);
   else if (w == 16) v = group_sum<16>(v);
   else v = group_sum<8>(v);
-  if ((lane & (w - 1)) == 0) atomicAdd(addr, v);
+  if ((lane & (w - 1)) == 0) atomicAdd(addr, (T)v);
 }
 
 // ---------------------------------------------------------------------------------
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(UNET_FWD_THREADS) void k_unet_fwd_t(Stage st, int B
   float* ws = rt + (st.r.z ? WP * COUT * lout : 0);
   float* bs = ws + WSZ;
   float* ca = bs + MAXC; float* cb = ca + 4 * MAXC; float* cr = cb + 4 * MAXC;
-  float* red = cr + 4 * MAXC;
+  double* red = reinterpret_cast<double*>(cr + 4 * MAXC);   // column sums of the output (S1 | S2), doubles
   UB_STAMP_INIT();
   // every global load of the prologue is requested before the first is waited for: the BatchNorm records of the
   // operands, the weights (at most 3 float4 per thread) and the bias
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(UNET_FWD_THREADS) void k_unet_fwd_t(Stage st, int B
     if (i < nw / 4) st_f4_as_f2(ws + (WLD == FKTOT ? 4 * i : (4 * i / FKTOT) * WLD + (4 * i) % FKTOT), wv[k]);
   }
   if ((int)threadIdx.x < COUT) bs[threadIdx.x] = bv;
-  for (int i = threadIdx.x; i < 2 * MAXC; i += blockDim.x) red[i] = 0.f;
+  for (int i = threadIdx.x; i < 2 * MAXC; i += blockDim.x) red[i] = 0.;
   for (int i = threadIdx.x; i < WP * CIN * 2 * HALO; i += blockDim.x) {   // halos stay zero for every pass
     const int c = i / (2 * HALO), h = i % (2 * HALO);
     in[c * LP + (h < HALO ? h : lin + h)] = 0.f;
@@ -437,7 +440,7 @@ __global__ __launch_bounds__(UNET_FWD_THREADS) void k_unet_fwd_t(Stage st, int B
         }
         if (st.sums_out) {   // the four position groups of a channel meet in one lane: one LDS atomic per channel, tile and sum
           s1 = rows_sum(s1); s2 = rows_sum(s2);
-          if (g4 == 0 && cow < COUT) { atomicAdd(red + cow, s1); atomicAdd(red + MAXC + cow, s2); }
+          if (g4 == 0 && cow < COUT) { atomicAdd(red + cow, (double)s1); atomicAdd(red + MAXC + cow, (double)s2); }
         }
       }
     } else
@@ -498,8 +501,8 @@ __global__ __launch_bounds__(UNET_FWD_THREADS) void k_unet_fwd_t(Stage st, int B
   }
   if (st.sums_out && (int)threadIdx.x < COUT) {
     double* rec = st.sums_out + (size_t)(blockIdx.x % st.nrep) * 64;
-    atomicAdd(rec + threadIdx.x, (double)red[threadIdx.x]);
-    atomicAdd(rec + MAXC + threadIdx.x, (double)red[MAXC + threadIdx.x]);
+    atomicAdd(rec + threadIdx.x, red[threadIdx.x]);
+    atomicAdd(rec + MAXC + threadIdx.x, red[MAXC + threadIdx.x]);
   }
   UB_STAMP(12);
 }
@@ -549,7 +552,7 @@ __global__ __launch_bounds__(256) void k_unet_gsums(const float* __restrict__ G,
   __shared__ float ss[4 * MAXC];
   __shared__ float red[2 * MAXC];
   src_coeffs(s, C, count, ss);
-  for (int i = threadIdx.x; i < 2 * MAXC; i += blockDim.x) red[i] = 0.f;
+  for (int i = threadIdx.x; i < 2 * MAXC; i += blockDim.x) red[i] = 0.;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, L4 = L >> 2;
   const size_t rows = total / L;
@@ -580,8 +583,8 @@ __global__ __launch_bounds__(256) void k_unet_gsums(const float* __restrict__ G,
   __syncthreads();
   if ((int)threadIdx.x < C) {
     double* rec = bsums + (size_t)(blockIdx.x % nrep) * 64;
-    atomicAdd(rec + threadIdx.x, (double)red[threadIdx.x]);
-    atomicAdd(rec + MAXC + threadIdx.x, (double)red[MAXC + threadIdx.x]);
+    atomicAdd(rec + threadIdx.x, red[threadIdx.x]);
+    atomicAdd(rec + MAXC + threadIdx.x, red[MAXC + threadIdx.x]);
   }
 }
 
@@ -799,8 +802,9 @@ __global__ __launch_bounds__(UNET_BWD_THREADS, 2) void k_unet_bwd_t(Stage st, in
   float* ws = dc + ((WP * COUT * LPO + 3) & ~3);  // weights (16-byte aligned)
   float* gws = ws + BWSZ;                        // weight-gradient partial of the workgroup
   float* ca = gws + nw; float* cb = ca + 4 * MAXC; float* cr = cb + 4 * MAXC; float* co_ = cr + 4 * MAXC;
-  float* sa = co_ + 5 * MAXC; float* sb = sa + 2 * MAXC; float* sr = sb + 2 * MAXC;
-  float* gbs = sr + 2 * MAXC;                    // MAXC bias grads + 4*MAXC scratch
+  // backward BatchNorm sums of the operands / the residual and the bias gradient: doubles (see seg_atomic)
+  double* sa = reinterpret_cast<double*>(co_ + 5 * MAXC); double* sb = sa + 2 * MAXC; double* sr = sb + 2 * MAXC;
+  double* gbs = sr + 2 * MAXC;                   // MAXC bias grads
   // every global load of the prologue is requested before the first is waited for: the BatchNorm records and affine
   // parameters of the operands and of this stage's output (forward statistics and backward sums) and the weights
   Src o; o.norm = st.type != TY_PLAIN ? NORM_BATCH : NORM_NONE; o.sums = st.sums_out; o.nrep = 1; o.gamma = st.gamma_out; o.beta = st.gamma_out; o.act = ACT_NONE;
@@ -822,7 +826,7 @@ __global__ __launch_bounds__(UNET_BWD_THREADS, 2) void k_unet_bwd_t(Stage st, in
     if (i < nw / 4) st_f4_as_f2(ws + (BWLD == BWROW ? 4 * i : (4 * i / BWROW) * BWLD + (4 * i) % BWROW), wv[k]);
   }
   for (int i = threadIdx.x; i < nw; i += NT) gws[i] = 0.f;
-  for (int i = threadIdx.x; i < 7 * MAXC; i += NT) sa[i] = 0.f;   // sa, sb, sr, gbs[0:MAXC]
+  for (int i = threadIdx.x; i < 7 * MAXC; i += NT) sa[i] = 0.;   // sa, sb, sr, gbs[0:MAXC]
   for (int i = threadIdx.x; i < WP * CIN * 2 * HALO; i += NT) {
     const int c = i / (2 * HALO), h = i % (2 * HALO);
     in[c * LP + (h < HALO ? h : lin + h)] = 0.f;
@@ -1050,10 +1054,10 @@ __global__ __launch_bounds__(UNET_BWD_THREADS, 2) void k_unet_bwd_t(Stage st, in
         // the sums of a channel are added up across the four position groups of the tile (lanes r, r + 16, r + 32,
         // r + 48) before ONE LDS atomic per channel and tile: same-address LDS atomics of a wave run one after the other
         s1a = rows_sum(s1a); s2a = rows_sum(s2a);
-        if (g4 == 0 && cokw && st.a.bsums) { atomicAdd(sa + cibw, s1a); atomicAdd(sa + MAXC + cibw, s2a); }
+        if (g4 == 0 && cokw && st.a.bsums) { atomicAdd(sa + cibw, (double)s1a); atomicAdd(sa + MAXC + cibw, (double)s2a); }
         if (has_b && st.b.G) {
           s1b = rows_sum(s1b); s2b = rows_sum(s2b);
-          if (g4 == 0 && cokw) { atomicAdd(sb + cibw, s1b); atomicAdd(sb + MAXC + cibw, s2b); }
+          if (g4 == 0 && cokw) { atomicAdd(sb + cibw, (double)s1b); atomicAdd(sb + MAXC + cibw, (double)s2b); }
         }
       }
     }
@@ -1134,10 +1138,10 @@ __global__ __launch_bounds__(UNET_BWD_THREADS, 2) void k_unet_bwd_t(Stage st, in
     float* row = st.part + (size_t)blockIdx.x * st.part_stride;
     for (int i = threadIdx.x; i < (nw >> 2); i += NT)
       reinterpret_cast<float4*>(row + st.part_w)[i] = reinterpret_cast<const float4*>(gws)[i];
-    if ((int)threadIdx.x < COUT) row[st.part_b + threadIdx.x] = gbs[threadIdx.x];
+    if ((int)threadIdx.x < COUT) row[st.part_b + threadIdx.x] = (float)gbs[threadIdx.x];
   } else {
     for (int i = threadIdx.x; i < nw; i += NT) atomicAdd(st.gw + i, gws[i]);
-    if ((int)threadIdx.x < COUT) atomicAdd(st.gb + threadIdx.x, gbs[threadIdx.x]);
+    if ((int)threadIdx.x < COUT) atomicAdd(st.gb + threadIdx.x, (float)gbs[threadIdx.x]);
   }
   if ((int)threadIdx.x < CIN) {
     if (st.a.G && st.a.bsums) {
@@ -1865,7 +1869,7 @@ static void launch_fwd_t(const Stage& st, int B, int grid, hipStream_t s) {
   // stages take 64 KB at WP = 2 already); dynamic LDS above 64 KB is opted into per instantiation
   auto lds_of = [&](int WP) {
     return ((size_t)WP * CIN * (st.lin + 8) + (st.r.z ? (size_t)WP * COUT * st.lout : 0) + (size_t)COUT * (CIN * KS + 4) + MAXC +
-            12 * MAXC + 2 * MAXC + 8) * sizeof(float);   // (weights: rows padded by up to 4 floats)
+            12 * MAXC + 4 * MAXC + 8) * sizeof(float);   // (weights: rows padded by up to 4 floats; the column sums are doubles)
   };
   int WP = (B + grid - 1) / grid;
   if (WP > 4) WP = 4;
@@ -2017,7 +2021,7 @@ static void launch_bwd_t(const Stage& st, int B, int grid, int wp_req, hipStream
   const bool want_din = st.a.G != nullptr, third = st.b.z != nullptr || (want_din && st.a.accumulate);
   auto lds_of = [&](int WP) {
     return ((size_t)WP * CIN * (st.lin + 8) * (1 + (want_din ? 1 : 0) + (third ? 1 : 0)) + (size_t)WP * COUT * (st.lout + 10) +
-            (size_t)2 * CIN * COUT * KS + 4 * CIN + 28 * MAXC + 12) * sizeof(float);   // (weights: rows padded by up to 4 floats)
+            (size_t)2 * CIN * COUT * KS + 4 * CIN + 31 * MAXC + 12) * sizeof(float);   // (weights: rows padded by up to 4 floats; 7 MAXC doubles of sums)
   };
   int WP = (B + grid - 1) / grid;                 // windows per workgroup
   if (WP > wp_req) WP = wp_req;
