@@ -126,7 +126,9 @@ __global__ __launch_bounds__(256, RAL_ATTNM_WPE) void k_attn_bwd_m(const float* 
   constexpr int T = HW * NT, TPL = T / 64;     // tokens per task, tokens per lane
   constexpr int KT = NT / 16;                  // key (query) tiles per head
   constexpr int BUF = 160;                     // floats of one dS piece tile: 16 key rows of 40 bytes
-  constexpr int WSZ = T * 18 + 4 * BUF;        // floats of LDS per wave
+  constexpr int PPAD = 32;                     // floats between plane images: the transposing reads take k with v (dO with q) chunks in one
+                                               // instruction, and images a multiple of 64 dwords apart would put them on the same banks
+  constexpr int WSZ = T * 18 + 4 * PPAD + 4 * BUF;   // floats of LDS per wave
   constexpr int SH = TAB ? 8 : 0, MSK = NT - 1;   // tiles rotated by 8 tokens with a table (see k_attn_bwd_w)
   extern __shared__ float4 smem4[];
   float* sm = reinterpret_cast<float*>(smem4);
@@ -134,10 +136,10 @@ __global__ __launch_bounds__(256, RAL_ATTNM_WPE) void k_attn_bwd_m(const float* 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // plane images, 16 bytes per token: [h1 x 4 | h2 x 4] of q log2 e cq, k ck, v cv, dO cd
   float* Qp = sm + wave * WSZ;
-  float* Kp = Qp + 4 * T;
-  float* Vp = Kp + 4 * T;
-  float* Dp = Vp + 4 * T;
-  float* Ls = Dp + 4 * T;          // RAL_PSH - lse log2 e
+  float* Kp = Qp + 4 * T + PPAD;
+  float* Vp = Kp + 4 * T + PPAD;
+  float* Dp = Vp + 4 * T + PPAD;
+  float* Ls = Dp + 4 * T + PPAD;   // RAL_PSH - lse log2 e
   float* Dl = Ls + T;              // -rowsum(dO O) cd cv
   float* Xb = Dl + T;              // dS piece tiles: [parity][piece][key 16][query 16 (+4 pad)] halves
   const int Len = TAB ? Len_rt : 0;
@@ -360,11 +362,12 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd_mh(const float* __restrict_
   extern __shared__ float4 smem4[];
   float* sm = reinterpret_cast<float*>(smem4);
   const int T = HG * N;
+  constexpr int PPAD = 32;                                // (see k_attn_bwd_m)
   float* Qp = sm;
-  float* Kp = Qp + 4 * T;
-  float* Vp = Kp + 4 * T;
-  float* Dp = Vp + 4 * T;
-  float* Ls = Dp + 4 * T;
+  float* Kp = Qp + 4 * T + PPAD;
+  float* Vp = Kp + 4 * T + PPAD;
+  float* Dp = Vp + 4 * T + PPAD;
+  float* Ls = Dp + 4 * T + PPAD;
   float* Dl = Ls + T;
   // dQ image, (T, 4) DOUBLES in units of 1 / sc_dq: on gfx950 ds_add_f64 takes 8 LDS cycles per wave-instruction, ds_add_f32
   // 192 (three per lane; tools/diag/lds_cost_probe.hip) - with fp32 adds this image was 48 of the 74 LDS cycles of a tile
@@ -591,7 +594,7 @@ size_t attn_bwd_m_scratch_floats(int N, int H, int Len, bool table, int B) {
 // ---- long windows
 static int attnmh_kt(int N) { return N >= 1024 ? 8 : 4; }
 size_t attn_bwd_mh_lds(int N, int H, int hg, int Len) {
-  return ((size_t)26 * hg * N + 4 * hg + 8 * 4 * 160 + (Len > 0 ? (size_t)3 * (2 * Len - 1) * H + 2 : 0) + 4) * sizeof(float);
+  return ((size_t)26 * hg * N + 4 * 32 + 4 * hg + 8 * 4 * 160 + (Len > 0 ? (size_t)3 * (2 * Len - 1) * H + 2 : 0) + 4) * sizeof(float);
 }
 static int attnmh_hg(int N, int H) {   // heads per item: eight waves of KT key tiles each
   const int wph = N / (16 * attnmh_kt(N));
@@ -634,7 +637,7 @@ void launch_attn_bwd_m(const float* qkv, const float* o_hm, const float* do_hm, 
   const int ntask = B * H / hw;
   const int ntab = table ? (2 * Len - 1) * H : 0;
   const int nwv = 4;
-  const size_t lds = ((size_t)nwv * (T * 18 + 4 * 160) + 3 * ntab + 2) * sizeof(float);
+  const size_t lds = ((size_t)nwv * (T * 18 + 4 * 32 + 4 * 160) + 3 * ntab + 2) * sizeof(float);
   int grid = 0;
   auto grid_of = [&](auto kern) {
     const int gmax = attnw_grid_max(N, H, B);          // (the scratch is sized for one workgroup per four tasks)
