@@ -114,8 +114,7 @@ RAL_DEV float f4amax(float4 v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fma
 #define RAL_ATTNM_WPE 4
 #endif
 
-// One wave per head (two heads at N = 32), N = 32, 64, 128: operands in a private LDS slice, the next task's operands
-// requested under the current task's tiles (as k_attn_bwd_w).  Loop order: query tile outside (dQ^T of the tile in one
+// One wave per head (two heads at N = 32), N = 32, 64, 128: operands in a private LDS slice, no workgroup barrier in the task loop.  Loop order: query tile outside (dQ^T of the tile in one
 // accumulator), key tiles inside (dV^T / dK^T of every key tile of the head in KT accumulators, statically indexed).
 template <int NT, bool TAB>
 __global__ __launch_bounds__(256, RAL_ATTNM_WPE) void k_attn_bwd_m(const float* qkv, const float* o_hm, const float* do_hm,
@@ -160,8 +159,6 @@ __global__ __launch_bounds__(256, RAL_ATTNM_WPE) void k_attn_bwd_m(const float* 
   // per-task factors (wave-uniform): results x these; su = 1 / (cq ck) brings the score tile back to log2 units
   float sc_dq = 1.f, sc_dk = 1.f, sc_dv = 1.f, sc_tab = 1.f, su = 1.f;
 
-  float4 pq, pk, pv, pd, po;
-  float pl;
   auto task_ptrs = [&](int tk, const float4*& gq, const float4*& gk, const float4*& gv, const float4*& gd, const float4*& go,
                        const float*& gl) {
     const int hh = tk * HW, win = hh / H, h0 = hh - win * H;
@@ -193,16 +190,6 @@ __global__ __launch_bounds__(256, RAL_ATTNM_WPE) void k_attn_bwd_m(const float* 
     sc_dk = RAL_LN2 * sc_tab * pow2_inv(cq); // the q planes carried log2(e) cq
     sc_dv = RAL_PSH_INV * icd;
   };
-  auto request = [&](int tk) {
-    const float4 *gq, *gk, *gv, *gd, *go; const float* gl;
-    task_ptrs(tk, gq, gk, gv, gd, go, gl);
-    pq = gq[lane]; pk = gk[lane]; pv = gv[lane]; pd = gd[lane]; po = go[lane]; pl = gl[lane];
-  };
-  auto deposit = [&]() {
-    float cq, ck, cv, cd;
-    scales(f4amax(pq), f4amax(pk), f4amax(pv), f4amax(pd), cq, ck, cv, cd);
-    put(lane, pq, pk, pv, pd, po, pl, cq, ck, cv, cd);
-  };
   auto stage = [&](int tk) {
     const float4 *gq, *gk, *gv, *gd, *go; const float* gl;
     task_ptrs(tk, gq, gk, gv, gd, go, gl);
@@ -225,12 +212,10 @@ __global__ __launch_bounds__(256, RAL_ATTNM_WPE) void k_attn_bwd_m(const float* 
   // lane roles of the transposing reads: row tq of the block, column quad tp
   const int tq = r >> 2, tp = r & 3;
   const bool lowrows = r < 8;
-  constexpr bool PREF = TPL == 1;
-  if constexpr (PREF) { if (task < ntask) { request(task); deposit(); } }
   while (task < ntask) {
-    const int next = task + stride;
-    if constexpr (PREF) { request(next < ntask ? next : task); asm volatile("" ::: "memory"); }
-    else stage(task);
+    // (the operands of a task are requested and deposited at the top of its trip: requesting the NEXT task's under the
+    // current one's tiles - 21 registers held across the sweep - measured 116 against 110 us per launch at N = 64)
+    stage(task);
     const int hh = task * HW, win = hh / H, h0 = hh - win * H;
     float* dbase = dqkv + (size_t)win * 3 * H * NT * 4;
 #pragma unroll
@@ -266,6 +251,7 @@ __global__ __launch_bounds__(256, RAL_ATTNM_WPE) void k_attn_bwd_m(const float* 
         for (int kt = 0; kt < KT; ++kt) {
           const int k0 = kt * 16;
           const int kr = (k0 + SH + r) & MSK;        // this lane's key: the column of the S tile
+          // (keeping these operands of all key tiles of a short head in registers measured the same: 111 against 109 us at N = 64)
           const u32x2 Bk = *reinterpret_cast<const u32x2*>(Kh + 4 * kr + 2 * (g & 1));
           const u32x2 Bv = *reinterpret_cast<const u32x2*>(Vh + 4 * kr + 2 * (g & 1));
           f32x4 s = mm16(Aq, Bk, cl);                // (cq ck) (S - lse + 8), log2 units   [query 4g+j][key r]
@@ -334,8 +320,7 @@ __global__ __launch_bounds__(256, RAL_ATTNM_WPE) void k_attn_bwd_m(const float* 
         if ((g & 1) == 0) *reinterpret_cast<float4*>(dst) = make_float4(v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc);
       }
     }
-    if constexpr (PREF) deposit();
-    task = next;
+    task += stride;
   }
   if constexpr (TAB) {
     __syncthreads();
@@ -636,7 +621,7 @@ void launch_attn_bwd_m(const float* qkv, const float* o_hm, const float* do_hm, 
   const int hw = N >= 64 ? 1 : 64 / N, T = hw * N;
   const int ntask = B * H / hw;
   const int ntab = table ? (2 * Len - 1) * H : 0;
-  const int nwv = 4;
+  const int nwv = 4;   // (two-wave workgroups: 198 / 125 against 176 / 111 us at N = 128 / 64)
   const size_t lds = ((size_t)nwv * (T * 18 + 4 * 32 + 4 * 160) + 3 * ntab + 2) * sizeof(float);
   int grid = 0;
   auto grid_of = [&](auto kern) {
