@@ -65,7 +65,7 @@ def _profile_json(name):
 
 def measured_traffic(kind):
     """HBM bytes per launch of this kernel kind from the committed PMC run (newest profiles/rNN_hbm_traffic.json)."""
-    for name in ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json"):
+    for name in ("r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json"):
         d = _profile_json(name)
         if d and kind in d.get("per_launch_bytes", {}):
             return d["per_launch_bytes"][kind]["total"]
@@ -74,7 +74,7 @@ def measured_traffic(kind):
 
 def unet_fused_traffic():
     """(bytes per launch of the fused U-Net inference kernel at batch 2048 from the committed PMC run, file name)"""
-    for name in ("r04_unet_hbm_traffic.json", "r03_unet_hbm_traffic.json", "r02_unet_hbm_traffic.json"):
+    for name in ("r05_unet_hbm_traffic.json", "r04_unet_hbm_traffic.json", "r03_unet_hbm_traffic.json", "r02_unet_hbm_traffic.json"):
         d = _profile_json(name)
         if d:
             f = d.get("fused", {})
@@ -190,7 +190,7 @@ def cpu_baseline(leads, L, variant, big_batch=256):
             res["large_batch"] = {"error": str(exc)[:200]}
     # the figure at the bench batch itself, measured once per round by tools/cpu_baseline_big.py on the GPU box's host
     # (40 s per step and ~50 GB of autograd state: not re-measured inside the default run) and committed under profiles/
-    for name in ("r04_cpu_baseline_b2048.json", "r03_cpu_baseline_b2048.json"):
+    for name in ("r05_cpu_baseline_b2048.json", "r04_cpu_baseline_b2048.json", "r03_cpu_baseline_b2048.json"):
         d = _profile_json(name)
         if d and "value" in d and leads == 1 and L == 512:
             res["bench_batch"] = {"value": d["value"], "batch": 2048, "cores": d.get("cores"), "source": "profiles/" + name,

@@ -4,7 +4,7 @@
 # --kernel-trace only), the same for the U-Net forward, plus the attention and VALU micro-benchmarks.
 #   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r03'
 # Everything lands under gpurun_out/<round>/; tools/summarise_profiles.py turns it into profiles/<round>_*.
-R=${1:-r04}
+R=${1:-r05}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$R
