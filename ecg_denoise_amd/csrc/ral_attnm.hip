@@ -97,7 +97,21 @@ RAL_DEV float pow2_to(unsigned maxbits, int e, int cap = 60) {
 }
 // the powers of two of q log2 e and k (bits of their largest magnitudes): planes in [8, 16), capped at 2^50 each so that the
 // C operand of the score tile, (cq ck) (8 - lse log2 e), stays finite
-RAL_DEV void qk_scales(unsigned mqbits, unsigned mkbits, float& cq, float& ck) { cq = pow2_to(mqbits, 3, 50); ck = pow2_to(mkbits, 3, 50); }
+// Two modes, chosen per head (returns true for the second):
+//   balanced: q' = 2^-a q log2 e, k' = 2^a k (pair_balance: the product - the score - is unchanged, nothing to undo), taken
+//     when both then sit in [2^-3, 2^14): their pairs carry 22 bits, also as operands of the dK / dQ products;
+//   independent: each its own power of two (largest magnitude into [8, 16)) and the score tile times 1 / (cq ck) in front of
+//     the exponential - four more v_mul per tile (5 % of the kernel), for heads whose scores are tiny (< 2^-6) or huge.
+RAL_DEV bool qk_scales(unsigned mqbits, unsigned mkbits, float& cq, float& ck) {
+  const int eq = (int)(mqbits >> 23), ek = (int)(mkbits >> 23);   // biased exponents of max |q log2 e|, max |k|
+  const int e2 = eq + ek - 254;                                     // exponent of their product
+  if (mqbits != 0u && mkbits != 0u && e2 >= -6 && e2 < 26) {
+    pair_balance(__uint_as_float(mqbits), __uint_as_float(mkbits), cq, ck);
+    return false;
+  }
+  cq = pow2_to(mqbits, 3, 50); ck = pow2_to(mkbits, 3, 50);
+  return true;
+}
 RAL_DEV float pow2_inv(float p) { return __uint_as_float((254u << 23) - __float_as_uint(p)); }
 
 RAL_DEV float f4amax(float4 v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
@@ -158,6 +172,7 @@ __global__ __launch_bounds__(256, RAL_ATTNM_WPE) void k_attn_bwd_m(const float* 
   int task = blockIdx.x * nwv + wave;
   // per-task factors (wave-uniform): results x these; su = 1 / (cq ck) brings the score tile back to log2 units
   float sc_dq = 1.f, sc_dk = 1.f, sc_dv = 1.f, sc_tab = 1.f, su = 1.f;
+  bool need_su = false;             // independent q / k scales: the score tile is multiplied by su (see qk_scales)
 
   auto task_ptrs = [&](int tk, const float4*& gq, const float4*& gk, const float4*& gv, const float4*& gd, const float4*& go,
                        const float*& gl) {
@@ -180,7 +195,7 @@ __global__ __launch_bounds__(256, RAL_ATTNM_WPE) void k_attn_bwd_m(const float* 
   };
   // the task's powers of two; sets the output factors
   auto scales = [&](float mq, float mk, float mv, float md, float& cq, float& ck, float& cv, float& cd) {
-    qk_scales(__float_as_uint(group_max<64>(mq) * RAL_LOG2E), __float_as_uint(group_max<64>(mk)), cq, ck);
+    need_su = qk_scales(__float_as_uint(group_max<64>(mq) * RAL_LOG2E), __float_as_uint(group_max<64>(mk)), cq, ck);
     cv = pow2_to(__float_as_uint(group_max<64>(mv)), 0);
     cd = pow2_to(__float_as_uint(group_max<64>(md)), 2);
     const float icd = pow2_inv(cd), icv = pow2_inv(cv);
@@ -218,6 +233,7 @@ __global__ __launch_bounds__(256, RAL_ATTNM_WPE) void k_attn_bwd_m(const float* 
     stage(task);
     const int hh = task * HW, win = hh / H, h0 = hh - win * H;
     float* dbase = dqkv + (size_t)win * 3 * H * NT * 4;
+    auto sweep = [&](auto su_on) {    // (instantiated for both scaling modes: the choice is per task, wave-uniform)
 #pragma unroll
     for (int hl = 0; hl < HW; ++hl) {
       const int head = h0 + hl, tb = hl * NT;
@@ -256,8 +272,10 @@ __global__ __launch_bounds__(256, RAL_ATTNM_WPE) void k_attn_bwd_m(const float* 
           const u32x2 Bv = *reinterpret_cast<const u32x2*>(Vh + 4 * kr + 2 * (g & 1));
           f32x4 s = mm16(Aq, Bk, cl);                // (cq ck) (S - lse + 8), log2 units   [query 4g+j][key r]
           const f32x4 dp = mm16(Ad, Bv, cdl);        // (dP - delta) cd cv
+          if constexpr (decltype(su_on)::value) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) s[j] *= su;
+            for (int j = 0; j < 4; ++j) s[j] *= su;
+          }
           float p[4];
           unsigned ph1[2], ph2[2], sh1[2], sh2[2];
           if (TAB && qin && meets(k0, 16)) {
@@ -320,6 +338,8 @@ __global__ __launch_bounds__(256, RAL_ATTNM_WPE) void k_attn_bwd_m(const float* 
         if ((g & 1) == 0) *reinterpret_cast<float4*>(dst) = make_float4(v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc);
       }
     }
+    };
+    if (need_su) sweep(std::true_type{}); else sweep(std::false_type{});
     task += stride;
   }
   if constexpr (TAB) {
@@ -436,21 +456,23 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd_mh(const float* __restrict_
     __syncthreads();
     // the head's output factors
     float sc_dk, sc_dv, sc_tab, su;
+    bool need_su;
     {
       const unsigned* m4 = mx + 4 * (hl < HG ? hl : 0);
       const float cd = pow2_to(m4[0], 2), cv = pow2_to(m4[1], 0);
       float cq, ck;
-      qk_scales(m4[2], m4[3], cq, ck);
+      need_su = qk_scales(m4[2], m4[3], cq, ck);
       su = pow2_inv(cq) * pow2_inv(ck);
       sc_tab = RAL_PSH_INV * pow2_inv(cd) * pow2_inv(cv);
       sc_dk = RAL_LN2 * sc_tab * pow2_inv(cq);
       sc_dv = RAL_PSH_INV * pow2_inv(cd);
     }
-    if (hl < HG) {
+    auto sweep = [&](auto su_on) {    // (both scaling modes: the choice is per head, wave-uniform)
       const int head = h0 + hl;
       const float* Qh = Qp + 4 * tb; const float* Kh = Kp + 4 * tb; const float* Vh = Vp + 4 * tb; const float* Dh = Dp + 4 * tb;
       // this wave's keys: S / dP column operands and k^T planes, for the whole sweep
-      u32x2 Bk[KT], Bv[KT], kx[KT];
+      u32x2 Bk[KT], Bv[KT];
+
       f32x4 acc[KT];
       bool kin[KT];
 #pragma unroll
@@ -458,7 +480,6 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd_mh(const float* __restrict_
         const int k0 = ks + 16 * kt;
         Bk[kt] = *reinterpret_cast<const u32x2*>(Kh + 4 * (k0 + r) + 2 * (g & 1));
         Bv[kt] = *reinterpret_cast<const u32x2*>(Vh + 4 * (k0 + r) + 2 * (g & 1));
-        kx[kt] = tr_read((tp < 2 ? Kh : Vh) + 4 * (k0 + 4 * g + tq) + 2 * (tp & 1));
         acc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
         kin[kt] = meets(k0, 16);
       }
@@ -477,15 +498,20 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd_mh(const float* __restrict_
         auto dq_step = [&](int kp) {
           const float* bp = Xb + (kp & 1) * 2 * BUF + (4 * g + tq) * 10 + 2 * tp;
           const u32x2 b1 = tr_read(bp), b2 = tr_read(bp + BUF);
-          dq = mm32(u32x4{kx[kp][0], kx[kp][1], kx[kp][0], kx[kp][1]}, u32x4{b1[0], b1[1], b2[0], b2[1]}, dq);
+          // (k planes^T of the wave's four key tiles read again per query tile: kept in registers they are 8 more and the kernel
+          // spills at the 128 of four waves per SIMD - 569 against 550 us at N = 512, same box; rows 8-15: v planes, unused)
+          const u32x2 kx = tr_read((tp < 2 ? Kh : Vh) + 4 * (ks + 16 * kp + 4 * g + tq) + 2 * (tp & 1));
+          dq = mm32(u32x4{kx[0], kx[1], kx[0], kx[1]}, u32x4{b1[0], b1[1], b2[0], b2[1]}, dq);
         };
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
           const int k0 = ks + 16 * kt;
-          f32x4 s = mm16(Aq, Bk[kt], cl);
+          f32x4 s = mm16(Aq, Bk[kt], cl);           // (Bk / Bv read per tile instead of kept: 546 against 531 us at N = 512, same box)
           const f32x4 dp = mm16(Ad, Bv[kt], cdl);
+          if constexpr (decltype(su_on)::value) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) s[j] *= su;
+            for (int j = 0; j < 4; ++j) s[j] *= su;
+          }
           float p[4];
           unsigned ph1[2], ph2[2], sh1[2], sh2[2];
           if (TAB && qin && kin[kt]) {
@@ -542,7 +568,8 @@ __global__ __launch_bounds__(512, 4) void k_attn_bwd_mh(const float* __restrict_
         float* dst = dbase + (size_t)(g < 2 ? 2 : 1) * H * N * 4 + ((size_t)head * N + kr) * 4;
         if ((g & 1) == 0) *reinterpret_cast<float4*>(dst) = make_float4(v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc);
       }
-    }
+    };
+    if (hl < HG) { if (need_su) sweep(std::true_type{}); else sweep(std::false_type{}); }
     __syncthreads();
     // dQ leaves, scaled per head
     for (int t = threadIdx.x; t < T; t += blockDim.x) {
