@@ -115,3 +115,36 @@ def test_product_path_has_no_cpu_fallback():
     for f in os.listdir(pkg):
         if f.endswith(".py"):
             assert "oracle" not in open(os.path.join(pkg, f)).read().replace("no CPU fallback", ""), f
+
+
+def test_global_option_validates_its_key_and_value():
+    """`ral_global_option` is the only way to change a library switch (no environment variable does): unknown names and negative
+    values are rejected with a message, known names are case-insensitive and accept an optional RAL_ prefix"""
+    L = _lib.lib()
+    assert L.ral_global_option(b"attn_f16", 1) == 0
+    assert L.ral_global_option(b"RAL_ATTN_F16", 1) == 0
+    assert L.ral_global_option(b"Grid_QkvB", 192) == 0
+    assert L.ral_global_option(b"no_such_switch", 1) != 0 and b"unknown switch" in L.ral_last_error()
+    assert L.ral_global_option(b"attn_f16", -1) != 0 and b"negative" in L.ral_last_error()
+    assert L.ral_global_option(None, 1) != 0
+
+
+def test_library_reads_only_the_two_documented_environment_variables():
+    """the product build of the library has exactly two getenv call sites outside `#ifdef RAL_DIAG`: ral_env_int (RAL_LANES,
+    RAL_NO_SIDE_STREAM) - and no other source file calls getenv at all"""
+    import glob
+    n_outside, in_diag = 0, False
+    for f in sorted(glob.glob(os.path.join(ROOT, "ecg_denoise_amd", "csrc", "*.h*"))):
+        depth_diag = None
+        for line in open(f):
+            s = line.strip()
+            if s.startswith("#ifdef RAL_DIAG"):
+                in_diag = True
+            elif s.startswith("#endif") and in_diag:
+                in_diag = False
+            elif "getenv(" in line and not s.startswith("//") and not in_diag:
+                n_outside += 1
+                assert f.endswith("ral_api.hip"), (f, line)
+    assert n_outside == 1                      # the one inside ral_env_int
+    src = open(os.path.join(ROOT, "ecg_denoise_amd", "csrc", "ral_api.hip")).read()
+    assert sorted(set(re.findall(r'ral_env_int\("(RAL_[A-Z_]+)"', src))) == ["RAL_LANES", "RAL_NO_SIDE_STREAM"]

@@ -119,7 +119,10 @@ def test_unet_bench_batch_matches_fp64_oracle(L, B):
                 bad[k] = "nonzero"
             continue
         e = rel(ng[k].cpu().numpy(), gr.numpy())
-        if e > bound:
+        # the last layer's gradients see no LeakyReLU on the way back (DecList.3 is ConvTranspose1d + BatchNorm, then the loss):
+        # no slope can flip between fp32 and fp64, so they keep the tight bar whatever the size - a regression of a few 1e-3
+        # in the MFMA conv / weight-gradient paths cannot hide behind the kink allowance of the other layers
+        if e > (2e-4 if k.startswith("DecList.3.") else bound):
             bad[k] = e
     assert not bad, (bad, bound)
     sd = m.state_dict()
