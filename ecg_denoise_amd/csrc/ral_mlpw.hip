@@ -489,6 +489,11 @@ void launch_mlp_fwd_w(int C, int kind, const float* x, const float* o, const Blo
 //   gradient tiles meet in the LDS (the weight copies are no longer needed then) and leave with one atomic per element.
 // fp32 MFMA and fp32 vector ALU throughout (this form); weights staged once per persistent workgroup.
 // =================================================================================
+// The flush at the end of the strip-backward kernels - every workgroup adds its sums to the gradient buffer with atomics, a
+// chain of (workgroups) same-address atomics per element - measures 20 - 27 us when it is all a launch does (make VARIANT=..
+// EXTRA=-DRAL_DIAG_SKIP=1 against 3) but 7 - 10 us at the end of a real launch, where the workgroups do not arrive together.
+// One row of sums per workgroup in scratch memory and a kernel that adds the rows up (built, parity-clean, removed): the strip
+// kernels 4 - 10 us shorter, the extra kernel 11 us (~4 with more row groups): nothing gained.
 template <int C>
 struct MlpbwShape {
   static constexpr int KP = C < 16 ? 16 : C, MT = KP / 16, HID = 4 * C, HT = HID / 16;
@@ -585,7 +590,10 @@ __global__ __launch_bounds__(256, RAL_MLPW_WPE) void k_mlp_bwd_w(const float* __
     }
   };
   request(blockIdx.x * 4 + wave, pxa, pda, pxh, pdh);
-  for (int tile = blockIdx.x * 4 + wave; tile < ntile; tile += gridDim.x * 4) {
+#ifndef RAL_DIAG_SKIP
+#define RAL_DIAG_SKIP 0
+#endif
+  for (int tile = blockIdx.x * 4 + wave; tile < ((RAL_DIAG_SKIP & 1) ? 0 : ntile); tile += gridDim.x * 4) {
     const int win = tile / tpw, t0 = (tile - win * tpw) << 4, tok = t0 + r;
     const size_t wo = (size_t)win * N * C;
     f32x4 xv[MT], dv[MT];
@@ -789,6 +797,332 @@ __global__ __launch_bounds__(256, RAL_MLPW_WPE) void k_mlp_bwd_w(const float* __
     if (lane == 0) { atomicAdd(sLe, v0); atomicAdd(sLe + 1, v1); atomicAdd(sLe + 2, v2); }
   }
   __syncthreads();
+  if (RAL_DIAG_SKIP & 2) return;
+  if (want_dw) {
+    for (int i = threadIdx.x; i < 4 * C * C; i += blockDim.x) { atomicAdd(gr.w1 + i, (float)stg[i]); atomicAdd(gr.w2 + i, (float)stg[4 * C * C + i]); }
+    for (int i = threadIdx.x; i < HID; i += blockDim.x) atomicAdd(gr.b1 + i, sB1[i]);
+    for (int i = threadIdx.x; i < C; i += blockDim.x) atomicAdd(gr.b2 + i, sB2[i]);
+  }
+  for (int i = threadIdx.x; i < C; i += blockDim.x) { atomicAdd(gr.ln2w + i, sG[i]); atomicAdd(gr.ln2b + i, sBe[i]); }
+  if (le && threadIdx.x < 3) atomicAdd(gr.le + threadIdx.x, sLe[threadIdx.x]);
+}
+
+// ---- the same chain with TWO waves per 16-token tile (C = 32).  The weight-gradient tiles of a level are
+// 2 x (4C x C) / 64 accumulator registers per wave that carries all of them: 128 at C = 32, with everything else the chain keeps
+// that is 256 registers and ~100 spilled.  Here a PAIR of waves shares a tile and each takes half of the hidden range - half of
+// the fc1 products, GELU evaluations and weight-gradient tiles (64 registers); nothing of the expensive part is computed twice.
+// What both compute: LayerNorm forward and backward of the tile (a few dozen instructions).  They meet twice per tile: LN2(x1)
+// and dx2 tiles for the transposed reads are written once per pair, and the two partial d LN2(x1) tiles - each wave's sum over
+// its own hidden channels - are exchanged through the LDS.  After that wave 0 keeps channel tile 0 (dx1 store, proj^T product,
+// bias / LayerNorm gradients), wave 1 tile 1.  The local enhancement (hidden channel 0) belongs to wave 0.
+#ifndef RAL_MLPW2_NP
+#define RAL_MLPW2_NP 2     // pairs per workgroup.  4 (100 KB of LDS, one workgroup per CU): 177.7 us per launch against 182.0 with 2 (78 KB, two
+#endif                     // per CU), but the STEP is 12.85 ms with 2 against 12.98 with 4 and 12.94 with k_mlp_bwd_s (tools/diag/ab_step.sh, four
+                           // interleaved rounds on one box): the other lane's kernels find room beside the smaller workgroups
+template <int C>
+struct Mlpbw2Shape {
+  static constexpr int KP = C, MT = KP / 16, HID = 4 * C, HT = HID / 16, HW = HT / 2, NP = RAL_MLPW2_NP;   // NP: pairs per workgroup
+  static constexpr int LDC = KP + 4, LDH = HID + 4, LDT = 20;
+  // floats: W1 [HID][LDC] | W2T [HID][LDC] | W1T [KP][LDH] | WpT [KP][LDC] | g2, be2, w10, w2c0 [KP each] | b1 [HID] |
+  //         per pair: LN2(x1) tiles [MT], dx2 tiles [MT] (shared), then per wave: du | a2 tiles (the wave's partial
+  //         d LN2(x1), MT x 64 lanes x 4 floats, goes over them at the end of a tile)
+  static constexpr int W2TO = HID * LDC, W1TO = W2TO + HID * LDC, WPTO = W1TO + KP * LDH, VO = WPTO + KP * LDC, B1O = VO + 4 * KP,
+                       SCR = B1O + HID, WTILES = 2 * 16 * LDT, PSCR = 2 * MT * 16 * LDT + 2 * WTILES, TOTAL = SCR + NP * PSCR;
+  static_assert(MT == 2, "a pair splits the channel tiles of the tail one each");
+  static_assert(256 * MT <= WTILES, "the partial d LN2(x1) of a wave fits its du / a2 tiles");
+  static_assert(TOTAL >= 16 * C * C + 2 * HID + 4 * KP + 8, "the flush staging (weight-gradient tiles in doubles) fits the kernel's LDS");
+};
+
+template <int C>
+__global__ __launch_bounds__(128 * RAL_MLPW2_NP, 2) void k_mlp_bwd_w2(const float* __restrict__ dx2, const float* __restrict__ x1,
+                                                       BlockP w, BlockP gr, float* __restrict__ dx1_out,
+                                                       float* __restrict__ do_hm, int N, int B, int want_dw) {
+  using SH = Mlpbw2Shape<C>;
+  constexpr int KP = SH::KP, MT = SH::MT, HID = SH::HID, HW = SH::HW, NP = SH::NP, LDC = SH::LDC, LDH = SH::LDH, LDT = SH::LDT;
+  extern __shared__ float4 smem4[];
+  float* sm = reinterpret_cast<float*>(smem4);
+  float* W1 = sm; float* W2T = sm + SH::W2TO; float* W1T = sm + SH::W1TO; float* WpT = sm + SH::WPTO;
+  float* g2 = sm + SH::VO; float* be2 = g2 + KP; float* w10 = be2 + KP; float* w2c0 = w10 + KP; float* b1 = sm + SH::B1O;
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pair = wave >> 1, half = wave & 1;
+  float* PT = sm + SH::SCR + pair * SH::PSCR;                         // the pair's LN2(x1) | dx2 tiles
+  float* TW = PT + 2 * MT * 16 * LDT + half * SH::WTILES;             // this wave's du | a2 tiles
+  const float* TO = PT + 2 * MT * 16 * LDT + (half ^ 1) * SH::WTILES; // the other wave's
+  // ---- weights -> LDS (once per workgroup)
+  for (int i = threadIdx.x; i < SH::SCR; i += blockDim.x) sm[i] = 0.f;
+  __syncthreads();
+  for (int i = threadIdx.x; i < HID * C; i += blockDim.x) {
+    const int h = i / C, c = i - h * C;
+    const float a = w.w1[i];                         // W1[h][c]
+    W1[h * LDC + c] = a; W1T[c * LDH + h] = a;
+    W2T[h * LDC + c] = w.w2[c * HID + h];            // W2[c][h]
+  }
+  for (int i = threadIdx.x; i < C * C; i += blockDim.x) { const int c = i / C, j = i - c * C; WpT[j * LDC + c] = w.wp[i]; }   // Wp[c][j]
+  for (int i = threadIdx.x; i < C; i += blockDim.x) { g2[i] = w.ln2w[i]; be2[i] = w.ln2b[i]; w10[i] = w.w1[i]; w2c0[i] = w.w2[i * HID]; }
+  for (int i = threadIdx.x; i < HID; i += blockDim.x) b1[i] = w.b1[i];
+  const bool le = w.le != nullptr;
+  const bool leh = le && half == 0;                    // the wave that carries hidden channel 0 through the conv
+  float lw0 = 0.f, lw1 = 0.f, lw2 = 0.f;
+  if (le) { lw0 = w.le[0]; lw1 = w.le[1]; lw2 = w.le[2]; }
+  __syncthreads();
+  constexpr float invC = 1.0f / C;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  auto mma_block = [&](const float* W, int ld, int mo, int kb, f32x4 bt, f32x4 acc) -> f32x4 {
+    const float4 wa = *reinterpret_cast<const float4*>(W + (16 * mo + r) * ld + 16 * kb + 4 * g);
+    acc = mfma4(wa.x, bt[0], acc); acc = mfma4(wa.y, bt[1], acc); acc = mfma4(wa.z, bt[2], acc); acc = mfma4(wa.w, bt[3], acc);
+    return acc;
+  };
+  auto vec4 = [&](const float* v, int tile) -> f32x4 {
+    const float4 t = *reinterpret_cast<const float4*>(v + 16 * tile + 4 * g);
+    return f32x4{t.x, t.y, t.z, t.w};
+  };
+  auto tr_read = [&](const float* T) -> f32x4 {
+    return f32x4{T[(4 * g + 0) * LDT + r], T[(4 * g + 1) * LDT + r], T[(4 * g + 2) * LDT + r], T[(4 * g + 3) * LDT + r]};
+  };
+  auto mine = [&](const f32x4 (&a)[MT]) -> f32x4 {   // the channel tile this wave keeps (element-wise selects: an indexed array goes to scratch)
+    const f32x4 a0 = a[0], a1 = a[1];
+    return f32x4{half ? a1[0] : a0[0], half ? a1[1] : a0[1], half ? a1[2] : a0[2], half ? a1[3] : a0[3]};
+  };
+  // accumulators that live over all the tiles of the wave: hidden tiles HW half .. HW half + HW - 1, channel tile `half`
+  f32x4 dW1[HW][MT], dW2[MT][HW], sb1[HW], sb2 = zero4, sgam = zero4, sbet = zero4;
+#pragma unroll
+  for (int h = 0; h < HW; ++h) { sb1[h] = zero4;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) { dW1[h][m] = zero4; dW2[m][h] = zero4; } }
+  float gle0 = 0.f, gle1 = 0.f, gle2 = 0.f;
+  const int tpw = N >> 4, ntile = B * tpw;
+  // operands requested one tile ahead (k_mlp_bwd_w); the halo tokens by the wave of the conv only
+  float4 pxa[MT], pda[MT];
+  constexpr int CPL = C / 16;
+  float pxh[CPL], pdh[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) { pxh[c] = 0.f; pdh[c] = 0.f; }
+  auto request = [&](int tl, float4 (&xa)[MT], float4 (&da)[MT], float (&hx)[CPL], float (&hd)[CPL]) {
+    const int tlc = tl < ntile ? tl : ntile - 1;                      // (past the end: a valid address, its gradient rows are zeroed)
+    const int win_ = tlc / tpw, t0_ = (tlc - win_ * tpw) << 4;
+    const float* xw_ = x1 + (size_t)win_ * N * C; const float* dw_ = dx2 + (size_t)win_ * N * C;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int off = (t0_ + r) * C + 16 * m + 4 * g;
+      xa[m] = *reinterpret_cast<const float4*>(xw_ + off);
+      da[m] = *reinterpret_cast<const float4*>(dw_ + off);
+    }
+    if (leh) {
+      const int th = g < 2 ? t0_ - 2 + g : t0_ + 14 + g;
+      const int thc = (th >= 0 && th < N) ? th : 0;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) { hx[c] = xw_[(size_t)thc * C + r + 16 * c]; hd[c] = dw_[(size_t)thc * C + r + 16 * c]; }
+    }
+  };
+  // every pair of the workgroup makes the same number of trips (the two meetings per tile are workgroup barriers); a trip past
+  // the last tile runs on the last tile's x1 with a zero gradient tile - every sum it adds to is a sum of zeros - and stores nothing
+  const int stride = gridDim.x * NP, ntrip = (ntile + stride - 1) / stride;
+  int tile = blockIdx.x * NP + pair;
+  request(tile, pxa, pda, pxh, pdh);
+  for (int trip = 0; trip < ((RAL_DIAG_SKIP & 1) ? 0 : ntrip); ++trip, tile += stride) {
+    const bool live = tile < ntile;
+    const int tlc = live ? tile : ntile - 1;
+    const int win = tlc / tpw, t0 = (tlc - win * tpw) << 4, tok = t0 + r;
+    const size_t wo = (size_t)win * N * C;
+    f32x4 xv[MT], dv[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      xv[m] = f32x4{pxa[m].x, pxa[m].y, pxa[m].z, pxa[m].w};
+      dv[m] = live ? f32x4{pda[m].x, pda[m].y, pda[m].z, pda[m].w} : zero4;
+    }
+    float cxh[CPL], cdh[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) { cxh[c] = pxh[c]; cdh[c] = live ? pdh[c] : 0.f; }
+    request(tile + stride, pxa, pda, pxh, pdh);                 // the next tile's operands
+    float hA0[4] = {0.f, 0.f, 0.f, 0.f}, hD[2] = {0.f, 0.f};   // GELU(u[:, 0]) of the halo tokens; da2[:, 0] of t0-1 and t0+16
+    if (leh) {   // halo tokens t0-2, t0-1, t0+16, t0+17: lane group g = slot, lane r (+ 16 c) = channel
+      const int th = g < 2 ? t0 - 2 + g : t0 + 14 + g;
+      const bool tin = th >= 0 && th < N;
+      float xs = 0.f;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) xs += cxh[c];
+      const float mean = group_sum<16>(xs) * invC;
+      float dd[CPL], vs = 0.f;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) { dd[c] = cxh[c] - mean; vs += dd[c] * dd[c]; }
+      const float rstd = 1.0f / sqrtf(group_sum<16>(vs) * invC + 1e-5f);
+      float gg = 0.f, dh = 0.f;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const int rc = r + 16 * c;
+        gg += (dd[c] * rstd * g2[rc] + be2[rc]) * w10[rc];
+        dh += cdh[c] * w2c0[rc];
+      }
+      const float u0 = group_sum<16>(gg) + b1[0];
+      const float a0 = tin ? gelu_f(u0) : 0.f;
+      const float d0 = tin ? group_sum<16>(dh) : 0.f;
+      hA0[0] = lane_value(a0, 0); hA0[1] = lane_value(a0, 16); hA0[2] = lane_value(a0, 32); hA0[3] = lane_value(a0, 48);
+      hD[0] = lane_value(d0, 16); hD[1] = lane_value(d0, 32);
+    }
+    // ---- LN2 forward of the tile (both waves)
+    float sum = 0.f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) sum += (xv[m][0] + xv[m][1]) + (xv[m][2] + xv[m][3]);
+    const float mean = rows_sum(sum) * invC;
+    float var = 0.f;
+    f32x4 xh[MT], gx[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      xh[m] = xv[m] - mean;
+      var += (xh[m][0] * xh[m][0] + xh[m][1] * xh[m][1]) + (xh[m][2] * xh[m][2] + xh[m][3] * xh[m][3]);
+    }
+    const float rstd = 1.0f / sqrtf(rows_sum(var) * invC + 1e-5f);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) { xh[m] = xh[m] * rstd; gx[m] = xh[m] * vec4(g2, m) + vec4(be2, m); }
+    // ---- local enhancement through hidden channel 0 (wave 0 of the pair; every lane of a token column computes the same numbers)
+    float a2_0 = 0.f, du_0 = 0.f;
+    if (leh) {
+      float u0p = 0.f, d0p = 0.f;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const f32x4 wr0 = vec4(w10, m), wc0 = vec4(w2c0, m);
+        u0p += (gx[m][0] * wr0[0] + gx[m][1] * wr0[1]) + (gx[m][2] * wr0[2] + gx[m][3] * wr0[3]);
+        d0p += (dv[m][0] * wc0[0] + dv[m][1] * wc0[1]) + (dv[m][2] * wc0[2] + dv[m][3] * wc0[3]);
+      }
+      const float u0 = rows_sum(u0p) + b1[0], da0 = rows_sum(d0p);       // u[tok, 0], da2[tok, 0]
+      float A0, dA;
+      gelu_pair(u0, A0, dA);
+      const float sm1 = dpp_shift<0x111>(A0), sp1 = dpp_shift<0x101>(A0);   // row_shr:1 / row_shl:1
+      const float Am = r == 0 ? hA0[1] : sm1, Ap = r == 15 ? hA0[2] : sp1;   // A0 of tokens tok - 1, tok + 1
+      float c0g, c0d;
+      gelu_pair(lw0 * Am + lw1 * A0 + lw2 * Ap, c0g, c0d);
+      a2_0 = c0g;
+      const float DC = da0 * c0d;                                         // d loss / d conv output at tok
+      const float A_first = lane_value(A0, 0), A_last = lane_value(A0, 15);
+      const float DCl = (t0 - 1 >= 0) ? hD[0] * gelu_grad_f(lw0 * hA0[0] + lw1 * hA0[1] + lw2 * A_first) : 0.f;
+      const float DCr = (t0 + 16 < N) ? hD[1] * gelu_grad_f(lw0 * A_last + lw1 * hA0[2] + lw2 * hA0[3]) : 0.f;
+      const float dm1 = dpp_shift<0x111>(DC), dp1 = dpp_shift<0x101>(DC);
+      const float DCm = r == 0 ? DCl : dm1, DCp = r == 15 ? DCr : dp1;     // DC of tokens tok - 1, tok + 1
+      du_0 = (lw0 * DCp + lw1 * DC + lw2 * DCm) * dA;
+      if (g == 0) { gle0 += DC * Am; gle1 += DC * A0; gle2 += DC * Ap; }
+    }
+    // ---- first meeting: LN2(x1) tiles from wave 0, dx2 tiles from wave 1; behind the barrier the other wave has also read this
+    // wave's partial of the previous tile, so the du / a2 tiles may be written again
+    if (want_dw) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) *reinterpret_cast<float4*>(PT + ((half ? MT : 0) + m) * 16 * LDT + r * LDT + 4 * g) = tofloat4(half ? dv[m] : gx[m]);
+    }
+    __syncthreads();
+    f32x4 gxT[MT], dvT[MT];
+    if (want_dw) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) { gxT[m] = tr_read(PT + m * 16 * LDT); dvT[m] = tr_read(PT + (MT + m) * 16 * LDT); }
+      sb2 += mine(dv);
+    }
+    // ---- this wave's hidden chunks of 16 channels
+    f32x4 dg[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) dg[m] = zero4;
+    float* Tdu = TW; float* Ta2 = TW + 16 * LDT;
+#pragma unroll
+    for (int hl = 0; hl < HW; ++hl) {
+      const int ht = HW * half + hl;
+      f32x4 u = vec4(b1, ht), da2 = zero4;
+#pragma unroll
+      for (int kb = 0; kb < MT; ++kb) { u = mma_block(W1, LDC, ht, kb, gx[kb], u); da2 = mma_block(W2T, LDC, ht, kb, dv[kb], da2); }
+      f32x4 du, a2, a1v, d1v;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { float a_, d_; gelu_pair(u[q], a_, d_); a1v[q] = a_; d1v[q] = d_; }
+      if (le) {
+        f32x4 g2v, d2v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { float a_, d_; gelu_pair(a1v[q], a_, d_); g2v[q] = a_; d2v[q] = d_; }
+        du = da2 * d2v * d1v; a2 = g2v;
+        if (hl == 0 && half == 0 && g == 0) { du[0] = du_0; a2[0] = a2_0; }    // hidden channel 0: through the conv
+      } else { du = da2 * d1v; a2 = a1v; }
+#pragma unroll
+      for (int mo = 0; mo < MT; ++mo) dg[mo] = mma_block(W1T, LDH, mo, ht, du, dg[mo]);
+      if (want_dw) {
+        *reinterpret_cast<float4*>(Tdu + r * LDT + 4 * g) = tofloat4(du);
+        *reinterpret_cast<float4*>(Ta2 + r * LDT + 4 * g) = tofloat4(a2);
+        const f32x4 duT = tr_read(Tdu), a2T = tr_read(Ta2);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            dW1[hl][m] = mfma4(duT[q], gxT[m][q], dW1[hl][m]);      // rows: hidden 16 ht + ., columns: channel 16 m + .
+            dW2[m][hl] = mfma4(dvT[m][q], a2T[q], dW2[m][hl]);      // rows: channel 16 m + ., columns: hidden 16 ht + .
+          }
+        }
+        sb1[hl] += du;
+      }
+    }
+    // ---- second meeting: the two partial d LN2(x1) tiles (a + b = b + a: both waves hold the same sum)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) *reinterpret_cast<float4*>(TW + (m * 64 + lane) * 4) = tofloat4(dg[m]);
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const float4 o = *reinterpret_cast<const float4*>(TO + (m * 64 + lane) * 4);
+      dg[m] += f32x4{o.x, o.y, o.z, o.w};
+    }
+    // ---- LN2 backward (both waves), then this wave's channel tile: dx1 = dx2 + dLN, do = Wp^T dx1 rows 16 half ..
+    float s1 = 0.f, s2 = 0.f;
+    f32x4 dyh[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      dyh[m] = dg[m] * vec4(g2, m);
+      s1 += (dyh[m][0] + dyh[m][1]) + (dyh[m][2] + dyh[m][3]);
+      s2 += (dyh[m][0] * xh[m][0] + dyh[m][1] * xh[m][1]) + (dyh[m][2] * xh[m][2] + dyh[m][3] * xh[m][3]);
+    }
+    { const f32x4 dgm = mine(dg); sgam += dgm * mine(xh); sbet += dgm; }
+    const float m1 = rows_sum(s1) * invC, m2 = rows_sum(s2) * invC;
+    f32x4 dx[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) dx[m] = dv[m] + (dyh[m] - m1 - xh[m] * m2) * rstd;
+    f32x4 o = zero4;
+#pragma unroll
+    for (int kb = 0; kb < MT; ++kb) o = mma_block(WpT, LDC, half, kb, dx[kb], o);
+    if (live) {
+      *reinterpret_cast<float4*>(dx1_out + wo + (size_t)tok * C + 16 * half + 4 * g) = tofloat4(mine(dx));
+      *reinterpret_cast<float4*>(do_hm + wo + ((size_t)(4 * half + g) * N + tok) * 4) = tofloat4(o);
+    }
+  }
+  // ---- flush (as k_mlp_bwd_w: weight-gradient tiles through doubles in the LDS)
+  __syncthreads();
+  double* stg = reinterpret_cast<double*>(sm);
+  float* sB1 = sm + 16 * C * C; float* sB2 = sB1 + HID; float* sG = sB2 + KP; float* sBe = sG + KP; float* sLe = sBe + KP;
+  for (int i = threadIdx.x; i < 8 * C * C; i += blockDim.x) stg[i] = 0.;
+  for (int i = threadIdx.x; i < HID + 3 * KP + 4; i += blockDim.x) sB1[i] = 0.f;
+  __syncthreads();
+  if (want_dw) {
+#pragma unroll
+    for (int h = 0; h < HW; ++h) {
+      const int hb = 16 * (HW * half + h);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float v = group_sum<16>(sb1[h][q]);
+        if (r == 0) atomicAdd(sB1 + hb + 4 * g + q, v);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          atomicAdd(stg + (hb + 4 * g + q) * C + 16 * m + r, (double)dW1[h][m][q]);                    // dW1 tile: row hidden, column channel
+          atomicAdd(stg + 4 * C * C + (16 * m + 4 * g + q) * HID + hb + r, (double)dW2[m][h][q]);      // dW2 tile: row channel, column hidden
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float v = group_sum<16>(sb2[q]);
+      if (r == 0) atomicAdd(sB2 + 16 * half + 4 * g + q, v);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float vg = group_sum<16>(sgam[q]), vb = group_sum<16>(sbet[q]);
+    if (r == 0) { atomicAdd(sG + 16 * half + 4 * g + q, vg); atomicAdd(sBe + 16 * half + 4 * g + q, vb); }
+  }
+  if (leh) {
+    const float v0 = group_sum<64>(gle0), v1 = group_sum<64>(gle1), v2 = group_sum<64>(gle2);
+    if (lane == 0) { atomicAdd(sLe, v0); atomicAdd(sLe + 1, v1); atomicAdd(sLe + 2, v2); }
+  }
+  __syncthreads();
+  if (RAL_DIAG_SKIP & 2) return;
   if (want_dw) {
     for (int i = threadIdx.x; i < 4 * C * C; i += blockDim.x) { atomicAdd(gr.w1 + i, (float)stg[i]); atomicAdd(gr.w2 + i, (float)stg[4 * C * C + i]); }
     for (int i = threadIdx.x; i < HID; i += blockDim.x) atomicAdd(gr.b1 + i, sB1[i]);
@@ -801,11 +1135,15 @@ __global__ __launch_bounds__(256, RAL_MLPW_WPE) void k_mlp_bwd_w(const float* __
 // Measured at batch 2048 (rocprofv3, serialised step, us per launch; k_mlp_bwd_s / this kernel): C = 16 (N = 256): 181 / 150.5;
 // C = 8 (N = 512): 247 / 153.  An f16 form of it (every product as fp16 pairs, one power of two per tile on the gradient
 // side; built, parity-clean, removed again) measured 146.5 / 152.8: the kernel is not bound by its matrix instructions.
-// RAL_MLP_BWD_W: 0 never, 1: C = 16 only, 2 (default): C = 8 and 16.
+// Round 5 (operands requested a tile ahead, flush through doubles): C = 16: 111, C = 8: 139; C = 32 (N = 128): k_mlp_bwd_s 241,
+// k_mlp_bwd_w2 178 - 182.  Its tile loop is 1 571 instructions per wave and tile (~1 000 vector, 168 matrix, 75 transcendental)
+// and takes ~27 000 cycles per pair of tiles and SIMD: both pipes are under half busy, the waves wait on each other's chain
+// (fc1 MFMAs -> GELU -> fc1^T MFMAs -> LDS transposes -> weight-gradient MFMAs) with two waves per SIMD to hide it.
+// MLP_BWD_W: 0 never, 1: C = 16 only, 2: C = 8 and 16, 3 (default): C = 32 too (k_mlp_bwd_w2, two waves per tile).
 int mlp_bwd_w_kind(int C, int N, bool f16_ok) {
   (void)f16_ok;
-  static const int on = (int)ral_knob("MLP_BWD_W", 2);
-  if (!on || N % 16 != 0 || !(C == 16 || (on >= 2 && C == 8))) return 0;
+  static const int on = (int)ral_knob("MLP_BWD_W", 3);
+  if (!on || N % 16 != 0 || !(C == 16 || (on >= 2 && C == 8) || (on >= 3 && C == 32))) return 0;
   return 1;
 }
 template <int C>
@@ -821,9 +1159,21 @@ static void go_mlp_bwd_w(const float* dx2, const float* x1, const BlockP& w, con
   if (grid > nwg) grid = nwg;
   k_mlp_bwd_w<C><<<grid, 256, lds, s>>>(dx2, x1, w, gr, dx1, do_hm, N, B, want_dw ? 1 : 0);
 }
+static void go_mlp_bwd_w2(const float* dx2, const float* x1, const BlockP& w, const BlockP& gr, float* dx1, float* do_hm, int N, int B,
+                          bool want_dw, hipStream_t s) {
+  using SH = Mlpbw2Shape<32>;
+  static const int genv = (int)ral_knob("GRID_MLPBW", 0);
+  const int nwg = (B * (N / 16) + SH::NP - 1) / SH::NP;
+  const size_t lds = (size_t)SH::TOTAL * sizeof(float);
+  RAL_SET_LDS((k_mlp_bwd_w2<32>), lds);
+  int grid = genv > 0 ? genv : 256 * (4 / SH::NP);      // (eight waves per CU: 232 registers)
+  if (grid > nwg) grid = nwg;
+  k_mlp_bwd_w2<32><<<grid, 128 * SH::NP, lds, s>>>(dx2, x1, w, gr, dx1, do_hm, N, B, want_dw ? 1 : 0);
+}
 void launch_mlp_bwd_w(int C, int kind, const float* dx2, const float* x1, const BlockP& w, const BlockP& gr, float* dx1, float* do_hm, int N, int B,
                       bool want_dw, hipStream_t s) {
   (void)kind;
-  if (C == 8) go_mlp_bwd_w<8>(dx2, x1, w, gr, dx1, do_hm, N, B, want_dw, s);
+  if (C == 32) go_mlp_bwd_w2(dx2, x1, w, gr, dx1, do_hm, N, B, want_dw, s);
+  else if (C == 8) go_mlp_bwd_w<8>(dx2, x1, w, gr, dx1, do_hm, N, B, want_dw, s);
   else go_mlp_bwd_w<16>(dx2, x1, w, gr, dx1, do_hm, N, B, want_dw, s);
 }
