@@ -57,6 +57,7 @@ _SIGS = {
     "ral_loss_flat": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int64, _VP, _VP, _VP, _VP, _VP]),
     "ral_loss_mean": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int64, _VP, _VP, _VP, _VP, _VP, _VP]),
     "ral_loss_means": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int64, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "ral_forward_loss_means": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP]),
     "ral_backward": (C.c_int, [_VP, _VP, _VP, C.c_int, _VP]),
     "ral_backward_input": (C.c_int, [_VP, _VP, _VP, C.c_int, _VP]),
     "ral_backward_begin": (C.c_int, [_VP, _VP, C.c_int, _VP]),

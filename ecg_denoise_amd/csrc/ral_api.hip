@@ -1116,6 +1116,18 @@ int ral_loss_means(const float* pred, const float* target, int n, int B, int64_t
   return 0;
 }
 
+int ral_forward_loss_means(ral_handle* h, const float* x, const float* target, float* y, int B, float* dy, float* snr,
+                           float* rmse, double* means3, double* scratch64, ral_stream s) {
+  if (!h) return fail("null handle");
+  if (!x || !target || !y || !means3 || !scratch64) return fail("ral_forward_loss_means: null pointer");
+  if (h->kind == 1 && dy && unet_public(h->u)->cfg.train)      // U-Net: the output BatchNorm, the loss and the backward's first sums in one kernel
+    return unet_forward_loss(h->u, x, target, y, B, dy, snr, rmse, scratch64, means3, 1.0 / (double)B, 1, (hipStream_t)s, g_err, sizeof(g_err));
+  if (ral_forward(h, x, y, B, 1, s)) return -1;
+  const ral_config& c = h->kind == 1 ? unet_public(h->u)->cfg
+                        : (h->kind == 2 ? acdae_public(h->a)->cfg : (h->kind == 3 ? danet_public(h->d)->cfg : h->m->cfg));
+  return ral_loss_means(y, target, c.leads * c.L, B, B, dy, snr, rmse, means3, scratch64, s);
+}
+
 int ral_loss_flat(const float* pred, const float* target, int n, int B, int64_t global_windows, float* dy, float* snr,
                   float* rmse, double* loss_sum, ral_stream s) {
   if (!pred || !target) return fail("ral_loss_flat: null pointer");

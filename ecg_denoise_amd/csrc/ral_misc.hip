@@ -161,39 +161,7 @@ __global__ __launch_bounds__(256) void k_final_fwd(const float* __restrict__ u0,
   }
 }
 
-// ---------------------------------------------------------------------------------
-// loss + metrics: per window sse = sum (p-t)^2, sy2 = sum t^2 over leads*L
-//   snr = 10 log10(sy2/sse), rmse = sqrt(sse/n), dy = 2 (p-t) / (global_B * n)
-//   loss_sum += sse / n   (caller divides by the global batch)
-// ---------------------------------------------------------------------------------
-// One thread per workgroup adds the workgroup's share.  With `fin` (ral_loss_mean) the LAST workgroup to arrive also
-// finishes the job on the device: fin[0] = total * fin_scale (the mean over the global batch), and the accumulator and
-// the arrival counter go back to zero for the next call - no fill kernel before the launch, no division kernel after it
-// (they were two torch kernels per training step).  scratch: {double sum, unsigned long long arrivals}, zero on entry.
-// fin3 (ral_loss_means): the sums of the windows' SNR and RMSE ride along and their means over the global batch leave as
-// fin[1], fin[2] - the trainer's per-step metrics then cost no kernel of their own.  The four words then sit in FOUR cache
-// lines (scratch of 64 doubles: sum [0], arrivals [16], SNR [32], RMSE [48]): same-line atomics are served one after the other,
-// ~12 ns each (256 workgroups: 12.8 us with two words in one line, 18.8 with four), different lines side by side.
-RAL_DEV void loss_commit(double* sum, double mine, double* fin, double fin_scale, int fin3 = 0, double msnr = 0.0, double mrmse = 0.0) {
-  atomicAdd(sum, mine);
-  if (!fin) return;
-  if (fin3) { atomicAdd(sum + 32, msnr); atomicAdd(sum + 48, mrmse); }
-  unsigned long long* cnt = reinterpret_cast<unsigned long long*>(sum + (fin3 ? 16 : 1));
-  __threadfence();
-  if (atomicAdd(cnt, 1ull) == (unsigned long long)gridDim.x - 1ull) {
-    __threadfence();
-    const double tot = atomicAdd(sum, 0.0);
-    fin[0] = tot * fin_scale;
-    atomicExch(reinterpret_cast<unsigned long long*>(sum), 0ull);
-    if (fin3) {
-      fin[1] = atomicAdd(sum + 32, 0.0) * fin_scale;
-      fin[2] = atomicAdd(sum + 48, 0.0) * fin_scale;
-      atomicExch(reinterpret_cast<unsigned long long*>(sum + 32), 0ull);
-      atomicExch(reinterpret_cast<unsigned long long*>(sum + 48), 0ull);
-    }
-    atomicExch(cnt, 0ull);
-  }
-}
+// (loss_commit: ral_device.hpp)
 __global__ __launch_bounds__(256) void k_loss(const float* __restrict__ pred, const float* __restrict__ target,
                                               float* __restrict__ dy, float* __restrict__ snr,
                                               float* __restrict__ rmse, double* __restrict__ loss_sum, int n,

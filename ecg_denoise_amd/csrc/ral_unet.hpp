@@ -23,6 +23,9 @@ UNetModel* unet_create(const ral_config* c, char* err, size_t cap);
 void unet_destroy(UNetModel* u);
 int unet_bind(UNetModel* u, float* params, float* grads, float* am, float* av, float* state, double* bn_sums);
 int unet_forward(UNetModel* u, const float* x, float* y, int B, int training, hipStream_t s, char* err, size_t cap);
+// training forward + MSE loss / SNR / RMSE sums + dy in one pass over the output (see unet_forward_loss, ral_unet.hip)
+int unet_forward_loss(UNetModel* u, const float* x, const float* target, float* y, int B, float* dy, float* snr, float* rmse,
+                      double* loss_sum, double* fin, double fin_scale, int fin3, hipStream_t s, char* err, size_t cap);
 int unet_backward(UNetModel* u, const float* dy, float* dx, int B, hipStream_t s, char* err, size_t cap);
 // staged execution (data-parallel sync-BatchNorm): gwin = windows of the global batch
 int unet_forward_stage(UNetModel* u, const float* x, int B, int training, int si, int64_t gwin, hipStream_t s, char* err, size_t cap);

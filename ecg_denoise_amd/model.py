@@ -229,6 +229,32 @@ class _ModuleBase:
         self._dy = dy
         return loss, snr, rmse
 
+    def forward_loss(self, x, target):
+        """`pred = model(x); loss = criterion(pred, target)` and the step's SNR / RMSE (denoise_train.py:52-53,58-59) as ONE
+        library call in training mode: the same numbers as `forward` + `loss_and_metrics`; the U-Net's output BatchNorm, its
+        loss sums and the first sums of its backward pass then share one pass over the output (ral_forward_loss_means)."""
+        if not self.training:
+            pred = self.forward(x)
+            return (pred,) + tuple(self.loss_and_metrics(pred, target))
+        x = self._check_x(x)
+        target = target.contiguous()
+        B = x.shape[0]
+        y = torch.empty_like(x)
+        self._x = x
+        snr = torch.empty(B, dtype=torch.float32, device=x.device)
+        rmse = torch.empty_like(snr)
+        means = torch.empty(3, dtype=torch.float64, device=x.device)
+        dy = torch.empty_like(x)
+        if getattr(self, "_loss_scratch", None) is None:
+            self._loss_scratch = torch.zeros(64, dtype=torch.float64, device=x.device)
+        _lib.check(_lib.lib().ral_forward_loss_means(self.eng.h, _ptr(x), _ptr(target), _ptr(y), B, _ptr(dy), _ptr(snr), _ptr(rmse),
+                                                     _ptr(means), _ptr(self._loss_scratch), _stream()))
+        for k in self.eng.counters:
+            self.eng.counters[k] += 1
+        self._means = means
+        self._dy = dy
+        return y, means[:1], snr, rmse
+
     def backward(self, dy=None, want_dx=False):
         dy = self._dy if dy is None else dy.contiguous()
         dx = torch.empty_like(dy) if want_dx else None
@@ -254,8 +280,7 @@ class _ModuleBase:
 
     def train_step(self, x, target, lr=1e-3):
         """zero_grad -> forward -> mse -> backward -> Adam (denoise_train.py:51-57)."""
-        pred = self.forward(x)
-        loss, snr, rmse = self.loss_and_metrics(pred, target)
+        pred, loss, snr, rmse = self.forward_loss(x, target)
         self.backward()
         self.step(lr)
         return {"loss": loss, "pred": pred, "snr": snr, "rmse": rmse}

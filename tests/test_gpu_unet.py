@@ -145,3 +145,42 @@ def test_unet_backward_twice_gives_the_same_gradients():
     for k in g1:
         if g1[k].double().norm().item() > 1e-7:          # (zero-gradient biases in front of a BatchNorm are pure noise)
             assert rel(g2[k].cpu().numpy(), g1[k].cpu().numpy()) < 1e-5, k
+
+
+@pytest.mark.parametrize("leads,L,B", [(2, 512, 2048), (1, 256, 37), (2, 48, 5), (2, 2048, 9), (2, 64, 1025)])
+def test_unet_forward_loss_in_one_call_equals_forward_then_loss(leads, L, B):
+    """`forward_loss` (ral_forward_loss_means: the output BatchNorm, the loss sums, dy and the first two sums of the backward pass
+    in ONE kernel, k_unet_out_loss) against `forward` + `loss_and_metrics` + `backward` (k_unet_out, k_loss_w, k_unet_gsums) on
+    twin models: the prediction, dy, the per-window metrics and the loss to 1e-6, the running
+    statistics and every gradient to the rounding noise of the atomics.  Then a second backward from the same dy (the sums of
+    the one-call path are used once; the second pass forms them with k_unet_gsums) and a backward from a COPY of dy (another
+    pointer: the sums left behind must not be used)."""
+    from ecg_denoise_amd import UNet
+    p32 = O.init_params(O.unet_param_shapes(leads), 77)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, leads, L, generator=g).to(DEV); t = torch.randn(B, leads, L, generator=g).to(DEV)
+    a = UNet(leads=leads, L=L, max_batch=B, device=DEV); a.load_state_dict(p32, strict=False); a.train()
+    b = UNet(leads=leads, L=L, max_batch=B, device=DEV); b.load_state_dict(p32, strict=False); b.train()
+    ya = a(x); la, sa, ra = a.loss_and_metrics(ya, t); a.backward()
+    yb, lb, sb, rb = b.forward_loss(x, t); b.backward()
+    torch.cuda.synchronize()
+    # (twin models: their BatchNorm sums are accumulated with atomics in an order of their own - equal to rounding, not bit for bit)
+    assert rel(yb.cpu().numpy(), ya.cpu().numpy()) < 1e-6 and rel(b._dy.cpu().numpy(), a._dy.cpu().numpy()) < 1e-6
+    # (the sums of squares are the same expressions in two kernels, contracted into fused multiply-adds as the compiler saw fit in each)
+    assert rel(sb.cpu().numpy(), sa.cpu().numpy()) < 1e-6 and rel(rb.cpu().numpy(), ra.cpu().numpy()) < 1e-6
+    assert abs(la.item() - lb.item()) <= 1e-6 * abs(la.item())
+    ga, gb = a.named_grads(), b.named_grads()
+
+    def same(g1, g2):
+        for k in g1:
+            if g1[k].double().norm().item() > 1e-5:      # (the oracle bar of these gradients is 1e-4; two runs differ by the
+                assert rel(g2[k].cpu().numpy(), g1[k].cpu().numpy()) < 5e-5, k   # noise of their float atomics, ~1e-5 on the BatchNorm weights)
+    same(ga, gb)
+    sda, sdb = a.state_dict(), b.state_dict()
+    for k in sda:
+        if "running" in k:
+            np.testing.assert_allclose(sdb[k].cpu().numpy(), sda[k].cpu().numpy(), rtol=1e-6, atol=1e-7, err_msg=k)
+    ref = {k: v.clone() for k, v in gb.items()}
+    b.backward(); same(ref, b.named_grads())                     # the same dy again: k_unet_gsums this time
+    yb2, _, _, _ = b.forward_loss(x, t)
+    b.backward(b._dy.clone()); same(ref, b.named_grads())        # running statistics moved, batch statistics did not
