@@ -13,7 +13,7 @@ KIND_OF = {"k_qkv_fwd": "qkv_fwd", "k_attn_fwd": "attn_fwd", "k_mlp_fwd": "mlp_f
            "k_attn_bwd_vkv": "attn_bwd", "k_attn_table_reduce": "attn_bwd",
            "k_attn_bwd_w": "attn_bwd", "k_attn_bwd_h": "attn_bwd", "k_attn_bwd_m": "attn_bwd", "k_attn_bwd_mh": "attn_bwd", "k_attn_fwd_w": "attn_fwd",   # (k_attn_tpart_reduce: 0.1 MB
            # behind 14 of the 18 attention launches - not a launch of its own in the per-launch average)
-           "k_mlp_fwd_w": "mlp_fwd", "k_mlp_fwd_wh": "mlp_fwd", "k_mlp_fwd_h": "mlp_fwd", "k_mlp_bwd_h": "mlp_bwd", "k_mlp_bwd_w": "mlp_bwd",
+           "k_mlp_fwd_w": "mlp_fwd", "k_mlp_fwd_wh": "mlp_fwd", "k_mlp_fwd_h": "mlp_fwd", "k_mlp_bwd_h": "mlp_bwd", "k_mlp_bwd_w": "mlp_bwd", "k_mlp_bwd_w2": "mlp_bwd",
            "k_qkv_fwd_ws": "qkv_fwd",
            "k_qkv_fwd_h": "qkv_fwd", "k_qkv_bwd_h": "qkv_bwd",
            "k_unet_infer": "unet_infer_fused", "k_unet_fwd_t": "unet_fwd_stage", "k_unet_out": "unet_fwd_stage"}
