@@ -165,3 +165,24 @@ def test_state_dict_round_trip_and_errors():
     bad = dict(sd); bad["conv1.0.weight"] = torch.zeros(8, 3, 3)
     with pytest.raises(RalError):
         m.load_state_dict(bad)
+
+
+def test_forward_loss_in_one_call_is_forward_then_loss():
+    """`forward_loss` (ral_forward_loss_means) on a model without a BatchNorm at its output runs the same kernels as `forward` +
+    `loss_and_metrics`: prediction, dy, metrics and loss bit for bit, the same gradients after `backward`."""
+    from ecg_denoise_amd import RALENet
+    B = 6
+    a = RALENet("full", leads=2, L=512, max_batch=B, device=DEV, seed=4)
+    b = RALENet("full", leads=2, L=512, max_batch=B, device=DEV, seed=4)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, 2, 512, generator=g).to(DEV); t = torch.randn(B, 2, 512, generator=g).to(DEV)
+    a.train(); b.train()
+    ya = a(x); la, sa, ra = a.loss_and_metrics(ya, t); a.backward()
+    yb, lb, sb, rb = b.forward_loss(x, t); b.backward()
+    torch.cuda.synchronize()
+    assert torch.equal(ya, yb) and torch.equal(a._dy, b._dy) and torch.equal(sa, sb) and torch.equal(ra, rb)
+    assert la.item() == lb.item()
+    assert rel(b.eng.grads.cpu().numpy(), a.eng.grads.cpu().numpy()) < 1e-6
+    b.eval()
+    out = b.forward_loss(x, t)              # eval mode: forward + metrics, no gradient state touched
+    assert len(out) == 4 and torch.equal(out[0], b(x))
