@@ -41,7 +41,7 @@ static const char* const KNOB_NAMES[] = {
   "DANET_GRID_B", "DANET_GRID_D", "DANET_GRID_F", "DANET_GRID_W", "DIAG_SKIP_WIDE_DW", "DW_F16", "DW_KSPLIT_128", "DW_KSPLIT_16",
   "DW_KSPLIT_32", "DW_KSPLIT_64", "DW_KSPLIT_8", "DW_LDS", "DW_PRIO", "DW_SETS", "F16_SPLIT", "FUSE_DW", "GRID_ATTNB", 
   "GRID_ATTNW", "GRID_FWD", "GRID_MLPB", "GRID_MLPBW", "GRID_MLPS", "GRID_MLPW", "GRID_QKVB", "GRID_QKVW", "GRID_RESB", "LOSS_GRID",
-  "MLP_BWD_W", "MLP_F16", "MLP_FWD_W", "MLP_HLDS", "MLP_HTHREADS", "MLP_LDS", "MLP_TOK", "QKVB_F16", "QKV_WS", "UNET_BWD_GRID",
+  "MLP_BWD_W", "MLP_F16", "MLP_FWD_W", "MLP_HLDS", "MLP_HTHREADS", "MLP_LDS", "MLP_TOK", "PREP_OVERLAP", "QKVB_F16", "QKV_WS", "UNET_BWD_GRID",
   "UNET_BWD_WP", "UNET_DEBUG", "UNET_EVAL_GRID", "UNET_FOLD", "UNET_FUSED", "UNET_FWD_GRID", "UNET_NREP", "UNET_WG_PER_CU"};
 static std::mutex g_knob_mu;
 static std::map<std::string, long long>& knob_table() { static std::map<std::string, long long> t; return t; }
@@ -315,6 +315,11 @@ struct RalModel {
   bool want_dw = true;      // false inside ral_backward_input: frozen weights, data gradients only
   int dec_lanes = 0; bool dec_side = false;   // lanes / side streams that carried the last backward (bucket events)
   hipEvent_t ev_bwd_done = nullptr;          // recorded at the end of ral_backward_end
+  // weight preparation under the stem: the split planes of this forward (and, in training, the transposes + their planes for
+  // its backward) are formed on lane 0's weight-gradient stream - idle during a forward - while the caller's stream runs the
+  // stem conv / BatchNorm; fwd_end / bwd_begin wait for the events instead of launching the kernels (side_stream = 0: inline)
+  hipEvent_t ev_prep_go = nullptr, ev_prep_fwd = nullptr, ev_prep_bwd = nullptr;
+  bool prep_fwd = false, prep_bwd = false;
   bool bwd_recorded = false;
   float* paramsT = nullptr;   // transposed copies of the weight matrices (same offsets), refreshed per backward
   unsigned short* wh = nullptr;             // tiled split planes of the wide levels' weight matrices (a matrix at twice its float
@@ -583,6 +588,22 @@ static int fwd_begin(RalModel* m, const float* x, int B, int training, hipStream
   if (training && !m->bn_sums) return fail("training forward needs bn_sums bound");
   const Layout& Y = m->lay;
   m->last_x = x; m->last_B = B;
+  m->prep_fwd = m->prep_bwd = false;
+  static const bool prep_on = ral_knob("PREP_OVERLAP", 1) != 0;
+  if (prep_on && m->side_stream && m->ev_prep_go) {
+    hipStream_t ps = lanes_of(m)->l[0].s2;
+    HIP_OK(hipEventRecord(m->ev_prep_go, s));            // (the parameters are final: everything queued on s so far has run)
+    HIP_OK(hipStreamWaitEvent(ps, m->ev_prep_go, 0));
+    if (m->f16_split > 0) launch_tile_planes(m->params, m->wh, m->wdesc, m->ndesc, m->nwork, 0, ps);
+    HIP_OK(hipEventRecord(m->ev_prep_fwd, ps));
+    m->prep_fwd = true;
+    if (training) {
+      launch_transpose_mats(m->params, m->paramsT, m->tdesc, m->tn, m->ttotal, ps);
+      if (m->f16_split > 0) launch_tile_planes(m->paramsT, m->whT, m->wdescT, m->ndescT, m->nworkT, 1, ps);
+      HIP_OK(hipEventRecord(m->ev_prep_bwd, ps));
+      m->prep_bwd = true;
+    }
+  }
   if (training) {
     HIP_OK(hipMemsetAsync(m->bn_sums, 0, 64 * sizeof(double), s));
     launch_conv1_fwd(m->cfg.leads, 0, x, m->params + Y.conv1_w, m->params + Y.conv1_b, m->a0, m->bn_sums, nullptr,
@@ -603,7 +624,8 @@ static int fwd_end(RalModel* m, float* y, int B, int64_t global_windows, int tra
     launch_bn_apply8(m->a0, m->ss, m->x0, (size_t)B * m->L, s);
   }
   const bool tr = training != 0;
-  if (m->f16_split > 0) launch_tile_planes(m->params, m->wh, m->wdesc, m->ndesc, m->nwork, 0, s);   // split planes of the wide levels' weights
+  if (m->prep_fwd) { HIP_OK(hipStreamWaitEvent(s, m->ev_prep_fwd, 0)); m->prep_fwd = false; }   // split planes of the wide levels' weights: formed under the stem
+  else if (m->f16_split > 0) launch_tile_planes(m->params, m->wh, m->wdesc, m->ndesc, m->nwork, 0, s);
   const int nl = plan_lanes(m, B, s);
   fork_lanes(m, s);
   LaneSet* LS = lanes_of(m);
@@ -729,8 +751,11 @@ static int bwd_begin(RalModel* m, const float* dy, int B, hipStream_t s) {
   const Layout& Y = m->lay;
   HIP_OK(hipMemsetAsync(m->grads, 0, (size_t)Y.nparam * sizeof(float), s));
   HIP_OK(hipMemsetAsync(m->bn_sums + 32, 0, 32 * sizeof(double), s));
-  launch_transpose_mats(m->params, m->paramsT, m->tdesc, m->tn, m->ttotal, s);
-  if (m->f16_split > 0) launch_tile_planes(m->paramsT, m->whT, m->wdescT, m->ndescT, m->nworkT, 1, s);
+  if (m->prep_bwd) { HIP_OK(hipStreamWaitEvent(s, m->ev_prep_bwd, 0)); m->prep_bwd = false; }   // transposes + their planes: formed during the forward
+  else {
+    launch_transpose_mats(m->params, m->paramsT, m->tdesc, m->tn, m->ttotal, s);
+    if (m->f16_split > 0) launch_tile_planes(m->paramsT, m->whT, m->wdescT, m->ndescT, m->nworkT, 1, s);
+  }
   HIP_OK(hipMemsetAsync(m->gmax, 0, 18 * 4 * 4 * sizeof(unsigned), s));
   float** gy = m->gy; float** gin = m->gin;
   const int nl = plan_lanes(m, B, s);
@@ -896,6 +921,7 @@ static void destroy_model(RalModel* m) {
   }
   for (auto& pr : m->prof_ev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (m->ev_bwd_done) (void)hipEventDestroy(m->ev_bwd_done);
+  for (hipEvent_t e : {m->ev_prep_go, m->ev_prep_fwd, m->ev_prep_bwd}) if (e) (void)hipEventDestroy(e);
   if (m->slab) (void)hipFree(m->slab);
   delete m;
 }
@@ -969,6 +995,9 @@ int ral_create(const ral_config* cfg, ral_handle** out) {
       ok(hipEventCreateWithFlags(&ln.ev_dec_side, hipEventDisableTiming));
     }
     ok(hipEventCreateWithFlags(&m->ev_bwd_done, hipEventDisableTiming));
+    ok(hipEventCreateWithFlags(&m->ev_prep_go, hipEventDisableTiming));
+    ok(hipEventCreateWithFlags(&m->ev_prep_fwd, hipEventDisableTiming));
+    ok(hipEventCreateWithFlags(&m->ev_prep_bwd, hipEventDisableTiming));
     if (first != hipSuccess) {
       fail("stream / event creation failed: %s", hipGetErrorString(first));
       destroy_model(m); delete h;
