@@ -760,10 +760,13 @@ static int bwd_begin(RalModel* m, const float* dy, int B, hipStream_t s) {
   float** gy = m->gy; float** gin = m->gin;
   const int nl = plan_lanes(m, B, s);
   LaneSet* LS = lanes_of(m);
-  // output conv: dy -> d(u0 + x0)   (whole batch, then the lanes fork)
-  launch_final_bwd(m->cfg.leads, dy, m->res_out[7], m->x0, m->params + Y.tc_w, m->grads + Y.tc_w, m->grads + Y.tc_b,
-                   m->du0, m->L, B, s);
   fork_lanes(m, s);
+  // output conv: dy -> d(u0 + x0), each lane its windows
+  for (int k = 0; k < nl; ++k) {
+    const Lane& ln = LS->l[k];
+    launch_final_bwd(m->cfg.leads, woff(dy, ln.w0, (size_t)m->cfg.leads * m->L), woff(m->res_out[7], ln.w0, m->E1), woff(m->x0, ln.w0, m->E1),
+                     m->params + Y.tc_w, m->grads + Y.tc_w, m->grads + Y.tc_b, woff(m->du0, ln.w0, m->E1), m->L, ln.B, ln.s);
+  }
   const bool side = m->side_stream && m->want_dw;
   if (side)   // side streams start after the gradient buffer has been zeroed
     for (int k = 0; k < nl; ++k) {
