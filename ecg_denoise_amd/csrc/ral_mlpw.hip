@@ -833,32 +833,81 @@ struct Mlpbw2Shape {
   static_assert(TOTAL >= 16 * C * C + 2 * HID + 4 * KP + 8, "the flush staging (weight-gradient tiles in doubles) fits the kernel's LDS");
 };
 
+// H16: the four CHANNEL products of a tile (fc1, fc2^T, fc1^T, proj^T: 104 of a wave's 168 fp32 matrix instructions per tile, 34
+// issue cycles each beside the vector work) as fp16-pair products - three 18-cycle instructions for four.  The weights sit in the
+// LDS as two fp16 planes per matrix (one power of two per matrix - largest |w| into [2^13, 2^14) -, second piece as it stands: the
+// three products of a pair go into ONE accumulator; no transposed copy of W1: the A operand
+// of fc1^T is a transposing read, ds_read_b64_tr_b16, of the same rows), the tile's gradient rows (dx2, du, dx1) pass one power of
+// two per tile (largest |dx2| of the tile into [2^8, 2^9): seven binades of headroom for du and dx1) that leaves with the
+// epilogues.  The weight-gradient products stay on the fp32 instruction (their operands are fp32 tiles transposed through the LDS).
 template <int C>
+struct Mlpbw2hShape {
+  using S2 = Mlpbw2Shape<C>;
+  static constexpr int KP = S2::KP, MT = S2::MT, HID = S2::HID, NP = S2::NP, LDA = KP + 8;       // LDA: plane row stride in halves
+  static constexpr int PA = HID * LDA, PP = KP * LDA;                                           // plane strides of W1 / W2T, WpT
+  static constexpr int HW1 = 0, HW2T = HW1 + 2 * PA, HWPT = HW2T + 2 * PA, HTOT = HWPT + 2 * PP;
+  static constexpr int VO = (HTOT / 2 + 3) & ~3, B1O = VO + 4 * KP, UNO = B1O + HID, SCR = UNO + 8, TOTAL = SCR + NP * S2::PSCR;
+  static_assert(TOTAL >= 16 * C * C + 2 * HID + 4 * KP + 8, "the flush staging fits the kernel's LDS");
+};
+
+typedef short mw_s16x4 __attribute__((ext_vector_type(4)));
+typedef mw_s16x4 __attribute__((address_space(3))) * mw_lds_s16x4;
+
+template <int C, bool H16>
 __global__ __launch_bounds__(128 * RAL_MLPW2_NP, 2) void k_mlp_bwd_w2(const float* __restrict__ dx2, const float* __restrict__ x1,
                                                        BlockP w, BlockP gr, float* __restrict__ dx1_out,
                                                        float* __restrict__ do_hm, int N, int B, int want_dw) {
-  using SH = Mlpbw2Shape<C>;
+  using SH = Mlpbw2Shape<C>; using SP = Mlpbw2hShape<C>;
   constexpr int KP = SH::KP, MT = SH::MT, HID = SH::HID, HW = SH::HW, NP = SH::NP, LDC = SH::LDC, LDH = SH::LDH, LDT = SH::LDT;
+  constexpr int VO = H16 ? SP::VO : SH::VO, B1O = H16 ? SP::B1O : SH::B1O, SCR = H16 ? SP::SCR : SH::SCR;
+  constexpr int LDA = SP::LDA, PA = SP::PA, PP = SP::PP;
   extern __shared__ float4 smem4[];
   float* sm = reinterpret_cast<float*>(smem4);
-  float* W1 = sm; float* W2T = sm + SH::W2TO; float* W1T = sm + SH::W1TO; float* WpT = sm + SH::WPTO;
-  float* g2 = sm + SH::VO; float* be2 = g2 + KP; float* w10 = be2 + KP; float* w2c0 = w10 + KP; float* b1 = sm + SH::B1O;
+  float* W1 = sm; float* W2T = sm + SH::W2TO; float* W1T = sm + SH::W1TO; float* WpT = sm + SH::WPTO;          // (fp32 form)
+  _Float16* hb = reinterpret_cast<_Float16*>(sm);                                                               // (H16: plane images)
+  _Float16* W1H = hb + SP::HW1; _Float16* W2TH = hb + SP::HW2T; _Float16* WpTH = hb + SP::HWPT;
+  unsigned* mxb = reinterpret_cast<unsigned*>(sm + SP::UNO);
+  float* g2 = sm + VO; float* be2 = g2 + KP; float* w10 = be2 + KP; float* w2c0 = w10 + KP; float* b1 = sm + B1O;
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int pair = wave >> 1, half = wave & 1;
-  float* PT = sm + SH::SCR + pair * SH::PSCR;                         // the pair's LN2(x1) | dx2 tiles
+  float* PT = sm + SCR + pair * SH::PSCR;                             // the pair's LN2(x1) | dx2 tiles
   float* TW = PT + 2 * MT * 16 * LDT + half * SH::WTILES;             // this wave's du | a2 tiles
   const float* TO = PT + 2 * MT * 16 * LDT + (half ^ 1) * SH::WTILES; // the other wave's
   // ---- weights -> LDS (once per workgroup)
-  for (int i = threadIdx.x; i < SH::SCR; i += blockDim.x) sm[i] = 0.f;
+  for (int i = threadIdx.x; i < SCR; i += blockDim.x) sm[i] = 0.f;
   __syncthreads();
-  for (int i = threadIdx.x; i < HID * C; i += blockDim.x) {
-    const int h = i / C, c = i - h * C;
-    const float a = w.w1[i];                         // W1[h][c]
-    W1[h * LDC + c] = a; W1T[c * LDH + h] = a;
-    W2T[h * LDC + c] = w.w2[c * HID + h];            // W2[c][h]
+  float unp = 1.f, un1 = 1.f, un2 = 1.f;            // H16: inverses of the matrices' powers of two
+  if constexpr (H16) {
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+    for (int i = threadIdx.x; i < C * C; i += blockDim.x) m0 = fmaxf(m0, fabsf(w.wp[i]));
+    for (int i = threadIdx.x; i < HID * C; i += blockDim.x) { m1 = fmaxf(m1, fabsf(w.w1[i])); m2 = fmaxf(m2, fabsf(w.w2[i])); }
+    m0 = group_max<64>(m0); m1 = group_max<64>(m1); m2 = group_max<64>(m2);
+    if (lane == 0) { atomicMax(mxb, __float_as_uint(m0)); atomicMax(mxb + 1, __float_as_uint(m1)); atomicMax(mxb + 2, __float_as_uint(m2)); }
+    __syncthreads();
+    const float sp = h2_row_scale(mxb[0]), s1 = h2_row_scale(mxb[1]), s2 = h2_row_scale(mxb[2]);
+    unp = h2_row_unscale(mxb[0]); un1 = h2_row_unscale(mxb[1]); un2 = h2_row_unscale(mxb[2]);
+    for (int i = threadIdx.x; i < HID * C; i += blockDim.x) {
+      const int h = i / C, c = i - h * C;
+      const H2 a = f16_split2u(w.w1[i] * s1);                     // W1[h][c]
+      W1H[h * LDA + c] = a.a; W1H[PA + h * LDA + c] = a.b;
+      const H2 b = f16_split2u(w.w2[c * HID + h] * s2);           // W2[c][h]
+      W2TH[h * LDA + c] = b.a; W2TH[PA + h * LDA + c] = b.b;
+    }
+    for (int i = threadIdx.x; i < C * C; i += blockDim.x) {
+      const int c = i / C, j = i - c * C;
+      const H2 a = f16_split2u(w.wp[i] * sp);                     // Wp[c][j] -> WpT[j][c]
+      WpTH[j * LDA + c] = a.a; WpTH[PP + j * LDA + c] = a.b;
+    }
+  } else {
+    for (int i = threadIdx.x; i < HID * C; i += blockDim.x) {
+      const int h = i / C, c = i - h * C;
+      const float a = w.w1[i];                         // W1[h][c]
+      W1[h * LDC + c] = a; W1T[c * LDH + h] = a;
+      W2T[h * LDC + c] = w.w2[c * HID + h];            // W2[c][h]
+    }
+    for (int i = threadIdx.x; i < C * C; i += blockDim.x) { const int c = i / C, j = i - c * C; WpT[j * LDC + c] = w.wp[i]; }   // Wp[c][j]
   }
-  for (int i = threadIdx.x; i < C * C; i += blockDim.x) { const int c = i / C, j = i - c * C; WpT[j * LDC + c] = w.wp[i]; }   // Wp[c][j]
   for (int i = threadIdx.x; i < C; i += blockDim.x) { g2[i] = w.ln2w[i]; be2[i] = w.ln2b[i]; w10[i] = w.w1[i]; w2c0[i] = w.w2[i * HID]; }
   for (int i = threadIdx.x; i < HID; i += blockDim.x) b1[i] = w.b1[i];
   const bool le = w.le != nullptr;
@@ -872,6 +921,23 @@ __global__ __launch_bounds__(128 * RAL_MLPW2_NP, 2) void k_mlp_bwd_w2(const floa
     const float4 wa = *reinterpret_cast<const float4*>(W + (16 * mo + r) * ld + 16 * kb + 4 * g);
     acc = mfma4(wa.x, bt[0], acc); acc = mfma4(wa.y, bt[1], acc); acc = mfma4(wa.z, bt[2], acc); acc = mfma4(wa.w, bt[3], acc);
     return acc;
+  };
+  // H16: (acc, accx) += W[16 mo + r][K block kb] x the split tile `bt`; with TR the A operand is the TRANSPOSE of the stored rows:
+  // A[row = column 16 mo + r of the image][k = image rows 16 kb + 4 g ..] (lane 4 q + p of a 16-lane group passes the address of
+  // image row 16 kb + 4 g + q, columns 16 mo + 4 p .. + 3 and receives column r of the four rows)
+  auto mma_h = [&](const _Float16* Wh, int plane, int mo, int kb, const H2x4& bt, f32x4& acc, auto tr) {
+    h16x4 a1, a2;
+    if constexpr (decltype(tr)::value) {
+      const _Float16* pw = Wh + (16 * kb + 4 * g + (r >> 2)) * LDA + 16 * mo + 4 * (r & 3);
+      a1 = __builtin_bit_cast(h16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((mw_lds_s16x4)(pw)));
+      a2 = __builtin_bit_cast(h16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((mw_lds_s16x4)(pw + plane)));
+    } else {
+      const _Float16* pw = Wh + (16 * mo + r) * LDA + 16 * kb + 4 * g;
+      a1 = *reinterpret_cast<const h16x4*>(pw); a2 = *reinterpret_cast<const h16x4*>(pw + plane);
+    }
+    acc = __builtin_amdgcn_mfma_f32_16x16x16f16(a1, bt.a, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x16f16(a2, bt.a, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x16f16(a1, bt.b, acc, 0, 0, 0);
   };
   auto vec4 = [&](const float* v, int tile) -> f32x4 {
     const float4 t = *reinterpret_cast<const float4*>(v + 16 * tile + 4 * g);
@@ -930,6 +996,19 @@ __global__ __launch_bounds__(128 * RAL_MLPW2_NP, 2) void k_mlp_bwd_w2(const floa
     for (int m = 0; m < MT; ++m) {
       xv[m] = f32x4{pxa[m].x, pxa[m].y, pxa[m].z, pxa[m].w};
       dv[m] = live ? f32x4{pda[m].x, pda[m].y, pda[m].z, pda[m].w} : zero4;
+    }
+    float sc_t = 1.f, inv_t = 1.f;       // H16: the tile's gradient rows times one power of two (both waves of the pair form the same one)
+    H2x4 dvh[MT];
+    if constexpr (H16) {
+      float tmax = 0.f;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) tmax = fmaxf(tmax, fmaxf(fmaxf(fabsf(dv[m][0]), fabsf(dv[m][1])), fmaxf(fabsf(dv[m][2]), fabsf(dv[m][3]))));
+      const unsigned tbits = __float_as_uint(group_max<64>(tmax));
+      const int tf = 262 - (int)(tbits >> 23);
+      sc_t = tbits == 0u ? 1.0f : __uint_as_float((unsigned)(tf < 187 ? (tf > 1 ? tf : 1) : 187) << 23);
+      inv_t = __uint_as_float((254u << 23) - __float_as_uint(sc_t));
+#pragma unroll
+      for (int m = 0; m < MT; ++m) dvh[m] = split4(tofloat4(dv[m] * sc_t));
     }
     float cxh[CPL], cdh[CPL];
 #pragma unroll
@@ -1017,15 +1096,27 @@ __global__ __launch_bounds__(128 * RAL_MLPW2_NP, 2) void k_mlp_bwd_w2(const floa
     }
     // ---- this wave's hidden chunks of 16 channels
     f32x4 dg[MT];
+    H2x4 gxh[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) dg[m] = zero4;
+    for (int m = 0; m < MT; ++m) { dg[m] = zero4; if constexpr (H16) gxh[m] = split4(tofloat4(gx[m])); }
     float* Tdu = TW; float* Ta2 = TW + 16 * LDT;
 #pragma unroll
     for (int hl = 0; hl < HW; ++hl) {
       const int ht = HW * half + hl;
       f32x4 u = vec4(b1, ht), da2 = zero4;
+      if constexpr (H16) {
+        f32x4 ua = zero4;
 #pragma unroll
-      for (int kb = 0; kb < MT; ++kb) { u = mma_block(W1, LDC, ht, kb, gx[kb], u); da2 = mma_block(W2T, LDC, ht, kb, dv[kb], da2); }
+        for (int kb = 0; kb < MT; ++kb) {
+          mma_h(W1H, PA, ht, kb, gxh[kb], ua, std::false_type{});
+          mma_h(W2TH, PA, ht, kb, dvh[kb], da2, std::false_type{});
+        }
+        u = ua * un1 + u;
+        da2 = da2 * (un2 * inv_t);
+      } else {
+#pragma unroll
+        for (int kb = 0; kb < MT; ++kb) { u = mma_block(W1, LDC, ht, kb, gx[kb], u); da2 = mma_block(W2T, LDC, ht, kb, dv[kb], da2); }
+      }
       f32x4 du, a2, a1v, d1v;
 #pragma unroll
       for (int q = 0; q < 4; ++q) { float a_, d_; gelu_pair(u[q], a_, d_); a1v[q] = a_; d1v[q] = d_; }
@@ -1036,8 +1127,14 @@ __global__ __launch_bounds__(128 * RAL_MLPW2_NP, 2) void k_mlp_bwd_w2(const floa
         du = da2 * d2v * d1v; a2 = g2v;
         if (hl == 0 && half == 0 && g == 0) { du[0] = du_0; a2[0] = a2_0; }    // hidden channel 0: through the conv
       } else { du = da2 * d1v; a2 = a1v; }
+      if constexpr (H16) {
+        const H2x4 duh = split4(tofloat4(du * sc_t));
 #pragma unroll
-      for (int mo = 0; mo < MT; ++mo) dg[mo] = mma_block(W1T, LDH, mo, ht, du, dg[mo]);
+        for (int mo = 0; mo < MT; ++mo) mma_h(W1H, PA, mo, ht, duh, dg[mo], std::true_type{});
+      } else {
+#pragma unroll
+        for (int mo = 0; mo < MT; ++mo) dg[mo] = mma_block(W1T, LDH, mo, ht, du, dg[mo]);
+      }
       if (want_dw) {
         *reinterpret_cast<float4*>(Tdu + r * LDT + 4 * g) = tofloat4(du);
         *reinterpret_cast<float4*>(Ta2 + r * LDT + 4 * g) = tofloat4(a2);
@@ -1052,6 +1149,10 @@ __global__ __launch_bounds__(128 * RAL_MLPW2_NP, 2) void k_mlp_bwd_w2(const floa
         }
         sb1[hl] += du;
       }
+    }
+    if constexpr (H16) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) dg[m] = dg[m] * (un1 * inv_t);
     }
     // ---- second meeting: the two partial d LN2(x1) tiles (a + b = b + a: both waves hold the same sum)
 #pragma unroll
@@ -1077,8 +1178,14 @@ __global__ __launch_bounds__(128 * RAL_MLPW2_NP, 2) void k_mlp_bwd_w2(const floa
 #pragma unroll
     for (int m = 0; m < MT; ++m) dx[m] = dv[m] + (dyh[m] - m1 - xh[m] * m2) * rstd;
     f32x4 o = zero4;
+    if constexpr (H16) {
 #pragma unroll
-    for (int kb = 0; kb < MT; ++kb) o = mma_block(WpT, LDC, half, kb, dx[kb], o);
+      for (int kb = 0; kb < MT; ++kb) mma_h(WpTH, PP, half, kb, split4(tofloat4(dx[kb] * sc_t)), o, std::false_type{});
+      o = o * (unp * inv_t);
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < MT; ++kb) o = mma_block(WpT, LDC, half, kb, dx[kb], o);
+    }
     if (live) {
       *reinterpret_cast<float4*>(dx1_out + wo + (size_t)tok * C + 16 * half + 4 * g) = tofloat4(mine(dx));
       *reinterpret_cast<float4*>(do_hm + wo + ((size_t)(4 * half + g) * N + tok) * 4) = tofloat4(o);
@@ -1135,16 +1242,17 @@ __global__ __launch_bounds__(128 * RAL_MLPW2_NP, 2) void k_mlp_bwd_w2(const floa
 // Measured at batch 2048 (rocprofv3, serialised step, us per launch; k_mlp_bwd_s / this kernel): C = 16 (N = 256): 181 / 150.5;
 // C = 8 (N = 512): 247 / 153.  An f16 form of it (every product as fp16 pairs, one power of two per tile on the gradient
 // side; built, parity-clean, removed again) measured 146.5 / 152.8: the kernel is not bound by its matrix instructions.
-// Round 5 (operands requested a tile ahead, flush through doubles): C = 16: 111, C = 8: 139; C = 32 (N = 128): k_mlp_bwd_s 241,
-// k_mlp_bwd_w2 178 - 182.  Its tile loop is 1 571 instructions per wave and tile (~1 000 vector, 168 matrix, 75 transcendental)
+// Round 5 (operands requested a tile ahead, flush through doubles): C = 16: 111, C = 8: 139 - and the f16 form again (as
+// k_mlp_bwd_w2's, transposing reads for fc1^T): 108 / 137.6, still not worth its code; C = 32 (N = 128): k_mlp_bwd_s 241,
+// k_mlp_bwd_w2 178 - 182 on the fp32 instruction, 167 with the channel products as fp16 pairs (default where the model allows).  Its tile loop is 1 571 instructions per wave and tile (~1 000 vector, 168 matrix, 75 transcendental)
 // and takes ~27 000 cycles per pair of tiles and SIMD: both pipes are under half busy, the waves wait on each other's chain
 // (fc1 MFMAs -> GELU -> fc1^T MFMAs -> LDS transposes -> weight-gradient MFMAs) with two waves per SIMD to hide it.
 // MLP_BWD_W: 0 never, 1: C = 16 only, 2: C = 8 and 16, 3 (default): C = 32 too (k_mlp_bwd_w2, two waves per tile).
 int mlp_bwd_w_kind(int C, int N, bool f16_ok) {
-  (void)f16_ok;
   static const int on = (int)ral_knob("MLP_BWD_W", 3);
+  static const int h16 = (int)ral_knob("MLP_BWD_W_F16", 1);   // C = 32: the channel products as fp16 pairs where the model allows them
   if (!on || N % 16 != 0 || !(C == 16 || (on >= 2 && C == 8) || (on >= 3 && C == 32))) return 0;
-  return 1;
+  return (C == 32 && f16_ok && h16) ? 2 : 1;
 }
 template <int C>
 static void go_mlp_bwd_w(const float* dx2, const float* x1, const BlockP& w, const BlockP& gr, float* dx1, float* do_hm, int N, int B,
@@ -1159,21 +1267,22 @@ static void go_mlp_bwd_w(const float* dx2, const float* x1, const BlockP& w, con
   if (grid > nwg) grid = nwg;
   k_mlp_bwd_w<C><<<grid, 256, lds, s>>>(dx2, x1, w, gr, dx1, do_hm, N, B, want_dw ? 1 : 0);
 }
+template <bool H16>
 static void go_mlp_bwd_w2(const float* dx2, const float* x1, const BlockP& w, const BlockP& gr, float* dx1, float* do_hm, int N, int B,
                           bool want_dw, hipStream_t s) {
   using SH = Mlpbw2Shape<32>;
   static const int genv = (int)ral_knob("GRID_MLPBW", 0);
   const int nwg = (B * (N / 16) + SH::NP - 1) / SH::NP;
-  const size_t lds = (size_t)SH::TOTAL * sizeof(float);
-  RAL_SET_LDS((k_mlp_bwd_w2<32>), lds);
+  const size_t lds = (size_t)(H16 ? Mlpbw2hShape<32>::TOTAL : SH::TOTAL) * sizeof(float);
+  RAL_SET_LDS((k_mlp_bwd_w2<32, H16>), lds);
   int grid = genv > 0 ? genv : 256 * (4 / SH::NP);      // (eight waves per CU: 232 registers)
   if (grid > nwg) grid = nwg;
-  k_mlp_bwd_w2<32><<<grid, 128 * SH::NP, lds, s>>>(dx2, x1, w, gr, dx1, do_hm, N, B, want_dw ? 1 : 0);
+  k_mlp_bwd_w2<32, H16><<<grid, 128 * SH::NP, lds, s>>>(dx2, x1, w, gr, dx1, do_hm, N, B, want_dw ? 1 : 0);
 }
 void launch_mlp_bwd_w(int C, int kind, const float* dx2, const float* x1, const BlockP& w, const BlockP& gr, float* dx1, float* do_hm, int N, int B,
                       bool want_dw, hipStream_t s) {
-  (void)kind;
-  if (C == 32) go_mlp_bwd_w2(dx2, x1, w, gr, dx1, do_hm, N, B, want_dw, s);
+  if (C == 32 && kind == 2) go_mlp_bwd_w2<true>(dx2, x1, w, gr, dx1, do_hm, N, B, want_dw, s);
+  else if (C == 32) go_mlp_bwd_w2<false>(dx2, x1, w, gr, dx1, do_hm, N, B, want_dw, s);
   else if (C == 8) go_mlp_bwd_w<8>(dx2, x1, w, gr, dx1, do_hm, N, B, want_dw, s);
   else go_mlp_bwd_w<16>(dx2, x1, w, gr, dx1, do_hm, N, B, want_dw, s);
 }

@@ -3,7 +3,7 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r5
 for V in ${@:-2 3}; do
 
-OPT="--opt mlp_bwd_w=$V"
+OPT="--opt mlp_bwd_w=$V ${XOPT}"
 echo "== mlp_bwd_w=$V"
 ( export RAL_LANES=1 RAL_NO_SIDE_STREAM=1
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r5/mb -- python3 bench.py $OPT ${BATCH:+--batch $BATCH} --steps 5 --warmup 2 --no-cpu --no-infer --no-fp32 > gpurun_out/r5/mb.log 2>&1
