@@ -561,8 +561,9 @@ def main():
             "higher_is_better": True, "scaling": "strong" if a.global_batch else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "arithmetic": "fp32 tensors and accumulators; the Linear layers of the two wide levels (C = 64, 128: forward, "
-                          "data-gradient and weight-gradient products), the MLP forward of the narrow levels (C = 8, 16, 32) and the attention "
-                          "score tiles (S = q k^T, dP = dO v^T; head_dim 4) are error-compensated fp16-pair products on the "
+                          "data-gradient and weight-gradient products), the MLP forward of the narrow levels (C = 8, 16, 32), the channel products of "
+                          "the C = 32 MLP backward and every contraction of the attention backward plus the forward's score tiles "
+                          "(S = q k^T, dP = dO v^T, P and dS against v, dO, q, k; head_dim 4) are error-compensated fp16-pair products on the "
                           "f16 matrix cores (x = h1 + h2, ~2^-22 relative; operands brought into range by powers of two per "
                           "weight matrix / token / head, nothing clamped); everything else on the fp32 MFMA / vector ALU.  "
                           "fp32_mfma: the same step with ral_set_option f16_split=0 (every product on the fp32 MFMA)",
