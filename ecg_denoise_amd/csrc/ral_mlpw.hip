@@ -290,6 +290,18 @@ __global__ __launch_bounds__(256, RAL_MLPW_WPE) void k_mlp_fwd_wh(const float* _
     accx = __builtin_amdgcn_mfma_f32_16x16x16f16(a2, bt.a, accx, 0, 0, 0);
     accx = __builtin_amdgcn_mfma_f32_16x16x16f16(a1, bt.b, accx, 0, 0, 0);
   };
+  // C = 32: the K = 2 x 16 channels of a row in ONE v_mfma_f32_16x16x32_f16 (the issue cycles of the K = 16 instruction): the lane's
+  // k slots 8 g .. 8 g + 7 are channels 4 g .. 4 g + 3 and 16 + 4 g .. + 3 on both operands
+  auto mma_h32 = [&](const _Float16* Wh, int plane, int ld, int mo, const H2x4& b0, const H2x4& b1_, f32x4& acc, f32x4& accx) {
+    const _Float16* p = Wh + (16 * mo + r) * ld + 4 * g;
+    const h16x4 a10 = *reinterpret_cast<const h16x4*>(p), a11 = *reinterpret_cast<const h16x4*>(p + 16);
+    const h16x4 a20 = *reinterpret_cast<const h16x4*>(p + plane), a21 = *reinterpret_cast<const h16x4*>(p + plane + 16);
+    const f16x8 a1 = __builtin_shufflevector(a10, a11, 0, 1, 2, 3, 4, 5, 6, 7), a2 = __builtin_shufflevector(a20, a21, 0, 1, 2, 3, 4, 5, 6, 7);
+    const f16x8 p1 = __builtin_shufflevector(b0.a, b1_.a, 0, 1, 2, 3, 4, 5, 6, 7), p2 = __builtin_shufflevector(b0.b, b1_.b, 0, 1, 2, 3, 4, 5, 6, 7);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, p1, acc, 0, 0, 0);
+    accx = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, p1, accx, 0, 0, 0);
+    accx = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, p2, accx, 0, 0, 0);
+  };
   auto vec4 = [&](const float* v, int tile) -> f32x4 {
     const float4 t = *reinterpret_cast<const float4*>(v + 16 * tile + 4 * g);
     return f32x4{t.x, t.y, t.z, t.w};
@@ -341,9 +353,10 @@ __global__ __launch_bounds__(256, RAL_MLPW_WPE) void k_mlp_fwd_wh(const float* _
         acc[m] = zero4; accx[m] = zero4;
       }
 #pragma unroll
-      for (int mo = 0; mo < MT; ++mo)
-#pragma unroll
-        for (int kb = 0; kb < MT; ++kb) mma_h(WpH, PWP, LDA, mo, kb, ob[kb], acc[mo], accx[mo]);
+      for (int mo = 0; mo < MT; ++mo) {
+        if constexpr (MT == 2) mma_h32(WpH, PWP, LDA, mo, ob[0], ob[MT - 1], acc[mo], accx[mo]);
+        else mma_h(WpH, PWP, LDA, mo, 0, ob[0], acc[mo], accx[mo]);
+      }
       float sum = 0.f;
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
@@ -390,8 +403,8 @@ __global__ __launch_bounds__(256, RAL_MLPW_WPE) void k_mlp_fwd_wh(const float* _
 #pragma unroll
       for (int ht = 0; ht < HT; ++ht) {
         f32x4 h = zero4, hx = zero4;
-#pragma unroll
-        for (int kb = 0; kb < MT; ++kb) mma_h(W1H, PW1, LDA, ht, kb, gth[s][kb], h, hx);
+        if constexpr (MT == 2) mma_h32(W1H, PW1, LDA, ht, gth[s][0], gth[s][MT - 1], h, hx);
+        else mma_h(W1H, PW1, LDA, ht, 0, gth[s][0], h, hx);
         h = (h + hx * RAL_H2_SCALE) * un1 + vec4(b1, ht);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -939,6 +952,18 @@ __global__ __launch_bounds__(128 * RAL_MLPW2_NP, 2) void k_mlp_bwd_w2(const floa
     acc = __builtin_amdgcn_mfma_f32_16x16x16f16(a2, bt.a, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x16f16(a1, bt.b, acc, 0, 0, 0);
   };
+  // the K = 2 x 16 = 32 channels of a row in ONE instruction (v_mfma_f32_16x16x32_f16 takes the issue cycles of the K = 16 one): the
+  // lane's k slots 8 g .. 8 g + 7 are channels 4 g .. 4 g + 3 and 16 + 4 g .. + 3 on both operands - any order, as long as it is the same
+  auto mma_h32 = [&](const _Float16* Wh, int plane, int mo, const H2x4& b0, const H2x4& b1_, f32x4& acc) {
+    const _Float16* pw = Wh + (16 * mo + r) * LDA + 4 * g;
+    const h16x4 a10 = *reinterpret_cast<const h16x4*>(pw), a11 = *reinterpret_cast<const h16x4*>(pw + 16);
+    const h16x4 a20 = *reinterpret_cast<const h16x4*>(pw + plane), a21 = *reinterpret_cast<const h16x4*>(pw + plane + 16);
+    const f16x8 a1 = __builtin_shufflevector(a10, a11, 0, 1, 2, 3, 4, 5, 6, 7), a2 = __builtin_shufflevector(a20, a21, 0, 1, 2, 3, 4, 5, 6, 7);
+    const f16x8 p1 = __builtin_shufflevector(b0.a, b1_.a, 0, 1, 2, 3, 4, 5, 6, 7), p2 = __builtin_shufflevector(b0.b, b1_.b, 0, 1, 2, 3, 4, 5, 6, 7);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, p1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, p1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, p2, acc, 0, 0, 0);
+  };
   auto vec4 = [&](const float* v, int tile) -> f32x4 {
     const float4 t = *reinterpret_cast<const float4*>(v + 16 * tile + 4 * g);
     return f32x4{t.x, t.y, t.z, t.w};
@@ -1106,11 +1131,8 @@ __global__ __launch_bounds__(128 * RAL_MLPW2_NP, 2) void k_mlp_bwd_w2(const floa
       f32x4 u = vec4(b1, ht), da2 = zero4;
       if constexpr (H16) {
         f32x4 ua = zero4;
-#pragma unroll
-        for (int kb = 0; kb < MT; ++kb) {
-          mma_h(W1H, PA, ht, kb, gxh[kb], ua, std::false_type{});
-          mma_h(W2TH, PA, ht, kb, dvh[kb], da2, std::false_type{});
-        }
+        mma_h32(W1H, PA, ht, gxh[0], gxh[1], ua);
+        mma_h32(W2TH, PA, ht, dvh[0], dvh[1], da2);
         u = ua * un1 + u;
         da2 = da2 * (un2 * inv_t);
       } else {
@@ -1179,8 +1201,7 @@ __global__ __launch_bounds__(128 * RAL_MLPW2_NP, 2) void k_mlp_bwd_w2(const floa
     for (int m = 0; m < MT; ++m) dx[m] = dv[m] + (dyh[m] - m1 - xh[m] * m2) * rstd;
     f32x4 o = zero4;
     if constexpr (H16) {
-#pragma unroll
-      for (int kb = 0; kb < MT; ++kb) mma_h(WpTH, PP, half, kb, split4(tofloat4(dx[kb] * sc_t)), o, std::false_type{});
+      mma_h32(WpTH, PP, half, split4(tofloat4(dx[0] * sc_t)), split4(tofloat4(dx[1] * sc_t)), o);
       o = o * (unp * inv_t);
     } else {
 #pragma unroll
