@@ -16,7 +16,7 @@ from collections import Counter
 def main():
     d = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r02/ks_default"
     which = int(sys.argv[2]) if len(sys.argv) > 2 else 4           # a step of the timed region (2 warm-up steps first)
-    f = glob.glob(d + "/*/*kernel_trace.csv")[0]
+    f = max(glob.glob(d + "/*/*kernel_trace.csv"), key=__import__("os").path.getmtime)   # (newest: re-collections merge into the same directory)
     rows = list(csv.DictReader(open(f)))
     for r in rows:
         r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])

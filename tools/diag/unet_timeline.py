@@ -5,7 +5,7 @@ to the previous kernel of every launch (what is kernel time, what is between ker
 import csv, glob, re, sys
 d = sys.argv[1]
 which = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-f = glob.glob(d + "/*/*kernel_trace.csv")[0]
+f = max(glob.glob(d + "/*/*kernel_trace.csv"), key=__import__("os").path.getmtime)   # (newest: re-collections merge into the same directory)
 rows = list(csv.DictReader(open(f)))
 for r in rows:
     r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])

@@ -10,8 +10,8 @@ SRC, DST = os.path.join(ROOT, "gpurun_out", R), os.path.join(ROOT, "profiles")
 
 
 def one(pattern):
-    f = sorted(glob.glob(os.path.join(SRC, pattern)))
-    if not f:
+    f = sorted(glob.glob(os.path.join(SRC, pattern)), key=os.path.getmtime)   # (a re-collection merges into the same directories:
+    if not f:                                                                  #  the newest file of a pattern is the current one)
         raise SystemExit(f"missing {pattern} under {SRC}")
     return f[-1]
 
