@@ -850,7 +850,7 @@ struct Mlpbw2Shape {
 // issue cycles each beside the vector work) as fp16-pair products - three 18-cycle instructions for four.  The weights sit in the
 // LDS as two fp16 planes per matrix (one power of two per matrix - largest |w| into [2^13, 2^14) -, second piece as it stands: the
 // three products of a pair go into ONE accumulator; no transposed copy of W1: the A operand
-// of fc1^T is a transposing read, ds_read_b64_tr_b16, of the same rows), the tile's gradient rows (dx2, du, dx1) pass one power of
+// of fc1^T is a transposing read, ds_read_b64_tr_b16, of the same rows), the tile's LayerNorm rows and its gradient rows (dx2, du, dx1) pass one power of
 // two per tile (largest |dx2| of the tile into [2^8, 2^9): seven binades of headroom for du and dx1) that leaves with the
 // epilogues.  The weight-gradient products stay on the fp32 instruction (their operands are fp32 tiles transposed through the LDS).
 template <int C>
@@ -1022,15 +1022,19 @@ __global__ __launch_bounds__(128 * RAL_MLPW2_NP, 2) void k_mlp_bwd_w2(const floa
       xv[m] = f32x4{pxa[m].x, pxa[m].y, pxa[m].z, pxa[m].w};
       dv[m] = live ? f32x4{pda[m].x, pda[m].y, pda[m].z, pda[m].w} : zero4;
     }
-    float sc_t = 1.f, inv_t = 1.f;       // H16: the tile's gradient rows times one power of two (both waves of the pair form the same one)
-    H2x4 dvh[MT];
-    if constexpr (H16) {
+    // H16: the power of two that puts the largest magnitude of a tile's rows into [2^8, 2^9) (both waves of the pair form the same one)
+    auto tile_scale = [&](const f32x4 (&t)[MT]) -> float {
       float tmax = 0.f;
 #pragma unroll
-      for (int m = 0; m < MT; ++m) tmax = fmaxf(tmax, fmaxf(fmaxf(fabsf(dv[m][0]), fabsf(dv[m][1])), fmaxf(fabsf(dv[m][2]), fabsf(dv[m][3]))));
+      for (int m = 0; m < MT; ++m) tmax = fmaxf(tmax, fmaxf(fmaxf(fabsf(t[m][0]), fabsf(t[m][1])), fmaxf(fabsf(t[m][2]), fabsf(t[m][3]))));
       const unsigned tbits = __float_as_uint(group_max<64>(tmax));
       const int tf = 262 - (int)(tbits >> 23);
-      sc_t = tbits == 0u ? 1.0f : __uint_as_float((unsigned)(tf < 187 ? (tf > 1 ? tf : 1) : 187) << 23);
+      return tbits == 0u ? 1.0f : __uint_as_float((unsigned)(tf < 187 ? (tf > 1 ? tf : 1) : 187) << 23);
+    };
+    float sc_t = 1.f, inv_t = 1.f;       // the tile's gradient rows (dx2, then du and dx1 with the same factor: it leaves with the epilogues)
+    H2x4 dvh[MT];
+    if constexpr (H16) {
+      sc_t = tile_scale(dv);
       inv_t = __uint_as_float((254u << 23) - __float_as_uint(sc_t));
 #pragma unroll
       for (int m = 0; m < MT; ++m) dvh[m] = split4(tofloat4(dv[m] * sc_t));
@@ -1122,8 +1126,15 @@ __global__ __launch_bounds__(128 * RAL_MLPW2_NP, 2) void k_mlp_bwd_w2(const floa
     // ---- this wave's hidden chunks of 16 channels
     f32x4 dg[MT];
     H2x4 gxh[MT];
+    float ung = un1;                     // H16: fc1's epilogue factor (the weights' and the LayerNorm tile's powers of two)
+    if constexpr (H16) {
+      const float sg = tile_scale(gx);
+      ung = un1 * __uint_as_float((254u << 23) - __float_as_uint(sg));
 #pragma unroll
-    for (int m = 0; m < MT; ++m) { dg[m] = zero4; if constexpr (H16) gxh[m] = split4(tofloat4(gx[m])); }
+      for (int m = 0; m < MT; ++m) gxh[m] = split4(tofloat4(gx[m] * sg));
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) dg[m] = zero4;
     float* Tdu = TW; float* Ta2 = TW + 16 * LDT;
 #pragma unroll
     for (int hl = 0; hl < HW; ++hl) {
@@ -1133,7 +1144,7 @@ __global__ __launch_bounds__(128 * RAL_MLPW2_NP, 2) void k_mlp_bwd_w2(const floa
         f32x4 ua = zero4;
         mma_h32(W1H, PA, ht, gxh[0], gxh[1], ua);
         mma_h32(W2TH, PA, ht, dvh[0], dvh[1], da2);
-        u = ua * un1 + u;
+        u = ua * ung + u;
         da2 = da2 * (un2 * inv_t);
       } else {
 #pragma unroll
