@@ -3,10 +3,10 @@ the default arithmetic next to the fp32-MFMA one (the switch f16_split = 0) from
 two stay within the run-to-run noise of the fp32 atomics for the first steps.   python tools/diag/soak_split.py"""
 import os, sys, subprocess, json
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from ecg_denoise_amd import _lib
-_lib.apply_options(os.environ.get("RAL_TOOL_OPTIONS", ""))
+sys.path.insert(0, ROOT)
 if len(sys.argv) > 1:
-    sys.path.insert(0, ROOT)
+    from ecg_denoise_amd import _lib
+    _lib.apply_options(os.environ.get("RAL_TOOL_OPTIONS", ""))
     import torch
     from ecg_denoise_amd import RALENet
     torch.manual_seed(0)
