@@ -10,6 +10,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../include/ralenet.h"
@@ -45,9 +46,16 @@ static const char* const KNOB_NAMES[] = {
   "UNET_BWD_WP", "UNET_DEBUG", "UNET_EVAL_GRID", "UNET_FOLD", "UNET_FUSED", "UNET_FWD_GRID", "UNET_NREP", "UNET_WG_PER_CU"};
 static std::mutex g_knob_mu;
 static std::map<std::string, long long>& knob_table() { static std::map<std::string, long long> t; return t; }
+static std::map<std::string, int>& knob_read() { static std::map<std::string, int> t; return t; }   // switches a consumer has read already
+// grid caps, thread counts and split counts: 0 would be a launch with no workgroup (a launch error), not "automatic"
+static const char* const KNOB_MIN1[] = {
+  "DANET_GRID_A", "DANET_GRID_B", "DANET_GRID_D", "DANET_GRID_F", "DANET_GRID_W", "GRID_FWD", "GRID_ATTNB", "GRID_MLPB", "GRID_MLPS",
+  "GRID_QKVB", "GRID_RESB", "LOSS_GRID", "UNET_FWD_GRID", "UNET_EVAL_GRID", "UNET_BWD_GRID", "UNET_BWD_WP", "UNET_NREP", "DW_SETS",
+  "DW_KSPLIT_8", "DW_KSPLIT_16", "DW_KSPLIT_32", "DW_KSPLIT_64", "DW_KSPLIT_128"};
 long long ral_knob(const char* name, long long dflt) {
   {
     std::lock_guard<std::mutex> lk(g_knob_mu);
+    knob_read()[name] = 1;
     auto it = knob_table().find(name);
     if (it != knob_table().end()) return it->second;
   }
@@ -69,6 +77,31 @@ int ral_env_int(const char* name, int dflt, int lo, int hi) {
   }
   return (int)x;
 }
+int ral_num_cus() {
+  static std::mutex mu;
+  static std::map<int, int> cus;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cus.find(dev);
+  if (it != cus.end()) return it->second;
+  hipDeviceProp_t prop;
+  const int n = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  cus[dev] = n;
+  return n;
+}
+int ral_occupancy(const void* kernel, int threads, size_t lds, int dflt) {
+  static std::mutex mu;
+  static std::map<std::tuple<const void*, int, size_t>, int> cache;
+  const auto key = std::make_tuple(kernel, threads, lds);
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  int occ = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, threads, lds) != hipSuccess || occ < 1) occ = dflt;
+  cache[key] = occ;
+  return occ;
+}
 extern "C" int ral_global_option(const char* key, long long value) {
   if (!key) return fail("null key");
   std::string k(key);
@@ -78,7 +111,15 @@ extern "C" int ral_global_option(const char* key, long long value) {
   for (const char* n : KNOB_NAMES) known = known || k == n;
   if (!known) return fail("unknown switch %s", key);
   if (value < 0) return fail("switch %s: negative value %lld", key, value);
+  for (const char* n : KNOB_MIN1)
+    if (k == n && value < 1) return fail("switch %s: value %lld out of range (a grid / thread / split count: >= 1)", key, value);
+  if (k == "MLP_HTHREADS" && value != 256 && value != 512) return fail("switch %s: 256 or 512 threads (got %lld)", key, value);
   std::lock_guard<std::mutex> lk(g_knob_mu);
+  // most consumers read a switch once and keep it: a change after that first read would be ignored silently, so it is refused
+  // (the same value again is fine: tests and tools set their switches at start-up, possibly more than once)
+  auto cur = knob_table().find(k);
+  if (knob_read().count(k) && !(cur != knob_table().end() && cur->second == value))
+    return fail("switch %s was already read by the library (switches are latched at first use): set it before the first model is created", key);
   knob_table()[k] = value;
   return 0;
 }
@@ -320,6 +361,7 @@ struct RalModel {
   // stem conv / BatchNorm; fwd_end / bwd_begin wait for the events instead of launching the kernels (side_stream = 0: inline)
   hipEvent_t ev_prep_go = nullptr, ev_prep_fwd = nullptr, ev_prep_bwd = nullptr;
   bool prep_fwd = false, prep_bwd = false;
+  bool prep_stale = false;   // parameters or arithmetic options changed after the preparation was queued: the backward re-builds its planes
   bool bwd_recorded = false;
   float* paramsT = nullptr;   // transposed copies of the weight matrices (same offsets), refreshed per backward
   unsigned short* wh = nullptr;             // tiled split planes of the wide levels' weight matrices (a matrix at twice its float
@@ -589,6 +631,7 @@ static int fwd_begin(RalModel* m, const float* x, int B, int training, hipStream
   const Layout& Y = m->lay;
   m->last_x = x; m->last_B = B;
   m->prep_fwd = m->prep_bwd = false;
+  m->prep_stale = false;
   static const bool prep_on = ral_knob("PREP_OVERLAP", 1) != 0;
   if (prep_on && m->side_stream && m->ev_prep_go) {
     hipStream_t ps = lanes_of(m)->l[0].s2;
@@ -751,8 +794,9 @@ static int bwd_begin(RalModel* m, const float* dy, int B, hipStream_t s) {
   const Layout& Y = m->lay;
   HIP_OK(hipMemsetAsync(m->grads, 0, (size_t)Y.nparam * sizeof(float), s));
   HIP_OK(hipMemsetAsync(m->bn_sums + 32, 0, 32 * sizeof(double), s));
+  const bool prep_ok = m->prep_bwd && !m->prep_stale;
   if (m->prep_bwd) { HIP_OK(hipStreamWaitEvent(s, m->ev_prep_bwd, 0)); m->prep_bwd = false; }   // transposes + their planes: formed during the forward
-  else {
+  if (!prep_ok) {   // (... or formed from parameters / for options that have changed since: after them, again, from what is bound now)
     launch_transpose_mats(m->params, m->paramsT, m->tdesc, m->tn, m->ttotal, s);
     if (m->f16_split > 0) launch_tile_planes(m->paramsT, m->whT, m->wdescT, m->ndescT, m->nworkT, 1, s);
   }
@@ -1089,6 +1133,7 @@ int ral_bind(ral_handle* h, float* params, float* grads, float* adam_m, float* a
   if (h->kind == 2) return acdae_bind(h->a, params, grads, adam_m, adam_v);
   if (h->kind == 3) return danet_bind(h->d, params, grads, adam_m, adam_v, state);
   RalModel* m = h->m;
+  m->prep_stale = true;
   m->params = params; m->grads = grads; m->am = adam_m; m->av = adam_v; m->state = state; m->bn_sums = bn_sums;
   return 0;
 }
@@ -1242,7 +1287,8 @@ int ral_grad_bucket_wait(ral_handle* h, int k, ral_stream s) {
 
 int ral_backward(ral_handle* h, const float* dy, float* dx, int B, ral_stream s) {
   if (!h) return fail("null handle");
-  if (h->kind == 1) return unet_backward(h->u, dy, dx, B, (hipStream_t)s, g_err, sizeof(g_err));
+  if (h->kind == 1) return unet_backward(h->u, dy, dx, B, (hipStream_t)s, g_err, sizeof(g_err));   // (dy = NULL: the gradient ral_forward_loss_means wrote)
+  if (!dy) return fail("ral_backward: dy is NULL");
   if (h->kind == 2) return acdae_backward(h->a, dy, dx, B, (hipStream_t)s, g_err, sizeof(g_err));
   if (h->kind == 3) return danet_backward(h->d, dy, dx, B, (hipStream_t)s, g_err, sizeof(g_err));
   if (bwd_begin(h->m, dy, B, (hipStream_t)s)) return -1;
@@ -1286,7 +1332,7 @@ int ral_adam_step(ral_handle* h, double lr, double beta1, double beta2, double e
   if (h->kind == 1) { UNetPublic* u = unet_public(h->u); p = u->params; g = u->grads; am = u->am; av = u->av; n = u->nparam; }
   else if (h->kind == 2) { AcdaePublic* u = acdae_public(h->a); p = u->params; g = u->grads; am = u->am; av = u->av; n = u->nparam; }
   else if (h->kind == 3) { DanetPublic* u = danet_public(h->d); p = u->params; g = u->grads; am = u->am; av = u->av; n = u->nparam; }
-  else { p = h->m->params; g = h->m->grads; am = h->m->am; av = h->m->av; n = h->m->lay.nparam; }
+  else { p = h->m->params; g = h->m->grads; am = h->m->am; av = h->m->av; n = h->m->lay.nparam; h->m->prep_stale = true; }
   if (!p || !g || !am || !av) return fail("ral_bind: params/grads/adam buffers not bound");
   if (step < 1) return fail("step is 1-based");
   launch_adam(p, g, am, av, (size_t)n, lr, beta1, beta2, eps, step, grad_scale, (hipStream_t)s);
@@ -1302,6 +1348,7 @@ int ral_set_option(ral_handle* h, const char* key, int value) {
   }
   if (h->kind != 0) return fail("no options for this handle");
   RalModel* m = h->m;
+  m->prep_stale = true;   // (weight planes queued by a forward were formed for the options of that moment)
   if (!strcmp(key, "lanes")) { m->n_lanes = value < 1 ? 1 : (value > MAX_LANES ? MAX_LANES : value); return 0; }
   if (!strcmp(key, "side_stream")) { m->side_stream = value != 0; return 0; }
   if (!strcmp(key, "f16_split")) { m->f16_split = value; return 0; }

@@ -418,9 +418,8 @@ static int attnw_grid(K kernel, size_t lds, int N, int H, int B) {
   static const int genv = (int)ral_knob("GRID_ATTNW", 0);
   const int gmax = attnw_grid_max(N, H, B);
   if (genv > 0) return genv < gmax ? genv : gmax;
-  int occ = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, lds) != hipSuccess || occ < 1) occ = 3;
-  const int slots = 256 * (occ > 4 ? 4 : occ);
+  const int occ = ral_occupancy(reinterpret_cast<const void*>(kernel), 256, lds, 3);
+  const int slots = ral_num_cus() * (occ > 4 ? 4 : occ);
   return slots < gmax ? slots : gmax;
 }
 bool attn_bwd_w_takes(int N, int H, int Len, bool table) {
@@ -710,9 +709,8 @@ void launch_attn_bwd_w(const float* qkv, const float* o_hm, const float* do_hm, 
     static const int genv = (int)ral_knob("GRID_ATTNW", 0);
     const int gmax = attnw_grid_max(N, H, B);          // (the scratch is sized for one workgroup per four tasks)
     if (genv > 0) return genv < gmax ? genv : gmax;
-    int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64 * nwv, lds) != hipSuccess || occ < 1) occ = 3;
-    const int slots = 256 * (occ > 8 ? 8 : occ);
+    const int occ = ral_occupancy(reinterpret_cast<const void*>(kern), 64 * nwv, lds, 3);
+    const int slots = ral_num_cus() * (occ > 8 ? 8 : occ);
     const int need = (ntask + nwv - 1) / nwv;
     int g = slots < need ? slots : need;
     return g < gmax ? g : gmax;

@@ -653,9 +653,8 @@ void launch_attn_bwd_m(const float* qkv, const float* o_hm, const float* do_hm, 
   int grid = 0;
   auto grid_of = [&](auto kern) {
     const int gmax = attnw_grid_max(N, H, B);          // (the scratch is sized for one workgroup per four tasks)
-    int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64 * nwv, lds) != hipSuccess || occ < 1) occ = 3;
-    const int slots = 256 * (occ > 8 ? 8 : occ);
+    const int occ = ral_occupancy(reinterpret_cast<const void*>(kern), 64 * nwv, lds, 3);
+    const int slots = ral_num_cus() * (occ > 8 ? 8 : occ);
     const int need = (ntask + nwv - 1) / nwv;
     int g = slots < need ? slots : need;
     return g < gmax ? g : gmax;

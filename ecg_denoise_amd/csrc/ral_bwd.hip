@@ -623,6 +623,7 @@ __global__ __launch_bounds__(512, 4) void k_mlp_bwd_s(const float* __restrict__ 
   if constexpr (KS > 1) {
     float* fold = Ds;   // (KS - 1) x JOBS x (NCH x 256 + NCH x 16 + 16) floats <= 3 x 2 x 1104: inside the 4 N x LD tiles
     constexpr int PER = NCH * 256 + NCH * 16 + 16;
+    __syncthreads();    // `redd` sits at the base of the LDS, where the fold region starts: its readers (the atomics above) must be done
     float* mine = fold + ((kpart - 1) * JOBS + job) * PER;
     if (kpart > 0) {
 #pragma unroll

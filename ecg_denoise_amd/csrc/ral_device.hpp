@@ -22,6 +22,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // also reads RAL_<NAME> from the environment); ral_env_int: the two validated environment variables of the product build
 long long ral_knob(const char* name, long long dflt);
 int ral_env_int(const char* name, int dflt, int lo, int hi);
+int ral_num_cus();                                                          // compute units of the current device (cached per device)
+int ral_occupancy(const void* kernel, int threads, size_t lds, int dflt);   // workgroups per CU, queried once per (kernel, threads, LDS bytes)
 
 
 #define RAL_DEV __device__ __forceinline__

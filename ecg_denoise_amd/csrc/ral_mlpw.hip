@@ -457,7 +457,7 @@ static void go_mlp_fwd_w(const float* x, const float* o, const BlockP& w, float*
   static int occ = 0;
   if (!occ && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_mlp_fwd_w<C>, 256, lds) != hipSuccess || occ < 1)) occ = 3;
   const int nwg = (B * (N / (16 * MlpwShape<C>::S)) + 3) / 4;
-  int grid = genv > 0 ? genv : 256 * (occ > 4 ? 4 : occ);
+  int grid = genv > 0 ? genv : ral_num_cus() * (occ > 4 ? 4 : occ);
   if (grid > nwg) grid = nwg;
   k_mlp_fwd_w<C><<<grid, 256, lds, s>>>(x, o, w, x1, x2, N, B);
 }
@@ -469,7 +469,7 @@ static void go_mlp_fwd_wh(const float* x, const float* o, const BlockP& w, float
   static int occ = 0;
   if (!occ && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_mlp_fwd_wh<C>, 256, lds) != hipSuccess || occ < 1)) occ = 3;
   const int nwg = (B * (N / (16 * MlpwhShape<C>::S)) + 3) / 4;
-  int grid = genv > 0 ? genv : 256 * (occ > 4 ? 4 : occ);
+  int grid = genv > 0 ? genv : ral_num_cus() * (occ > 4 ? 4 : occ);
   if (grid > nwg) grid = nwg;
   k_mlp_fwd_wh<C><<<grid, 256, lds, s>>>(x, o, w, x1, x2, N, B);
 }
@@ -1295,7 +1295,7 @@ static void go_mlp_bwd_w(const float* dx2, const float* x1, const BlockP& w, con
   RAL_SET_LDS((k_mlp_bwd_w<C>), lds);
   static int occ = 0;
   if (!occ && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_mlp_bwd_w<C>, 256, lds) != hipSuccess || occ < 1)) occ = 3;
-  int grid = genv > 0 ? genv : 256 * (occ > 3 ? 3 : occ);
+  int grid = genv > 0 ? genv : ral_num_cus() * (occ > 3 ? 3 : occ);
   if (grid > nwg) grid = nwg;
   k_mlp_bwd_w<C><<<grid, 256, lds, s>>>(dx2, x1, w, gr, dx1, do_hm, N, B, want_dw ? 1 : 0);
 }
@@ -1307,7 +1307,7 @@ static void go_mlp_bwd_w2(const float* dx2, const float* x1, const BlockP& w, co
   const int nwg = (B * (N / 16) + SH::NP - 1) / SH::NP;
   const size_t lds = (size_t)(H16 ? Mlpbw2hShape<32>::TOTAL : SH::TOTAL) * sizeof(float);
   RAL_SET_LDS((k_mlp_bwd_w2<32, H16>), lds);
-  int grid = genv > 0 ? genv : 256 * (4 / SH::NP);      // (eight waves per CU: 232 registers)
+  int grid = genv > 0 ? genv : ral_num_cus() * (4 / SH::NP);      // (eight waves per CU: 232 registers)
   if (grid > nwg) grid = nwg;
   k_mlp_bwd_w2<32, H16><<<grid, 128 * SH::NP, lds, s>>>(dx2, x1, w, gr, dx1, do_hm, N, B, want_dw ? 1 : 0);
 }

@@ -2198,9 +2198,17 @@ int unet_backward_start(UNetModel* m, const float* dy, int B, int64_t gwin, hipS
   if (B != m->last_B) { snprintf(err, cap, "backward batch %d != forward batch %d", B, m->last_B); return -1; }
   // with the fold every gradient entry is WRITTEN by k_unet_fold; the atomic path accumulates into a zeroed buffer
   if (!m->fold) (void)hipMemsetAsync(P.grads, 0, (size_t)m->lay.nparam * sizeof(float), s);
+  // dy == NULL: "the gradient unet_forward_loss wrote, untouched" - its sums are already in the output layer's backward record.
+  // A dy the caller passes explicitly is summed again, whatever its address: its CONTENTS may have changed since (loss
+  // scaling, gradient accumulation), and the stage kernels read the new values.
+  bool have_sums = false;
+  if (!dy) {
+    if (!m->gsums_dy) { snprintf(err, cap, "U-Net backward with dy = NULL must follow ral_forward_loss_means"); return -1; }
+    dy = m->gsums_dy;
+    have_sums = m->gsums_nrep == m->nrep_b;
+  }
   m->last_dy = dy;
   m->bwd_rows = 0;
-  const bool have_sums = dy && m->gsums_dy == dy && m->gsums_nrep == m->nrep_b;   // (unet_forward_loss: records zeroed, sums in place)
   m->gsums_dy = nullptr;
   if (have_sums) return 0;
   unet_zero_bwd_records(m, s);

@@ -227,6 +227,7 @@ class _ModuleBase:
                                              _ptr(means), _ptr(self._loss_scratch), _stream()))
         self._means = means
         self._dy = dy
+        self._dy_fused = False
         return loss, snr, rmse
 
     def forward_loss(self, x, target):
@@ -253,12 +254,19 @@ class _ModuleBase:
             self.eng.counters[k] += 1
         self._means = means
         self._dy = dy
+        self._dy_fused = True
         return y, means[:1], snr, rmse
 
     def backward(self, dy=None, want_dx=False):
+        """`loss.backward()` (denoise_train.py:56).  dy = None: the gradient the last loss call left (`self._dy`).  For the
+        U-Net, `forward_loss` also left the first BatchNorm-backward sums of exactly that gradient, and `backward()` starts
+        from them (a NULL dy at the C ABI); a dy passed explicitly - also `m.backward(m._dy.mul_(k))` - is always summed
+        again, so rescaling it in place is safe."""
+        fused = dy is None and getattr(self, "_dy_fused", False) and self.eng.variant == "unet"
         dy = self._dy if dy is None else dy.contiguous()
         dx = torch.empty_like(dy) if want_dx else None
-        _lib.check(_lib.lib().ral_backward(self.eng.h, _ptr(dy), _ptr(dx), dy.shape[0], _stream()))
+        self._dy_fused = False
+        _lib.check(_lib.lib().ral_backward(self.eng.h, C.c_void_p(0) if fused else _ptr(dy), _ptr(dx), dy.shape[0], _stream()))
         return dx
 
     def backward_input(self, dy):

@@ -127,6 +127,24 @@ def test_global_option_validates_its_key_and_value():
     assert L.ral_global_option(b"no_such_switch", 1) != 0 and b"unknown switch" in L.ral_last_error()
     assert L.ral_global_option(b"attn_f16", -1) != 0 and b"negative" in L.ral_last_error()
     assert L.ral_global_option(None, 1) != 0
+    # grid / thread / split counts: 0 would be a launch without a workgroup
+    for k in (b"unet_fwd_grid", b"grid_fwd", b"danet_grid_a", b"dw_ksplit_64", b"grid_qkvb"):
+        assert L.ral_global_option(k, 0) != 0 and b"out of range" in L.ral_last_error(), k
+    assert L.ral_global_option(b"mlp_hthreads", 384) != 0
+    assert L.ral_global_option(b"grid_attnw", 0) == 0          # 0 = automatic for this one
+
+
+def test_global_option_after_the_first_read_is_refused_not_ignored():
+    """switches are latched at first use: once the library has read one, a different value is an error (the same value
+    again is accepted)"""
+    L = _lib.lib()
+    cfg = _lib.make_config("full", 2, 512, 8, 1)
+    first = L.ral_global_option(b"dw_sets", 6)                 # (an earlier test of this process may have sized a workspace)
+    assert first == 0 or b"already read" in L.ral_last_error()
+    assert L.ral_workspace_bytes(C.byref(cfg)) > 0             # plan_workspace reads DW_SETS
+    if first == 0:
+        assert L.ral_global_option(b"dw_sets", 6) == 0
+    assert L.ral_global_option(b"dw_sets", 4) != 0 and b"already read" in L.ral_last_error()
 
 
 def test_library_reads_only_the_two_documented_environment_variables():
