@@ -63,18 +63,87 @@ def _profile_json(name):
         return None
 
 
+def _profile_rounds(suffix):
+    """committed profiles/rNN_<suffix>, newest round first"""
+    import glob
+    return [os.path.basename(f) for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)), reverse=True)]
+
+
 def measured_traffic(kind):
     """HBM bytes per launch of this kernel kind from the committed PMC run (newest profiles/rNN_hbm_traffic.json)."""
-    for name in ("r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json"):
+    for name in _profile_rounds("hbm_traffic.json"):
         d = _profile_json(name)
         if d and kind in d.get("per_launch_bytes", {}):
             return d["per_launch_bytes"][kind]["total"]
     return None
 
 
+def measured_counters(kind):
+    """(matrix-pipe busy fraction, vector-issue busy fraction, file) of this kernel kind from the newest committed SQ counter
+    run (profiles/rNN_sq_counters.json, tools/sq_counters.py): what the pipes did, as opposed to useful FLOP over a peak"""
+    for name in _profile_rounds("sq_counters.json"):
+        d = _profile_json(name)
+        k = (d or {}).get("per_kind", {}).get(kind)
+        if k and "mfma_busy" in k:
+            return k.get("mfma_busy"), k.get("valu_issue"), "profiles/" + name
+    return None, None, None
+
+
+# the pipe a kernel kind's contractions execute on in the default arithmetic (DESIGN.md section 3); `peak` in the roofline
+# object stays the fp32 figure the path's dtype is priced against - the f16 matrix pipe's own dense peak is ~2.5 PFLOP/s,
+# which is why `mfma_busy` / `valu_issue` are reported next to `frac`
+KIND_PIPE = {"attn_bwd": "f16 mfma (fp16-pair operands, fp32 accumulate) + valu exp/convert", "attn_fwd": "valu (exp2, packed fma) + f16 mfma score tiles",
+             "mlp_fwd": "f16 mfma (fp16 pairs) + valu gelu", "mlp_bwd": "f16 mfma (fp16 pairs; C <= 16: f32 mfma) + valu gelu",
+             "qkv_fwd": "f16 mfma (C >= 64) / f32 mfma", "qkv_bwd": "f16 mfma (C >= 64) / f32 mfma", "dw": "f16 mfma (C >= 64) / f32 mfma",
+             "resample_fwd": "f32 mfma", "resample_bwd": "f32 mfma"}
+STEP_FLOP_PER_WINDOW = 441.7e6      # fwd 147.2 MFLOP x 3 (SURVEY 8d / DESIGN.md section 3), 512-sample window
+
+
+def roofline_object(kind, config, L, B, kind_ms, launches, rl_steps, attn_ms, n_timed, dt):
+    """The `roofline` object of the JSON line for an RA-LENet workload.  kind_ms: summed hipEvent time of the `launches` launches
+    of `kind` over `rl_steps` serialised steps; attn_ms: {"attn_fwd", "attn_bwd"} -> serialised ms per step; n_timed / dt:
+    steps and seconds of the timed region (the whole step's useful FLOP rate).  `frac` is useful FLOP (SURVEY 8d's count)
+    over the fp32 peak; what the pipes did is `mfma_busy` / `valu_issue` from the newest committed counter run."""
+    ksec = kind_ms * 1e-3
+    ach = kind_work(kind, L, B) * rl_steps / ksec / 1e12 if ksec > 0 else 0.0
+    peak = VALU_F32_PEAK_TF if kind.startswith("attn") else MFMA_F32_PEAK_TF
+    busy, vissue, csrc = measured_counters(kind) if config == "ralenet" else (None, None, None)
+    step_tf = STEP_FLOP_PER_WINDOW * (L / 512.0) * B * n_timed / dt / 1e12 if config == "ralenet" and dt > 0 else None
+    blk = None
+    if attn_ms.get("attn_fwd") and attn_ms.get("attn_bwd"):
+        fl = kind_work("attn_fwd", L, B) + kind_work("attn_bwd", L, B)
+        blk = fl / ((attn_ms["attn_fwd"] + attn_ms["attn_bwd"]) * 1e-3) / 1e12
+    r = {"bound": "mfma", "kernel": kind, "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+         "traffic": measured_traffic(kind) if config == "ralenet" else None,
+         "pipe": KIND_PIPE.get(kind),
+         "peak_is": "fp32 vector = fp32 matrix peak (the path's dtype); the f16 matrix pipe the fp16-pair products execute on peaks at "
+                    "~2.5 PFLOP/s dense, so `frac` is useful fp32-equivalent FLOP over the fp32 peak, not pipe occupancy: that is "
+                    "mfma_busy / valu_issue",
+         "mfma_busy": busy, "valu_issue": vissue, "counters_source": csrc,
+         "step_frac": round(step_tf / MFMA_F32_PEAK_TF, 4) if step_tf else None,
+         "step_TFLOPs": round(step_tf, 2) if step_tf else None,
+         "attn_block_frac": round(blk / VALU_F32_PEAK_TF, 4) if blk else None,
+         "attn_block": ({"fwd_ms": round(attn_ms["attn_fwd"], 3), "bwd_ms": round(attn_ms["attn_bwd"], 3),
+                         "fwd_frac": round(kind_work("attn_fwd", L, B) / (attn_ms["attn_fwd"] * 1e-3) / 1e12 / VALU_F32_PEAK_TF, 4),
+                         "bwd_frac": round(kind_work("attn_bwd", L, B) / (attn_ms["attn_bwd"] * 1e-3) / 1e12 / VALU_F32_PEAK_TF, 4),
+                         "TFLOPs": round(blk, 2),
+                         "what": "serialised per-step times of all attention forward / backward launches, SURVEY 8d FLOP "
+                                 "(4 / 8 N^2 C per block)"} if blk else None),
+         "launches": launches, "avg_launch_ms": round(kind_ms / max(launches, 1), 4),
+         "flop_count": "algorithmic (SURVEY 8d)",
+         "measured": f"hipEvent pairs on the kernel's stream over {rl_steps} serialised steps (lanes=1, no side stream) run right "
+                     "after the timed region"}
+    if kind == "attn_bwd":       # the S re-computation counted as well (what the kernel executes per visit once)
+        ach10 = kind_work(kind, L, B, True) * rl_steps / ksec / 1e12 if ksec > 0 else 0.0
+        r["flop_count"] = "8 N^2 C per block (SURVEY 8d: 2 x forward); with the S re-computation (10 N^2 C) in *_incl_recompute"
+        r["achieved_incl_recompute"] = round(ach10, 3)
+        r["frac_incl_recompute"] = round(ach10 / peak, 4)
+    return r
+
+
 def unet_fused_traffic():
     """(bytes per launch of the fused U-Net inference kernel at batch 2048 from the committed PMC run, file name)"""
-    for name in ("r05_unet_hbm_traffic.json", "r04_unet_hbm_traffic.json", "r03_unet_hbm_traffic.json", "r02_unet_hbm_traffic.json"):
+    for name in _profile_rounds("unet_hbm_traffic.json"):
         d = _profile_json(name)
         if d:
             f = d.get("fused", {})
@@ -190,7 +259,7 @@ def cpu_baseline(leads, L, variant, big_batch=256):
             res["large_batch"] = {"error": str(exc)[:200]}
     # the figure at the bench batch itself, measured once per round by tools/cpu_baseline_big.py on the GPU box's host
     # (40 s per step and ~50 GB of autograd state: not re-measured inside the default run) and committed under profiles/
-    for name in ("r05_cpu_baseline_b2048.json", "r04_cpu_baseline_b2048.json", "r03_cpu_baseline_b2048.json"):
+    for name in _profile_rounds("cpu_baseline_b2048.json"):
         d = _profile_json(name)
         if d and "value" in d and leads == 1 and L == 512:
             res["bench_batch"] = {"value": d["value"], "batch": 2048, "cores": d.get("cores"), "source": "profiles/" + name,
@@ -272,7 +341,8 @@ def launcher_dry_run(a):
         B, G = batch_plan(a, world)
         print(json.dumps({"dry_run": True, "n_gpus": world, "local_rank": int(os.environ.get("LOCAL_RANK", "0")),
                           "rank_sum": t.item(), "steps": a.steps, "warmup": a.warmup,
-                          "batch_per_gpu": B, "global_batch": G, "config3_leg": config3_batch(a, world), "collective": facts}))
+                          "batch_per_gpu": B, "global_batch": G, "config3_leg": config3_batch(a, world), "collective": facts,
+                          "unet_dp": unet_dp_modes(world) if a.config == "unet" else None}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -297,6 +367,23 @@ def config3_batch(a, world):
     if a.config == "ralenet" and world == 8 and not a.batch and not a.global_batch and not a.leads and not a.L:
         return 1024
     return None
+
+
+UNET_DP_DEVIATION = {"loss_rel": 3.5e-5, "grad_rel_of_norm": 3.6e-2, "at": "2 ranks x 64 windows, random initialisation, fp64 stand-in",
+                     "source": "tests/test_dp_gloo.py::test_unet_per_rank_batchnorm_statistics_stay_within_1e_3_of_the_global_batch_step"}
+
+
+def unet_dp_modes(world):
+    """U-Net under data parallelism has a BatchNorm after every conv (UNet.py:46-141).  Two modes, both timed at N > 1:
+      per_rank_bn (HEADLINE): every rank normalises with its own shard's statistics - what DistributedDataParallel does without
+        SyncBatchNorm - the fused single-GPU step plus ONE gradient all-reduce;
+      sync_bn (exact): the global batch's statistics, 10 + 10 dependent all-reduces of 64 doubles inside a 0.4 ms step + the
+        gradient all-reduce = 21 latency-bound collectives: it reproduces the single-process step, and cannot scale."""
+    if world <= 1:
+        return None
+    return {"headline_mode": "per_rank_bn",
+            "per_rank_bn": {"collectives_per_step": 1, "sync_bn": False, "deviation_from_global_batch_step": UNET_DP_DEVIATION},
+            "sync_bn": {"collectives_per_step": 21, "sync_bn": True, "deviation_from_global_batch_step": None}}
 
 
 def collective_facts(dist, world, rank, local, backend, trainer):
@@ -347,7 +434,8 @@ def build_workload(a, dev, rank):
     x = torch.randn(B, leads, L, generator=g).to(dev)
     tgt = torch.randn(B, leads, L, generator=g).to(dev)
     model.train()
-    return {"model": model, "inner": inner, "trainer": DataParallelTrainer(eng), "x": x, "tgt": tgt, "B": B, "leads": leads,
+    sync_bn = not (a.config == "unet" and world > 1 and not getattr(a, "unet_sync_bn_leg", False))   # U-Net at N > 1: per-rank statistics are the headline
+    return {"model": model, "inner": inner, "trainer": DataParallelTrainer(eng, sync_bn=sync_bn), "sync_bn": sync_bn, "x": x, "tgt": tgt, "B": B, "leads": leads,
             "L": L, "text": text + " (fwd+mse/SNR/RMSE+bwd+Adam), N(0,1) inputs seed 2023, random-init weights"}
 
 
@@ -356,6 +444,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--min-seconds", type=float, default=2.0,
+                    help="the timed region repeats the --steps block until it lasts at least this long (whole blocks; "
+                         "`steps` in the line = steps actually timed, `steps_requested` = --steps; 0 = exactly --steps)")
     ap.add_argument("--config", default="ralenet", choices=("ralenet", "unet", "newrale"))
     ap.add_argument("--batch", type=int, default=0, help="windows per GPU (default: the config's stated batch)")
     ap.add_argument("--global-batch", type=int, default=0,
@@ -426,6 +517,20 @@ def main():
         step()
     sync()
     lib = _lib.lib()
+    # A timed region of --steps steps is 0.26 s at the default 20: too short for anything sampling the GPU from outside (the
+    # driver's 5 s SMI samples never land in it).  One untimed calibration block of --steps steps sizes the region: it repeats
+    # the block until >= --min-seconds, with no synchronisation between blocks; every rank uses the slowest rank's estimate.
+    steps_req, blocks = a.steps, 1
+    if a.min_seconds > 0 and a.steps > 0:
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        sync()
+        tb = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+        blocks = max(1, int(-(-a.min_seconds // max(tb.item(), 1e-6))))
+    a.steps = steps_req * blocks
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     t0 = time.perf_counter()
     ev[0].record()
@@ -436,6 +541,8 @@ def main():
     dt = time.perf_counter() - t0
     per_step = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(a.steps))
     median_ms = per_step[len(per_step) // 2] if per_step else None
+    n_timed, a.steps = a.steps, steps_req          # (the legs below size themselves from --steps)
+    blocks_calibrated = a.min_seconds > 0 and steps_req > 0
 
     # roofline leg: the same step with the kernels serialised (one lane, no side stream), so that the hipEvent
     # pair around each launch of the selected kernel measures that kernel alone, not its share of a busy GPU
@@ -452,6 +559,20 @@ def main():
             step()
         sync()
         _lib.check(lib.ral_profile_read(h, C.byref(ms), C.byref(cnt)))
+        _lib.check(lib.ral_profile_select(h, b""))
+        # the attention block as a whole (north star: "MFMA utilisation on the attention block"): forward + backward kernels
+        attn_ms = {}
+        for kind in ("attn_fwd", "attn_bwd"):
+            if kind == a.kind:
+                attn_ms[kind] = ms.value / rl_steps
+                continue
+            _lib.check(lib.ral_profile_select(h, kind.encode()))
+            for _ in range(3):
+                step()
+            sync()
+            ms2, cnt2 = C.c_double(), C.c_int64()
+            _lib.check(lib.ral_profile_read(h, C.byref(ms2), C.byref(cnt2)))
+            attn_ms[kind] = ms2.value / 3
         _lib.check(lib.ral_profile_select(h, b""))
         if a.kinds:                        # every rank runs the steps (they contain collectives); rank 0 prints
             tot = 0.0
@@ -552,11 +673,35 @@ def main():
         del W3
         a.batch_override = 0
 
+    # U-Net at N > 1: the exact mode (global-batch statistics, 21 collectives per step) next to the per-rank headline
+    unet_dp = None
+    if a.config == "unet" and world > 1:
+        unet_dp = unet_dp_modes(world)
+        unet_dp["per_rank_bn"].update({"value": round(B * world * n_timed / dt, 1), "unit": "windows/s", "ms_per_step": round(dt / n_timed * 1e3, 3),
+                                       "collectives_counted": trainer.collectives_last_step})
+        a.unet_sync_bn_leg = True
+        Ws = build_workload(a, dev, rank)
+        a.unet_sync_bn_leg = False
+        for _ in range(max(2, a.warmup)):
+            Ws["trainer"].train_step(Ws["x"], Ws["tgt"])
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            Ws["trainer"].train_step(Ws["x"], Ws["tgt"])
+        sync()
+        ts = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+        unet_dp["sync_bn"].update({"value": round(B * world * a.steps / ts.item(), 1), "unit": "windows/s",
+                                   "ms_per_step": round(ts.item() / a.steps * 1e3, 3), "steps": a.steps,
+                                   "collectives_counted": Ws["trainer"].collectives_last_step})
+        del Ws
+
     if rank == 0:
         res = {
             "metric": f"ECG windows/sec ({L}-sample, bs{B}) train step; inference forward in infer_*_windows_per_s",
-            "value": round(B * world * a.steps / dt, 1), "unit": "windows/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "value": round(B * world * n_timed / dt, 1), "unit": "windows/s",
+            "n_gpus": world, "steps": n_timed, "steps_requested": steps_req, "timed_s": round(dt, 3),
+            "warmup": a.warmup + (steps_req if blocks_calibrated else 0), "ms_per_step": round(dt / n_timed * 1e3, 3),
             "median_ms_per_step_hipevent": round(median_ms, 3) if median_ms else None,
             "higher_is_better": True, "scaling": "strong" if a.global_batch else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -567,34 +712,22 @@ def main():
                           "f16 matrix cores (x = h1 + h2, ~2^-22 relative; operands brought into range by powers of two per "
                           "weight matrix / token / head, nothing clamped); everything else on the fp32 MFMA / vector ALU.  "
                           "fp32_mfma: the same step with ral_set_option f16_split=0 (every product on the fp32 MFMA)",
-            "config": {"workload": W["text"], "global_batch": B * world, "batch_per_gpu": B, "parallelism": f"dp{world}", "sync_bn": True},
+            "config": {"workload": W["text"], "global_batch": B * world, "batch_per_gpu": B, "parallelism": f"dp{world}", "sync_bn": W["sync_bn"]},
             "final_loss": round(loss, 6),
         }
         if facts is not None:
             res["collective"] = facts
         if config3 is not None:
             res["config3"] = config3
+        if unet_dp is not None:
+            res["unet_dp"] = unet_dp
         if inner is not None:
-            ksec = ms.value * 1e-3
-            ach = kind_work(a.kind, Lk, Bk) * rl_steps / ksec / 1e12 if ksec > 0 else 0.0
-            peak = VALU_F32_PEAK_TF if a.kind.startswith("attn") else MFMA_F32_PEAK_TF
-            res["roofline"] = {"bound": "mfma", "kernel": a.kind, "achieved": round(ach, 3), "peak": peak,
-                               "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                               "traffic": measured_traffic(a.kind) if a.config == "ralenet" else None,
-                               "launches": int(cnt.value), "avg_launch_ms": round(ms.value / max(cnt.value, 1), 4),
-                               "flop_count": "algorithmic (SURVEY 8d)",
-                               "measured": f"hipEvent pairs on the kernel's stream over {rl_steps} serialised steps "
-                                           "(lanes=1, no side stream) run right after the timed region"}
-            if a.kind == "attn_bwd":       # the S re-computation counted as well (what the kernel executes per visit once)
-                ach10 = kind_work(a.kind, Lk, Bk, True) * rl_steps / ksec / 1e12 if ksec > 0 else 0.0
-                res["roofline"]["flop_count"] = "8 N^2 C per block (SURVEY 8d: 2 x forward); with the S re-computation (10 N^2 C) in *_incl_recompute"
-                res["roofline"]["achieved_incl_recompute"] = round(ach10, 3)
-                res["roofline"]["frac_incl_recompute"] = round(ach10 / peak, 4)
+            res["roofline"] = roofline_object(a.kind, a.config, Lk, Bk, ms.value, int(cnt.value), rl_steps, attn_ms, n_timed, dt)
         else:
             # U-Net: every kernel of the step is an HBM-bound conv stage; stage-granular bytes of SURVEY 8d per window
             # (forward with batch statistics 147 KB + backward 200 KB at 2 leads x 512 samples) over the whole step
             by = 347e3 * (W["leads"] * L) / 1024.0
-            ach = by * B * world * a.steps / dt / 1e9 / world
+            ach = by * B * world * n_timed / dt / 1e9 / world
             res["roofline"] = {"bound": "hbm", "kernel": "whole U-Net train step (all conv stages)", "achieved": round(ach, 1),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                                "measured": "stage-granular algorithmic bytes per window (SURVEY 8d) x windows / step time, per GPU"}

@@ -253,9 +253,12 @@ class DataParallelTrainer:
     reduction and returns the global loss, as the reference loop prints it every step (denoise_train.py:54-64); with a
     longer interval `train_step` returns this rank's own mean (`loss_is_global` False) and never waits."""
 
-    def __init__(self, engine, group=None, sync_bn=True, sync_state=True, log_every=1):
+    def __init__(self, engine, group=None, sync_bn=True, sync_state=True, log_every=1, force_collectives=False):
         self.e, self.group, self.sync_bn, self.log_every = engine, group, sync_bn, max(1, int(log_every))
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # `force_collectives`: issue every collective, the bucket stream and its events although the group has ONE rank (an
+        # all-reduce over one rank is the identity): the way a box with one GPU runs the real RCCL path (tests/test_gpu_dp_procs.py)
+        self._coll = self.world > 1 or (bool(force_collectives) and dist.is_initialized())
         self._hist, self._pending, self._last = [], None, None
         # collectives issued by the last train_step: data path (BatchNorm sums, gradient buckets) / metric reductions
         self._ncoll, self._nmet, self.collectives_last_step, self.metric_collectives_last_step = 0, 0, None, None
@@ -275,7 +278,7 @@ class DataParallelTrainer:
         set_counters(c.tolist())
 
     def _allreduce(self, t):
-        if self.world > 1:
+        if self._coll:
             self._ncoll += 1
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
@@ -297,7 +300,7 @@ class DataParallelTrainer:
             if k > 1:
                 buf = torch.stack(self._hist).sum(0) / k
             else:     # (a copy where the all-reduce below would otherwise overwrite the tensor `loss` is a view of)
-                buf = self._hist[0].clone() if self.world > 1 else self._hist[0]
+                buf = self._hist[0].clone() if self._coll else self._hist[0]
         else:
             self._hist.append((loss, snr, rmse))
             if len(self._hist) < self.log_every:
@@ -308,7 +311,7 @@ class DataParallelTrainer:
                                torch.stack([r.double().sum() for _, _, r in self._hist]).sum() / G]) / k
         self._hist = []
         work = None
-        if self.world > 1:
+        if self._coll:
             self._nmet += 1
             if self._pending is not None and self._pending[1] is not None:
                 self._pending[1].wait()          # a reduction nobody asked for (metrics() not called): finish it before its buffer goes
@@ -368,7 +371,7 @@ class DataParallelTrainer:
         loss, snr, rmse = e.loss(pred, target_local, G)
         e.backward_begin()
         early = None
-        if self.world > 1 and hasattr(e, "grad_buckets"):
+        if self._coll and hasattr(e, "grad_buckets"):
             # decoder half of the gradients: all-reduced on the engine's communication stream, which only waits
             # for the kernels that write it, so the collective runs under the rest of the backward pass
             (o0, n0), (o1, n1) = e.grad_buckets()

@@ -69,16 +69,91 @@ class _Engine:
         return buf[e["offset"]:e["offset"] + n].view(e["shape"])
 
 
-class _ModuleBase:
+class _RalFunction(torch.autograd.Function):
+    """Host glue with no arithmetic of its own: puts the library's forward / backward pair into a torch autograd graph, so that
+    the reference loop runs as written (`pre = model(data); loss = F.mse_loss(pre, target); loss.backward();
+    optimizer.step()`, denoise_train.py:51-57).  The saved state is the model handle (the library keeps the activations of
+    its most recent training forward)."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, model):
+        ctx.model = model
+        ctx.need_dx = bool(x.requires_grad)
+        y = model._forward_raw(x)
+        model._fwd_gen += 1
+        ctx.gen = model._fwd_gen
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        m = ctx.model
+        if ctx.gen != m._fwd_gen:
+            raise _lib.RalError("backward through a forward that is not this model's most recent training forward "
+                                "(the library keeps one set of activations)")
+        return m._backward_autograd(dy, ctx.need_dx), None, None
+
+
+class _AutogradMixin:
+    """`autograd=True` at construction (or `enable_autograd()`): `model(x)` in training mode returns a tensor with a
+    `grad_fn`, `parameters()` yields LEAF views into the flat parameter buffer whose `.grad` aliases the flat gradient
+    buffer - `optim.Adam(model.parameters())`, `loss.backward()`, `optimizer.step()`, `optimizer.zero_grad()` work unchanged.
+    This is the slow path (torch's optimiser and loss kernels instead of the fused ones); `train_step` is the fast one."""
+
+    _autograd = False
+    _fwd_gen = 0
+
+    def enable_autograd(self, on=True):
+        self._autograd = bool(on)
+        self._leaves = None
+        return self
+
+    def _flat_pairs(self):
+        """[(name, parameter view, gradient view)] over the flat buffers, in `parameters()` order"""
+        raise NotImplementedError
+
+    def _leaf_parameters(self):
+        if getattr(self, "_leaves", None) is None:
+            self._leaves = []
+            for name, p, g in self._flat_pairs():
+                leaf = p.detach()              # a view of the flat buffer: the optimiser's in-place update is the library's weight
+                leaf.requires_grad_(True)
+                self._leaves.append((name, leaf, g))
+            self._anchor = torch.zeros(1, device=self._leaves[0][1].device, requires_grad=True)
+        return self._leaves
+
+    def _forward_autograd(self, x):
+        self._leaf_parameters()
+        return _RalFunction.apply(x, self._anchor, self)
+
+    def _backward_autograd(self, dy, need_dx):
+        leaves = self._leaf_parameters()
+        # torch accumulates into .grad; the library overwrites its flat buffer.  A gradient that is still attached (the caller
+        # did not zero it, or zeroed it in place) is kept and added back.
+        keep = [(leaf, g, (leaf.grad.clone() if leaf.grad is not None and leaf.grad.data_ptr() == g.data_ptr() else None))
+                for _, leaf, g in leaves if leaf.grad is not None]
+        dx = self._backward_raw(dy.contiguous(), need_dx)
+        for leaf, g, old in keep:
+            if old is not None:
+                g.add_(old)
+            else:                               # a gradient tensor of the caller's own: accumulate into it, as autograd would
+                leaf.grad.add_(g)
+        for _, leaf, g in leaves:
+            if leaf.grad is None:
+                leaf.grad = g                   # alias: optimizer.step() reads the library's gradient buffer directly
+        return dx
+
+
+class _ModuleBase(_AutogradMixin):
     VARIANT = None
 
-    def __init__(self, variant, leads=2, L=512, max_batch=32, train=True, device="cuda:0", seed=None):
+    def __init__(self, variant, leads=2, L=512, max_batch=32, train=True, device="cuda:0", seed=None, autograd=False):
         self.eng = _Engine(variant, leads, L, max_batch, train, device)
         self.training = bool(train)
         self.step_count = 0
         self._dy = None
         self._loss_sum = None
         self.reset_parameters(seed)
+        self.enable_autograd(autograd)
 
     # ---- nn.Module surface ------------------------------------------------------
     def train(self, mode=True):
@@ -97,12 +172,22 @@ class _ModuleBase:
         return self
 
     def named_parameters(self):
+        if self._autograd:
+            for name, leaf, _ in self._leaf_parameters():
+                yield name, leaf
+            return
         for e in self.eng.entries:
             if e["kind"] == _lib.KIND_PARAM:
                 yield e["name"], self.eng.view(self.eng.params, e)
 
     def parameters(self):
         return [p for _, p in self.named_parameters()]
+
+    def _flat_pairs(self):
+        if self.eng.grads is None:
+            raise _lib.RalError("model was created with train=False")
+        return [(e["name"], self.eng.view(self.eng.params, e), self.eng.view(self.eng.grads, e))
+                for e in self.eng.entries if e["kind"] == _lib.KIND_PARAM]
 
     def named_grads(self):
         return OrderedDict((e["name"], self.eng.view(self.eng.grads, e)) for e in self.eng.entries
@@ -196,7 +281,7 @@ class _ModuleBase:
             raise _lib.RalError("input must be a float32 HIP tensor")
         return x.contiguous()
 
-    def forward(self, x):
+    def _forward_raw(self, x):
         x = self._check_x(x)
         y = torch.empty_like(x)
         self._x = x  # keep alive for backward (the stem gradient re-reads it)
@@ -206,7 +291,19 @@ class _ModuleBase:
                 self.eng.counters[k] += 1
         return y
 
-    __call__ = forward
+    def _backward_raw(self, dy, want_dx):
+        dx = torch.empty_like(dy) if want_dx else None
+        self._dy_fused = False
+        _lib.check(_lib.lib().ral_backward(self.eng.h, _ptr(dy), _ptr(dx), dy.shape[0], _stream()))
+        return dx
+
+    def forward(self, x):
+        if self._autograd and self.training and torch.is_grad_enabled():
+            return self._forward_autograd(x)
+        return self._forward_raw(x)
+
+    def __call__(self, x):
+        return self.forward(x)
 
     def loss_and_metrics(self, pred, target, want_grad=True, global_windows=None):
         """F.mse_loss(pred, target), SNR(target, pred), RMSE(target, pred) of denoise_train.py:53,58-59
@@ -234,7 +331,7 @@ class _ModuleBase:
         """`pred = model(x); loss = criterion(pred, target)` and the step's SNR / RMSE (denoise_train.py:52-53,58-59) as ONE
         library call in training mode: the same numbers as `forward` + `loss_and_metrics`; the U-Net's output BatchNorm, its
         loss sums and the first sums of its backward pass then share one pass over the output (ral_forward_loss_means)."""
-        if not self.training or type(self).forward is not _ModuleBase.forward:   # (a subclass with bookkeeping of its own in forward)
+        if not self.training or type(self)._forward_raw is not _ModuleBase._forward_raw:   # (a subclass with bookkeeping of its own in forward)
             pred = self.forward(x)
             return (pred,) + tuple(self.loss_and_metrics(pred, target))
         x = self._check_x(x)
@@ -312,18 +409,18 @@ class RALENet(_ModuleBase):
     (main.py:69-77), generalised to `leads` in {1,2} and `L` in {256,512,768,1024} the way
     SURVEY §8c states (R-wave window stays centred, Len constants unchanged)."""
 
-    def __init__(self, variant="full", leads=2, L=512, max_batch=32, train=True, device="cuda:0", seed=None):
+    def __init__(self, variant="full", leads=2, L=512, max_batch=32, train=True, device="cuda:0", seed=None, autograd=False):
         if variant not in ("nra", "full", "mlp"):
             raise _lib.RalError(f"unknown RA-LENet variant {variant!r}")
-        super().__init__(variant, leads, L, max_batch, train, device, seed)
+        super().__init__(variant, leads, L, max_batch, train, device, seed, autograd)
 
 
 class UNet(_ModuleBase):
     """model/UNet.py::UNet (main.py:63-65): conv U-Net baseline, BatchNorm after every conv
     (the reference's LazyBatchNorm1d materialised eagerly, quirk A15)."""
 
-    def __init__(self, leads=2, L=512, max_batch=32, train=True, device="cuda:0", seed=None):
-        super().__init__("unet", leads, L, max_batch, train, device, seed)
+    def __init__(self, leads=2, L=512, max_batch=32, train=True, device="cuda:0", seed=None, autograd=False):
+        super().__init__("unet", leads, L, max_batch, train, device, seed, autograd)
 
 
 class ACDAE(_ModuleBase):
@@ -331,8 +428,8 @@ class ACDAE(_ModuleBase):
     compares against - Conv1d / MaxPool / LeakyReLU encoder, ConvTranspose1d / linear Upsample / LeakyReLU / ECA decoder
     with additive skips, 2 leads, no BatchNorm (train and eval forward are the same function)."""
 
-    def __init__(self, L=512, max_batch=32, train=True, device="cuda:0", seed=None):
-        super().__init__("acdae", 2, L, max_batch, train, device, seed)
+    def __init__(self, L=512, max_batch=32, train=True, device="cuda:0", seed=None, autograd=False):
+        super().__init__("acdae", 2, L, max_batch, train, device, seed, autograd)
 
 
 class DANet(_ModuleBase):
@@ -343,8 +440,8 @@ class DANet(_ModuleBase):
     (`fcn1` and `fcn2` are the same modules): their state_dict entries appear under both names, their running
     statistics take two momentum updates per training forward and `num_batches_tracked` advances by 2."""
 
-    def __init__(self, L=512, max_batch=32, train=True, device="cuda:0", seed=None, leads=2):
-        super().__init__("danet", leads, L, max_batch, train, device, seed)      # (2 output channels: leads must be 2)
+    def __init__(self, L=512, max_batch=32, train=True, device="cuda:0", seed=None, leads=2, autograd=False):
+        super().__init__("danet", leads, L, max_batch, train, device, seed, autograd)      # (2 output channels: leads must be 2)
 
     def named_parameters(self):
         for k, v in super().named_parameters():
@@ -354,22 +451,23 @@ class DANet(_ModuleBase):
     def named_grads(self):
         return OrderedDict((k, v) for k, v in super().named_grads().items() if ".dam.fcn2." not in k)
 
+    def _flat_pairs(self):
+        return [t for t in super()._flat_pairs() if ".dam.fcn2." not in t[0]]
+
     def num_parameters(self):
         return sum(int(np.prod(e["shape"])) for e in self.eng.entries
                    if e["kind"] == _lib.KIND_PARAM and ".dam.fcn2." not in e["name"])
 
-    def forward(self, x):
-        y = super().forward(x)
+    def _forward_raw(self, x):
+        y = super()._forward_raw(x)
         if self.training:
             for k in self.eng.counters:
                 if ".dam.fcn" in k:
                     self.eng.counters[k] += 1   # the second batch through the shared fcn
         return y
 
-    __call__ = forward
 
-
-class NewRALE:
+class NewRALE(_AutogradMixin):
     """model/ralenet_12leads.py::newrale — 12-lead adapter around a pretrained, frozen RA-LENet
     (Transfer_learning.py:71-75): Conv1d 12->6->2 (k13, LeakyReLU 0.01), RA-LENet, Conv1d 2->6->12.
     Only the 2 210 adapter parameters train; the inner model keeps running in whatever mode
@@ -379,8 +477,9 @@ class NewRALE:
                           ("conv2.bias", (2,)), ("conv3.weight", (6, 2, 13)), ("conv3.bias", (6,)),
                           ("conv4.weight", (12, 6, 13)), ("conv4.bias", (12,))])
 
-    def __init__(self, pretrained_rale_model, seed=None):
+    def __init__(self, pretrained_rale_model, seed=None, autograd=False):
         self.rale = pretrained_rale_model
+        self.enable_autograd(autograd)
         if self.rale.eng.leads != 2:
             raise _lib.RalError("newrale wraps a 2-lead RA-LENet")
         self.device, self.L = self.rale.eng.device, self.rale.eng.L
@@ -413,10 +512,15 @@ class NewRALE:
         return self
 
     def named_parameters(self):
+        if self._autograd:
+            return [(k, leaf) for k, leaf, _ in self._leaf_parameters()]
         return [(k, self._view(self.params, k)) for k in self.SHAPES]
 
     def parameters(self):            # trainable parameters only (requires_grad filter of the reference)
         return [p for _, p in self.named_parameters()]
+
+    def _flat_pairs(self):
+        return [(k, self._view(self.params, k), self._view(self.grads, k)) for k in self.SHAPES]
 
     def named_grads(self):
         return OrderedDict((k, self._view(self.grads, k)) for k in self.SHAPES)
@@ -465,10 +569,22 @@ class NewRALE:
         self._saved += [r, a3, y]
         return y
 
-    def forward(self, x):
-        return self._forward_post(self.rale.forward(self._forward_pre(x)))
+    def _forward_raw(self, x):
+        return self._forward_post(self.rale._forward_raw(self._forward_pre(x)))
 
-    __call__ = forward
+    def _backward_raw(self, dy, want_dx):
+        if want_dx:
+            raise _lib.RalError("newrale: the input gradient is not provided")
+        self.backward(dy)
+        return None
+
+    def forward(self, x):
+        if self._autograd and self.training and torch.is_grad_enabled():
+            return self._forward_autograd(x)
+        return self._forward_raw(x)
+
+    def __call__(self, x):
+        return self.forward(x)
 
     def loss_and_metrics(self, pred, target, want_grad=True, global_windows=None):
         """F.mse_loss / SNR / RMSE over the flattened 12 x L windows (denoise_train.py:53,58-59) in the fused loss kernel."""

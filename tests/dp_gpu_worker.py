@@ -17,6 +17,8 @@ def main():
     out, kind, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
+    if kind.startswith("nccl1:"):
+        return nccl_one_rank(out, kind[6:], steps)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from ecg_denoise_amd import NewRALE, RALENet, UNet
     from ecg_denoise_amd.dp import DataParallelTrainer, HipEngineAdapter, NewRALEEngineAdapter, UNetEngineAdapter
@@ -48,6 +50,46 @@ def main():
     grads = {k: v.cpu().clone() for k, v in m.named_grads().items()}      # the all-reduced (global-batch) gradient of the last step
     torch.save({"state": sd, "grads": grads, "losses": losses, "step_count": m.step_count}, f"{out}.rank{rank}")
     dist.barrier()
+    dist.destroy_process_group()
+
+
+def nccl_one_rank(out, kind, steps):
+    """The REAL backend (RCCL, `nccl`) with the one rank a one-GPU box allows: process-group initialisation on the device, the
+    trainer with `force_collectives` - BatchNorm all-reduces on the compute stream, the early gradient bucket on its
+    communication stream behind `ral_grad_bucket_wait`'s events, the metric reduction - every one a true RCCL call (the
+    identity over one rank), and the replica must end where the plain single-process step ends."""
+    try:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+        probe = torch.ones(4, device="cuda:0")
+        dist.all_reduce(probe)
+        torch.cuda.synchronize()
+    except Exception as exc:                      # no usable RCCL on this box: the caller skips
+        torch.save({"skip": repr(exc)[:300]}, f"{out}.rank0")
+        return
+    from ecg_denoise_amd import RALENet, UNet
+    from ecg_denoise_amd.dp import DataParallelTrainer, HipEngineAdapter, UNetEngineAdapter
+    B, L = 128, 256
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(B, 2, L, generator=g).cuda(); t = torch.randn(B, 2, L, generator=g).cuda()
+    if kind == "unet":
+        m = UNet(leads=2, L=L, max_batch=B, device="cuda:0", seed=100)
+        tr = DataParallelTrainer(UNetEngineAdapter(m), force_collectives=True)
+    else:
+        m = RALENet("full", leads=2, L=L, max_batch=B, device="cuda:0", seed=100)
+        tr = DataParallelTrainer(HipEngineAdapter(m), force_collectives=True)
+    m.train()
+    losses, ncoll = [], []
+    for _ in range(steps):
+        losses.append(tr.train_step(x, t)["loss"].item())
+        ncoll.append((tr.collectives_last_step, tr.metric_collectives_last_step))
+    torch.cuda.synchronize()
+    ver = None
+    try:
+        ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:
+        pass
+    torch.save({"state": {k: v.cpu() for k, v in m.state_dict().items()}, "losses": losses, "collectives": ncoll,
+                "backend": dist.get_backend(), "rccl_version": ver, "step_count": m.step_count}, f"{out}.rank0")
     dist.destroy_process_group()
 
 

@@ -185,3 +185,31 @@ def test_early_gradient_bucket_runs_under_the_backward_pass():
     assert len(fr) >= 4, p.stdout
     # measured 49-54 %; with the default 4 hardware queues 100 %.  (Generous bounds: the point is "not after the pass".)
     assert all(20 <= f <= 88 for f in fr), p.stdout
+
+
+@pytest.mark.parametrize("kind", ["ralenet", "unet"])
+def test_trainer_on_the_real_rccl_backend_with_one_rank(kind, tmp_path):
+    """RCCL itself, every round: backend `nccl` with world size 1 (what a one-GPU box allows), the trainer forced to issue all
+    its collectives - RCCL initialisation on the device, all-reduces on the compute stream, the early gradient bucket on the
+    communication stream behind the library's events, the metric reduction.  The step must equal the plain one."""
+    from ecg_denoise_amd import RALENet, UNet
+    steps = 1 if kind == "unet" else 3
+    out = str(tmp_path / "nccl1")
+    _launch([out, "nccl1:" + kind, str(steps)], n=1)
+    r = torch.load(out + ".rank0")
+    if "skip" in r:
+        pytest.skip("RCCL process group unavailable on this box: " + r["skip"])
+    assert r["backend"] == "nccl" and r["step_count"] == steps
+    # RA-LENet: two BatchNorm reductions + two gradient buckets per step, one metric reduction; U-Net: 20 + 1
+    assert r["collectives"] == [((4 if kind == "ralenet" else 21), 1)] * steps, r["collectives"]
+    B, L = 128, 256
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(B, 2, L, generator=g).cuda(); t = torch.randn(B, 2, L, generator=g).cuda()
+    m = (UNet(leads=2, L=L, max_batch=B, device="cuda:0", seed=100) if kind == "unet"
+         else RALENet("full", leads=2, L=L, max_batch=B, device="cuda:0", seed=100))
+    m.train()
+    losses = [m.train_step(x, t)["loss"].item() for _ in range(steps)]
+    assert np.allclose(losses, r["losses"], rtol=2e-5), (losses, r["losses"])
+    sd = m.state_dict()
+    for k in ("conv1.2.running_var", "transformer.blocks.0.mlp.fc1.weight") if kind == "ralenet" else ():
+        assert rel(r["state"][k].numpy(), sd[k].cpu().numpy()) < 2e-4, k
