@@ -366,6 +366,8 @@ struct RalModel {
   float* paramsT = nullptr;   // transposed copies of the weight matrices (same offsets), refreshed per backward
   unsigned short* wh = nullptr;             // tiled split planes of the wide levels' weight matrices (a matrix at twice its float
                                             // offset), re-written every forward from the descriptors below
+  float* ascale = nullptr;                  // device: ASC_N activation scales per transformer block (k_act_scales, once per forward)
+  int* adesc = nullptr;                     // device: 12 ints per block (its descriptor)
   int* wdesc = nullptr;                     // device: int4 {offset, rows, columns, first work item} per matrix
   int ndesc = 0, nwork = 0;
   unsigned* gmax = nullptr;                 // (18 blocks x 4 lanes x 4) largest-magnitude bits of dx2 / du / dx1 / dqkv per block and lane: scales of the split weight-gradient products; zeroed per backward
@@ -452,6 +454,8 @@ static size_t plan_workspace(const ral_config& c, RalModel* m /* may be null: si
   }
   { Layout L_; build_layout(c, L_); M.wh = reinterpret_cast<unsigned short*>(take("wh", (size_t)L_.nparam)); }
   M.wdesc = reinterpret_cast<int*>(take("wdesc", 4 * 64));
+  M.ascale = take("ascale", 18 * ASC_N);
+  M.adesc = reinterpret_cast<int*>(take("adesc", 18 * 12));
   static const char* RN[8] = {"p1", "p2", "p3", "p4", "u3", "u2", "u1", "u0"};
   for (int r = 0; r < 8; ++r) M.res_out[r] = take(RN[r], E);
   M.xmid = take("xmid", E);
@@ -522,6 +526,7 @@ static BlockP block_ptrs(const BlockOff& o, float* base) {
   p.ln1w = base + o.ln1w; p.ln1b = base + o.ln1b; p.ln2w = base + o.ln2w; p.ln2b = base + o.ln2b;
   p.w1 = base + o.w1; p.b1 = base + o.b1; p.w2 = base + o.w2; p.b2 = base + o.b2;
   p.le = o.le >= 0 ? base + o.le : nullptr;
+  p.asc = nullptr;
   return p;
 }
 
@@ -553,7 +558,8 @@ template <class T> static inline T* woff(T* p, int w0, size_t per_window) { retu
 static void run_block_fwd(RalModel* m, int bi, const float* in, bool training, const Lane& ln) {
   const int si = bi / 2, l = STAGES[si].level, C = CH[l], N = m->L >> l, H = C / 4;
   const size_t E1 = m->E1;
-  const BlockP w = block_ptrs(m->lay.blk[bi], m->params);
+  BlockP w = block_ptrs(m->lay.blk[bi], m->params);
+  w.asc = m->f16_split > 0 ? m->ascale + ASC_N * bi : nullptr;
   BlockAct& a = m->act[bi];
   a.in = const_cast<float*>(in);   // base pointer (window 0); lanes offset it
   const float* table = nullptr;
@@ -637,7 +643,10 @@ static int fwd_begin(RalModel* m, const float* x, int B, int training, hipStream
     hipStream_t ps = lanes_of(m)->l[0].s2;
     HIP_OK(hipEventRecord(m->ev_prep_go, s));            // (the parameters are final: everything queued on s so far has run)
     HIP_OK(hipStreamWaitEvent(ps, m->ev_prep_go, 0));
-    if (m->f16_split > 0) launch_tile_planes(m->params, m->wh, m->wdesc, m->ndesc, m->nwork, 0, ps);
+    if (m->f16_split > 0) {
+      launch_act_scales(m->params, m->adesc, m->ascale, 18, ps);
+      launch_tile_planes(m->params, m->wh, m->wdesc, m->ndesc, m->nwork, 0, ps);
+    }
     HIP_OK(hipEventRecord(m->ev_prep_fwd, ps));
     m->prep_fwd = true;
     if (training) {
@@ -668,7 +677,10 @@ static int fwd_end(RalModel* m, float* y, int B, int64_t global_windows, int tra
   }
   const bool tr = training != 0;
   if (m->prep_fwd) { HIP_OK(hipStreamWaitEvent(s, m->ev_prep_fwd, 0)); m->prep_fwd = false; }   // split planes of the wide levels' weights: formed under the stem
-  else if (m->f16_split > 0) launch_tile_planes(m->params, m->wh, m->wdesc, m->ndesc, m->nwork, 0, s);
+  else if (m->f16_split > 0) {
+    launch_act_scales(m->params, m->adesc, m->ascale, 18, s);
+    launch_tile_planes(m->params, m->wh, m->wdesc, m->ndesc, m->nwork, 0, s);
+  }
   const int nl = plan_lanes(m, B, s);
   fork_lanes(m, s);
   LaneSet* LS = lanes_of(m);
@@ -708,7 +720,8 @@ static int fwd_end(RalModel* m, float* y, int B, int64_t global_windows, int tra
 static void run_block_bwd(RalModel* m, int bi, const float* dy, const float* extra, float* dx, Lane& ln) {
   const int si = bi / 2, l = STAGES[si].level, C = CH[l], N = m->L >> l, H = C / 4;
   const size_t E1 = m->E1;
-  const BlockP w = block_ptrs(m->lay.blk[bi], m->params);
+  BlockP w = block_ptrs(m->lay.blk[bi], m->params);
+  w.asc = m->f16_split > 0 ? m->ascale + ASC_N * bi : nullptr;
   const BlockP g = block_ptrs(m->lay.blk[bi], m->grads);
   const BlockP wt = block_ptrs(m->lay.blk[bi], m->paramsT);
   BlockAct& a = m->act[bi];
@@ -798,7 +811,10 @@ static int bwd_begin(RalModel* m, const float* dy, int B, hipStream_t s) {
   if (m->prep_bwd) { HIP_OK(hipStreamWaitEvent(s, m->ev_prep_bwd, 0)); m->prep_bwd = false; }   // transposes + their planes: formed during the forward
   if (!prep_ok) {   // (... or formed from parameters / for options that have changed since: after them, again, from what is bound now)
     launch_transpose_mats(m->params, m->paramsT, m->tdesc, m->tn, m->ttotal, s);
-    if (m->f16_split > 0) launch_tile_planes(m->paramsT, m->whT, m->wdescT, m->ndescT, m->nworkT, 1, s);
+    if (m->f16_split > 0) {
+      launch_tile_planes(m->paramsT, m->whT, m->wdescT, m->ndescT, m->nworkT, 1, s);
+      if (m->prep_stale) launch_act_scales(m->params, m->adesc, m->ascale, 18, s);   // (the weight-gradient products scale their activation operands)
+    }
   }
   HIP_OK(hipMemsetAsync(m->gmax, 0, 18 * 4 * 4 * sizeof(unsigned), s));
   float** gy = m->gy; float** gin = m->gin;
@@ -1061,6 +1077,17 @@ int ral_create(const ral_config* cfg, ral_handle** out) {
       destroy_model(m); delete h;
       return -1;
     }
+  }
+  {   // descriptors of the activation-scale kernel
+    std::vector<int> d;
+    for (int b = 0; b < 18; ++b) {
+      const BlockOff& o = m->lay.blk[b];
+      const int v[12] = {CH[STAGES[b / 2].level], (int)o.ln1w, (int)o.ln1b, (int)o.wqkv, (int)o.bqkv, (int)o.ln2w, (int)o.ln2b, (int)o.w1, (int)o.b1,
+                         (int)o.le, 0, 0};
+      d.insert(d.end(), v, v + 12);
+    }
+    e = hipMemcpy(m->adesc, d.data(), d.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { fail("hipMemcpy(adesc) failed: %s", hipGetErrorString(e)); destroy_model(m); delete h; return -1; }
   }
   m->f16_split = (int)ral_knob("F16_SPLIT", m->f16_split);   // (a process-wide default for tests: ral_global_option; never the environment)
   m->attn_f16 = attn_f16_default() != 0;

@@ -1566,7 +1566,8 @@ template <int LEADS>
 __global__ __launch_bounds__(256) void k_final_bwd(const float* __restrict__ dy, const float* __restrict__ u0,
                                                    const float* __restrict__ x0, const float* __restrict__ w,
                                                    float* __restrict__ gw, float* __restrict__ gb,
-                                                   float* __restrict__ dz, int L, int B) {
+                                                   float* __restrict__ dz, int L, int Lp, int B) {
+  // L: samples per window of dy; Lp >= L: token slots per window of u0 / x0 / dz (slots past L: no gradient, they do not exist)
   constexpr int NG = LEADS * 24 + LEADS;
   __shared__ float red[4][NG];
   float wr[LEADS][8][3];
@@ -1579,9 +1580,14 @@ __global__ __launch_bounds__(256) void k_final_bwd(const float* __restrict__ dy,
   float acc[NG];
 #pragma unroll
   for (int i = 0; i < NG; ++i) acc[i] = 0.f;
-  const size_t total = (size_t)B * L;
+  const size_t total = (size_t)B * Lp;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int b = (int)(i / L), l = (int)(i - (size_t)b * L);
+    const int b = (int)(i / Lp), l = (int)(i - (size_t)b * Lp);
+    if (l >= L) {
+      float4* pz0 = reinterpret_cast<float4*>(dz + i * 8);
+      pz0[0] = make_float4(0.f, 0.f, 0.f, 0.f); pz0[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      continue;
+    }
     float dyv[LEADS][3];  // dy[o][l-1], dy[o][l], dy[o][l+1]
 #pragma unroll
     for (int o = 0; o < LEADS; ++o) {
@@ -1674,7 +1680,8 @@ __global__ __launch_bounds__(256) void k_conv1_bwd(const float* __restrict__ dy,
                                                    const float* __restrict__ x, const float* __restrict__ ss,
                                                    const float* __restrict__ bnw, const double* __restrict__ bst,
                                                    double count, float* __restrict__ gw, float* __restrict__ gb,
-                                                   float* __restrict__ dzout, int L, int B) {
+                                                   float* __restrict__ dzout, int L, int Lp, int B) {
+  // L: samples per window of x; Lp >= L: token slots per window of dy / a0 / dzout (slots past L do not exist: no gradient)
   constexpr int NG = 8 * LEADS * 3 + 8;
   __shared__ float red[4][NG];
   float k1[8], m1[8], m2[8];
@@ -1687,9 +1694,16 @@ __global__ __launch_bounds__(256) void k_conv1_bwd(const float* __restrict__ dy,
   float acc[NG];
 #pragma unroll
   for (int i = 0; i < NG; ++i) acc[i] = 0.f;
-  const size_t total = (size_t)B * L;
+  const size_t total = (size_t)B * Lp;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int b = (int)(i / L), l = (int)(i - (size_t)b * L);
+    const int b = (int)(i / Lp), l = (int)(i - (size_t)b * Lp);
+    if (l >= L) {
+      if (dzout) {
+        float4* pz0 = reinterpret_cast<float4*>(dzout + i * 8);
+        pz0[0] = make_float4(0.f, 0.f, 0.f, 0.f); pz0[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      continue;
+    }
     const float4 d0 = reinterpret_cast<const float4*>(dy)[i * 2], d1 = reinterpret_cast<const float4*>(dy)[i * 2 + 1];
     const float4 v0 = reinterpret_cast<const float4*>(a0)[i * 2], v1 = reinterpret_cast<const float4*>(a0)[i * 2 + 1];
     const float d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
@@ -1747,7 +1761,7 @@ __global__ void k_bn_affine_grads(const double* __restrict__ bst, float* __restr
 // dx[b][c][l] = sum_o sum_k w[o][c][k] dz[b][l-k+1][o]   (input gradient of the stem, 12-lead adapter only)
 template <int LEADS>
 __global__ void k_conv1_bwd_dx(const float* __restrict__ dz, const float* __restrict__ w, float* __restrict__ dx,
-                               int L, int B) {
+                               int L, int Lp, int B) {
   const size_t total = (size_t)B * L;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int b = (int)(i / L), l = (int)(i - (size_t)b * L);
@@ -1758,7 +1772,7 @@ __global__ void k_conv1_bwd_dx(const float* __restrict__ dz, const float* __rest
     for (int k = 0; k < 3; ++k) {
       const int ll = l - k + 1;
       if (ll < 0 || ll >= L) continue;
-      const float* dr = dz + ((size_t)b * L + ll) * 8;
+      const float* dr = dz + ((size_t)b * Lp + ll) * 8;
 #pragma unroll
       for (int o = 0; o < 8; ++o)
 #pragma unroll
@@ -2041,10 +2055,10 @@ void launch_resample_bwd(int D, bool sep, const float* dy, const float* x, const
 }
 
 void launch_final_bwd(int leads, const float* dy, const float* u0, const float* x0, const float* w, float* gw,
-                      float* gb, float* dz, int L, int B, hipStream_t s) {
-  const int grid = ew_grid((size_t)B * L, 1024);
-  if (leads == 1) k_final_bwd<1><<<grid, 256, 0, s>>>(dy, u0, x0, w, gw, gb, dz, L, B);
-  else k_final_bwd<2><<<grid, 256, 0, s>>>(dy, u0, x0, w, gw, gb, dz, L, B);
+                      float* gb, float* dz, int L, int Lp, int B, hipStream_t s) {
+  const int grid = ew_grid((size_t)B * Lp, 1024);
+  if (leads == 1) k_final_bwd<1><<<grid, 256, 0, s>>>(dy, u0, x0, w, gw, gb, dz, L, Lp, B);
+  else k_final_bwd<2><<<grid, 256, 0, s>>>(dy, u0, x0, w, gw, gb, dz, L, Lp, B);
 }
 
 void launch_bn8_bwd_stats(const float* dy, const float* a0, const float* ss, double* out, size_t ntok, hipStream_t s) {
@@ -2052,18 +2066,18 @@ void launch_bn8_bwd_stats(const float* dy, const float* a0, const float* ss, dou
 }
 
 void launch_conv1_bwd(int leads, const float* dy, const float* a0, const float* x, const float* ss, const float* bnw,
-                      const double* bst, double count, float* gw, float* gb, float* dz, int L, int B, hipStream_t s) {
-  const int grid = ew_grid((size_t)B * L, 1024);
-  if (leads == 1) k_conv1_bwd<1><<<grid, 256, 0, s>>>(dy, a0, x, ss, bnw, bst, count, gw, gb, dz, L, B);
-  else k_conv1_bwd<2><<<grid, 256, 0, s>>>(dy, a0, x, ss, bnw, bst, count, gw, gb, dz, L, B);
+                      const double* bst, double count, float* gw, float* gb, float* dz, int L, int Lp, int B, hipStream_t s) {
+  const int grid = ew_grid((size_t)B * Lp, 1024);
+  if (leads == 1) k_conv1_bwd<1><<<grid, 256, 0, s>>>(dy, a0, x, ss, bnw, bst, count, gw, gb, dz, L, Lp, B);
+  else k_conv1_bwd<2><<<grid, 256, 0, s>>>(dy, a0, x, ss, bnw, bst, count, gw, gb, dz, L, Lp, B);
 }
 
 void launch_bn_affine_grads(const double* bst, float* gw, float* gb, int nch, double share, hipStream_t s) {
   k_bn_affine_grads<<<1, 64, 0, s>>>(bst, gw, gb, nch, share);
 }
 
-void launch_conv1_bwd_dx(int leads, const float* dz, const float* w, float* dx, int L, int B, hipStream_t s) {
+void launch_conv1_bwd_dx(int leads, const float* dz, const float* w, float* dx, int L, int Lp, int B, hipStream_t s) {
   const int grid = ew_grid((size_t)B * L);
-  if (leads == 1) k_conv1_bwd_dx<1><<<grid, 256, 0, s>>>(dz, w, dx, L, B);
-  else k_conv1_bwd_dx<2><<<grid, 256, 0, s>>>(dz, w, dx, L, B);
+  if (leads == 1) k_conv1_bwd_dx<1><<<grid, 256, 0, s>>>(dz, w, dx, L, Lp, B);
+  else k_conv1_bwd_dx<2><<<grid, 256, 0, s>>>(dz, w, dx, L, Lp, B);
 }

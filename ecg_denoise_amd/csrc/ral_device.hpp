@@ -635,7 +635,19 @@ struct BlockP {
   float* w2;    // (C, 4C)  mlp.fc2
   float* b2;    // (C)
   float* le;    // (3) leconv.partial_conv3.weight or nullptr
+  const float* asc;   // the block's activation scales (ASC_* below; k_act_scales) or nullptr = every scale 1 (gradient / transposed views)
 };
+
+// Powers of two for the ACTIVATION operands of the fp16-pair products of one block, from bounds that hold for ANY input:
+//   LayerNorm output   |h_i| <= sqrt(C) max|gamma| + max|beta|,   |h|_2 <= sqrt(C) max|gamma| + |beta|_2
+//   attention output   |o_i| <= max |v_i| <= max_j (|Wv_j|_2 |h1|_2 + |bv_j|)          (a convex combination of value rows)
+//   hidden (fc2 input) |a2_i| <= max(1, sum|le|) max_j (|W1_j|_2 |h2|_2 + |b1_j|)      (|GELU(z)| <= |z|; the 3-tap conv on channel 0)
+// each scale puts its bound into [2^13, 2^14): no operand of a forward or weight-gradient product can reach fp16's largest
+// finite value whatever the weights are (a model whose hidden values pass 65504 used to end in NaN on this path where the
+// reference's fp32 nn.Linear is finite), and activations far BELOW their usual size (weights x 1e-6) keep their 22 bits.
+// The inverse of every scale is a power of two as well and is folded into the product's weight-plane unscale: exact.
+enum { ASC_LN1 = 0, ASC_LN1_INV = 1, ASC_O = 2, ASC_O_INV = 3, ASC_LN2 = 4, ASC_LN2_INV = 5, ASC_HID = 6, ASC_HID_INV = 7, ASC_N = 8 };
+RAL_DEV float asc_get(const float* asc, int k) { return asc ? __builtin_nontemporal_load(asc + k) : 1.0f; }
 
 // ---------------------------------------------------------------------------------
 // loss + metrics: per window sse = sum (p-t)^2, sy2 = sum t^2 over leads*L

@@ -74,7 +74,7 @@ RAL_DEV void issue_then_store(LD ld, ST st, IN inner) {
 
 // H (wide levels, behind the split data-gradient kernels): both operands staged as fp16-pair planes - Y (a gradient) times
 // the power of two that puts the launch's largest |Y| (ymax, published by k_mlp_bwd_h / k_qkv_bwd_h) into [2^13, 2^14), X
-// (LayerNorm / GELU / attention outputs) times 2^8, residuals unscaled (f16_split2u) -, token-major rows; the consumers
+// (LayerNorm / GELU / attention outputs) times the block's power of two for that activation (`xscale`: its bound into [2^13, 2^14), ASC_*), residuals unscaled (f16_split2u) -, token-major rows; the consumers
 // fetch their fragments with the transposing LDS read (ds_read_b64_tr_b16: per 16 lanes a block of 4 tokens x 16 channels,
 // delivered channel-major - the contraction index of these products is the token) and issue three
 // v_mfma_f32_16x16x32_f16 per 32 tokens and tile into the one accumulator, which is unscaled once, at the flush.
@@ -87,13 +87,16 @@ template <int M, int NC, int MS, int NS, int LAYY, int XF, bool H = false>
 __global__ __launch_bounds__(512, RAL_DW_WPE) void k_dw(const float* Y, const float* X, const float* pe,
                                                const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                const float* a2c0, float* dW, float* dB, const unsigned* __restrict__ ymax,
+                                               const float* __restrict__ xscale /* {scale, inverse} of the X operand (ASC_*), or nullptr: 2^8 */,
                                                int N, int TC, int B) {
   extern __shared__ float4 smem4[];
   constexpr bool YHM = LAYY == LAY_HM, XHM = XF == XF_HM;
   constexpr int LDYH = MS + 8, LDXH = NS + 8;   // H: row strides of the token-major planes (2-byte elements)
   typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
   const float ysc = H ? h2_row_scale(ymax[0]) : 1.0f;
-  constexpr float XSC = 256.0f;
+  // the activation operand times the block's power of two for that activation (its bound into [2^13, 2^14): ral_device.hpp, ASC_*)
+  const float XSC = (H && xscale) ? __builtin_nontemporal_load(xscale) : 256.0f;
+  const float XSCI = (H && xscale) ? __builtin_nontemporal_load(xscale + 1) : 1.0f / 256.0f;
   constexpr int TM = (MS + 15) / 16, TN = (NS + 15) / 16;
   constexpr int WM = WaveGrid4<TM, TN>::WM, WN = WaveGrid4<TM, TN>::WN, MI = TM / WM, NI = TN / WN;
   constexpr int NWB = WM * WN, KW = 4 / NWB;      // spare consumer waves split the chunk's tokens (folded at the end)
@@ -402,7 +405,7 @@ __global__ __launch_bounds__(512, RAL_DW_WPE) void k_dw(const float* Y, const fl
 #pragma unroll
   for (int i = 0; i < MI; ++i) bsum[i] = rows_sum(bsum[i]);   // over the 4 k-groups: every lane (r, *) holds column r
   if constexpr (H) {   // out of the operand scales
-    const float uy = h2_row_unscale(ymax[0]), ua = uy * (1.0f / XSC);
+    const float uy = h2_row_unscale(ymax[0]), ua = uy * XSCI;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       bsum[i] *= uy;
@@ -482,7 +485,7 @@ void set_dw_lds_budget(size_t bytes) { g_dw_budget = bytes < (size_t)RAL_DW_LDS_
 template <int M, int NC, int MS, int NS, int LAYY, int XF>
 static void launch_dw_t(const float* Y, const float* X, const float* pe, const float* lnw, const float* lnb,
                         const float* a2c0, float* dW, float* dB, int N, int B, int ksplit, hipStream_t s,
-                        const unsigned* ymax = nullptr) {
+                        const unsigned* ymax = nullptr, const float* xscale = nullptr) {
   static_assert(M % MS == 0 && NC % NS == 0, "slices must tile dW");
   constexpr bool yhm = LAYY == LAY_HM, xhm = XF == XF_HM;
   constexpr int TM = (MS + 15) / 16, TN = (NS + 15) / 16;
@@ -502,7 +505,7 @@ static void launch_dw_t(const float* Y, const float* X, const float* pe, const f
       if (TC >= 32 && N % TC == 0 && bytesh(TC) <= g_dw_budget + 4096) {
         const size_t lds = bytesh(TC) > fold ? bytesh(TC) : fold;
         RAL_SET_LDS((k_dw<M, NC, MS, NS, LAYY, XF, true>), lds);
-        k_dw<M, NC, MS, NS, LAYY, XF, true><<<grid, 512, lds, s>>>(Y, X, pe, lnw, lnb, a2c0, dW, dB, ymax, N, TC, B);
+        k_dw<M, NC, MS, NS, LAYY, XF, true><<<grid, 512, lds, s>>>(Y, X, pe, lnw, lnb, a2c0, dW, dB, ymax, xscale, N, TC, B);
         return;
       }
     }
@@ -513,7 +516,7 @@ static void launch_dw_t(const float* Y, const float* X, const float* pe, const f
   while (TC > 16 && (N % TC != 0 || bytes(TC) > g_dw_budget)) TC /= 2;
   const size_t lds = bytes(TC) > fold ? bytes(TC) : fold;
   RAL_SET_LDS((k_dw<M, NC, MS, NS, LAYY, XF>), lds);
-  k_dw<M, NC, MS, NS, LAYY, XF><<<grid, 512, lds, s>>>(Y, X, pe, lnw, lnb, a2c0, dW, dB, nullptr, N, TC, B);
+  k_dw<M, NC, MS, NS, LAYY, XF><<<grid, 512, lds, s>>>(Y, X, pe, lnw, lnb, a2c0, dW, dB, nullptr, nullptr, N, TC, B);
 }
 
 // slice widths: at most RAL_DW_SLICE rows/columns of the wide operand per workgroup
@@ -528,11 +531,11 @@ static void launch_block_dw_c(const float* dx2, const float* upre, const float* 
   static const bool h_on = (ral_knob("DW_F16", 1) != 0);
   const unsigned* gm = (h_on && C >= 32) ? gmax : nullptr;
   if (!skip_mlp) {
-  launch_dw_t<C, 4 * C, C, SliceOf<4 * C>::v, LAY_TOK, XF_A2>(dx2, upre, nullptr, nullptr, nullptr, a2c0, gr.w2, gr.b2, N, B, ks, s, gm ? gm + 0 : nullptr);
-  launch_dw_t<4 * C, C, SliceOf<4 * C>::v, C, LAY_TOK, XF_LN>(dupre, x1, nullptr, w.ln2w, w.ln2b, nullptr, gr.w1, gr.b1, N, B, ks, s, gm ? gm + 1 : nullptr);
+  launch_dw_t<C, 4 * C, C, SliceOf<4 * C>::v, LAY_TOK, XF_A2>(dx2, upre, nullptr, nullptr, nullptr, a2c0, gr.w2, gr.b2, N, B, ks, s, gm ? gm + 0 : nullptr, w.asc ? w.asc + ASC_HID : nullptr);
+  launch_dw_t<4 * C, C, SliceOf<4 * C>::v, C, LAY_TOK, XF_LN>(dupre, x1, nullptr, w.ln2w, w.ln2b, nullptr, gr.w1, gr.b1, N, B, ks, s, gm ? gm + 1 : nullptr, w.asc ? w.asc + ASC_LN2 : nullptr);
   }
-  launch_dw_t<C, C, SliceOf<C>::v, C, LAY_TOK, XF_HM>(dx1, o_hm, nullptr, nullptr, nullptr, nullptr, gr.wp, gr.bp, N, B, ks, s, gm ? gm + 2 : nullptr);
-  launch_dw_t<3 * C, C, SliceOf<3 * C>::v, C, LAY_HM, XF_LNPE>(dqkv, x, pe, w.ln1w, w.ln1b, nullptr, gr.wqkv, gr.bqkv, N, B, ks, s, gm ? gm + 3 : nullptr);
+  launch_dw_t<C, C, SliceOf<C>::v, C, LAY_TOK, XF_HM>(dx1, o_hm, nullptr, nullptr, nullptr, nullptr, gr.wp, gr.bp, N, B, ks, s, gm ? gm + 2 : nullptr, w.asc ? w.asc + ASC_O : nullptr);
+  launch_dw_t<3 * C, C, SliceOf<3 * C>::v, C, LAY_HM, XF_LNPE>(dqkv, x, pe, w.ln1w, w.ln1b, nullptr, gr.wqkv, gr.bqkv, N, B, ks, s, gm ? gm + 3 : nullptr, w.asc ? w.asc + ASC_LN1 : nullptr);
 }
 
 void launch_block_dw(int C, const float* dx2, const float* upre, const float* a2c0, const float* dupre, const float* x1,

@@ -66,12 +66,14 @@ __global__ __launch_bounds__(256) void k_qkv_fwd_h(const float* __restrict__ x, 
   typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
   const float sqrtC = sqrtf((float)C);
   const int cq = (threadIdx.x % LPR) * 4;
-  const float4 gam = *reinterpret_cast<const float4*>(w.ln1w + cq);
-  const float4 bet = *reinterpret_cast<const float4*>(w.ln1b + cq);
+  // (the LayerNorm affine carries the operand's power of two, the weight-plane unscale its inverse: ASC_LN1, ral_device.hpp)
+  const float sg = asc_get(w.asc, ASC_LN1);
+  const float4 gam = f4scale(*reinterpret_cast<const float4*>(w.ln1w + cq), sg);
+  const float4 bet = f4scale(*reinterpret_cast<const float4*>(w.ln1b + cq), sg);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
   const long total = (long)B * N;
   const int ngroups = (int)((total + GT - 1) / GT);
-  const float wun = wplane_unscale(wt, 3 * C, C);
+  const float wun = wplane_unscale(wt, 3 * C, C) * asc_get(w.asc, ASC_LN1_INV);
   RAL_STAMP_INIT();
   for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     RAL_STAMP_AT(8);
@@ -154,9 +156,10 @@ __global__ __launch_bounds__(6 * C) void k_qkv_fwd_ws(const float* __restrict__ 
     for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
       for (int p = 0; p < 2; ++p) wf[mi][kc][p] = *reinterpret_cast<const f16x8*>(wtile(wt, KC, 2 * wave + mi, kc, p));
-  const float wun = wplane_unscale(wt, 3 * C, C);
-  const float4 gam = *reinterpret_cast<const float4*>(w.ln1w + cq);
-  const float4 bet = *reinterpret_cast<const float4*>(w.ln1b + cq);
+  const float sg = asc_get(w.asc, ASC_LN1);         // (as in k_qkv_fwd_h)
+  const float wun = wplane_unscale(wt, 3 * C, C) * asc_get(w.asc, ASC_LN1_INV);
+  const float4 gam = f4scale(*reinterpret_cast<const float4*>(w.ln1w + cq), sg);
+  const float4 bet = f4scale(*reinterpret_cast<const float4*>(w.ln1b + cq), sg);
   float4 pev[NP];
 #pragma unroll
   for (int k = 0; k < NP; ++k) {
@@ -297,6 +300,76 @@ __global__ void k_tile_planes(const float* __restrict__ params, _Float16* __rest
     *reinterpret_cast<f16x8*>(dst + 512) = h2;
   }
 }
+// Activation scales of every transformer block (ASC_*, ral_device.hpp): one workgroup per block.  desc[b] = 12 ints: C, then the
+// float offsets of ln1w, ln1b, wqkv, bqkv, ln2w, ln2b, w1, b1, le (-1: no local enhancement), 0, 0.  Row norms with 16 lanes per
+// row (four rows per wave and pass).
+__global__ __launch_bounds__(1024) void k_act_scales(const float* __restrict__ params, const int* __restrict__ desc, float* __restrict__ asc) {
+  const int* D = desc + 12 * blockIdx.x;
+  const int C = D[0];
+  __shared__ float red[8][16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15, sub = lane >> 4;
+  // 0: max|g1| 1: max|b1ln| 2: |b1ln|^2 3: max|g2| 4: max|b2ln| 5: |b2ln|^2
+  float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int i = threadIdx.x; i < C; i += blockDim.x) {
+    const float g1 = params[D[1] + i], b1 = params[D[2] + i], g2 = params[D[5] + i], b2 = params[D[6] + i];
+    v[0] = fabsf(g1); v[1] = fabsf(b1); v[2] = b1 * b1; v[3] = fabsf(g2); v[4] = fabsf(b2); v[5] = b2 * b2;
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const float r_ = (k == 2 || k == 5) ? group_sum<64>(v[k]) : group_max<64>(v[k]);
+    if (lane == 0) red[k][wave] = r_;
+  }
+  __syncthreads();
+  float st[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    float a = red[k][0];
+    for (int w_ = 1; w_ < 16; ++w_) a = (k == 2 || k == 5) ? a + red[k][w_] : fmaxf(a, red[k][w_]);
+    st[k] = a;
+  }
+  const float sqC = sqrtf((float)C);
+  const float e1 = sqC * st[0] + st[1], n1 = sqC * st[0] + sqrtf(st[2]);      // element bound / L2 bound of LN1's output
+  const float e2 = sqC * st[3] + st[4], n2 = sqC * st[3] + sqrtf(st[5]);
+  // max_j (|W_j|_2 * nrm + |b_j|) over the rows of a (rows x C) matrix
+  auto row_bound = [&](const float* W, const float* bias, int rows, float nrm) -> float {
+    float best = 0.f;
+    for (int r0 = (wave * 4 + sub); r0 < rows; r0 += 64) {
+      float ss = 0.f;
+      for (int c = l16 * 4; c < C; c += 64) {
+        const float4 q = *reinterpret_cast<const float4*>(W + (size_t)r0 * C + c);
+        ss += f4dot(q, q);
+      }
+      ss = group_sum<16>(ss);
+      best = fmaxf(best, sqrtf(ss) * nrm + fabsf(bias[r0]));
+    }
+    return group_max<64>(best);
+  };
+  const float bv = row_bound(params + D[3] + 2 * C * C, params + D[4] + 2 * C, C, n1);
+  const float bu = row_bound(params + D[7], params + D[8], 4 * C, n2);
+  __syncthreads();
+  if (lane == 0) { red[6][wave] = bv; red[7][wave] = bu; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float mv = red[6][0], mu = red[7][0];
+    for (int w_ = 1; w_ < 16; ++w_) { mv = fmaxf(mv, red[6][w_]); mu = fmaxf(mu, red[7][w_]); }
+    if (D[9] >= 0) {
+      const float sl = fabsf(params[D[9]]) + fabsf(params[D[9] + 1]) + fabsf(params[D[9] + 2]);
+      mu *= fmaxf(1.0f, sl);
+    }
+    const float bnd[4] = {e1, mv, e2, mu};
+    float* out = asc + ASC_N * blockIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned bits = __float_as_uint(bnd[k] * 1.001f);    // (the bounds' own rounding)
+      out[2 * k] = h2_row_scale(bits);
+      out[2 * k + 1] = h2_row_unscale(bits);
+    }
+  }
+}
+void launch_act_scales(const float* params, const void* desc, float* asc, int nblk, hipStream_t s) {
+  k_act_scales<<<nblk, 1024, 0, s>>>(params, reinterpret_cast<const int*>(desc), asc);
+}
+
 void launch_tile_planes(const float* params, void* wt, const void* desc, int ndesc, int nwork, int unscaled, hipStream_t s) {
   if (ndesc <= 0) return;
   k_weight_scales<<<ndesc, 1024, 0, s>>>(params, reinterpret_cast<_Float16*>(wt), reinterpret_cast<const int4*>(desc));
@@ -770,7 +843,10 @@ __global__ __launch_bounds__(NTH, 4) void k_mlp_fwd_h(const float* __restrict__ 
   const _Float16* wph = wt + 2 * (w.wp - pbase);   // tiled split planes of the three weight matrices
   const _Float16* w1h = wt + 2 * (w.w1 - pbase);
   const _Float16* w2h = wt + 2 * (w.w2 - pbase);
-  const float wunp = wplane_unscale(wph, C, C), wun1 = wplane_unscale(w1h, 4 * C, C), wun2 = wplane_unscale(w2h, C, 4 * C);
+  // activation operands times the block's powers of two (ASC_*, ral_device.hpp), their inverses in the weight-plane unscales
+  const float so = asc_get(w.asc, ASC_O), sg2 = asc_get(w.asc, ASC_LN2), sh = asc_get(w.asc, ASC_HID);
+  const float wunp = wplane_unscale(wph, C, C) * asc_get(w.asc, ASC_O_INV), wun1 = wplane_unscale(w1h, 4 * C, C) * asc_get(w.asc, ASC_LN2_INV),
+              wun2 = wplane_unscale(w2h, C, 4 * C) * asc_get(w.asc, ASC_HID_INV);
   auto put_split = [&](_Float16* base, int plane, int off, float4 v) {
     const H2 s0 = f16_split2(v.x), s1 = f16_split2(v.y), s2 = f16_split2(v.z), s3 = f16_split2(v.w);
     *reinterpret_cast<f16x4*>(base + off) = f16x4{s0.a, s1.a, s2.a, s3.a};
@@ -788,7 +864,7 @@ __global__ __launch_bounds__(NTH, 4) void k_mlp_fwd_h(const float* __restrict__ 
       auto put = [&](int i, float4 xv, float4 ov) {
         *reinterpret_cast<float4*>(Xs + (i / q) * LD + (i % q) * 4) = xv;
         const int wl = i / nq, i2 = i - wl * nq, qd = i2 / N, t = i2 - qd * N;
-        put_split(Gh, gplane, (wl * N + t) * LDG + qd * 4, ov);
+        put_split(Gh, gplane, (wl * N + t) * LDG + qd * 4, f4scale(ov, so));
       };
       for (int i0 = 0; i0 < n4; i0 += 2 * NTH) {
         const int i = i0 + threadIdx.x, j = i + NTH;
@@ -812,8 +888,8 @@ __global__ __launch_bounds__(NTH, 4) void k_mlp_fwd_h(const float* __restrict__ 
     RAL_STAMP_AT(2);
     // ---- LN2 -> split planes ----
     {
-      const float4 gam = *reinterpret_cast<const float4*>(w.ln2w + cq);
-      const float4 bet = *reinterpret_cast<const float4*>(w.ln2b + cq);
+      const float4 gam = f4scale(*reinterpret_cast<const float4*>(w.ln2w + cq), sg2);
+      const float4 bet = f4scale(*reinterpret_cast<const float4*>(w.ln2b + cq), sg2);
       for (int row = threadIdx.x / LPR; row < T; row += RPP) {
         const float4 v = *reinterpret_cast<const float4*>(Xs + row * LD + cq);
         float4 d; float rstd;
@@ -836,14 +912,14 @@ __global__ __launch_bounds__(NTH, 4) void k_mlp_fwd_h(const float* __restrict__ 
           if (ch == 0 && row0 == 0) A0[tok + 1 + 2 * (tok / N)] = h.x;   // conv input; hidden channel 0 is filled below
           h = make_float4(gelu_f(h.x), gelu_f(h.y), gelu_f(h.z), gelu_f(h.w));
         }
-        put_split(Uh, uplane, tok * LDU + row0, h);
+        put_split(Uh, uplane, tok * LDU + row0, f4scale(h, sh));
       });
       __syncthreads();
       RAL_STAMP_AT(4);
       if (le && ch == 0) {
         for (int n = threadIdx.x; n < T; n += NTH) {
           const int a = n + 1 + 2 * (n / N);
-          const H2 s = f16_split2(gelu_f(lw0 * A0[a - 1] + lw1 * A0[a] + lw2 * A0[a + 1]));
+          const H2 s = f16_split2(gelu_f(lw0 * A0[a - 1] + lw1 * A0[a] + lw2 * A0[a + 1]) * sh);
           Uh[n * LDU] = s.a; Uh[uplane + n * LDU] = s.b;
         }
         __syncthreads();

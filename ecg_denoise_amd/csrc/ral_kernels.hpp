@@ -22,6 +22,8 @@
 // in `wt`).  wt == nullptr selects the fp32-MFMA kernels.
 bool qkv_fwd_uses_f16(int C);
 void launch_tile_planes(const float* params, void* wt, const void* desc, int ndesc, int nwork, int unscaled_residual, hipStream_t s);
+// the activation scales of the nblk transformer blocks (ASC_N floats each; desc: 12 ints per block - see k_act_scales)
+void launch_act_scales(const float* params, const void* desc, float* asc, int nblk, hipStream_t s);
 void launch_qkv_fwd(int C, const float* x, const float* pe, const BlockP& w, const void* wt /* of Wqkv */, float* qkv, int N, int B, hipStream_t s);
 size_t attn_fwd_lds(int N, int HG, int Len);
 void launch_attn_fwd(const float* qkv, float* o_hm, float* lse, const float* table, int N, int H, int HG, int Len,
@@ -48,12 +50,12 @@ void launch_add(const float* a, const float* b, float* y, size_t n, hipStream_t 
 
 // ---- stem / head / loss / optimiser (ral_misc.hip)
 void launch_conv1_fwd(int leads, int mode, const float* x, const float* w, const float* b, float* out, double* stats,
-                      const float* bnw, const float* bnb, const float* rmean, const float* rvar, int L, int B,
+                      const float* bnw, const float* bnb, const float* rmean, const float* rvar, int L, int Lp /* token slots per window (>= L) */, int B,
                       hipStream_t s);
 void launch_bn_finalize(const double* stats, double count, const float* bnw, const float* bnb, float* ss,
                         float* rmean, float* rvar, int nch, int update_running, hipStream_t s);
 void launch_bn_apply8(const float* a0, const float* ss, float* x0, size_t ntok, hipStream_t s);
-void launch_final_fwd(int leads, const float* u0, const float* x0, const float* w, const float* b, float* y, int L,
+void launch_final_fwd(int leads, const float* u0, const float* x0, const float* w, const float* b, float* y, int L, int Lp,
                       int B, hipStream_t s);
 // fin != nullptr: loss_sum is a {double, counter} scratch that is zero on entry and left zero; fin[0] = sum * fin_scale
 // fin3: the scratch has 64 doubles (sum [0], counter [16], SNR sum [32], RMSE sum [48]: a cache line each); fin[1], fin[2] = the sums of the windows' SNR / RMSE * fin_scale
@@ -123,12 +125,12 @@ void launch_qkv_bwd(int C, const float* dqkv, const float* x, const float* pe, c
 void launch_resample_bwd(int D, bool sep, const float* dy, const float* x, const float* wred, const float* lnw,
                          float* g_lnw, float* g_lnb, float* dx, int T, int B, hipStream_t s);
 void launch_final_bwd(int leads, const float* dy, const float* u0, const float* x0, const float* w, float* gw,
-                      float* gb, float* dz, int L, int B, hipStream_t s);
+                      float* gb, float* dz, int L, int Lp, int B, hipStream_t s);
 void launch_bn8_bwd_stats(const float* dy, const float* a0, const float* ss, double* out, size_t ntok, hipStream_t s);
 void launch_conv1_bwd(int leads, const float* dy, const float* a0, const float* x, const float* ss, const float* bnw,
-                      const double* bst, double count, float* gw, float* gb, float* dz, int L, int B, hipStream_t s);
+                      const double* bst, double count, float* gw, float* gb, float* dz, int L, int Lp, int B, hipStream_t s);
 void launch_bn_affine_grads(const double* bst, float* gw, float* gb, int nch, double share, hipStream_t s);
-void launch_conv1_bwd_dx(int leads, const float* dz, const float* w, float* dx, int L, int B, hipStream_t s);
+void launch_conv1_bwd_dx(int leads, const float* dz, const float* w, float* dx, int L, int Lp, int B, hipStream_t s);
 
 // ---- weight gradients (ral_dw.hip)
 void launch_block_dw(int C, const float* dx2, const float* upre, const float* a2c0, const float* dupre, const float* x1,

@@ -34,7 +34,9 @@ __global__ __launch_bounds__(256) void k_conv1_fwd(const float* __restrict__ x, 
                                                    const float* __restrict__ bias, float* __restrict__ out,
                                                    double* __restrict__ stats, const float* __restrict__ bnw,
                                                    const float* __restrict__ bnb, const float* __restrict__ rmean,
-                                                   const float* __restrict__ rvar, int L, int B) {
+                                                   const float* __restrict__ rvar, int L, int Lp, int B) {
+  // L: samples of a window (row stride of x); Lp >= L: token slots per window in `out` (a window length that is not a multiple
+  // of 256 runs on the next multiple, ral_api.hip: the slots past L are written as zeros and are not part of the statistics)
   __shared__ double red[16 * 4];
   float wr[8][LEADS][3], br[8];
 #pragma unroll
@@ -56,9 +58,14 @@ __global__ __launch_bounds__(256) void k_conv1_fwd(const float* __restrict__ x, 
   float acc[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  const size_t total = (size_t)B * L;
+  const size_t total = (size_t)B * Lp;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int b = (int)(i / L), l = (int)(i - (size_t)b * L);
+    const int b = (int)(i / Lp), l = (int)(i - (size_t)b * Lp);
+    if (l >= L) {
+      float4* pz = reinterpret_cast<float4*>(out + i * 8);
+      pz[0] = make_float4(0.f, 0.f, 0.f, 0.f); pz[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      continue;
+    }
     float xv[LEADS][3];
 #pragma unroll
     for (int c = 0; c < LEADS; ++c) {
@@ -128,7 +135,8 @@ __global__ void k_bn_apply8(const float* __restrict__ a0, const float* __restric
 template <int LEADS>
 __global__ __launch_bounds__(256) void k_final_fwd(const float* __restrict__ u0, const float* __restrict__ x0,
                                                    const float* __restrict__ w, const float* __restrict__ bias,
-                                                   float* __restrict__ y, int L, int B) {
+                                                   float* __restrict__ y, int L, int Lp, int B) {
+  // L: samples per window of y; Lp >= L: token slots per window of u0 / x0 (the slots past L do not exist for the conv: zero halo)
   float wr[LEADS][8][3];
 #pragma unroll
   for (int o = 0; o < LEADS; ++o)
@@ -146,7 +154,7 @@ __global__ __launch_bounds__(256) void k_final_fwd(const float* __restrict__ u0,
     for (int k = 0; k < 3; ++k) {
       const int ll = l + k - 1;
       if (ll < 0 || ll >= L) continue;
-      const size_t t = (size_t)b * L + ll;
+      const size_t t = (size_t)b * Lp + ll;
       const float4 a0 = reinterpret_cast<const float4*>(u0)[t * 2], a1 = reinterpret_cast<const float4*>(u0)[t * 2 + 1];
       const float4 b0 = reinterpret_cast<const float4*>(x0)[t * 2], b1 = reinterpret_cast<const float4*>(x0)[t * 2 + 1];
       const float z[8] = {a0.x + b0.x, a0.y + b0.y, a0.z + b0.z, a0.w + b0.w,
@@ -291,15 +299,15 @@ static inline int ew_grid(size_t n, int per = 256) {
 }
 
 void launch_conv1_fwd(int leads, int mode, const float* x, const float* w, const float* b, float* out, double* stats,
-                      const float* bnw, const float* bnb, const float* rmean, const float* rvar, int L, int B,
+                      const float* bnw, const float* bnb, const float* rmean, const float* rvar, int L, int Lp, int B,
                       hipStream_t s) {
   // training: every workgroup ends with 16 double atomics on the same 16 addresses (~15 ns per link of a same-address
   // chain): 4096 workgroups were a 56 us kernel for 38 MB of traffic, 512 are an 18 us one
-  const int grid = ew_grid((size_t)B * L, mode == 0 ? 2048 : 256);
+  const int grid = ew_grid((size_t)B * Lp, mode == 0 ? 2048 : 256);
 #define CASE(ld)                                                                                             \
   case ld:                                                                                                   \
-    if (mode == 0) k_conv1_fwd<ld, 0><<<grid, 256, 0, s>>>(x, w, b, out, stats, bnw, bnb, rmean, rvar, L, B); \
-    else k_conv1_fwd<ld, 1><<<grid, 256, 0, s>>>(x, w, b, out, stats, bnw, bnb, rmean, rvar, L, B);           \
+    if (mode == 0) k_conv1_fwd<ld, 0><<<grid, 256, 0, s>>>(x, w, b, out, stats, bnw, bnb, rmean, rvar, L, Lp, B); \
+    else k_conv1_fwd<ld, 1><<<grid, 256, 0, s>>>(x, w, b, out, stats, bnw, bnb, rmean, rvar, L, Lp, B);           \
     break;
   switch (leads) { CASE(1) CASE(2) }
 #undef CASE
@@ -314,11 +322,11 @@ void launch_bn_apply8(const float* a0, const float* ss, float* x0, size_t ntok, 
   k_bn_apply8<<<ew_grid(ntok * 2), 256, 0, s>>>(a0, ss, x0, ntok);
 }
 
-void launch_final_fwd(int leads, const float* u0, const float* x0, const float* w, const float* b, float* y, int L,
+void launch_final_fwd(int leads, const float* u0, const float* x0, const float* w, const float* b, float* y, int L, int Lp,
                       int B, hipStream_t s) {
   const int grid = ew_grid((size_t)B * L);
-  if (leads == 1) k_final_fwd<1><<<grid, 256, 0, s>>>(u0, x0, w, b, y, L, B);
-  else k_final_fwd<2><<<grid, 256, 0, s>>>(u0, x0, w, b, y, L, B);
+  if (leads == 1) k_final_fwd<1><<<grid, 256, 0, s>>>(u0, x0, w, b, y, L, Lp, B);
+  else k_final_fwd<2><<<grid, 256, 0, s>>>(u0, x0, w, b, y, L, Lp, B);
 }
 
 void launch_loss(const float* pred, const float* target, float* dy, float* snr, float* rmse, double* loss_sum,

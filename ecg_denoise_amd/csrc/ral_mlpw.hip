@@ -268,12 +268,17 @@ __global__ __launch_bounds__(256, RAL_MLPW_WPE) void k_mlp_fwd_wh(const float* _
   }
   __syncthreads();
   const float sp = h2_row_scale(mxb[0]), s1 = h2_row_scale(mxb[1]), s2 = h2_row_scale(mxb[2]);
-  const float unp = h2_row_unscale(mxb[0]), un1 = h2_row_unscale(mxb[1]), un2 = h2_row_unscale(mxb[2]);
+  // the three activation operands (attention output, LayerNorm output, hidden tile) times the block's powers of two (ASC_*,
+  // ral_device.hpp): o and the hidden tile when they are split, the LayerNorm output through its affine (g2, be2 carry the scale,
+  // row 0 of W1 for the local-enhancement channel - w10 - its inverse: gv * w10 is unchanged), the inverses in the unscales
+  const float so = asc_get(w.asc, ASC_O), sg = asc_get(w.asc, ASC_LN2), sgi = asc_get(w.asc, ASC_LN2_INV), sh = asc_get(w.asc, ASC_HID);
+  const float unp = h2_row_unscale(mxb[0]) * asc_get(w.asc, ASC_O_INV), un1 = h2_row_unscale(mxb[1]) * sgi,
+              un2 = h2_row_unscale(mxb[2]) * asc_get(w.asc, ASC_HID_INV);
   stage_planes(w.wp, C, C, sp, WpH, LDA, PWP);
   stage_planes(w.w1, HID, C, s1, W1H, LDA, PW1);
   stage_planes(w.w2, C, HID, s2, W2H, LDB, PW2);
   for (int i = threadIdx.x; i < C * C; i += blockDim.x) Wp[(i / C) * LDC + i % C] = w.wp[i];
-  for (int i = threadIdx.x; i < C; i += blockDim.x) { w10[i] = w.w1[i]; bp[i] = w.bp[i]; g2[i] = w.ln2w[i]; be2[i] = w.ln2b[i]; b2[i] = w.b2[i]; }
+  for (int i = threadIdx.x; i < C; i += blockDim.x) { w10[i] = w.w1[i] * sgi; bp[i] = w.bp[i]; g2[i] = w.ln2w[i] * sg; be2[i] = w.ln2b[i] * sg; b2[i] = w.b2[i]; }
   for (int i = threadIdx.x; i < HID; i += blockDim.x) b1[i] = w.b1[i];
   const bool le = w.le != nullptr;
   float lw0 = 0.f, lw1 = 0.f, lw2 = 0.f;
@@ -348,7 +353,7 @@ __global__ __launch_bounds__(256, RAL_MLPW_WPE) void k_mlp_fwd_wh(const float* _
       for (int m = 0; m < MT; ++m) {
         const float4 ov = cv ? *reinterpret_cast<const float4*>(ow + ((size_t)(4 * m + g) * N + tok) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 xv = cv ? *reinterpret_cast<const float4*>(xw + (size_t)tok * C + 16 * m + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
-        ob[m] = split4s(f32x4{ov.x, ov.y, ov.z, ov.w});
+        ob[m] = split4s(f32x4{ov.x, ov.y, ov.z, ov.w} * so);
         xin[m] = f32x4{xv.x, xv.y, xv.z, xv.w} + vec4(bp, m);
         acc[m] = zero4; accx[m] = zero4;
       }
@@ -412,7 +417,7 @@ __global__ __launch_bounds__(256, RAL_MLPW_WPE) void k_mlp_fwd_wh(const float* _
           if (le) a = (ht == 0 && q == 0 && g == 0) ? c0 : gelu_f(a);
           h[q] = a;
         }
-        const H2x4 hh = split4s(h);
+        const H2x4 hh = split4s(h * sh);
 #pragma unroll
         for (int mo = 0; mo < MT; ++mo) mma_h(W2H, PW2, LDB, mo, ht, hh, out[mo], outx[mo]);
       }
