@@ -42,7 +42,7 @@ static const char* const KNOB_NAMES[] = {
   "DANET_GRID_B", "DANET_GRID_D", "DANET_GRID_F", "DANET_GRID_W", "DIAG_SKIP_WIDE_DW", "DW_F16", "DW_KSPLIT_128", "DW_KSPLIT_16",
   "DW_KSPLIT_32", "DW_KSPLIT_64", "DW_KSPLIT_8", "DW_LDS", "DW_PRIO", "DW_SETS", "F16_SPLIT", "FUSE_DW", "GRID_ATTNB", 
   "GRID_ATTNW", "GRID_FWD", "GRID_MLPB", "GRID_MLPBW", "GRID_MLPS", "GRID_MLPW", "GRID_QKVB", "GRID_QKVW", "GRID_RESB", "LOSS_GRID",
-  "MLP_BWD_W", "MLP_BWD_W_F16", "MLP_F16", "MLP_FWD_W", "MLP_HLDS", "MLP_HTHREADS", "MLP_LDS", "MLP_TOK", "PREP_OVERLAP", "QKVB_F16", "QKV_WS", "UNET_BWD_GRID",
+  "MLP_BWD_W", "MLP_BWD_W_F16", "MLP_F16", "MLP_FWD_W", "MLP_HLDS", "MLP_HTHREADS", "MLP_LDS", "MLP_TOK", "PREP_OVERLAP", "QKVB_F16", "QKVB_FDW", "QKV_WS", "UNET_BWD_GRID",
   "UNET_BWD_WP", "UNET_DEBUG", "UNET_EVAL_GRID", "UNET_FOLD", "UNET_FUSED", "UNET_FWD_GRID", "UNET_NREP", "UNET_WG_PER_CU"};
 static std::mutex g_knob_mu;
 static std::map<std::string, long long>& knob_table() { static std::map<std::string, long long> t; return t; }
@@ -113,7 +113,7 @@ extern "C" int ral_global_option(const char* key, long long value) {
   if (value < 0) return fail("switch %s: negative value %lld", key, value);
   for (const char* n : KNOB_MIN1)
     if (k == n && value < 1) return fail("switch %s: value %lld out of range (a grid / thread / split count: >= 1)", key, value);
-  if (k == "MLP_HTHREADS" && value != 256 && value != 512) return fail("switch %s: 256 or 512 threads (got %lld)", key, value);
+  if (k == "MLP_HTHREADS" && value != 512 && value != 1024) return fail("switch %s: 512 or 1024 threads (got %lld)", key, value);
   std::lock_guard<std::mutex> lk(g_knob_mu);
   // most consumers read a switch once and keep it: a change after that first read would be ignored silently, so it is refused
   // (the same value again is fine: tests and tools set their switches at start-up, possibly more than once)
@@ -288,7 +288,10 @@ static int check_cfg(const ral_config* c) {
   if (c->variant == RAL_DANET) return danet_check_cfg(c, g_err, sizeof(g_err));
   if (c->variant < 0 || c->variant > RAL_DANET) return fail("unknown variant %d", c->variant);
   if (c->leads != 1 && c->leads != 2) return fail("leads must be 1 or 2 (got %d); use the 12-lead adapter above it", c->leads);
-  if (c->L <= 0 || c->L % 256 != 0 || c->L > 1024) return fail("L must be a multiple of 256 and <= 1024 (got %d)", c->L);
+  // the reference's own constraint (raletransformer.py:170,448-450): four PatchMerging halvings -> a multiple of 16 (its positional
+  // table ends at 1000; 1024 is accepted here).  The R-wave variants also need their (32, 16, 8, 4)-token windows to fit.
+  if (c->L <= 0 || c->L % 16 != 0 || c->L > 1024) return fail("L must be a multiple of 16 and <= 1024 (got %d)", c->L);
+  if (c->variant != RAL_NRA && c->L < 32) return fail("L must be at least 32 for the R-wave variants (got %d)", c->L);
   if (c->max_batch <= 0) return fail("max_batch must be positive");
   return 0;
 }
@@ -328,7 +331,9 @@ static int dw_sets() {
 struct RalModel {
   ral_config cfg;
   Layout lay;
-  int L, E1;  // E1 = 8*L floats per window per stage tensor
+  int L, Lp, E1;  // L: samples per window; Lp: token slots per window at level 0 = L rounded up to a multiple of 256 (every level then
+                  // has a multiple of 16 slots; the slots past L >> level do not exist for the model: masked keys, zero conv halos, no
+                  // gradient); E1 = 8 * Lp floats per window per stage tensor
   char* slab = nullptr;
   size_t slab_bytes = 0;
   std::map<std::string, std::pair<float*, int64_t>> dbg;
@@ -426,7 +431,8 @@ struct ral_handle {
 
 static size_t plan_workspace(const ral_config& c, RalModel* m /* may be null: size only */, char* base) {
   size_t cur = 0;
-  const size_t B = c.max_batch, E = (size_t)8 * c.L * B;
+  const int Lp = (c.L + 255) / 256 * 256;      // token slots per window (RalModel::Lp)
+  const size_t B = c.max_batch, E = (size_t)8 * Lp * B;
   auto take = [&](const char* name, size_t nfloat) -> float* {
     float* p = base ? reinterpret_cast<float*>(base + cur) : nullptr;
     if (m && base) m->dbg[name] = {p, (int64_t)nfloat};
@@ -435,7 +441,7 @@ static size_t plan_workspace(const ral_config& c, RalModel* m /* may be null: si
   };
   RalModel tmp_;
   RalModel& M = m ? *m : tmp_;
-  for (int l = 0; l < 5; ++l) M.pe[l] = take(("pe" + std::to_string(l)).c_str(), (size_t)(c.L >> l) * CH[l]);
+  for (int l = 0; l < 5; ++l) M.pe[l] = take(("pe" + std::to_string(l)).c_str(), (size_t)(Lp >> l) * CH[l]);
   M.a0 = take("a0", E); M.x0 = take("x0", E); M.ss = take("bn_ss", 64);
   const bool tr = c.train != 0;
   float *sh_qkv = nullptr, *sh_o = nullptr;
@@ -449,7 +455,7 @@ static size_t plan_workspace(const ral_config& c, RalModel* m /* may be null: si
     a.x1 = tr ? take((p + "x1").c_str(), E) : nullptr;
     // u_pre is kept only where the backward reads it: the narrow levels re-compute it (k_mlp_bwd_s)
     const int lvl = STAGES[b / 2].level;
-    a.upre = (tr && !mlp_bwd_is_fused(CH[lvl], c.L >> lvl)) ? take((p + "upre").c_str(), 4 * E) : nullptr;
+    a.upre = (tr && !mlp_bwd_is_fused(CH[lvl], Lp >> lvl)) ? take((p + "upre").c_str(), 4 * E) : nullptr;
     a.out = take((p + "out").c_str(), E);
   }
   { Layout L_; build_layout(c, L_); M.wh = reinterpret_cast<unsigned short*>(take("wh", (size_t)L_.nparam)); }
@@ -507,7 +513,7 @@ static void choose_tiling(RalModel* m) {
   }
   set_dw_lds_budget(env_size("RAL_DW_LDS", 76 * 1024));
   for (int l = 0; l < 5; ++l) {
-    const int C = CH[l], N = m->L >> l, H = C / 4;
+    const int C = CH[l], N = m->Lp >> l, H = C / 4;
     int n = 1;
     while (n < 4 && mlp_fwd_lds(C, N, n) > budget) n *= 2;
     m->nch_f[l] = n;
@@ -556,7 +562,7 @@ template <class T> static inline T* woff(T* p, int w0, size_t per_window) { retu
 // forward
 // ---------------------------------------------------------------------------------
 static void run_block_fwd(RalModel* m, int bi, const float* in, bool training, const Lane& ln) {
-  const int si = bi / 2, l = STAGES[si].level, C = CH[l], N = m->L >> l, H = C / 4;
+  const int si = bi / 2, l = STAGES[si].level, C = CH[l], N = m->Lp >> l, H = C / 4;
   const size_t E1 = m->E1;
   BlockP w = block_ptrs(m->lay.blk[bi], m->params);
   w.asc = m->f16_split > 0 ? m->ascale + ASC_N * bi : nullptr;
@@ -575,13 +581,14 @@ static void run_block_fwd(RalModel* m, int bi, const float* in, bool training, c
   float* qkv = woff(a.qkv, w0, 3 * E1);
   float* o = woff(a.o, w0, E1);
   { ProfScope p(m, K_QKV_FWD, s); launch_qkv_fwd(C, x, m->pe[l], w, split ? m->wh + 2 * m->lay.blk[bi].wqkv : nullptr, qkv, N, B, s); }
+  const int NE = m->L >> l;   // existing tokens of the N slots (NE < N: a window length that is not a multiple of 256)
   { ProfScope p(m, K_ATTN_FWD, s);
     launch_attn_fwd(qkv, o, training ? woff(a.lse, w0, E1 / 4) : nullptr, table, N, H, m->hg_f[l], Len, B,
-                    (m->f16_split > 0 && m->attn_f16) ? 1 : 0, s); }
+                    (m->f16_split > 0 && m->attn_f16) ? 1 : 0, s, NE); }
   { ProfScope p(m, K_MLP_FWD, s);
     launch_mlp_fwd(C, m->nch_f[l], x, o, w, m->params, split ? m->wh : nullptr, training ? woff(a.x1, w0, E1) : nullptr,
                    (training && !mlp_bwd_is_fused(C, N)) ? woff(a.upre, w0, 4 * E1) : nullptr,
-                   woff(a.out, w0, E1), N, B, (m->f16_split > 0 && m->narrow_f16) ? 1 : 0, s); }
+                   woff(a.out, w0, E1), N, B, (m->f16_split > 0 && m->narrow_f16) ? 1 : 0, s, NE); }
 }
 
 static const float* run_stage_fwd(RalModel* m, int si, const float* in, bool training, const Lane& ln) {
@@ -592,10 +599,10 @@ static const float* run_stage_fwd(RalModel* m, int si, const float* in, bool tra
 
 static void run_res_fwd(RalModel* m, int ri, const float* in, const float* skip, const Lane& ln) {
   const ResOff& r = m->lay.res[ri];
-  const int T = m->E1 / r.D;  // output tokens per window
+  const int T = m->E1 / r.D, Tv = 8 * m->L / r.D;  // output token slots per window, and how many of them exist
   ProfScope p(m, K_RES_FWD, ln.s);
   launch_resample_fwd(r.D, ri >= 4, woff(in, ln.w0, m->E1), m->params + r.w, m->params + r.lnw, m->params + r.lnb,
-                      woff(skip, ln.w0, m->E1), woff(m->res_out[ri], ln.w0, m->E1), T, ln.B, ln.s);
+                      woff(skip, ln.w0, m->E1), woff(m->res_out[ri], ln.w0, m->E1), T, Tv, ln.B, ln.s);
 }
 
 // split [0, B) over the lanes; lane 0 runs on the caller's stream
@@ -659,10 +666,10 @@ static int fwd_begin(RalModel* m, const float* x, int B, int training, hipStream
   if (training) {
     HIP_OK(hipMemsetAsync(m->bn_sums, 0, 64 * sizeof(double), s));
     launch_conv1_fwd(m->cfg.leads, 0, x, m->params + Y.conv1_w, m->params + Y.conv1_b, m->a0, m->bn_sums, nullptr,
-                     nullptr, nullptr, nullptr, m->L, B, s);
+                     nullptr, nullptr, nullptr, m->L, m->Lp, B, s);
   } else {
     launch_conv1_fwd(m->cfg.leads, 1, x, m->params + Y.conv1_w, m->params + Y.conv1_b, m->x0, nullptr,
-                     m->params + Y.bn_w, m->params + Y.bn_b, m->state, m->state + 8, m->L, B, s);
+                     m->params + Y.bn_w, m->params + Y.bn_b, m->state, m->state + 8, m->L, m->Lp, B, s);
   }
   return 0;
 }
@@ -673,7 +680,7 @@ static int fwd_end(RalModel* m, float* y, int B, int64_t global_windows, int tra
   if (training) {
     launch_bn_finalize(m->bn_sums, (double)global_windows * m->L, m->params + Y.bn_w, m->params + Y.bn_b, m->ss,
                        m->state, m->state + 8, 8, 1, s);
-    launch_bn_apply8(m->a0, m->ss, m->x0, (size_t)B * m->L, s);
+    launch_bn_apply8(m->a0, m->ss, m->x0, (size_t)B * m->Lp, s);
   }
   const bool tr = training != 0;
   if (m->prep_fwd) { HIP_OK(hipStreamWaitEvent(s, m->ev_prep_fwd, 0)); m->prep_fwd = false; }   // split planes of the wide levels' weights: formed under the stem
@@ -706,7 +713,7 @@ static int fwd_end(RalModel* m, float* y, int B, int64_t global_windows, int tra
   for (int k = 0; k < nl; ++k) {
     const Lane& ln = LS->l[k];
     launch_final_fwd(m->cfg.leads, woff(cur, ln.w0, m->E1), woff(m->x0, ln.w0, m->E1), m->params + Y.tc_w, m->params + Y.tc_b,
-                     woff(y, ln.w0, (size_t)m->cfg.leads * m->L), m->L, ln.B, ln.s);
+                     woff(y, ln.w0, (size_t)m->cfg.leads * m->L), m->L, m->Lp, ln.B, ln.s);
   }
   join_lanes(m, s);
   HIP_OK(hipGetLastError());
@@ -718,7 +725,7 @@ static int fwd_end(RalModel* m, float* y, int B, int64_t global_windows, int tra
 // ---------------------------------------------------------------------------------
 // one block: dy (grad of block output) -> dx (grad of block input) [+ extra]; all pointers are window-0 bases
 static void run_block_bwd(RalModel* m, int bi, const float* dy, const float* extra, float* dx, Lane& ln) {
-  const int si = bi / 2, l = STAGES[si].level, C = CH[l], N = m->L >> l, H = C / 4;
+  const int si = bi / 2, l = STAGES[si].level, C = CH[l], N = m->Lp >> l, H = C / 4;
   const size_t E1 = m->E1;
   BlockP w = block_ptrs(m->lay.blk[bi], m->params);
   w.asc = m->f16_split > 0 ? m->ascale + ASC_N * bi : nullptr;
@@ -741,7 +748,7 @@ static void run_block_bwd(RalModel* m, int bi, const float* dy, const float* ext
   if (side && ln.dw_pending[k]) EV(hipStreamWaitEvent(s, ln.ev_done[k], 0));   // set k free again?
   const float* dyw = woff(dy, w0, E1);
   float *dupre = woff(m->dupre[k], w0, 4 * E1), *dx1 = woff(m->dx1[k], w0, E1), *dohm = woff(m->dohm[k], w0, E1),
-        *dqkv = woff(m->dqkv[k], w0, 3 * E1), *a2c0 = woff(m->a2c0[k], w0, m->L);   // (per-window stride L at every level: the lanes run different levels concurrently)
+        *dqkv = woff(m->dqkv[k], w0, 3 * E1), *a2c0 = woff(m->a2c0[k], w0, m->Lp);   // (per-window stride L at every level: the lanes run different levels concurrently)
   const float *x1 = woff(a.x1, w0, E1), *upre = woff(a.upre, w0, 4 * E1), *qkv = woff(a.qkv, w0, 3 * E1),
               *o = woff(a.o, w0, E1), *lse = woff(a.lse, w0, E1 / 4), *xin = woff(a.in, w0, E1);
   bool fused_mlp_dw;
@@ -749,15 +756,17 @@ static void run_block_bwd(RalModel* m, int bi, const float* dy, const float* ext
   // maxima of this block's gradient tensors (this lane's windows), for the split weight-gradient products: only when both
   // split data-gradient kernels take the shape (they publish them)
   unsigned* gmax = (splitb && m->want_dw && !mlp_bwd_is_fused(C, N) && mlp_bwd_h_nch(C, N) && qkv_bwd_uses_f16(C, N)) ? m->gmax + ((size_t)bi * 4 + (&ln - lanes_of(m)->l)) * 4 : nullptr;
+  const int NE = m->L >> l;
   { ProfScope p(m, K_MLP_BWD, s); fused_mlp_dw = launch_mlp_bwd(C, m->nch_b[l], dyw, x1, upre, w, wt, m->paramsT, splitb ? m->whT : nullptr, gmax, g, dupre, dx1, dohm, a2c0, N, B, m->want_dw, s,
-                                                                  (m->f16_split > 0 && m->narrow_f16) ? 1 : 0); }
+                                                                  (m->f16_split > 0 && m->narrow_f16) ? 1 : 0, NE); }
   { ProfScope p(m, K_ATTN_BWD, s);
     // (each lane's scratch: its share of the stat2 region followed by its share of the partials region)
     float* scratch = m->astat[k] + (size_t)w0 * (E1 / 2 + 2048);
     launch_attn_bwd(qkv, o, dohm, lse, table, gtable, dqkv, scratch, (size_t)B * (E1 / 2 + 2048), N, H, m->hg_b[l], Len, B,
-                    (m->f16_split > 0 && m->attn_f16) ? 1 : 0, s); }
+                    (m->f16_split > 0 && m->attn_f16) ? 1 : 0, s, NE); }
+  bool fused_qkv_dw;
   { ProfScope p(m, K_QKV_BWD, s);
-    launch_qkv_bwd(C, dqkv, xin, m->pe[l], dx1, woff(extra, w0, E1), w, wt, m->paramsT, splitb ? m->whT : nullptr, gmax, g, woff(dx, w0, E1), N, B, s); }
+    fused_qkv_dw = launch_qkv_bwd(C, dqkv, xin, m->pe[l], dx1, woff(extra, w0, E1), w, wt, m->paramsT, splitb ? m->whT : nullptr, gmax, g, woff(dx, w0, E1), N, B, m->want_dw, s); }
   if (!m->want_dw) return;
   if (side) {
     EV(hipEventRecord(ln.ev_ready[k], s));
@@ -768,7 +777,7 @@ static void run_block_bwd(RalModel* m, int bi, const float* dy, const float* ext
     static const int skipw = (int)ral_knob("DIAG_SKIP_WIDE_DW", 0);
     if (!(skipw && C >= skipw))
 #endif
-    launch_block_dw(C, dyw, upre, w.le ? a2c0 : nullptr, dupre, x1, dx1, o, dqkv, xin, m->pe[l], w, g, N, B, m->dw_ksplit[l], fused_mlp_dw, gmax, sd); }
+    launch_block_dw(C, dyw, upre, w.le ? a2c0 : nullptr, dupre, x1, dx1, o, dqkv, xin, m->pe[l], w, g, N, B, m->dw_ksplit[l], fused_mlp_dw, gmax, sd, fused_qkv_dw); }
   if (side) { EV(hipEventRecord(ln.ev_done[k], sd)); ln.dw_pending[k] = true; }
 }
 
@@ -780,12 +789,12 @@ static void run_stage_bwd(RalModel* m, int si, const float* dy, const float* ext
 
 static void run_res_bwd(RalModel* m, int ri, const float* dy, const float* in, float* dx, Lane& ln) {
   const ResOff& r = m->lay.res[ri];
-  const int T = m->E1 / r.D;
+  const int T = m->E1 / r.D, Tv = 8 * m->L / r.D;
   const size_t E1 = m->E1;
   hipStream_t s = ln.s;
   { ProfScope p(m, K_RES_BWD, s);
     launch_resample_bwd(r.D, ri >= 4, woff(dy, ln.w0, E1), woff(in, ln.w0, E1), m->paramsT + r.w, m->params + r.lnw,
-                        m->grads + r.lnw, m->grads + r.lnb, woff(dx, ln.w0, E1), T, ln.B, s); }
+                        m->grads + r.lnw, m->grads + r.lnb, woff(dx, ln.w0, E1), T, Tv, ln.B, s); }
   if (!m->want_dw) return;
   int lvl = 0;
   while ((8 << lvl) < r.D) ++lvl;
@@ -796,7 +805,7 @@ static void run_res_bwd(RalModel* m, int ri, const float* dy, const float* in, f
     sd = ln.s2;
   }
   launch_resample_dw(r.D, ri >= 4, woff(dy, ln.w0, E1), woff(in, ln.w0, E1), m->params + r.lnw, m->params + r.lnb,
-                     m->grads + r.w, T, ln.B, m->dw_ksplit[lvl], sd);
+                     m->grads + r.w, T, Tv, ln.B, m->dw_ksplit[lvl], sd);
 }
 
 static int bwd_begin(RalModel* m, const float* dy, int B, hipStream_t s) {
@@ -825,7 +834,7 @@ static int bwd_begin(RalModel* m, const float* dy, int B, hipStream_t s) {
   for (int k = 0; k < nl; ++k) {
     const Lane& ln = LS->l[k];
     launch_final_bwd(m->cfg.leads, woff(dy, ln.w0, (size_t)m->cfg.leads * m->L), woff(m->res_out[7], ln.w0, m->E1), woff(m->x0, ln.w0, m->E1),
-                     m->params + Y.tc_w, m->grads + Y.tc_w, m->grads + Y.tc_b, woff(m->du0, ln.w0, m->E1), m->L, ln.B, ln.s);
+                     m->params + Y.tc_w, m->grads + Y.tc_w, m->grads + Y.tc_b, woff(m->du0, ln.w0, m->E1), m->L, m->Lp, ln.B, ln.s);
   }
   const bool side = m->side_stream && m->want_dw;
   if (side)   // side streams start after the gradient buffer has been zeroed
@@ -864,7 +873,7 @@ static int bwd_begin(RalModel* m, const float* dy, int B, hipStream_t s) {
       EV(hipStreamWaitEvent(LS->l[k].s, LS->l[k].ev_join, 0));
     }
   join_lanes(m, s);
-  launch_bn8_bwd_stats(gin[0], m->a0, m->ss, m->bn_sums + 32, (size_t)B * m->L, s);
+  launch_bn8_bwd_stats(gin[0], m->a0, m->ss, m->bn_sums + 32, (size_t)B * m->Lp, s);
   HIP_OK(hipGetLastError());
   return sched_check();
 }
@@ -874,9 +883,9 @@ static int bwd_end(RalModel* m, float* dx, int B, int64_t global_windows, hipStr
   const Layout& Y = m->lay;
   launch_conv1_bwd(m->cfg.leads, m->gin[0], m->a0, m->last_x, m->ss, m->params + Y.bn_w, m->bn_sums + 32,
                    (double)global_windows * m->L, m->grads + Y.conv1_w, m->grads + Y.conv1_b, dx ? m->dz0 : nullptr,
-                   m->L, B, s);
+                   m->L, m->Lp, B, s);
   launch_bn_affine_grads(m->bn_sums + 32, m->grads + Y.bn_w, m->grads + Y.bn_b, 8, (double)B / (double)global_windows, s);
-  if (dx) launch_conv1_bwd_dx(m->cfg.leads, m->dz0, m->params + Y.conv1_w, dx, m->L, B, s);
+  if (dx) launch_conv1_bwd_dx(m->cfg.leads, m->dz0, m->params + Y.conv1_w, dx, m->L, m->Lp, B, s);
   HIP_OK(hipEventRecord(m->ev_bwd_done, s));
   m->bwd_recorded = true;
   HIP_OK(hipGetLastError());
@@ -1017,7 +1026,8 @@ int ral_create(const ral_config* cfg, ral_handle** out) {
   RalModel* m = new RalModel();
   m->cfg = *cfg;
   m->L = cfg->L;
-  m->E1 = 8 * cfg->L;
+  m->Lp = (cfg->L + 255) / 256 * 256;
+  m->E1 = 8 * m->Lp;
   build_layout(*cfg, m->lay);
   m->slab_bytes = plan_workspace(*cfg, nullptr, nullptr);
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&m->slab), m->slab_bytes);
@@ -1068,7 +1078,7 @@ int ral_create(const ral_config* cfg, ral_handle** out) {
     }
   }
   for (int l = 0; l < 5; ++l) {
-    const int n = cfg->L >> l, C = CH[l];
+    const int n = m->Lp >> l, C = CH[l];
     std::vector<float> P((size_t)n * C);
     fill_pe(P.data(), n, C);
     e = hipMemcpy(m->pe[l], P.data(), P.size() * sizeof(float), hipMemcpyHostToDevice);
@@ -1090,6 +1100,7 @@ int ral_create(const ral_config* cfg, ral_handle** out) {
     if (e != hipSuccess) { fail("hipMemcpy(adesc) failed: %s", hipGetErrorString(e)); destroy_model(m); delete h; return -1; }
   }
   m->f16_split = (int)ral_knob("F16_SPLIT", m->f16_split);   // (a process-wide default for tests: ral_global_option; never the environment)
+  if (m->L != m->Lp) m->f16_split = 0;   // padded windows run on the generic fp32-MFMA kernels (the ones that know where a window ends)
   m->attn_f16 = attn_f16_default() != 0;
   if (cfg->train) {
     m->side_stream = ral_env_int("RAL_NO_SIDE_STREAM", 0, 0, 1) == 0;   // ... and the other
@@ -1378,7 +1389,10 @@ int ral_set_option(ral_handle* h, const char* key, int value) {
   m->prep_stale = true;   // (weight planes queued by a forward were formed for the options of that moment)
   if (!strcmp(key, "lanes")) { m->n_lanes = value < 1 ? 1 : (value > MAX_LANES ? MAX_LANES : value); return 0; }
   if (!strcmp(key, "side_stream")) { m->side_stream = value != 0; return 0; }
-  if (!strcmp(key, "f16_split")) { m->f16_split = value; return 0; }
+  if (!strcmp(key, "f16_split")) {
+    if (value > 0 && m->L != m->Lp) return fail("f16_split > 0 needs a window length that is a multiple of 256 (L = %d runs on padded windows, fp32 MFMA)", m->L);
+    m->f16_split = value; return 0;
+  }
   if (!strcmp(key, "attn_f16")) { m->attn_f16 = value != 0; return 0; }
   if (!strcmp(key, "narrow_f16")) { m->narrow_f16 = value != 0; return 0; }
   return fail("unknown option %s", key);

@@ -31,7 +31,8 @@ template <int C, int NCH>
 __global__ __launch_bounds__(512) void k_mlp_bwd(const float* __restrict__ dx2, const float* __restrict__ x1,
                                                  const float* __restrict__ upre, BlockP w, BlockP wt, BlockP gr,
                                                  float* __restrict__ dupre, float* __restrict__ dx1,
-                                                 float* __restrict__ do_hm, float* __restrict__ a2c0, int N, int B) {
+                                                 float* __restrict__ do_hm, float* __restrict__ a2c0, int N, int B,
+                                                 int NE /* existing tokens of the N slots (padded windows: < N; the others carry dx2 = 0) */) {
   extern __shared__ float4 smem4[];
   constexpr int LD = LDof<C>::v, HC = 4 * C / NCH, LDU = LDof<HC>::v, LPR = C / 4;
   float* Ds = reinterpret_cast<float*>(smem4);  // N x LD : dx2 -> dx1
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(512) void k_mlp_bwd(const float* __restrict__ dx2, 
         for (int i = threadIdx.x; i < N + 2; i += blockDim.x) {
           const bool halo = (i == 0 || i == N + 1);
           const float u = halo ? 0.f : Us[(i - 1) * LDU];
-          A0[i] = halo ? 0.f : gelu_f(u);
+          A0[i] = (halo || i > NE) ? 0.f : gelu_f(u);            // (a slot past NE does not exist for the conv: zero, like the halo)
           DC0[i] = 0.f;
           if (!halo) U0[i - 1] = u;
         }
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(512) void k_mlp_bwd(const float* __restrict__ dx2, 
       if (le && ch == 0) {
         for (int n = threadIdx.x; n < N; n += blockDim.x) {
           const float da1 = lw0 * DC0[n + 2] + lw1 * DC0[n + 1] + lw2 * DC0[n];
-          Us[n * LDU] = da1 * gelu_grad_f(U0[n]);
+          Us[n * LDU] = n < NE ? da1 * gelu_grad_f(U0[n]) : 0.f;   // (... and takes no gradient)
           const float dc = DC0[n + 1];
           gle0 += dc * A0[n]; gle1 += dc * A0[n + 1]; gle2 += dc * A0[n + 2];
         }
@@ -426,7 +427,7 @@ template <int C, int TW>
 __global__ __launch_bounds__(512, 4) void k_mlp_bwd_s(const float* __restrict__ dx2, const float* __restrict__ x1,
                                                       BlockP w, BlockP wt, BlockP gr,
                                                       float* __restrict__ dx1, float* __restrict__ do_hm, int N, int B,
-                                                      int want_dw) {
+                                                      int want_dw, int NE /* existing tokens of the N slots (padded windows: < N) */) {
   extern __shared__ float4 smem4[];
   constexpr int LD = LDof<C>::v, HC = C, NCH = 4, LPR = C / 4;
   // Xl and As are only read as B operands of the dW jobs (4-byte reads): at C = 16 they go unpadded so that two
@@ -495,7 +496,7 @@ __global__ __launch_bounds__(512, 4) void k_mlp_bwd_s(const float* __restrict__ 
         for (int i = threadIdx.x; i < N + 2; i += blockDim.x) {
           const bool halo = (i == 0 || i == N + 1);
           const float u = halo ? 0.f : Us[(i - 1) * LD];
-          A0[i] = halo ? 0.f : gelu_f(u);
+          A0[i] = (halo || i > NE) ? 0.f : gelu_f(u);
           DC0[i] = 0.f;
           if (!halo) U0[i - 1] = u;
         }
@@ -533,7 +534,7 @@ __global__ __launch_bounds__(512, 4) void k_mlp_bwd_s(const float* __restrict__ 
       if (le && ch == 0) {
         for (int n = threadIdx.x; n < N; n += blockDim.x) {
           const float da1 = lw0 * DC0[n + 2] + lw1 * DC0[n + 1] + lw2 * DC0[n];
-          Us[n * LD] = da1 * gelu_grad_f(U0[n]);
+          Us[n * LD] = n < NE ? da1 * gelu_grad_f(U0[n]) : 0.f;
           As[n * LDB] = gelu_f(C0[n]);
           const float dc = DC0[n + 1];
           gle0 += dc * A0[n]; gle1 += dc * A0[n + 1]; gle2 += dc * A0[n + 2];
@@ -694,13 +695,16 @@ RAL_DEV f32x2 splat2(float v) { return f32x2{v, v}; }
 #ifndef RAL_ATTNB_WPE
 #define RAL_ATTNB_WPE 4   // waves per SIMD the register budget is sized for (3 = 168 registers, no spills: N = 128 257 vs 250 us, equal elsewhere)
 #endif
-template <int QT, int NT = 0, bool TAB = true>
+// RAG: only the first NE of the N token slots exist (see k_attn_fwd): keys past NE are masked (p = 0: no dS, dK, dV), the
+// padding queries carry dO = 0 and add nothing; both sweeps stop at the last tile that holds an existing token
+template <int QT, int NT = 0, bool TAB = true, bool RAG = false>
 __global__ __launch_bounds__(512, RAL_ATTNB_WPE) void k_attn_bwd(const float* __restrict__ qkv, const float* __restrict__ o_hm,
                                                   const float* __restrict__ do_hm, const float* __restrict__ lse,
                                                   const float* __restrict__ table, float* __restrict__ gtable,
-                                                  float* __restrict__ dqkv, int N_rt, int H, int HG, int Len, int B) {
+                                                  float* __restrict__ dqkv, int N_rt, int H, int HG, int Len, int B, int NE_rt = 0) {
   extern __shared__ float4 smem4[];
   const int N = NT ? NT : N_rt;
+  const int NE = RAG ? NE_rt : N, NEt = RAG ? ((NE + 15) & ~15) : N;
   if constexpr (!TAB) { table = nullptr; Len = 0; }
   float* Qs = reinterpret_cast<float*>(smem4);  // q * log2(e)
   float* Ks = Qs + HG * N * 4;
@@ -714,8 +718,8 @@ __global__ __launch_bounds__(512, RAL_ATTNB_WPE) void k_attn_bwd(const float* __
   const int ngrp = H / HG;
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
   const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  const int off = (N - Len) >> 1;
-  const int kb0 = table ? (off & ~15) : N, kb1 = table ? ((off + Len + 15) & ~15) : N;
+  const int off = (NE - Len) >> 1;
+  const int kb0 = table ? (off & ~15) : NEt, kb1 = table ? ((off + Len + 15) & ~15) : NEt;
   for (int i = threadIdx.x; i < ntab; i += blockDim.x) dtab[i] = 0.f;
 #ifdef RAL_STAMP
   constexpr int C = -1;   // (stamp conditions name the channel width)
@@ -791,6 +795,12 @@ __global__ __launch_bounds__(512, RAL_ATTNB_WPE) void k_attn_bwd(const float* __
         for (int qt = 0; qt < QT; ++qt) {
           f32x4 s = mfma4(kf, qf[qt], f32x4{lq[qt], lq[qt], lq[qt], lq[qt]});          // s - lse
           const f32x4 dp = mfma4(vf, df[qt], f32x4{dl[qt], dl[qt], dl[qt], dl[qt]});   // dP - delta
+          if constexpr (RAG) {
+            if (kt + 16 > NE) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) s[j] = (kt + 4 * g + j < NE) ? s[j] : -INFINITY;
+            }
+          }
           const int qi = q0 + 16 * qt + r - off;
           if constexpr (decltype(biased)::value) {
 #pragma unroll
@@ -817,7 +827,7 @@ __global__ __launch_bounds__(512, RAL_ATTNB_WPE) void k_attn_bwd(const float* __
         }
       };
       const bool qbias = table && (q0 < off + Len) && (q0 + 16 * QT > off);
-      const int e0 = qbias ? kb0 : N, e1 = qbias ? kb1 : N;
+      const int e0 = qbias ? kb0 : NEt, e1 = qbias ? kb1 : NEt;
       if constexpr (NT > 0 && NT <= 64) {   // compile-time trip count: unrolled, the table variant chosen per tile (wave-uniform)
 #pragma unroll
         for (int kt = 0; kt < NT; kt += 16) {
@@ -827,7 +837,7 @@ __global__ __launch_bounds__(512, RAL_ATTNB_WPE) void k_attn_bwd(const float* __
       } else {
         for (int kt = 0; kt < e0; kt += 16) tileA(kt, std::false_type{});
         for (int kt = e0; kt < e1; kt += 16) tileA(kt, std::true_type{});
-        for (int kt = e1; kt < N; kt += 16) tileA(kt, std::false_type{});
+        for (int kt = e1; kt < NEt; kt += 16) tileA(kt, std::false_type{});
       }
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {
@@ -864,6 +874,9 @@ __global__ __launch_bounds__(512, RAL_ATTNB_WPE) void k_attn_bwd(const float* __
         for (int t = 0; t < QT; ++t) {
           f32x4 s = mfma4(qa, kf[t], f32x4{l4.x, l4.y, l4.z, l4.w});        // S[query 4g+j][key r] - lse
           const f32x4 dp = mfma4(da, vf[t], f32x4{d4.x, d4.y, d4.z, d4.w});  // dP[query][key] - delta
+          if constexpr (RAG) {
+            if (k0 + 16 * t + r >= NE) s = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};   // this lane's key does not exist
+          }
           if constexpr (decltype(biased)::value) {
             const int ki = k0 + 16 * t + r - off;
 #pragma unroll
@@ -884,7 +897,7 @@ __global__ __launch_bounds__(512, RAL_ATTNB_WPE) void k_attn_bwd(const float* __
         }
       };
       const bool kbias = table && (k0 < off + Len) && (k0 + 16 * QT > off);
-      const int e0 = kbias ? kb0 : N, e1 = kbias ? kb1 : N;
+      const int e0 = kbias ? kb0 : NEt, e1 = kbias ? kb1 : NEt;
       if constexpr (NT > 0 && NT <= 64) {
 #pragma unroll
         for (int qt = 0; qt < NT; qt += 16) {
@@ -894,7 +907,7 @@ __global__ __launch_bounds__(512, RAL_ATTNB_WPE) void k_attn_bwd(const float* __
       } else {
         for (int qt = 0; qt < e0; qt += 16) tileB(qt, std::false_type{});
         for (int qt = e0; qt < e1; qt += 16) tileB(qt, std::true_type{});
-        for (int qt = e1; qt < N; qt += 16) tileB(qt, std::false_type{});
+        for (int qt = e1; qt < NEt; qt += 16) tileB(qt, std::false_type{});   // (padding queries: dO = 0, nothing to add)
       }
 #pragma unroll
       for (int t = 0; t < QT; ++t) {
@@ -1102,7 +1115,20 @@ __global__ __launch_bounds__(256) void k_attn_bwd_vkv(const float* __restrict__ 
 // B1: QKV projection + LN1 backward:  dh = dqkv Wqkv;  dx = dx1 + sqrt(C) * LN1bwd(dh)
 //   grads: bqkv, ln1 w/b.   `extra` (optional) is added to dx (skip-connection gradient).
 // =================================================================================
-template <int C>
+// FDW (narrow levels, C <= 32): the weight gradient of the projection, dWqkv[m][c] = sum_t dqkv[t][m] LN1(x)[t][c], and its bias
+// gradient are formed HERE - both operands pass through this kernel anyway (dqkv sits in the LDS, the LayerNorm output is one
+// FMA away from the row the LayerNorm backward holds), so the separate token-contraction launch of ral_dw.hip, which read dqkv
+// (3E) and x (E) again from HBM and re-computed the LayerNorm, disappears for these blocks.  Every wave owns NJ (tile, token
+// range) jobs for the whole kernel - fp32 MFMA tiles with the token as the contraction index, accumulators in registers over
+// all the windows of the (persistent) workgroup -; the partials of the token ranges meet in the LDS at the end and leave as
+// one pass of coalesced atomics.
+template <int C> struct QkvDwShape {
+  static constexpr int TM = (3 * C + 15) / 16, TN = (C + 15) / 16, TILES = TM * TN;
+  static constexpr int KS = C == 32 ? 2 : (C == 16 ? 8 : 4);        // token ranges per tile
+  static constexpr int NJ = TILES * KS / 8;                          // jobs per wave (8 waves)
+  static_assert(TILES * KS % 8 == 0, "whole jobs per wave");
+};
+template <int C, bool FDW = false>
 // (dqkv, x, dx1 and extra are deliberately NOT __restrict__: see k_dw - loads the compiler can prove invariant are sunk
 // across the compiler barrier of the prefetch, next to their uses, which puts the HBM round trip back in front of them)
 #ifndef RAL_QKVB_MINB
@@ -1116,13 +1142,21 @@ __global__ __launch_bounds__(512, RAL_QKVB_MINB) void k_qkv_bwd(const float* dqk
   constexpr int LD = LDof<C>::v, LPR = C / 4;
   float* DQ = reinterpret_cast<float*>(smem4);  // HM, N x 3C
   float* Dh = DQ + N * 3 * C;                   // N x LD
-  float* red = Dh + N * LD;                     // 2C
+  float* Hl = Dh + N * LD;                      // FDW: N x LD, LN1 output (the B operand of the weight-gradient tiles)
+  float* red = Hl + (FDW ? N * LD : 0);         // 2C
   const int RPP = blockDim.x / LPR;
   const int cq = (threadIdx.x % LPR) * 4;
   const float sqrtC = sqrtf((float)C);
   const float4 gam1 = *reinterpret_cast<const float4*>(w.ln1w + cq);
+  float4 bet1 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (FDW) bet1 = *reinterpret_cast<const float4*>(w.ln1b + cq);
   float4 dgam = make_float4(0.f, 0.f, 0.f, 0.f), dbet = make_float4(0.f, 0.f, 0.f, 0.f);
   const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  using DWS = QkvDwShape<C>;
+  f32x4 accw[FDW ? DWS::NJ : 1];
+  float bsw[FDW ? DWS::NJ : 1];
+#pragma unroll
+  for (int j = 0; j < (FDW ? DWS::NJ : 1); ++j) { accw[j] = f32x4{0.f, 0.f, 0.f, 0.f}; bsw[j] = 0.f; }
   // One workgroup per CU is resident next to the weight-gradient kernels, so nothing else hides this kernel's HBM round
   // trips: the next window's operands are requested under the current window's LayerNorm phase.  NQ float4 of dqkv and
   // NR rows of x / dx1 / extra per thread are kept in flight (the BASELINE shapes have N C = 4096: NQ = 6, NR = 2 cover
@@ -1163,6 +1197,7 @@ __global__ __launch_bounds__(512, RAL_QKVB_MINB) void k_qkv_bwd(const float* dqk
     out = f4add(out, d1);
     if (extra) out = f4add(out, e);
     *reinterpret_cast<float4*>(dx + wo + (size_t)row * C + cq) = out;
+    if constexpr (FDW) *reinterpret_cast<float4*>(Hl + row * LD + cq) = f4add(f4mul(xh, gam1), bet1);
     dgam = f4add(dgam, f4mul(dh, xh));
     dbet = f4add(dbet, dh);
   };
@@ -1242,6 +1277,32 @@ __global__ __launch_bounds__(512, RAL_QKVB_MINB) void k_qkv_bwd(const float* dqk
       ln_row(wo, row, *reinterpret_cast<const float4*>(x + o), *reinterpret_cast<const float4*>(pe + row * C + cq),
              *reinterpret_cast<const float4*>(dx1 + o), *reinterpret_cast<const float4*>(ex + o));
     }
+    if constexpr (FDW) {
+      if (gr.wqkv) {   // (frozen weights, ral_backward_input: no weight gradients)
+        __syncthreads();   // the window's LayerNorm output is in Hl; dqkv still in DQ
+        const int tlen = N / DWS::KS;
+#pragma unroll
+        for (int j = 0; j < DWS::NJ; ++j) {
+          const int job = wave + 8 * j, tile = job % DWS::TILES, kpart = job / DWS::TILES;
+          const int mi = tile / DWS::TN, nj = tile % DWS::TN;
+          int am = mi * 16 + r, bc = nj * 16 + r;                 // operand columns of this lane, clamped into the matrix
+          am = am < 3 * C ? am : 3 * C - 1;
+          bc = bc < C ? bc : C - 1;
+          const float* Ap = DQ + ((am >> 2) * N) * 4 + (am & 3);   // dqkv[t][am] at Ap[4 t] (head-major quads)
+          const float* Bp = Hl + bc;                               // LN1(x)[t][bc] at Bp[t LD]
+          for (int t0 = kpart * tlen; t0 < (kpart + 1) * tlen; t0 += 16) {
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) {
+              const int t = t0 + 4 * g + s_;
+              const float av = Ap[4 * t], bv = Bp[t * LD];
+              accw[j] = mfma4(av, bv, accw[j]);
+              bsw[j] += av;
+            }
+          }
+        }
+        __syncthreads();   // DQ may take the next window now
+      }
+    }
     if (more) {
       if (pfq) {
 #pragma unroll
@@ -1265,6 +1326,31 @@ __global__ __launch_bounds__(512, RAL_QKVB_MINB) void k_qkv_bwd(const float* dqk
     atomicAdd(gr.ln1w + threadIdx.x, (float)redd[threadIdx.x]);
     atomicAdd(gr.ln1b + threadIdx.x, (float)redd[C + threadIdx.x]);
 #endif
+  }
+  if constexpr (FDW) {
+    if (!gr.wqkv) return;
+    // ---- flush dWqkv / dbqkv: the token-range partials meet in an LDS image of the matrix (3C x C floats + 3C, behind the small
+    // sums above), then consecutive threads add consecutive floats (global float atomics run at full rate for 256 contiguous bytes)
+    float* img = reinterpret_cast<float*>(smem4) + 4 * C + 8;   // (past the 2C doubles of redd)
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * C * C + 3 * C; i += blockDim.x) img[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < DWS::NJ; ++j) {
+      const int job = wave + 8 * j, tile = job % DWS::TILES;
+      const int mi = tile / DWS::TN, nj = tile % DWS::TN;
+      const int col = nj * 16 + r;
+#pragma unroll
+      for (int q_ = 0; q_ < 4; ++q_) {
+        const int row = mi * 16 + 4 * g + q_;
+        if (row < 3 * C && col < C) atomicAdd(img + row * C + col, accw[j][q_]);
+      }
+      const float bs = rows_sum(bsw[j]);         // column sums of dqkv over this job's tokens: lane (r, *) holds row mi * 16 + r
+      if (nj == 0 && g == 0 && mi * 16 + r < 3 * C) atomicAdd(img + 3 * C * C + mi * 16 + r, bs);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * C * C; i += blockDim.x) atomicAdd(gr.wqkv + i, img[i]);
+    for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) atomicAdd(gr.bqkv + i, img[3 * C * C + i]);
   }
 }
 
@@ -1451,7 +1537,7 @@ template <int D, bool SEP>
 __global__ __launch_bounds__(256) void k_resample_bwd(const float* dy, const float* x,
                                                       const float* __restrict__ wred, const float* __restrict__ lnw,
                                                       float* __restrict__ g_lnw, float* __restrict__ g_lnb,
-                                                      float* __restrict__ dx, int T, int B) {
+                                                      float* __restrict__ dx, int T, int Tv, int B) {
   extern __shared__ float4 smem4[];
   constexpr int LD = LDof<D>::v, LPR = D / 4, RPP = 256 / LPR;
   float* Ys = reinterpret_cast<float*>(smem4);  // T x LD
@@ -1461,7 +1547,7 @@ __global__ __launch_bounds__(256) void k_resample_bwd(const float* dy, const flo
   const float4 gam = *reinterpret_cast<const float4*>(lnw + cq);
   float4 dgam = make_float4(0.f, 0.f, 0.f, 0.f), dbet = make_float4(0.f, 0.f, 0.f, 0.f);
   auto src_of = [&](size_t wo, int row) -> size_t {
-    return SEP ? wo + (size_t)(row % (T / 2)) * 2 * D + (row / (T / 2)) * D : wo + (size_t)row * D;
+    return SEP ? wo + sep_src(row, T, Tv, D) : wo + (size_t)row * D;
   };
   auto ln_row = [&](int row, size_t src, float4 v) {   // LayerNorm backward of one row (all LPR lanes of the row take part)
     float4 d; float rstd;
@@ -1837,7 +1923,7 @@ bool mlp_bwd_is_fused(int C, int N) {
 
 template <int C>
 static bool launch_mlp_bwd_s(const float* dx2, const float* x1, const BlockP& w, const BlockP& wt,
-                             const BlockP& gr, float* dx1, float* do_hm, int N, int B, bool want_dw, hipStream_t s) {
+                             const BlockP& gr, float* dx1, float* do_hm, int N, int B, bool want_dw, hipStream_t s, int NE) {
   // widest level that takes the fused kernel: RAL_FUSE_DW (0 disables it, 8 / 16 narrow it).  Measured at batch 2048:
   // none 102.8k, C <= 8 103.8k, C <= 16 105.5k, C <= 32 105.8k windows/s (at C = 32 the weight-gradient MFMAs are
   // no longer negligible on the critical stream, so the gain flattens)
@@ -1845,7 +1931,7 @@ static bool launch_mlp_bwd_s(const float* dx2, const float* x1, const BlockP& w,
   if (!mlp_bwd_s_applies<C>(N, &tw, &lds)) return false;
   static const int gs = env_grid("RAL_GRID_MLPS", 384);
   const int grid = cap(B, gs);
-#define GO(t) { RAL_SET_LDS((k_mlp_bwd_s<C, t>), lds); k_mlp_bwd_s<C, t><<<grid, 512, lds, s>>>(dx2, x1, w, wt, gr, dx1, do_hm, N, B, want_dw ? 1 : 0); return true; }
+#define GO(t) { RAL_SET_LDS((k_mlp_bwd_s<C, t>), lds); k_mlp_bwd_s<C, t><<<grid, 512, lds, s>>>(dx2, x1, w, wt, gr, dx1, do_hm, N, B, want_dw ? 1 : 0, NE); return true; }
   switch (tw) { case 1: GO(1) case 2: GO(2) case 4: GO(4) case 8: GO(8) default: return false; }
 #undef GO
 }
@@ -1879,16 +1965,16 @@ static void launch_mlp_bwd_hc(int nch, const float* dx2, const float* x1, const 
 template <int C>
 static bool launch_mlp_bwd_c(int nch, const float* dx2, const float* x1, const float* upre, const BlockP& w,
                              const BlockP& wt, const BlockP& gr, float* dupre, float* dx1, float* do_hm, float* a2c0, int N, int B,
-                             bool want_dw, hipStream_t s) {
+                             bool want_dw, hipStream_t s, int NE) {
   if constexpr (C <= 32) {
-    if (launch_mlp_bwd_s<C>(dx2, x1, w, wt, gr, dx1, do_hm, N, B, want_dw, s)) return true;
+    if (launch_mlp_bwd_s<C>(dx2, x1, w, wt, gr, dx1, do_hm, N, B, want_dw, s, NE)) return true;
   }
   const size_t lds = mlp_bwd_lds(C, N, nch);
   static const int gm = env_grid("RAL_GRID_MLPB", 512);
   const int grid = cap(B, gm);
-  if (nch == 1) { RAL_SET_LDS((k_mlp_bwd<C, 1>), lds); k_mlp_bwd<C, 1><<<grid, 512, lds, s>>>(dx2, x1, upre, w, wt, gr, dupre, dx1, do_hm, a2c0, N, B); }
-  else if (nch == 2) { RAL_SET_LDS((k_mlp_bwd<C, 2>), lds); k_mlp_bwd<C, 2><<<grid, 512, lds, s>>>(dx2, x1, upre, w, wt, gr, dupre, dx1, do_hm, a2c0, N, B); }
-  else { RAL_SET_LDS((k_mlp_bwd<C, 4>), lds); k_mlp_bwd<C, 4><<<grid, 512, lds, s>>>(dx2, x1, upre, w, wt, gr, dupre, dx1, do_hm, a2c0, N, B); }
+  if (nch == 1) { RAL_SET_LDS((k_mlp_bwd<C, 1>), lds); k_mlp_bwd<C, 1><<<grid, 512, lds, s>>>(dx2, x1, upre, w, wt, gr, dupre, dx1, do_hm, a2c0, N, B, NE); }
+  else if (nch == 2) { RAL_SET_LDS((k_mlp_bwd<C, 2>), lds); k_mlp_bwd<C, 2><<<grid, 512, lds, s>>>(dx2, x1, upre, w, wt, gr, dupre, dx1, do_hm, a2c0, N, B, NE); }
+  else { RAL_SET_LDS((k_mlp_bwd<C, 4>), lds); k_mlp_bwd<C, 4><<<grid, 512, lds, s>>>(dx2, x1, upre, w, wt, gr, dupre, dx1, do_hm, a2c0, N, B, NE); }
   return false;
 }
 
@@ -1896,22 +1982,24 @@ static bool launch_mlp_bwd_c(int nch, const float* dx2, const float* x1, const f
 // skips those two products in launch_block_dw
 bool launch_mlp_bwd(int C, int nch, const float* dx2, const float* x1, const float* upre, const BlockP& w,
                     const BlockP& wt, const float* ptbase, const void* wtt, unsigned* gmax, const BlockP& gr, float* dupre, float* dx1, float* do_hm,
-                    float* a2c0, int N, int B, bool want_dw, hipStream_t s, int f16_narrow) {
+                    float* a2c0, int N, int B, bool want_dw, hipStream_t s, int f16_narrow, int NE) {
   if (!want_dw) { dupre = nullptr; a2c0 = nullptr; }   // consumed by the weight-gradient kernels only
-  if (wtt && upre) {   // (upre == nullptr: a level whose forward does not store u_pre - the fused narrow-level kernel re-computes it)
+  if (NE <= 0 || NE > N) NE = N;
+  const bool padded = NE < N;   // padded windows: the generic kernels (their local-enhancement conv knows where the window ends)
+  if (!padded && wtt && upre) {   // (upre == nullptr: a level whose forward does not store u_pre - the fused narrow-level kernel re-computes it)
     const int nh = mlp_bwd_h_nch(C, N);
     if (nh && C == 32) { launch_mlp_bwd_hc<32>(nh, dx2, x1, upre, w, wt, ptbase, wtt, gr, dupre, dx1, do_hm, a2c0, want_dw ? gmax : nullptr, N, B, s); return false; }
     if (nh && C == 64) { launch_mlp_bwd_hc<64>(nh, dx2, x1, upre, w, wt, ptbase, wtt, gr, dupre, dx1, do_hm, a2c0, want_dw ? gmax : nullptr, N, B, s); return false; }
     if (nh && C == 128) { launch_mlp_bwd_hc<128>(nh, dx2, x1, upre, w, wt, ptbase, wtt, gr, dupre, dx1, do_hm, a2c0, want_dw ? gmax : nullptr, N, B, s); return false; }
   }
-  if (!upre && mlp_bwd_is_fused(C, N)) {   // strip kernels (ral_mlpw.hip), fc1 / fc2 weight gradients fused
+  if (!padded && !upre && mlp_bwd_is_fused(C, N)) {   // strip kernels (ral_mlpw.hip), fc1 / fc2 weight gradients fused
     if (const int kind = mlp_bwd_w_kind(C, N, f16_narrow != 0)) {
       launch_mlp_bwd_w(C, kind, dx2, x1, w, gr, dx1, do_hm, N, B, want_dw, s);
       return true;
     }
   }
   switch (C) {
-#define CASE(c) case c: return launch_mlp_bwd_c<c>(nch, dx2, x1, upre, w, wt, gr, dupre, dx1, do_hm, a2c0, N, B, want_dw, s);
+#define CASE(c) case c: return launch_mlp_bwd_c<c>(nch, dx2, x1, upre, w, wt, gr, dupre, dx1, do_hm, a2c0, N, B, want_dw, s, NE);
     CASE(8) CASE(16) CASE(32) CASE(64) CASE(128)
 #undef CASE
   }
@@ -1946,7 +2034,14 @@ size_t attn_bwd_scratch_floats(int N, int H, int Len, bool table, int B) {
 
 void launch_attn_bwd(const float* qkv, const float* o_hm, const float* do_hm, const float* lse, const float* table,
                      float* gtable, float* dqkv, float* stat2, size_t scratch_floats, int N, int H, int HG, int Len, int B,
-                     int f16, hipStream_t s) {
+                     int f16, hipStream_t s, int NE) {
+  if (NE > 0 && NE < N) {   // padded windows (NE of the N token slots exist): the generic tile kernel with its key mask
+    const size_t lds = attn_bwd_lds(N, HG, Len);
+    const int items = B * (H / HG), grid = items < 4096 ? items : 4096;
+    RAL_SET_LDS((k_attn_bwd<1, 0, true, true>), lds);
+    k_attn_bwd<1, 0, true, true><<<grid, 512, lds, s>>>(qkv, o_hm, do_hm, lse, table, gtable, dqkv, N, H, HG, Len, B, NE);
+    return;
+  }
   // one sweep with every contraction on the f16 matrix cores (ral_attnm.hip)
   if (f16 && attn_bwd_m_takes(N, H, Len, table != nullptr) &&
       (stat2 ? scratch_floats : 0) >= attn_bwd_m_scratch_floats(N, H, Len, table != nullptr, B)) {
@@ -2016,14 +2111,21 @@ void launch_attn_bwd(const float* qkv, const float* o_hm, const float* do_hm, co
 }
 
 size_t qkv_bwd_lds(int C, int N) { return ((size_t)N * 3 * C + (size_t)N * ld_of(C) + 5 * C + 8) * sizeof(float); }
+// the narrow levels form the projection's weight gradient inside k_qkv_bwd (QKVB_FDW = 0: the separate launch of ral_dw.hip)
+bool qkv_bwd_fuses_dw(int C, int N) {
+  static const bool on = (ral_knob("QKVB_FDW", 1) != 0);
+  if (!on || C > 32) return false;
+  const int ks = C == 32 ? 2 : (C == 16 ? 8 : 4);
+  return N % (16 * ks) == 0;
+}
 
 bool qkv_bwd_uses_f16(int C, int N) {
   static const bool on = (ral_knob("QKVB_F16", 1) != 0);
   return on && (C == 32 || C == 64 || C == 128) && N % 32 == 0 && N * 3 * C / 4 <= 6 * 512;
 }
-void launch_qkv_bwd(int C, const float* dqkv, const float* x, const float* pe, const float* dx1, const float* extra,
+bool launch_qkv_bwd(int C, const float* dqkv, const float* x, const float* pe, const float* dx1, const float* extra,
                     const BlockP& w, const BlockP& wt, const float* ptbase, const void* wtt, unsigned* gmax, const BlockP& gr, float* dx, int N, int B,
-                    hipStream_t s) {
+                    bool want_dw, hipStream_t s) {
   static const int gq = env_grid("RAL_GRID_QKVB", 192);
   const int grid = cap(B, gq);
   if (wtt && qkv_bwd_uses_f16(C, N)) {
@@ -2032,24 +2134,39 @@ void launch_qkv_bwd(int C, const float* dqkv, const float* x, const float* pe, c
     if (C == 32) { RAL_SET_LDS((k_qkv_bwd_h<32>), ldsh); k_qkv_bwd_h<32><<<grid, 512, ldsh, s>>>(dqkv, x, pe, dx1, extra, w, wt, ptbase, wp, gr, dx, gmax, N, B); }
     else if (C == 64) { RAL_SET_LDS((k_qkv_bwd_h<64>), ldsh); k_qkv_bwd_h<64><<<grid, 512, ldsh, s>>>(dqkv, x, pe, dx1, extra, w, wt, ptbase, wp, gr, dx, gmax, N, B); }
     else { RAL_SET_LDS((k_qkv_bwd_h<128>), ldsh); k_qkv_bwd_h<128><<<grid, 512, ldsh, s>>>(dqkv, x, pe, dx1, extra, w, wt, ptbase, wp, gr, dx, gmax, N, B); }
-    return;
+    return false;
   }
   const size_t lds = qkv_bwd_lds(C, N);
+  if (qkv_bwd_fuses_dw(C, N)) {   // narrow levels: weight gradient of the projection inside the kernel
+    size_t ldsf = lds + (size_t)N * ld_of(C) * sizeof(float);
+    const size_t img = ((size_t)4 * C + 8 + 3 * C * C + 3 * C) * sizeof(float);
+    if (ldsf < img) ldsf = img;
+    BlockP g2 = gr;
+    if (!want_dw) g2.wqkv = nullptr;   // (frozen weights: the kernel skips the tiles)
+    switch (C) {
+#define CASE(c) case c: RAL_SET_LDS((k_qkv_bwd<c, true>), ldsf); \
+      k_qkv_bwd<c, true><<<grid, 512, ldsf, s>>>(dqkv, x, pe, dx1, extra, w, wt, g2, dx, N, B); break;
+      CASE(8) CASE(16) CASE(32)
+#undef CASE
+    }
+    return true;
+  }
   switch (C) {
 #define CASE(c) case c: RAL_SET_LDS((k_qkv_bwd<c>), lds); \
     k_qkv_bwd<c><<<grid, 512, lds, s>>>(dqkv, x, pe, dx1, extra, w, wt, gr, dx, N, B); break;
     CASE(8) CASE(16) CASE(32) CASE(64) CASE(128)
 #undef CASE
   }
+  return false;
 }
 
 void launch_resample_bwd(int D, bool sep, const float* dy, const float* x, const float* wred, const float* lnw,
-                         float* g_lnw, float* g_lnb, float* dx, int T, int B, hipStream_t s) {
+                         float* g_lnw, float* g_lnb, float* dx, int T, int Tv, int B, hipStream_t s) {
   const size_t lds = ((size_t)2 * T * ld_of(D) + 2 * D + 4) * sizeof(float);
   static const int gr = env_grid("RAL_GRID_RESB", 256);
   const int grid = cap(B, gr);
-#define CASE(d) case d: if (sep) { RAL_SET_LDS((k_resample_bwd<d, true>), lds); k_resample_bwd<d, true><<<grid, 256, lds, s>>>(dy, x, wred, lnw, g_lnw, g_lnb, dx, T, B); } \
-                        else { RAL_SET_LDS((k_resample_bwd<d, false>), lds); k_resample_bwd<d, false><<<grid, 256, lds, s>>>(dy, x, wred, lnw, g_lnw, g_lnb, dx, T, B); } break;
+#define CASE(d) case d: if (sep) { RAL_SET_LDS((k_resample_bwd<d, true>), lds); k_resample_bwd<d, true><<<grid, 256, lds, s>>>(dy, x, wred, lnw, g_lnw, g_lnb, dx, T, Tv, B); } \
+                        else { RAL_SET_LDS((k_resample_bwd<d, false>), lds); k_resample_bwd<d, false><<<grid, 256, lds, s>>>(dy, x, wred, lnw, g_lnw, g_lnb, dx, T, Tv, B); } break;
   switch (D) { CASE(8) CASE(16) CASE(32) CASE(64) CASE(128) }
 #undef CASE
 }

@@ -623,6 +623,20 @@ RAL_DEV void copy_flat(float* dst, const float* __restrict__ src, int n4) {
   for_each_f4<4>(src, n4, [&](int i, float4 v) { reinterpret_cast<float4*>(dst)[i] = v; });
 }
 
+// PatchSeparate's token order (reference quirk A5: the output rows are [first channel halves of all input tokens ; second
+// halves]) on a window of T output slots of which the first Tv exist (Tv <= T, both even; a window length that is not a multiple
+// of 256 runs on padded slots, ral_api.hip): output row `row` reads / back-propagates into input slot l, channel half c1 - float
+// offset l * 2D + c1 * D inside the window.  Existing rows map onto the existing input slots [0, Tv / 2) exactly as the reference
+// orders them; the padding rows are mapped one to one onto the padding input slots, so that the backward writes every input slot
+// exactly once (zeros into the padding).
+RAL_DEV size_t sep_src(int row, int T, int Tv, int D) {
+  const int hv = Tv >> 1;
+  int l, c1;
+  if (row < Tv) { c1 = row >= hv ? 1 : 0; l = row - c1 * hv; }
+  else { const int hp = (T >> 1) - hv, p = row - Tv; c1 = p >= hp ? 1 : 0; l = hv + p - c1 * hp; }
+  return (size_t)l * 2 * D + (size_t)c1 * D;
+}
+
 // Parameters of one TransformerBlock inside the flat parameter (or gradient) buffer.
 struct BlockP {
   float* wqkv;  // (3C, C): to_q.weight then to_kv.weight

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(512, RAL_DW_WPE) void k_dw(const float* Y, const fl
                                                const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                const float* a2c0, float* dW, float* dB, const unsigned* __restrict__ ymax,
                                                const float* __restrict__ xscale /* {scale, inverse} of the X operand (ASC_*), or nullptr: 2^8 */,
-                                               int N, int TC, int B) {
+                                               int N, int TC, int B, int NV = 0 /* XF_LN_SEP: existing tokens of the N slots (0: all) */) {
   extern __shared__ float4 smem4[];
   constexpr bool YHM = LAYY == LAY_HM, XHM = XF == XF_HM;
   constexpr int LDYH = MS + 8, LDXH = NS + 8;   // H: row strides of the token-major planes (2-byte elements)
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(512, RAL_DW_WPE) void k_dw(const float* Y, const fl
         o.v = *reinterpret_cast<const float4*>(Xw + ((size_t)(nb / 4 + q) * N + t0 + t) * 4);
       } else {
         const int row = j / (NS / 4), c = (j - row * (NS / 4)) * 4, t = t0 + row;
-        const float* src = (XF == XF_LN_SEP) ? Xw + (size_t)(t % (N / 2)) * 2 * NC + (t / (N / 2)) * NC
+        const float* src = (XF == XF_LN_SEP) ? Xw + sep_src(t, N, NV ? NV : N, NC)
                                              : Xw + (size_t)t * NC + nb;
         o.v = *reinterpret_cast<const float4*>(src + c);
         if constexpr (XF == XF_LNPE) o.p = *reinterpret_cast<const float4*>(pe + (size_t)t * NC + c);
@@ -485,7 +485,7 @@ void set_dw_lds_budget(size_t bytes) { g_dw_budget = bytes < (size_t)RAL_DW_LDS_
 template <int M, int NC, int MS, int NS, int LAYY, int XF>
 static void launch_dw_t(const float* Y, const float* X, const float* pe, const float* lnw, const float* lnb,
                         const float* a2c0, float* dW, float* dB, int N, int B, int ksplit, hipStream_t s,
-                        const unsigned* ymax = nullptr, const float* xscale = nullptr) {
+                        const unsigned* ymax = nullptr, const float* xscale = nullptr, int NV = 0) {
   static_assert(M % MS == 0 && NC % NS == 0, "slices must tile dW");
   constexpr bool yhm = LAYY == LAY_HM, xhm = XF == XF_HM;
   constexpr int TM = (MS + 15) / 16, TN = (NS + 15) / 16;
@@ -505,7 +505,7 @@ static void launch_dw_t(const float* Y, const float* X, const float* pe, const f
       if (TC >= 32 && N % TC == 0 && bytesh(TC) <= g_dw_budget + 4096) {
         const size_t lds = bytesh(TC) > fold ? bytesh(TC) : fold;
         RAL_SET_LDS((k_dw<M, NC, MS, NS, LAYY, XF, true>), lds);
-        k_dw<M, NC, MS, NS, LAYY, XF, true><<<grid, 512, lds, s>>>(Y, X, pe, lnw, lnb, a2c0, dW, dB, ymax, xscale, N, TC, B);
+        k_dw<M, NC, MS, NS, LAYY, XF, true><<<grid, 512, lds, s>>>(Y, X, pe, lnw, lnb, a2c0, dW, dB, ymax, xscale, N, TC, B, NV);
         return;
       }
     }
@@ -516,7 +516,7 @@ static void launch_dw_t(const float* Y, const float* X, const float* pe, const f
   while (TC > 16 && (N % TC != 0 || bytes(TC) > g_dw_budget)) TC /= 2;
   const size_t lds = bytes(TC) > fold ? bytes(TC) : fold;
   RAL_SET_LDS((k_dw<M, NC, MS, NS, LAYY, XF>), lds);
-  k_dw<M, NC, MS, NS, LAYY, XF><<<grid, 512, lds, s>>>(Y, X, pe, lnw, lnb, a2c0, dW, dB, nullptr, nullptr, N, TC, B);
+  k_dw<M, NC, MS, NS, LAYY, XF><<<grid, 512, lds, s>>>(Y, X, pe, lnw, lnb, a2c0, dW, dB, nullptr, nullptr, N, TC, B, NV);
 }
 
 // slice widths: at most RAL_DW_SLICE rows/columns of the wide operand per workgroup
@@ -527,7 +527,7 @@ template <int W> struct SliceOf { static constexpr int v = W > RAL_DW_SLICE ? ((
 template <int C>
 static void launch_block_dw_c(const float* dx2, const float* upre, const float* a2c0, const float* dupre, const float* x1,
                               const float* dx1, const float* o_hm, const float* dqkv, const float* x, const float* pe,
-                              const BlockP& w, const BlockP& gr, int N, int B, int ks, bool skip_mlp, const unsigned* gmax, hipStream_t s) {
+                              const BlockP& w, const BlockP& gr, int N, int B, int ks, bool skip_mlp, const unsigned* gmax, hipStream_t s, bool skip_qkv) {
   static const bool h_on = (ral_knob("DW_F16", 1) != 0);
   const unsigned* gm = (h_on && C >= 32) ? gmax : nullptr;
   if (!skip_mlp) {
@@ -535,22 +535,23 @@ static void launch_block_dw_c(const float* dx2, const float* upre, const float* 
   launch_dw_t<4 * C, C, SliceOf<4 * C>::v, C, LAY_TOK, XF_LN>(dupre, x1, nullptr, w.ln2w, w.ln2b, nullptr, gr.w1, gr.b1, N, B, ks, s, gm ? gm + 1 : nullptr, w.asc ? w.asc + ASC_LN2 : nullptr);
   }
   launch_dw_t<C, C, SliceOf<C>::v, C, LAY_TOK, XF_HM>(dx1, o_hm, nullptr, nullptr, nullptr, nullptr, gr.wp, gr.bp, N, B, ks, s, gm ? gm + 2 : nullptr, w.asc ? w.asc + ASC_O : nullptr);
+  if (!skip_qkv)
   launch_dw_t<3 * C, C, SliceOf<3 * C>::v, C, LAY_HM, XF_LNPE>(dqkv, x, pe, w.ln1w, w.ln1b, nullptr, gr.wqkv, gr.bqkv, N, B, ks, s, gm ? gm + 3 : nullptr, w.asc ? w.asc + ASC_LN1 : nullptr);
 }
 
 void launch_block_dw(int C, const float* dx2, const float* upre, const float* a2c0, const float* dupre, const float* x1,
                      const float* dx1, const float* o_hm, const float* dqkv, const float* x, const float* pe,
-                     const BlockP& w, const BlockP& gr, int N, int B, int ksplit, bool skip_mlp, const unsigned* gmax, hipStream_t s) {
+                     const BlockP& w, const BlockP& gr, int N, int B, int ksplit, bool skip_mlp, const unsigned* gmax, hipStream_t s, bool skip_qkv) {
   switch (C) {
-#define CASE(c) case c: launch_block_dw_c<c>(dx2, upre, a2c0, dupre, x1, dx1, o_hm, dqkv, x, pe, w, gr, N, B, ksplit, skip_mlp, gmax, s); break;
+#define CASE(c) case c: launch_block_dw_c<c>(dx2, upre, a2c0, dupre, x1, dx1, o_hm, dqkv, x, pe, w, gr, N, B, ksplit, skip_mlp, gmax, s, skip_qkv); break;
     CASE(8) CASE(16) CASE(32) CASE(64) CASE(128)
 #undef CASE
   }
 }
 
 void launch_resample_dw(int D, bool sep, const float* dy, const float* x, const float* lnw, const float* lnb,
-                        float* dW, int T, int B, int ksplit, hipStream_t s) {
-#define CASE(d) case d: if (sep) launch_dw_t<d, d, d, d, LAY_TOK, XF_LN_SEP>(dy, x, nullptr, lnw, lnb, nullptr, dW, nullptr, T, B, ksplit, s); \
+                        float* dW, int T, int Tv, int B, int ksplit, hipStream_t s) {
+#define CASE(d) case d: if (sep) launch_dw_t<d, d, d, d, LAY_TOK, XF_LN_SEP>(dy, x, nullptr, lnw, lnb, nullptr, dW, nullptr, T, B, ksplit, s, nullptr, nullptr, Tv); \
                         else launch_dw_t<d, d, d, d, LAY_TOK, XF_LN>(dy, x, nullptr, lnw, lnb, nullptr, dW, nullptr, T, B, ksplit, s); break;
   switch (D) { CASE(8) CASE(16) CASE(32) CASE(64) CASE(128) }
 #undef CASE

@@ -411,12 +411,16 @@ RAL_DEV void put_pair_planes(float* X, int t, float4 x) {
   *reinterpret_cast<fh16x4*>(X + 4 * t) = fh16x4{s0.a, s1.a, s2.a, s3.a};
   *reinterpret_cast<fh16x4*>(X + 4 * t + 2) = fh16x4{s0.b, s1.b, s2.b, s3.b};
 }
-template <int QT, int NT = 0, bool TAB = true, bool F16 = false>
+// RAG: only the first NE of the window's N token slots exist (a window length that is not a multiple of 256 runs on padded
+// slots, ral_api.hip): keys past NE are masked out of the softmax (s = -inf), the R-wave window is centred in the NE tokens;
+// the padding queries are computed like any other (their rows are never used)
+template <int QT, int NT = 0, bool TAB = true, bool F16 = false, bool RAG = false>
 __global__ __launch_bounds__(512, (QT >= 4 ? 3 : 4)) void k_attn_fwd(const float* __restrict__ qkv, float* __restrict__ o_hm,
                                                   float* __restrict__ lse, const float* __restrict__ table,
-                                                  int N_rt, int H, int HG, int Len, int B) {
+                                                  int N_rt, int H, int HG, int Len, int B, int NE_rt = 0) {
   extern __shared__ float4 smem4[];
   const int N = NT ? NT : N_rt;
+  const int NE = RAG ? NE_rt : N, NEt = RAG ? ((NE + 15) & ~15) : N;   // existing keys; key tiles that hold one
   if constexpr (!TAB) { table = nullptr; Len = 0; }
   float* Qs = reinterpret_cast<float*>(smem4);
   float* Ks = Qs + HG * N * 4;
@@ -429,8 +433,8 @@ __global__ __launch_bounds__(512, (QT >= 4 ? 3 : 4)) void k_attn_fwd(const float
   const int ngrp = H / HG;
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
   const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  const int off = (N - Len) >> 1;
-  const int kb0 = table ? (off & ~15) : N, kb1 = table ? ((off + Len + 15) & ~15) : N;  // biased key tiles
+  const int off = (NE - Len) >> 1;
+  const int kb0 = table ? (off & ~15) : NEt, kb1 = table ? ((off + Len + 15) & ~15) : NEt;  // biased key tiles
   for (int item = blockIdx.x; item < B * ngrp; item += gridDim.x) {
     const int win = item / ngrp, h0 = (item - win * ngrp) * HG;
     const float* base = qkv + (size_t)win * 3 * H * N * 4;
@@ -509,6 +513,12 @@ __global__ __launch_bounds__(512, (QT >= 4 ? 3 : 4)) void k_attn_fwd(const float
         for (int qt = 0; qt < QT; ++qt) {
           const float nm = -mq[qt];
           f32x4 s = sc_tile(kt, qt, f32x4{nm, nm, nm, nm});   // s - m, log2 units
+          if constexpr (RAG) {
+            if (kt + 16 > NE) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) s[j] = (kt + 4 * g + j < NE) ? s[j] : -INFINITY;
+            }
+          }
           if constexpr (decltype(biased)::value) {
             const int qi = q0 + 16 * qt + r - off;
 #pragma unroll
@@ -533,10 +543,10 @@ __global__ __launch_bounds__(512, (QT >= 4 ? 3 : 4)) void k_attn_fwd(const float
       };
       // only query blocks that touch the centred R-wave window take the biased key tiles
       const bool qbias = table && (q0 < off + Len) && (q0 + 16 * QT > off);
-      const int e0 = qbias ? kb0 : N, e1 = qbias ? kb1 : N;
+      const int e0 = qbias ? kb0 : NEt, e1 = qbias ? kb1 : NEt;
       for (int kt = 0; kt < e0; kt += 16) tile(kt, std::false_type{});
       for (int kt = e0; kt < e1; kt += 16) tile(kt, std::true_type{});
-      for (int kt = e1; kt < N; kt += 16) tile(kt, std::false_type{});
+      for (int kt = e1; kt < NEt; kt += 16) tile(kt, std::false_type{});
       bool redo = false;
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {
@@ -559,8 +569,12 @@ __global__ __launch_bounds__(512, (QT >= 4 ? 3 : 4)) void k_attn_fwd(const float
           float mx = -INFINITY, l = 0.f;
           float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
           const int qi = q0 + 16 * qt + r - off;
-          for (int kt = 0; kt < N; kt += 16) {
+          for (int kt = 0; kt < NEt; kt += 16) {
             f32x4 s = sc_tile(kt, qt, f32x4{0.f, 0.f, 0.f, 0.f});
+            if constexpr (RAG) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) s[j] = (kt + 4 * g + j < NE) ? s[j] : -INFINITY;
+            }
             if (table) {
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
@@ -569,12 +583,12 @@ __global__ __launch_bounds__(512, (QT >= 4 ? 3 : 4)) void k_attn_fwd(const float
               }
             }
             const float mn = fmaxf(fmaxf(mx, fmaxf(s[0], s[1])), fmaxf(s[2], s[3]));
-            const float corr = __builtin_amdgcn_exp2f(mx - mn);
+            const float corr = (RAG && mx == mn) ? 1.0f : __builtin_amdgcn_exp2f(mx - mn);   // (RAG: a lane that has seen masked keys only holds -inf)
             mx = mn;
             l *= corr; o = f4scale(o, corr);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              const float p = __builtin_amdgcn_exp2f(s[j] - mn);
+              const float p = (RAG && s[j] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(s[j] - mn);
               const float4 v = Vh[kt + 4 * g + j];
               l += p;
               o.x = fmaf(p, v.x, o.x); o.y = fmaf(p, v.y, o.y); o.z = fmaf(p, v.z, o.z); o.w = fmaf(p, v.w, o.w);
@@ -582,7 +596,7 @@ __global__ __launch_bounds__(512, (QT >= 4 ? 3 : 4)) void k_attn_fwd(const float
           }
           float mg = fmaxf(mx, __shfl_xor(mx, 16));
           mg = fmaxf(mg, __shfl_xor(mg, 32));
-          const float sc = __builtin_amdgcn_exp2f(mx - mg);
+          const float sc = (RAG && mx == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mx - mg);
           l *= sc; o = f4scale(o, sc);
 #pragma unroll
           for (int sh = 16; sh <= 32; sh <<= 1) {
@@ -710,7 +724,7 @@ template <int C, int NCH>
 __global__ __launch_bounds__(512) void k_mlp_fwd(const float* __restrict__ x, const float* __restrict__ o_hm,
                                                  BlockP w, float* __restrict__ x1_out,
                                                  float* __restrict__ upre_out, float* __restrict__ x2_out,
-                                                 int N, int B) {
+                                                 int N, int B, int NE /* existing tokens of the N slots (padded windows: < N) */) {
   extern __shared__ float4 smem4[];
   constexpr int LD = LDof<C>::v, HC = 4 * C / NCH, LDU = LDof<HC>::v, LPR = C / 4;
   float* Xs = reinterpret_cast<float*>(smem4);  // N x LD   : x -> x1 -> x2
@@ -783,7 +797,7 @@ __global__ __launch_bounds__(512) void k_mlp_fwd(const float* __restrict__ x, co
         if (upw) *reinterpret_cast<float4*>(upw + (size_t)tok * 4 * C + j0 + row0) = u;
         float4 h = make_float4(gelu_f(u.x), gelu_f(u.y), gelu_f(u.z), gelu_f(u.w));
         if (le) {
-          if (ch == 0 && row0 == 0) A0[tok + 1] = h.x;          // conv input; Us[tok][0] is filled below
+          if (ch == 0 && row0 == 0) A0[tok + 1] = tok < NE ? h.x : 0.f;   // conv input (a slot past NE does not exist: zero, like the halo); Us[tok][0] is filled below
           h = make_float4(gelu_f(h.x), gelu_f(h.y), gelu_f(h.z), gelu_f(h.w));
         }
         *reinterpret_cast<float4*>(Us + tok * LDU + row0) = h;
@@ -947,7 +961,7 @@ template <int D, bool SEP>
 __global__ __launch_bounds__(256) void k_resample_fwd(const float* __restrict__ x, const float* __restrict__ wred,
                                                       const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                       const float* __restrict__ skip, float* __restrict__ y,
-                                                      int T, int B) {
+                                                      int T, int Tv, int B) {
   extern __shared__ float4 smem4[];
   float* Hs = reinterpret_cast<float*>(smem4);
   constexpr int LD = LDof<D>::v, LPR = D / 4, RPP = 256 / LPR;
@@ -957,8 +971,8 @@ __global__ __launch_bounds__(256) void k_resample_fwd(const float* __restrict__ 
   for (int win = blockIdx.x; win < B; win += gridDim.x) {
     const float* xw = x + (size_t)win * T * D;
     for (int row = threadIdx.x / LPR; row < T; row += RPP) {
-      // SEP: out token t = c1*(T/2) + l  reads  x[l][c1*D + :D] of the (T/2, 2D) input
-      const float* src = SEP ? xw + (size_t)(row % (T / 2)) * 2 * D + (row / (T / 2)) * D : xw + (size_t)row * D;
+      // SEP: out token t = c1*(Tv/2) + l  reads  x[l][c1*D + :D] of the (T/2, 2D) input (sep_src: Tv of the T slots exist)
+      const float* src = SEP ? xw + sep_src(row, T, Tv, D) : xw + (size_t)row * D;
       const float4 v = *reinterpret_cast<const float4*>(src + cq);
       float4 d; float rstd;
       ln_stats<LPR>(v, d, rstd);
@@ -1034,7 +1048,13 @@ size_t attn_fwd_lds(int N, int HG, int Len) {
 }
 
 void launch_attn_fwd(const float* qkv, float* o_hm, float* lse, const float* table, int N, int H, int HG, int Len,
-                     int B, int f16, hipStream_t s) {
+                     int B, int f16, hipStream_t s, int NE) {
+  if (NE > 0 && NE < N) {   // padded windows (NE of the N token slots exist): the generic tile kernel with its key mask
+    const size_t lds = attn_fwd_lds(N, HG, Len);
+    RAL_SET_LDS((k_attn_fwd<1, 0, true, false, true>), lds);
+    k_attn_fwd<1, 0, true, false, true><<<grid_for(B * (H / HG)), 512, lds, s>>>(qkv, o_hm, lse, table, N, H, HG, Len, B, NE);
+    return;
+  }
   if (attn_fwd_w_takes(N, H, Len, table != nullptr)) { launch_attn_fwd_w(qkv, o_hm, lse, table, N, H, Len, B, f16, s); return; }
   // Window lengths [lo, hi] that take the query-per-lane kernel on the scalar path.  Measured at batch 2048
   // (tools/attn_bench.py, us per launch, MFMA-tile kernel vs scalar path): N = 512: 322 / 333, 256: 184 / 172,
@@ -1098,11 +1118,11 @@ size_t mlp_fwd_lds(int C, int N, int nch) {
 
 template <int C>
 static void launch_mlp_fwd_c(int nch, const float* x, const float* o, const BlockP& w, float* x1, float* upre,
-                             float* x2, int N, int B, hipStream_t s) {
+                             float* x2, int N, int B, hipStream_t s, int NE) {
   const size_t lds = mlp_fwd_lds(C, N, nch);
-  if (nch == 1) { RAL_SET_LDS((k_mlp_fwd<C, 1>), lds); k_mlp_fwd<C, 1><<<grid_for(B), 512, lds, s>>>(x, o, w, x1, upre, x2, N, B); }
-  else if (nch == 2) { RAL_SET_LDS((k_mlp_fwd<C, 2>), lds); k_mlp_fwd<C, 2><<<grid_for(B), 512, lds, s>>>(x, o, w, x1, upre, x2, N, B); }
-  else { RAL_SET_LDS((k_mlp_fwd<C, 4>), lds); k_mlp_fwd<C, 4><<<grid_for(B), 512, lds, s>>>(x, o, w, x1, upre, x2, N, B); }
+  if (nch == 1) { RAL_SET_LDS((k_mlp_fwd<C, 1>), lds); k_mlp_fwd<C, 1><<<grid_for(B), 512, lds, s>>>(x, o, w, x1, upre, x2, N, B, NE); }
+  else if (nch == 2) { RAL_SET_LDS((k_mlp_fwd<C, 2>), lds); k_mlp_fwd<C, 2><<<grid_for(B), 512, lds, s>>>(x, o, w, x1, upre, x2, N, B, NE); }
+  else { RAL_SET_LDS((k_mlp_fwd<C, 4>), lds); k_mlp_fwd<C, 4><<<grid_for(B), 512, lds, s>>>(x, o, w, x1, upre, x2, N, B, NE); }
 }
 
 // wide levels on split fp16 operands (RAL_MLP_F16=0: the fp32-MFMA kernel everywhere)
@@ -1139,27 +1159,30 @@ static void launch_mlp_fwd_hc(const float* x, const float* o, const BlockP& w, c
 }
 
 void launch_mlp_fwd(int C, int nch, const float* x, const float* o, const BlockP& w, const float* pbase, const void* wh,
-                    float* x1, float* upre, float* x2, int N, int B, int f16_narrow, hipStream_t s) {
-  if (wh && mlp_fwd_uses_f16(C, N)) {
+                    float* x1, float* upre, float* x2, int N, int B, int f16_narrow, hipStream_t s, int NE) {
+  if (NE <= 0 || NE > N) NE = N;
+  const bool padded = NE < N;   // padded windows: the generic kernel (its local-enhancement conv knows where the window ends)
+  if (!padded && wh && mlp_fwd_uses_f16(C, N)) {
     static const int nth = (int)ral_knob("MLP_HTHREADS", 512);
     if (C == 32) launch_mlp_fwd_hc<32, 512>(x, o, w, pbase, wh, x1, upre, x2, N, B, s);
     else if (C == 64) { if (nth == 1024) launch_mlp_fwd_hc<64, 1024>(x, o, w, pbase, wh, x1, upre, x2, N, B, s); else launch_mlp_fwd_hc<64, 512>(x, o, w, pbase, wh, x1, upre, x2, N, B, s); }
     else { if (nth == 1024) launch_mlp_fwd_hc<128, 1024>(x, o, w, pbase, wh, x1, upre, x2, N, B, s); else launch_mlp_fwd_hc<128, 512>(x, o, w, pbase, wh, x1, upre, x2, N, B, s); }
     return;
   }
-  if (const int kind = mlp_fwd_w_kind(C, N, upre != nullptr, f16_narrow != 0)) { launch_mlp_fwd_w(C, kind, x, o, w, x1, x2, N, B, s); return; }   // narrow levels: ral_mlpw.hip
+  if (!padded)
+    if (const int kind = mlp_fwd_w_kind(C, N, upre != nullptr, f16_narrow != 0)) { launch_mlp_fwd_w(C, kind, x, o, w, x1, x2, N, B, s); return; }   // narrow levels: ral_mlpw.hip
   switch (C) {
-#define CASE(c) case c: launch_mlp_fwd_c<c>(nch, x, o, w, x1, upre, x2, N, B, s); break;
+#define CASE(c) case c: launch_mlp_fwd_c<c>(nch, x, o, w, x1, upre, x2, N, B, s, NE); break;
     CASE(8) CASE(16) CASE(32) CASE(64) CASE(128)
 #undef CASE
   }
 }
 
 void launch_resample_fwd(int D, bool sep, const float* x, const float* wred, const float* lnw, const float* lnb,
-                         const float* skip, float* y, int T, int B, hipStream_t s) {
+                         const float* skip, float* y, int T, int Tv, int B, hipStream_t s) {
   const size_t lds = (size_t)T * ld_of(D) * sizeof(float);
-#define CASE(d) case d: if (sep) k_resample_fwd<d, true><<<grid_for(B), 256, lds, s>>>(x, wred, lnw, lnb, skip, y, T, B); \
-                        else k_resample_fwd<d, false><<<grid_for(B), 256, lds, s>>>(x, wred, lnw, lnb, skip, y, T, B); break;
+#define CASE(d) case d: if (sep) k_resample_fwd<d, true><<<grid_for(B), 256, lds, s>>>(x, wred, lnw, lnb, skip, y, T, Tv, B); \
+                        else k_resample_fwd<d, false><<<grid_for(B), 256, lds, s>>>(x, wred, lnw, lnb, skip, y, T, Tv, B); break;
   switch (D) { CASE(8) CASE(16) CASE(32) CASE(64) CASE(128) CASE(256) }
 #undef CASE
 }

@@ -26,15 +26,16 @@ void launch_tile_planes(const float* params, void* wt, const void* desc, int nde
 void launch_act_scales(const float* params, const void* desc, float* asc, int nblk, hipStream_t s);
 void launch_qkv_fwd(int C, const float* x, const float* pe, const BlockP& w, const void* wt /* of Wqkv */, float* qkv, int N, int B, hipStream_t s);
 size_t attn_fwd_lds(int N, int HG, int Len);
+// NE: existing tokens of the N slots (0 or N: all; fewer: padded windows, the generic kernel masks the keys past NE)
 void launch_attn_fwd(const float* qkv, float* o_hm, float* lse, const float* table, int N, int H, int HG, int Len,
-                     int B, int f16, hipStream_t s);
+                     int B, int f16, hipStream_t s, int NE = 0);
 size_t mlp_fwd_lds(int C, int N, int nch);
 // pbase / wt: the parameter buffer and the tiled-plane buffer; the levels where mlp_fwd_uses_f16(C, N) run their Linear
 // layers on the planes (wt == nullptr: fp32 MFMA everywhere)
 bool mlp_fwd_uses_f16(int C, int N);
 // f16_narrow: the model allows fp16-pair products (f16_split > 0): the narrow levels may take their f16 strip kernel
 void launch_mlp_fwd(int C, int nch, const float* x, const float* o, const BlockP& w, const float* pbase, const void* wt,
-                    float* x1, float* upre, float* x2, int N, int B, int f16_narrow, hipStream_t s);
+                    float* x1, float* upre, float* x2, int N, int B, int f16_narrow, hipStream_t s, int NE = 0 /* existing tokens; see launch_attn_fwd */);
 // narrow levels (C <= 32), wave-autonomous (ral_mlpw.hip): kind 0 = not taken, 1 = fp32-MFMA strips, 2 = f16 strips
 int mlp_fwd_w_kind(int C, int N, bool want_upre, bool f16_ok);
 bool mlp_fwd_w_takes(int C, int N, bool want_upre);
@@ -45,7 +46,7 @@ int mlp_bwd_w_kind(int C, int N, bool f16_ok);
 void launch_mlp_bwd_w(int C, int kind, const float* dx2, const float* x1, const BlockP& w, const BlockP& gr, float* dx1, float* do_hm, int N, int B,
                       bool want_dw, hipStream_t s);
 void launch_resample_fwd(int D, bool sep, const float* x, const float* wred, const float* lnw, const float* lnb,
-                         const float* skip, float* y, int T, int B, hipStream_t s);
+                         const float* skip, float* y, int T, int Tv /* existing output tokens (<= T slots) */, int B, hipStream_t s);
 void launch_add(const float* a, const float* b, float* y, size_t n, hipStream_t s);
 
 // ---- stem / head / loss / optimiser (ral_misc.hip)
@@ -88,14 +89,14 @@ bool qkv_bwd_uses_f16(int C, int N);
 // |dqkv| (qkv) of the launch - the scales of the split weight-gradient products (launch_block_dw)
 bool launch_mlp_bwd(int C, int nch, const float* dx2, const float* x1, const float* upre, const BlockP& w,
                     const BlockP& wt, const float* ptbase, const void* wtt, unsigned* gmax, const BlockP& gr, float* dupre, float* dx1, float* do_hm,
-                    float* a2c0, int N, int B, bool want_dw, hipStream_t s, int f16_narrow = 0);
+                    float* a2c0, int N, int B, bool want_dw, hipStream_t s, int f16_narrow = 0, int NE = 0 /* existing tokens; see launch_attn_fwd */);
 size_t attn_bwd_lds(int N, int HG, int Len);
 bool attn_bwd_uses_stat2(int N, int Len, bool table);   // does launch_attn_bwd need its (B, H, N, 2) scratch for this shape?
 // scratch / scratch_floats: caller-owned; attn_bwd_scratch_floats() says how much the kernels chosen for a shape need
 size_t attn_bwd_scratch_floats(int N, int H, int Len, bool table, int B);
 void launch_attn_bwd(const float* qkv, const float* o_hm, const float* do_hm, const float* lse, const float* table,
                      float* gtable, float* dqkv, float* scratch, size_t scratch_floats, int N, int H, int HG, int Len, int B,
-                     int f16, hipStream_t s);
+                     int f16, hipStream_t s, int NE = 0);
 // f16: S and dP tiles as fp16-pair products on the f16 matrix cores (0: exact fp32 MFMA).  attn_f16_default(): 1 unless
 // RAL_ATTN_F16=0 (what the handle-free operator entry points use; a model handle follows its f16_split option)
 int attn_f16_default();
@@ -119,11 +120,14 @@ size_t attn_bwd_mh_scratch_floats(int N, int H, int Len, bool table, int B);
 void launch_attn_bwd_mh(const float* qkv, const float* o_hm, const float* do_hm, const float* lse, const float* table,
                         float* gtable, float* dqkv, float* tpart, int N, int H, int Len, int B, hipStream_t s);
 size_t qkv_bwd_lds(int C, int N);
-void launch_qkv_bwd(int C, const float* dqkv, const float* x, const float* pe, const float* dx1, const float* extra,
+// returns true when the projection's weight / bias gradients were produced here (narrow levels: qkv_bwd_fuses_dw): the caller
+// then skips that product in launch_block_dw
+bool qkv_bwd_fuses_dw(int C, int N);
+bool launch_qkv_bwd(int C, const float* dqkv, const float* x, const float* pe, const float* dx1, const float* extra,
                     const BlockP& w, const BlockP& wt, const float* ptbase, const void* wtt /* as launch_mlp_bwd */, unsigned* gmax,
-                    const BlockP& gr, float* dx, int N, int B, hipStream_t s);
+                    const BlockP& gr, float* dx, int N, int B, bool want_dw, hipStream_t s);
 void launch_resample_bwd(int D, bool sep, const float* dy, const float* x, const float* wred, const float* lnw,
-                         float* g_lnw, float* g_lnb, float* dx, int T, int B, hipStream_t s);
+                         float* g_lnw, float* g_lnb, float* dx, int T, int Tv, int B, hipStream_t s);
 void launch_final_bwd(int leads, const float* dy, const float* u0, const float* x0, const float* w, float* gw,
                       float* gb, float* dz, int L, int Lp, int B, hipStream_t s);
 void launch_bn8_bwd_stats(const float* dy, const float* a0, const float* ss, double* out, size_t ntok, hipStream_t s);
@@ -135,10 +139,11 @@ void launch_conv1_bwd_dx(int leads, const float* dz, const float* w, float* dx, 
 // ---- weight gradients (ral_dw.hip)
 void launch_block_dw(int C, const float* dx2, const float* upre, const float* a2c0, const float* dupre, const float* x1,
                      const float* dx1, const float* o_hm, const float* dqkv, const float* x, const float* pe,
-                     const BlockP& w, const BlockP& gr, int N, int B, int ksplit, bool skip_mlp, const unsigned* gmax /* 4 maxima of the split data-gradient kernels, or nullptr */, hipStream_t s);
+                     const BlockP& w, const BlockP& gr, int N, int B, int ksplit, bool skip_mlp, const unsigned* gmax /* 4 maxima of the split data-gradient kernels, or nullptr */, hipStream_t s,
+                     bool skip_qkv = false /* the projection's weight gradient was formed inside k_qkv_bwd */);
 void set_dw_lds_budget(size_t bytes);
 void launch_resample_dw(int D, bool sep, const float* dy, const float* x, const float* lnw, const float* lnb,
-                        float* dW, int T, int B, int ksplit, hipStream_t s);
+                        float* dW, int T, int Tv, int B, int ksplit, hipStream_t s);
 
 // db8 wavelet-threshold baseline (ral_wavelet.hip); non-zero = rejected arguments
 int launch_wavelet_denoise(const float* x, float* y, long long rows, int L, float threshold, hipStream_t s);

@@ -84,7 +84,7 @@ def test_pe_table_matches_reference(golden_dir):
 
 
 @pytest.mark.parametrize("kw,msg", [
-    (dict(L=500), "multiple of 256"), (dict(L=2048), "multiple of 256"), (dict(leads=3), "leads"),
+    (dict(L=500), "multiple of 16"), (dict(L=2048), "multiple of 16"), (dict(L=16), "at least 32"), (dict(leads=3), "leads"),
     (dict(max_batch=0), "max_batch"),
 ])
 def test_config_validation(kw, msg):

@@ -41,8 +41,24 @@ def test_train_step_matches_oracle(variant, leads, L, B):
     _check(res)
 
 
+@pytest.mark.parametrize("variant,leads,L,B", [
+    ("nra", 2, 128, 3), ("nra", 2, 320, 2), ("full", 2, 640, 2), ("full", 1, 128, 5), ("mlp", 2, 320, 3), ("full", 2, 96, 2),
+    ("nra", 1, 16, 4), ("full", 2, 1008, 1), ("full", 2, 32, 2),
+])
+def test_window_lengths_that_are_multiples_of_16_match_oracle(variant, leads, L, B):
+    """The reference runs at any window length that is a multiple of 16 (raletransformer.py:170,448-450: four PatchMerging
+    halvings; its positional table ends at 1000); here such a length runs on the next multiple of 256 token slots with the
+    missing tokens masked - attention keys, the zero halo of the local-enhancement conv and of the stem / output convs,
+    BatchNorm statistics, PatchSeparate's row order - and their gradients exactly zero.  Outputs, loss, metrics, BatchNorm
+    running statistics and every parameter gradient against the fp64 oracle, as for the other lengths: 128, 320, 640 (the
+    review's list), 96 / 32 / 16 (fewer than 16 tokens at the deep levels), 1008 (one tile short of 1024)."""
+    res, _, _ = run_parity(variant, leads, L, B, DEV, trace=False)
+    _check(res)
+
+
 @pytest.mark.parametrize("variant,leads,L", [("nra", 2, 512), ("full", 2, 256), ("mlp", 2, 256), ("full", 2, 512),
-                                             ("full", 1, 512), ("full", 2, 1024)])
+                                             ("full", 1, 512), ("full", 2, 1024), ("nra", 2, 320), ("nra", 2, 128),
+                                             ("full", 2, 640)])
 def test_against_reference_golden(variant, leads, L, golden_dir):
     """Same weights/inputs as oracle/gen_golden.py fed to the reference itself."""
     from ecg_denoise_amd import RALENet

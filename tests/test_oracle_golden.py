@@ -89,8 +89,9 @@ def test_patch_modules(golden_dir):
     assert np.array_equal(b.numpy(), g["rw_bias"])
 
 
+# (the last three: window lengths that are multiples of 16 but not of 256 - oracle/gen_golden_r6.py)
 CASES = [("nra", 2, 512), ("nra", 2, 256), ("full", 2, 256), ("mlp", 2, 256), ("full", 2, 512),
-         ("full", 1, 512), ("full", 2, 1024)]
+         ("full", 1, 512), ("full", 2, 1024), ("nra", 2, 320), ("nra", 2, 128), ("full", 2, 640)]
 
 
 @pytest.mark.parametrize("variant,leads,L", CASES)
