@@ -42,7 +42,7 @@ static const char* const KNOB_NAMES[] = {
   "DANET_GRID_B", "DANET_GRID_D", "DANET_GRID_F", "DANET_GRID_W", "DIAG_SKIP_WIDE_DW", "DW_F16", "DW_KSPLIT_128", "DW_KSPLIT_16",
   "DW_KSPLIT_32", "DW_KSPLIT_64", "DW_KSPLIT_8", "DW_LDS", "DW_PRIO", "DW_SETS", "F16_SPLIT", "FUSE_DW", "GRID_ATTNB", 
   "GRID_ATTNW", "GRID_FWD", "GRID_MLPB", "GRID_MLPBW", "GRID_MLPS", "GRID_MLPW", "GRID_QKVB", "GRID_QKVW", "GRID_RESB", "LOSS_GRID",
-  "MLP_BWD_W", "MLP_BWD_W_F16", "MLP_F16", "MLP_FWD_W", "MLP_HLDS", "MLP_HTHREADS", "MLP_LDS", "MLP_TOK", "PREP_OVERLAP", "QKVB_F16", "QKVB_FDW", "QKV_WS", "UNET_BWD_GRID",
+  "MLP_BWD_W", "MLP_BWD_W_F16", "MLP_F16", "MLP_FWD_W", "MLP_HLDS", "MLP_HTHREADS", "MLP_LDS", "MLP_TOK", "PREP_OVERLAP", "QKVB_F16", "QKVB_FDW", "TABRED_SIDE", "QKV_WS", "UNET_BWD_GRID",
   "UNET_BWD_WP", "UNET_DEBUG", "UNET_EVAL_GRID", "UNET_FOLD", "UNET_FUSED", "UNET_FWD_GRID", "UNET_NREP", "UNET_WG_PER_CU"};
 static std::mutex g_knob_mu;
 static std::map<std::string, long long>& knob_table() { static std::map<std::string, long long> t; return t; }
@@ -561,7 +561,7 @@ template <class T> static inline T* woff(T* p, int w0, size_t per_window) { retu
 // ---------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------
-static void run_block_fwd(RalModel* m, int bi, const float* in, bool training, const Lane& ln) {
+static void run_block_fwd(RalModel* m, int bi, const float* in, bool training, const Lane& ln, const float* addend = nullptr, float* sum_out = nullptr) {
   const int si = bi / 2, l = STAGES[si].level, C = CH[l], N = m->Lp >> l, H = C / 4;
   const size_t E1 = m->E1;
   BlockP w = block_ptrs(m->lay.blk[bi], m->params);
@@ -588,7 +588,7 @@ static void run_block_fwd(RalModel* m, int bi, const float* in, bool training, c
   { ProfScope p(m, K_MLP_FWD, s);
     launch_mlp_fwd(C, m->nch_f[l], x, o, w, m->params, split ? m->wh : nullptr, training ? woff(a.x1, w0, E1) : nullptr,
                    (training && !mlp_bwd_is_fused(C, N)) ? woff(a.upre, w0, 4 * E1) : nullptr,
-                   woff(a.out, w0, E1), N, B, (m->f16_split > 0 && m->narrow_f16) ? 1 : 0, s, NE); }
+                   woff(a.out, w0, E1), N, B, (m->f16_split > 0 && m->narrow_f16) ? 1 : 0, s, NE, woff(addend, w0, E1), woff(sum_out, w0, E1)); }
 }
 
 static const float* run_stage_fwd(RalModel* m, int si, const float* in, bool training, const Lane& ln) {
@@ -700,9 +700,9 @@ static int fwd_end(RalModel* m, float* y, int B, int64_t global_windows, int tra
   }
   for (int k = 0; k < nl; ++k) {
     const Lane& ln = LS->l[k];
-    run_stage_fwd(m, 4, cur, tr, ln);
-    launch_add(woff(m->act[9].out, ln.w0, m->E1), woff(m->res_out[3], ln.w0, m->E1), woff(m->xmid, ln.w0, m->E1),
-               (size_t)ln.B * m->E1, ln.s);
+    // x_mid = transformer(x4) + x4 (raletransformer.py:659): the second output of the bottleneck's last MLP kernel
+    run_block_fwd(m, 8, cur, tr, ln);
+    run_block_fwd(m, 9, m->act[8].out, tr, ln, m->res_out[3], m->xmid);
   }
   cur = m->xmid;
   for (int i = 0; i < 4; ++i) {
@@ -759,11 +759,17 @@ static void run_block_bwd(RalModel* m, int bi, const float* dy, const float* ext
   const int NE = m->L >> l;
   { ProfScope p(m, K_MLP_BWD, s); fused_mlp_dw = launch_mlp_bwd(C, m->nch_b[l], dyw, x1, upre, w, wt, m->paramsT, splitb ? m->whT : nullptr, gmax, g, dupre, dx1, dohm, a2c0, N, B, m->want_dw, s,
                                                                   (m->f16_split > 0 && m->narrow_f16) ? 1 : 0, NE); }
+  // the R-wave table gradient leaves the one-sweep attention kernels as one row of partials per workgroup; the kernel that adds
+  // the rows up runs with the block's weight-gradient kernels (side stream), not on the chain: nothing on the chain reads it
+  AttnTabReduce tabred{nullptr, nullptr, 0, 0};
+  static const bool tab_side = ral_knob("TABRED_SIDE", 1) != 0;
   { ProfScope p(m, K_ATTN_BWD, s);
+    if (side && tab_side) attn_tab_defer_to(&tabred);
     // (each lane's scratch: its share of the stat2 region followed by its share of the partials region)
     float* scratch = m->astat[k] + (size_t)w0 * (E1 / 2 + 2048);
     launch_attn_bwd(qkv, o, dohm, lse, table, gtable, dqkv, scratch, (size_t)B * (E1 / 2 + 2048), N, H, m->hg_b[l], Len, B,
-                    (m->f16_split > 0 && m->attn_f16) ? 1 : 0, s, NE); }
+                    (m->f16_split > 0 && m->attn_f16) ? 1 : 0, s, NE);
+    attn_tab_defer_to(nullptr); }
   bool fused_qkv_dw;
   { ProfScope p(m, K_QKV_BWD, s);
     fused_qkv_dw = launch_qkv_bwd(C, dqkv, xin, m->pe[l], dx1, woff(extra, w0, E1), w, wt, m->paramsT, splitb ? m->whT : nullptr, gmax, g, woff(dx, w0, E1), N, B, m->want_dw, s); }
@@ -772,6 +778,7 @@ static void run_block_bwd(RalModel* m, int bi, const float* dy, const float* ext
     EV(hipEventRecord(ln.ev_ready[k], s));
     EV(hipStreamWaitEvent(sd, ln.ev_ready[k], 0));
   }
+  if (tabred.ntab > 0) launch_attn_tpart_reduce(tabred.tpart, tabred.gtable, tabred.ntab, tabred.nrow, sd);
   { ProfScope p(m, K_DW, sd);
 #ifdef RAL_DIAG   // diagnostic builds only (make VARIANT=diag EXTRA=-DRAL_DIAG; WRONG gradients): what the weight-gradient kernels of the levels C >= RAL_DIAG_SKIP_WIDE_DW cost the step
     static const int skipw = (int)ral_knob("DIAG_SKIP_WIDE_DW", 0);

@@ -392,7 +392,13 @@ __global__ __launch_bounds__(256) void k_attn_tpart_reduce(const float* __restri
   if (lane == 0) atomicAdd(gtable + i, t);
 }
 
+// A caller that wants the reduction somewhere else than behind the attention kernel on the chain stream (ral_api.hip runs it on
+// the block's weight-gradient stream: nothing on the chain reads the table gradient) sets this slot around launch_attn_bwd; the
+// reduction is then recorded instead of launched.
+thread_local AttnTabReduce* g_attn_tab_defer = nullptr;
+void attn_tab_defer_to(AttnTabReduce* slot) { g_attn_tab_defer = slot; if (slot) slot->ntab = 0; }
 void launch_attn_tpart_reduce(const float* tpart, float* gtable, int ntab, int nrow, hipStream_t s) {
+  if (g_attn_tab_defer) { *g_attn_tab_defer = AttnTabReduce{tpart, gtable, ntab, nrow}; return; }
   k_attn_tpart_reduce<<<(ntab + 3) / 4, 256, 0, s>>>(tpart, gtable, ntab, nrow);
 }
 
@@ -725,5 +731,5 @@ void launch_attn_bwd_w(const float* qkv, const float* o_hm, const float* do_hm, 
   else { if (table) GOH(128, true) else GOH(128, false) }
 #undef GOH
 #undef GO
-  if (table) k_attn_tpart_reduce<<<(ntab + 3) / 4, 256, 0, s>>>(tpart, gtable, ntab, grid);
+  if (table) launch_attn_tpart_reduce(tpart, gtable, ntab, grid, s);
 }

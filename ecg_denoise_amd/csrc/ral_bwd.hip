@@ -1124,7 +1124,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_vkv(const float* __restrict__ 
 // one pass of coalesced atomics.
 template <int C> struct QkvDwShape {
   static constexpr int TM = (3 * C + 15) / 16, TN = (C + 15) / 16, TILES = TM * TN;
-  static constexpr int KS = C == 32 ? 2 : (C == 16 ? 8 : 4);        // token ranges per tile
+  static constexpr int KS = C == 32 ? 2 : 8;                        // token ranges per tile
   static constexpr int NJ = TILES * KS / 8;                          // jobs per wave (8 waves)
   static_assert(TILES * KS % 8 == 0, "whole jobs per wave");
 };
@@ -1279,8 +1279,11 @@ __global__ __launch_bounds__(512, RAL_QKVB_MINB) void k_qkv_bwd(const float* dqk
     }
     if constexpr (FDW) {
       if (gr.wqkv) {   // (frozen weights, ral_backward_input: no weight gradients)
-        __syncthreads();   // the window's LayerNorm output is in Hl; dqkv still in DQ
+        lds_barrier();   // the window's LayerNorm output is in Hl; dqkv still in DQ (the next window's prefetch stays in flight)
         const int tlen = N / DWS::KS;
+        // the jobs of a wave advance together, 16 tokens at a time: the operand reads of all of them are issued before the
+        // first product, and consecutive MFMAs go to different accumulators
+        const float* Ap[DWS::NJ]; const float* Bp[DWS::NJ];
 #pragma unroll
         for (int j = 0; j < DWS::NJ; ++j) {
           const int job = wave + 8 * j, tile = job % DWS::TILES, kpart = job / DWS::TILES;
@@ -1288,19 +1291,24 @@ __global__ __launch_bounds__(512, RAL_QKVB_MINB) void k_qkv_bwd(const float* dqk
           int am = mi * 16 + r, bc = nj * 16 + r;                 // operand columns of this lane, clamped into the matrix
           am = am < 3 * C ? am : 3 * C - 1;
           bc = bc < C ? bc : C - 1;
-          const float* Ap = DQ + ((am >> 2) * N) * 4 + (am & 3);   // dqkv[t][am] at Ap[4 t] (head-major quads)
-          const float* Bp = Hl + bc;                               // LN1(x)[t][bc] at Bp[t LD]
-          for (int t0 = kpart * tlen; t0 < (kpart + 1) * tlen; t0 += 16) {
-#pragma unroll
-            for (int s_ = 0; s_ < 4; ++s_) {
-              const int t = t0 + 4 * g + s_;
-              const float av = Ap[4 * t], bv = Bp[t * LD];
-              accw[j] = mfma4(av, bv, accw[j]);
-              bsw[j] += av;
-            }
-          }
+          Ap[j] = DQ + ((am >> 2) * N + kpart * tlen + 4 * g) * 4 + (am & 3);   // dqkv[t][am] at + 4 t (head-major quads)
+          Bp[j] = Hl + (kpart * tlen + 4 * g) * LD + bc;                        // LN1(x)[t][bc] at + t LD
         }
-        __syncthreads();   // DQ may take the next window now
+        for (int t0 = 0; t0 < tlen; t0 += 16) {
+          float av[DWS::NJ][4], bv[DWS::NJ][4];
+#pragma unroll
+          for (int j = 0; j < DWS::NJ; ++j)
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) { av[j][s_] = Ap[j][4 * (t0 + s_)]; bv[j][s_] = Bp[j][(t0 + s_) * LD]; }
+#pragma unroll
+          for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+            for (int j = 0; j < DWS::NJ; ++j) {
+              accw[j] = mfma4(av[j][s_], bv[j][s_], accw[j]);
+              bsw[j] += av[j][s_];
+            }
+        }
+        lds_barrier();   // DQ may take the next window now
       }
     }
     if (more) {
@@ -2115,7 +2123,8 @@ size_t qkv_bwd_lds(int C, int N) { return ((size_t)N * 3 * C + (size_t)N * ld_of
 bool qkv_bwd_fuses_dw(int C, int N) {
   static const bool on = (ral_knob("QKVB_FDW", 1) != 0);
   if (!on || C > 32) return false;
-  const int ks = C == 32 ? 2 : (C == 16 ? 8 : 4);
+  const int ks = C == 32 ? 2 : 8;
+  if (qkv_bwd_lds(C, N) + (size_t)N * ld_of(C) * sizeof(float) > 156 * 1024) return false;   // (C = 8 at 1024 tokens: the LayerNorm-output tile does not fit)
   return N % (16 * ks) == 0;
 }
 

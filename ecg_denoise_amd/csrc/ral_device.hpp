@@ -623,6 +623,11 @@ RAL_DEV void copy_flat(float* dst, const float* __restrict__ src, int n4) {
   for_each_f4<4>(src, n4, [&](int i, float4 v) { reinterpret_cast<float4*>(dst)[i] = v; });
 }
 
+// Workgroup barrier that orders LDS accesses ONLY: __syncthreads() also waits for every outstanding GLOBAL load of the wave
+// (s_waitcnt vmcnt(0) in front of s_barrier), which puts the HBM round trip of a prefetch issued earlier back on the critical
+// path; here the prefetched values stay in flight (the compiler waits for them where their registers are first used).
+RAL_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // PatchSeparate's token order (reference quirk A5: the output rows are [first channel halves of all input tokens ; second
 // halves]) on a window of T output slots of which the first Tv exist (Tv <= T, both even; a window length that is not a multiple
 // of 256 runs on padded slots, ral_api.hip): output row `row` reads / back-propagates into input slot l, channel half c1 - float

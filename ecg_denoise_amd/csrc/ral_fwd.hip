@@ -724,7 +724,8 @@ template <int C, int NCH>
 __global__ __launch_bounds__(512) void k_mlp_fwd(const float* __restrict__ x, const float* __restrict__ o_hm,
                                                  BlockP w, float* __restrict__ x1_out,
                                                  float* __restrict__ upre_out, float* __restrict__ x2_out,
-                                                 int N, int B, int NE /* existing tokens of the N slots (padded windows: < N) */) {
+                                                 int N, int B, int NE /* existing tokens of the N slots (padded windows: < N) */,
+                                                 const float* __restrict__ addend, float* __restrict__ sum_out /* optional: sum_out = block output + addend (the bottleneck's x_mid = transformer(x4) + x4, raletransformer.py:659) */) {
   extern __shared__ float4 smem4[];
   constexpr int LD = LDof<C>::v, HC = 4 * C / NCH, LDU = LDof<HC>::v, LPR = C / 4;
   float* Xs = reinterpret_cast<float*>(smem4);  // N x LD   : x -> x1 -> x2
@@ -786,6 +787,8 @@ __global__ __launch_bounds__(512) void k_mlp_fwd(const float* __restrict__ x, co
     RAL_STAMP_AT(3);
     float* upw = upre_out ? upre_out + (size_t)win * N * 4 * C : nullptr;
     float* x2w = x2_out + wo;
+    const float* addw = sum_out ? addend + wo : nullptr;
+    float* sumw = sum_out ? sum_out + wo : nullptr;
 #pragma unroll 1
     for (int ch = 0; ch < NCH; ++ch) {
       const int j0 = ch * HC;
@@ -815,7 +818,10 @@ __global__ __launch_bounds__(512) void k_mlp_fwd(const float* __restrict__ x, co
         float4* px = reinterpret_cast<float4*>(Xs + tok * LD + row0);
         float4 v = f4add(*px, tofloat4(a));
         if (ch == 0) v = f4add(v, *reinterpret_cast<const float4*>(w.b2 + row0));
-        if (ch == NCH - 1) *reinterpret_cast<float4*>(x2w + (size_t)tok * C + row0) = v;   // block output
+        if (ch == NCH - 1) {
+          *reinterpret_cast<float4*>(x2w + (size_t)tok * C + row0) = v;   // block output
+          if (sumw) *reinterpret_cast<float4*>(sumw + (size_t)tok * C + row0) = f4add(v, *reinterpret_cast<const float4*>(addw + (size_t)tok * C + row0));
+        }
         else *px = v;
       });
       __syncthreads();
@@ -839,7 +845,7 @@ __global__ __launch_bounds__(NTH, 4) void k_mlp_fwd_h(const float* __restrict__ 
                                                    BlockP w, const float* __restrict__ pbase, const _Float16* __restrict__ wt,
                                                    float* __restrict__ x1_out,
                                                    float* __restrict__ upre_out, float* __restrict__ x2_out,
-                                                   int N, int B, int WPI) {
+                                                   int N, int B, int WPI, const float* __restrict__ addend, float* __restrict__ sum_out /* see k_mlp_fwd */) {
   extern __shared__ float4 smem4[];
   constexpr int LD = LDof<C>::v, HC = 4 * C / NCH, LDG = ldb_of(C), LDU = ldb_of(HC), LPR = C / 4, RPP = NTH / LPR;
   typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -915,6 +921,8 @@ __global__ __launch_bounds__(NTH, 4) void k_mlp_fwd_h(const float* __restrict__ 
     RAL_STAMP_AT(3);
     float* upw = upre_out ? upre_out + wo * 4 : nullptr;
     float* x2w = x2_out + wo;
+    const float* addw = sum_out ? addend + wo : nullptr;
+    float* sumw = sum_out ? sum_out + wo : nullptr;
 #pragma unroll 1
     for (int ch = 0; ch < NCH; ++ch) {
       const int j0 = ch * HC;
@@ -942,7 +950,10 @@ __global__ __launch_bounds__(NTH, 4) void k_mlp_fwd_h(const float* __restrict__ 
       gemm_phase_h2<HC>(w2h, 4 * C / 32, 0, j0 / 32, C, ch == 0 ? w.b2 : nullptr, wun2, Uh, uplane, LDU, T >> 4, [&](int row0, int tok, f32x4 a) {
         float4* px = reinterpret_cast<float4*>(Xs + tok * LD + row0);
         const float4 v = f4add(*px, tofloat4(a));
-        if (ch == NCH - 1) *reinterpret_cast<float4*>(x2w + (size_t)tok * C + row0) = v;   // block output
+        if (ch == NCH - 1) {
+          *reinterpret_cast<float4*>(x2w + (size_t)tok * C + row0) = v;   // block output
+          if (sumw) *reinterpret_cast<float4*>(sumw + (size_t)tok * C + row0) = f4add(v, *reinterpret_cast<const float4*>(addw + (size_t)tok * C + row0));
+        }
         else *px = v;
       });
       __syncthreads();
@@ -1118,11 +1129,11 @@ size_t mlp_fwd_lds(int C, int N, int nch) {
 
 template <int C>
 static void launch_mlp_fwd_c(int nch, const float* x, const float* o, const BlockP& w, float* x1, float* upre,
-                             float* x2, int N, int B, hipStream_t s, int NE) {
+                             float* x2, int N, int B, hipStream_t s, int NE, const float* addend, float* sum_out) {
   const size_t lds = mlp_fwd_lds(C, N, nch);
-  if (nch == 1) { RAL_SET_LDS((k_mlp_fwd<C, 1>), lds); k_mlp_fwd<C, 1><<<grid_for(B), 512, lds, s>>>(x, o, w, x1, upre, x2, N, B, NE); }
-  else if (nch == 2) { RAL_SET_LDS((k_mlp_fwd<C, 2>), lds); k_mlp_fwd<C, 2><<<grid_for(B), 512, lds, s>>>(x, o, w, x1, upre, x2, N, B, NE); }
-  else { RAL_SET_LDS((k_mlp_fwd<C, 4>), lds); k_mlp_fwd<C, 4><<<grid_for(B), 512, lds, s>>>(x, o, w, x1, upre, x2, N, B, NE); }
+  if (nch == 1) { RAL_SET_LDS((k_mlp_fwd<C, 1>), lds); k_mlp_fwd<C, 1><<<grid_for(B), 512, lds, s>>>(x, o, w, x1, upre, x2, N, B, NE, addend, sum_out); }
+  else if (nch == 2) { RAL_SET_LDS((k_mlp_fwd<C, 2>), lds); k_mlp_fwd<C, 2><<<grid_for(B), 512, lds, s>>>(x, o, w, x1, upre, x2, N, B, NE, addend, sum_out); }
+  else { RAL_SET_LDS((k_mlp_fwd<C, 4>), lds); k_mlp_fwd<C, 4><<<grid_for(B), 512, lds, s>>>(x, o, w, x1, upre, x2, N, B, NE, addend, sum_out); }
 }
 
 // wide levels on split fp16 operands (RAL_MLP_F16=0: the fp32-MFMA kernel everywhere)
@@ -1147,32 +1158,32 @@ static void mlp_fwd_h_plan(int C, int N, int B, int* wpi_out, int* nch_out) {
 }
 template <int C, int NTH>
 static void launch_mlp_fwd_hc(const float* x, const float* o, const BlockP& w, const float* pbase, const void* wh,
-                              float* x1, float* upre, float* x2, int N, int B, hipStream_t s) {
+                              float* x1, float* upre, float* x2, int N, int B, hipStream_t s, const float* addend, float* sum_out) {
   int wpi, nch;
   mlp_fwd_h_plan(C, N, B, &wpi, &nch);
   const size_t lds = mlp_fwd_h_lds(C, wpi * N, nch);
   const _Float16* whp = reinterpret_cast<const _Float16*>(wh);
   const int grid = grid_for(B / wpi);
-  if (nch == 1) { RAL_SET_LDS((k_mlp_fwd_h<C, 1, NTH>), lds); k_mlp_fwd_h<C, 1, NTH><<<grid, NTH, lds, s>>>(x, o, w, pbase, whp, x1, upre, x2, N, B, wpi); }
-  else if (nch == 2) { RAL_SET_LDS((k_mlp_fwd_h<C, 2, NTH>), lds); k_mlp_fwd_h<C, 2, NTH><<<grid, NTH, lds, s>>>(x, o, w, pbase, whp, x1, upre, x2, N, B, wpi); }
-  else { RAL_SET_LDS((k_mlp_fwd_h<C, 4, NTH>), lds); k_mlp_fwd_h<C, 4, NTH><<<grid, NTH, lds, s>>>(x, o, w, pbase, whp, x1, upre, x2, N, B, wpi); }
+  if (nch == 1) { RAL_SET_LDS((k_mlp_fwd_h<C, 1, NTH>), lds); k_mlp_fwd_h<C, 1, NTH><<<grid, NTH, lds, s>>>(x, o, w, pbase, whp, x1, upre, x2, N, B, wpi, addend, sum_out); }
+  else if (nch == 2) { RAL_SET_LDS((k_mlp_fwd_h<C, 2, NTH>), lds); k_mlp_fwd_h<C, 2, NTH><<<grid, NTH, lds, s>>>(x, o, w, pbase, whp, x1, upre, x2, N, B, wpi, addend, sum_out); }
+  else { RAL_SET_LDS((k_mlp_fwd_h<C, 4, NTH>), lds); k_mlp_fwd_h<C, 4, NTH><<<grid, NTH, lds, s>>>(x, o, w, pbase, whp, x1, upre, x2, N, B, wpi, addend, sum_out); }
 }
 
 void launch_mlp_fwd(int C, int nch, const float* x, const float* o, const BlockP& w, const float* pbase, const void* wh,
-                    float* x1, float* upre, float* x2, int N, int B, int f16_narrow, hipStream_t s, int NE) {
+                    float* x1, float* upre, float* x2, int N, int B, int f16_narrow, hipStream_t s, int NE, const float* addend, float* sum_out) {
   if (NE <= 0 || NE > N) NE = N;
   const bool padded = NE < N;   // padded windows: the generic kernel (its local-enhancement conv knows where the window ends)
   if (!padded && wh && mlp_fwd_uses_f16(C, N)) {
     static const int nth = (int)ral_knob("MLP_HTHREADS", 512);
-    if (C == 32) launch_mlp_fwd_hc<32, 512>(x, o, w, pbase, wh, x1, upre, x2, N, B, s);
-    else if (C == 64) { if (nth == 1024) launch_mlp_fwd_hc<64, 1024>(x, o, w, pbase, wh, x1, upre, x2, N, B, s); else launch_mlp_fwd_hc<64, 512>(x, o, w, pbase, wh, x1, upre, x2, N, B, s); }
-    else { if (nth == 1024) launch_mlp_fwd_hc<128, 1024>(x, o, w, pbase, wh, x1, upre, x2, N, B, s); else launch_mlp_fwd_hc<128, 512>(x, o, w, pbase, wh, x1, upre, x2, N, B, s); }
+    if (C == 32) launch_mlp_fwd_hc<32, 512>(x, o, w, pbase, wh, x1, upre, x2, N, B, s, addend, sum_out);
+    else if (C == 64) { if (nth == 1024) launch_mlp_fwd_hc<64, 1024>(x, o, w, pbase, wh, x1, upre, x2, N, B, s, addend, sum_out); else launch_mlp_fwd_hc<64, 512>(x, o, w, pbase, wh, x1, upre, x2, N, B, s, addend, sum_out); }
+    else { if (nth == 1024) launch_mlp_fwd_hc<128, 1024>(x, o, w, pbase, wh, x1, upre, x2, N, B, s, addend, sum_out); else launch_mlp_fwd_hc<128, 512>(x, o, w, pbase, wh, x1, upre, x2, N, B, s, addend, sum_out); }
     return;
   }
-  if (!padded)
+  if (!padded && !sum_out)
     if (const int kind = mlp_fwd_w_kind(C, N, upre != nullptr, f16_narrow != 0)) { launch_mlp_fwd_w(C, kind, x, o, w, x1, x2, N, B, s); return; }   // narrow levels: ral_mlpw.hip
   switch (C) {
-#define CASE(c) case c: launch_mlp_fwd_c<c>(nch, x, o, w, x1, upre, x2, N, B, s, NE); break;
+#define CASE(c) case c: launch_mlp_fwd_c<c>(nch, x, o, w, x1, upre, x2, N, B, s, NE, addend, sum_out); break;
     CASE(8) CASE(16) CASE(32) CASE(64) CASE(128)
 #undef CASE
   }

@@ -35,7 +35,8 @@ size_t mlp_fwd_lds(int C, int N, int nch);
 bool mlp_fwd_uses_f16(int C, int N);
 // f16_narrow: the model allows fp16-pair products (f16_split > 0): the narrow levels may take their f16 strip kernel
 void launch_mlp_fwd(int C, int nch, const float* x, const float* o, const BlockP& w, const float* pbase, const void* wt,
-                    float* x1, float* upre, float* x2, int N, int B, int f16_narrow, hipStream_t s, int NE = 0 /* existing tokens; see launch_attn_fwd */);
+                    float* x1, float* upre, float* x2, int N, int B, int f16_narrow, hipStream_t s, int NE = 0 /* existing tokens; see launch_attn_fwd */,
+                    const float* addend = nullptr, float* sum_out = nullptr /* optional second output: block output + addend */);
 // narrow levels (C <= 32), wave-autonomous (ral_mlpw.hip): kind 0 = not taken, 1 = fp32-MFMA strips, 2 = f16 strips
 int mlp_fwd_w_kind(int C, int N, bool want_upre, bool f16_ok);
 bool mlp_fwd_w_takes(int C, int N, bool want_upre);
@@ -110,6 +111,11 @@ void launch_attn_bwd_w(const float* qkv, const float* o_hm, const float* do_hm, 
                        float* gtable, float* dqkv, float* tpart, int N, int H, int Len, int B, int f16, hipStream_t s);
 int attnw_grid_max(int N, int H, int B);   // upper bound of the wave-autonomous kernels' grids (what their scratch is sized for)
 void launch_attn_tpart_reduce(const float* tpart, float* gtable, int ntab, int nrow, hipStream_t s);
+// deferred form: while a slot is set (attn_tab_defer_to(&slot) ... attn_tab_defer_to(nullptr)), launch_attn_tpart_reduce records
+// its arguments there (ntab > 0) instead of launching; the caller launches it later with launch_attn_tpart_reduce on the stream of
+// its choice (after un-setting the slot)
+struct AttnTabReduce { const float* tpart; float* gtable; int ntab, nrow; };
+void attn_tab_defer_to(AttnTabReduce* slot);
 // one sweep, every contraction on the f16 matrix cores (ral_attnm.hip; only with f16 != 0)
 bool attn_bwd_m_takes(int N, int H, int Len, bool table);
 size_t attn_bwd_m_scratch_floats(int N, int H, int Len, bool table, int B);

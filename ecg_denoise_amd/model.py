@@ -406,8 +406,9 @@ class _ModuleBase(_AutogradMixin):
 class RALENet(_ModuleBase):
     """variant: "nra" = model/raletransformer.py::ralenet(), "full" =
     model/transformer.py::ralenet(high_level_enhence=True), "mlp" = ...(low_level_enhence=False)
-    (main.py:69-77), generalised to `leads` in {1,2} and `L` in {256,512,768,1024} the way
-    SURVEY §8c states (R-wave window stays centred, Len constants unchanged)."""
+    (main.py:69-77), generalised to `leads` in {1,2} and any `L` that is a multiple of 16 up to 1024 the way
+    SURVEY §8c states (R-wave window stays centred in the level's tokens, Len constants unchanged).  Multiples of 256 are the
+    fast shapes; other lengths run on padded token slots with the missing tokens masked (fp32 MFMA kernels)."""
 
     def __init__(self, variant="full", leads=2, L=512, max_batch=32, train=True, device="cuda:0", seed=None, autograd=False):
         if variant not in ("nra", "full", "mlp"):
