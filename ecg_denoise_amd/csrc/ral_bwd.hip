@@ -2119,9 +2119,14 @@ void launch_attn_bwd(const float* qkv, const float* o_hm, const float* do_hm, co
 }
 
 size_t qkv_bwd_lds(int C, int N) { return ((size_t)N * 3 * C + (size_t)N * ld_of(C) + 5 * C + 8) * sizeof(float); }
-// the narrow levels form the projection's weight gradient inside k_qkv_bwd (QKVB_FDW = 0: the separate launch of ral_dw.hip)
+// QKVB_FDW = 1: the narrow levels form the projection's weight gradient inside k_qkv_bwd instead of the separate launch of
+// ral_dw.hip.  Built in round 6 for its HBM bytes (-4E per narrow block: 0.5 GB of the step's 33 GB) and measured: the
+// weight-gradient kind 2.91 -> 2.51 ms per step serialised, k_qkv_bwd 1.10 -> 1.35 ms - and the STEP 0.06 ms slower (12.90 ->
+// 12.96 ms, same box, three interleaved rounds): the separate launch runs on the side stream and is bound by HBM, which the
+// chain kernels beside it leave idle; inside k_qkv_bwd the same product is fp32-MFMA tiles fed by 4-byte LDS reads on the
+// critical path.  Default OFF; the switch and tests/test_gpu_configs.py keep it alive.
 bool qkv_bwd_fuses_dw(int C, int N) {
-  static const bool on = (ral_knob("QKVB_FDW", 1) != 0);
+  static const bool on = (ral_knob("QKVB_FDW", 0) != 0);
   if (!on || C > 32) return false;
   const int ks = C == 32 ? 2 : 8;
   if (qkv_bwd_lds(C, N) + (size_t)N * ld_of(C) * sizeof(float) > 156 * 1024) return false;   // (C = 8 at 1024 tokens: the LayerNorm-output tile does not fit)

@@ -70,3 +70,4 @@ def train(epochs, model, batch_size, train_loader, test_loader, use_gpu=True, mo
         f.write(f"{model_name}_{epoch}_{noise_name}_intensity{noise_intensity}:snr:{test_snr}, rmse:{test_rmse}\n")
     train.last_losses = (train_loss_list, eval_loss_list)
     return train_snr_list, test_snr_list, train_rmse_list, test_rmse_list
+

@@ -7,8 +7,10 @@ import pytest
 import torch
 
 import ralenet_oracle as O
+from parity_util import rel
 
 pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
 
 
 def batches(x, y, bs):
@@ -105,3 +107,4 @@ def test_full_protocol_end_of_training_inside_the_reference_spread(golden_dir, t
     s = float(last10.std(ddof=1))
     assert last10.min() - s <= mine <= last10.max() + s, (runs, last10)
     assert abs(mine - last10.mean()) < 0.3, (runs, last10)
+
