@@ -364,7 +364,7 @@ struct RalModel {
   // weight preparation under the stem: the split planes of this forward (and, in training, the transposes + their planes for
   // its backward) are formed on lane 0's weight-gradient stream - idle during a forward - while the caller's stream runs the
   // stem conv / BatchNorm; fwd_end / bwd_begin wait for the events instead of launching the kernels (side_stream = 0: inline)
-  hipEvent_t ev_prep_go = nullptr, ev_prep_fwd = nullptr, ev_prep_bwd = nullptr;
+  hipEvent_t ev_prep_go = nullptr, ev_prep_asc = nullptr, ev_prep_fwd = nullptr, ev_prep_bwd = nullptr;   // (asc: the activation scales, which every level's kernels read; fwd: the weight planes of the wide levels)
   bool prep_fwd = false, prep_bwd = false;
   bool prep_stale = false;   // parameters or arithmetic options changed after the preparation was queued: the backward re-builds its planes
   bool bwd_recorded = false;
@@ -650,10 +650,9 @@ static int fwd_begin(RalModel* m, const float* x, int B, int training, hipStream
     hipStream_t ps = lanes_of(m)->l[0].s2;
     HIP_OK(hipEventRecord(m->ev_prep_go, s));            // (the parameters are final: everything queued on s so far has run)
     HIP_OK(hipStreamWaitEvent(ps, m->ev_prep_go, 0));
-    if (m->f16_split > 0) {
-      launch_act_scales(m->params, m->adesc, m->ascale, 18, ps);
-      launch_tile_planes(m->params, m->wh, m->wdesc, m->ndesc, m->nwork, 0, ps);
-    }
+    if (m->f16_split > 0) launch_act_scales(m->params, m->adesc, m->ascale, 18, ps);
+    HIP_OK(hipEventRecord(m->ev_prep_asc, ps));
+    if (m->f16_split > 0) launch_tile_planes(m->params, m->wh, m->wdesc, m->ndesc, m->nwork, 0, ps);
     HIP_OK(hipEventRecord(m->ev_prep_fwd, ps));
     m->prep_fwd = true;
     if (training) {
@@ -683,7 +682,10 @@ static int fwd_end(RalModel* m, float* y, int B, int64_t global_windows, int tra
     launch_bn_apply8(m->a0, m->ss, m->x0, (size_t)B * m->Lp, s);
   }
   const bool tr = training != 0;
-  if (m->prep_fwd) { HIP_OK(hipStreamWaitEvent(s, m->ev_prep_fwd, 0)); m->prep_fwd = false; }   // split planes of the wide levels' weights: formed under the stem
+  // formed under the stem on an idle stream: the activation scales (waited for here: the narrow levels' kernels read them too) and
+  // the split planes of the wide levels' weights (waited for by every lane in front of the first level that multiplies them)
+  const bool planes_pending = m->prep_fwd;
+  if (m->prep_fwd) { HIP_OK(hipStreamWaitEvent(s, m->ev_prep_asc, 0)); m->prep_fwd = false; }
   else if (m->f16_split > 0) {
     launch_act_scales(m->params, m->adesc, m->ascale, 18, s);
     launch_tile_planes(m->params, m->wh, m->wdesc, m->ndesc, m->nwork, 0, s);
@@ -693,11 +695,19 @@ static int fwd_end(RalModel* m, float* y, int B, int64_t global_windows, int tra
   LaneSet* LS = lanes_of(m);
   // issue stage by stage, alternating lanes, so that the lanes progress together
   const float* cur = m->x0;
+  bool planes_waited = !planes_pending;
+  auto need_planes = [&](int level) {
+    if (planes_waited || !(m->f16_split > 0 && CH[level] >= m->f16_split)) return;
+    for (int k = 0; k < nl; ++k) EV(hipStreamWaitEvent(LS->l[k].s, m->ev_prep_fwd, 0));
+    planes_waited = true;
+  };
   for (int i = 0; i < 4; ++i) {
+    need_planes(i);
     for (int k = 0; k < nl; ++k) run_stage_fwd(m, i, cur, tr, LS->l[k]);
     for (int k = 0; k < nl; ++k) run_res_fwd(m, i, m->act[2 * i + 1].out, nullptr, LS->l[k]);
     cur = m->res_out[i];
   }
+  need_planes(4);
   for (int k = 0; k < nl; ++k) {
     const Lane& ln = LS->l[k];
     // x_mid = transformer(x4) + x4 (raletransformer.py:659): the second output of the bottleneck's last MLP kernel
@@ -716,6 +726,7 @@ static int fwd_end(RalModel* m, float* y, int B, int64_t global_windows, int tra
                      woff(y, ln.w0, (size_t)m->cfg.leads * m->L), m->L, m->Lp, ln.B, ln.s);
   }
   join_lanes(m, s);
+  if (!planes_waited) HIP_OK(hipStreamWaitEvent(s, m->ev_prep_fwd, 0));   // (no level multiplies planes: the preparation stream still joins the caller's)
   HIP_OK(hipGetLastError());
   return sched_check();
 }
@@ -1000,7 +1011,7 @@ static void destroy_model(RalModel* m) {
   }
   for (auto& pr : m->prof_ev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (m->ev_bwd_done) (void)hipEventDestroy(m->ev_bwd_done);
-  for (hipEvent_t e : {m->ev_prep_go, m->ev_prep_fwd, m->ev_prep_bwd}) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : {m->ev_prep_go, m->ev_prep_asc, m->ev_prep_fwd, m->ev_prep_bwd}) if (e) (void)hipEventDestroy(e);
   if (m->slab) (void)hipFree(m->slab);
   delete m;
 }
@@ -1076,6 +1087,7 @@ int ral_create(const ral_config* cfg, ral_handle** out) {
     }
     ok(hipEventCreateWithFlags(&m->ev_bwd_done, hipEventDisableTiming));
     ok(hipEventCreateWithFlags(&m->ev_prep_go, hipEventDisableTiming));
+    ok(hipEventCreateWithFlags(&m->ev_prep_asc, hipEventDisableTiming));
     ok(hipEventCreateWithFlags(&m->ev_prep_fwd, hipEventDisableTiming));
     ok(hipEventCreateWithFlags(&m->ev_prep_bwd, hipEventDisableTiming));
     if (first != hipSuccess) {
