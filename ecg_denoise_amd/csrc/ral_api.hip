@@ -366,6 +366,7 @@ struct RalModel {
   // stem conv / BatchNorm; fwd_end / bwd_begin wait for the events instead of launching the kernels (side_stream = 0: inline)
   hipEvent_t ev_prep_go = nullptr, ev_prep_asc = nullptr, ev_prep_fwd = nullptr, ev_prep_bwd = nullptr;   // (asc: the activation scales, which every level's kernels read; fwd: the weight planes of the wide levels)
   bool prep_fwd = false, prep_bwd = false;
+  bool sums_clean = false;   // bn_sums[0, 32) were zeroed by the optimiser kernel of the previous step (no fill kernel in front of the stem)
   bool prep_stale = false;   // parameters or arithmetic options changed after the preparation was queued: the backward re-builds its planes
   bool bwd_recorded = false;
   float* paramsT = nullptr;   // transposed copies of the weight matrices (same offsets), refreshed per backward
@@ -663,7 +664,8 @@ static int fwd_begin(RalModel* m, const float* x, int B, int training, hipStream
     }
   }
   if (training) {
-    HIP_OK(hipMemsetAsync(m->bn_sums, 0, 64 * sizeof(double), s));
+    if (!m->sums_clean) HIP_OK(hipMemsetAsync(m->bn_sums, 0, 64 * sizeof(double), s));
+    m->sums_clean = false;
     launch_conv1_fwd(m->cfg.leads, 0, x, m->params + Y.conv1_w, m->params + Y.conv1_b, m->a0, m->bn_sums, nullptr,
                      nullptr, nullptr, nullptr, m->L, m->Lp, B, s);
   } else {
@@ -677,9 +679,8 @@ static int fwd_end(RalModel* m, float* y, int B, int64_t global_windows, int tra
   sched_reset();
   const Layout& Y = m->lay;
   if (training) {
-    launch_bn_finalize(m->bn_sums, (double)global_windows * m->L, m->params + Y.bn_w, m->params + Y.bn_b, m->ss,
-                       m->state, m->state + 8, 8, 1, s);
-    launch_bn_apply8(m->a0, m->ss, m->x0, (size_t)B * m->Lp, s);
+    launch_bn_train8(m->bn_sums, (double)global_windows * m->L, m->params + Y.bn_w, m->params + Y.bn_b, m->ss,
+                     m->state, m->state + 8, m->a0, m->x0, (size_t)B * m->Lp, s);
   }
   const bool tr = training != 0;
   // formed under the stem on an idle stream: the activation scales (waited for here: the narrow levels' kernels read them too) and
@@ -832,8 +833,7 @@ static int bwd_begin(RalModel* m, const float* dy, int B, hipStream_t s) {
   if (!m->grads || !m->bn_sums) return fail("ral_bind: grads / bn_sums not bound");
   if (B != m->last_B) return fail("backward batch %d != forward batch %d", B, m->last_B);
   const Layout& Y = m->lay;
-  HIP_OK(hipMemsetAsync(m->grads, 0, (size_t)Y.nparam * sizeof(float), s));
-  HIP_OK(hipMemsetAsync(m->bn_sums + 32, 0, 32 * sizeof(double), s));
+  launch_zero_bwd(m->grads, (size_t)Y.nparam, m->bn_sums + 32, 32, m->gmax, 18 * 4 * 4, s);   // gradient buffer, backward BatchNorm sums, gradient maxima
   const bool prep_ok = m->prep_bwd && !m->prep_stale;
   if (m->prep_bwd) { HIP_OK(hipStreamWaitEvent(s, m->ev_prep_bwd, 0)); m->prep_bwd = false; }   // transposes + their planes: formed during the forward
   if (!prep_ok) {   // (... or formed from parameters / for options that have changed since: after them, again, from what is bound now)
@@ -843,7 +843,6 @@ static int bwd_begin(RalModel* m, const float* dy, int B, hipStream_t s) {
       if (m->prep_stale) launch_act_scales(m->params, m->adesc, m->ascale, 18, s);   // (the weight-gradient products scale their activation operands)
     }
   }
-  HIP_OK(hipMemsetAsync(m->gmax, 0, 18 * 4 * 4 * sizeof(unsigned), s));
   float** gy = m->gy; float** gin = m->gin;
   const int nl = plan_lanes(m, B, s);
   LaneSet* LS = lanes_of(m);
@@ -901,8 +900,7 @@ static int bwd_end(RalModel* m, float* dx, int B, int64_t global_windows, hipStr
   const Layout& Y = m->lay;
   launch_conv1_bwd(m->cfg.leads, m->gin[0], m->a0, m->last_x, m->ss, m->params + Y.bn_w, m->bn_sums + 32,
                    (double)global_windows * m->L, m->grads + Y.conv1_w, m->grads + Y.conv1_b, dx ? m->dz0 : nullptr,
-                   m->L, m->Lp, B, s);
-  launch_bn_affine_grads(m->bn_sums + 32, m->grads + Y.bn_w, m->grads + Y.bn_b, 8, (double)B / (double)global_windows, s);
+                   m->L, m->Lp, B, s, m->grads + Y.bn_w, m->grads + Y.bn_b, (double)B / (double)global_windows);
   if (dx) launch_conv1_bwd_dx(m->cfg.leads, m->dz0, m->params + Y.conv1_w, dx, m->L, m->Lp, B, s);
   HIP_OK(hipEventRecord(m->ev_bwd_done, s));
   m->bwd_recorded = true;
@@ -1191,6 +1189,7 @@ int ral_bind(ral_handle* h, float* params, float* grads, float* adam_m, float* a
   if (h->kind == 3) return danet_bind(h->d, params, grads, adam_m, adam_v, state);
   RalModel* m = h->m;
   m->prep_stale = true;
+  m->sums_clean = false;
   m->params = params; m->grads = grads; m->am = adam_m; m->av = adam_v; m->state = state; m->bn_sums = bn_sums;
   return 0;
 }
@@ -1392,7 +1391,9 @@ int ral_adam_step(ral_handle* h, double lr, double beta1, double beta2, double e
   else { p = h->m->params; g = h->m->grads; am = h->m->am; av = h->m->av; n = h->m->lay.nparam; h->m->prep_stale = true; }
   if (!p || !g || !am || !av) return fail("ral_bind: params/grads/adam buffers not bound");
   if (step < 1) return fail("step is 1-based");
-  launch_adam(p, g, am, av, (size_t)n, lr, beta1, beta2, eps, step, grad_scale, (hipStream_t)s);
+  double* zero64 = nullptr;
+  if (h->kind == 0 && h->m->bn_sums) { zero64 = h->m->bn_sums; h->m->sums_clean = true; }   // (the next step's stem starts from cleared sums)
+  launch_adam(p, g, am, av, (size_t)n, lr, beta1, beta2, eps, step, grad_scale, (hipStream_t)s, zero64);
   HIP_OK(hipGetLastError());
   return 0;
 }

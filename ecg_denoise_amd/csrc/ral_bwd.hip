@@ -1734,7 +1734,7 @@ __global__ __launch_bounds__(256) void k_final_bwd(const float* __restrict__ dy,
 // =================================================================================
 // conv stem backward.  Pass 1: per-channel sums of dy and dy*xhat (BatchNorm backward).
 // Pass 2: d a0 = gamma rstd (dy - mean(dy) - xhat mean(dy xhat)); LeakyReLU'; conv w/b grads.
-// ss = [scale(8), shift(8), mean(8), rstd(8)] from k_bn_finalize.
+// ss = [scale(8), shift(8), mean(8), rstd(8)] from k_bn_train8.
 // =================================================================================
 __global__ __launch_bounds__(256) void k_bn8_bwd_stats(const float* __restrict__ dy, const float* __restrict__ a0,
                                                        const float* __restrict__ ss, double* __restrict__ out,
@@ -1774,7 +1774,8 @@ __global__ __launch_bounds__(256) void k_conv1_bwd(const float* __restrict__ dy,
                                                    const float* __restrict__ x, const float* __restrict__ ss,
                                                    const float* __restrict__ bnw, const double* __restrict__ bst,
                                                    double count, float* __restrict__ gw, float* __restrict__ gb,
-                                                   float* __restrict__ dzout, int L, int Lp, int B) {
+                                                   float* __restrict__ dzout, int L, int Lp, int B,
+                                                   float* __restrict__ gbnw, float* __restrict__ gbnb, double share) {
   // L: samples per window of x; Lp >= L: token slots per window of dy / a0 / dzout (slots past L do not exist: no gradient)
   constexpr int NG = 8 * LEADS * 3 + 8;
   __shared__ float red[4][NG];
@@ -1841,15 +1842,13 @@ __global__ __launch_bounds__(256) void k_conv1_bwd(const float* __restrict__ dy,
     if ((int)threadIdx.x < 8 * LEADS * 3) atomicAdd(gw + threadIdx.x, s);
     else atomicAdd(gb + threadIdx.x - 8 * LEADS * 3, s);
   }
-}
-
-// BatchNorm affine grads from the (all-reduced) backward sums: g_w += sum dy*xhat, g_b += sum dy
-// `share` = this rank's fraction of the global batch: the sums are already all-reduced, and the gradient
-// all-reduce (sum over ranks) that follows must reproduce them exactly once.
-__global__ void k_bn_affine_grads(const double* __restrict__ bst, float* __restrict__ gw, float* __restrict__ gb, int nch,
-                                  double share) {
-  const int c = threadIdx.x;
-  if (c < nch) { gb[c] += (float)(bst[c] * share); gw[c] += (float)(bst[nch + c] * share); }
+  // BatchNorm affine grads from the (all-reduced) backward sums: g_w += sum dy*xhat, g_b += sum dy (one workgroup's eight
+  // threads; it was a launch of its own).  `share` = this rank's fraction of the global batch: the sums are already all-reduced,
+  // and the gradient all-reduce (sum over ranks) that follows must reproduce them exactly once.
+  if (blockIdx.x == 0 && threadIdx.x < 8) {
+    const int c = threadIdx.x;
+    gbnb[c] += (float)(bst[c] * share); gbnw[c] += (float)(bst[8 + c] * share);
+  }
 }
 
 // dx[b][c][l] = sum_o sum_k w[o][c][k] dz[b][l-k+1][o]   (input gradient of the stem, 12-lead adapter only)
@@ -2197,14 +2196,11 @@ void launch_bn8_bwd_stats(const float* dy, const float* a0, const float* ss, dou
 }
 
 void launch_conv1_bwd(int leads, const float* dy, const float* a0, const float* x, const float* ss, const float* bnw,
-                      const double* bst, double count, float* gw, float* gb, float* dz, int L, int Lp, int B, hipStream_t s) {
+                      const double* bst, double count, float* gw, float* gb, float* dz, int L, int Lp, int B, hipStream_t s,
+                      float* gbnw, float* gbnb, double share) {
   const int grid = ew_grid((size_t)B * Lp, 1024);
-  if (leads == 1) k_conv1_bwd<1><<<grid, 256, 0, s>>>(dy, a0, x, ss, bnw, bst, count, gw, gb, dz, L, Lp, B);
-  else k_conv1_bwd<2><<<grid, 256, 0, s>>>(dy, a0, x, ss, bnw, bst, count, gw, gb, dz, L, Lp, B);
-}
-
-void launch_bn_affine_grads(const double* bst, float* gw, float* gb, int nch, double share, hipStream_t s) {
-  k_bn_affine_grads<<<1, 64, 0, s>>>(bst, gw, gb, nch, share);
+  if (leads == 1) k_conv1_bwd<1><<<grid, 256, 0, s>>>(dy, a0, x, ss, bnw, bst, count, gw, gb, dz, L, Lp, B, gbnw, gbnb, share);
+  else k_conv1_bwd<2><<<grid, 256, 0, s>>>(dy, a0, x, ss, bnw, bst, count, gw, gb, dz, L, Lp, B, gbnw, gbnb, share);
 }
 
 void launch_conv1_bwd_dx(int leads, const float* dz, const float* w, float* dx, int L, int Lp, int B, hipStream_t s) {

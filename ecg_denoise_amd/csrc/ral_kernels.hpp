@@ -54,17 +54,19 @@ void launch_add(const float* a, const float* b, float* y, size_t n, hipStream_t 
 void launch_conv1_fwd(int leads, int mode, const float* x, const float* w, const float* b, float* out, double* stats,
                       const float* bnw, const float* bnb, const float* rmean, const float* rvar, int L, int Lp /* token slots per window (>= L) */, int B,
                       hipStream_t s);
-void launch_bn_finalize(const double* stats, double count, const float* bnw, const float* bnb, float* ss,
-                        float* rmean, float* rvar, int nch, int update_running, hipStream_t s);
-void launch_bn_apply8(const float* a0, const float* ss, float* x0, size_t ntok, hipStream_t s);
+// the stem BatchNorm of a training forward: scale / shift / mean / rstd into ss, running statistics updated, x0 = a0 * scale + shift
+void launch_bn_train8(const double* stats, double count, const float* bnw, const float* bnb, float* ss, float* rmean, float* rvar,
+                      const float* a0, float* x0, size_t ntok, hipStream_t s);
 void launch_final_fwd(int leads, const float* u0, const float* x0, const float* w, const float* b, float* y, int L, int Lp,
                       int B, hipStream_t s);
 // fin != nullptr: loss_sum is a {double, counter} scratch that is zero on entry and left zero; fin[0] = sum * fin_scale
 // fin3: the scratch has 64 doubles (sum [0], counter [16], SNR sum [32], RMSE sum [48]: a cache line each); fin[1], fin[2] = the sums of the windows' SNR / RMSE * fin_scale
 void launch_loss(const float* pred, const float* target, float* dy, float* snr, float* rmse, double* loss_sum,
                  int n, int B, float gscale, hipStream_t s, double* fin = nullptr, double fin_scale = 1.0, int fin3 = 0);
+// grads[0, nfloat) (nfloat % 4 == 0), sums[0, nsums) and gmax[0, ngmax) = 0 in one launch (nsums, ngmax <= 131072)
+void launch_zero_bwd(float* grads, size_t nfloat, double* sums, int nsums, unsigned* gmax, int ngmax, hipStream_t s);
 void launch_adam(float* p, const float* g, float* m, float* v, size_t n, double lr, double b1, double b2, double eps,
-                 int step, float gscale, hipStream_t s);
+                 int step, float gscale, hipStream_t s, double* zero64 = nullptr /* optional: 64 doubles cleared by the same launch */);
 
 int launch_prep_windows(const float* sig, const float* noise, long long T, int leads, int L, double snr_db, double* sums,
                         float* noisy, float* clean, hipStream_t s);
@@ -138,8 +140,8 @@ void launch_final_bwd(int leads, const float* dy, const float* u0, const float* 
                       float* gb, float* dz, int L, int Lp, int B, hipStream_t s);
 void launch_bn8_bwd_stats(const float* dy, const float* a0, const float* ss, double* out, size_t ntok, hipStream_t s);
 void launch_conv1_bwd(int leads, const float* dy, const float* a0, const float* x, const float* ss, const float* bnw,
-                      const double* bst, double count, float* gw, float* gb, float* dz, int L, int Lp, int B, hipStream_t s);
-void launch_bn_affine_grads(const double* bst, float* gw, float* gb, int nch, double share, hipStream_t s);
+                      const double* bst, double count, float* gw, float* gb, float* dz, int L, int Lp, int B, hipStream_t s,
+                      float* gbnw, float* gbnb /* BatchNorm affine gradients += the backward sums x share */, double share);
 void launch_conv1_bwd_dx(int leads, const float* dz, const float* w, float* dx, int L, int Lp, int B, hipStream_t s);
 
 // ---- weight gradients (ral_dw.hip)

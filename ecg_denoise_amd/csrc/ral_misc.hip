@@ -94,34 +94,34 @@ __global__ __launch_bounds__(256) void k_conv1_fwd(const float* __restrict__ x, 
   if (MODE == 0) block_atomic_sums<16>(acc, stats, red);
 }
 
-// BatchNorm (training) finalize: scale/shift from the (all-reduced) sums, running-stat update.
 // stats: [sum(8), sumsq(8)] double; ss: [scale(8), shift(8), mean(8), rstd(8)] float
-__global__ void k_bn_finalize(const double* __restrict__ stats, double count, const float* __restrict__ bnw,
-                              const float* __restrict__ bnb, float* __restrict__ ss, float* __restrict__ rmean,
-                              float* __restrict__ rvar, int nch, int update_running) {
-  const int c = threadIdx.x;
-  if (c >= nch) return;
-  const double mean = stats[c] / count;
-  double var = stats[nch + c] / count - mean * mean;
-  if (var < 0.0) var = 0.0;
-  const float rstd = (float)(1.0 / sqrt(var + 1e-5));
-  const float sc = bnw[c] * rstd;
-  ss[c] = sc;
-  ss[nch + c] = bnb[c] - (float)mean * sc;
-  ss[2 * nch + c] = (float)mean;
-  ss[3 * nch + c] = rstd;
-  if (update_running) {
-    rmean[c] = 0.9f * rmean[c] + 0.1f * (float)mean;
-    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-    rvar[c] = 0.9f * rvar[c] + 0.1f * (float)unb;
+// The stem's BatchNorm in ONE launch (training): every workgroup forms the eight channels' scale / shift from the (all-reduced)
+// sums itself - eight lanes of double arithmetic - and applies them to its share of the tokens; workgroup 0 also leaves ss
+// (scale, shift, mean, rstd: the backward reads them) and the running statistics, (a finalise kernel and an apply kernel were two
+// launches on the one stream that runs at the start of a step.)
+__global__ __launch_bounds__(256) void k_bn_train8(const double* __restrict__ stats, double count, const float* __restrict__ bnw,
+                                                   const float* __restrict__ bnb, float* __restrict__ ss, float* __restrict__ rmean,
+                                                   float* __restrict__ rvar, const float* __restrict__ a0, float* __restrict__ x0,
+                                                   size_t ntok) {
+  __shared__ float sc_[8], sh_[8];
+  if (threadIdx.x < 8) {
+    const int c = threadIdx.x;
+    const double mean = stats[c] / count;
+    double var = stats[8 + c] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + 1e-5));
+    const float sc = bnw[c] * rstd, sh = bnb[c] - (float)mean * sc;
+    sc_[c] = sc; sh_[c] = sh;
+    if (blockIdx.x == 0) {
+      ss[c] = sc; ss[8 + c] = sh; ss[16 + c] = (float)mean; ss[24 + c] = rstd;
+      rmean[c] = 0.9f * rmean[c] + 0.1f * (float)mean;
+      const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+      rvar[c] = 0.9f * rvar[c] + 0.1f * (float)unb;
+    }
   }
-}
-
-// x0 = a0 * scale[c] + shift[c]   (token-major, 8 channels)
-__global__ void k_bn_apply8(const float* __restrict__ a0, const float* __restrict__ ss, float* __restrict__ x0,
-                            size_t ntok) {
-  const float4 s0 = *reinterpret_cast<const float4*>(ss), s1 = *reinterpret_cast<const float4*>(ss + 4);
-  const float4 h0 = *reinterpret_cast<const float4*>(ss + 8), h1 = *reinterpret_cast<const float4*>(ss + 12);
+  __syncthreads();
+  const float4 s0 = make_float4(sc_[0], sc_[1], sc_[2], sc_[3]), s1 = make_float4(sc_[4], sc_[5], sc_[6], sc_[7]);
+  const float4 h0 = make_float4(sh_[0], sh_[1], sh_[2], sh_[3]), h1 = make_float4(sh_[4], sh_[5], sh_[6], sh_[7]);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ntok * 2; i += (size_t)gridDim.x * blockDim.x) {
     const float4 v = reinterpret_cast<const float4*>(a0)[i];
     const bool hi = i & 1;
@@ -275,7 +275,10 @@ __global__ __launch_bounds__(64 * LOSS_W_WAVES) void k_loss_w(const float* __res
 // ---------------------------------------------------------------------------------
 __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                        float* __restrict__ v, size_t n4, float step, float b1, float b2, float omb1, float omb2,
-                       float eps, float sqrt_bc2, float gscale) {
+                       float eps, float sqrt_bc2, float gscale, double* __restrict__ zero64) {
+  // (zero64: the 64 BatchNorm sums of the model, cleared here for the next step's stem: the last kernel of a step instead of a
+  // fill kernel in front of the first one)
+  if (zero64 && blockIdx.x == 0 && threadIdx.x < 64) zero64[threadIdx.x] = 0.0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     float4 pp = reinterpret_cast<float4*>(p)[i];
     const float4 gg = f4scale(reinterpret_cast<const float4*>(g)[i], gscale);
@@ -313,13 +316,10 @@ void launch_conv1_fwd(int leads, int mode, const float* x, const float* w, const
 #undef CASE
 }
 
-void launch_bn_finalize(const double* stats, double count, const float* bnw, const float* bnb, float* ss,
-                        float* rmean, float* rvar, int nch, int update_running, hipStream_t s) {
-  k_bn_finalize<<<1, 64, 0, s>>>(stats, count, bnw, bnb, ss, rmean, rvar, nch, update_running);
-}
-
-void launch_bn_apply8(const float* a0, const float* ss, float* x0, size_t ntok, hipStream_t s) {
-  k_bn_apply8<<<ew_grid(ntok * 2), 256, 0, s>>>(a0, ss, x0, ntok);
+void launch_bn_train8(const double* stats, double count, const float* bnw, const float* bnb, float* ss, float* rmean, float* rvar,
+                      const float* a0, float* x0, size_t ntok, hipStream_t s) {
+  const int g = ew_grid(ntok * 2);
+  k_bn_train8<<<g < 2048 ? g : 2048, 256, 0, s>>>(stats, count, bnw, bnb, ss, rmean, rvar, a0, x0, ntok);
 }
 
 void launch_final_fwd(int leads, const float* u0, const float* x0, const float* w, const float* b, float* y, int L, int Lp,
@@ -343,13 +343,25 @@ void launch_loss(const float* pred, const float* target, float* dy, float* snr, 
   }
 }
 
+// the three buffers a backward pass starts from, zeroed by ONE launch (they were three fill kernels of ~5 us, each with its launch
+// gap, between the loss and the first backward kernel: nothing else runs there)
+__global__ void k_zero_bwd(float4* __restrict__ grads, size_t n4, double* __restrict__ sums, int nsums, unsigned* __restrict__ gmax, int ngmax) {
+  const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (size_t i = i0; i < n4; i += (size_t)gridDim.x * blockDim.x) grads[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i0 < (size_t)nsums) sums[i0] = 0.0;
+  if (i0 < (size_t)ngmax) gmax[i0] = 0u;
+}
+void launch_zero_bwd(float* grads, size_t nfloat, double* sums, int nsums, unsigned* gmax, int ngmax, hipStream_t s) {
+  k_zero_bwd<<<512, 256, 0, s>>>(reinterpret_cast<float4*>(grads), nfloat / 4, sums, nsums, gmax, ngmax);
+}
+
 void launch_adam(float* p, const float* g, float* m, float* v, size_t n, double lr, double b1, double b2, double eps,
-                 int step, float gscale, hipStream_t s) {
+                 int step, float gscale, hipStream_t s, double* zero64) {
   // scalars are formed in double on the host and rounded once, as torch.optim.Adam does
   const double bc1 = 1.0 - pow(b1, (double)step);
   const double bc2 = 1.0 - pow(b2, (double)step);
   k_adam<<<ew_grid(n / 4), 256, 0, s>>>(p, g, m, v, n / 4, (float)(lr / bc1), (float)b1, (float)b2, (float)(1.0 - b1),
-                                        (float)(1.0 - b2), (float)eps, (float)sqrt(bc2), gscale);
+                                        (float)(1.0 - b2), (float)eps, (float)sqrt(bc2), gscale, zero64);
 }
 
 // ---------------------------------------------------------------------------------
