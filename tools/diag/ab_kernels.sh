@@ -7,7 +7,7 @@ for i in $(seq 1 ${3:-2}); do
 for lib in "" "$1"; do
   echo "== ${lib:-default}"
   ( export RAL_LANES=1 RAL_NO_SIDE_STREAM=1 RAL_LIB_PATH=$lib
-  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r5/abk -- python3 bench.py --steps 5 --warmup 2 --no-cpu --no-infer --no-fp32 > gpurun_out/r5/abk.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r5/abk -- python3 bench.py --min-seconds 0 --steps 5 --warmup 2 --no-cpu --no-infer --no-fp32 > gpurun_out/r5/abk.log 2>&1
   f=$(ls gpurun_out/r5/abk/*/*kernel_stats.csv | head -1)
   python3 - "$f" "$2" <<'PY'
 import csv, sys, re

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 export RAL_LANES=1 RAL_NO_SIDE_STREAM=1
 run() { # name, lib
   D=/tmp/abl_$1; rm -rf $D
-  RAL_LIB_PATH=$2 rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 5 --warmup 2 --no-cpu --no-infer > $D.log 2>&1
+  RAL_LIB_PATH=$2 rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 "$GRAFT_REPO_ROOT/bench.py" --min-seconds 0 --steps 5 --warmup 2 --no-cpu --no-infer > $D.log 2>&1
   find $D -name "*kernel_stats.csv" | head -1
 }
 F0=$(run base "$GRAFT_REPO_ROOT/ecg_denoise_amd/libralenet.so")

@@ -3,7 +3,7 @@ cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r4
 export RAL_LANES=1 RAL_NO_SIDE_STREAM=1
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r4/ks_$1 -- python3 bench.py --steps 5 --warmup 2 --no-cpu --no-infer --no-fp32 > gpurun_out/r4/ks_$1.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r4/ks_$1 -- python3 bench.py --min-seconds 0 --steps 5 --warmup 2 --no-cpu --no-infer --no-fp32 > gpurun_out/r4/ks_$1.log 2>&1
 f=$(ls gpurun_out/r4/ks_$1/*/*kernel_stats.csv | head -1)
 python3 - "$f" "${2:-}" <<'PY'
 import csv, sys

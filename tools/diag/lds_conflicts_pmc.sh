@@ -3,7 +3,7 @@ cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r4/ldspmc
 rm -rf $O; mkdir -p $O
 export RAL_LANES=1 RAL_NO_SIDE_STREAM=1
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/a -- python3 bench.py --steps 1 --warmup 1 --no-cpu --no-infer --no-fp32 > $O/a.log 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/a -- python3 bench.py --min-seconds 0 --steps 1 --warmup 1 --no-cpu --no-infer --no-fp32 > $O/a.log 2>&1
 python3 - $O/a <<'PY'
 import collections, csv, glob, sys
 acc = collections.defaultdict(collections.Counter); n = collections.Counter()

@@ -6,7 +6,7 @@ for V in ${@:-2 3}; do
 OPT="--opt mlp_bwd_w=$V ${XOPT}"
 echo "== mlp_bwd_w=$V"
 ( export RAL_LANES=1 RAL_NO_SIDE_STREAM=1
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r5/mb -- python3 bench.py $OPT ${BATCH:+--batch $BATCH} --steps 5 --warmup 2 --no-cpu --no-infer --no-fp32 > gpurun_out/r5/mb.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r5/mb -- python3 bench.py --min-seconds 0 $OPT ${BATCH:+--batch $BATCH} --steps 5 --warmup 2 --no-cpu --no-infer --no-fp32 > gpurun_out/r5/mb.log 2>&1
 f=$(ls gpurun_out/r5/mb/*/*kernel_stats.csv | head -1)
 python3 - "$f" <<'PY'
 import csv, sys

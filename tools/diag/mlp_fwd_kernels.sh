@@ -4,7 +4,7 @@ mkdir -p gpurun_out/r4
 for v in 3 4; do
 echo "mlp_fwd_w=$v"
 ( export RAL_MLP_FWD_W=$v RAL_LANES=1 RAL_NO_SIDE_STREAM=1
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r4/mf -- python3 bench.py --steps 5 --warmup 2 --no-cpu --no-infer --no-fp32 > gpurun_out/r4/mf.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r4/mf -- python3 bench.py --min-seconds 0 --steps 5 --warmup 2 --no-cpu --no-infer --no-fp32 > gpurun_out/r4/mf.log 2>&1
 f=$(ls gpurun_out/r4/mf/*/*kernel_stats.csv | head -1)
 python3 - "$f" <<'PY'
 import csv, sys

@@ -6,7 +6,7 @@ cd $GRAFT_REPO_ROOT
 T=${1:-x}; O=gpurun_out/pmc_lds_$T
 rm -rf $O.d
 export RAL_LANES=1 RAL_NO_SIDE_STREAM=1
-rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O.d -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-infer --no-fp32 > $O.log 2>&1
+rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O.d -- python3 bench.py --min-seconds 0 --steps 2 --warmup 1 --no-cpu --no-infer --no-fp32 > $O.log 2>&1
 python3 - $O.d > $O.txt <<'PY'
 import collections, csv, glob, sys
 acc = collections.defaultdict(collections.Counter); n = collections.Counter()
