@@ -364,8 +364,12 @@ struct RalModel {
   // weight preparation under the stem: the split planes of this forward (and, in training, the transposes + their planes for
   // its backward) are formed on lane 0's weight-gradient stream - idle during a forward - while the caller's stream runs the
   // stem conv / BatchNorm; fwd_end / bwd_begin wait for the events instead of launching the kernels (side_stream = 0: inline)
-  hipEvent_t ev_prep_go = nullptr, ev_prep_asc = nullptr, ev_prep_fwd = nullptr, ev_prep_bwd = nullptr;   // (asc: the activation scales, which every level's kernels read; fwd: the weight planes of the wide levels)
+  hipEvent_t ev_prep_go = nullptr, ev_prep_fwd = nullptr, ev_prep_bwd = nullptr;
   bool prep_fwd = false, prep_bwd = false;
+  // option "static_params" (the host mirror sets it in eval mode): the caller promises not to touch the parameters until it says so
+  // again, so the activation scales and the weight planes an eval forward formed stay valid for the next one - a forward then has no
+  // preparation kernels at all (they were ~0.1 ms of a 3.6 ms inference forward)
+  bool static_params = false, planes_valid = false, skip_prep = false;
   bool sums_clean = false;   // bn_sums[0, 32) were zeroed by the optimiser kernel of the previous step (no fill kernel in front of the stem)
   bool prep_stale = false;   // parameters or arithmetic options changed after the preparation was queued: the backward re-builds its planes
   bool bwd_recorded = false;
@@ -646,14 +650,18 @@ static int fwd_begin(RalModel* m, const float* x, int B, int training, hipStream
   m->last_x = x; m->last_B = B;
   m->prep_fwd = m->prep_bwd = false;
   m->prep_stale = false;
+  m->skip_prep = !training && m->static_params && m->planes_valid;
+  if (training) m->planes_valid = false;                         // (an optimiser step will follow)
+  else if (m->static_params) m->planes_valid = true;             // (what this forward prepares stays)
   static const bool prep_on = ral_knob("PREP_OVERLAP", 1) != 0;
-  if (prep_on && m->side_stream && m->ev_prep_go) {
+  if (!m->skip_prep && prep_on && m->side_stream && m->ev_prep_go) {
     hipStream_t ps = lanes_of(m)->l[0].s2;
     HIP_OK(hipEventRecord(m->ev_prep_go, s));            // (the parameters are final: everything queued on s so far has run)
     HIP_OK(hipStreamWaitEvent(ps, m->ev_prep_go, 0));
-    if (m->f16_split > 0) launch_act_scales(m->params, m->adesc, m->ascale, 18, ps);
-    HIP_OK(hipEventRecord(m->ev_prep_asc, ps));
-    if (m->f16_split > 0) launch_tile_planes(m->params, m->wh, m->wdesc, m->ndesc, m->nwork, 0, ps);
+    if (m->f16_split > 0) {
+      launch_act_scales(m->params, m->adesc, m->ascale, 18, ps);
+      launch_tile_planes(m->params, m->wh, m->wdesc, m->ndesc, m->nwork, 0, ps);
+    }
     HIP_OK(hipEventRecord(m->ev_prep_fwd, ps));
     m->prep_fwd = true;
     if (training) {
@@ -683,11 +691,12 @@ static int fwd_end(RalModel* m, float* y, int B, int64_t global_windows, int tra
                      m->state, m->state + 8, m->a0, m->x0, (size_t)B * m->Lp, s);
   }
   const bool tr = training != 0;
-  // formed under the stem on an idle stream: the activation scales (waited for here: the narrow levels' kernels read them too) and
-  // the split planes of the wide levels' weights (waited for by every lane in front of the first level that multiplies them)
-  const bool planes_pending = m->prep_fwd;
-  if (m->prep_fwd) { HIP_OK(hipStreamWaitEvent(s, m->ev_prep_asc, 0)); m->prep_fwd = false; }
-  else if (m->f16_split > 0) {
+  // (the activation scales and the split planes of the wide levels' weights: formed under the stem on an idle stream.  ONE join, here,
+  // in front of the fork: waiting for the planes only in front of the first wide level - an edge from the preparation stream into each
+  // lane - gained nothing measurable on the eager step, and the hipGraph replay of the forward measured 457 k windows/s against 541 k
+  // eager with it in the round-6 collection (572 k / 563 k without it))
+  if (m->prep_fwd) { HIP_OK(hipStreamWaitEvent(s, m->ev_prep_fwd, 0)); m->prep_fwd = false; }
+  else if (m->f16_split > 0 && !m->skip_prep) {
     launch_act_scales(m->params, m->adesc, m->ascale, 18, s);
     launch_tile_planes(m->params, m->wh, m->wdesc, m->ndesc, m->nwork, 0, s);
   }
@@ -696,19 +705,11 @@ static int fwd_end(RalModel* m, float* y, int B, int64_t global_windows, int tra
   LaneSet* LS = lanes_of(m);
   // issue stage by stage, alternating lanes, so that the lanes progress together
   const float* cur = m->x0;
-  bool planes_waited = !planes_pending;
-  auto need_planes = [&](int level) {
-    if (planes_waited || !(m->f16_split > 0 && CH[level] >= m->f16_split)) return;
-    for (int k = 0; k < nl; ++k) EV(hipStreamWaitEvent(LS->l[k].s, m->ev_prep_fwd, 0));
-    planes_waited = true;
-  };
   for (int i = 0; i < 4; ++i) {
-    need_planes(i);
     for (int k = 0; k < nl; ++k) run_stage_fwd(m, i, cur, tr, LS->l[k]);
     for (int k = 0; k < nl; ++k) run_res_fwd(m, i, m->act[2 * i + 1].out, nullptr, LS->l[k]);
     cur = m->res_out[i];
   }
-  need_planes(4);
   for (int k = 0; k < nl; ++k) {
     const Lane& ln = LS->l[k];
     // x_mid = transformer(x4) + x4 (raletransformer.py:659): the second output of the bottleneck's last MLP kernel
@@ -727,7 +728,6 @@ static int fwd_end(RalModel* m, float* y, int B, int64_t global_windows, int tra
                      woff(y, ln.w0, (size_t)m->cfg.leads * m->L), m->L, m->Lp, ln.B, ln.s);
   }
   join_lanes(m, s);
-  if (!planes_waited) HIP_OK(hipStreamWaitEvent(s, m->ev_prep_fwd, 0));   // (no level multiplies planes: the preparation stream still joins the caller's)
   HIP_OK(hipGetLastError());
   return sched_check();
 }
@@ -1009,7 +1009,7 @@ static void destroy_model(RalModel* m) {
   }
   for (auto& pr : m->prof_ev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (m->ev_bwd_done) (void)hipEventDestroy(m->ev_bwd_done);
-  for (hipEvent_t e : {m->ev_prep_go, m->ev_prep_asc, m->ev_prep_fwd, m->ev_prep_bwd}) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : {m->ev_prep_go, m->ev_prep_fwd, m->ev_prep_bwd}) if (e) (void)hipEventDestroy(e);
   if (m->slab) (void)hipFree(m->slab);
   delete m;
 }
@@ -1085,7 +1085,6 @@ int ral_create(const ral_config* cfg, ral_handle** out) {
     }
     ok(hipEventCreateWithFlags(&m->ev_bwd_done, hipEventDisableTiming));
     ok(hipEventCreateWithFlags(&m->ev_prep_go, hipEventDisableTiming));
-    ok(hipEventCreateWithFlags(&m->ev_prep_asc, hipEventDisableTiming));
     ok(hipEventCreateWithFlags(&m->ev_prep_fwd, hipEventDisableTiming));
     ok(hipEventCreateWithFlags(&m->ev_prep_bwd, hipEventDisableTiming));
     if (first != hipSuccess) {
@@ -1190,6 +1189,7 @@ int ral_bind(ral_handle* h, float* params, float* grads, float* adam_m, float* a
   RalModel* m = h->m;
   m->prep_stale = true;
   m->sums_clean = false;
+  m->planes_valid = false;
   m->params = params; m->grads = grads; m->am = adam_m; m->av = adam_v; m->state = state; m->bn_sums = bn_sums;
   return 0;
 }
@@ -1388,7 +1388,7 @@ int ral_adam_step(ral_handle* h, double lr, double beta1, double beta2, double e
   if (h->kind == 1) { UNetPublic* u = unet_public(h->u); p = u->params; g = u->grads; am = u->am; av = u->av; n = u->nparam; }
   else if (h->kind == 2) { AcdaePublic* u = acdae_public(h->a); p = u->params; g = u->grads; am = u->am; av = u->av; n = u->nparam; }
   else if (h->kind == 3) { DanetPublic* u = danet_public(h->d); p = u->params; g = u->grads; am = u->am; av = u->av; n = u->nparam; }
-  else { p = h->m->params; g = h->m->grads; am = h->m->am; av = h->m->av; n = h->m->lay.nparam; h->m->prep_stale = true; }
+  else { p = h->m->params; g = h->m->grads; am = h->m->am; av = h->m->av; n = h->m->lay.nparam; h->m->prep_stale = true; h->m->planes_valid = false; }
   if (!p || !g || !am || !av) return fail("ral_bind: params/grads/adam buffers not bound");
   if (step < 1) return fail("step is 1-based");
   double* zero64 = nullptr;
@@ -1407,6 +1407,8 @@ int ral_set_option(ral_handle* h, const char* key, int value) {
   if (h->kind != 0) return fail("no options for this handle");
   RalModel* m = h->m;
   m->prep_stale = true;   // (weight planes queued by a forward were formed for the options of that moment)
+  m->planes_valid = false;
+  if (!strcmp(key, "static_params")) { m->static_params = value != 0; return 0; }   // (setting it again = "the parameters have changed")
   if (!strcmp(key, "lanes")) { m->n_lanes = value < 1 ? 1 : (value > MAX_LANES ? MAX_LANES : value); return 0; }
   if (!strcmp(key, "side_stream")) { m->side_stream = value != 0; return 0; }
   if (!strcmp(key, "f16_split")) {

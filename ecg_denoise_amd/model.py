@@ -160,7 +160,15 @@ class _ModuleBase(_AutogradMixin):
         if mode and not self.eng.trainable:
             raise _lib.RalError("model was created with train=False")
         self.training = bool(mode)
+        self._params_changed()
         return self
+
+    def _params_changed(self):
+        """tell the library whether the parameters stand still (eval mode: the weight planes of one forward serve the next) - and, by
+        telling it again, that they may have been rewritten (load_state_dict, reset_parameters).  Parameters edited in place in eval
+        mode through `parameters()` / `eng.params` need this call too."""
+        if self.eng.variant in ("nra", "full", "mlp") and getattr(self.eng, "h", None):
+            _lib.check(_lib.lib().ral_set_option(self.eng.h, b"static_params", 0 if self.training else 1))
 
     def eval(self):
         return self.train(False)
@@ -230,6 +238,7 @@ class _ModuleBase(_AutogradMixin):
                 dst.copy_(v.to(dtype=torch.float32, device=dst.device))
             elif e["kind"] == _lib.KIND_COUNTER:
                 self.eng.counters[e["name"]] = int(v)
+        self._params_changed()
         if strict and (missing or unexpected):
             raise _lib.RalError(f"load_state_dict: missing {missing}, unexpected {unexpected}")
         return missing, unexpected
@@ -269,6 +278,7 @@ class _ModuleBase(_AutogradMixin):
         self.eng.state.copy_(torch.from_numpy(st))
         for k in self.eng.counters:
             self.eng.counters[k] = 0
+        self._params_changed()
 
     # ---- hot path -----------------------------------------------------------------
     def _check_x(self, x):
