@@ -217,6 +217,7 @@ class NewRALEEngineAdapter:
             m.step_count = int(v[0])
             for k, c in zip(sorted(ie.counters), v[1:]):
                 ie.counters[k] = int(c)
+            self.inner._params_changed()      # (see _replica_state)
         return tensors, get_counters, set_counters
 
 
@@ -233,6 +234,8 @@ def _replica_state(model):
         model.step_count = int(v[0])
         for k, c in zip(sorted(e.counters), v[1:]):
             e.counters[k] = int(c)
+        if hasattr(model, "_params_changed"):
+            model._params_changed()           # (the broadcast rewrote the parameter buffer: cached weight planes of an eval-mode model are stale)
     return tensors, get_counters, set_counters
 
 
