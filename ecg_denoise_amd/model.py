@@ -295,6 +295,7 @@ class _ModuleBase(_AutogradMixin):
         x = self._check_x(x)
         y = torch.empty_like(x)
         self._x = x  # keep alive for backward (the stem gradient re-reads it)
+        self._dy_fused = False   # (the sums `forward_loss` left for `backward()` belonged to the previous forward)
         _lib.check(_lib.lib().ral_forward(self.eng.h, _ptr(x), _ptr(y), x.shape[0], int(self.training), _stream()))
         if self.training:
             for k in self.eng.counters:
