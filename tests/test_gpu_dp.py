@@ -178,3 +178,44 @@ def test_newrale_sync_batchnorm_two_ranks_equal_one_process():
     # per-rank statistics would NOT reproduce the whole batch
     solo = make(B // 2)
     assert (solo(xs[0]) - y[:B // 2]).abs().max().item() > 1e-4
+
+
+def test_padded_window_length_two_ranks_equal_one_process():
+    """A window length that is not a multiple of 256 (L = 320: padded token slots, masked) under the data-parallel split: two
+    RA-LENet engines with half the batch each, their stem BatchNorm sums added where the all-reduces sit - the statistics count
+    B x L existing samples, not the padded slots - reproduce the whole-batch engine: outputs, running statistics, summed
+    gradients."""
+    from ecg_denoise_amd import RALENet
+    from ecg_denoise_amd.dp import HipEngineAdapter
+    B, L = 16, 320
+    torch.manual_seed(1)
+    x = torch.randn(B, 2, L, device=DEV); t = torch.randn(B, 2, L, device=DEV)
+    ref = RALENet("full", leads=2, L=L, max_batch=B, device=DEV, seed=31); ref.train()
+    y = ref(x); ref.loss_and_metrics(y, t); ref.backward()
+    halves = [RALENet("full", leads=2, L=L, max_batch=B // 2, device=DEV, seed=31) for _ in range(2)]
+    ads = [HipEngineAdapter(h) for h in halves]
+    xs, ts = [x[:B // 2].contiguous(), x[B // 2:].contiguous()], [t[:B // 2].contiguous(), t[B // 2:].contiguous()]
+    for h in halves:
+        h.train()
+    for a, xx in zip(ads, xs):
+        a.forward_begin(xx)
+    tot = sum(a.bn_sums[:32].clone() for a in ads)
+    for a in ads:
+        a.bn_sums[:32].copy_(tot)
+    preds = [a.forward_end(B) for a in ads]
+    for a, p, tt in zip(ads, preds, ts):
+        a.loss(p, tt, B)
+        a.backward_begin()
+    tot = sum(a.bn_sums[32:64].clone() for a in ads)
+    for a in ads:
+        a.bn_sums[32:64].copy_(tot)
+    for a in ads:
+        a.backward_end(B)
+    torch.cuda.synchronize()
+    assert torch.allclose(torch.cat(preds), y, rtol=0, atol=2e-6)
+    torch.testing.assert_close(halves[0].eng.state, ref.eng.state, rtol=1e-5, atol=1e-7)
+    g = halves[0].eng.grads + halves[1].eng.grads
+    ng = {e["name"]: (e["offset"], int(torch.tensor(e["shape"]).prod())) for e in ref.eng.entries if e["kind"] == 0}
+    for k, (o, n) in ng.items():
+        a_, b_ = g[o:o + n].double(), ref.eng.grads[o:o + n].double()
+        assert (a_ - b_).norm().item() <= 2e-4 * b_.norm().item() + 1e-8, k
