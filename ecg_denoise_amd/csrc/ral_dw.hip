@@ -2,14 +2,14 @@
 //
 // A workgroup owns one (M-slice x N-slice) block of dW for the windows blockIdx.x, blockIdx.x + gridDim.x, ...
 // and walks their tokens in chunks of TC.  Its 8 waves are split by role:
-//   waves 4..7 (producers) stage chunk i+1 into one LDS buffer -- every global load of the chunk is issued
-//     before the first one is consumed, and the X operand is RE-COMPUTED from what the forward pass saved
-//     (LayerNorm, the GELU / local-enhancement chain) rather than stored;
-//   waves 0..3 (consumers) run the MFMAs of chunk i out of the other buffer: they form a WM x WN grid, each wave
-//     keeping an MI x NI block of 16x16 tiles in accumulators across ALL the windows (MI + NI LDS fragment reads
-//     feed MI*NI MFMAs).
+//   waves 4..7 (producers) stage the X operand of chunk i+1 into one LDS buffer -- every global load of the chunk is issued
+//     before the first one is consumed, and X is RE-COMPUTED from what the forward pass saved (LayerNorm, the GELU /
+//     local-enhancement chain) rather than stored;
+//   waves 0..3 (consumers) stage the Y operand of chunk i+1 (a gradient: a copy, or scale-and-split) and then run the MFMAs
+//     of chunk i out of the other buffer: they form a WM x WN grid, each wave keeping an MI x NI block of 16x16 tiles in
+//     accumulators across ALL the windows (MI + NI LDS fragment reads feed MI*NI MFMAs).
 // One barrier per chunk swaps the buffers, so HBM latency, the re-computation and the MFMAs overlap inside a
-// workgroup; two to three workgroups fit a CU.  The accumulators are added to the gradient buffer once at the
+// workgroup; one to three workgroups fit a CU.  The accumulators are added to the gradient buffer once at the
 // end (fp32 global atomics; a same-address atomic chain costs ~30 ns per link on MI355X, which is what bounds
 // the split-K count of the narrow levels).
 #ifdef RAL_STAMP_TU_DW
@@ -129,9 +129,13 @@ __global__ __launch_bounds__(512, RAL_DW_WPE) void k_dw(const float* Y, const fl
   // ---- producer: stage chunk ci into buf (256 threads, no barriers inside).  Straight-line code: indices past
   // the chunk are clamped rather than branched around (the duplicates rewrite identical values), because hipcc
   // waits for a conditional load on the spot and the whole point is to have every load of the chunk in flight.
-  struct Pack { float4 y[UY]; XLoad x[UX]; };   // the in-flight loads of one chunk (static indices only)
-  auto with_chunk = [&](int ci, float* buf, auto&& fn) {
-    const int tid = threadIdx.x - 256;
+  // the in-flight loads of one chunk (static indices only): the X operand - the one with the re-computation - is staged by the four
+  // producer waves, the Y operand (a gradient: scale and split, or a plain copy) by the four consumer waves in front of their MFMAs.
+  // (With both operands on the producers a chunk cost them ~1.3 us at C = 128 while the consumers' tiles take ~0.3 us: the
+  // workgroup ran at the producers' pace with half of its waves idle three quarters of the time.)
+  struct PackY { float4 y[UY]; };
+  struct PackX { XLoad x[UX]; };
+  auto with_chunk = [&](int tid, int ci, float* buf, auto&& fn) {
     const int win = blockIdx.x + (ci / cpw) * gridDim.x, t0 = (ci % cpw) * TC;
     const float* Yw = Y + (size_t)win * N * M;
     const float* Xw = X + (size_t)win * N * NC;
@@ -234,24 +238,34 @@ __global__ __launch_bounds__(512, RAL_DW_WPE) void k_dw(const float* Y, const fl
     };
     fn(load_y, store_y, load_x, store_x);
   };
-  // issue(): request every load of chunk ci (nothing waits on them here).  The compiler barrier pins the loads
+  // issue_*(): request every load of chunk ci (nothing waits on them here).  The compiler barrier pins the loads
   // above it -- otherwise they are sunk next to their stores, one HBM round trip each -- and the scheduling barrier
   // keeps the machine scheduler from undoing that.
-  auto issue = [&](int ci, Pack& p) {
-    with_chunk(ci, buf0, [&](auto& load_y, auto&, auto& load_x, auto&) {
-#pragma unroll
-      for (int u = 0; u < UY; ++u) p.y[u] = load_y(u);
+  auto issue_x = [&](int ci, PackX& p) {
+    with_chunk((int)threadIdx.x - 256, ci, buf0, [&](auto&, auto&, auto& load_x, auto&) {
 #pragma unroll
       for (int u = 0; u < UX; ++u) p.x[u] = load_x(u);
     });
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   };
-  // commit(): wait for the chunk's loads, transform, store into the LDS buffer
-  auto commit = [&](int ci, float* buf, const Pack& p) {
-    with_chunk(ci, buf, [&](auto&, auto& store_y, auto&, auto& store_x) {
+  auto issue_y = [&](int ci, PackY& p) {
+    with_chunk((int)threadIdx.x, ci, buf0, [&](auto& load_y, auto&, auto&, auto&) {
+#pragma unroll
+      for (int u = 0; u < UY; ++u) p.y[u] = load_y(u);
+    });
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // commit_*(): wait for the chunk's loads, transform, store into the LDS buffer
+  auto commit_x = [&](int ci, float* buf, const PackX& p) {
+    with_chunk((int)threadIdx.x - 256, ci, buf, [&](auto&, auto&, auto&, auto& store_x) {
 #pragma unroll
       for (int u = 0; u < UX; ++u) store_x(u, p.x[u]);
+    });
+  };
+  auto commit_y = [&](int ci, float* buf, const PackY& p) {
+    with_chunk((int)threadIdx.x, ci, buf, [&](auto&, auto& store_y, auto&, auto&) {
 #pragma unroll
       for (int u = 0; u < UY; ++u) store_y(u, p.y[u]);
     });
@@ -271,32 +285,36 @@ __global__ __launch_bounds__(512, RAL_DW_WPE) void k_dw(const float* Y, const fl
         // transform and the consumers' MFMAs (which share the producer's SIMD) ADD UP here - measured with the
         // `RAL_DW_NOLOAD / NOXF / NOMFMA` variants of this kernel: 154 us = 55 + 53 + 45 at C = 128; this ordering
         // brings it to 132 us.  The LayerNorm operands did not gain (their packs are larger) and keep one chunk.
-        Pack pa, pb;
+        PackX pa, pb;
         const int last = nci - 1;
-        issue(0, pa);
-        commit(0, buf0, pa);
-        issue(last < 1 ? last : 1, pa);
-        issue(last < 2 ? last : 2, pb);
+        issue_x(0, pa);
+        commit_x(0, buf0, pa);
+        issue_x(last < 1 ? last : 1, pa);
+        issue_x(last < 2 ? last : 2, pb);
         __syncthreads();
-        for (int ci = 0; ci < nci; ci += 2) {
-          if (ci + 1 < nci) commit(ci + 1, buf1, pa);
-          issue(ci + 3 < nci ? ci + 3 : last, pa);     // (past the end: a harmless re-read, no branch around the loads)
+        // The loop body is a PAIR of chunks with no path around its second half: with `if (ci + 1 < nci) { second half }` inside
+        // the loop, the wait-count pass merges, at the loop header, the state "pb requested after pa" with the state of the path
+        // that skipped pb's request - and then makes the commit of pa wait for pb's loads as well (s_waitcnt vmcnt(6 .. 0) where
+        // 18 .. 12 is right: one chunk in flight again, every other chunk).  An odd last chunk is peeled off below.
+        int ci = 0;
+        for (; ci + 1 < nci; ci += 2) {
+          commit_x(ci + 1, buf1, pa);
+          issue_x(ci + 3 < nci ? ci + 3 : last, pa);     // (past the end: a harmless re-read, no branch around the loads)
           __syncthreads();
-          if (ci + 1 < nci) {
-            if (ci + 2 < nci) commit(ci + 2, buf0, pb);
-            issue(ci + 4 < nci ? ci + 4 : last, pb);
-            __syncthreads();
-          }
+          if (ci + 2 < nci) commit_x(ci + 2, buf0, pb);
+          issue_x(ci + 4 < nci ? ci + 4 : last, pb);
+          __syncthreads();
         }
+        if (ci < nci) __syncthreads();                 // (odd count: the consumers' last chunk is staged already)
       } else {
-        Pack p;
-        issue(0, p);
-        commit(0, buf0, p);
-        issue(nci > 1 ? 1 : 0, p);
+        PackX p;
+        issue_x(0, p);
+        commit_x(0, buf0, p);
+        issue_x(nci > 1 ? 1 : 0, p);
         __syncthreads();
         for (int ci = 0; ci < nci; ++ci) {
-          if (ci + 1 < nci) commit(ci + 1, (ci & 1) ? buf0 : buf1, p);
-          issue(ci + 2 < nci ? ci + 2 : nci - 1, p);   // (past the end: a harmless re-read, no branch around the loads)
+          if (ci + 1 < nci) commit_x(ci + 1, (ci & 1) ? buf0 : buf1, p);
+          issue_x(ci + 2 < nci ? ci + 2 : nci - 1, p);   // (past the end: a harmless re-read, no branch around the loads)
           __syncthreads();
         }
       }
@@ -319,10 +337,19 @@ __global__ __launch_bounds__(512, RAL_DW_WPE) void k_dw(const float* Y, const fl
   float bsum[MI];
 #pragma unroll
   for (int i = 0; i < MI; ++i) bsum[i] = 0.f;
+  // Y operand: chunk ci + 1 is committed (requested one iteration ago) and chunk ci + 2 requested in front of the tiles of chunk ci
+  PackY py;
+  if (nci > 0) {
+    issue_y(0, py);
+    commit_y(0, buf0, py);
+    issue_y(nci > 1 ? 1 : 0, py);
+  }
   __syncthreads();
   for (int ci = 0; ci < nci; ++ci) {
     const float* Ys = (ci & 1) ? buf1 : buf0;
     const float* Xs = Ys + ysz;
+    if (ci + 1 < nci) commit_y(ci + 1, (ci & 1) ? buf0 : buf1, py);
+    issue_y(ci + 2 < nci ? ci + 2 : nci - 1, py);      // (past the end: a harmless re-read, no branch around the loads)
     if constexpr (H) {
       if (kw < KW) {
         const _Float16* Yh = reinterpret_cast<const _Float16*>(Ys);
