@@ -193,20 +193,25 @@ __global__ __launch_bounds__(512) void k_mlp_bwd(const float* __restrict__ dx2, 
 // reads any more.  That is why the kernel takes (N, HC) with exactly one 32 x 32 unit per wave: (HC / 32) (N / 32) == 8.
 // dx2 is not kept in fp32: the LayerNorm backward reads it again from global memory (L2).
 // =================================================================================
-template <int C, int NCH>
-__global__ __launch_bounds__(512, 4) void k_mlp_bwd_h(const float* __restrict__ dx2, const float* __restrict__ x1,
+// NTH = 512: two workgroups per CU at 128 registers (one 32 x 32 unit of the fc2^T phase per wave: (HC / 32)(N / 32) = 8);
+// NTH = 256: three per CU at 168 registers ((HC / 32)(N / 32) = 4: twice the hidden chunks)
+template <int C, int NCH, int NTH = 512>
+__global__ __launch_bounds__(NTH, (NTH == 512 ? 4 : 3)) void k_mlp_bwd_h(const float* __restrict__ dx2, const float* __restrict__ x1,
                                                       const float* __restrict__ upre, BlockP w, BlockP wt, const float* __restrict__ ptbase,
                                                       const _Float16* __restrict__ wtt, BlockP gr,
                                                       float* __restrict__ dupre, float* __restrict__ dx1,
                                                       float* __restrict__ do_hm, float* __restrict__ a2c0,
                                                       unsigned* __restrict__ gmax, int N, int B) {
   extern __shared__ float4 smem4[];
-  constexpr int LD = LDof<C>::v, HC = 4 * C / NCH, LDUF = LDof<HC>::v, LDG = ldb_of(C), LDU = ldb_of(HC), LPR = C / 4, RPP = 512 / LPR;
+  constexpr int LD = LDof<C>::v, HC = 4 * C / NCH, LDUF = LDof<HC>::v, LDG = ldb_of(C), LDU = ldb_of(HC), LPR = C / 4, RPP = NTH / LPR;
   typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
   _Float16* Dh = reinterpret_cast<_Float16*>(smem4);            // 2 x N x LDG : dx2, later dx1 (scaled, split)
   const int dplane = N * LDG, uplane = N * LDU;
+  // NTH = 256: dg is accumulated in registers over the hidden chunks (every wave owns ONE 32 x 32 unit of it: (C / 32)(N / 32) = 4)
+  // and meets the LayerNorm backward through the bytes of the u_pre / du chunk, which is free by then
+  constexpr bool DGR = NTH == 256;
   float* Gs = reinterpret_cast<float*>(Dh + 2 * dplane);        // N x LD      : dg accumulator (fp32)
-  float* Us = Gs + N * LD;                                      // N x LDUF    : u_pre chunk (fp32) ...
+  float* Us = DGR ? Gs : Gs + N * LD;                           // N x LDUF    : u_pre chunk (fp32) ...
   _Float16* Uh = reinterpret_cast<_Float16*>(Us);               // 2 x N x LDU : ... then du (scaled, split); N (HC + 8) floats
   float* A0 = Us + N * (HC + 8);                                // N + 2  : gelu(u[:,0]), zero halo
   float* DC0 = A0 + N + 2;                                      // N + 2  : d c0, zero halo
@@ -244,8 +249,10 @@ __global__ __launch_bounds__(512, 4) void k_mlp_bwd_h(const float* __restrict__ 
     tmx = fmaxf(tmx, mx);
   };
   const int mb_ = HC / 32, um = wave % mb_, ut = wave / mb_;   // the wave's unit of the fc2^T phase
+  RAL_STAMP_INIT();
   for (int win = blockIdx.x; win < B; win += gridDim.x) {
     const size_t wo = (size_t)win * N * C;
+    RAL_STAMP_AT(12);                                            // (loop control; the previous window's last barrier)
     for (int row0 = threadIdx.x / LPR; row0 < N; row0 += 2 * RPP) {
       const int rowb = row0 + RPP < N ? row0 + RPP : row0;
       const float4 va = *reinterpret_cast<const float4*>(dx2 + wo + (size_t)row0 * C + cq);
@@ -254,11 +261,19 @@ __global__ __launch_bounds__(512, 4) void k_mlp_bwd_h(const float* __restrict__ 
       if (row0 + RPP < N) put_row(rowb, vb, tmx2);
     }
     if ((int)threadIdx.x < N) smU[threadIdx.x] = 0u;
+    f32x4 dgr[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) dgr[mi][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int gm_ = wave % (C / 32), gt_ = wave / (C / 32);      // DGR: the wave's unit of dg (rows 32 gm_ .., tokens 32 gt_ ..)
 #pragma unroll 1
     for (int ch = 0; ch < NCH; ++ch) {
       const int j0 = ch * HC;
+      RAL_STAMP_AT(13);                                          // dx2 rows staged (ch = 0) / dg product (ch > 0)
       copy_in(Us, LDUF, upre + (size_t)win * N * 4 * C + j0, 4 * C, N, HC);
       __syncthreads();
+      RAL_STAMP_AT(14);                                          // u_pre chunk: global loads waited for in place
       if (le && ch == 0) {
         for (int i = threadIdx.x; i < N + 2; i += blockDim.x) {
           const bool halo = (i == 0 || i == N + 1);
@@ -275,6 +290,7 @@ __global__ __launch_bounds__(512, 4) void k_mlp_bwd_h(const float* __restrict__ 
         }
         __syncthreads();
       }
+      RAL_STAMP_AT(16);                                          // local-enhancement preparation (ch = 0)
       // ---- d a2 = dx2 W2[:, chunk] -> du: the wave's 32 hidden x 32 token unit, values kept in registers ----
       float outv[2][2][4];
       {
@@ -320,6 +336,7 @@ __global__ __launch_bounds__(512, 4) void k_mlp_bwd_h(const float* __restrict__ 
         }
       }
       __syncthreads();
+      RAL_STAMP_AT(17);                                          // fc2^T product + GELU-derivative epilogue
       if (le && ch == 0) {
         for (int n = threadIdx.x; n < N; n += blockDim.x) {
           const float da1 = lw0 * DC0[n + 2] + lw1 * DC0[n + 1] + lw2 * DC0[n];
@@ -332,6 +349,7 @@ __global__ __launch_bounds__(512, 4) void k_mlp_bwd_h(const float* __restrict__ 
         }
         __syncthreads();
       }
+      RAL_STAMP_AT(18);                                          // channel-0 pass of the local enhancement
       // every reader of the u_pre chunk is past a barrier: du goes to global memory (fp32) and, scaled and split, over it
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {
@@ -347,7 +365,22 @@ __global__ __launch_bounds__(512, 4) void k_mlp_bwd_h(const float* __restrict__ 
         }
       }
       __syncthreads();
+      RAL_STAMP_AT(19);                                          // du written and split
       // ---- dg (+)= du W1[chunk, :] ----
+      if constexpr (DGR) {
+        f32x4 acc[2][2], accx[2][2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) { acc[mi][tt] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[mi][tt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        gemm_wx_h2<HC, 2, 2, NoHook, 0, 1>(w1t, 4 * C / 32, gm_ * 2, j0 / 32, Uh, uplane, LDU, gt_ * 32, acc, accx);
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          const float si = h2_row_unscale(smU[gt_ * 32 + tt * 16 + r]) * wun1;   // (the chunk's power of two of this token's du row)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) dgr[mi][tt] += acc[mi][tt] * si;
+        }
+      } else
       gemm_phase_h2<HC, 0, 1>(w1t, 4 * C / 32, 0, j0 / 32, C, nullptr, 1.0f, Uh, uplane, LDU, N >> 4, [&](int row0, int tok, f32x4 a) {
         const float si = h2_row_unscale(smU[tok]) * wun1;
         float4* pg = reinterpret_cast<float4*>(Gs + tok * LD + row0);
@@ -356,6 +389,15 @@ __global__ __launch_bounds__(512, 4) void k_mlp_bwd_h(const float* __restrict__ 
       });
       __syncthreads();
       if ((int)threadIdx.x < N) smU[threadIdx.x] = 0u;
+    }
+    RAL_STAMP_AT(25);                                            // last chunk's dg product
+    if constexpr (DGR) {   // (every reader of the last du chunk is past the barrier above)
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+          *reinterpret_cast<float4*>(Gs + (gt_ * 32 + tt * 16 + r) * LD + (gm_ * 2 + mi) * 16 + 4 * g) = tofloat4(dgr[mi][tt]);
+      __syncthreads();
     }
     // ---- LN2 backward, dx1 = dx2 + dLN: to global memory and, scaled and split, into Dh ----
     for (int row = threadIdx.x / LPR; row < N; row += RPP) {
@@ -377,12 +419,14 @@ __global__ __launch_bounds__(512, 4) void k_mlp_bwd_h(const float* __restrict__ 
       dbet = f4add(dbet, dg);
     }
     __syncthreads();
+    RAL_STAMP_AT(26);                                            // LayerNorm backward: x1 / dx2 rows waited for in place
     // ---- do = dx1 Wp (head-major) ----
     float* dow = do_hm + wo;
     gemm_phase_h2<C, 0, 1>(wpt, C / 32, 0, 0, C, nullptr, 1.0f, Dh, dplane, LDG, N >> 4, [&](int row0, int tok, f32x4 a) {
       *reinterpret_cast<float4*>(dow + ((size_t)(row0 >> 2) * N + tok) * 4) = f4scale(tofloat4(a), h2_row_unscale(smD[tok]) * wunp);
     });
     __syncthreads();
+    RAL_STAMP_AT(27);                                            // do product
   }
   // ---- flush the small gradients ----
   double* redd = reinterpret_cast<double*>(smem4);
@@ -1945,25 +1989,49 @@ static bool launch_mlp_bwd_s(const float* dx2, const float* x1, const BlockP& w,
 
 // wide levels on split fp16 operands (RAL_MLP_F16=0: the fp32-MFMA kernel everywhere): the hidden-chunk count that gives
 // the fc2^T phase exactly one 32 x 32 unit per wave and fits the LDS budget, or 0
-size_t mlp_bwd_h_lds(int C, int N, int nch) {
+size_t mlp_bwd_h_lds(int C, int N, int nch, bool small = false) {   // small: the four-wave form (no separate dg tile)
   const int HC = 4 * C / nch;
-  return (size_t)2 * N * ldb_of(C) * 2 + (size_t)N * ld_of(C) * 4 + (size_t)N * (HC + 8) * 4 + ((size_t)2 * (N + 2) + 5 * N + 2 * C + 4) * 4;
+  return (size_t)2 * N * ldb_of(C) * 2 + (small ? 0 : (size_t)N * ld_of(C) * 4) + (size_t)N * (HC + 8) * 4 + ((size_t)2 * (N + 2) + 5 * N + 2 * C + 4) * 4;
+}
+// Threads of a k_mlp_bwd_h workgroup (MLPB_HTHREADS).  256 (default): four waves, 37-39 KB of LDS, 150 registers per lane, three
+// workgroups per CU; 512: eight waves, 75-78 KB, 128 registers (28-68 bytes of scratch), two per CU.  Measured at batch 2048: the
+// four-wave form is the SLOWER kernel on an empty GPU (`mlp_bwd` 2.66 -> 2.76 ms per step serialised) and the faster training step
+// (12.98 -> 12.88 ms, 13.57 -> 13.42 on a slower box; interleaved A/B, three rounds each): beside the other lane's kernels and the
+// 76 KB weight-gradient workgroups a 38 KB / four-wave workgroup finds a CU far more often than a 78 KB / eight-wave one.
+static int mlp_bwd_h_threads() {
+  static const int t = (int)ral_knob("MLPB_HTHREADS", 256);
+  return t == 512 ? 512 : 256;
 }
 int mlp_bwd_h_nch(int C, int N) {
   static const bool on = (ral_knob("MLP_F16", 1) != 0);
   if (!on || (C != 32 && C != 64 && C != 128) || N % 32 != 0) return 0;
+  const int nwaves = mlp_bwd_h_threads() / 64;
+  if (nwaves == 4) {   // N C = 4096: one 32 x 32 unit of dg per wave; HC + 8 >= C + 4: the dg tile fits the chunk's bytes
+    for (int nch = 1; nch <= 4; nch *= 2)
+      if (N * C == 4096 && 4 * C / nch >= C && (4 * C / nch / 32) * (N / 32) == 4 && mlp_bwd_h_lds(C, N, nch, true) <= 54400) return nch;
+  } else
   for (int nch = 1; nch <= 4; nch *= 2)
     if ((4 * C / nch / 32) * (N / 32) == 8 && mlp_bwd_h_lds(C, N, nch) <= 79872) return nch;
+  if (nwaves != 8)   // (a shape the small workgroups do not cover keeps the eight-wave form)
+    for (int nch = 1; nch <= 4; nch *= 2)
+      if ((4 * C / nch / 32) * (N / 32) == 8 && mlp_bwd_h_lds(C, N, nch) <= 79872) return -nch;
   return 0;
 }
 template <int C>
 static void launch_mlp_bwd_hc(int nch, const float* dx2, const float* x1, const float* upre, const BlockP& w, const BlockP& wt,
                               const float* ptbase, const void* wtt, const BlockP& gr, float* dupre, float* dx1, float* do_hm,
                               float* a2c0, unsigned* gmax, int N, int B, hipStream_t s) {
-  const size_t lds = mlp_bwd_h_lds(C, N, nch);
+  const bool small = nch > 0 && mlp_bwd_h_threads() == 256;
+  if (nch < 0) nch = -nch;
+  const size_t lds = mlp_bwd_h_lds(C, N, nch, small);
   static const int gm = env_grid("RAL_GRID_MLPB", 512);
-  const int grid = cap(B, gm);
+  const int grid = cap(B, small ? gm * 3 / 2 : gm);
   const _Float16* wp = reinterpret_cast<const _Float16*>(wtt);
+  if (small) {
+    if (nch == 2) { RAL_SET_LDS((k_mlp_bwd_h<C, 2, 256>), lds); k_mlp_bwd_h<C, 2, 256><<<grid, 256, lds, s>>>(dx2, x1, upre, w, wt, ptbase, wp, gr, dupre, dx1, do_hm, a2c0, gmax, N, B); }
+    else { RAL_SET_LDS((k_mlp_bwd_h<C, 4, 256>), lds); k_mlp_bwd_h<C, 4, 256><<<grid, 256, lds, s>>>(dx2, x1, upre, w, wt, ptbase, wp, gr, dupre, dx1, do_hm, a2c0, gmax, N, B); }
+    return;
+  }
   if (nch == 1) { RAL_SET_LDS((k_mlp_bwd_h<C, 1>), lds); k_mlp_bwd_h<C, 1><<<grid, 512, lds, s>>>(dx2, x1, upre, w, wt, ptbase, wp, gr, dupre, dx1, do_hm, a2c0, gmax, N, B); }
   else if (nch == 2) { RAL_SET_LDS((k_mlp_bwd_h<C, 2>), lds); k_mlp_bwd_h<C, 2><<<grid, 512, lds, s>>>(dx2, x1, upre, w, wt, ptbase, wp, gr, dupre, dx1, do_hm, a2c0, gmax, N, B); }
   else { RAL_SET_LDS((k_mlp_bwd_h<C, 4>), lds); k_mlp_bwd_h<C, 4><<<grid, 512, lds, s>>>(dx2, x1, upre, w, wt, ptbase, wp, gr, dupre, dx1, do_hm, a2c0, gmax, N, B); }
