@@ -42,7 +42,7 @@ static const char* const KNOB_NAMES[] = {
   "DANET_GRID_B", "DANET_GRID_D", "DANET_GRID_F", "DANET_GRID_W", "DIAG_SKIP_WIDE_DW", "DW_F16", "DW_KSPLIT_128", "DW_KSPLIT_16",
   "DW_KSPLIT_32", "DW_KSPLIT_64", "DW_KSPLIT_8", "DW_LDS", "DW_PRIO", "DW_SETS", "F16_SPLIT", "FUSE_DW", "GRID_ATTNB", 
   "GRID_ATTNW", "GRID_FWD", "GRID_MLPB", "GRID_MLPBW", "GRID_MLPS", "GRID_MLPW", "GRID_QKVB", "GRID_QKVW", "GRID_RESB", "LOSS_GRID",
-  "MLP_BWD_W", "MLP_BWD_W_F16", "MLP_F16", "MLP_FWD_W", "MLP_HLDS", "MLP_HTHREADS", "MLPB_HTHREADS", "MLP_LDS", "MLP_TOK", "PREP_OVERLAP", "QKVB_F16", "QKVB_FDW", "TABRED_SIDE", "QKV_WS", "UNET_BWD_GRID",
+  "MLP_BWD_W", "MLP_BWD_W_F16", "MLP_F16", "MLP_FWD_W", "MLP_HLDS", "MLP_HTHREADS", "MLPB_HTHREADS", "MLP_LDS", "MLP_TOK", "PREP_OVERLAP", "QKVB_F16", "QKVB_FDW", "QKVB_SEG", "TABRED_SIDE", "QKV_WS", "UNET_BWD_GRID",
   "UNET_BWD_WP", "UNET_DEBUG", "UNET_EVAL_GRID", "UNET_FOLD", "UNET_FUSED", "UNET_FWD_GRID", "UNET_NREP", "UNET_WG_PER_CU"};
 static std::mutex g_knob_mu;
 static std::map<std::string, long long>& knob_table() { static std::map<std::string, long long> t; return t; }

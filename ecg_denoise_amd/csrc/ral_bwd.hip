@@ -1418,15 +1418,20 @@ __global__ __launch_bounds__(512, RAL_QKVB_MINB) void k_qkv_bwd_h(const float* d
                                                  const float* __restrict__ pe, const float* dx1,
                                                  const float* extra, BlockP w, BlockP wt, const float* __restrict__ ptbase,
                                                  const _Float16* __restrict__ wtt, BlockP gr,
-                                                 float* __restrict__ dx, unsigned* __restrict__ gmax, int N, int B) {
+                                                 float* __restrict__ dx, unsigned* __restrict__ gmax, int N, int B,
+                                                 int NS /* token segments per window (1, 2): a work item is one segment; gridDim.x % NS == 0 */) {
   extern __shared__ float4 smem4[];
   constexpr int LD = LDof<C>::v, LPR = C / 4, LDQ = ldb_of(3 * C);
   typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-  _Float16* Qh = reinterpret_cast<_Float16*>(smem4);   // 2 x N x LDQ : dqkv, token-major, scaled, split
-  const int qplane = N * LDQ;
-  float* Dh = reinterpret_cast<float*>(Qh + 2 * qplane);   // N x LD
-  float* red = Dh + N * LD;                     // 2C
-  unsigned* smQ = reinterpret_cast<unsigned*>(red + 2 * C);   // 2 x N : bits of max |dqkv row|, by window parity
+  // Everything in this kernel is per token (row maxima, the product, the LayerNorm backward), so a work item may be a SEGMENT of
+  // a window: NT = N / NS tokens from token t0.  A workgroup always gets the same segment index (gridDim.x % NS == 0), so its
+  // positional-encoding rows stay in registers.
+  const int NT = N / NS, t0 = ((int)blockIdx.x % NS) * NT, items = B * NS;
+  _Float16* Qh = reinterpret_cast<_Float16*>(smem4);   // 2 x NT x LDQ : dqkv, token-major, scaled, split
+  const int qplane = NT * LDQ;
+  float* Dh = reinterpret_cast<float*>(Qh + 2 * qplane);   // NT x LD
+  float* red = Dh + NT * LD;                    // 2C
+  unsigned* smQ = reinterpret_cast<unsigned*>(red + 2 * C);   // 2 x NT : bits of max |dqkv row|, by item parity
   const int RPP = blockDim.x / LPR;
   const int cq = (threadIdx.x % LPR) * 4;
   const float sqrtC = sqrtf((float)C);
@@ -1435,15 +1440,16 @@ __global__ __launch_bounds__(512, RAL_QKVB_MINB) void k_qkv_bwd_h(const float* d
   const _Float16* wq = wtt + 2 * (wt.wqkv - ptbase);
   const float wunq = wplane_unscale(wq, C, 3 * C);
   constexpr int NQ = 6, NR = 2;
-  const int n4 = N * 3 * C / 4;   // <= NQ * 512 (launcher)
+  const int n4 = NT * 3 * C / 4;   // <= NQ * blockDim.x (launcher)
   const int rbase = threadIdx.x / LPR;
   const float* const ex = extra ? extra : dx1;
-  auto row_off = [&](int win, int u) -> size_t {
-    return (size_t)win * N * C + (size_t)min(rbase + u * RPP, N - 1) * C + cq;
+  auto row_off = [&](int item, int u) -> size_t {
+    return (size_t)(item / NS) * N * C + (size_t)(t0 + min(rbase + u * RPP, NT - 1)) * C + cq;
   };
   auto ld4 = [&](const float* base, size_t o) -> float4 { return *reinterpret_cast<const float4*>(base + o); };
-  auto ld_dq = [&](int win, int u) -> float4 {
-    return reinterpret_cast<const float4*>(dqkv + (size_t)win * N * 3 * C)[min((int)threadIdx.x + u * (int)blockDim.x, n4 - 1)];
+  auto ld_dq = [&](int item, int u) -> float4 {   // flat float4 i of the segment = (channel quad i / NT, token t0 + i % NT) of the window
+    const int i = min((int)threadIdx.x + u * (int)blockDim.x, n4 - 1), qd = i / NT, t = i - qd * NT;
+    return reinterpret_cast<const float4*>(dqkv + (size_t)(item / NS) * N * 3 * C)[qd * N + t0 + t];
   };
   float tmxq = 0.f;   // largest |dqkv| this thread has seen: gmax[3], for the weight-gradient kernel (see k_mlp_bwd_h)
   auto max_dq = [&](unsigned* sm, int u, float4 v) {   // flat float4 i = (channel quad, token)
@@ -1451,13 +1457,13 @@ __global__ __launch_bounds__(512, RAL_QKVB_MINB) void k_qkv_bwd_h(const float* d
     if (i < n4) {
       const float mx = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
       tmxq = fmaxf(tmxq, mx);
-      atomicMax(sm + i % N, __float_as_uint(mx));
+      atomicMax(sm + i % NT, __float_as_uint(mx));
     }
   };
   auto st_dq = [&](const unsigned* sm, int u, float4 v) {
     const int i = threadIdx.x + u * blockDim.x;
     if (i < n4) {
-      const int qd = i / N, t = i - qd * N;
+      const int qd = i / NT, t = i - qd * NT;
       v = f4scale(v, h2_row_scale(sm[t]));
       const H2 s0 = f16_split2u(v.x), s1 = f16_split2u(v.y), s2 = f16_split2u(v.z), s3 = f16_split2u(v.w);
       *reinterpret_cast<f16x4*>(Qh + t * LDQ + qd * 4) = f16x4{s0.a, s1.a, s2.a, s3.a};
@@ -1466,7 +1472,7 @@ __global__ __launch_bounds__(512, RAL_QKVB_MINB) void k_qkv_bwd_h(const float* d
   };
   float4 pe4[NR];
 #pragma unroll
-  for (int u = 0; u < NR; ++u) pe4[u] = *reinterpret_cast<const float4*>(pe + min(rbase + u * RPP, N - 1) * C + cq);
+  for (int u = 0; u < NR; ++u) pe4[u] = *reinterpret_cast<const float4*>(pe + (t0 + min(rbase + u * RPP, NT - 1)) * C + cq);
   auto ln_row = [&](size_t wo, int row, float4 v, float4 p, float4 d1, float4 e) {
     v = f4add(f4scale(v, sqrtC), p);
     float4 d; float rstd;
@@ -1490,11 +1496,11 @@ __global__ __launch_bounds__(512, RAL_QKVB_MINB) void k_qkv_bwd_h(const float* d
   float4 rx[NR], rd[NR], re[NR];
 #pragma unroll
   for (int u = 0; u < NR; ++u) rx[u] = rd[u] = re[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int i = threadIdx.x; i < 2 * N; i += blockDim.x) smQ[i] = 0u;
+  for (int i = threadIdx.x; i < 2 * NT; i += blockDim.x) smQ[i] = 0u;
   __syncthreads();
   {
     const int win0 = blockIdx.x;
-    if (win0 < B) {
+    if (win0 < items) {
 #pragma unroll
       for (int u = 0; u < NR; ++u) {
         const size_t o = row_off(win0, u);
@@ -1512,18 +1518,18 @@ __global__ __launch_bounds__(512, RAL_QKVB_MINB) void k_qkv_bwd_h(const float* d
     __syncthreads();
   }
   int par = 0;
-  for (int win = blockIdx.x; win < B; win += gridDim.x, par ^= 1) {
-    const size_t wo = (size_t)win * N * C;
-    const unsigned* smc = smQ + par * N;
-    unsigned* smn = smQ + (par ^ 1) * N;
-    if ((int)threadIdx.x < N) smn[threadIdx.x] = 0u;   // (last read by the previous window's product)
+  for (int win = blockIdx.x; win < items; win += gridDim.x, par ^= 1) {   // (win: the item)
+    const size_t wo = (size_t)(win / NS) * N * C + (size_t)t0 * C;
+    const unsigned* smc = smQ + par * NT;
+    unsigned* smn = smQ + (par ^ 1) * NT;
+    if ((int)threadIdx.x < NT) smn[threadIdx.x] = 0u;   // (last read by the previous item's product)
     // dh[t][c] = sum_m dqkv[t][m] Wqkv[m][c]
-    gemm_phase_h2<3 * C, 0, 2>(wq, 3 * C / 32, 0, 0, C, nullptr, 1.0f, Qh, qplane, LDQ, N >> 4, [&](int row0, int tok, f32x4 a) {
+    gemm_phase_h2<3 * C, 0, 2>(wq, 3 * C / 32, 0, 0, C, nullptr, 1.0f, Qh, qplane, LDQ, NT >> 4, [&](int row0, int tok, f32x4 a) {
       *reinterpret_cast<float4*>(Dh + tok * LD + row0) = f4scale(tofloat4(a), h2_row_unscale(smc[tok]) * wunq);
     });
     __syncthreads();   // Dh complete, Qh free
     const int nxt = win + gridDim.x;
-    const bool more = nxt < B;
+    const bool more = nxt < items;
     const int pw = more ? nxt : win;   // (past the end: a harmless re-read, no branch around the loads)
     float4 q[NQ], nx[NR], nd[NR], ne[NR];
 #pragma unroll
@@ -1538,11 +1544,11 @@ __global__ __launch_bounds__(512, RAL_QKVB_MINB) void k_qkv_bwd_h(const float* d
 #pragma unroll
     for (int u = 0; u < NR; ++u) {
       const int row = rbase + u * RPP;
-      if (row < N) ln_row(wo, row, rx[u], pe4[u], rd[u], re[u]);
+      if (row < NT) ln_row(wo, row, rx[u], pe4[u], rd[u], re[u]);
     }
-    for (int row = rbase + NR * RPP; row < N; row += RPP) {
+    for (int row = rbase + NR * RPP; row < NT; row += RPP) {
       const size_t o = wo + (size_t)row * C + cq;
-      ln_row(wo, row, *reinterpret_cast<const float4*>(x + o), *reinterpret_cast<const float4*>(pe + row * C + cq),
+      ln_row(wo, row, *reinterpret_cast<const float4*>(x + o), *reinterpret_cast<const float4*>(pe + (t0 + row) * C + cq),
              *reinterpret_cast<const float4*>(dx1 + o), *reinterpret_cast<const float4*>(ex + o));
     }
     if (more) {
@@ -2210,11 +2216,17 @@ bool launch_qkv_bwd(int C, const float* dqkv, const float* x, const float* pe, c
   static const int gq = env_grid("RAL_GRID_QKVB", 192);
   const int grid = cap(B, gq);
   if (wtt && qkv_bwd_uses_f16(C, N)) {
-    const size_t ldsh = (size_t)2 * N * ldb_of(3 * C) * 2 + ((size_t)N * ld_of(C) + 2 * C + 2 * N) * 4;
+    // QKVB_SEG = 2: a work item is HALF a window (four-wave workgroups, half the LDS) where half a window still is a whole number of
+    // 32-token product units and one prefetch round of 256 threads (N C = 4096, N >= 64).  Measured: `qkv_bwd` 1.105 -> 1.075 ms per
+    // step serialised, the step unchanged (13.03 / 13.02 ms, and flat over grids of 128 .. 256 workgroups): default off.
+    static const int seg = (int)ral_knob("QKVB_SEG", 1);
+    const int NS = (seg == 2 && N * C == 4096 && N % 64 == 0) ? 2 : 1, NT = N / NS, nth = 512 / NS;
+    const size_t ldsh = (size_t)2 * NT * ldb_of(3 * C) * 2 + ((size_t)NT * ld_of(C) + 2 * C + 2 * NT) * 4;
     const _Float16* wp = reinterpret_cast<const _Float16*>(wtt);
-    if (C == 32) { RAL_SET_LDS((k_qkv_bwd_h<32>), ldsh); k_qkv_bwd_h<32><<<grid, 512, ldsh, s>>>(dqkv, x, pe, dx1, extra, w, wt, ptbase, wp, gr, dx, gmax, N, B); }
-    else if (C == 64) { RAL_SET_LDS((k_qkv_bwd_h<64>), ldsh); k_qkv_bwd_h<64><<<grid, 512, ldsh, s>>>(dqkv, x, pe, dx1, extra, w, wt, ptbase, wp, gr, dx, gmax, N, B); }
-    else { RAL_SET_LDS((k_qkv_bwd_h<128>), ldsh); k_qkv_bwd_h<128><<<grid, 512, ldsh, s>>>(dqkv, x, pe, dx1, extra, w, wt, ptbase, wp, gr, dx, gmax, N, B); }
+    const int gridh = NS == 1 ? grid : (cap(B * NS, gq * NS) / NS) * NS;
+    if (C == 32) { RAL_SET_LDS((k_qkv_bwd_h<32>), ldsh); k_qkv_bwd_h<32><<<gridh, nth, ldsh, s>>>(dqkv, x, pe, dx1, extra, w, wt, ptbase, wp, gr, dx, gmax, N, B, NS); }
+    else if (C == 64) { RAL_SET_LDS((k_qkv_bwd_h<64>), ldsh); k_qkv_bwd_h<64><<<gridh, nth, ldsh, s>>>(dqkv, x, pe, dx1, extra, w, wt, ptbase, wp, gr, dx, gmax, N, B, NS); }
+    else { RAL_SET_LDS((k_qkv_bwd_h<128>), ldsh); k_qkv_bwd_h<128><<<gridh, nth, ldsh, s>>>(dqkv, x, pe, dx1, extra, w, wt, ptbase, wp, gr, dx, gmax, N, B, NS); }
     return false;
   }
   const size_t lds = qkv_bwd_lds(C, N);
