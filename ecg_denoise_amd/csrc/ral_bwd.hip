@@ -2002,8 +2002,9 @@ size_t mlp_bwd_h_lds(int C, int N, int nch, bool small = false) {   // small: th
 // Threads of a k_mlp_bwd_h workgroup (MLPB_HTHREADS).  256 (default): four waves, 37-39 KB of LDS, 150 registers per lane, three
 // workgroups per CU; 512: eight waves, 75-78 KB, 128 registers (28-68 bytes of scratch), two per CU.  Measured at batch 2048: the
 // four-wave form is the SLOWER kernel on an empty GPU (`mlp_bwd` 2.66 -> 2.76 ms per step serialised) and the faster training step
-// (12.98 -> 12.88 ms, 13.57 -> 13.42 on a slower box; interleaved A/B, three rounds each): beside the other lane's kernels and the
-// 76 KB weight-gradient workgroups a 38 KB / four-wave workgroup finds a CU far more often than a 78 KB / eight-wave one.
+// (12.98 -> 12.88 ms, 13.57 -> 13.42 on a slower box; interleaved A/B, three rounds each).  What it changes beside the other lane's
+// kernels and the 76 KB weight-gradient workgroups: half the LDS and half the waves per workgroup, no spills, and no dg
+// read-modify-write through LDS per hidden chunk (k_qkv_bwd_h with half the LDS and waves alone - QKVB_SEG - did not move the step).
 static int mlp_bwd_h_threads() {
   static const int t = (int)ral_knob("MLPB_HTHREADS", 256);
   return t == 512 ? 512 : 256;
