@@ -113,7 +113,8 @@ extern "C" int ral_global_option(const char* key, long long value) {
   if (value < 0) return fail("switch %s: negative value %lld", key, value);
   for (const char* n : KNOB_MIN1)
     if (k == n && value < 1) return fail("switch %s: value %lld out of range (a grid / thread / split count: >= 1)", key, value);
-  if (k == "MLP_HTHREADS" && value != 512 && value != 1024) return fail("switch %s: 512 or 1024 threads (got %lld)", key, value);
+  if (k == "MLP_HTHREADS" && value != 256 && value != 512 && value != 1024) return fail("switch %s: 256, 512 or 1024 threads (got %lld)", key, value);
+  if (k == "MLPB_HTHREADS" && value != 256 && value != 512) return fail("switch %s: 256 or 512 threads (got %lld)", key, value);
   std::lock_guard<std::mutex> lk(g_knob_mu);
   // most consumers read a switch once and keep it: a change after that first read would be ignored silently, so it is refused
   // (the same value again is fine: tests and tools set their switches at start-up, possibly more than once)

@@ -841,7 +841,7 @@ __global__ __launch_bounds__(512) void k_mlp_fwd(const float* __restrict__ x, co
 // per ITEM.  Only the 3-tap conv of the local enhancement sees window boundaries (per-window zero halos in A0).
 // =================================================================================
 template <int C, int NCH, int NTH>
-__global__ __launch_bounds__(NTH, 4) void k_mlp_fwd_h(const float* __restrict__ x, const float* __restrict__ o_hm,
+__global__ __launch_bounds__(NTH, (NTH == 256 ? 3 : 4)) void k_mlp_fwd_h(const float* __restrict__ x, const float* __restrict__ o_hm,
                                                    BlockP w, const float* __restrict__ pbase, const _Float16* __restrict__ wt,
                                                    float* __restrict__ x1_out,
                                                    float* __restrict__ upre_out, float* __restrict__ x2_out,
@@ -1152,7 +1152,8 @@ static void mlp_fwd_h_plan(int C, int N, int B, int* wpi_out, int* nch_out) {
   int wpi = 1;
   while (wpi * 2 * N <= tokmax && B % (wpi * 2) == 0 && mlp_fwd_h_lds(C, wpi * 2 * N, 4) <= budget) wpi *= 2;
   int nch = 1;
-  const size_t b1 = wpi == 1 ? 78000 : budget;
+  static const int nth_ = (int)ral_knob("MLP_HTHREADS", 512);
+  const size_t b1 = wpi == 1 ? (nth_ == 256 ? 54600 : 78000) : budget;   // (four-wave workgroups: three per CU)
   while (nch < 4 && mlp_fwd_h_lds(C, wpi * N, nch) > b1) nch *= 2;
   *wpi_out = wpi; *nch_out = nch;
 }
@@ -1176,6 +1177,8 @@ void launch_mlp_fwd(int C, int nch, const float* x, const float* o, const BlockP
   if (!padded && wh && mlp_fwd_uses_f16(C, N)) {
     static const int nth = (int)ral_knob("MLP_HTHREADS", 512);
     if (C == 32) launch_mlp_fwd_hc<32, 512>(x, o, w, pbase, wh, x1, upre, x2, N, B, s, addend, sum_out);
+    else if (nth == 256 && C == 64) launch_mlp_fwd_hc<64, 256>(x, o, w, pbase, wh, x1, upre, x2, N, B, s, addend, sum_out);
+    else if (nth == 256) launch_mlp_fwd_hc<128, 256>(x, o, w, pbase, wh, x1, upre, x2, N, B, s, addend, sum_out);
     else if (C == 64) { if (nth == 1024) launch_mlp_fwd_hc<64, 1024>(x, o, w, pbase, wh, x1, upre, x2, N, B, s, addend, sum_out); else launch_mlp_fwd_hc<64, 512>(x, o, w, pbase, wh, x1, upre, x2, N, B, s, addend, sum_out); }
     else { if (nth == 1024) launch_mlp_fwd_hc<128, 1024>(x, o, w, pbase, wh, x1, upre, x2, N, B, s, addend, sum_out); else launch_mlp_fwd_hc<128, 512>(x, o, w, pbase, wh, x1, upre, x2, N, B, s, addend, sum_out); }
     return;
