@@ -195,6 +195,9 @@ __global__ __launch_bounds__(512) void k_mlp_bwd(const float* __restrict__ dx2, 
 // =================================================================================
 // NTH = 512: two workgroups per CU at 128 registers (one 32 x 32 unit of the fc2^T phase per wave: (HC / 32)(N / 32) = 8);
 // NTH = 256: three per CU at 168 registers ((HC / 32)(N / 32) = 4: twice the hidden chunks)
+#ifndef RAL_MLPBH_ALLK
+#define RAL_MLPBH_ALLK 1
+#endif
 template <int C, int NCH, int NTH = 512>
 __global__ __launch_bounds__(NTH, (NTH == 512 ? 4 : 3)) void k_mlp_bwd_h(const float* __restrict__ dx2, const float* __restrict__ x1,
                                                       const float* __restrict__ upre, BlockP w, BlockP wt, const float* __restrict__ ptbase,
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(NTH, (NTH == 512 ? 4 : 3)) void k_mlp_bwd_h(const f
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
           for (int tt = 0; tt < 2; ++tt) { acc[mi][tt] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[mi][tt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        gemm_wx_h2<C, 2, 2, NoHook, 0, 1>(w2t, C / 32, j0 / 16 + um * 2, 0, Dh, dplane, LDG, ut * 32, acc, accx);
+        gemm_wx_h2<C, 2, 2, NoHook, (DGR && RAL_MLPBH_ALLK ? -1 : 0), 1>(w2t, C / 32, j0 / 16 + um * 2, 0, Dh, dplane, LDG, ut * 32, acc, accx);
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
           const int tok = ut * 32 + tt * 16 + r;
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(NTH, (NTH == 512 ? 4 : 3)) void k_mlp_bwd_h(const f
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
           for (int tt = 0; tt < 2; ++tt) { acc[mi][tt] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[mi][tt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        gemm_wx_h2<HC, 2, 2, NoHook, 0, 1>(w1t, 4 * C / 32, gm_ * 2, j0 / 32, Uh, uplane, LDU, gt_ * 32, acc, accx);
+        gemm_wx_h2<HC, 2, 2, NoHook, (RAL_MLPBH_ALLK ? -1 : 0), 1>(w1t, 4 * C / 32, gm_ * 2, j0 / 32, Uh, uplane, LDU, gt_ * 32, acc, accx);
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
           const float si = h2_row_unscale(smU[gt_ * 32 + tt * 16 + r]) * wun1;   // (the chunk's power of two of this token's du row)

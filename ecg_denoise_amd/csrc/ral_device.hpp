@@ -298,7 +298,7 @@ RAL_DEV void gemm_wx_h2(const _Float16* __restrict__ Wt, int KT, int mt0, int kt
   const _Float16* xr = Xh + (t0 + r) * ldx + 8 * g;
   if constexpr (MT == 1) {
     // (with a hook the caller keeps prefetched data in registers meanwhile: four chunks at a time then)
-    constexpr int GMAX = GMAX_ ? GMAX_ : (std::is_same<Hook, NoHook>::value ? 8 : 4), GS = h2_group(KC, GMAX);
+    constexpr int GMAX = GMAX_ > 0 ? GMAX_ : (std::is_same<Hook, NoHook>::value ? 8 : 4), GS = h2_group(KC, GMAX);
 #pragma unroll 1
     for (int k0 = 0; k0 < KC; k0 += GS) {
       f16x8 a[GS][1][2];
@@ -316,6 +316,20 @@ RAL_DEV void gemm_wx_h2(const _Float16* __restrict__ Wt, int KT, int mt0, int kt
 #pragma unroll
       for (int j = 0; j < GS; ++j) h2_mma<1, TT, ONE>(a[j], xr + (k0 + j) * 32, xplane, ldx, acc, accx);
     }
+  } else if constexpr (GMAX_ < 0) {
+    // GMAX_ = -1: every K-chunk's fragments requested up front (KC * MT * 8 registers): ONE round trip per unit.  With one chunk in
+    // flight (below) a unit of KC chunks costs ~KC - 1 round trips: the three MFMAs of a chunk are ~200 cycles, a fragment from the
+    // L2 under load ~2000, and chunk k + 1 is only requested when chunk k is consumed.
+    f16x8 a[KC][MT][2];
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) a[kc][mi][p] = *reinterpret_cast<const f16x8*>(wtile(Wt, KT, mt0 + mi, kt0 + kc, p));
+    hook();
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) h2_mma<MT, TT, ONE>(a[kc], xr + kc * 32, xplane, ldx, acc, accx);
   } else {
     f16x8 a[MT][2], an[MT][2];
 #pragma unroll
