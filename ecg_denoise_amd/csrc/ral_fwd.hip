@@ -898,7 +898,7 @@ __global__ __launch_bounds__(NTH, (NTH == 256 ? 3 : 4)) void k_mlp_fwd_h(const f
     RAL_STAMP_AT(1);
     // ---- attention output projection + residual ----
     float* x1w = x1_out ? x1_out + wo : nullptr;
-    gemm_phase_h2<C>(wph, C / 32, 0, 0, C, w.bp, wunp, Gh, gplane, LDG, T >> 4, [&](int row0, int tok, f32x4 a) {
+    gemm_phase_h2<C, (NTH == 256 ? -1 : 0)>(wph, C / 32, 0, 0, C, w.bp, wunp, Gh, gplane, LDG, T >> 4, [&](int row0, int tok, f32x4 a) {
       float4* px = reinterpret_cast<float4*>(Xs + tok * LD + row0);
       const float4 v = f4add(*px, tofloat4(a));
       *px = v;
@@ -926,7 +926,7 @@ __global__ __launch_bounds__(NTH, (NTH == 256 ? 3 : 4)) void k_mlp_fwd_h(const f
 #pragma unroll 1
     for (int ch = 0; ch < NCH; ++ch) {
       const int j0 = ch * HC;
-      gemm_phase_h2<C>(w1h, C / 32, j0 / 16, 0, HC, w.b1 + j0, wun1, Gh, gplane, LDG, T >> 4, [&](int row0, int tok, f32x4 a) {
+      gemm_phase_h2<C, (NTH == 256 ? -1 : 0)>(w1h, C / 32, j0 / 16, 0, HC, w.b1 + j0, wun1, Gh, gplane, LDG, T >> 4, [&](int row0, int tok, f32x4 a) {
         const float4 u = tofloat4(a);
         if (upw) *reinterpret_cast<float4*>(upw + (size_t)tok * 4 * C + j0 + row0) = u;
         float4 h = make_float4(gelu_f(u.x), gelu_f(u.y), gelu_f(u.z), gelu_f(u.w));
@@ -1152,7 +1152,7 @@ static void mlp_fwd_h_plan(int C, int N, int B, int* wpi_out, int* nch_out) {
   int wpi = 1;
   while (wpi * 2 * N <= tokmax && B % (wpi * 2) == 0 && mlp_fwd_h_lds(C, wpi * 2 * N, 4) <= budget) wpi *= 2;
   int nch = 1;
-  static const int nth_ = (int)ral_knob("MLP_HTHREADS", 512);
+  static const int nth_ = (int)ral_knob("MLP_HTHREADS", 256);
   const size_t b1 = wpi == 1 ? (nth_ == 256 ? 54600 : 78000) : budget;   // (four-wave workgroups: three per CU)
   while (nch < 4 && mlp_fwd_h_lds(C, wpi * N, nch) > b1) nch *= 2;
   *wpi_out = wpi; *nch_out = nch;
@@ -1175,7 +1175,11 @@ void launch_mlp_fwd(int C, int nch, const float* x, const float* o, const BlockP
   if (NE <= 0 || NE > N) NE = N;
   const bool padded = NE < N;   // padded windows: the generic kernel (its local-enhancement conv knows where the window ends)
   if (!padded && wh && mlp_fwd_uses_f16(C, N)) {
-    static const int nth = (int)ral_knob("MLP_HTHREADS", 512);
+    // threads of a k_mlp_fwd_h workgroup: 256 (default; four waves, four hidden chunks, 52-55 KB of LDS, three workgroups per CU, every
+    // K-chunk's weight fragments of a proj / fc1 unit requested together: 135-163 registers), 512 (two per CU at 128 registers) or
+    // 1024.  Measured: `mlp_fwd` 1.620 / 1.625 ms per step serialised for 512 / 256, the step 12.69 -> 12.67 ms (three interleaved
+    // rounds, each in favour), inference 557.6 k -> 562.3 k windows/s
+    static const int nth = (int)ral_knob("MLP_HTHREADS", 256);
     if (C == 32) launch_mlp_fwd_hc<32, 512>(x, o, w, pbase, wh, x1, upre, x2, N, B, s, addend, sum_out);
     else if (nth == 256 && C == 64) launch_mlp_fwd_hc<64, 256>(x, o, w, pbase, wh, x1, upre, x2, N, B, s, addend, sum_out);
     else if (nth == 256) launch_mlp_fwd_hc<128, 256>(x, o, w, pbase, wh, x1, upre, x2, N, B, s, addend, sum_out);
