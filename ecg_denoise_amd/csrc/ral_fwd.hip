@@ -1146,28 +1146,31 @@ size_t mlp_fwd_h_lds(int C, int T, int nch) {   // T = tokens of a work item
 }
 // windows per work item and hidden chunks of the split-operand kernel: the most tokens (up to RAL_MLP_TOK, a power-of-two
 // number of windows dividing the batch) whose tiles fit RAL_MLP_HLDS bytes with at most four hidden chunks
-static void mlp_fwd_h_plan(int C, int N, int B, int* wpi_out, int* nch_out) {
+static void mlp_fwd_h_plan(int C, int N, int B, int nth_ /* threads of the workgroup that will run it */, int* wpi_out, int* nch_out) {
   static const int tokmax = (int)ral_knob("MLP_TOK", 0);   // default: one window per item (64 / 128 tokens measured slower: mlp_fwd 1.87 / 1.93 against 1.76 ms per step - one workgroup per CU)
   static const size_t budget = (size_t)ral_knob("MLP_HLDS", 150 * 1024);
   int wpi = 1;
   while (wpi * 2 * N <= tokmax && B % (wpi * 2) == 0 && mlp_fwd_h_lds(C, wpi * 2 * N, 4) <= budget) wpi *= 2;
   int nch = 1;
-  static const int nth_ = (int)ral_knob("MLP_HTHREADS", 256);
-  const size_t b1 = wpi == 1 ? (nth_ == 256 ? 54600 : 78000) : budget;   // (four-wave workgroups: three per CU)
-  while (nch < 4 && mlp_fwd_h_lds(C, wpi * N, nch) > b1) nch *= 2;
+  // (four-wave workgroups: three per CU.  The hardware admits one workgroup fewer than 160 KB / LDS suggests once the last one
+  // would end within a granule of the top: 53 000 bytes run three per CU, 54 576 two - tools/diag/occ_probe.hip, census - while
+  // hipOccupancyMaxActiveBlocksPerMultiprocessor still answers three.)
+  const size_t b1 = wpi == 1 ? (nth_ == 256 ? 53000 : 78000) : budget;
+  while (nch < (nth_ == 256 ? 8 : 4) && mlp_fwd_h_lds(C, wpi * N, nch) > b1) nch *= 2;
   *wpi_out = wpi; *nch_out = nch;
 }
 template <int C, int NTH>
 static void launch_mlp_fwd_hc(const float* x, const float* o, const BlockP& w, const float* pbase, const void* wh,
                               float* x1, float* upre, float* x2, int N, int B, hipStream_t s, const float* addend, float* sum_out) {
   int wpi, nch;
-  mlp_fwd_h_plan(C, N, B, &wpi, &nch);
+  mlp_fwd_h_plan(C, N, B, NTH, &wpi, &nch);
   const size_t lds = mlp_fwd_h_lds(C, wpi * N, nch);
   const _Float16* whp = reinterpret_cast<const _Float16*>(wh);
   const int grid = grid_for(B / wpi);
   if (nch == 1) { RAL_SET_LDS((k_mlp_fwd_h<C, 1, NTH>), lds); k_mlp_fwd_h<C, 1, NTH><<<grid, NTH, lds, s>>>(x, o, w, pbase, whp, x1, upre, x2, N, B, wpi, addend, sum_out); }
   else if (nch == 2) { RAL_SET_LDS((k_mlp_fwd_h<C, 2, NTH>), lds); k_mlp_fwd_h<C, 2, NTH><<<grid, NTH, lds, s>>>(x, o, w, pbase, whp, x1, upre, x2, N, B, wpi, addend, sum_out); }
-  else { RAL_SET_LDS((k_mlp_fwd_h<C, 4, NTH>), lds); k_mlp_fwd_h<C, 4, NTH><<<grid, NTH, lds, s>>>(x, o, w, pbase, whp, x1, upre, x2, N, B, wpi, addend, sum_out); }
+  else if (nch == 4 || NTH != 256) { RAL_SET_LDS((k_mlp_fwd_h<C, 4, NTH>), lds); k_mlp_fwd_h<C, 4, NTH><<<grid, NTH, lds, s>>>(x, o, w, pbase, whp, x1, upre, x2, N, B, wpi, addend, sum_out); }
+  else if constexpr (NTH == 256) { RAL_SET_LDS((k_mlp_fwd_h<C, 8, NTH>), lds); k_mlp_fwd_h<C, 8, NTH><<<grid, NTH, lds, s>>>(x, o, w, pbase, whp, x1, upre, x2, N, B, wpi, addend, sum_out); }
 }
 
 void launch_mlp_fwd(int C, int nch, const float* x, const float* o, const BlockP& w, const float* pbase, const void* wh,
@@ -1175,7 +1178,7 @@ void launch_mlp_fwd(int C, int nch, const float* x, const float* o, const BlockP
   if (NE <= 0 || NE > N) NE = N;
   const bool padded = NE < N;   // padded windows: the generic kernel (its local-enhancement conv knows where the window ends)
   if (!padded && wh && mlp_fwd_uses_f16(C, N)) {
-    // threads of a k_mlp_fwd_h workgroup: 256 (default; four waves, four hidden chunks, 52-55 KB of LDS, three workgroups per CU, every
+    // threads of a k_mlp_fwd_h workgroup: 256 (default; four waves, four or eight hidden chunks, <= 53 000 bytes of LDS, three workgroups per CU, every
     // K-chunk's weight fragments of a proj / fc1 unit requested together: 135-163 registers), 512 (two per CU at 128 registers) or
     // 1024.  Measured: `mlp_fwd` 1.620 / 1.625 ms per step serialised for 512 / 256, the step 12.69 -> 12.67 ms (three interleaved
     // rounds, each in favour), inference 557.6 k -> 562.3 k windows/s
